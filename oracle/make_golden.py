@@ -1,0 +1,229 @@
+"""
+ORACLE -- test infrastructure only. Generates tests/golden/*.npz by running the REFERENCE ITSELF
+(/root/reference, CPU, fp32) on the seeded synthetic inputs of cseg_oracle.synth_case. Run in the build
+container only:   PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--only NAME]
+
+What is stored per loss case (inputs are regenerated from the seed, never stored):
+  total / ce / contrast loss scalars, n_view, the mined anchors as (image, class, pixel index) triples in the
+  reference's order (recovered by feeding index-encoding features through the reference's
+  _hard_anchor_sampling, lib/loss/loss_contrast.py:30-89), and for the small cases the autograd gradients
+  w.r.t. seg (dense) and embed (rows at the mined pixels).
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import ref_shim  # noqa: E402
+from oracle import cseg_oracle as O  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+CITYSCAPES_W = [0.8373, 0.9180, 0.8660, 1.0345, 1.0166, 0.9969, 0.9754, 1.0489, 0.8786, 1.0023, 0.9539,
+                0.9843, 1.1116, 0.9037, 1.0865, 1.0955, 1.0865, 1.1529, 1.0507]
+
+# name -> dict(seed, B, K, H, W, stride, D, blocky, contrast overrides, loss_type, ce_weight, grads, torch_seed)
+LOSS_CASES = {
+    "small_self": dict(seed=11, B=2, K=5, H=64, W=128, stride=4, D=16, blocky=True, loss="contrast_ce_loss",
+                       contrast=dict(max_samples=64, max_views=10, temperature=0.1, loss_weight=0.1),
+                       ce_weight=[0.9, 1.1, 1.0, 0.8, 1.2], grads=True, torch_seed=304),
+    "mid_self": dict(seed=12, B=4, K=19, H=128, W=256, stride=4, D=64, blocky=True, loss="contrast_ce_loss",
+                     contrast=dict(max_samples=1024, max_views=100, temperature=0.1, loss_weight=0.1),
+                     ce_weight=CITYSCAPES_W, grads=True, torch_seed=7),
+    "uniform_self": dict(seed=13, B=3, K=19, H=128, W=256, stride=4, D=32, blocky=False, loss="contrast_ce_loss",
+                         contrast=dict(max_samples=1024, max_views=50, temperature=0.07, loss_weight=1.0),
+                         ce_weight=None, grads=True, torch_seed=304),
+    "odd_stride8_aux": dict(seed=14, B=2, K=7, H=97, W=161, stride=8, D=24, blocky=True,
+                            loss="contrast_auxce_loss", hw=(13, 21),
+                            contrast=dict(max_samples=128, max_views=6, temperature=0.1, loss_weight=0.1),
+                            ce_weight=None, grads=True, torch_seed=5),
+    "warmup_self": dict(seed=15, B=2, K=5, H=64, W=128, stride=4, D=16, blocky=True, loss="contrast_ce_loss",
+                        contrast=dict(max_samples=64, max_views=10, temperature=0.1, loss_weight=0.1),
+                        ce_weight=None, grads=True, torch_seed=304, with_embed=False),
+    "mem_v1": dict(seed=16, B=4, K=19, H=128, W=256, stride=4, D=64, blocky=True, loss="mem_contrast_ce_loss",
+                   contrast=dict(max_samples=1024, max_views=1, temperature=0.07, loss_weight=1.0,
+                                 with_memory=True, memory_size=12, pixel_update_freq=10),
+                   ce_weight=CITYSCAPES_W, grads=True, torch_seed=304),
+    "mem_v3": dict(seed=17, B=2, K=6, H=64, W=128, stride=4, D=32, blocky=True, loss="mem_contrast_ce_loss",
+                   contrast=dict(max_samples=48, max_views=3, temperature=0.1, loss_weight=0.5,
+                                 with_memory=True, memory_size=20, pixel_update_freq=10),
+                   ce_weight=None, grads=True, torch_seed=9),
+    # BASELINE.json configs[1] loss shapes (HRNet-W48 head outputs, bs8, 512x1024, D=256): scalars + indices only
+    "cfg2_full": dict(seed=304, B=8, K=19, H=512, W=1024, stride=4, D=256, blocky=True, n_rect=24,
+                      loss="contrast_ce_loss",
+                      contrast=dict(max_samples=1024, max_views=100, temperature=0.1, loss_weight=0.1),
+                      ce_weight=CITYSCAPES_W, grads=False, torch_seed=304),
+    "cfg2_uniform": dict(seed=305, B=8, K=19, H=512, W=1024, stride=4, D=256, blocky=False,
+                         loss="contrast_ce_loss",
+                         contrast=dict(max_samples=1024, max_views=100, temperature=0.1, loss_weight=0.1),
+                         ce_weight=CITYSCAPES_W, grads=False, torch_seed=304),
+}
+
+
+def case_inputs(c):
+    target, seg, embed = O.synth_case(c["seed"], c["B"], c["K"], c["H"], c["W"], c["stride"], c["D"],
+                                      blocky=c["blocky"], n_rect=c.get("n_rect", 14))
+    if "hw" in c:   # feature size not H//stride (DeepLab ceil-mode sizes): regenerate seg/embed at that size
+        h, w = c["hw"]
+        rs = np.random.RandomState(c["seed"] + 1000)
+        lab = O.nearest_downsample_labels(target, h, w)
+        onehot = (lab[:, None] == np.arange(c["K"])[None, :, None, None]).astype(np.float32)
+        seg = (onehot * 4.0 + rs.standard_normal((c["B"], c["K"], h, w)) * 2.0).astype(np.float32)
+        e = rs.standard_normal((c["B"], c["D"], h, w)).astype(np.float32)
+        embed = (e / np.sqrt((e.astype(np.float64) ** 2).sum(1, keepdims=True))).astype(np.float32)
+    extra = {}
+    rs = np.random.RandomState(c["seed"] + 2000)
+    if c["loss"] == "contrast_auxce_loss":
+        extra["seg_aux"] = (seg * 0.5 + rs.standard_normal(seg.shape) * 1.0).astype(np.float32)
+    if c["loss"] == "mem_contrast_ce_loss":
+        ms = c["contrast"]["memory_size"]
+        for name in ("segment_queue", "pixel_queue"):
+            q = rs.standard_normal((c["K"], ms, c["D"])).astype(np.float32)
+            extra[name] = (q / np.sqrt((q.astype(np.float64) ** 2).sum(2, keepdims=True))).astype(np.float32)
+    return target, seg, embed, extra
+
+
+def run_loss_case(name, c):
+    import torch
+    ref_shim.install()
+    from lib.loss.loss_manager import SEG_LOSS_DICT
+    cfg = ref_shim.configer(num_classes=c["K"], loss_type=c["loss"], contrast=c["contrast"],
+                            ce_weight=c["ce_weight"])
+    crit = SEG_LOSS_DICT[c["loss"]](cfg)
+    target, seg, embed, extra = case_inputs(c)
+    t_target = torch.from_numpy(target)
+    t_seg = torch.from_numpy(seg).requires_grad_(True)
+    t_embed = torch.from_numpy(embed).requires_grad_(True)
+    preds = {"seg": t_seg, "embed": t_embed}
+    leaves = {"seg": t_seg, "embed": t_embed}
+    for k, v in extra.items():
+        preds[k] = torch.from_numpy(v)
+        if k == "seg_aux":
+            preds[k].requires_grad_(True)
+            leaves[k] = preds[k]
+    with_embed = c.get("with_embed", True)
+
+    torch.manual_seed(c["torch_seed"])
+    total = crit(preds, t_target, with_embed=with_embed)
+    out = {"total": float(total.detach())}
+    if c["grads"]:
+        total.backward()
+
+    # separate terms, same RNG position
+    with torch.no_grad():
+        h, w = seg.shape[-2:]
+        _, predict = torch.max(t_seg, 1)
+        torch.manual_seed(c["torch_seed"])
+        if c["loss"] == "mem_contrast_ce_loss":
+            queue = torch.cat((preds["segment_queue"], preds["pixel_queue"]), dim=1)
+            lc = crit.contrast_criterion(t_embed, t_target, predict, queue)
+        else:
+            lc = crit.contrast_criterion(t_embed, t_target, predict)
+        out["contrast"] = float(lc)
+        # mined anchors: feed index-encoding features through the reference sampler
+        B, D = embed.shape[:2]
+        P = h * w
+        enc = torch.zeros(B, P, 2)
+        enc[:, :, 0] = torch.arange(B).view(B, 1).float()
+        enc[:, :, 1] = torch.arange(P).view(1, P).float()
+        labels = torch.nn.functional.interpolate(t_target.unsqueeze(1).float(), (h, w), mode="nearest")
+        labels = labels.squeeze(1).long().view(B, -1)
+        torch.manual_seed(c["torch_seed"])
+        X_, y_ = crit.contrast_criterion._hard_anchor_sampling(enc, labels, predict.view(B, -1))
+        out["n_view"] = int(X_.shape[1])
+        out["anchor_img"] = X_[:, :, 0].long().numpy()          # [T, n_view]
+        out["anchor_pix"] = X_[:, :, 1].long().numpy()          # [T, n_view]
+        out["anchor_cls"] = y_.long().numpy()                   # [T]
+        out["labels_ds"] = labels.numpy().astype(np.int16)
+        out["predict"] = predict.view(B, -1).numpy().astype(np.int16)
+    if c["grads"]:
+        out["d_seg"] = t_seg.grad.numpy()
+        g = t_embed.grad.numpy().reshape(embed.shape[0], embed.shape[1], -1)
+        img = out["anchor_img"].reshape(-1)
+        pix = out["anchor_pix"].reshape(-1)
+        out["d_embed_rows"] = g[img, :, pix]                     # [T*n_view, D] in (class-major, view) order
+        mask = np.ones(g.shape, dtype=bool)
+        mask[img, :, pix] = False
+        out["d_embed_rest_absmax"] = float(np.abs(g[mask]).max()) if mask.any() else 0.0
+        if "seg_aux" in leaves:
+            out["d_seg_aux"] = leaves["seg_aux"].grad.numpy()
+    out["ce"] = out["total"] - (c["contrast"]["loss_weight"] if with_embed else 0.0) * out["contrast"]
+    np.savez_compressed(os.path.join(OUT, "loss_%s.npz" % name), **out)
+    print("loss_%s: total %.6f contrast %.6f n_view %d T %d" % (name, out["total"], out["contrast"],
+                                                                 out["n_view"], len(out["anchor_cls"])))
+
+
+ENQ_CASES = {
+    "enq_a": dict(seed=21, B=3, K=7, H=64, W=128, kstride=4, D=16, network_stride=8, memory_size=9,
+                  pixel_update_freq=4, torch_seed=304, rounds=3),
+    "enq_b": dict(seed=22, B=2, K=19, H=128, W=256, kstride=4, D=32, network_stride=8, memory_size=50,
+                  pixel_update_freq=10, torch_seed=11, rounds=2),
+}
+
+
+def enq_inputs(c, r):
+    target, _, embed = O.synth_case(c["seed"] + 31 * r, c["B"], c["K"], c["H"], c["W"], c["kstride"], c["D"],
+                                    blocky=True)
+    return target, embed
+
+
+def enq_init(c):
+    rs = np.random.RandomState(c["seed"] + 500)
+    sq = rs.standard_normal((c["K"], c["memory_size"], c["D"])).astype(np.float32)
+    pq = rs.standard_normal((c["K"], c["memory_size"], c["D"])).astype(np.float32)
+    return sq, pq
+
+
+def run_enq_case(name, c):
+    import torch
+    ref_shim.install()
+    # segmentor/trainer_contrastive.py imports the whole data/vis stack; _dequeue_and_enqueue only reads three
+    # attributes of self, so bind the unmodified function to a bare namespace.
+    import importlib
+    for m in ("lib.vis.seg_visualizer", "lib.datasets.data_loader", "segmentor.tools.evaluator"):
+        if m not in sys.modules:
+            stub = types.ModuleType(m)
+            stub.SegVisualizer = object
+            stub.DataLoader = object
+            stub.get_evaluator = lambda *a, **k: None
+            sys.modules[m] = stub
+    tc = importlib.import_module("segmentor.trainer_contrastive")
+    me = types.SimpleNamespace(network_stride=c["network_stride"], memory_size=c["memory_size"],
+                               pixel_update_freq=c["pixel_update_freq"])
+    sq, pq = enq_init(c)
+    sq, pq = torch.from_numpy(sq), torch.from_numpy(pq)
+    sp = torch.zeros(c["K"], dtype=torch.long)
+    pp = torch.zeros(c["K"], dtype=torch.long)
+    torch.manual_seed(c["torch_seed"])
+    out = {}
+    for r in range(c["rounds"]):
+        target, embed = enq_inputs(c, r)
+        tc.Trainer._dequeue_and_enqueue(me, torch.from_numpy(embed), torch.from_numpy(target), sq, sp, pq, pp)
+        out["segment_queue_%d" % r] = sq.numpy().copy()
+        out["pixel_queue_%d" % r] = pq.numpy().copy()
+        out["segment_ptr_%d" % r] = sp.numpy().copy()
+        out["pixel_ptr_%d" % r] = pp.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "%s.npz" % name), **out)
+    print(name, "ptrs", sp.tolist(), pp.tolist())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    for name, c in LOSS_CASES.items():
+        if a.only is None or a.only == name:
+            run_loss_case(name, c)
+    for name, c in ENQ_CASES.items():
+        if a.only is None or a.only == name:
+            run_enq_case(name, c)
+
+
+if __name__ == "__main__":
+    main()
