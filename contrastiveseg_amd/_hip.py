@@ -1,0 +1,90 @@
+"""ctypes binding of libcseg_hip.so (the C-ABI declared in include/cseg_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every call below passes raw device pointers and
+the current HIP stream. There is NO CPU fallback: a missing library or a non-GPU tensor raises (the reference's
+native ops fail the same way, lib/extensions/inplace_abn/functions.py:25-28 `_check`)."""
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libcseg_hip.so")
+
+_c_int = ctypes.c_int
+_c_float = ctypes.c_float
+_ptr = ctypes.c_void_p
+
+
+class ContrastDesc(ctypes.Structure):
+    _fields_ = [("mode", _c_int), ("N", _c_int), ("M", _c_int), ("D", _c_int),
+                ("anchors", _ptr), ("a_lab", _ptr), ("contrast", _ptr), ("c_lab", _ptr),
+                ("segment_queue", _ptr), ("pixel_queue", _ptr),
+                ("bank_classes", _c_int), ("bank_size", _c_int),
+                ("temperature", _c_float), ("base_temperature", _c_float)]
+
+
+# name -> (restype, argtypes); must list every symbol of include/cseg_hip.h (tests/test_cabi.py checks it)
+SIGNATURES = {
+    "cseg_abi_version": (_c_int, []),
+    "cseg_last_error": (ctypes.c_char_p, []),
+    "cseg_classify_partition": (_c_int, [_ptr, _ptr, _ptr] + [_c_int] * 7 + [_ptr] * 7 + [_ptr]),
+    "cseg_gather_anchors": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr]),
+    "cseg_scatter_anchor_grad": (_c_int, [_ptr, _c_int, _ptr, _c_int, _c_int, _c_int, _c_float, _ptr, _ptr]),
+    "cseg_contrast_ws_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
+    "cseg_contrast_fwd": (_c_int, [ctypes.POINTER(ContrastDesc), _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "cseg_contrast_bwd_parts": (_c_int, [_c_int, _c_int, _c_int]),
+    "cseg_contrast_bwd": (_c_int, [ctypes.POINTER(ContrastDesc), _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "cseg_upcat_fwd": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr]),
+    "cseg_upcat_bwd": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr]),
+    "cseg_upsample_ce_blocks": (_c_int, [_c_int, _c_int, _c_int]),
+    "cseg_upsample_ce_fwd": (_c_int, [_ptr, _ptr, _ptr, _c_int] + [_c_int] * 6 + [_ptr, _ptr, _ptr, _ptr]),
+    "cseg_upsample_ce_bwd": (_c_int, [_ptr, _ptr, _ptr, _c_int] + [_c_int] * 6 + [_ptr, _ptr, _ptr, _ptr]),
+    "cseg_queue_count": (_c_int, [_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    "cseg_queue_class_sums": (_c_int, [_ptr, _ptr] + [_c_int] * 7 + [_ptr, _ptr]),
+    "cseg_queue_write_segments": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _c_int, _ptr]),
+    "cseg_queue_write_pixels": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _c_int,
+                                         _ptr]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads the library once. Raises if it was not built (run `python __graft_entry__.py` / csrc/build.py)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libcseg_hip.so is missing at %s: the HIP extension was not built; there is no CPU "
+                               "fallback for the contrastive hot path" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def _check(ok, what):
+    if ok != 1:
+        raise RuntimeError("%s failed: %s" % (what, lib().cseg_last_error().decode()))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev(t, dtype, what):
+    """Validates a tensor that is about to be handed to the kernels as a raw pointer."""
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU (got %s): libcseg_hip has no CPU path" % (what, t.device))
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s (got %s)" % (what, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % what)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def call(name, *args):
+    _check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,58 @@
+// Shared helpers for libcseg_hip.so (gfx950 only: 64-wide wavefronts hard-coded).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "cseg_hip.h"
+
+#define CSEG_WAVE 64
+
+void cseg_set_error(const char* fmt, ...);
+
+// reference convention: 1 = ok, 0 = error (lib/extensions/cc_attention/src/ca.cu:199-204)
+#define CSEG_CHECK_LAUNCH(name)                                                     \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            cseg_set_error("%s: %s", name, hipGetErrorString(e__));                 \
+            return 0;                                                               \
+        }                                                                           \
+    } while (0)
+
+#define CSEG_REQUIRE(cond, ...)                                                     \
+    do {                                                                            \
+        if (!(cond)) {                                                              \
+            cseg_set_error(__VA_ARGS__);                                            \
+            return 0;                                                               \
+        }                                                                           \
+    } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int n = __shfl_up(v, o, 64);
+        if (lane >= o) v += n;
+    }
+    return v;
+}
+
+// torch's area_pixel_compute_source_index for align_corners=True, fp32 (ATen UpSample.h): src = scale * dst
+__host__ __device__ __forceinline__ float ac_scale(int in_size, int out_size) {
+    return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.0f;
+}

@@ -1,0 +1,190 @@
+// HRNet head input: bilinear(align_corners=True) upsample of the coarse branches fused with the channel concat.
+// Reference: lib/models/nets/hrnet.py:86-91 (3x F.interpolate + torch.cat -> 705 MB of temporaries at bs8).
+// HBM-bound: forward writes each output element once with 16-byte stores, coarse maps are re-read from L2;
+// backward is the exact adjoint written as a gather (no atomics => deterministic).
+#include "cseg_common.h"
+
+namespace {
+
+struct UpcatMaps {
+    const float* x[4];
+    float* dx[4];
+    int C[4], h[4], w[4], coff[5];
+    int n;
+};
+
+// grid = (ceil(h0*w0/4 / 256), Ctot, B): the source map is block-uniform.
+__global__ __launch_bounds__(256) void upcat_fwd_kernel(UpcatMaps m, int Ctot, float* __restrict__ out) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int h0 = m.h[0], w0 = m.w[0];
+    const int w4 = w0 >> 2;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= h0 * w4) return;
+    const int y = e / w4, x = (e - y * w4) * 4;
+    int mi = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) if (k < m.n && c >= m.coff[k]) mi = k;
+    const int cm = c - m.coff[mi];
+    float4 v;
+    if (mi == 0) {
+        v = *reinterpret_cast<const float4*>(m.x[0] + (((size_t)b * m.C[0] + cm) * h0 + y) * w0 + x);
+    } else {
+        const int hs = m.h[mi], ws = m.w[mi];
+        const float sy = ac_scale(hs, h0), sx = ac_scale(ws, w0);
+        const float fy = sy * (float)y;
+        const int y0 = (int)fy;
+        const int y1 = y0 + (y0 < hs - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+        const float* r0 = m.x[mi] + (((size_t)b * m.C[mi] + cm) * hs + y0) * ws;
+        const float* r1 = m.x[mi] + (((size_t)b * m.C[mi] + cm) * hs + y1) * ws;
+        float o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float fx = sx * (float)(x + t);
+            const int x0 = (int)fx;
+            const int x1 = x0 + (x0 < ws - 1 ? 1 : 0);
+            const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+            o[t] = ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+        }
+        v = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    *reinterpret_cast<float4*>(out + (((size_t)b * Ctot + c) * h0 + y) * w0 + x) = v;
+}
+
+// scalar fallback when w0 % 4 != 0
+__global__ __launch_bounds__(256) void upcat_fwd_scalar_kernel(UpcatMaps m, int Ctot, float* __restrict__ out) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int h0 = m.h[0], w0 = m.w[0];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= h0 * w0) return;
+    const int y = e / w0, x = e - y * w0;
+    int mi = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) if (k < m.n && c >= m.coff[k]) mi = k;
+    const int cm = c - m.coff[mi];
+    float v;
+    if (mi == 0) {
+        v = m.x[0][(((size_t)b * m.C[0] + cm) * h0 + y) * w0 + x];
+    } else {
+        const int hs = m.h[mi], ws = m.w[mi];
+        const float fy = ac_scale(hs, h0) * (float)y, fx = ac_scale(ws, w0) * (float)x;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < hs - 1 ? 1 : 0), x1 = x0 + (x0 < ws - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+        const float* p = m.x[mi] + ((size_t)b * m.C[mi] + cm) * hs * ws;
+        v = ly0 * (lx0 * p[y0 * ws + x0] + lx1 * p[y0 * ws + x1]) + ly1 * (lx0 * p[y1 * ws + x0] + lx1 * p[y1 * ws + x1]);
+    }
+    out[(((size_t)b * Ctot + c) * h0 + y) * w0 + x] = v;
+}
+
+// backward for the pass-through map: strided channel-slice copy
+__global__ __launch_bounds__(256) void upcat_bwd_copy_kernel(const float* __restrict__ d_out, int Ctot, int C0, int hw,
+                                                             float* __restrict__ dx0) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < hw) dx0[((size_t)b * C0 + c) * hw + e] = d_out[((size_t)b * Ctot + c) * hw + e];
+}
+
+// backward for an upsampled map: one thread per source element gathers its footprint with the forward's own
+// fp32 index arithmetic, so the result is the exact adjoint.
+__global__ __launch_bounds__(256) void upcat_bwd_gather_kernel(const float* __restrict__ d_out, int Ctot, int coff,
+                                                               int Cm, int hs, int ws, int h0, int w0,
+                                                               float* __restrict__ dx) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= hs * ws) return;
+    const int ys = e / ws, xs = e - ys * ws;
+    const float sy = ac_scale(hs, h0), sx = ac_scale(ws, w0);
+    int y_lo = 0, y_hi = h0 - 1, x_lo = 0, x_hi = w0 - 1;
+    if (sy > 0.f) {
+        y_lo = max(0, (int)ceilf((float)(ys - 1) / sy) - 1);
+        y_hi = min(h0 - 1, (int)floorf((float)(ys + 1) / sy) + 1);
+    }
+    if (sx > 0.f) {
+        x_lo = max(0, (int)ceilf((float)(xs - 1) / sx) - 1);
+        x_hi = min(w0 - 1, (int)floorf((float)(xs + 1) / sx) + 1);
+    }
+    const float* g = d_out + ((size_t)b * Ctot + coff + c) * h0 * w0;
+    float acc = 0.f;
+    for (int y = y_lo; y <= y_hi; ++y) {
+        const float fy = sy * (float)y;
+        const int y0 = (int)fy;
+        const int y1 = y0 + (y0 < hs - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0;
+        float wy = 0.f;
+        if (y0 == ys) wy += 1.f - ly1;
+        if (y1 == ys) wy += ly1;
+        if (wy == 0.f) continue;
+        float racc = 0.f;
+        for (int x = x_lo; x <= x_hi; ++x) {
+            const float fx = sx * (float)x;
+            const int x0 = (int)fx;
+            const int x1 = x0 + (x0 < ws - 1 ? 1 : 0);
+            const float lx1 = fx - (float)x0;
+            float wx = 0.f;
+            if (x0 == xs) wx += 1.f - lx1;
+            if (x1 == xs) wx += lx1;
+            if (wx != 0.f) racc += wx * g[(size_t)y * w0 + x];
+        }
+        acc += wy * racc;
+    }
+    dx[(((size_t)b * Cm + c) * hs + ys) * ws + xs] = acc;
+}
+
+int fill_maps(UpcatMaps* m, const int* C, const int* hs, const int* ws, int n_maps) {
+    CSEG_REQUIRE(n_maps >= 1 && n_maps <= 4, "upcat: n_maps=%d not in [1,4]", n_maps);
+    m->n = n_maps;
+    m->coff[0] = 0;
+    for (int i = 0; i < 4; ++i) {
+        m->x[i] = nullptr; m->dx[i] = nullptr;
+        m->C[i] = i < n_maps ? C[i] : 0;
+        m->h[i] = i < n_maps ? hs[i] : 1;
+        m->w[i] = i < n_maps ? ws[i] : 1;
+        m->coff[i + 1] = m->coff[i] + m->C[i];
+        if (i < n_maps) CSEG_REQUIRE(C[i] > 0 && hs[i] > 0 && ws[i] > 0, "upcat: empty map %d", i);
+    }
+    return 1;
+}
+
+}  // namespace
+
+extern "C" int cseg_upcat_fwd(const float* const* xs, const int* C, const int* hs, const int* ws, int n_maps, int B,
+                              float* out, cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    UpcatMaps m;
+    if (!fill_maps(&m, C, hs, ws, n_maps)) return 0;
+    for (int i = 0; i < n_maps; ++i) m.x[i] = xs[i];
+    const int Ctot = m.coff[n_maps], h0 = hs[0], w0 = ws[0];
+    CSEG_REQUIRE(Ctot <= 65535 && B <= 65535, "upcat: grid too large");
+    if (w0 % 4 == 0) {
+        dim3 grid((h0 * (w0 / 4) + 255) / 256, Ctot, B);
+        hipLaunchKernelGGL(upcat_fwd_kernel, grid, dim3(256), 0, stream, m, Ctot, out);
+    } else {
+        dim3 grid((h0 * w0 + 255) / 256, Ctot, B);
+        hipLaunchKernelGGL(upcat_fwd_scalar_kernel, grid, dim3(256), 0, stream, m, Ctot, out);
+    }
+    CSEG_CHECK_LAUNCH("upcat_fwd_kernel");
+    return 1;
+}
+
+extern "C" int cseg_upcat_bwd(const float* d_out, const int* C, const int* hs, const int* ws, int n_maps, int B,
+                              float* const* d_xs, cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    UpcatMaps m;
+    if (!fill_maps(&m, C, hs, ws, n_maps)) return 0;
+    const int Ctot = m.coff[n_maps], h0 = hs[0], w0 = ws[0];
+    CSEG_REQUIRE(Ctot <= 65535 && B <= 65535, "upcat: grid too large");
+    if (d_xs[0]) {
+        dim3 grid((h0 * w0 + 255) / 256, C[0], B);
+        hipLaunchKernelGGL(upcat_bwd_copy_kernel, grid, dim3(256), 0, stream, d_out, Ctot, C[0], h0 * w0, d_xs[0]);
+        CSEG_CHECK_LAUNCH("upcat_bwd_copy_kernel");
+    }
+    for (int i = 1; i < n_maps; ++i) {
+        if (!d_xs[i]) continue;
+        dim3 grid((hs[i] * ws[i] + 255) / 256, C[i], B);
+        hipLaunchKernelGGL(upcat_bwd_gather_kernel, grid, dim3(256), 0, stream, d_out, Ctot, m.coff[i], C[i], hs[i],
+                           ws[i], h0, w0, d_xs[i]);
+        CSEG_CHECK_LAUNCH("upcat_bwd_gather_kernel");
+    }
+    return 1;
+}

@@ -1,0 +1,339 @@
+"""Thin autograd wrappers over the C-ABI (contrastiveseg_amd/_hip.py). Same pattern as the reference's own native
+ops (lib/extensions/cc_attention/functions.py:20-47): a torch.autograd.Function that pre-allocates outputs, passes
+raw pointers + the current stream, and raises RuntimeError on a 0 return. No CPU path."""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _hip
+
+I32, I16, I64, F32 = torch.int32, torch.int16, torch.int64, torch.float32
+
+
+def _p(t, dtype, what):
+    return _hip.dev(t, dtype, what)
+
+
+def _null():
+    return ctypes.c_void_p(None)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# anchor mining
+# ----------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def classify_partition(target, ignore_label, seg=None, predict=None, num_classes=None, feat_hw=None,
+                       want_maps=False):
+    """lib/loss/loss_contrast.py:131-134 + :183 + the unique/nonzero bookkeeping of :35-64, on the device.
+    Returns dict(counts [B,K,2], seg_off [B,K,2], part_idx [B,P], status [4], lab/pred [B,P] if want_maps)."""
+    B, H, W = target.shape
+    if seg is not None:
+        _, K, h, w = seg.shape
+        seg_p, pred_p = _p(seg, F32, "seg"), _null()
+    else:
+        K = int(num_classes)
+        h, w = feat_hw
+        predict = predict.reshape(B, h * w)
+        seg_p, pred_p = _null(), _p(predict, I64, "predict")
+    P = h * w
+    dev = target.device
+    out = {
+        "counts": torch.empty(B, K, 2, dtype=I32, device=dev),
+        "seg_off": torch.empty(B, K, 2, dtype=I32, device=dev),
+        "part_idx": torch.empty(B, P, dtype=I32, device=dev),
+        "status": torch.empty(4, dtype=I32, device=dev),
+        "key": torch.empty(B, P, dtype=I16, device=dev),
+    }
+    if want_maps:
+        out["lab"] = torch.empty(B, P, dtype=I32, device=dev)
+        out["pred"] = torch.empty(B, P, dtype=I32, device=dev)
+    _hip.call("cseg_classify_partition", seg_p, pred_p, _p(target, I64, "target"), B, K, h, w, H, W,
+              int(ignore_label),
+              _p(out["lab"], I32, "lab") if want_maps else _null(),
+              _p(out["pred"], I32, "pred") if want_maps else _null(),
+              _p(out["key"], I16, "key"), _p(out["counts"], I32, "counts"), _p(out["seg_off"], I32, "seg_off"),
+              _p(out["part_idx"], I32, "part_idx"), _p(out["status"], I32, "status"), _hip.stream_ptr())
+    return out
+
+
+@torch.no_grad()
+def gather_anchors(embed, part_idx, sel_pos):
+    B, D = embed.shape[:2]
+    P = embed.shape[2] * embed.shape[3]
+    N = sel_pos.numel()
+    anchors = torch.empty(N, D, dtype=F32, device=embed.device)
+    sel_pix = torch.empty(N, dtype=I32, device=embed.device)
+    _hip.call("cseg_gather_anchors", _p(embed, F32, "embed"), B, D, P, _p(part_idx, I32, "part_idx"),
+              _p(sel_pos, I32, "sel_pos"), N, _p(anchors, F32, "anchors"), _p(sel_pix, I32, "sel_pix"),
+              _hip.stream_ptr())
+    return anchors, sel_pix
+
+
+# ----------------------------------------------------------------------------------------------------------
+# contrastive term
+# ----------------------------------------------------------------------------------------------------------
+def _desc(mode, anchors, a_lab, temperature, base_temperature, contrast=None, c_lab=None, segment_queue=None,
+          pixel_queue=None):
+    d = _hip.ContrastDesc()
+    d.mode = mode
+    d.N, d.D = anchors.shape
+    d.anchors = _p(anchors, F32, "anchors")
+    d.a_lab = _p(a_lab, I32, "a_lab")
+    d.temperature = float(temperature)
+    d.base_temperature = float(base_temperature)
+    if mode == 0:
+        d.M = d.N
+    elif mode == 1:
+        d.M = contrast.shape[0]
+        d.contrast = _p(contrast, F32, "contrast")
+        d.c_lab = _p(c_lab, I32, "c_lab")
+    else:
+        K, ms, Dq = segment_queue.shape
+        if Dq != d.D or tuple(pixel_queue.shape) != (K, ms, Dq):
+            raise RuntimeError("queue shapes %s / %s do not match D=%d" % (tuple(segment_queue.shape),
+                                                                           tuple(pixel_queue.shape), d.D))
+        d.M = K * 2 * ms
+        d.segment_queue = _p(segment_queue, F32, "segment_queue")
+        d.pixel_queue = _p(pixel_queue, F32, "pixel_queue")
+        d.bank_classes, d.bank_size = K, ms
+    return d
+
+
+def contrast_forward(desc, device):
+    """Runs cseg_contrast_fwd. Returns (loss [1], saved) where saved feeds contrast_backward."""
+    lib = _hip.lib()
+    ws = lib.cseg_contrast_ws_bytes(desc.N, desc.M)
+    S = torch.empty(ws // 4, dtype=F32, device=device)
+    row_stats = torch.empty(desc.N, 4, dtype=F32, device=device)
+    row_loss = torch.empty(desc.N, dtype=F32, device=device)
+    loss = torch.empty(1, dtype=F32, device=device)
+    _hip.call("cseg_contrast_fwd", ctypes.byref(desc), _p(S, F32, "S_ws"), _p(row_stats, F32, "row_stats"),
+              _p(row_loss, F32, "row_loss"), _p(loss, F32, "loss"), _hip.stream_ptr())
+    return loss, (S, row_stats, row_loss)
+
+
+def contrast_backward(desc, saved, d_loss, device):
+    """Runs cseg_contrast_bwd. Returns d_anchor_parts [n_parts, N, D]."""
+    lib = _hip.lib()
+    S, row_stats, _ = saved
+    n_parts = lib.cseg_contrast_bwd_parts(desc.N, desc.M, desc.D)
+    parts = torch.empty(n_parts, desc.N, desc.D, dtype=F32, device=device)
+    d_loss = d_loss.reshape(1).to(F32).contiguous()
+    _hip.call("cseg_contrast_bwd", ctypes.byref(desc), _p(S, F32, "S_ws"), _p(row_stats, F32, "row_stats"),
+              _p(d_loss, F32, "d_loss"), _p(parts, F32, "d_anchor_parts"), _hip.stream_ptr())
+    return parts
+
+
+class ContrastOnAnchors(Function):
+    """loss = _contrastive(anchors, ...) with anchors already gathered ([N,D], view-major rows).
+    mode: 'self' | 'plain' | 'bank'. Gradient flows to `anchors` only (the reference gives the bank none,
+    loss_contrast_mem.py:221 reads buffers). Used by tests and by the cross-rank contrast set."""
+
+    @staticmethod
+    def forward(ctx, anchors, a_lab, mode, temperature, base_temperature, contrast, c_lab, segment_queue,
+                pixel_queue):
+        anchors = anchors.contiguous()
+        m = {"self": 0, "plain": 1, "bank": 2}[mode]
+        desc = _desc(m, anchors, a_lab, temperature, base_temperature, contrast, c_lab, segment_queue, pixel_queue)
+        loss, saved = contrast_forward(desc, anchors.device)
+        ctx.desc = desc
+        ctx.saved = saved
+        ctx.keep = (anchors, a_lab, contrast, c_lab, segment_queue, pixel_queue)  # keep pointers alive
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        anchors = ctx.keep[0]
+        parts = contrast_backward(ctx.desc, ctx.saved, g, anchors.device)
+        return (parts.sum(0) if parts.shape[0] > 1 else parts[0],) + (None,) * 8
+
+
+class PixelContrast(Function):
+    """gather(embed NCHW at mined pixels) -> _contrastive -> scalar, fused end to end; backward = contrast
+    backward + scatter of the anchor rows into a zero d_embed (no NHWC copy, no dense N x N temporaries).
+    `grad_scale` multiplies the gradient only (world size in the cross-rank mode, see lib/loss/loss_contrast.py
+    of this package)."""
+
+    @staticmethod
+    def forward(ctx, embed, part_idx, sel_pos, a_lab, mode, temperature, base_temperature, segment_queue,
+                pixel_queue):
+        if not embed.is_contiguous():
+            embed = embed.contiguous()
+        anchors, sel_pix = gather_anchors(embed, part_idx, sel_pos)
+        m = {"self": 0, "bank": 2}[mode]
+        desc = _desc(m, anchors, a_lab, temperature, base_temperature, None, None, segment_queue, pixel_queue)
+        loss, saved = contrast_forward(desc, embed.device)
+        ctx.desc, ctx.saved = desc, saved
+        ctx.keep = (anchors, a_lab, segment_queue, pixel_queue)
+        ctx.sel_pix = sel_pix
+        ctx.embed_shape = embed.shape
+        ctx.mark_non_differentiable(sel_pix)
+        return loss.reshape(()), sel_pix
+
+    @staticmethod
+    def backward(ctx, g, _g_sel):
+        B, D, h, w = ctx.embed_shape
+        dev = ctx.sel_pix.device
+        parts = contrast_backward(ctx.desc, ctx.saved, g, dev)
+        d_embed = torch.zeros(B, D, h, w, dtype=F32, device=dev)
+        _hip.call("cseg_scatter_anchor_grad", _p(parts, F32, "parts"), parts.shape[0], _p(ctx.sel_pix, I32, "sel_pix"),
+                  parts.shape[1], D, h * w, 1.0, _p(d_embed, F32, "d_embed"), _hip.stream_ptr())
+        return (d_embed,) + (None,) * 8
+
+
+class GatherAnchors(Function):
+    """anchors = embed[b, :, pix] rows (differentiable): used when the contrast set is assembled across ranks."""
+
+    @staticmethod
+    def forward(ctx, embed, part_idx, sel_pos):
+        if not embed.is_contiguous():
+            embed = embed.contiguous()
+        anchors, sel_pix = gather_anchors(embed, part_idx, sel_pos)
+        ctx.sel_pix = sel_pix
+        ctx.embed_shape = embed.shape
+        ctx.mark_non_differentiable(sel_pix)
+        return anchors, sel_pix
+
+    @staticmethod
+    def backward(ctx, g, _):
+        B, D, h, w = ctx.embed_shape
+        g = g.contiguous()
+        d_embed = torch.zeros(B, D, h, w, dtype=F32, device=g.device)
+        _hip.call("cseg_scatter_anchor_grad", _p(g, F32, "d_anchors"), 1, _p(ctx.sel_pix, I32, "sel_pix"),
+                  g.shape[0], D, h * w, 1.0, _p(d_embed, F32, "d_embed"), _hip.stream_ptr())
+        return d_embed, None, None
+
+
+# ----------------------------------------------------------------------------------------------------------
+# HRNet head: upsample + concat
+# ----------------------------------------------------------------------------------------------------------
+def _int_arr(vals):
+    return (ctypes.c_int * len(vals))(*vals)
+
+
+class UpsampleConcat(Function):
+    """lib/models/nets/hrnet.py:86-91 as one kernel (forward) and its exact adjoint (backward)."""
+
+    @staticmethod
+    def forward(ctx, *feats):
+        feats = [f.contiguous() for f in feats]
+        B = feats[0].shape[0]
+        C = [f.shape[1] for f in feats]
+        hs = [f.shape[2] for f in feats]
+        ws = [f.shape[3] for f in feats]
+        out = torch.empty(B, sum(C), hs[0], ws[0], dtype=F32, device=feats[0].device)
+        ptrs = (ctypes.c_void_p * len(feats))(*[_p(f, F32, "feat%d" % i).value for i, f in enumerate(feats)])
+        _hip.call("cseg_upcat_fwd", ptrs, _int_arr(C), _int_arr(hs), _int_arr(ws), len(feats), B,
+                  _p(out, F32, "out"), _hip.stream_ptr())
+        ctx.dims = (B, C, hs, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, hs, ws = ctx.dims
+        g = g.contiguous()
+        grads = []
+        ptrs = []
+        for i in range(len(C)):
+            if ctx.needs_input_grad[i]:
+                t = torch.empty(B, C[i], hs[i], ws[i], dtype=F32, device=g.device)
+                grads.append(t)
+                ptrs.append(t.data_ptr())
+            else:
+                grads.append(None)
+                ptrs.append(None)
+        arr = (ctypes.c_void_p * len(C))(*ptrs)
+        _hip.call("cseg_upcat_bwd", _p(g, F32, "d_out"), _int_arr(C), _int_arr(hs), _int_arr(ws), len(C), B, arr,
+                  _hip.stream_ptr())
+        return tuple(grads)
+
+
+def upsample_concat(feats):
+    return UpsampleConcat.apply(*feats)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# segmentation term: upsample + weighted CE
+# ----------------------------------------------------------------------------------------------------------
+class UpsampleCE(Function):
+    """FSCELoss(F.interpolate(seg, target.shape, bilinear, align_corners=True), target) without the [B,K,H,W]
+    tensor (lib/loss/loss_contrast.py:180-181, lib/loss/loss_helper.py:169-206)."""
+
+    @staticmethod
+    def forward(ctx, seg, target, weight, ignore_index):
+        seg = seg.contiguous()
+        B, K, h, w = seg.shape
+        _, H, W = target.shape
+        lib = _hip.lib()
+        nb = lib.cseg_upsample_ce_blocks(B, H, W)
+        dev = seg.device
+        partial = torch.empty(2 * nb, dtype=F32, device=dev)
+        out = torch.empty(2, dtype=F32, device=dev)
+        status = torch.zeros(4, dtype=I32, device=dev)
+        wp = _p(weight, F32, "ce_weight") if weight is not None else _null()
+        _hip.call("cseg_upsample_ce_fwd", _p(seg, F32, "seg"), _p(target, I64, "target"), wp, int(ignore_index), B, K,
+                  h, w, H, W, _p(partial, F32, "partial"), _p(out, F32, "out"), _p(status, I32, "status"),
+                  _hip.stream_ptr())
+        ctx.save_for_backward(seg, target, out)
+        ctx.weight = weight
+        ctx.ignore_index = int(ignore_index)
+        ctx.status = status
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        seg, target, out = ctx.saved_tensors
+        B, K, h, w = seg.shape
+        _, H, W = target.shape
+        d_seg = torch.empty_like(seg)
+        g = g.reshape(1).to(F32).contiguous()
+        wp = _p(ctx.weight, F32, "ce_weight") if ctx.weight is not None else _null()
+        _hip.call("cseg_upsample_ce_bwd", _p(seg, F32, "seg"), _p(target, I64, "target"), wp, ctx.ignore_index, B, K,
+                  h, w, H, W, _p(out, F32, "out"), _p(g, F32, "d_loss"), _p(d_seg, F32, "d_seg"), _hip.stream_ptr())
+        return d_seg, None, None, None
+
+
+def upsample_ce(seg, target, weight=None, ignore_index=-1):
+    return UpsampleCE.apply(seg, target, weight, ignore_index)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# memory bank
+# ----------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def queue_count(labels, stride, num_classes):
+    B, H, W = labels.shape
+    counts = torch.empty(B, num_classes, dtype=I32, device=labels.device)
+    _hip.call("cseg_queue_count", _p(labels, I64, "labels"), B, H, W, int(stride), int(num_classes),
+              _p(counts, I32, "counts"), _hip.stream_ptr())
+    return counts
+
+
+@torch.no_grad()
+def queue_class_sums(keys, labels, stride, num_classes):
+    B, D = keys.shape[:2]
+    Pk = keys.shape[2] * keys.shape[3]
+    _, H, W = labels.shape
+    sums = torch.empty(B, num_classes, D, dtype=F32, device=keys.device)
+    _hip.call("cseg_queue_class_sums", _p(keys, F32, "keys"), _p(labels, I64, "labels"), B, D, Pk, H, W, int(stride),
+              int(num_classes), _p(sums, F32, "sums"), _hip.stream_ptr())
+    return sums
+
+
+@torch.no_grad()
+def queue_write_segments(sums, counts, job_img, job_cls, job_dst_row, segment_queue):
+    K, ms, D = segment_queue.shape
+    _hip.call("cseg_queue_write_segments", _p(sums, F32, "sums"), _p(counts, I32, "counts"),
+              _p(job_img, I32, "job_img"), _p(job_cls, I32, "job_cls"), _p(job_dst_row, I32, "job_dst_row"),
+              job_img.numel(), K, D, _p(segment_queue, F32, "segment_queue"), ms, _hip.stream_ptr())
+
+
+@torch.no_grad()
+def queue_write_pixels(keys, src_img, src_pos, dst_cls, dst_row, pixel_queue):
+    B, D = keys.shape[:2]
+    Pk = keys.shape[2] * keys.shape[3]
+    K, ms, _ = pixel_queue.shape
+    _hip.call("cseg_queue_write_pixels", _p(keys, F32, "keys"), B, D, Pk, _p(src_img, I32, "src_img"),
+              _p(src_pos, I32, "src_pos"), _p(dst_cls, I32, "dst_cls"), _p(dst_row, I32, "dst_row"),
+              src_img.numel(), _p(pixel_queue, F32, "pixel_queue"), ms, _hip.stream_ptr())

@@ -1,0 +1,83 @@
+"""Host half of hard-anchor sampling.
+
+The device (cseg_classify_partition) produces per-(image, class) hard/easy counts and the stable partition of
+pixel indices; this module turns the counts into the selection the reference makes at
+lib/loss/loss_contrast.py:35-87, consuming the CPU default generator with `torch.randperm` in exactly the
+reference's order (hard then easy, per class ascending, per image; called even for n = 0) so that the mined
+indices are bit-identical under the same `torch.manual_seed`.
+
+Pure host integer logic: runs on CPU tensors, no kernels, shared by the single-GPU and the cross-rank paths."""
+import numpy as np
+import torch
+
+
+class NeverTouched(Exception):
+    """The reference raises a bare Exception here ('this shoud be never touched', loss_contrast.py:75-77)."""
+
+
+class SelectionPlan(object):
+    """Rows are in the contrast (view-major) order: row r = v * T + a (loss_contrast.py:98)."""
+    __slots__ = ("T", "n_view", "seg_img", "seg_cls", "row_img", "row_off", "row_lab")
+
+    def __init__(self, T, n_view, seg_img, seg_cls, row_img, row_off, row_lab):
+        self.T, self.n_view = T, n_view
+        self.seg_img, self.seg_cls = seg_img, seg_cls      # [T]
+        self.row_img, self.row_off, self.row_lab = row_img, row_off, row_lab   # [N] int32 numpy
+
+    @property
+    def N(self):
+        return self.T * self.n_view
+
+
+def keep_rule(num_hard, num_easy, n_view):
+    """loss_contrast.py:66-77."""
+    if num_hard >= n_view / 2 and num_easy >= n_view / 2:
+        kh = n_view // 2
+        ke = n_view - kh
+    elif num_hard >= n_view / 2:
+        ke = num_easy
+        kh = n_view - ke
+    elif num_easy >= n_view / 2:
+        kh = num_hard
+        ke = n_view - kh
+    else:
+        raise NeverTouched("this shoud be never touched! {} {} {}".format(num_hard, num_easy, n_view))
+    return kh, ke
+
+
+def plan_selection(counts, max_samples, max_views):
+    """counts: CPU int tensor/array [B, K, 2] (hard, easy) for ALL images of the contrast set, image-major.
+    Returns a SelectionPlan, or None when no class qualifies (reference returns (None, None), :44-45).
+    row_off[r] is the position inside image row_img[r]'s slice of part_idx."""
+    cnt = np.asarray(counts, dtype=np.int64)
+    B, K, _ = cnt.shape
+    tot = cnt.sum(-1)
+    qual = tot > max_views                                   # :39
+    T = int(qual.sum())
+    if T == 0:
+        return None
+    n_view = min(max_samples // T, max_views)                # :47-48
+    if n_view <= 0:
+        raise RuntimeError("anchor sampling: {} qualifying (image, class) segments exceed max_samples={}; the "
+                           "reference fails on the empty view axis too".format(T, max_samples))
+    flat = cnt.reshape(B, 2 * K)
+    off = np.cumsum(flat, axis=1) - flat                     # exclusive offsets inside each image's partition
+    seg_img = np.empty(T, dtype=np.int32)
+    seg_cls = np.empty(T, dtype=np.int32)
+    sel = np.empty((T, n_view), dtype=np.int64)
+    a = 0
+    for b in range(B):
+        for c in np.nonzero(qual[b])[0]:
+            nh, ne = int(cnt[b, c, 0]), int(cnt[b, c, 1])
+            kh, ke = keep_rule(nh, ne, n_view)
+            perm_h = torch.randperm(nh).numpy()              # :79  (CPU default generator)
+            perm_e = torch.randperm(ne).numpy()              # :81
+            sel[a, :kh] = off[b, 2 * c] + perm_h[:kh]
+            sel[a, kh:] = off[b, 2 * c + 1] + perm_e[:ke]
+            seg_img[a] = b
+            seg_cls[a] = c
+            a += 1
+    row_off = np.ascontiguousarray(sel.T).reshape(-1).astype(np.int32)     # view-major
+    row_img = np.tile(seg_img, n_view)
+    row_lab = np.tile(seg_cls, n_view)
+    return SelectionPlan(T, n_view, seg_img, seg_cls, row_img, row_off, row_lab)

@@ -1,0 +1,207 @@
+"""PixelContrastLoss / ContrastCELoss / ContrastAuxCELoss with the reference's constructor and forward contracts
+(lib/loss/loss_contrast.py:15-234), computed by the HIP kernels of libcseg_hip.so:
+
+  reference step (loss_contrast.py)                       here
+  ------------------------------------------------------  --------------------------------------------------
+  :180-181 F.interpolate(seg) + FSCELoss                  cseg_upsample_ce_fwd/bwd (no [B,K,H,W] tensor)
+  :183 torch.max(seg,1); :131-134 nearest label resize;   cseg_classify_partition (one pass over seg, stable
+  :35-64 unique / nonzero per (image,class)               hard/easy partition in .nonzero() order)
+  :66-82 keep rule + torch.randperm                       anchor_sampling.plan_selection (host, same CPU RNG
+                                                          stream => bit-identical indices)
+  :141-142 NHWC copy, :85-87 gather                       cseg_gather_anchors straight from NCHW
+  :91-128 _contrastive                                    cseg_contrast_fwd/bwd (fp32 MFMA)
+
+Data-parallel (one process per GPU, RCCL): with `contrast.cross_rank` (default on when world_size > 1) the
+contrast set is the union of every rank's anchors: counts are all-gathered so all ranks derive the same global
+selection from the same RNG stream, each rank gathers its own rows, rows are all-gathered, and every rank
+evaluates the global loss while back-propagating only into its own embeddings (gradient scaled by world_size so
+that DDP's gradient averaging reproduces the single-process gradient of the global loss)."""
+from abc import ABC
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from contrastiveseg_amd import kernels as K
+from contrastiveseg_amd.lib.loss.anchor_sampling import plan_selection
+from contrastiveseg_amd.lib.loss.loss_helper import FSAuxCELoss, FSCELoss
+from contrastiveseg_amd.lib.utils import distributed as D
+from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
+
+
+class _GradScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.s, None
+
+
+def _counts_to_host(cp):
+    """One D2H copy (the only host sync of the loss): counts + status."""
+    flat = torch.cat([cp["counts"].reshape(-1), cp["status"]]).cpu()
+    counts = flat[:-4].reshape(cp["counts"].shape).numpy()
+    if int(flat[-4]) != 0:
+        raise RuntimeError("PixelContrastLoss: %d label values are neither ignore_label nor in [0, num_classes); "
+                           "the HIP mining kernel handles classes 0..K-1 only" % int(flat[-4]))
+    return counts
+
+
+class PixelContrastLoss(nn.Module, ABC):
+    def __init__(self, configer):
+        super(PixelContrastLoss, self).__init__()
+        self.configer = configer
+        self.temperature = self.configer.get('contrast', 'temperature')
+        self.base_temperature = self.configer.get('contrast', 'base_temperature')
+        self.ignore_label = -1
+        if self.configer.exists('loss', 'params') and 'ce_ignore_index' in self.configer.get('loss', 'params'):
+            self.ignore_label = self.configer.get('loss', 'params')['ce_ignore_index']
+        self.max_samples = self.configer.get('contrast', 'max_samples')
+        self.max_views = self.configer.get('contrast', 'max_views')
+        self.cross_rank = True
+        if self.configer.exists('contrast', 'cross_rank'):
+            self.cross_rank = bool(self.configer.get('contrast', 'cross_rank'))
+        self.last_selection = None   # {'sel_pix': i32 [N] (b*P+pixel, view-major), 'plan': SelectionPlan}
+
+    # -- mining ------------------------------------------------------------------------------------------
+    def _mine(self, feats, labels, predict, seg):
+        B, Dm, h, w = feats.shape
+        if seg is not None:
+            cp = K.classify_partition(labels, self.ignore_label, seg=seg)
+        else:
+            cp = K.classify_partition(labels, self.ignore_label, predict=predict.contiguous(),
+                                      num_classes=self.configer.get('data', 'num_classes'), feat_hw=(h, w))
+        return cp
+
+    def _plan(self, counts):
+        plan = plan_selection(counts, self.max_samples, self.max_views)
+        if plan is None:
+            # the reference returns (None, None) and then fails on None.shape (loss_contrast.py:44-45, :92)
+            raise RuntimeError("PixelContrastLoss: no (image, class) segment has more than max_views=%d pixels"
+                               % self.max_views)
+        return plan
+
+    # -- forward -----------------------------------------------------------------------------------------
+    def forward(self, feats, labels=None, predict=None, seg=None):
+        """feats [B,D,h,w] (L2-normalised embeddings), labels [B,H,W] long, and either `predict` [B,h,w] long
+        (reference signature, loss_contrast.py:130) or `seg` [B,K,h,w] logits (argmax fused into the mining
+        kernel)."""
+        assert labels is not None and (predict is not None or seg is not None)
+        B, Dm, h, w = feats.shape
+        P = h * w
+        cp = self._mine(feats, labels, predict, seg)
+        world = D.get_world_size()
+        if world > 1 and self.cross_rank:
+            return self._forward_cross_rank(feats, cp, P, world)
+        plan = self._plan(_counts_to_host(cp))
+        dev = feats.device
+        sel_pos = torch.from_numpy(plan.row_img.astype(np.int32) * P + plan.row_off).to(dev, non_blocking=True)
+        a_lab = torch.from_numpy(plan.row_lab.astype(np.int32)).to(dev, non_blocking=True)
+        loss, sel_pix = K.PixelContrast.apply(feats, cp["part_idx"], sel_pos, a_lab, "self", self.temperature,
+                                              self.base_temperature, None, None)
+        self.last_selection = {"sel_pix": sel_pix, "plan": plan}
+        return loss
+
+    def _forward_cross_rank(self, feats, cp, P, world):
+        import torch.distributed as dist
+        rank = D.get_rank()
+        B = feats.shape[0]
+        dev = feats.device
+        local = torch.cat([cp["counts"].reshape(-1), cp["status"]])
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)                       # RCCL, B*K*2+4 ints per rank
+        host = torch.stack(gathered).cpu()
+        if int(host[:, -4].sum()) != 0:
+            raise RuntimeError("PixelContrastLoss: labels outside [0, num_classes) on some rank")
+        counts = host[:, :-4].reshape((world * B,) + tuple(cp["counts"].shape[1:])).numpy()
+        plan = self._plan(counts)                               # identical on every rank (same seed, same counts)
+        T, V = plan.T, plan.n_view
+        owner = plan.seg_img // B                               # rank of every segment
+        mine = np.nonzero(owner == rank)[0]
+        t_r = [int((owner == r).sum()) for r in range(world)]
+        # local rows, view-major inside this rank's segment range
+        rows_local = (np.arange(V)[:, None] * T + mine[None, :]).reshape(-1)
+        sel_pos = torch.from_numpy(((plan.row_img[rows_local] - rank * B) * P + plan.row_off[rows_local])
+                                   .astype(np.int32)).to(dev)
+        anchors_l, sel_pix = K.GatherAnchors.apply(feats, cp["part_idx"], sel_pos)
+        t_max = max(t_r)
+        pad = torch.zeros(t_max * V, feats.shape[1], dtype=feats.dtype, device=dev)
+        pad[:anchors_l.shape[0]] = anchors_l.detach()
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad)                              # RCCL, <= max_samples x D floats in total
+        pieces = []
+        order = np.empty(T * V, dtype=np.int64)                 # global row -> position in cat(pieces)
+        base = 0
+        for r in range(world):
+            n_r = t_r[r] * V
+            pieces.append(_GradScale.apply(anchors_l, float(world)) if r == rank else bufs[r][:n_r])
+            seg_r = np.nonzero(owner == r)[0]
+            glob_rows = (np.arange(V)[:, None] * T + seg_r[None, :]).reshape(-1)
+            order[glob_rows] = base + np.arange(n_r)
+            base += n_r
+        allrows = torch.cat(pieces, dim=0)
+        anchors_g = allrows.index_select(0, torch.from_numpy(order).to(dev))
+        a_lab = torch.from_numpy(plan.row_lab.astype(np.int32)).to(dev)
+        loss = K.ContrastOnAnchors.apply(anchors_g, a_lab, "self", self.temperature, self.base_temperature,
+                                         None, None, None, None)
+        self.last_selection = {"sel_pix": sel_pix, "plan": plan, "rows_local": rows_local}
+        return loss
+
+
+class ContrastCELoss(nn.Module, ABC):
+    def __init__(self, configer=None):
+        super(ContrastCELoss, self).__init__()
+        self.configer = configer
+        ignore_index = -1
+        if self.configer.exists('loss', 'params') and 'ce_ignore_index' in self.configer.get('loss', 'params'):
+            ignore_index = self.configer.get('loss', 'params')['ce_ignore_index']
+        Log.info('ignore_index: {}'.format(ignore_index))
+        self.loss_weight = self.configer.get('contrast', 'loss_weight')
+        self.use_rmi = self.configer.get('contrast', 'use_rmi')
+        if self.use_rmi:
+            raise NotImplementedError("contrast.use_rmi: the RMI criterion is outside the accelerated hot path")
+        self.seg_criterion = FSCELoss(configer=configer)
+        self.contrast_criterion = PixelContrastLoss(configer=configer)
+
+    def forward(self, preds, target, with_embed=False):
+        assert "seg" in preds
+        assert "embed" in preds
+        seg = preds['seg']
+        embedding = preds['embed']
+        loss = self.seg_criterion(seg, target)                       # upsample fused into the CE kernel
+        loss_contrast = self.contrast_criterion(embedding, target, seg=seg)
+        if with_embed is True:
+            return loss + self.loss_weight * loss_contrast
+        return loss + 0 * loss_contrast  # same trick as the reference: keeps every parameter in the DDP graph
+
+
+class ContrastAuxCELoss(nn.Module, ABC):
+    def __init__(self, configer=None):
+        super(ContrastAuxCELoss, self).__init__()
+        self.configer = configer
+        ignore_index = -1
+        if self.configer.exists('loss', 'params') and 'ce_ignore_index' in self.configer.get('loss', 'params'):
+            ignore_index = self.configer.get('loss', 'params')['ce_ignore_index']
+        Log.info('ignore_index: {}'.format(ignore_index))
+        self.loss_weight = self.configer.get('contrast', 'loss_weight')
+        self.use_rmi = self.configer.get('contrast', 'use_rmi')
+        if self.use_rmi:
+            raise NotImplementedError("contrast.use_rmi: the RMI criterion is outside the accelerated hot path")
+        self.seg_criterion = FSAuxCELoss(configer=configer)
+        self.contrast_criterion = PixelContrastLoss(configer=configer)
+
+    def forward(self, preds, target, with_embed=False):
+        assert "seg" in preds
+        assert "seg_aux" in preds
+        assert "embed" in preds
+        seg = preds['seg']
+        seg_aux = preds['seg_aux']
+        embedding = preds['embed']
+        loss = self.seg_criterion([seg_aux, seg], target)
+        loss_contrast = self.contrast_criterion(embedding, target, seg=seg)
+        if with_embed is True:
+            return loss + self.loss_weight * loss_contrast
+        return loss + 0 * loss_contrast

@@ -1,0 +1,154 @@
+/*
+ * cseg_hip.h -- C-ABI of libcseg_hip.so: the MI355X (gfx950) kernels behind the contrastive-training
+ * hot path of tfzhou/ContrastiveSeg.
+ *
+ * Convention (the reference's own native style, lib/extensions/cc_attention/src/ca.cu:188-205 and
+ * lib_cffi.cpp:24-37): every entry point is `extern "C" int f(..., stream)` returning 1 = ok, 0 = error;
+ * the caller pre-allocates every output and workspace on the device, passes plain pointers + sizes and the
+ * stream to launch on; the callee allocates nothing, owns nothing and never synchronises. After a 0 return
+ * cseg_last_error() gives a thread-local message. All floats are fp32, all indices int32 unless noted.
+ * No torch types appear here; the Python host side (contrastiveseg_amd/_hip.py) binds these with ctypes.
+ *
+ * Each entry cites the reference code (paths relative to the reference root) that it replaces.
+ */
+#ifndef CSEG_HIP_H
+#define CSEG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cseg_stream_t; /* hipStream_t */
+
+int cseg_abi_version(void);
+const char* cseg_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Anchor mining, device part.  Replaces the tensor work of
+ *   lib/loss/loss_contrast.py:131-134 (labels -> float -> nearest resize -> long),
+ *   lib/loss/loss_contrast.py:183     (torch.max(seg, 1)),
+ *   lib/loss/loss_contrast.py:35-42, 60-64 (unique / per-class nonzero of hard and easy pixels).
+ * P = h*w. Classes are 0..K-1; `ignore_label` pixels and labels outside [0,K) are dropped (the latter are
+ * counted in status[0] so the host can refuse them).
+ *   seg      [B,K,h,w] f32 (or NULL: then pred_in [B,P] i64 supplies the prediction)   target [B,H,W] i64
+ *   lab,pred [B,P] i32 (nullable)          key [B,P] i16 workspace (2*c + (pred==c), -1 = dropped)
+ *   counts   [B,K,2] i32  (hard, easy)     seg_off [B,K,2] i32 exclusive offsets inside image b's slice
+ *   part_idx [B,P] i32: for image b, part_idx[b*P + seg_off[b,c,e] + r] = r-th smallest pixel of class c,
+ *            e = 0 hard (lab==c, pred!=c), e = 1 easy (lab==c, pred==c) -- the order .nonzero() returns.
+ *   status   [4] i32: [0] = number of labels outside [0,K) that are not ignore_label.
+ * ------------------------------------------------------------------------------------------------ */
+int cseg_classify_partition(const float* seg, const int64_t* pred_in, const int64_t* target, int B, int K, int h, int w, int H, int W,
+                            int ignore_label, int32_t* lab, int32_t* pred, int16_t* key, int32_t* counts,
+                            int32_t* seg_off, int32_t* part_idx, int32_t* status, cseg_stream_t stream);
+
+/* Gather of the mined pixels.  Replaces lib/loss/loss_contrast.py:141-142 (NHWC copy of all embeddings) and
+ * :85-87 (fancy-index gather).  embed stays NCHW [B,D,P].
+ *   sel_pos [N] i32: b*P + seg_off + rank (position inside part_idx), rows already in contrast order
+ *   anchors [N,D] f32, sel_pix [N] i32 = b*P + pixel (kept for the backward scatter and for tests) */
+int cseg_gather_anchors(const float* embed, int B, int D, int P, const int32_t* part_idx,
+                        const int32_t* sel_pos, int N, float* anchors, int32_t* sel_pix, cseg_stream_t stream);
+
+/* Backward of the gather (autograd of X[ii, indices, :], loss_contrast.py:85): d_embed[b, :, pix] = scale *
+ * sum_s d_anchor_parts[s, r, :]. d_embed [B,D,P] must be zero-filled by the caller; rows of sel_pix are
+ * duplicate-free within one step, so no atomics. n_parts = cseg_contrast_bwd_parts(). */
+int cseg_scatter_anchor_grad(const float* d_anchor_parts, int n_parts, const int32_t* sel_pix, int N, int D,
+                             int P, float scale, float* d_embed, cseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Contrastive term.  Replaces PixelContrastLoss._contrastive:
+ *   self mode   lib/loss/loss_contrast.py:91-128      (contrast set = the anchors, view-major rows)
+ *   bank mode   lib/loss/loss_contrast_mem.py:91-152  (contrast set = cat(segment_queue, pixel_queue, 1)
+ *               read in place: columns are classes 1..K-1, 2*ms rows each, then 2*ms zero rows labelled 0)
+ *   plain mode  any [M,D] contrast matrix with labels (used for the cross-rank gathered set)
+ * S = A.C^T / temperature runs on the fp32 MFMA (v_mfma_f32_32x32x2_f32); row statistics, the
+ * "pair + all negatives" denominator, the column-index self mask and the mean over positives follow the
+ * reference formulas exactly (see oracle/cseg_oracle.py:_contrast_core).
+ *   anchors [N,D], a_lab [N] i32
+ *   mode 0 self : contrast/c_lab/queues ignored, M = N
+ *   mode 1 plain: contrast [M,D], c_lab [M]
+ *   mode 2 bank : segment_queue, pixel_queue [K,ms,D]; M = K*2*ms
+ *   S_ws [N,M] f32 workspace (kept for backward), row_stats [N,4] f32, row_loss [N] f32, loss [1] f32
+ * Requires N <= M (the reference's scatter_ raises otherwise) and D % 8 == 0.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int mode;               /* 0 self, 1 plain, 2 bank */
+    int N, M, D;
+    const float* anchors;   /* [N,D] */
+    const int32_t* a_lab;   /* [N] */
+    const float* contrast;  /* mode 1: [M,D] */
+    const int32_t* c_lab;   /* mode 1: [M] */
+    const float* segment_queue; /* mode 2: [K,ms,D] */
+    const float* pixel_queue;   /* mode 2: [K,ms,D] */
+    int bank_classes;       /* mode 2: K */
+    int bank_size;          /* mode 2: ms */
+    float temperature;
+    float base_temperature;
+} cseg_contrast_desc;
+
+size_t cseg_contrast_ws_bytes(int N, int M);
+int cseg_contrast_fwd(const cseg_contrast_desc* d, float* S_ws, float* row_stats, float* row_loss, float* loss,
+                      cseg_stream_t stream);
+/* d_loss [1] f32 on the device (upstream gradient). Writes d_anchor_parts [n_parts, N, D] (sum over parts =
+ * dLoss/dAnchors); in self mode this already contains both the row and the column role of every anchor. */
+int cseg_contrast_bwd_parts(int N, int M, int D);
+int cseg_contrast_bwd(const cseg_contrast_desc* d, const float* S_ws, const float* row_stats,
+                      const float* d_loss, float* d_anchor_parts, cseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * HRNet head input: bilinear(align_corners=True) upsample of the low-resolution maps to the first map's size
+ * fused with the channel concat.  Replaces lib/models/nets/hrnet.py:86-91 (3x F.interpolate + torch.cat).
+ *   n_maps <= 4; xs[i] [B,C[i],hs[i],ws[i]] NCHW; out [B,sum C,hs[0],ws[0]].
+ * ------------------------------------------------------------------------------------------------ */
+int cseg_upcat_fwd(const float* const* xs, const int* C, const int* hs, const int* ws, int n_maps, int B,
+                   float* out, cseg_stream_t stream);
+int cseg_upcat_bwd(const float* d_out, const int* C, const int* hs, const int* ws, int n_maps, int B,
+                   float* const* d_xs, cseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Segmentation term: bilinear(align_corners=True) upsample of the logits to the label size fused with the
+ * weighted cross entropy.  Replaces lib/loss/loss_contrast.py:180-181 + lib/loss/loss_helper.py:169-206
+ * (nn.CrossEntropyLoss(weight, ignore_index, reduction mean)); the [B,K,H,W] tensor is never materialised.
+ *   seg [B,K,h,w], target [B,H,W] i64, weight [K] or NULL
+ *   partial [2*n_blocks] f32 workspace, n_blocks = cseg_upsample_ce_blocks(B,H,W)
+ *   out [2] f32: out[0] = loss, out[1] = sum of weights of valid pixels; status[1] counts bad targets
+ *   bwd: d_loss [1] device scalar; d_seg [B,K,h,w] is overwritten
+ * ------------------------------------------------------------------------------------------------ */
+int cseg_upsample_ce_blocks(int B, int H, int W);
+int cseg_upsample_ce_fwd(const float* seg, const int64_t* target, const float* weight, int ignore_label, int B,
+                         int K, int h, int w, int H, int W, float* partial, float* out, int32_t* status,
+                         cseg_stream_t stream);
+int cseg_upsample_ce_bwd(const float* seg, const int64_t* target, const float* weight, int ignore_label, int B,
+                         int K, int h, int w, int H, int W, const float* out, const float* d_loss,
+                         float* d_seg, cseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Memory bank update, device part.  Replaces the tensor work of
+ * segmentor/trainer_contrastive.py:102-138 (_dequeue_and_enqueue).
+ *   cseg_queue_count:      histogram of labels[:, ::stride, ::stride] per image -> counts [B,K] i32 (labels
+ *                          outside [0,K) are skipped; the host applies the reference's `> 0` filter).
+ *   cseg_queue_class_sums: sums[b,c,:] = sum over positions q with strided label c of keys[b,:,q]; q indexes
+ *                          the strided label map and is used as a raw position into the key map exactly as the
+ *                          reference does (trainer_contrastive.py:111-120); needs Hs*Ws <= Pk.
+ *   cseg_queue_write_segments: segment_queue[job_cls, job_dst_row, :] = L2-normalise(sums[img,cls,:] / count).
+ *   cseg_queue_write_pixels:   pixel_queue[dst_cls, dst_row, :] = L2-normalise(keys[src_img, :, src_pos]).
+ *   keys [B,D,Pk] f32, labels [B,H,W] i64, queues [K,ms,D] f32. The host resolves the pointer arithmetic and
+ *   write-after-write order (later rows win) before building the job lists.
+ * ------------------------------------------------------------------------------------------------ */
+int cseg_queue_count(const int64_t* labels, int B, int H, int W, int stride, int K, int32_t* counts,
+                     cseg_stream_t stream);
+int cseg_queue_class_sums(const float* keys, const int64_t* labels, int B, int D, int Pk, int H, int W, int stride,
+                          int K, float* sums, cseg_stream_t stream);
+int cseg_queue_write_segments(const float* sums, const int32_t* counts, const int32_t* job_img,
+                              const int32_t* job_cls, const int32_t* job_dst_row, int n_jobs, int K, int D,
+                              float* segment_queue, int ms, cseg_stream_t stream);
+int cseg_queue_write_pixels(const float* keys, int B, int D, int Pk, const int32_t* src_img,
+                            const int32_t* src_pos, const int32_t* dst_cls, const int32_t* dst_row, int n_rows,
+                            float* pixel_queue, int ms, cseg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSEG_HIP_H */

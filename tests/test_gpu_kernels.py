@@ -1,0 +1,240 @@
+"""Parity tests proper: the HIP path (through the C-ABI, via contrastiveseg_amd.kernels) against
+ (a) golden vectors produced by the reference itself (tests/golden, oracle/make_golden.py),
+ (b) the CPU oracle on seeded inputs, and (c) size-independent properties at BASELINE.json's full sizes.
+Bars (BASELINE.json north_star): loss scalars within 1e-3 (asserted much tighter), mined anchor indices bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cseg_oracle as O
+from oracle.make_golden import LOSS_CASES, case_inputs
+
+pytestmark = pytest.mark.gpu
+
+LOSS_TOL = 1e-4      # relative; the contract is 1e-3
+GRAD_RTOL, GRAD_ATOL = 2e-3, 1e-6
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _configer(c):
+    from contrastiveseg_amd.lib.utils.tools.configer import Configer
+    k = dict(proj_dim=c["D"], base_temperature=0.07, use_rmi=False, use_lovasz=False, warmup_iters=0)
+    k.update(c["contrast"])
+    params = {"ce_ignore_index": -1, "ce_reduction": "elementwise_mean"}
+    if c["ce_weight"] is not None:
+        params["ce_weight"] = list(c["ce_weight"])
+    return Configer(config_dict={
+        "data": {"num_classes": c["K"]},
+        "network": {"loss_weights": {"aux_loss": 0.4, "seg_loss": 1.0}},
+        "contrast": k, "loss": {"loss_type": c["loss"], "params": params}})
+
+
+def _selection_class_major(crit, V, T):
+    sel = crit.contrast_criterion.last_selection["sel_pix"].cpu().numpy()
+    return sel.reshape(V, T).T          # [T, V] like the golden files
+
+
+@pytest.mark.parametrize("name", list(LOSS_CASES))
+def test_criterion_matches_reference_golden(name, golden_dir):
+    dev = _dev()
+    from contrastiveseg_amd.lib.loss.loss_manager import SEG_LOSS_DICT
+    c = LOSS_CASES[name]
+    g = np.load(os.path.join(golden_dir, "loss_%s.npz" % name))
+    target, seg, embed, extra = case_inputs(c)
+    crit = SEG_LOSS_DICT[c["loss"]](_configer(c)).to(dev)
+    t_seg = torch.from_numpy(seg).to(dev).requires_grad_(True)
+    t_embed = torch.from_numpy(embed).to(dev).requires_grad_(True)
+    preds = {"seg": t_seg, "embed": t_embed}
+    for k, v in extra.items():
+        preds[k] = torch.from_numpy(v).to(dev)
+        if k == "seg_aux":
+            preds[k].requires_grad_(True)
+    torch.manual_seed(c["torch_seed"])
+    total = crit(preds, torch.from_numpy(target).to(dev), with_embed=c.get("with_embed", True))
+    total.backward()
+    torch.cuda.synchronize()
+    # mined anchors: bit exact
+    T, V = len(g["anchor_cls"]), int(g["n_view"])
+    plan = crit.contrast_criterion.last_selection["plan"]
+    assert (plan.T, plan.n_view) == (T, V)
+    P = seg.shape[-2] * seg.shape[-1]
+    want = g["anchor_img"].astype(np.int64) * P + g["anchor_pix"]
+    got = _selection_class_major(crit, V, T)
+    assert np.array_equal(got, want), "mined anchor indices differ from the reference"
+    assert np.array_equal(plan.seg_cls, g["anchor_cls"])
+    # scalars
+    ref = float(g["total"])
+    assert abs(float(total.detach()) - ref) <= LOSS_TOL * max(1.0, abs(ref)), (float(total.detach()), ref)
+    if not c["grads"]:
+        return
+    # gradients
+    d_seg = t_seg.grad.cpu().numpy()
+    assert np.allclose(d_seg, g["d_seg"], rtol=GRAD_RTOL, atol=GRAD_ATOL), np.abs(d_seg - g["d_seg"]).max()
+    ge = t_embed.grad.cpu().numpy().reshape(embed.shape[0], embed.shape[1], -1)
+    img, pix = g["anchor_img"].reshape(-1), g["anchor_pix"].reshape(-1)
+    rows = ge[img, :, pix]
+    assert np.allclose(rows, g["d_embed_rows"], rtol=GRAD_RTOL, atol=GRAD_ATOL), \
+        np.abs(rows - g["d_embed_rows"]).max()
+    mask = np.ones(ge.shape, dtype=bool)
+    mask[img, :, pix] = False
+    assert not ge[mask].any()
+    if "seg_aux" in extra:
+        d_aux = preds["seg_aux"].grad.cpu().numpy()
+        assert np.allclose(d_aux, g["d_seg_aux"], rtol=GRAD_RTOL, atol=GRAD_ATOL)
+
+
+@pytest.mark.parametrize("name", ["small_self", "mid_self", "uniform_self", "odd_stride8_aux"])
+def test_classify_partition_matches_oracle(name):
+    dev = _dev()
+    from contrastiveseg_amd import kernels as K
+    c = LOSS_CASES[name]
+    target, seg, embed, _ = case_inputs(c)
+    B, Kc, h, w = seg.shape
+    cp = K.classify_partition(torch.from_numpy(target).to(dev), -1, seg=torch.from_numpy(seg).to(dev), want_maps=True)
+    lab = O.nearest_downsample_labels(target, h, w).reshape(B, -1)
+    pred = O.argmax_first(seg).reshape(B, -1)
+    assert np.array_equal(cp["lab"].cpu().numpy(), lab)
+    assert np.array_equal(cp["pred"].cpu().numpy(), pred)
+    counts = cp["counts"].cpu().numpy()
+    seg_off = cp["seg_off"].cpu().numpy()
+    part = cp["part_idx"].cpu().numpy()
+    for b in range(B):
+        off = 0
+        for cls in range(Kc):
+            hard = np.nonzero((lab[b] == cls) & (pred[b] != cls))[0]
+            easy = np.nonzero((lab[b] == cls) & (pred[b] == cls))[0]
+            assert counts[b, cls, 0] == len(hard) and counts[b, cls, 1] == len(easy)
+            assert seg_off[b, cls, 0] == off
+            assert np.array_equal(part[b, off:off + len(hard)], hard)
+            off += len(hard)
+            assert seg_off[b, cls, 1] == off
+            assert np.array_equal(part[b, off:off + len(easy)], easy)
+            off += len(easy)
+    # the predict= entry (reference signature) gives the same partition
+    cp2 = K.classify_partition(torch.from_numpy(target).to(dev), -1, predict=torch.from_numpy(pred).to(dev),
+                               num_classes=Kc, feat_hw=(h, w))
+    assert torch.equal(cp2["counts"], cp["counts"])
+    part2 = cp2["part_idx"].cpu().numpy()
+    for b in range(B):
+        n_valid = int(counts[b].sum())          # entries past the last class are unspecified (dropped pixels)
+        assert np.array_equal(part2[b, :n_valid], part[b, :n_valid])
+
+
+def _rand_unit(rs, n, d):
+    x = rs.standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("T,V,D,K", [(10, 6, 16, 5), (94, 10, 256, 19), (152, 6, 256, 19), (57, 17, 32, 19),
+                                     (8, 128, 256, 4)])
+def test_contrast_self_matches_oracle(T, V, D, K):
+    dev = _dev()
+    from contrastiveseg_amd import kernels as Kk
+    rs = np.random.RandomState(T * 1000 + V)
+    X = _rand_unit(rs, T * V, D).reshape(T, V, D)
+    y = rs.randint(0, K, size=T)
+    y[:2] = [0, 0]                                   # at least one class with positives in other segments
+    want, dX = O.contrastive_self(X, y, 0.1, 0.07, return_grad=True)
+    A = torch.from_numpy(np.ascontiguousarray(X.transpose(1, 0, 2)).reshape(T * V, D)).to(dev).requires_grad_(True)
+    lab = torch.from_numpy(np.tile(y, V).astype(np.int32)).to(dev)
+    loss = Kk.ContrastOnAnchors.apply(A, lab, "self", 0.1, 0.07, None, None, None, None)
+    (loss * 0.37).backward()
+    assert abs(float(loss) - want) <= 2e-5 * max(1.0, abs(want)), (float(loss), want)
+    got = A.grad.cpu().numpy().reshape(V, T, D).transpose(1, 0, 2) / 0.37
+    assert np.allclose(got, dX, rtol=2e-3, atol=1e-7), np.abs(got - dX).max()
+
+
+@pytest.mark.parametrize("N,Kc,ms,D", [(38, 19, 12, 64), (30, 6, 20, 32), (152, 19, 108, 256)])
+def test_contrast_bank_matches_oracle(N, Kc, ms, D):
+    dev = _dev()
+    from contrastiveseg_amd import kernels as Kk
+    rs = np.random.RandomState(N + ms)
+    X = _rand_unit(rs, N, D).reshape(N, 1, D)
+    y = rs.randint(0, Kc, size=N)
+    sq = _rand_unit(rs, Kc * ms, D).reshape(Kc, ms, D)
+    pq = _rand_unit(rs, Kc * ms, D).reshape(Kc, ms, D)
+    want, dX = O.contrastive_mem(X, y, np.concatenate([sq, pq], axis=1), 0.07, 0.07, return_grad=True)
+    A = torch.from_numpy(X.reshape(N, D)).to(dev).requires_grad_(True)
+    loss = Kk.ContrastOnAnchors.apply(A, torch.from_numpy(y.astype(np.int32)).to(dev), "bank", 0.07, 0.07, None, None,
+                                      torch.from_numpy(sq).to(dev), torch.from_numpy(pq).to(dev))
+    loss.backward()
+    assert abs(float(loss) - want) <= 2e-5 * max(1.0, abs(want)), (float(loss), want)
+    assert np.allclose(A.grad.cpu().numpy(), dX.reshape(N, D), rtol=2e-3, atol=1e-7)
+
+
+def test_contrast_headline_shape_properties():
+    """BASELINE.json sizes: 1024 anchors x 4096-entry bank, D=256. Oracle parity on the scalar + properties:
+    invariance to a permutation of bank slots inside a class, and plain mode == bank mode on the packed copy."""
+    dev = _dev()
+    from contrastiveseg_amd import kernels as Kk
+    rs = np.random.RandomState(5)
+    N, Kc, ms, D = 1024, 19, 108, 256
+    A = torch.from_numpy(_rand_unit(rs, N, D)).to(dev)
+    y = torch.from_numpy(rs.randint(0, Kc, size=N).astype(np.int32)).to(dev)
+    sq = torch.from_numpy(_rand_unit(rs, Kc * ms, D).reshape(Kc, ms, D)).to(dev)
+    pq = torch.from_numpy(_rand_unit(rs, Kc * ms, D).reshape(Kc, ms, D)).to(dev)
+    l_bank = Kk.ContrastOnAnchors.apply(A, y, "bank", 0.1, 0.07, None, None, sq, pq)
+    Xp, yp = O.sample_negative(np.concatenate([sq.cpu().numpy(), pq.cpu().numpy()], axis=1))
+    l_plain = Kk.ContrastOnAnchors.apply(A, y, "plain", 0.1, 0.07, torch.from_numpy(Xp.astype(np.float32)).to(dev),
+                                         torch.from_numpy(yp.astype(np.int32)).to(dev), None, None)
+    assert abs(float(l_bank) - float(l_plain)) < 1e-6 * abs(float(l_plain))
+    want = O.contrastive_mem(A.cpu().numpy().reshape(N, 1, D), y.cpu().numpy(),
+                             np.concatenate([sq.cpu().numpy(), pq.cpu().numpy()], axis=1), 0.1, 0.07)
+    assert abs(float(l_bank) - want) <= 2e-5 * abs(want)
+
+
+def test_upsample_concat_matches_torch():
+    dev = _dev()
+    import torch.nn.functional as F
+    from contrastiveseg_amd import kernels as Kk
+    torch.manual_seed(0)
+    shapes = [(2, 6, 16, 32), (2, 12, 8, 16), (2, 5, 4, 8), (2, 7, 2, 4)]
+    for shp in (shapes, [(1, 3, 13, 21), (1, 4, 7, 11), (1, 2, 3, 5)]):
+        xs = [torch.randn(*s, device=dev, requires_grad=True) for s in shp]
+        out = Kk.upsample_concat(xs)
+        h, w = shp[0][2:]
+        ref = torch.cat([xs[0]] + [F.interpolate(x, size=(h, w), mode="bilinear", align_corners=True) for x in xs[1:]], 1)
+        assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
+        g = torch.randn_like(out)
+        got = torch.autograd.grad(out, xs, g)
+        want = torch.autograd.grad(ref, xs, g)
+        for a, b in zip(got, want):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), (a - b).abs().max()
+        o = O.upcat([x.detach().cpu().numpy() for x in xs])
+        assert np.allclose(out.detach().cpu().numpy(), o, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,Kc,h,w,H,W,weighted", [(2, 5, 16, 32, 64, 128, True), (2, 19, 13, 21, 97, 161, False),
+                                                   (1, 171, 17, 9, 65, 33, True), (2, 7, 24, 40, 24, 40, True)])
+def test_upsample_ce_matches_torch_and_oracle(B, Kc, h, w, H, W, weighted):
+    dev = _dev()
+    import torch.nn.functional as F
+    from contrastiveseg_amd import kernels as Kk
+    rs = np.random.RandomState(H + Kc)
+    seg = torch.from_numpy(rs.standard_normal((B, Kc, h, w)).astype(np.float32) * 3).to(dev).requires_grad_(True)
+    target = torch.from_numpy(rs.randint(-1, Kc, size=(B, H, W)).astype(np.int64)).to(dev)
+    wt = torch.from_numpy((rs.rand(Kc) + 0.5).astype(np.float32)).to(dev) if weighted else None
+    loss = Kk.upsample_ce(seg, target, wt, -1)
+    (g_mine,) = torch.autograd.grad(loss * 1.7, seg)
+    up = F.interpolate(seg, size=(H, W), mode="bilinear", align_corners=True)
+    ref = F.cross_entropy(up, target, weight=wt, ignore_index=-1)
+    (g_ref,) = torch.autograd.grad(ref * 1.7, seg)
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert torch.allclose(g_mine, g_ref, rtol=1e-3, atol=1e-7), (g_mine - g_ref).abs().max()
+    want = O.upsample_ce(seg.detach().cpu().numpy(), target.cpu().numpy(),
+                         None if wt is None else wt.cpu().numpy(), -1)
+    assert abs(float(loss) - want) <= 1e-5 * max(1.0, abs(want))
+
+
+def test_missing_gpu_tensor_is_refused():
+    _dev()
+    from contrastiveseg_amd import kernels as Kk
+    with pytest.raises(RuntimeError):
+        Kk.upsample_ce(torch.zeros(1, 3, 4, 4), torch.zeros(1, 8, 8, dtype=torch.long))
