@@ -1,0 +1,283 @@
+"""bench.py -- contrastive train-step throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = one full contrastive training iteration of `configs/cityscapes/H_48_D_4.json` (BASELINE.json configs[1]:
+HRNet-W48 + contrast_ce_loss, synthetic Cityscapes 3x512x1024, 19 classes, per-GPU batch 8, fp32, tau 0.1,
+max_samples 1024, with_embed on): forward + criterion (HIP kernels) + backward + RCCL gradient all-reduce + SGD, on a
+batch that is already resident in HBM. W untimed warm-up steps, then exactly K timed steps bracketed by
+barrier + synchronize; time = MAX over ranks; rank 0 prints ONE JSON line.
+
+Besides the contract fields the line carries
+  roofline      whole-step view of the dominant work (dense conv contraction on MIOpen, MFMA-bound in fp32):
+                achieved = images/s x 2.0759 TFLOP/image (counted on the reference)
+                against the fp32 MFMA peak of the N GPUs; step time from HIP events on the compute stream.
+  kernels       per hand-written HIP kernel at this workload's shapes: HIP-event time, algorithmic bytes / flops
+                 and fraction of its own roofline.
+  cpu_baseline  N=1, rank 0 only: CPU port of the same train step (same model classes, oracle/cpu_port.py device
+                half) timed on this box's host cores on a bounded sample (1 image of 3x512x1024, 1 warm-up + 1 step).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TFLOP_PER_IMAGE = 2.0759          # fwd + loss + bwd, HRNet-W48-contrast @ 3x512x1024
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                   help="weak: per-GPU batch 8 (global 8N); strong: global batch 8 split over the ranks")
+    p.add_argument("--config", default=os.path.join(ROOT, "configs", "cityscapes", "H_48_D_4.json"))
+    p.add_argument("--per-gpu-batch", type=int, default=8)
+    p.add_argument("--miopen-find", type=int, default=1, help="cudnn.benchmark (MIOpen find mode) on/off")
+    p.add_argument("--channels-last", type=int, default=0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-kernels", action="store_true")
+    p.add_argument("--labels", choices=["uniform", "blocky"], default="uniform")
+    return p.parse_args()
+
+
+def build_trainer(args, world, device):
+    from contrastiveseg_amd.lib.utils.tools.configer import Configer
+    from contrastiveseg_amd.segmentor.tools.data_helper import SyntheticLoader
+    from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
+    cfg = Configer(configs=args.config)
+    global_batch = args.per_gpu_batch * world if args.scaling == "weak" else args.per_gpu_batch
+    assert global_batch % world == 0, "global batch %d not divisible by %d ranks" % (global_batch, world)
+    cfg.update(["train", "batch_size"], global_batch)
+    cfg.update(["contrast", "warmup_iters"], 0)
+    cfg.update(["solver", "max_iters"], 10 ** 9)
+    cfg.update(["solver", "display_iter"], 10 ** 9)
+    cfg.add(["network", "pretrained"], None)
+    cfg.add(["network", "resume"], None)
+    cfg.add(["network", "channels_last"], bool(args.channels_last))
+    torch.manual_seed(304)
+    tr = Trainer(cfg, train_loader=[])
+    loader = SyntheticLoader(cfg, device, length=1, seed=304, mode=args.labels, fixed=True)
+    tr.seg_net.train()
+    tr.pixel_loss.train()
+    return tr, cfg, next(iter(loader)), global_batch
+
+
+def time_kernel(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters      # us
+
+
+def kernel_rooflines(device, B, K=19, H=512, W=1024, stride=4, D=256):
+    """HIP-event timings of the hand-written kernels at the workload's shapes; algorithmic bytes per DESIGN.md."""
+    from contrastiveseg_amd import kernels as Kn
+    from contrastiveseg_amd.lib.loss.anchor_sampling import plan_selection
+    h, w = H // stride, W // stride
+    P = h * w
+    g = torch.Generator(device="cpu").manual_seed(1)
+    seg = torch.randn(B, K, h, w, generator=g).to(device)
+    target = torch.randint(-1, K, (B, H, W), generator=g).to(device)
+    embed = torch.nn.functional.normalize(torch.randn(B, D, h, w, generator=g), dim=1).to(device)
+    out = {}
+
+    def entry(name, us, bytes_=None, flops=None):
+        e = {"us": round(us, 2)}
+        if bytes_ is not None:
+            gbs = bytes_ / us * 1e-3
+            e.update(bound="hbm", bytes=int(bytes_), achieved_GBs=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBS, 4))
+        if flops is not None:
+            tf = flops / us * 1e-6
+            e.update(bound="mfma", flops=int(flops), achieved_TFLOPs=round(tf, 2),
+                     frac=round(tf / PEAK_FP32_MFMA_TFLOPS, 4))
+        out[name] = e
+
+    # mining: seg + strided labels in, key/part_idx/counts out
+    us = time_kernel(lambda: Kn.classify_partition(target, -1, seg=seg))
+    entry("classify_partition", us, bytes_=B * K * P * 4 + B * P * 8 + B * P * (2 + 4))
+    cp = Kn.classify_partition(target, -1, seg=seg)
+    plan = plan_selection(cp["counts"].cpu().numpy(), 1024, 100)
+    sel_pos = torch.from_numpy(plan.row_img * P + plan.row_off).to(device)
+    a_lab = torch.from_numpy(plan.row_lab).to(device)
+    N = plan.N
+    emb = embed.clone().requires_grad_(True)
+
+    def contrast_fwd():
+        return Kn.PixelContrast.apply(emb, cp["part_idx"], sel_pos, a_lab, "self", 0.1, 0.07, None, None)[0]
+    us_f = time_kernel(contrast_fwd)
+    loss = contrast_fwd()
+    us_fb = time_kernel(lambda: torch.autograd.grad(contrast_fwd(), emb))
+    entry("contrast_self_fwd(gather+S+rows+mean) N=%d" % N, us_f, flops=2.0 * N * N * D)
+    entry("contrast_self_fwd+bwd(+scatter,+268MB memset) N=%d" % N, us_fb, flops=2.0 * N * N * D * 2)
+    # headline bank shape: 1024 anchors x 4096-entry bank (4104 with the class-0 quirk)
+    A = torch.nn.functional.normalize(torch.randn(1024, D, generator=g), dim=1).to(device).requires_grad_(True)
+    yl = torch.randint(0, K, (1024,), generator=g).int().to(device)
+    sq = torch.nn.functional.normalize(torch.randn(K, 108, D, generator=g), dim=2).to(device)
+    pq = torch.nn.functional.normalize(torch.randn(K, 108, D, generator=g), dim=2).to(device)
+
+    def bank():
+        return Kn.ContrastOnAnchors.apply(A, yl, "bank", 0.1, 0.07, None, None, sq, pq)
+    entry("contrast_bank_fwd 1024x4104", time_kernel(bank), flops=2.0 * 1024 * 4104 * D)
+    entry("contrast_bank_fwd+bwd 1024x4104", time_kernel(lambda: torch.autograd.grad(bank(), A)),
+          flops=2.0 * 1024 * 4104 * D * 2)
+    # HRNet head input
+    chans = [48, 96, 192, 384]
+    feats = [torch.randn(B, c, h >> i, w >> i, generator=g).to(device).requires_grad_(True)
+             for i, c in enumerate(chans)]
+    in_b = sum(f.numel() for f in feats) * 4
+    out_b = B * sum(chans) * P * 4
+    entry("upcat_fwd", time_kernel(lambda: Kn.upsample_concat(feats)), bytes_=in_b + out_b)
+    o = Kn.upsample_concat(feats)
+    go = torch.randn_like(o)
+    entry("upcat_bwd", time_kernel(lambda: torch.autograd.grad(o, feats, go, retain_graph=True)), bytes_=in_b + out_b)
+    del o, go, feats
+    # segmentation term
+    wt = torch.ones(K, device=device)
+    sg = seg.clone().requires_grad_(True)
+    entry("upsample_ce_fwd", time_kernel(lambda: Kn.upsample_ce(sg, target, wt, -1)),
+          bytes_=B * K * P * 4 + B * H * W * 8)
+    l = Kn.upsample_ce(sg, target, wt, -1)
+    entry("upsample_ce_bwd", time_kernel(lambda: torch.autograd.grad(l, sg, retain_graph=True)),
+          bytes_=2 * B * K * P * 4 + B * H * W * 8)
+    return out
+
+
+def cpu_baseline():
+    """CPU port of the train step (model classes of this repo on CPU, device half = oracle/cpu_port.py)."""
+    from oracle import cpu_port
+    from contrastiveseg_amd.lib.utils.tools.configer import Configer
+    from contrastiveseg_amd.segmentor.tools.data_helper import SyntheticLoader
+    from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    restore = cpu_port.install(None)
+    try:
+        cfg = Configer(configs=os.path.join(ROOT, "configs", "cityscapes", "H_48_D_4.json"))
+        cfg.update(["train", "batch_size"], 1)
+        cfg.update(["contrast", "warmup_iters"], 0)
+        cfg.update(["solver", "max_iters"], 10 ** 9)
+        cfg.add(["network", "pretrained"], None)
+        cfg.add(["network", "resume"], None)
+        cfg.add(["gpu"], None)
+        cfg.update(["network", "bn_type"], "torchbn")
+        torch.manual_seed(304)
+        tr = Trainer(cfg, train_loader=[])
+        tr.seg_net.cpu().train()
+        tr.pixel_loss.cpu()
+        tr.module_runner.device = lambda: torch.device("cpu")
+        batch = next(iter(SyntheticLoader(cfg, torch.device("cpu"), length=1, seed=304, mode="uniform")))
+        tr.train_step(batch)                       # warm-up
+        t0 = time.time()
+        n = 1
+        for _ in range(n):
+            tr.train_step(batch)
+        dt = (time.time() - t0) / n
+    finally:
+        restore()
+    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "1 image 3x512x1024, fwd+criterion+bwd+SGD, 1 warm-up + %d timed step(s), fp32, %.2f s/step" % (n, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", init_method="env://")
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+
+    tr, cfg, batch, global_batch = build_trainer(args, world, device)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        tr.train_step(batch)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        loss = tr.train_step(batch)
+    e1.record()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        t = torch.tensor([dt, ev_ms], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt, ev_ms = float(t[0]), float(t[1])
+    final_loss = float(loss)
+
+    kernels = None
+    if rank == 0 and not args.no_kernels:
+        try:
+            kernels = kernel_rooflines(device, args.per_gpu_batch)
+        except Exception as e:            # never lose the headline number to a micro-benchmark problem
+            kernels = {"error": repr(e)}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline()
+        except Exception as e:
+            cpu = {"error": repr(e)}
+    if world > 1:
+        torch.distributed.barrier()
+
+    if rank == 0:
+        ips = global_batch * args.steps / dt
+        ips_ev = global_batch * args.steps / (ev_ms * 1e-3)
+        achieved = ips_ev * TFLOP_PER_IMAGE
+        peak = PEAK_FP32_MFMA_TFLOPS * world
+        line = {
+            "metric": "images/sec contrastive train step, HRNet-W48 1024x512 bs8",
+            "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: HRNet-W48 + contrast_ce_loss, synthetic Cityscapes "
+                                   "3x512x1024x19, tau=0.1, max_samples=1024, with_embed=True, SGD(0.01,0.9,5e-4)",
+                       "model": "hrnet_w48_contrast", "loss": "contrast_ce_loss", "global_batch": global_batch,
+                       "per_gpu_batch": global_batch // world, "input": [3, 512, 1024], "labels": args.labels,
+                       "parallelism": "dp%d" % world, "miopen_find": bool(args.miopen_find),
+                       "channels_last": bool(args.channels_last), "final_loss": round(final_loss, 5)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "note": "whole step: images/s (HIP-event time %.1f ms/step) x %.4f TFLOP/image vs fp32 MFMA "
+                                 "peak; per-kernel rooflines of the hand-written HIP kernels under 'kernels'"
+                                 % (ev_ms / args.steps, TFLOP_PER_IMAGE)},
+            "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,8 @@ Data-parallel (one process per GPU, RCCL): with `contrast.cross_rank` (default o
 contrast set is the union of every rank's anchors: counts are all-gathered so all ranks derive the same global
 selection from the same RNG stream, each rank gathers its own rows, rows are all-gathered, and every rank
 evaluates the global loss while back-propagating only into its own embeddings (gradient scaled by world_size so
-that DDP's gradient averaging reproduces the single-process gradient of the global loss)."""
+that DDP's gradient averaging reproduces the single-process gradient of the global loss). The anchor budget of the
+global set is max_samples * world_size by default (`contrast.cross_rank_budget`: 'per_rank' | 'global')."""
 from abc import ABC
 
 import numpy as np
@@ -64,6 +65,13 @@ class PixelContrastLoss(nn.Module, ABC):
         self.cross_rank = True
         if self.configer.exists('contrast', 'cross_rank'):
             self.cross_rank = bool(self.configer.get('contrast', 'cross_rank'))
+        # anchor budget of the cross-rank set: 'per_rank' = max_samples * world_size anchors in total (every rank of
+        # the reference's DDP run owns a max_samples budget), 'global' = max_samples in total (parity with a
+        # single process that sees the concatenated global batch).
+        self.cross_rank_budget = 'per_rank'
+        if self.configer.exists('contrast', 'cross_rank_budget'):
+            self.cross_rank_budget = self.configer.get('contrast', 'cross_rank_budget')
+        assert self.cross_rank_budget in ('per_rank', 'global')
         self.last_selection = None   # {'sel_pix': i32 [N] (b*P+pixel, view-major), 'plan': SelectionPlan}
 
     # -- mining ------------------------------------------------------------------------------------------
@@ -76,8 +84,8 @@ class PixelContrastLoss(nn.Module, ABC):
                                       num_classes=self.configer.get('data', 'num_classes'), feat_hw=(h, w))
         return cp
 
-    def _plan(self, counts):
-        plan = plan_selection(counts, self.max_samples, self.max_views)
+    def _plan(self, counts, budget_mult=1):
+        plan = plan_selection(counts, self.max_samples * budget_mult, self.max_views)
         if plan is None:
             # the reference returns (None, None) and then fails on None.shape (loss_contrast.py:44-45, :92)
             raise RuntimeError("PixelContrastLoss: no (image, class) segment has more than max_views=%d pixels"
@@ -117,7 +125,8 @@ class PixelContrastLoss(nn.Module, ABC):
         if int(host[:, -4].sum()) != 0:
             raise RuntimeError("PixelContrastLoss: labels outside [0, num_classes) on some rank")
         counts = host[:, :-4].reshape((world * B,) + tuple(cp["counts"].shape[1:])).numpy()
-        plan = self._plan(counts)                               # identical on every rank (same seed, same counts)
+        # identical on every rank (same seed, same counts)
+        plan = self._plan(counts, world if self.cross_rank_budget == 'per_rank' else 1)
         T, V = plan.T, plan.n_view
         owner = plan.seg_img // B                               # rank of every segment
         mine = np.nonzero(owner == rank)[0]

@@ -1,0 +1,192 @@
+"""HRNetV2 encoder (W18/W32/W48/W64) with the reference's parameter names and construction order
+(lib/models/backbones/hrnet/hrnet_backbone.py:35-574, configs hrnet_config.py:46-73), so reference checkpoints
+load unchanged and the same torch seed gives identical random initialisation.
+
+The network is expressed as data (stage table below) plus three small module kinds; conv / BN / ReLU execute on
+MIOpen through PyTorch-ROCm, the cross-resolution upsample+sum of the fuse step uses torch's bilinear kernel.
+Factory keys follow lib/models/backbones/hrnet/hrnet_backbone.py:742-803 ('hrnet18' ... 'hrnet64'); BN is hard-wired
+to torch SyncBN with momentum 0.1 exactly as the reference factory does (:773)."""
+import torch.nn as nn
+import torch.nn.functional as F
+
+from contrastiveseg_amd.lib.models.tools.module_helper import ModuleHelper
+
+# width -> per-stage (modules, blocks per branch); channel list is width * (1, 2, 4, 8)[:branches]
+STAGES = {2: (1, 4), 3: (4, 4), 4: (3, 4)}
+WIDTHS = {'hrnet18': 18, 'hrnet32': 32, 'hrnet48': 48, 'hrnet64': 64}
+
+
+def _norm(bn_type, c, momentum):
+    return ModuleHelper.BatchNorm2d(bn_type=bn_type)(c, momentum=momentum)
+
+
+def _conv_bn(cin, cout, k, stride, bn_type, momentum, relu):
+    layers = [nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=False), _norm(bn_type, cout, momentum)]
+    if relu:
+        layers.append(nn.ReLU(inplace=False))
+    return nn.Sequential(*layers)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, bn_type=None, bn_momentum=0.1):
+        super(BasicBlock, self).__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = _norm(bn_type, planes, bn_momentum)
+        self.relu = nn.ReLU(inplace=False)
+        self.relu_in = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = _norm(bn_type, planes, bn_momentum)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        res = x if self.downsample is None else self.downsample(x)
+        return self.relu_in(out + res)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, bn_type=None, bn_momentum=0.1):
+        super(Bottleneck, self).__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = _norm(bn_type, planes, bn_momentum)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = _norm(bn_type, planes, bn_momentum)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = _norm(bn_type, planes * 4, bn_momentum)
+        self.relu = nn.ReLU(inplace=False)
+        self.relu_in = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        res = x if self.downsample is None else self.downsample(x)
+        return self.relu_in(out + res)
+
+
+def _block_chain(block, inplanes, planes, n, bn_type, momentum):
+    """downsample projection (created first, as the reference does) + n residual blocks"""
+    down = None
+    if inplanes != planes * block.expansion:
+        down = _conv_bn(inplanes, planes * block.expansion, 1, 1, bn_type, momentum, relu=False)
+    blocks = [block(inplanes, planes, 1, down, bn_type=bn_type, bn_momentum=momentum)]
+    for _ in range(1, n):
+        blocks.append(block(planes * block.expansion, planes, bn_type=bn_type, bn_momentum=momentum))
+    return nn.Sequential(*blocks)
+
+
+class HighResolutionModule(nn.Module):
+    """One multi-resolution exchange unit: per-branch residual chains, then every output resolution sums all
+    branches (strided 3x3 chains going down, 1x1 + bilinear going up). Reference :108-288."""
+
+    def __init__(self, channels, num_blocks, bn_type, bn_momentum, multi_scale_output=True):
+        super(HighResolutionModule, self).__init__()
+        nb = len(channels)
+        self.num_branches = nb
+        self.branches = nn.ModuleList([_block_chain(BasicBlock, c, c, num_blocks, bn_type, bn_momentum)
+                                       for c in channels])
+        fuse = []
+        for i in range(nb if multi_scale_output else 1):
+            row = []
+            for j in range(nb):
+                if j > i:
+                    row.append(_conv_bn(channels[j], channels[i], 1, 1, bn_type, bn_momentum, relu=False))
+                elif j == i:
+                    row.append(None)
+                else:
+                    steps = [_conv_bn(channels[j], channels[j], 3, 2, bn_type, bn_momentum, relu=True)
+                             for _ in range(i - j - 1)]
+                    steps.append(_conv_bn(channels[j], channels[i], 3, 2, bn_type, bn_momentum, relu=False))
+                    row.append(nn.Sequential(*steps))
+            fuse.append(nn.ModuleList(row))
+        self.fuse_layers = nn.ModuleList(fuse) if nb > 1 else None
+        self.relu = nn.ReLU(inplace=False)
+
+    def forward(self, x):
+        x = [branch(xi) for branch, xi in zip(self.branches, x)]
+        if self.num_branches == 1:
+            return x
+        outs = []
+        for i, row in enumerate(self.fuse_layers):
+            y = x[0] if i == 0 else row[0](x[0])
+            for j in range(1, self.num_branches):
+                if j == i:
+                    y = y + x[j]
+                elif j > i:
+                    y = y + F.interpolate(row[j](x[j]), size=x[i].shape[-2:], mode='bilinear', align_corners=True)
+                else:
+                    y = y + row[j](x[j])
+            outs.append(self.relu(y))
+        return outs
+
+
+class HighResolutionNet(nn.Module):
+    def __init__(self, width, bn_type='torchsyncbn', bn_momentum=0.1):
+        super(HighResolutionNet, self).__init__()
+        self.conv1 = nn.Conv2d(3, 64, 3, 2, 1, bias=False)
+        self.bn1 = _norm(bn_type, 64, bn_momentum)
+        self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
+        self.bn2 = _norm(bn_type, 64, bn_momentum)
+        self.relu = nn.ReLU(inplace=False)
+        self.layer1 = _block_chain(Bottleneck, 64, 64, 4, bn_type, bn_momentum)
+        prev = [256]
+        for s in (2, 3, 4):
+            chans = [width * (2 ** k) for k in range(s)]
+            setattr(self, 'transition%d' % (s - 1), self._transition(prev, chans, bn_type, bn_momentum))
+            n_mod, n_blk = STAGES[s]
+            setattr(self, 'stage%d' % s, nn.Sequential(*[HighResolutionModule(chans, n_blk, bn_type, bn_momentum)
+                                                         for _ in range(n_mod)]))
+            prev = chans
+        self.num_features = sum(prev)
+
+    @staticmethod
+    def _transition(prev, cur, bn_type, momentum):
+        layers = []
+        for i, c in enumerate(cur):
+            if i < len(prev):
+                layers.append(None if c == prev[i] else _conv_bn(prev[i], c, 3, 1, bn_type, momentum, relu=True))
+            else:
+                steps = []
+                for j in range(i + 1 - len(prev)):
+                    cout = c if j == i - len(prev) else prev[-1]
+                    steps.append(_conv_bn(prev[-1], cout, 3, 2, bn_type, momentum, relu=True))
+                layers.append(nn.Sequential(*steps))
+        return nn.ModuleList(layers)
+
+    def forward(self, x):
+        x = self.relu(self.bn1(self.conv1(x)))
+        x = self.relu(self.bn2(self.conv2(x)))
+        x = self.layer1(x)
+        ys = [x]
+        for s in (2, 3, 4):
+            trans = getattr(self, 'transition%d' % (s - 1))
+            xs = []
+            for i, t in enumerate(trans):
+                if t is None:
+                    xs.append(ys[i])
+                else:
+                    xs.append(t(ys[-1]) if i >= len(ys) or s > 2 else t(ys[i]))
+            ys = getattr(self, 'stage%d' % s)(xs)
+        return ys
+
+
+class HRNetBackbone(object):
+    def __init__(self, configer):
+        self.configer = configer
+
+    def __call__(self):
+        arch = self.configer.get('network', 'backbone')
+        if arch not in WIDTHS:
+            raise Exception('Architecture undefined!')
+        net = HighResolutionNet(WIDTHS[arch], bn_type='torchsyncbn', bn_momentum=0.1)
+        if self.configer.get('network', 'resume') is None:
+            net = ModuleHelper.load_model(net, pretrained=self.configer.get('network', 'pretrained'),
+                                          all_match=False, network='hrnet')
+        return net

@@ -1,0 +1,23 @@
+"""Model registry with the reference's keys for the contrastive hot path (lib/models/model_manager.py:48-98)."""
+from contrastiveseg_amd.lib.models.nets.deeplab import DeepLabV3Contrast
+from contrastiveseg_amd.lib.models.nets.hrnet import HRNet_W48_CONTRAST, HRNet_W48_MEM, HRNet_W48_OCR_CONTRAST
+from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
+
+SEG_MODEL_DICT = {
+    'hrnet_w48_contrast': HRNet_W48_CONTRAST,
+    'hrnet_w48_ocr_contrast': HRNet_W48_OCR_CONTRAST,
+    'hrnet_w48_mem': HRNet_W48_MEM,
+    'deeplab_v3_contrast': DeepLabV3Contrast,
+}
+
+
+class ModelManager(object):
+    def __init__(self, configer):
+        self.configer = configer
+
+    def semantic_segmentor(self):
+        model_name = self.configer.get('network', 'model_name')
+        if model_name not in SEG_MODEL_DICT:
+            Log.error('Model: {} not valid!'.format(model_name))
+            exit(1)
+        return SEG_MODEL_DICT[model_name](self.configer)

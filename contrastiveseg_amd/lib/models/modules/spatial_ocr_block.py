@@ -1,0 +1,64 @@
+"""Object-contextual representation blocks used by hrnet_w48_ocr_contrast, with the reference's parameter names
+(lib/models/modules/spatial_ocr_block.py:37-67 SpatialGather_Module, :116-217 _ObjectAttentionBlock,
+:238-309 SpatialOCR_Module). Only the configuration the contrast model instantiates is kept (scale 1, no ground-truth
+or background context). The two small batched matmuls run on rocBLAS through torch."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from contrastiveseg_amd.lib.models.tools.module_helper import ModuleHelper
+
+
+class SpatialGather_Module(nn.Module):
+    """Soft region pooling: softmax over pixels of the coarse class scores, then scores . features."""
+
+    def __init__(self, cls_num=0, scale=1):
+        super(SpatialGather_Module, self).__init__()
+        self.cls_num = cls_num
+        self.scale = scale
+
+    def forward(self, feats, probs):
+        b, k = probs.shape[:2]
+        probs = F.softmax(self.scale * probs.reshape(b, k, -1), dim=2)          # b x k x hw
+        feats = feats.reshape(b, feats.shape[1], -1).permute(0, 2, 1)            # b x hw x c
+        return torch.matmul(probs, feats).permute(0, 2, 1).unsqueeze(3)          # b x c x k x 1
+
+
+def _conv_bnrelu(cin, cout, bn_type):
+    return [nn.Conv2d(cin, cout, kernel_size=1, stride=1, padding=0), ModuleHelper.BNReLU(cout, bn_type=bn_type)]
+
+
+class ObjectAttentionBlock2D(nn.Module):
+    def __init__(self, in_channels, key_channels, scale=1, bn_type=None):
+        super(ObjectAttentionBlock2D, self).__init__()
+        if scale != 1:
+            raise NotImplementedError('OCR scale != 1 is not used on the hot path')
+        self.in_channels, self.key_channels = in_channels, key_channels
+        self.f_pixel = nn.Sequential(*(_conv_bnrelu(in_channels, key_channels, bn_type) +
+                                       _conv_bnrelu(key_channels, key_channels, bn_type)))
+        self.f_object = nn.Sequential(*(_conv_bnrelu(in_channels, key_channels, bn_type) +
+                                        _conv_bnrelu(key_channels, key_channels, bn_type)))
+        self.f_down = nn.Sequential(*_conv_bnrelu(in_channels, key_channels, bn_type))
+        self.f_up = nn.Sequential(*_conv_bnrelu(key_channels, in_channels, bn_type))
+
+    def forward(self, x, proxy):
+        b, _, h, w = x.shape
+        query = self.f_pixel(x).reshape(b, self.key_channels, -1).permute(0, 2, 1)
+        key = self.f_object(proxy).reshape(b, self.key_channels, -1)
+        value = self.f_down(proxy).reshape(b, self.key_channels, -1).permute(0, 2, 1)
+        sim = F.softmax((self.key_channels ** -.5) * torch.matmul(query, key), dim=-1)
+        context = torch.matmul(sim, value).permute(0, 2, 1).contiguous().reshape(b, self.key_channels, h, w)
+        return self.f_up(context)
+
+
+class SpatialOCR_Module(nn.Module):
+    def __init__(self, in_channels, key_channels, out_channels, scale=1, dropout=0.1, bn_type=None):
+        super(SpatialOCR_Module, self).__init__()
+        self.object_context_block = ObjectAttentionBlock2D(in_channels, key_channels, scale, bn_type)
+        self.conv_bn_dropout = nn.Sequential(nn.Conv2d(2 * in_channels, out_channels, kernel_size=1, padding=0),
+                                             ModuleHelper.BNReLU(out_channels, bn_type=bn_type),
+                                             nn.Dropout2d(dropout))
+
+    def forward(self, feats, proxy_feats):
+        context = self.object_context_block(feats, proxy_feats)
+        return self.conv_bn_dropout(torch.cat([context, feats], 1))

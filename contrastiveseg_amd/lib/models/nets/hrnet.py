@@ -1,0 +1,91 @@
+"""HRNet-W48 contrastive segmentors with the reference's registry classes, parameter names and output dicts
+(lib/models/nets/hrnet.py:59-95 HRNet_W48_CONTRAST, :98-150 HRNet_W48_OCR_CONTRAST, :153-188 HRNet_W48_MEM).
+
+The 3x F.interpolate + torch.cat that builds the 720-channel head input (:86-91) is one HIP kernel
+(cseg_upcat_fwd/bwd); encoder and head convolutions run on MIOpen."""
+import torch
+import torch.nn as nn
+
+from contrastiveseg_amd import kernels as K
+from contrastiveseg_amd.lib.models.backbones.backbone_selector import BackboneSelector
+from contrastiveseg_amd.lib.models.modules.projection import ProjectionHead
+from contrastiveseg_amd.lib.models.modules.spatial_ocr_block import SpatialGather_Module, SpatialOCR_Module
+from contrastiveseg_amd.lib.models.tools.module_helper import ModuleHelper
+
+
+class HRNet_W48_CONTRAST(nn.Module):
+    def __init__(self, configer):
+        super(HRNet_W48_CONTRAST, self).__init__()
+        self.configer = configer
+        self.num_classes = self.configer.get('data', 'num_classes')
+        self.backbone = BackboneSelector(configer).get_backbone()
+        self.proj_dim = self.configer.get('contrast', 'proj_dim')
+        in_channels = self.backbone.num_features          # 720 = 48 + 96 + 192 + 384 for W48
+        self.cls_head = nn.Sequential(
+            nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1),
+            ModuleHelper.BNReLU(in_channels, bn_type=self.configer.get('network', 'bn_type')),
+            nn.Dropout2d(0.10),
+            nn.Conv2d(in_channels, self.num_classes, kernel_size=1, stride=1, padding=0, bias=False))
+        self.proj_head = ProjectionHead(dim_in=in_channels, proj_dim=self.proj_dim)
+
+    def forward(self, x_, with_embed=False, is_eval=False):
+        feats = K.upsample_concat(self.backbone(x_))
+        return {'seg': self.cls_head(feats), 'embed': self.proj_head(feats)}
+
+
+class HRNet_W48_OCR_CONTRAST(nn.Module):
+    def __init__(self, configer):
+        super(HRNet_W48_OCR_CONTRAST, self).__init__()
+        self.configer = configer
+        self.num_classes = self.configer.get('data', 'num_classes')
+        self.backbone = BackboneSelector(configer).get_backbone()
+        self.proj_dim = self.configer.get('contrast', 'proj_dim')
+        bn_type = self.configer.get('network', 'bn_type')
+        in_channels = self.backbone.num_features
+        self.conv3x3 = nn.Sequential(nn.Conv2d(in_channels, 512, kernel_size=3, stride=1, padding=1),
+                                     ModuleHelper.BNReLU(512, bn_type=bn_type))
+        self.ocr_gather_head = SpatialGather_Module(self.num_classes)
+        self.ocr_distri_head = SpatialOCR_Module(in_channels=512, key_channels=256, out_channels=512, scale=1,
+                                                 dropout=0.05, bn_type=bn_type)
+        self.cls_head = nn.Conv2d(512, self.num_classes, kernel_size=1, stride=1, padding=0, bias=True)
+        self.aux_head = nn.Sequential(
+            nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1),
+            ModuleHelper.BNReLU(in_channels, bn_type=bn_type),
+            nn.Conv2d(in_channels, self.num_classes, kernel_size=1, stride=1, padding=0, bias=True))
+        self.proj_head = ProjectionHead(dim_in=in_channels, proj_dim=self.proj_dim)
+
+    def forward(self, x_, with_embed=False, is_eval=False):
+        feats = K.upsample_concat(self.backbone(x_))
+        out_aux = self.aux_head(feats)
+        emb = self.proj_head(feats)
+        feats = self.conv3x3(feats)
+        context = self.ocr_gather_head(feats, out_aux)
+        out = self.cls_head(self.ocr_distri_head(feats, context))
+        return {'seg': out, 'seg_aux': out_aux, 'embed': emb}
+
+
+class HRNet_W48_MEM(nn.Module):
+    """encoder_q + per-class segment / pixel queues as buffers (so they live in the state_dict, reference :165-171).
+    The momentum key encoder of the reference is dead code (no encoder_k exists, :173-176) and is not carried."""
+
+    def __init__(self, configer, dim=256, m=0.999, with_masked_ppm=False):
+        super(HRNet_W48_MEM, self).__init__()
+        self.configer = configer
+        self.m = m
+        self.r = self.configer.get('contrast', 'memory_size')
+        self.with_masked_ppm = with_masked_ppm
+        num_classes = self.configer.get('data', 'num_classes')
+        self.encoder_q = HRNet_W48_CONTRAST(configer)
+        self.register_buffer("segment_queue", torch.randn(num_classes, self.r, dim))
+        self.segment_queue = nn.functional.normalize(self.segment_queue, p=2, dim=2)
+        self.register_buffer("segment_queue_ptr", torch.zeros(num_classes, dtype=torch.long))
+        self.register_buffer("pixel_queue", torch.randn(num_classes, self.r, dim))
+        self.pixel_queue = nn.functional.normalize(self.pixel_queue, p=2, dim=2)
+        self.register_buffer("pixel_queue_ptr", torch.zeros(num_classes, dtype=torch.long))
+
+    def forward(self, im_q, lb_q=None, with_embed=True, is_eval=False):
+        if is_eval is True or lb_q is None:
+            return self.encoder_q(im_q, with_embed=with_embed)
+        ret = self.encoder_q(im_q)
+        q = ret['embed']
+        return {'seg': ret['seg'], 'embed': q, 'key': q.detach(), 'lb_key': lb_q.detach()}

@@ -1,0 +1,160 @@
+"""ModuleRunner with the reference's responsibilities (segmentor/tools/module_runner.py:27-289): run counters in
+the Configer, device placement, data-parallel wrap, resume, checkpoint save, lr warm-up.
+
+Parallel wrap, MI355X-first: one process per GPU, torch DistributedDataParallel on the 'nccl' (= RCCL) backend
+over xGMI. Gradient buckets are reduced on RCCL's own HIP stream while backward keeps producing gradients;
+`gradient_as_bucket_view` removes the grad->bucket copy; the bucket size is a config knob
+(network.ddp_bucket_mb, default 64 MB: xGMI rings are per-link bound, so fewer, larger messages than the
+25 MB NVSwitch-era default). All parameters receive gradients every step (the `loss + 0 * loss_contrast` trick of
+the reference keeps the projection head in the graph during warm-up), so the unused-parameter graph walk the
+reference enables (:66-71) is off. There is no single-process multi-GPU DataParallel path."""
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from contrastiveseg_amd.lib.utils.distributed import get_local_rank, get_rank, is_distributed
+from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
+
+
+class ModuleRunner(object):
+    def __init__(self, configer):
+        self.configer = configer
+        for key, val in (('iters', 0), ('last_iters', 0), ('epoch', 0), ('last_epoch', 0), ('max_performance', 0.0),
+                         ('performance', 0.0), ('min_val_loss', 9999.0), ('val_loss', 9999.0)):
+            if not self.configer.exists(key):
+                self.configer.add([key], val)
+        if not self.configer.exists('network', 'bn_type'):
+            self.configer.add(['network', 'bn_type'], 'torchbn')
+        Log.info('BN Type is {}.'.format(self.configer.get('network', 'bn_type')))
+
+    def device(self):
+        if torch.cuda.is_available() and not (self.configer.exists('gpu') and self.configer.get('gpu') is None
+                                              and not is_distributed()):
+            return torch.device('cuda', get_local_rank() if is_distributed() else torch.cuda.current_device())
+        return torch.device('cpu')
+
+    def to_device(self, *params, force_list=False):
+        dev = self.device()
+        out = [p.to(dev) for p in params]
+        return out if force_list or len(out) != 1 else out[0]
+
+    def _make_parallel(self, net):
+        if not is_distributed():
+            return net
+        has_queues = any(name.endswith('_queue') for name, _ in net.named_buffers())
+        bucket_mb = 64
+        if self.configer.exists('network', 'ddp_bucket_mb'):
+            bucket_mb = self.configer.get('network', 'ddp_bucket_mb')
+        kwargs = dict(find_unused_parameters=False, gradient_as_bucket_view=True, bucket_cap_mb=bucket_mb,
+                      # SyncBN keeps BN buffers identical on all ranks; only the memory queues need rank 0's copy
+                      broadcast_buffers=has_queues)
+        if next(net.parameters()).is_cuda:
+            kwargs.update(device_ids=[get_local_rank()], output_device=get_local_rank())
+        return torch.nn.parallel.DistributedDataParallel(net, **kwargs)
+
+    def load_net(self, net):
+        net = self.to_device(net)
+        net.float()
+        resume = self.configer.get('network', 'resume') if self.configer.exists('network', 'resume') else None
+        if resume is not None:
+            Log.info('Loading checkpoint from {}...'.format(resume))
+            blob = torch.load(resume, map_location='cpu')
+            if 'state_dict' in blob:
+                state = blob['state_dict']
+            elif 'model' in blob:
+                state = blob['model']
+            elif isinstance(blob, OrderedDict):
+                state = blob
+            else:
+                raise RuntimeError('No state_dict found in checkpoint file {}'.format(resume))
+            if list(state.keys())[0].startswith('module.'):
+                state = {k[7:]: v for k, v in state.items()}
+            strict = self.configer.get('network', 'resume_strict') if self.configer.exists('network', 'resume_strict') \
+                else False
+            self.load_state_dict(net, state, strict)
+            if self.configer.exists('network', 'resume_continue') and self.configer.get('network', 'resume_continue'):
+                self.configer.update(['network', 'resume'], None)
+        return self._make_parallel(net)
+
+    @staticmethod
+    def load_state_dict(module, state_dict, strict=False):
+        """Non-strict copy with shape check and a report of unexpected / missing keys (reference :121-166)."""
+        own = module.state_dict()
+        unexpected, mismatched = [], []
+        for name, param in state_dict.items():
+            if name not in own:
+                unexpected.append(name)
+                continue
+            if own[name].shape != param.shape:
+                mismatched.append('{}: {} vs {}'.format(name, tuple(own[name].shape), tuple(param.shape)))
+                continue
+            own[name].copy_(param)
+        missing = sorted(set(own.keys()) - set(state_dict.keys()))
+        msg = []
+        if unexpected:
+            msg.append('unexpected key in source state_dict: {}'.format(', '.join(unexpected)))
+        if missing:
+            msg.append('missing keys in source state_dict: {}'.format(', '.join(missing)))
+        if mismatched:
+            msg.append('size mismatch: {}'.format('; '.join(mismatched)))
+        if msg:
+            if strict:
+                raise RuntimeError('\n'.join(msg))
+            Log.warn('\n'.join(msg))
+
+    def save_net(self, net, save_mode='iters', experiment=None):
+        if is_distributed() and get_rank() != 0:
+            return
+        state = {'config_dict': self.configer.to_dict(), 'state_dict': net.state_dict()}
+        ck = self.configer.get('checkpoints')
+        root = ck.get('checkpoints_root') or (self.configer.get('project_dir') if self.configer.exists('project_dir')
+                                              else '.')
+        directory = os.path.join(root, ck['checkpoints_dir'])
+        os.makedirs(directory, exist_ok=True)
+        name = ck['checkpoints_name']
+        torch.save(state, os.path.join(directory, '{}_latest.pth'.format(name)))
+        c = self.configer
+        if save_mode == 'performance':
+            if c.get('performance') > c.get('max_performance'):
+                torch.save(state, os.path.join(directory, '{}_max_performance.pth'.format(name)))
+                c.update(['max_performance'], c.get('performance'))
+        elif save_mode == 'val_loss':
+            if c.get('val_loss') < c.get('min_val_loss'):
+                torch.save(state, os.path.join(directory, '{}_min_loss.pth'.format(name)))
+                c.update(['min_val_loss'], c.get('val_loss'))
+        elif save_mode == 'iters':
+            if c.get('iters') - c.get('last_iters') >= ck['save_iters']:
+                torch.save(state, os.path.join(directory, '{}_iters{}.pth'.format(name, c.get('iters'))))
+                c.update(['last_iters'], c.get('iters'))
+        elif save_mode == 'epoch':
+            if c.get('epoch') - c.get('last_epoch') >= ck['save_epoch']:
+                torch.save(state, os.path.join(directory, '{}_epoch{}.pth'.format(name, c.get('epoch'))))
+                c.update(['last_epoch'], c.get('epoch'))
+        else:
+            Log.error('Metric: {} is invalid.'.format(save_mode))
+            exit(1)
+
+    def freeze_bn(self, net, syncbn=False):
+        for m in net.modules():
+            if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d, nn.SyncBatchNorm)):
+                m.eval()
+
+    def get_lr(self, optimizer):
+        return [g['lr'] for g in optimizer.param_groups]
+
+    def warm_lr(self, iters, scheduler, optimizer, backbone_list=(0,)):
+        """reference :271-289"""
+        if not self.configer.exists('lr', 'is_warm') or not self.configer.get('lr', 'is_warm'):
+            return
+        warm = self.configer.get('lr', 'warm')
+        if iters < warm['warm_iters']:
+            if warm['freeze_backbone']:
+                for i in backbone_list:
+                    optimizer.param_groups[i]['lr'] = 0.0
+            else:
+                ratio = (self.configer.get('iters') + 1) / warm['warm_iters']
+                base = scheduler.get_lr()
+                for i in backbone_list:
+                    optimizer.param_groups[i]['lr'] = base[i] * (ratio ** 4)

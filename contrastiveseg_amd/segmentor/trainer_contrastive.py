@@ -1,0 +1,305 @@
+"""Contrastive trainer with the reference's surface (segmentor/trainer_contrastive.py:25-439): `Trainer(configer)`,
+`.train()`, the warm-up gate `iters >= contrast.warmup_iters`, the two learning-rate groups, the five wall-clock
+meters and the log line, and `_dequeue_and_enqueue` for the memory-bank model.
+
+What changes underneath (MI355X-first):
+  * one process per GPU; model wrapped by ModuleRunner in DDP over RCCL/xGMI (no DataParallel path);
+  * the criterion is built from HIP kernels (lib/loss/*), with one host sync per step (the per-class counts that
+    the CPU randperm stream needs) instead of O(100) implicit syncs of the reference's Python loops;
+  * `_dequeue_and_enqueue` is one histogram + one all-class reduction + two row writers on the device; pointer
+    arithmetic, last-writer-wins resolution and the CPU `torch.randperm` draws (same order as the reference) stay
+    on the host;
+  * data: any iterable yielding {'img', 'labelmap'} dicts; by default a seeded synthetic loader resident in HBM
+    (file datasets / cv2 augmentation are out of scope)."""
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from contrastiveseg_amd import kernels as K
+from contrastiveseg_amd.lib.loss.loss_manager import LossManager
+from contrastiveseg_amd.lib.models.model_manager import ModelManager
+from contrastiveseg_amd.lib.utils.distributed import get_rank, get_world_size, is_distributed
+from contrastiveseg_amd.lib.utils.tools.average_meter import AverageMeter
+from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
+from contrastiveseg_amd.segmentor.tools.data_helper import DataHelper, SyntheticLoader
+from contrastiveseg_amd.segmentor.tools.module_runner import ModuleRunner
+from contrastiveseg_amd.segmentor.tools.optim_scheduler import OptimScheduler
+
+
+def _unwrap(net):
+    return net.module if hasattr(net, 'module') else net
+
+
+def plan_enqueue(counts, seg_ptr, pix_ptr, memory_size, pixel_update_freq):
+    """Host half of _dequeue_and_enqueue (reference :110-138) on the strided-label histogram `counts` [B,K].
+    Walks (image, class>0) in the reference's order, advances the pointers with its arithmetic (segment pointer +1;
+    pixel pointer +1 -- not +K -- or reset to 0 on wrap) and draws torch.randperm(num_pixel) per pair from the CPU
+    generator. Later writes to the same bank row win. Returns (segment jobs, pixel rows, new pointers)."""
+    B, Kc = counts.shape
+    seg_ptr = seg_ptr.copy()
+    pix_ptr = pix_ptr.copy()
+    seg_last, pix_last = {}, {}
+    for bs in range(B):
+        for lb in range(1, Kc):
+            n = int(counts[bs, lb])
+            if n == 0:
+                continue
+            seg_last[(lb, int(seg_ptr[lb]))] = bs
+            seg_ptr[lb] = (seg_ptr[lb] + 1) % memory_size
+            perm = torch.randperm(n).numpy()
+            k = min(n, pixel_update_freq)
+            ptr = int(pix_ptr[lb])
+            if ptr + k >= memory_size:
+                rows = range(memory_size - k, memory_size)
+                pix_ptr[lb] = 0
+            else:
+                rows = range(ptr, ptr + k)
+                pix_ptr[lb] = (pix_ptr[lb] + 1) % memory_size
+            for r, pos in zip(rows, perm[:k]):
+                pix_last[(lb, r)] = (bs, int(pos))
+    seg_jobs = np.array([(b, lb, row) for (lb, row), b in seg_last.items()], dtype=np.int32).reshape(-1, 3)
+    pix_rows = np.array([(b, pos, lb, row) for (lb, row), (b, pos) in pix_last.items()], dtype=np.int32).reshape(-1, 4)
+    return seg_jobs, pix_rows, seg_ptr, pix_ptr
+
+
+class Trainer(object):
+    def __init__(self, configer, train_loader=None, val_loader=None):
+        self.configer = configer
+        self.batch_time = AverageMeter()
+        self.foward_time = AverageMeter()
+        self.backward_time = AverageMeter()
+        self.loss_time = AverageMeter()
+        self.data_time = AverageMeter()
+        self.train_losses = AverageMeter()
+        self.val_losses = AverageMeter()
+        self.loss_manager = LossManager(configer)
+        self.module_runner = ModuleRunner(configer)
+        self.model_manager = ModelManager(configer)
+        self.optim_scheduler = OptimScheduler(configer)
+        self.data_helper = DataHelper(configer, self)
+        self.seg_net = None
+        self.train_loader = train_loader
+        self.val_loader = val_loader
+        self.optimizer = None
+        self.scheduler = None
+        self._init_model()
+
+    def _init_model(self):
+        self.seg_net = self.model_manager.semantic_segmentor()
+        if self.configer.exists('network', 'channels_last') and self.configer.get('network', 'channels_last'):
+            self.seg_net = self.seg_net.to(memory_format=torch.channels_last)
+        self.seg_net = self.module_runner.load_net(self.seg_net)
+
+        Log.info('Params Group Method: {}'.format(self.configer.get('optim', 'group_method')))
+        if self.configer.get('optim', 'group_method') == 'decay':
+            params_group = self.group_weight(self.seg_net)
+        else:
+            assert self.configer.get('optim', 'group_method') is None
+            params_group = self._get_parameters()
+        self.optimizer, self.scheduler = self.optim_scheduler.init_optimizer(params_group)
+
+        if self.train_loader is None:
+            self.train_loader = SyntheticLoader(self.configer, self.module_runner.device(),
+                                                length=self.configer.get('solver', 'max_iters'))
+        self.pixel_loss = self.module_runner.to_device(self.loss_manager.get_seg_loss())
+
+        self.with_contrast = True if self.configer.exists("contrast") else False
+        self.contrast_warmup_iters = self.configer.get("contrast", "warmup_iters") \
+            if self.configer.exists("contrast", "warmup_iters") else 0
+        self.with_memory = self.configer.exists('contrast', 'with_memory')
+        if self.with_memory:
+            self.memory_size = self.configer.get('contrast', 'memory_size')
+            self.pixel_update_freq = self.configer.get('contrast', 'pixel_update_freq')
+        self.network_stride = self.configer.get('network', 'stride')
+        Log.info("with_contrast: {}, warmup_iters: {}, with_memory: {}".format(
+            self.with_contrast, self.contrast_warmup_iters, self.with_memory))
+
+    # ------------------------------------------------------------------------------------------------------
+    def _dequeue_and_enqueue(self, keys, labels, segment_queue, segment_queue_ptr, pixel_queue, pixel_queue_ptr):
+        """reference :102-138; all four queue tensors are updated in place."""
+        Kc = segment_queue.shape[0]
+        keys = keys.contiguous()
+        counts_d = K.queue_count(labels, self.network_stride, Kc)
+        sums = K.queue_class_sums(keys, labels, self.network_stride, Kc)     # queued before the host sync below
+        host = torch.cat([counts_d.reshape(-1).long(), segment_queue_ptr, pixel_queue_ptr]).cpu().numpy()
+        B = keys.shape[0]
+        counts = host[:B * Kc].reshape(B, Kc)
+        seg_ptr, pix_ptr = host[B * Kc:B * Kc + Kc], host[B * Kc + Kc:]
+        seg_jobs, pix_rows, seg_ptr, pix_ptr = plan_enqueue(counts, seg_ptr, pix_ptr, self.memory_size,
+                                                            self.pixel_update_freq)
+        dev = keys.device
+        if len(seg_jobs):
+            j = torch.from_numpy(seg_jobs).to(dev)
+            K.queue_write_segments(sums, counts_d, j[:, 0].contiguous(), j[:, 1].contiguous(), j[:, 2].contiguous(),
+                                   segment_queue)
+        if len(pix_rows):
+            r = torch.from_numpy(pix_rows).to(dev)
+            K.queue_write_pixels(keys, r[:, 0].contiguous(), r[:, 1].contiguous(), r[:, 2].contiguous(),
+                                 r[:, 3].contiguous(), pixel_queue)
+        segment_queue_ptr.copy_(torch.from_numpy(seg_ptr.astype(np.int64)))
+        pixel_queue_ptr.copy_(torch.from_numpy(pix_ptr.astype(np.int64)))
+
+    @staticmethod
+    def group_weight(module):
+        """reference :141-161"""
+        group_decay, group_no_decay = [], []
+        for m in module.modules():
+            if isinstance(m, (nn.Linear, nn.modules.conv._ConvNd)):
+                group_decay.append(m.weight)
+                if m.bias is not None:
+                    group_no_decay.append(m.bias)
+            else:
+                if hasattr(m, 'weight') and isinstance(getattr(m, 'weight'), nn.Parameter):
+                    group_no_decay.append(m.weight)
+                if hasattr(m, 'bias') and isinstance(getattr(m, 'bias'), nn.Parameter):
+                    group_no_decay.append(m.bias)
+        assert len(list(module.parameters())) == len(group_decay) + len(group_no_decay)
+        return [dict(params=group_decay), dict(params=group_no_decay, weight_decay=.0)]
+
+    def _get_parameters(self):
+        """reference :163-175: backbone lr / head lr * nbb_mult"""
+        bb_lr, nbb_lr = [], []
+        for key, value in dict(self.seg_net.named_parameters()).items():
+            (nbb_lr if 'backbone' not in key else bb_lr).append(value)
+        base = self.configer.get('lr', 'base_lr')
+        return [{'params': bb_lr, 'lr': base}, {'params': nbb_lr, 'lr': base * self.configer.get('lr', 'nbb_mult')}]
+
+    # ------------------------------------------------------------------------------------------------------
+    def train_step(self, data_dict):
+        """One iteration of the reference's loop body (:193-267). Returns the (rank-local) loss tensor."""
+        c = self.configer
+        start_time = getattr(self, '_t_last', time.time())
+        if c.get('lr', 'metric') == 'iters':
+            self.scheduler.step(c.get('iters'))
+        else:
+            self.scheduler.step(c.get('epoch'))
+        if c.exists('lr', 'is_warm') and c.get('lr', 'is_warm'):
+            self.module_runner.warm_lr(c.get('iters'), self.scheduler, self.optimizer, backbone_list=[0, ])
+
+        (inputs, targets), batch_size = self.data_helper.prepare_data(data_dict)
+        self.data_time.update(time.time() - start_time)
+
+        t0 = time.time()
+        with_embed = True if c.get('iters') >= self.contrast_warmup_iters else False
+        net = _unwrap(self.seg_net)
+        if self.with_contrast and self.with_memory:
+            outputs = self.seg_net(*inputs, targets, with_embed=with_embed)
+            outputs['pixel_queue'] = net.pixel_queue
+            outputs['pixel_queue_ptr'] = net.pixel_queue_ptr
+            outputs['segment_queue'] = net.segment_queue
+            outputs['segment_queue_ptr'] = net.segment_queue_ptr
+        elif self.with_contrast:
+            outputs = self.seg_net(*inputs, with_embed=with_embed)
+        else:
+            outputs = self.seg_net(*inputs)
+        self.foward_time.update(time.time() - t0)
+
+        t0 = time.time()
+        loss = self.pixel_loss(outputs, targets, with_embed=with_embed)
+        if self.with_memory and 'key' in outputs and 'lb_key' in outputs:
+            self._dequeue_and_enqueue(outputs['key'], outputs['lb_key'], segment_queue=net.segment_queue,
+                                      segment_queue_ptr=net.segment_queue_ptr, pixel_queue=net.pixel_queue,
+                                      pixel_queue_ptr=net.pixel_queue_ptr)
+        self.loss_time.update(time.time() - t0)
+
+        t0 = time.time()
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.optimizer.step()
+        self.backward_time.update(time.time() - t0)
+
+        self._last_loss = loss.detach()
+        self._last_batch = batch_size
+        self.batch_time.update(time.time() - start_time)
+        self._t_last = time.time()
+        c.plus_one('iters')
+        return self._last_loss
+
+    def _display(self):
+        """The reference reduces the loss to rank 0 and calls .item() every step (:228-254); that is a host sync per
+        step, so here it happens only when the line is printed."""
+        c = self.configer
+        disp = self._last_loss.clone()
+        if is_distributed() and get_world_size() > 1:
+            import torch.distributed as dist
+            dist.reduce(disp, dst=0)
+            disp = disp / get_world_size()
+        self.train_losses.update(disp.item(), self._last_batch)
+        if not is_distributed() or get_rank() == 0:
+            Log.info('Train Epoch: {0}\tTrain Iteration: {1}\t'
+                     'Time {batch_time.sum:.3f}s / {2}iters, ({batch_time.avg:.3f})\t'
+                     'Forward Time {foward_time.sum:.3f}s / {2}iters, ({foward_time.avg:.3f})\t'
+                     'Backward Time {backward_time.sum:.3f}s / {2}iters, ({backward_time.avg:.3f})\t'
+                     'Loss Time {loss_time.sum:.3f}s / {2}iters, ({loss_time.avg:.3f})\t'
+                     'Data load {data_time.sum:.3f}s / {2}iters, ({data_time.avg:3f})\n'
+                     'Learning rate = {3}\tLoss = {loss.val:.8f} (ave = {loss.avg:.8f})\n'.format(
+                         c.get('epoch'), c.get('iters'), c.get('solver', 'display_iter'),
+                         self.module_runner.get_lr(self.optimizer), batch_time=self.batch_time,
+                         foward_time=self.foward_time, backward_time=self.backward_time, loss_time=self.loss_time,
+                         data_time=self.data_time, loss=self.train_losses))
+        for m in (self.batch_time, self.foward_time, self.backward_time, self.loss_time, self.data_time,
+                  self.train_losses):
+            m.reset()
+
+    def __train(self):
+        self.seg_net.train()
+        self.pixel_loss.train()
+        c = self.configer
+        self._t_last = time.time()
+        if hasattr(getattr(self.train_loader, 'sampler', None), 'set_epoch'):
+            self.train_loader.sampler.set_epoch(c.get('epoch'))
+        for data_dict in self.train_loader:
+            self.train_step(data_dict)
+            if c.get('iters') % c.get('solver', 'display_iter') == 0:
+                self._display()
+            if c.get('iters') == c.get('solver', 'max_iters'):
+                break
+            if self.val_loader is not None and c.get('iters') % c.get('solver', 'test_interval') == 0:
+                self.__val()
+        c.plus_one('epoch')
+
+    @torch.no_grad()
+    def __val(self, data_loader=None):
+        """Validation loss + mIoU from an on-device confusion matrix (reference :306-401 uses cv2 + numpy)."""
+        self.seg_net.eval()
+        self.pixel_loss.eval()
+        Kc = self.configer.get('data', 'num_classes')
+        conf = None
+        for data_dict in (self.val_loader if data_loader is None else data_loader):
+            (inputs, targets), batch_size = self.data_helper.prepare_data(data_dict)
+            outputs = self.seg_net(*inputs, is_eval=True)
+            self.val_losses.update(self.pixel_loss(outputs, targets).item(), batch_size)
+            seg = nn.functional.interpolate(outputs['seg'], size=targets.shape[-2:], mode='bilinear',
+                                            align_corners=True)
+            pred = seg.argmax(1)
+            valid = (targets >= 0) & (targets < Kc)
+            idx = targets[valid] * Kc + pred[valid]
+            cm = torch.bincount(idx, minlength=Kc * Kc).reshape(Kc, Kc).double()
+            conf = cm if conf is None else conf + cm
+        if conf is not None:
+            if is_distributed() and get_world_size() > 1:
+                import torch.distributed as dist
+                dist.all_reduce(conf)
+            iou = conf.diag() / (conf.sum(0) + conf.sum(1) - conf.diag()).clamp(min=1)
+            self.configer.update(['performance'], float(iou.mean()))
+            self.configer.update(['val_loss'], self.val_losses.avg)
+            if self.configer.exists('checkpoints'):
+                self.module_runner.save_net(self.seg_net, save_mode='performance')
+                self.module_runner.save_net(self.seg_net, save_mode='val_loss')
+            Log.info('Val mIoU {:.4f}\tLoss {:.8f}'.format(float(iou.mean()), self.val_losses.avg))
+        self.val_losses.reset()
+        self.seg_net.train()
+        self.pixel_loss.train()
+
+    def train(self):
+        """reference :403-427 (SWA tail omitted: torchcontrib is outside the hot path)."""
+        c = self.configer
+        if c.exists('network', 'resume') and c.get('network', 'resume') is not None and c.exists('network', 'resume_val') \
+                and c.get('network', 'resume_val') and self.val_loader is not None:
+            self.__val()
+        while c.get('iters') < c.get('solver', 'max_iters'):
+            self.__train()
+        if self.val_loader is not None:
+            self.__val()

@@ -1,0 +1,191 @@
+"""
+ORACLE -- test infrastructure only.
+
+Torch-CPU (fp32, autograd) restatement of the device half of the hot path with the same call surface as
+`contrastiveseg_amd.kernels`, so that
+  * the host logic of the product (loss modules, trainer, cross-rank exchange) can be exercised on CPU in
+    `-m "not gpu"` tests by injecting this module in place of the HIP binding (tests only: the product has no CPU
+    path and fails loudly without libcseg_hip.so), and
+  * bench.py's `cpu_baseline` leg can time a CPU port of the train step on the GPU box's host cores.
+Each function restates the reference lines cited in oracle/cseg_oracle.py; results are pinned against the numpy
+oracle (and through it against the reference-generated golden vectors) in tests/test_cpu_port.py.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ---- mining ------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def classify_partition(target, ignore_label, seg=None, predict=None, num_classes=None, feat_hw=None, want_maps=False):
+    B, H, W = target.shape
+    if seg is not None:
+        K, h, w = seg.shape[1:]
+        pred = torch.max(seg, 1)[1].reshape(B, -1)                       # loss_contrast.py:183
+    else:
+        K = int(num_classes)
+        h, w = feat_hw
+        pred = predict.reshape(B, -1)
+    lab = F.interpolate(target.unsqueeze(1).float(), (h, w), mode="nearest").squeeze(1).long().reshape(B, -1)  # :131-134
+    P = h * w
+    counts = torch.zeros(B, K, 2, dtype=torch.int32)
+    seg_off = torch.zeros(B, K, 2, dtype=torch.int32)
+    part = torch.zeros(B, P, dtype=torch.int32)
+    bad = int(((lab != ignore_label) & ((lab < 0) | (lab >= K))).sum())
+    for b in range(B):
+        off = 0
+        for c in range(K):
+            hard = ((lab[b] == c) & (pred[b] != c)).nonzero().reshape(-1)   # :60
+            easy = ((lab[b] == c) & (pred[b] == c)).nonzero().reshape(-1)   # :61
+            counts[b, c, 0], counts[b, c, 1] = len(hard), len(easy)
+            seg_off[b, c, 0] = off
+            part[b, off:off + len(hard)] = hard.int()
+            off += len(hard)
+            seg_off[b, c, 1] = off
+            part[b, off:off + len(easy)] = easy.int()
+            off += len(easy)
+    out = {"counts": counts, "seg_off": seg_off, "part_idx": part,
+           "status": torch.tensor([bad, 0, 0, 0], dtype=torch.int32)}
+    if want_maps:
+        out["lab"], out["pred"] = lab.int(), pred.int()
+    return out
+
+
+def _rows(embed, part_idx, sel_pos):
+    B, D = embed.shape[:2]
+    P = embed.shape[2] * embed.shape[3]
+    pos = sel_pos.long()
+    b = pos // P
+    pix = part_idx.reshape(-1)[pos].long()
+    flat = embed.reshape(B, D, P)
+    return flat[b, :, pix], (b * P + pix).int()          # [N, D]
+
+
+def _contrast(A, ya, C, yc, temperature, base_temperature):
+    """loss_contrast.py:91-128 / loss_contrast_mem.py:107-152 on already view-major rows."""
+    N = A.shape[0]
+    adc = torch.matmul(A, C.T) / temperature
+    logits = adc - adc.max(dim=1, keepdim=True)[0].detach()
+    same = (ya.reshape(-1, 1) == yc.reshape(1, -1)).float()
+    neg_mask = 1 - same
+    logits_mask = torch.ones_like(same).scatter_(1, torch.arange(N).reshape(-1, 1), 0)
+    mask = same * logits_mask
+    neg = (torch.exp(logits) * neg_mask).sum(1, keepdim=True)
+    log_prob = logits - torch.log(torch.exp(logits) + neg)
+    mlpp = (mask * log_prob).sum(1) / mask.sum(1)
+    return (-(temperature / base_temperature) * mlpp).mean()
+
+
+def _bank(segment_queue, pixel_queue):
+    """loss_contrast_mem.py:91-105 on cat(segment_queue, pixel_queue, dim=1)."""
+    Q = torch.cat((segment_queue, pixel_queue), dim=1)
+    Kc, S, D = Q.shape
+    X = torch.zeros(Kc * S, D)
+    y = torch.zeros(Kc * S)
+    X[:(Kc - 1) * S] = Q[1:].reshape(-1, D)
+    y[:(Kc - 1) * S] = torch.arange(1, Kc).repeat_interleave(S).float()
+    return X, y
+
+
+class _Apply(object):
+    def __init__(self, fn):
+        self.apply = fn
+
+
+def _pixel_contrast(embed, part_idx, sel_pos, a_lab, mode, temperature, base_temperature, segment_queue, pixel_queue):
+    A, sel_pix = _rows(embed, part_idx, sel_pos)
+    if mode == "self":
+        loss = _contrast(A, a_lab, A, a_lab, temperature, base_temperature)
+    else:
+        C, yc = _bank(segment_queue, pixel_queue)
+        loss = _contrast(A, a_lab.float(), C, yc, temperature, base_temperature)
+    return loss, sel_pix
+
+
+def _contrast_on_anchors(anchors, a_lab, mode, temperature, base_temperature, contrast, c_lab, segment_queue,
+                         pixel_queue):
+    if mode == "self":
+        return _contrast(anchors, a_lab, anchors, a_lab, temperature, base_temperature)
+    if mode == "plain":
+        return _contrast(anchors, a_lab, contrast, c_lab, temperature, base_temperature)
+    C, yc = _bank(segment_queue, pixel_queue)
+    return _contrast(anchors, a_lab.float(), C, yc, temperature, base_temperature)
+
+
+PixelContrast = _Apply(_pixel_contrast)
+ContrastOnAnchors = _Apply(_contrast_on_anchors)
+GatherAnchors = _Apply(_rows)
+
+
+# ---- head / CE ----------------------------------------------------------------------------------------------
+def upsample_concat(feats):
+    h, w = feats[0].shape[-2:]                                               # nets/hrnet.py:86-91
+    return torch.cat([feats[0]] + [F.interpolate(f, size=(h, w), mode="bilinear", align_corners=True)
+                                   for f in feats[1:]], 1)
+
+
+def upsample_ce(seg, target, weight=None, ignore_index=-1):
+    pred = F.interpolate(seg, size=target.shape[-2:], mode="bilinear", align_corners=True)   # loss_contrast.py:180
+    return F.cross_entropy(pred, target, weight=weight, ignore_index=ignore_index)            # loss_helper.py:186
+
+
+# ---- memory bank ----------------------------------------------------------------------------------------------
+@torch.no_grad()
+def queue_count(labels, stride, num_classes):
+    lab = labels[:, ::stride, ::stride].reshape(labels.shape[0], -1)
+    out = torch.zeros(labels.shape[0], num_classes, dtype=torch.int32)
+    for b in range(lab.shape[0]):
+        v = lab[b][(lab[b] >= 0) & (lab[b] < num_classes)]
+        out[b] = torch.bincount(v, minlength=num_classes).int()
+    return out
+
+
+@torch.no_grad()
+def queue_class_sums(keys, labels, stride, num_classes):
+    B, D = keys.shape[:2]
+    lab = labels[:, ::stride, ::stride].reshape(B, -1)
+    feat = keys.reshape(B, D, -1)
+    sums = torch.zeros(B, num_classes, D)
+    for b in range(B):
+        for c in range(num_classes):
+            idx = (lab[b] == c).nonzero().reshape(-1)
+            if len(idx):
+                sums[b, c] = feat[b][:, idx].sum(1)
+    return sums
+
+
+@torch.no_grad()
+def queue_write_segments(sums, counts, job_img, job_cls, job_dst_row, segment_queue):
+    for b, c, r in zip(job_img.tolist(), job_cls.tolist(), job_dst_row.tolist()):
+        segment_queue[c, r] = F.normalize(sums[b, c] / counts[b, c].float(), p=2, dim=0)
+
+
+@torch.no_grad()
+def queue_write_pixels(keys, src_img, src_pos, dst_cls, dst_row, pixel_queue):
+    feat = keys.reshape(keys.shape[0], keys.shape[1], -1)
+    for b, p, c, r in zip(src_img.tolist(), src_pos.tolist(), dst_cls.tolist(), dst_row.tolist()):
+        pixel_queue[c, r] = F.normalize(feat[b, :, p], p=2, dim=0)
+
+
+def install(monkeypatch_or_none=None):
+    """Points the product's loss / model / trainer modules at this CPU restatement. TESTS AND THE cpu_baseline LEG
+    ONLY. Returns a function that restores the HIP binding."""
+    import sys
+    me = sys.modules[__name__]
+    import contrastiveseg_amd.lib.loss.loss_contrast as lc
+    import contrastiveseg_amd.lib.loss.loss_contrast_mem as lm
+    import contrastiveseg_amd.lib.loss.loss_helper as lh
+    import contrastiveseg_amd.lib.models.nets.hrnet as nh
+    import contrastiveseg_amd.segmentor.trainer_contrastive as tc
+    mods = [lc, lm, lh, nh, tc]
+    saved = [m.K for m in mods]
+    for m in mods:
+        if monkeypatch_or_none is not None:
+            monkeypatch_or_none.setattr(m, "K", me)
+        else:
+            m.K = me
+
+    def restore():
+        for m, k in zip(mods, saved):
+            m.K = k
+    return restore
