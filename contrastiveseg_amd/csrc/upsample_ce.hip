@@ -109,8 +109,10 @@ __global__ __launch_bounds__(1024) void ce_finish_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// backward: block owns a BT x BT low-res tile of d_seg for one image; it rebuilds the softmax statistics of
-// every hi-res pixel in the tile's footprint once, then each (ys, xs, k) task gathers its footprint.
+// backward: block owns a BT x BT low-res tile of d_seg for one image. It rebuilds the softmax statistics of every
+// hi-res pixel in the tile's footprint once (phase 1), then per class k: (A) d_k = coef * (softmax_k - onehot_k)
+// for every footprint pixel, (B) horizontal adjoint of the bilinear taps, (C) vertical adjoint -> d_seg[k] tile.
+// The separable form keeps all 64 lanes busy and evaluates every exp once; no atomics.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ seg, const int64_t* __restrict__ target,
                                                      const float* __restrict__ weight, CeDims d, int nY_max,
@@ -119,15 +121,19 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ s
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int SR = BT + 2;  // staged seg rows/cols (tile + 1 halo each side)
     const int plane = SR * SR;
+    const int nF = nY_max * nX_max;
     float* seg_t = smem;                          // [K][SR][SR]
-    float* f_lse = seg_t + d.K * plane;           // [nY_max*nX_max]
-    float* f_coef = f_lse + nY_max * nX_max;      // [nY_max*nX_max]
-    int* f_tgt = (int*)(f_coef + nY_max * nX_max);  // [nY_max*nX_max]
-    int* yi0 = f_tgt + nY_max * nX_max;           // [nY_max] y0 of each footprint row
+    float* f_lse = seg_t + d.K * plane;           // [nF]
+    float* f_coef = f_lse + nF;                   // [nF]
+    int* f_tgt = (int*)(f_coef + nF);             // [nF]
+    float* dk = (float*)(f_tgt + nF);             // [nF]   d_k of the current class
+    float* hrow = dk + nF;                        // [nY_max][BT] horizontally reduced
+    int* yi0 = (int*)(hrow + nY_max * BT);        // [nY_max] y0 of each footprint row
     float* yl1 = (float*)(yi0 + nY_max);
     int* xi0 = (int*)(yl1 + nY_max);
     float* xl1 = (float*)(xi0 + nX_max);
-    __shared__ int rng[4];  // Y_lo, nY, X_lo, nX
+    __shared__ int rng[4];         // Y_lo, nY, X_lo, nX
+    __shared__ int lo_hi[4][BT];   // per tile row: fy_lo, fy_hi ; per tile col: fx_lo, fx_hi (inclusive)
 
     const int tiles_x = (d.w + BT - 1) / BT, tiles_y = (d.h + BT - 1) / BT;
     int blk = blockIdx.x;
@@ -136,8 +142,9 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ s
     const int b = blk / tiles_y;
     const int ys0 = ty * BT, xs0 = tx * BT;
     const int sr0 = ys0 - 1, sc0 = xs0 - 1;  // staged region origin (may be -1)
+    const int tid = threadIdx.x;
 
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         // hi-res rows whose y0 lies in [ys0-1, ys0+BT-1] (their y0 or y1 tap can hit the tile)
         int lo = 0, hi = d.H - 1;
         if (d.sy > 0.f) {
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ s
         }
         rng[2] = lo; rng[3] = max(0, hi - lo + 1);
     }
-    for (int e = threadIdx.x; e < d.K * plane; e += 256) {
+    for (int e = tid; e < d.K * plane; e += 256) {
         const int k = e / plane, rem = e - k * plane;
         const int r = sr0 + rem / SR, c = sc0 + rem % SR;
         float v = 0.f;
@@ -165,20 +172,33 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ s
     }
     __syncthreads();
     const int Y_lo = rng[0], nY = min(rng[1], nY_max), X_lo = rng[2], nX = min(rng[3], nX_max);
-    for (int e = threadIdx.x; e < nY; e += 256) {
+    for (int e = tid; e < nY; e += 256) {
         int i0, i1; float l1;
         tap(d.sy, d.h, Y_lo + e, i0, i1, l1);
         yi0[e] = i0; yl1[e] = l1;
     }
-    for (int e = threadIdx.x; e < nX; e += 256) {
+    for (int e = tid; e < nX; e += 256) {
         int i0, i1; float l1;
         tap(d.sx, d.w, X_lo + e, i0, i1, l1);
         xi0[e] = i0; xl1[e] = l1;
     }
     __syncthreads();
+    // footprint index ranges per tile row / column (y0 in {s-1, s})
+    if (tid < 2 * BT) {
+        const bool is_x = tid >= BT;
+        const int s = (is_x ? xs0 : ys0) + (tid & (BT - 1));
+        const int n = is_x ? nX : nY;
+        const int* i0 = is_x ? xi0 : yi0;
+        int lo = n, hi = -1;
+        for (int f = 0; f < n; ++f) {
+            if (i0[f] >= s - 1 && i0[f] <= s) { lo = min(lo, f); hi = f; }
+        }
+        lo_hi[is_x ? 2 : 0][tid & (BT - 1)] = lo;
+        lo_hi[is_x ? 3 : 1][tid & (BT - 1)] = hi;
+    }
     const float gscale = d_loss[0] / out[1];
     // phase 1: softmax statistics of every footprint pixel
-    for (int e = threadIdx.x; e < nY * nX; e += 256) {
+    for (int e = tid; e < nY * nX; e += 256) {
         const int fy = e / nX, fx = e - fy * nX;
         const int Y = Y_lo + fy, X = X_lo + fx;
         const int64_t t64 = target[((size_t)b * d.H + Y) * d.W + X];
@@ -204,46 +224,61 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ s
         f_lse[e] = lse; f_coef[e] = coef; f_tgt[e] = t;
     }
     __syncthreads();
-    // phase 2: gather
-    const int n_tasks = d.K * BT * BT;
-    for (int task = threadIdx.x; task < n_tasks; task += 256) {
-        const int k = task / (BT * BT), rem = task - k * BT * BT;
-        const int ys = ys0 + rem / BT, xs = xs0 + rem % BT;
-        if (ys >= d.h || xs >= d.w) continue;
+    for (int k = 0; k < d.K; ++k) {
         const float* pl = seg_t + k * plane;
-        float acc = 0.f;
-        for (int fy = 0; fy < nY; ++fy) {
-            const int y0 = yi0[fy];
-            if (y0 > ys) break;
-            if (y0 < ys - 1) continue;
-            const int y1 = y0 + (y0 < d.h - 1 ? 1 : 0);
-            const float ly1 = yl1[fy], ly0 = 1.f - ly1;
-            float wy = 0.f;
-            if (y0 == ys) wy += ly0;
-            if (y1 == ys) wy += ly1;
-            if (wy == 0.f) continue;
-            float racc = 0.f;
-            for (int fx = 0; fx < nX; ++fx) {
-                const int x0 = xi0[fx];
-                if (x0 > xs) break;
-                if (x0 < xs - 1) continue;
-                const int x1 = x0 + (x0 < d.w - 1 ? 1 : 0);
-                const float lx1 = xl1[fx], lx0 = 1.f - lx1;
-                float wx = 0.f;
-                if (x0 == xs) wx += lx0;
-                if (x1 == xs) wx += lx1;
-                const int e = fy * nX + fx;
-                const float coef = f_coef[e];
-                if (wx == 0.f || coef == 0.f) continue;
+        // (A) d_k at every footprint pixel
+        for (int e = tid; e < nY * nX; e += 256) {
+            const float coef = f_coef[e];
+            float dv = 0.f;
+            if (coef != 0.f) {
+                const int fy = e / nX, fx = e - fy * nX;
+                const int y0 = yi0[fy], x0 = xi0[fx];
+                const int y1 = y0 + (y0 < d.h - 1 ? 1 : 0), x1 = x0 + (x0 < d.w - 1 ? 1 : 0);
+                const float ly1 = yl1[fy], lx1 = xl1[fx], ly0 = 1.f - ly1, lx0 = 1.f - lx1;
                 const int o00 = (y0 - sr0) * SR + (x0 - sc0), o01 = (y0 - sr0) * SR + (x1 - sc0);
                 const int o10 = (y1 - sr0) * SR + (x0 - sc0), o11 = (y1 - sr0) * SR + (x1 - sc0);
                 const float v = ly0 * (lx0 * pl[o00] + lx1 * pl[o01]) + ly1 * (lx0 * pl[o10] + lx1 * pl[o11]);
-                const float p = expf(v - f_lse[e]);
-                racc += wx * coef * (p - (f_tgt[e] == k ? 1.f : 0.f));
+                dv = coef * (expf(v - f_lse[e]) - (f_tgt[e] == k ? 1.f : 0.f));
             }
-            acc += wy * racc;
+            dk[e] = dv;
         }
-        d_seg[(((size_t)b * d.K + k) * d.h + ys) * d.w + xs] = acc;
+        __syncthreads();
+        // (B) horizontal adjoint: hrow[fy][xl] = sum_fx wx(fx, xs) * d_k[fy][fx]
+        for (int e = tid; e < nY * BT; e += 256) {
+            const int fy = e / BT, xl = e - fy * BT;
+            const int xs = xs0 + xl;
+            float acc = 0.f;
+            for (int fx = lo_hi[2][xl]; fx <= lo_hi[3][xl]; ++fx) {
+                const int x0 = xi0[fx];
+                const int x1 = x0 + (x0 < d.w - 1 ? 1 : 0);
+                const float lx1 = xl1[fx];
+                float wx = 0.f;
+                if (x0 == xs) wx += 1.f - lx1;
+                if (x1 == xs) wx += lx1;
+                acc += wx * dk[fy * nX + fx];
+            }
+            hrow[e] = acc;
+        }
+        __syncthreads();
+        // (C) vertical adjoint -> output tile of class k
+        if (tid < BT * BT) {
+            const int yl = tid / BT, xl = tid - yl * BT;
+            const int ys = ys0 + yl, xs = xs0 + xl;
+            if (ys < d.h && xs < d.w) {
+                float acc = 0.f;
+                for (int fy = lo_hi[0][yl]; fy <= lo_hi[1][yl]; ++fy) {
+                    const int y0 = yi0[fy];
+                    const int y1 = y0 + (y0 < d.h - 1 ? 1 : 0);
+                    const float ly1 = yl1[fy];
+                    float wy = 0.f;
+                    if (y0 == ys) wy += 1.f - ly1;
+                    if (y1 == ys) wy += ly1;
+                    acc += wy * hrow[fy * BT + xl];
+                }
+                d_seg[(((size_t)b * d.K + k) * d.h + ys) * d.w + xs] = acc;
+            }
+        }
+        // hrow is rewritten only after the next (A)+barrier; dk only after this (B)'s barrier: no extra sync needed
     }
 }
 
@@ -289,8 +324,8 @@ extern "C" int cseg_upsample_ce_bwd(const float* seg, const int64_t* target, con
     // footprint of BT low-res rows: hi-res rows with y0 in [ys0-1, ys0+BT-1]  ->  at most (BT+1)/sy + 2 rows
     const int nY_max = d.sy > 0.f ? (int)((float)(BT + 1) / d.sy) + 3 : H;
     const int nX_max = d.sx > 0.f ? (int)((float)(BT + 1) / d.sx) + 3 : W;
-    const size_t lds = sizeof(float) * ((size_t)K * (BT + 2) * (BT + 2) + 3 * (size_t)nY_max * nX_max +
-                                        2 * (size_t)nY_max + 2 * (size_t)nX_max);
+    const size_t lds = sizeof(float) * ((size_t)K * (BT + 2) * (BT + 2) + 4 * (size_t)nY_max * nX_max +
+                                        (size_t)nY_max * BT + 2 * (size_t)nY_max + 2 * (size_t)nX_max);
     CSEG_REQUIRE(lds <= 150 * 1024, "upsample_ce_bwd: K=%d scale %dx needs %zu B of LDS per block", K, H / h, lds);
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)ce_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=

@@ -28,7 +28,9 @@ def classify_partition(target, ignore_label, seg=None, predict=None, num_classes
     """lib/loss/loss_contrast.py:131-134 + :183 + the unique/nonzero bookkeeping of :35-64, on the device.
     Returns dict(counts [B,K,2], seg_off [B,K,2], part_idx [B,P], status [4], lab/pred [B,P] if want_maps)."""
     B, H, W = target.shape
+    target = target.contiguous()
     if seg is not None:
+        seg = seg.contiguous()          # NCHW planes are what the kernel walks (channels_last models included)
         _, K, h, w = seg.shape
         seg_p, pred_p = _p(seg, F32, "seg"), _null()
     else:
