@@ -212,6 +212,47 @@ def run_enq_case(name, c):
     print(name, "ptrs", sp.tolist(), pp.tolist())
 
 
+MODEL_CASES = {
+    "hrnet_w48_contrast": dict(backbone="hrnet48", K=19, B=2, H=64, W=128, seed=31, contrast={}),
+    "hrnet_w48_ocr_contrast": dict(backbone="hrnet48", K=19, B=2, H=64, W=96, seed=32, contrast={}),
+    "deeplab_v3_contrast": dict(backbone="deepbase_resnet101_dilated8", K=19, B=2, H=65, W=97, seed=33, contrast={}),
+}
+
+
+def model_input(c):
+    rs = np.random.RandomState(c["seed"])
+    return rs.standard_normal((c["B"], 3, c["H"], c["W"])).astype(np.float32)
+
+
+def freeze_dropout(net):
+    import torch.nn as nn
+    for m in net.modules():
+        if isinstance(m, (nn.Dropout, nn.Dropout2d)):
+            m.eval()            # the only stochastic layer; BN stays in train mode (batch statistics)
+
+
+def run_model_case(name, c):
+    """Reference model (seed 304 init, train-mode BN, dropout off) forward on a seeded input; stores the logits and a
+    strided slice of the embedding. The repo's models are seed-identical (tests/test_models_vs_reference.py), so a
+    GPU forward of the repo's model under the same seed must reproduce these within 1e-3."""
+    import torch
+    ref_shim.install()
+    from lib.models.model_manager import ModelManager
+    cfg = ref_shim.configer(num_classes=c["K"], model_name=name, backbone=c["backbone"], contrast=c["contrast"])
+    torch.manual_seed(304)
+    net = ModelManager(cfg).semantic_segmentor().train()
+    freeze_dropout(net)
+    with torch.no_grad():
+        out = net(torch.from_numpy(model_input(c)), with_embed=True)
+    res = {"seg": out["seg"].numpy(), "embed_s4": out["embed"][:, :, ::4, ::4].numpy().copy(),
+           "embed_shape": np.array(out["embed"].shape)}
+    if "seg_aux" in out:
+        res["seg_aux"] = out["seg_aux"].numpy()
+    np.savez_compressed(os.path.join(OUT, "model_%s.npz" % name), **res)
+    print("model_%s: seg %s absmax %.4f embed %s" % (name, tuple(out["seg"].shape), float(out["seg"].abs().max()),
+                                                      tuple(out["embed"].shape)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -223,6 +264,9 @@ def main():
     for name, c in ENQ_CASES.items():
         if a.only is None or a.only == name:
             run_enq_case(name, c)
+    for name, c in MODEL_CASES.items():
+        if a.only is None or a.only == name or a.only == "models":
+            run_model_case(name, c)
 
 
 if __name__ == "__main__":
