@@ -42,10 +42,13 @@ def parse():
                    help="weak: per-GPU batch 8 (global 8N); strong: global batch 8 split over the ranks")
     p.add_argument("--config", default=os.path.join(ROOT, "configs", "cityscapes", "H_48_D_4.json"))
     p.add_argument("--per-gpu-batch", type=int, default=8)
-    p.add_argument("--miopen-find", type=int, default=1, help="cudnn.benchmark (MIOpen find mode) on/off")
+    p.add_argument("--miopen-find", type=int, default=0,
+                   help="cudnn.benchmark = MIOpen exhaustive find (a 20+ min warm-up on a fresh box); default off: "
+                        "immediate mode + the tuned records shipped in contrastiveseg_amd/miopen_db")
     p.add_argument("--channels-last", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernels", action="store_true")
+    p.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--labels", choices=["uniform", "blocky"], default="uniform")
     return p.parse_args()
 
@@ -72,7 +75,7 @@ def build_trainer(args, world, device):
     return tr, cfg, next(iter(loader)), global_batch
 
 
-def time_kernel(fn, iters=20, warm=3):
+def time_kernel(fn, iters=20, warm=5):
     for _ in range(warm):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -158,44 +161,78 @@ def kernel_rooflines(device, B, K=19, H=512, W=1024, stride=4, D=256):
     return out
 
 
-def cpu_baseline():
-    """CPU port of the train step (model classes of this repo on CPU, device half = oracle/cpu_port.py)."""
+def usable_cores():
+    """Cores this process may really use: affinity mask and cgroup CPU quota, not the host's core count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline_worker():
+    """CPU port of the train step (model classes of this repo on CPU, device half = oracle/cpu_port.py).
+    Runs in its own process (bench.py --cpu-baseline-worker) so that a slow host can be cut off by a timeout."""
     from oracle import cpu_port
     from contrastiveseg_amd.lib.utils.tools.configer import Configer
     from contrastiveseg_amd.segmentor.tools.data_helper import SyntheticLoader
     from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
-    restore = cpu_port.install(None)
+    cpu_port.install(None)
+    cfg = Configer(configs=os.path.join(ROOT, "configs", "cityscapes", "H_48_D_4.json"))
+    cfg.update(["train", "batch_size"], 1)
+    cfg.update(["contrast", "warmup_iters"], 0)
+    cfg.update(["solver", "max_iters"], 10 ** 9)
+    cfg.add(["network", "pretrained"], None)
+    cfg.add(["network", "resume"], None)
+    cfg.add(["gpu"], None)
+    torch.manual_seed(304)
+    tr = Trainer(cfg, train_loader=[])
+    tr.module_runner.device = lambda: torch.device("cpu")
+    tr.seg_net.cpu().train()
+    tr.pixel_loss.cpu()
+    batch = next(iter(SyntheticLoader(cfg, torch.device("cpu"), length=1, seed=304, mode="uniform")))
+    tr.train_step(batch)                       # warm-up
+    n = 2
+    t0 = time.time()
+    for _ in range(n):
+        tr.train_step(batch)
+    dt = (time.time() - t0) / n
+    print("CPU_BASELINE " + json.dumps({
+        "value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+        "sample": "1 image 3x512x1024 per step, fwd+criterion+bwd+SGD, 1 warm-up + %d timed steps, fp32, "
+                  "%.2f s/step" % (n, dt)}))
+
+
+def cpu_baseline(timeout_s=240):
+    import subprocess
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
     try:
-        cfg = Configer(configs=os.path.join(ROOT, "configs", "cityscapes", "H_48_D_4.json"))
-        cfg.update(["train", "batch_size"], 1)
-        cfg.update(["contrast", "warmup_iters"], 0)
-        cfg.update(["solver", "max_iters"], 10 ** 9)
-        cfg.add(["network", "pretrained"], None)
-        cfg.add(["network", "resume"], None)
-        cfg.add(["gpu"], None)
-        cfg.update(["network", "bn_type"], "torchbn")
-        torch.manual_seed(304)
-        tr = Trainer(cfg, train_loader=[])
-        tr.seg_net.cpu().train()
-        tr.pixel_loss.cpu()
-        tr.module_runner.device = lambda: torch.device("cpu")
-        batch = next(iter(SyntheticLoader(cfg, torch.device("cpu"), length=1, seed=304, mode="uniform")))
-        tr.train_step(batch)                       # warm-up
-        t0 = time.time()
-        n = 1
-        for _ in range(n):
-            tr.train_step(batch)
-        dt = (time.time() - t0) / n
-    finally:
-        restore()
-    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "1 image 3x512x1024, fwd+criterion+bwd+SGD, 1 warm-up + %d timed step(s), fp32, %.2f s/step" % (n, dt)}
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], env=env,
+                             capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "cpu baseline exceeded %d s and was cut off" % timeout_s, "cores": usable_cores()}
+    for line in out.stdout.splitlines():
+        if line.startswith("CPU_BASELINE "):
+            return json.loads(line[len("CPU_BASELINE "):])
+    return {"error": "cpu baseline failed: " + out.stderr[-400:]}
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_worker:
+        cpu_baseline_worker()
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

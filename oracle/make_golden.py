@@ -215,7 +215,10 @@ def run_enq_case(name, c):
 MODEL_CASES = {
     "hrnet_w48_contrast": dict(backbone="hrnet48", K=19, B=2, H=64, W=128, seed=31, contrast={}),
     "hrnet_w48_ocr_contrast": dict(backbone="hrnet48", K=19, B=2, H=64, W=96, seed=32, contrast={}),
-    "deeplab_v3_contrast": dict(backbone="deepbase_resnet101_dilated8", K=19, B=2, H=65, W=97, seed=33, contrast={}),
+    # eval-mode BN here: the ASPP image-pool BN sees only B=2 values per channel in train mode, which amplifies
+    # fp32 rounding differences by up to 1/sqrt(eps) -- an ill-conditioned comparison, not a property of the model
+    "deeplab_v3_contrast": dict(backbone="deepbase_resnet101_dilated8", K=19, B=2, H=65, W=97, seed=33, contrast={},
+                                mode="eval"),
 }
 
 
@@ -242,6 +245,8 @@ def run_model_case(name, c):
     torch.manual_seed(304)
     net = ModelManager(cfg).semantic_segmentor().train()
     freeze_dropout(net)
+    if c.get("mode") == "eval":
+        net.eval()
     with torch.no_grad():
         out = net(torch.from_numpy(model_input(c)), with_embed=True)
     res = {"seg": out["seg"].numpy(), "embed_s4": out["embed"][:, :, ::4, ::4].numpy().copy(),
