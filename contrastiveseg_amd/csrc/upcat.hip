@@ -3,6 +3,7 @@
 // HBM-bound: forward writes each output element once with 16-byte stores, coarse maps are re-read from L2;
 // backward is the exact adjoint written as a gather (no atomics => deterministic).
 #include "cseg_common.h"
+#include "cseg_bilinear.h"
 
 namespace {
 
@@ -85,52 +86,6 @@ __global__ __launch_bounds__(256) void upcat_bwd_copy_kernel(const float* __rest
     if (e < hw) dx0[((size_t)b * C0 + c) * hw + e] = d_out[((size_t)b * Ctot + c) * hw + e];
 }
 
-// backward for an upsampled map: one thread per source element gathers its footprint with the forward's own
-// fp32 index arithmetic, so the result is the exact adjoint.
-__global__ __launch_bounds__(256) void upcat_bwd_gather_kernel(const float* __restrict__ d_out, int Ctot, int coff,
-                                                               int Cm, int hs, int ws, int h0, int w0,
-                                                               float* __restrict__ dx) {
-    const int c = blockIdx.y, b = blockIdx.z;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= hs * ws) return;
-    const int ys = e / ws, xs = e - ys * ws;
-    const float sy = ac_scale(hs, h0), sx = ac_scale(ws, w0);
-    int y_lo = 0, y_hi = h0 - 1, x_lo = 0, x_hi = w0 - 1;
-    if (sy > 0.f) {
-        y_lo = max(0, (int)ceilf((float)(ys - 1) / sy) - 1);
-        y_hi = min(h0 - 1, (int)floorf((float)(ys + 1) / sy) + 1);
-    }
-    if (sx > 0.f) {
-        x_lo = max(0, (int)ceilf((float)(xs - 1) / sx) - 1);
-        x_hi = min(w0 - 1, (int)floorf((float)(xs + 1) / sx) + 1);
-    }
-    const float* g = d_out + ((size_t)b * Ctot + coff + c) * h0 * w0;
-    float acc = 0.f;
-    for (int y = y_lo; y <= y_hi; ++y) {
-        const float fy = sy * (float)y;
-        const int y0 = (int)fy;
-        const int y1 = y0 + (y0 < hs - 1 ? 1 : 0);
-        const float ly1 = fy - (float)y0;
-        float wy = 0.f;
-        if (y0 == ys) wy += 1.f - ly1;
-        if (y1 == ys) wy += ly1;
-        if (wy == 0.f) continue;
-        float racc = 0.f;
-        for (int x = x_lo; x <= x_hi; ++x) {
-            const float fx = sx * (float)x;
-            const int x0 = (int)fx;
-            const int x1 = x0 + (x0 < ws - 1 ? 1 : 0);
-            const float lx1 = fx - (float)x0;
-            float wx = 0.f;
-            if (x0 == xs) wx += 1.f - lx1;
-            if (x1 == xs) wx += lx1;
-            if (wx != 0.f) racc += wx * g[(size_t)y * w0 + x];
-        }
-        acc += wy * racc;
-    }
-    dx[(((size_t)b * Cm + c) * hs + ys) * ws + xs] = acc;
-}
-
 int fill_maps(UpcatMaps* m, const int* C, const int* hs, const int* ws, int n_maps) {
     CSEG_REQUIRE(n_maps >= 1 && n_maps <= 4, "upcat: n_maps=%d not in [1,4]", n_maps);
     m->n = n_maps;
@@ -182,8 +137,8 @@ extern "C" int cseg_upcat_bwd(const float* d_out, const int* C, const int* hs, c
     for (int i = 1; i < n_maps; ++i) {
         if (!d_xs[i]) continue;
         dim3 grid((hs[i] * ws[i] + 255) / 256, C[i], B);
-        hipLaunchKernelGGL(upcat_bwd_gather_kernel, grid, dim3(256), 0, stream, d_out, Ctot, m.coff[i], C[i], hs[i],
-                           ws[i], h0, w0, d_xs[i]);
+        hipLaunchKernelGGL((bilinear_adjoint_gather_kernel<false>), grid, dim3(256), 0, stream, d_out, Ctot, m.coff[i], C[i], hs[i],
+                           ws[i], h0, w0, nullptr, d_xs[i]);
         CSEG_CHECK_LAUNCH("upcat_bwd_gather_kernel");
     }
     return 1;

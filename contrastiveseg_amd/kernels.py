@@ -255,6 +255,49 @@ def upsample_concat(feats):
     return UpsampleConcat.apply(*feats)
 
 
+class FuseSumReLU(Function):
+    """out = relu(sum(same-resolution terms) + sum(bilinear-upsampled coarse terms)) in one kernel; the exchange
+    step of HighResolutionModule.forward (hrnet_backbone.py:271-286 of the reference)."""
+
+    @staticmethod
+    def forward(ctx, n_same, *terms):
+        if n_same < 1:
+            raise RuntimeError("fuse_sum_relu needs at least one same-resolution term")
+        terms = [t.contiguous() for t in terms]
+        same, low = terms[:n_same], terms[n_same:]
+        B, C, h, w = same[0].shape
+        out = torch.empty(B, C, h, w, dtype=F32, device=terms[0].device)
+        sp = (ctypes.c_void_p * max(1, len(same)))(*[_p(t, F32, "same").value for t in same])
+        lp = (ctypes.c_void_p * max(1, len(low)))(*([_p(t, F32, "low").value for t in low] or [None]))
+        lh = [t.shape[2] for t in low]
+        lw = [t.shape[3] for t in low]
+        _hip.call("cseg_fuse_sum_fwd", sp, len(same), lp, _int_arr(lh or [1]), _int_arr(lw or [1]), len(low), B, C, h, w,
+                  1, _p(out, F32, "out"), _hip.stream_ptr())
+        ctx.save_for_backward(out)
+        ctx.meta = (len(same), lh, lw, B, C, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        n_same, lh, lw, B, C, h, w = ctx.meta
+        g = g.contiguous()
+        need_same = any(ctx.needs_input_grad[1:1 + n_same])
+        g_same = torch.empty_like(out) if need_same else None
+        d_low = [torch.empty(B, C, lh[i], lw[i], dtype=F32, device=g.device)
+                 if ctx.needs_input_grad[1 + n_same + i] else None for i in range(len(lh))]
+        dl = (ctypes.c_void_p * max(1, len(d_low)))(*([t.data_ptr() if t is not None else None for t in d_low] or [None]))
+        _hip.call("cseg_fuse_sum_bwd", _p(g, F32, "d_out"), _p(out, F32, "out"), _int_arr(lh or [1]), _int_arr(lw or [1]),
+                  len(lh), B, C, h, w, _p(g_same, F32, "g_same") if need_same else _null(), dl, _hip.stream_ptr())
+        grads = [g_same if ctx.needs_input_grad[1 + i] else None for i in range(n_same)]
+        return (None,) + tuple(grads) + tuple(d_low)
+
+
+def fuse_sum_relu(same, low):
+    """same: list of [B,C,h,w]; low: list of [B,C,hs,ws] coarser maps (upsampled with align_corners=True)."""
+    return FuseSumReLU.apply(len(same), *same, *low)
+
+
 # ----------------------------------------------------------------------------------------------------------
 # segmentation term: upsample + weighted CE
 # ----------------------------------------------------------------------------------------------------------

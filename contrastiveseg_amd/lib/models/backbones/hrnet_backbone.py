@@ -3,12 +3,13 @@
 load unchanged and the same torch seed gives identical random initialisation.
 
 The network is expressed as data (stage table below) plus three small module kinds; conv / BN / ReLU execute on
-MIOpen through PyTorch-ROCm, the cross-resolution upsample+sum of the fuse step uses torch's bilinear kernel.
+MIOpen through PyTorch-ROCm; the cross-resolution exchange (sum of same-resolution terms + bilinear-upsampled
+coarse terms + ReLU, reference :271-286) is one HIP kernel per output branch (cseg_fuse_sum_fwd/bwd).
 Factory keys follow lib/models/backbones/hrnet/hrnet_backbone.py:742-803 ('hrnet18' ... 'hrnet64'); BN is hard-wired
 to torch SyncBN with momentum 0.1 exactly as the reference factory does (:773)."""
 import torch.nn as nn
-import torch.nn.functional as F
 
+from contrastiveseg_amd import kernels as K
 from contrastiveseg_amd.lib.models.tools.module_helper import ModuleHelper
 
 # width -> per-stage (modules, blocks per branch); channel list is width * (1, 2, 4, 8)[:branches]
@@ -115,15 +116,9 @@ class HighResolutionModule(nn.Module):
             return x
         outs = []
         for i, row in enumerate(self.fuse_layers):
-            y = x[0] if i == 0 else row[0](x[0])
-            for j in range(1, self.num_branches):
-                if j == i:
-                    y = y + x[j]
-                elif j > i:
-                    y = y + F.interpolate(row[j](x[j]), size=x[i].shape[-2:], mode='bilinear', align_corners=True)
-                else:
-                    y = y + row[j](x[j])
-            outs.append(self.relu(y))
+            same = [x[j] if j == i else row[j](x[j]) for j in range(i + 1)]     # finer branches arrive strided
+            low = [row[j](x[j]) for j in range(i + 1, self.num_branches)]       # coarser ones: 1x1 conv + BN
+            outs.append(K.fuse_sum_relu(same, low))                              # summed in branch order, then ReLU
         return outs
 
 

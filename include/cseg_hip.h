@@ -108,6 +108,20 @@ int cseg_upcat_bwd(const float* d_out, const int* C, const int* hs, const int* w
                    float* const* d_xs, cseg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * HRNet exchange unit: out = relu(sum_s same[s] + sum_l bilinear_up(low[l])), all terms with C channels.
+ * Replaces the chain of F.interpolate + add + ReLU in HighResolutionModule.forward
+ * (lib/models/backbones/hrnet/hrnet_backbone.py:271-286).  n_same <= 4, n_low <= 3.
+ *   bwd: g_same [B,C,h,w] = d_out * (out > 0) is the gradient of every same-resolution term (NULL to skip; pass
+ *   out_act = NULL when the forward ran without ReLU, then the same-resolution gradient is d_out itself);
+ *   d_low[l] [B,C,low_h[l],low_w[l]] = exact adjoint of the upsample applied to the masked gradient.
+ * ------------------------------------------------------------------------------------------------ */
+int cseg_fuse_sum_fwd(const float* const* same, int n_same, const float* const* low, const int* low_h,
+                      const int* low_w, int n_low, int B, int C, int h, int w, int relu, float* out,
+                      cseg_stream_t stream);
+int cseg_fuse_sum_bwd(const float* d_out, const float* out_act, const int* low_h, const int* low_w, int n_low, int B,
+                      int C, int h, int w, float* g_same, float* const* d_low, cseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Segmentation term: bilinear(align_corners=True) upsample of the logits to the label size fused with the
  * weighted cross entropy.  Replaces lib/loss/loss_contrast.py:180-181 + lib/loss/loss_helper.py:169-206
  * (nn.CrossEntropyLoss(weight, ignore_index, reduction mean)); the [B,K,H,W] tensor is never materialised.

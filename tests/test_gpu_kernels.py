@@ -211,6 +211,28 @@ def test_upsample_concat_matches_torch():
         assert np.allclose(out.detach().cpu().numpy(), o, rtol=1e-5, atol=5e-6)
 
 
+def test_fuse_sum_relu_matches_torch():
+    dev = _dev()
+    import torch.nn.functional as F
+    from contrastiveseg_amd import kernels as Kk
+    from oracle import cpu_port
+    torch.manual_seed(1)
+    for (B, C, h, w), n_same, lows in [((2, 6, 16, 32), 1, [(8, 16), (4, 8), (2, 4)]), ((2, 5, 8, 16), 2, [(4, 8), (2, 4)]),
+                                       ((1, 3, 13, 21), 3, [(7, 11)]), ((2, 4, 4, 8), 4, [])]:
+        same = [torch.randn(B, C, h, w, device=dev, requires_grad=True) for _ in range(n_same)]
+        low = [torch.randn(B, C, lh, lw, device=dev, requires_grad=True) for lh, lw in lows]
+        out = Kk.fuse_sum_relu(same, low)
+        ref = cpu_port.fuse_sum_relu(same, low)
+        assert torch.allclose(out, ref, rtol=1e-5, atol=5e-6), (out - ref).abs().max()
+        g = torch.randn_like(out)
+        got = torch.autograd.grad(out, same + low, g)
+        want = torch.autograd.grad(ref, same + low, g)
+        for a, b in zip(got, want):
+            # the ReLU mask may differ where |pre-activation| ~ 1e-7: compare away from those points
+            assert (a - b).abs().max() <= 1e-4 * max(1.0, b.abs().max().item()) or \
+                ((a - b).abs() > 1e-4).float().mean().item() < 1e-4, (a - b).abs().max()
+
+
 @pytest.mark.parametrize("B,Kc,h,w,H,W,weighted", [(2, 5, 16, 32, 64, 128, True), (2, 19, 13, 21, 97, 161, False),
                                                    (1, 171, 17, 9, 65, 33, True), (2, 7, 24, 40, 24, 40, True)])
 def test_upsample_ce_matches_torch_and_oracle(B, Kc, h, w, H, W, weighted):
@@ -238,3 +260,27 @@ def test_missing_gpu_tensor_is_refused():
     from contrastiveseg_amd import kernels as Kk
     with pytest.raises(RuntimeError):
         Kk.upsample_ce(torch.zeros(1, 3, 4, 4), torch.zeros(1, 8, 8, dtype=torch.long))
+
+
+@pytest.mark.parametrize("name", ["enq_a", "enq_b"])
+def test_trainer_enqueue_on_gpu_matches_reference_golden(name, golden_dir):
+    """segmentor/trainer_contrastive.py:102-138 of the reference vs the HIP queue kernels + host pointer logic."""
+    dev = _dev()
+    from oracle.make_golden import ENQ_CASES, enq_init, enq_inputs
+    from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
+    c = ENQ_CASES[name]
+    g = np.load(os.path.join(golden_dir, "%s.npz" % name))
+    me = Trainer.__new__(Trainer)
+    me.network_stride, me.memory_size, me.pixel_update_freq = c["network_stride"], c["memory_size"], c["pixel_update_freq"]
+    sq, pq = enq_init(c)
+    sq, pq = torch.from_numpy(sq).to(dev), torch.from_numpy(pq).to(dev)
+    sp = torch.zeros(c["K"], dtype=torch.long, device=dev)
+    pp = torch.zeros(c["K"], dtype=torch.long, device=dev)
+    torch.manual_seed(c["torch_seed"])
+    for r in range(c["rounds"]):
+        target, embed = enq_inputs(c, r)
+        me._dequeue_and_enqueue(torch.from_numpy(embed).to(dev), torch.from_numpy(target).to(dev), sq, sp, pq, pp)
+        assert np.array_equal(sp.cpu().numpy(), g["segment_ptr_%d" % r])
+        assert np.array_equal(pp.cpu().numpy(), g["pixel_ptr_%d" % r])
+        assert np.allclose(sq.cpu().numpy(), g["segment_queue_%d" % r], rtol=1e-5, atol=1e-6)
+        assert np.allclose(pq.cpu().numpy(), g["pixel_queue_%d" % r], rtol=1e-5, atol=1e-6)

@@ -19,8 +19,11 @@ def main():
     p.add_argument("--find", type=int, default=0)
     p.add_argument("--iters", type=int, default=5)
     p.add_argument("--tag", default="")
+    p.add_argument("--immediate", type=int, default=0)
     a = p.parse_args()
     torch.backends.cudnn.benchmark = bool(a.find)
+    if a.immediate:
+        torch.backends.miopen.immediate = True
     N, C, H, W = [int(v) for v in a.shape.split(",")]
     dev = "cuda"
     x = torch.randn(N, C, H, W, device=dev, requires_grad=True)
