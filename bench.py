@@ -150,6 +150,16 @@ def kernel_rooflines(device, B, K=19, H=512, W=1024, stride=4, D=256):
     go = torch.randn_like(o)
     entry("upcat_bwd", time_kernel(lambda: torch.autograd.grad(o, feats, go, retain_graph=True)), bytes_=in_b + out_b)
     del o, go, feats
+    # HRNet exchange unit, finest branch of a 4-branch module: 1 same-resolution term + 3 coarse terms, 48 channels
+    same = [torch.randn(B, 48, h, w, generator=g).to(device).requires_grad_(True)]
+    low = [torch.randn(B, 48, h >> i, w >> i, generator=g).to(device).requires_grad_(True) for i in (1, 2, 3)]
+    fb = (same[0].numel() * 2 + sum(t.numel() for t in low)) * 4
+    entry("fuse_sum_relu_fwd 48ch", time_kernel(lambda: Kn.fuse_sum_relu(same, low)), bytes_=fb)
+    fo = Kn.fuse_sum_relu(same, low)
+    fg = torch.randn_like(fo)
+    entry("fuse_sum_relu_bwd 48ch", time_kernel(lambda: torch.autograd.grad(fo, same + low, fg, retain_graph=True)),
+          bytes_=same[0].numel() * 4 * 3 + sum(t.numel() for t in low) * 4)
+    del fo, fg, same, low
     # segmentation term
     wt = torch.ones(K, device=device)
     sg = seg.clone().requires_grad_(True)

@@ -6,6 +6,7 @@ immediate mode picks the measured-fastest solver (e.g. the xdlops implicit-GEMM 
 3x3 720->720 head convolution instead of the 2.7x slower Winograd default) without paying a 20+ minute find on
 every fresh machine. The records are copied to a per-process scratch directory because MIOpen opens its user
 database read-write."""
+import atexit
 import os
 import shutil
 import tempfile
@@ -26,6 +27,7 @@ def configure_miopen(force=False):
         if f.endswith(".txt"):
             shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
     os.environ["MIOPEN_USER_DB_PATH"] = dst
+    atexit.register(shutil.rmtree, dst, True)
     return dst
 
 

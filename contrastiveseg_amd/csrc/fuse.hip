@@ -127,14 +127,11 @@ extern "C" int cseg_fuse_sum_bwd(const float* d_out, const float* out_act, const
     }
     for (int i = 0; i < n_low; ++i) {
         if (!d_low[i]) continue;
-        dim3 grid((low_h[i] * low_w[i] + 255) / 256, C, B);
         if (out_act)
-            hipLaunchKernelGGL((bilinear_adjoint_gather_kernel<true>), grid, dim3(256), 0, stream, d_out, C, 0, C,
-                               low_h[i], low_w[i], h, w, out_act, d_low[i]);
+            launch_bilinear_adjoint<true>(d_out, C, 0, C, low_h[i], low_w[i], h, w, B, out_act, d_low[i], stream);
         else
-            hipLaunchKernelGGL((bilinear_adjoint_gather_kernel<false>), grid, dim3(256), 0, stream, d_out, C, 0, C,
-                               low_h[i], low_w[i], h, w, nullptr, d_low[i]);
-        CSEG_CHECK_LAUNCH("bilinear_adjoint_gather_kernel");
+            launch_bilinear_adjoint<false>(d_out, C, 0, C, low_h[i], low_w[i], h, w, B, nullptr, d_low[i], stream);
+        CSEG_CHECK_LAUNCH("bilinear_adjoint (fuse)");
     }
     return 1;
 }

@@ -136,10 +136,8 @@ extern "C" int cseg_upcat_bwd(const float* d_out, const int* C, const int* hs, c
     }
     for (int i = 1; i < n_maps; ++i) {
         if (!d_xs[i]) continue;
-        dim3 grid((hs[i] * ws[i] + 255) / 256, C[i], B);
-        hipLaunchKernelGGL((bilinear_adjoint_gather_kernel<false>), grid, dim3(256), 0, stream, d_out, Ctot, m.coff[i], C[i], hs[i],
-                           ws[i], h0, w0, nullptr, d_xs[i]);
-        CSEG_CHECK_LAUNCH("upcat_bwd_gather_kernel");
+        launch_bilinear_adjoint<false>(d_out, Ctot, m.coff[i], C[i], hs[i], ws[i], h0, w0, B, nullptr, d_xs[i], stream);
+        CSEG_CHECK_LAUNCH("bilinear_adjoint (upcat)");
     }
     return 1;
 }

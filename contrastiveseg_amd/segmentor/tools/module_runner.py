@@ -47,7 +47,10 @@ class ModuleRunner(object):
         bucket_mb = 64
         if self.configer.exists('network', 'ddp_bucket_mb'):
             bucket_mb = self.configer.get('network', 'ddp_bucket_mb')
-        kwargs = dict(find_unused_parameters=False, gradient_as_bucket_view=True, bucket_cap_mb=bucket_mb,
+        find_unused = False          # e.g. deeplab_v3_contrast trained without its auxiliary head needs True
+        if self.configer.exists('network', 'ddp_find_unused'):
+            find_unused = bool(self.configer.get('network', 'ddp_find_unused'))
+        kwargs = dict(find_unused_parameters=find_unused, gradient_as_bucket_view=True, bucket_cap_mb=bucket_mb,
                       # SyncBN keeps BN buffers identical on all ranks; only the memory queues need rank 0's copy
                       broadcast_buffers=has_queues)
         if next(net.parameters()).is_cuda:
