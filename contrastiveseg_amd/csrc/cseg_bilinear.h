@@ -28,22 +28,21 @@ __device__ __forceinline__ void bl_fine_range(float s, int n_fine, int c_lo, int
     }
 }
 
-constexpr int BL_TY = 4;          // coarse rows per block
 constexpr int BL_MAX_TAPS = 40;   // fine columns touching one coarse column (2/scale + 1) -- up to 16x upsampling
 
-// grid = (ceil(hs / BL_TY), Cm, B); dynamic LDS = (nY_max * w0 + nY_max * ws) floats
+// grid = (ceil(hs / TY), Cm, B), TY coarse rows per block; dynamic LDS = (nY_max * w0 + nY_max * ws) floats
 template <bool MASKED>
 __global__ __launch_bounds__(256) void bilinear_adjoint_band_kernel(const float* __restrict__ d_out, int Ctot, int coff,
                                                                     int Cm, int hs, int ws, int h0, int w0, int nY_max,
-                                                                    const float* __restrict__ act,
+                                                                    int TY, const float* __restrict__ act,
                                                                     float* __restrict__ dx) {
     extern __shared__ __attribute__((aligned(16))) float bl_smem[];
     float* band = bl_smem;                 // [nY][w0]
     float* hbuf = bl_smem + nY_max * w0;   // [nY][ws]
     __shared__ int rng[2];
     const int c = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-    const int ys0 = blockIdx.x * BL_TY;
-    const int ys1 = min(hs - 1, ys0 + BL_TY - 1);
+    const int ys0 = blockIdx.x * TY;
+    const int ys1 = min(hs - 1, ys0 + TY - 1);
     const float sy = ac_scale(hs, h0), sx = ac_scale(ws, w0);
     if (tid == 0) {
         int lo, hi;
@@ -164,21 +163,23 @@ __global__ __launch_bounds__(256) void bilinear_adjoint_gather_kernel(const floa
     dx[(((size_t)b * Cm + c) * hs + ys) * ws + xs] = acc;
 }
 
-// Host-side dispatch: band kernel when one band fits in LDS and the tap count is bounded, gather otherwise.
+// Host-side dispatch: band kernel with the largest band that fits 64 KiB of LDS (fewer halo re-reads), gather otherwise.
 template <bool MASKED>
 static inline int launch_bilinear_adjoint(const float* d_out, int Ctot, int coff, int Cm, int hs, int ws, int h0, int w0,
                                           int B, const float* act, float* dx, hipStream_t stream) {
     const float sy = ac_scale(hs, h0), sx = ac_scale(ws, w0);
-    const int nY_max = sy > 0.f ? (int)((float)(BL_TY + 1) / sy) + 3 : h0;
     const int taps = sx > 0.f ? (int)(2.0f / sx) + 3 : w0;
-    const size_t lds = sizeof(float) * ((size_t)nY_max * w0 + (size_t)nY_max * ws);
-    if (ws <= 256 && taps <= BL_MAX_TAPS && lds <= 96 * 1024 && nY_max <= h0 + 2) {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)bilinear_adjoint_band_kernel<MASKED>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        dim3 grid((hs + BL_TY - 1) / BL_TY, Cm, B);
+    int TY = 0, nY_max = 0;
+    size_t lds = 0;
+    for (int ty = 32; ty >= 2; ty >>= 1) {
+        const int ny = sy > 0.f ? (int)((float)(ty + 1) / sy) + 3 : h0;
+        const size_t need = sizeof(float) * ((size_t)ny * w0 + (size_t)ny * ws);
+        if (need <= 64 * 1024) { TY = ty; nY_max = ny; lds = need; break; }
+    }
+    if (TY && ws <= 256 && taps <= BL_MAX_TAPS) {
+        dim3 grid((hs + TY - 1) / TY, Cm, B);
         hipLaunchKernelGGL((bilinear_adjoint_band_kernel<MASKED>), grid, dim3(256), lds, stream, d_out, Ctot, coff, Cm,
-                           hs, ws, h0, w0, nY_max, act, dx);
+                           hs, ws, h0, w0, nY_max, TY, act, dx);
     } else {
         dim3 grid((hs * ws + 255) / 256, Cm, B);
         hipLaunchKernelGGL((bilinear_adjoint_gather_kernel<MASKED>), grid, dim3(256), 0, stream, d_out, Ctot, coff, Cm,

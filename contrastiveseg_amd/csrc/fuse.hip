@@ -127,7 +127,9 @@ extern "C" int cseg_fuse_sum_bwd(const float* d_out, const float* out_act, const
     }
     for (int i = 0; i < n_low; ++i) {
         if (!d_low[i]) continue;
-        if (out_act)
+        if (g_same)   // masked gradient already materialised for the same-resolution terms: read it instead of 2 tensors
+            launch_bilinear_adjoint<false>(g_same, C, 0, C, low_h[i], low_w[i], h, w, B, nullptr, d_low[i], stream);
+        else if (out_act)
             launch_bilinear_adjoint<true>(d_out, C, 0, C, low_h[i], low_w[i], h, w, B, out_act, d_low[i], stream);
         else
             launch_bilinear_adjoint<false>(d_out, C, 0, C, low_h[i], low_w[i], h, w, B, nullptr, d_low[i], stream);
