@@ -29,9 +29,10 @@ __device__ __forceinline__ void bl_fine_range(float s, int n_fine, int c_lo, int
 }
 
 constexpr int BL_MAX_TAPS = 40;   // fine columns touching one coarse column (2/scale + 1) -- up to 16x upsampling
+constexpr int BL_TY = 4;          // coarse rows per block (larger bands measured slower: fewer, LDS-heavier blocks)
 
 // grid = (ceil(hs / TY), Cm, B), TY coarse rows per block; dynamic LDS = (nY_max * w0 + nY_max * ws) floats
-template <bool MASKED>
+template <bool MASKED, int TAPS>
 __global__ __launch_bounds__(256) void bilinear_adjoint_band_kernel(const float* __restrict__ d_out, int Ctot, int coff,
                                                                     int Cm, int hs, int ws, int h0, int w0, int nY_max,
                                                                     int TY, const float* __restrict__ act,
@@ -79,10 +80,10 @@ __global__ __launch_bounds__(256) void bilinear_adjoint_band_kernel(const float*
     if (grp < groups) {
         int x_lo, x_hi;
         bl_fine_range(sx, w0, xs, xs, x_lo, x_hi);
-        float wx[BL_MAX_TAPS];
-        const int nt = min(BL_MAX_TAPS, x_hi - x_lo + 1);
+        float wx[TAPS];
+        const int nt = min(TAPS, x_hi - x_lo + 1);
 #pragma unroll
-        for (int t = 0; t < BL_MAX_TAPS; ++t) {
+        for (int t = 0; t < TAPS; ++t) {
             float wv = 0.f;
             if (t < nt) {
                 int x0, x1; float l1;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void bilinear_adjoint_band_kernel(const float*
             const float* row = band + fy * w0 + x_lo;
             float acc = 0.f;
 #pragma unroll
-            for (int t = 0; t < BL_MAX_TAPS; ++t)
+            for (int t = 0; t < TAPS; ++t)
                 if (t < nt) acc += wx[t] * row[t];
             hbuf[fy * ws + xs] = acc;
         }
@@ -163,23 +164,27 @@ __global__ __launch_bounds__(256) void bilinear_adjoint_gather_kernel(const floa
     dx[(((size_t)b * Cm + c) * hs + ys) * ws + xs] = acc;
 }
 
-// Host-side dispatch: band kernel with the largest band that fits 64 KiB of LDS (fewer halo re-reads), gather otherwise.
+// Host-side dispatch: band kernel (tap count templated by the upsampling factor), gather when a band cannot fit.
+template <bool MASKED, int TAPS>
+static inline void launch_band(const float* d_out, int Ctot, int coff, int Cm, int hs, int ws, int h0, int w0, int B,
+                               int nY_max, size_t lds, const float* act, float* dx, hipStream_t stream) {
+    dim3 grid((hs + BL_TY - 1) / BL_TY, Cm, B);
+    hipLaunchKernelGGL((bilinear_adjoint_band_kernel<MASKED, TAPS>), grid, dim3(256), lds, stream, d_out, Ctot, coff, Cm,
+                       hs, ws, h0, w0, nY_max, BL_TY, act, dx);
+}
+
 template <bool MASKED>
 static inline int launch_bilinear_adjoint(const float* d_out, int Ctot, int coff, int Cm, int hs, int ws, int h0, int w0,
                                           int B, const float* act, float* dx, hipStream_t stream) {
     const float sy = ac_scale(hs, h0), sx = ac_scale(ws, w0);
     const int taps = sx > 0.f ? (int)(2.0f / sx) + 3 : w0;
-    int TY = 0, nY_max = 0;
-    size_t lds = 0;
-    for (int ty = 32; ty >= 2; ty >>= 1) {
-        const int ny = sy > 0.f ? (int)((float)(ty + 1) / sy) + 3 : h0;
-        const size_t need = sizeof(float) * ((size_t)ny * w0 + (size_t)ny * ws);
-        if (need <= 64 * 1024) { TY = ty; nY_max = ny; lds = need; break; }
-    }
-    if (TY && ws <= 256 && taps <= BL_MAX_TAPS) {
-        dim3 grid((hs + TY - 1) / TY, Cm, B);
-        hipLaunchKernelGGL((bilinear_adjoint_band_kernel<MASKED>), grid, dim3(256), lds, stream, d_out, Ctot, coff, Cm,
-                           hs, ws, h0, w0, nY_max, TY, act, dx);
+    const int nY_max = sy > 0.f ? (int)((float)(BL_TY + 1) / sy) + 3 : h0;
+    const size_t lds = sizeof(float) * ((size_t)nY_max * w0 + (size_t)nY_max * ws);
+    if (ws <= 256 && taps <= BL_MAX_TAPS && lds <= 64 * 1024) {
+        if (taps <= 8) launch_band<MASKED, 8>(d_out, Ctot, coff, Cm, hs, ws, h0, w0, B, nY_max, lds, act, dx, stream);
+        else if (taps <= 12) launch_band<MASKED, 12>(d_out, Ctot, coff, Cm, hs, ws, h0, w0, B, nY_max, lds, act, dx, stream);
+        else if (taps <= 24) launch_band<MASKED, 24>(d_out, Ctot, coff, Cm, hs, ws, h0, w0, B, nY_max, lds, act, dx, stream);
+        else launch_band<MASKED, BL_MAX_TAPS>(d_out, Ctot, coff, Cm, hs, ws, h0, w0, B, nY_max, lds, act, dx, stream);
     } else {
         dim3 grid((hs * ws + 255) / 256, Cm, B);
         hipLaunchKernelGGL((bilinear_adjoint_gather_kernel<MASKED>), grid, dim3(256), 0, stream, d_out, Ctot, coff, Cm,
