@@ -43,7 +43,11 @@ class _GradScale(torch.autograd.Function):
 
 def _counts_to_host(cp):
     """One D2H copy (the only host sync of the loss): counts + status."""
-    flat = torch.cat([cp["counts"].reshape(-1), cp["status"]]).cpu()
+    if "host_counts" in cp:
+        flat, done = cp["host_counts"]
+        done.synchronize()                       # waits for the side stream only
+    else:
+        flat = torch.cat([cp["counts"].reshape(-1), cp["status"]]).cpu()
     counts = flat[:-4].reshape(cp["counts"].shape).numpy()
     if int(flat[-4]) != 0:
         raise RuntimeError("PixelContrastLoss: %d label values are neither ignore_label nor in [0, num_classes); "
@@ -72,16 +76,40 @@ class PixelContrastLoss(nn.Module, ABC):
         if self.configer.exists('contrast', 'cross_rank_budget'):
             self.cross_rank_budget = self.configer.get('contrast', 'cross_rank_budget')
         assert self.cross_rank_budget in ('per_rank', 'global')
+        self._side = None            # side HIP stream for mining (created lazily on the first GPU call)
         self.last_selection = None   # {'sel_pix': i32 [N] (b*P+pixel, view-major), 'plan': SelectionPlan}
 
     # -- mining ------------------------------------------------------------------------------------------
-    def _mine(self, feats, labels, predict, seg):
+    def _mine(self, feats, labels, predict, seg, seg_ready=None):
+        """Runs cseg_classify_partition. With `seg_ready` (a HIP event recorded right after the logits were produced,
+        see nets/hrnet.py) the kernels and the counts D2H copy go to a side stream, so they -- and the host-side
+        selection plan that follows -- overlap the projection head still running on the compute stream."""
         B, Dm, h, w = feats.shape
-        if seg is not None:
-            cp = K.classify_partition(labels, self.ignore_label, seg=seg)
-        else:
-            cp = K.classify_partition(labels, self.ignore_label, predict=predict.contiguous(),
-                                      num_classes=self.configer.get('data', 'num_classes'), feat_hw=(h, w))
+
+        def run():
+            if seg is not None:
+                return K.classify_partition(labels, self.ignore_label, seg=seg)
+            return K.classify_partition(labels, self.ignore_label, predict=predict.contiguous(),
+                                        num_classes=self.configer.get('data', 'num_classes'), feat_hw=(h, w))
+        if seg_ready is None or seg is None or not seg.is_cuda:
+            return run()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=seg.device)
+        main = torch.cuda.current_stream(seg.device)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(seg_ready)
+            cp = run()
+            flat = torch.cat([cp["counts"].reshape(-1), cp["status"]])
+            host = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
+            host.copy_(flat, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        for t in cp.values():
+            t.record_stream(main)                # produced on the side stream, consumed on the compute stream
+        seg.record_stream(self._side)
+        labels.record_stream(self._side)
+        main.wait_event(done)
+        cp["host_counts"] = (host, done)
         return cp
 
     def _plan(self, counts, budget_mult=1):
@@ -93,14 +121,14 @@ class PixelContrastLoss(nn.Module, ABC):
         return plan
 
     # -- forward -----------------------------------------------------------------------------------------
-    def forward(self, feats, labels=None, predict=None, seg=None):
+    def forward(self, feats, labels=None, predict=None, seg=None, seg_ready=None):
         """feats [B,D,h,w] (L2-normalised embeddings), labels [B,H,W] long, and either `predict` [B,h,w] long
         (reference signature, loss_contrast.py:130) or `seg` [B,K,h,w] logits (argmax fused into the mining
         kernel)."""
         assert labels is not None and (predict is not None or seg is not None)
         B, Dm, h, w = feats.shape
         P = h * w
-        cp = self._mine(feats, labels, predict, seg)
+        cp = self._mine(feats, labels, predict, seg, seg_ready)
         world = D.get_world_size()
         if world > 1 and self.cross_rank:
             return self._forward_cross_rank(feats, cp, P, world)
@@ -118,7 +146,7 @@ class PixelContrastLoss(nn.Module, ABC):
         rank = D.get_rank()
         B = feats.shape[0]
         dev = feats.device
-        local = torch.cat([cp["counts"].reshape(-1), cp["status"]])
+        local = torch.cat([cp["counts"].reshape(-1), cp["status"]])      # compute stream (waits on the side stream)
         gathered = [torch.empty_like(local) for _ in range(world)]
         dist.all_gather(gathered, local)                       # RCCL, B*K*2+4 ints per rank
         host = torch.stack(gathered).cpu()
@@ -181,7 +209,7 @@ class ContrastCELoss(nn.Module, ABC):
         seg = preds['seg']
         embedding = preds['embed']
         loss = self.seg_criterion(seg, target)                       # upsample fused into the CE kernel
-        loss_contrast = self.contrast_criterion(embedding, target, seg=seg)
+        loss_contrast = self.contrast_criterion(embedding, target, seg=seg, seg_ready=preds.get('seg_ready'))
         if with_embed is True:
             return loss + self.loss_weight * loss_contrast
         return loss + 0 * loss_contrast  # same trick as the reference: keeps every parameter in the DDP graph
@@ -210,7 +238,7 @@ class ContrastAuxCELoss(nn.Module, ABC):
         seg_aux = preds['seg_aux']
         embedding = preds['embed']
         loss = self.seg_criterion([seg_aux, seg], target)
-        loss_contrast = self.contrast_criterion(embedding, target, seg=seg)
+        loss_contrast = self.contrast_criterion(embedding, target, seg=seg, seg_ready=preds.get('seg_ready'))
         if with_embed is True:
             return loss + self.loss_weight * loss_contrast
         return loss + 0 * loss_contrast

@@ -21,7 +21,7 @@ from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
 
 class PixelContrastLoss(_SelfPixelContrastLoss):
     def forward(self, feats, labels=None, predict=None, queue=None, seg=None, segment_queue=None,
-                pixel_queue=None):
+                pixel_queue=None, seg_ready=None):
         """Reference signature is (feats, labels, predict, queue) with queue = cat(segment, pixel) [K, 2*ms, D]
         (:154, :221). Passing the two queues separately avoids that concat."""
         if queue is not None and segment_queue is None:
@@ -29,10 +29,10 @@ class PixelContrastLoss(_SelfPixelContrastLoss):
             segment_queue = queue[:, :ms].contiguous()
             pixel_queue = queue[:, ms:].contiguous()
         if segment_queue is None:
-            return super(PixelContrastLoss, self).forward(feats, labels, predict=predict, seg=seg)
+            return super(PixelContrastLoss, self).forward(feats, labels, predict=predict, seg=seg, seg_ready=seg_ready)
         B, Dm, h, w = feats.shape
         P = h * w
-        cp = self._mine(feats, labels, predict, seg)
+        cp = self._mine(feats, labels, predict, seg, seg_ready)
         plan = self._plan(_counts_to_host(cp))
         dev = feats.device
         sel_pos = torch.from_numpy(plan.row_img.astype(np.int32) * P + plan.row_off).to(dev, non_blocking=True)
@@ -71,7 +71,7 @@ class ContrastCELoss(nn.Module, ABC):
         loss = self.seg_criterion(seg, target)
         if segment_queue is not None and pixel_queue is not None:
             loss_contrast = self.contrast_criterion(embedding, target, seg=seg, segment_queue=segment_queue,
-                                                    pixel_queue=pixel_queue)
+                                                    pixel_queue=pixel_queue, seg_ready=preds.get('seg_ready'))
         else:
             loss_contrast = 0
         if with_embed is True:

@@ -30,7 +30,14 @@ class HRNet_W48_CONTRAST(nn.Module):
 
     def forward(self, x_, with_embed=False, is_eval=False):
         feats = K.upsample_concat(self.backbone(x_))
-        return {'seg': self.cls_head(feats), 'embed': self.proj_head(feats)}
+        out = {'seg': self.cls_head(feats)}
+        if out['seg'].is_cuda and self.training:
+            # lets the criterion start anchor mining (and its one host round trip) on a side HIP stream while the
+            # projection head below is still running on the compute stream (lib/loss/loss_contrast.py)
+            out['seg_ready'] = torch.cuda.Event()
+            out['seg_ready'].record()
+        out['embed'] = self.proj_head(feats)
+        return out
 
 
 class HRNet_W48_OCR_CONTRAST(nn.Module):
@@ -88,4 +95,5 @@ class HRNet_W48_MEM(nn.Module):
             return self.encoder_q(im_q, with_embed=with_embed)
         ret = self.encoder_q(im_q)
         q = ret['embed']
-        return {'seg': ret['seg'], 'embed': q, 'key': q.detach(), 'lb_key': lb_q.detach()}
+        ret.update({'key': q.detach(), 'lb_key': lb_q.detach()})
+        return ret

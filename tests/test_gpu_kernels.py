@@ -284,3 +284,32 @@ def test_trainer_enqueue_on_gpu_matches_reference_golden(name, golden_dir):
         assert np.array_equal(pp.cpu().numpy(), g["pixel_ptr_%d" % r])
         assert np.allclose(sq.cpu().numpy(), g["segment_queue_%d" % r], rtol=1e-5, atol=1e-6)
         assert np.allclose(pq.cpu().numpy(), g["pixel_queue_%d" % r], rtol=1e-5, atol=1e-6)
+
+
+def test_side_stream_mining_is_equivalent():
+    """The overlap path (mining on a side HIP stream behind a 'seg ready' event) gives the same selection and loss."""
+    dev = _dev()
+    from contrastiveseg_amd.lib.loss.loss_manager import SEG_LOSS_DICT
+    c = LOSS_CASES["mid_self"]
+    target, seg, embed, _ = case_inputs(c)
+    crit = SEG_LOSS_DICT[c["loss"]](_configer(c)).to(dev)
+    t_target = torch.from_numpy(target).to(dev)
+    res = []
+    for use_event in (False, True, True):
+        t_seg = torch.from_numpy(seg).to(dev).requires_grad_(True)
+        t_embed = torch.from_numpy(embed).to(dev).requires_grad_(True)
+        preds = {"seg": t_seg, "embed": t_embed}
+        if use_event:
+            preds["seg_ready"] = torch.cuda.Event()
+            preds["seg_ready"].record()
+            _ = torch.randn(4096, 4096, device=dev) @ torch.randn(4096, 4096, device=dev)   # keep the main stream busy
+        torch.manual_seed(c["torch_seed"])
+        loss = crit(preds, t_target, with_embed=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((float(loss.detach()), crit.contrast_criterion.last_selection["sel_pix"].cpu().numpy(),
+                    t_embed.grad.cpu().numpy(), t_seg.grad.cpu().numpy()))
+    for r in res[1:]:
+        assert r[0] == res[0][0]
+        assert np.array_equal(r[1], res[0][1])
+        assert np.array_equal(r[2], res[0][2]) and np.array_equal(r[3], res[0][3])
