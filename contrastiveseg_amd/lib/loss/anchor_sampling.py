@@ -45,10 +45,12 @@ def keep_rule(num_hard, num_easy, n_view):
     return kh, ke
 
 
-def plan_selection(counts, max_samples, max_views):
+def plan_selection(counts, max_samples, max_views, draw_images=None):
     """counts: CPU int tensor/array [B, K, 2] (hard, easy) for ALL images of the contrast set, image-major.
     Returns a SelectionPlan, or None when no class qualifies (reference returns (None, None), :44-45).
-    row_off[r] is the position inside image row_img[r]'s slice of part_idx."""
+    row_off[r] is the position inside image row_img[r]'s slice of part_idx.
+    draw_images=(lo, hi): draw (and consume the generator) only for images lo <= b < hi; rows of other images get
+    row_off = -1. Used by the cross-rank contrast set when every rank samples from its own generator stream."""
     cnt = np.asarray(counts, dtype=np.int64)
     B, K, _ = cnt.shape
     tot = cnt.sum(-1)
@@ -67,9 +69,16 @@ def plan_selection(counts, max_samples, max_views):
     sel = np.empty((T, n_view), dtype=np.int64)
     a = 0
     for b in range(B):
+        mine = draw_images is None or draw_images[0] <= b < draw_images[1]
         for c in np.nonzero(qual[b])[0]:
             nh, ne = int(cnt[b, c, 0]), int(cnt[b, c, 1])
             kh, ke = keep_rule(nh, ne, n_view)
+            if not mine:
+                sel[a, :] = -1
+                seg_img[a] = b
+                seg_cls[a] = c
+                a += 1
+                continue
             perm_h = torch.randperm(nh).numpy()              # :79  (CPU default generator)
             perm_e = torch.randperm(ne).numpy()              # :81
             sel[a, :kh] = off[b, 2 * c] + perm_h[:kh]

@@ -76,6 +76,13 @@ class PixelContrastLoss(nn.Module, ABC):
         if self.configer.exists('contrast', 'cross_rank_budget'):
             self.cross_rank_budget = self.configer.get('contrast', 'cross_rank_budget')
         assert self.cross_rank_budget in ('per_rank', 'global')
+        # RNG of the cross-rank set: 'local' = every rank draws only its own segments from its own generator (host
+        # cost independent of world size); 'global' = every rank draws for all global segments in global image order,
+        # which reproduces a single process on the concatenated batch index for index (host cost grows with world).
+        self.cross_rank_rng = 'local'
+        if self.configer.exists('contrast', 'cross_rank_rng'):
+            self.cross_rank_rng = self.configer.get('contrast', 'cross_rank_rng')
+        assert self.cross_rank_rng in ('local', 'global')
         self._side = None            # side HIP stream for mining (created lazily on the first GPU call)
         self.last_selection = None   # {'sel_pix': i32 [N] (b*P+pixel, view-major), 'plan': SelectionPlan}
 
@@ -112,8 +119,8 @@ class PixelContrastLoss(nn.Module, ABC):
         cp["host_counts"] = (host, done)
         return cp
 
-    def _plan(self, counts, budget_mult=1):
-        plan = plan_selection(counts, self.max_samples * budget_mult, self.max_views)
+    def _plan(self, counts, budget_mult=1, draw_images=None):
+        plan = plan_selection(counts, self.max_samples * budget_mult, self.max_views, draw_images)
         if plan is None:
             # the reference returns (None, None) and then fails on None.shape (loss_contrast.py:44-45, :92)
             raise RuntimeError("PixelContrastLoss: no (image, class) segment has more than max_views=%d pixels"
@@ -153,8 +160,10 @@ class PixelContrastLoss(nn.Module, ABC):
         if int(host[:, -4].sum()) != 0:
             raise RuntimeError("PixelContrastLoss: labels outside [0, num_classes) on some rank")
         counts = host[:, :-4].reshape((world * B,) + tuple(cp["counts"].shape[1:])).numpy()
-        # identical on every rank (same seed, same counts)
-        plan = self._plan(counts, world if self.cross_rank_budget == 'per_rank' else 1)
+        # T, n_view, labels and row order are identical on every rank (same counts); the drawn offsets are needed
+        # for the rank's own images only
+        plan = self._plan(counts, world if self.cross_rank_budget == 'per_rank' else 1,
+                          (rank * B, (rank + 1) * B) if self.cross_rank_rng == 'local' else None)
         T, V = plan.T, plan.n_view
         owner = plan.seg_img // B                               # rank of every segment
         mine = np.nonzero(owner == rank)[0]
