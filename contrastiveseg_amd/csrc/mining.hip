@@ -62,6 +62,22 @@ __global__ __launch_bounds__(CLS_THREADS) void classify_kernel(
     }
 }
 
+// 8 consecutive int16 keys of one lane: one 16-byte load when aligned and fully in range
+__device__ __forceinline__ void load_keys8(const int16_t* __restrict__ kb, int p0, int p_hi, bool vec_ok, int16_t (&ks)[8]) {
+    if (vec_ok && p0 + 8 <= p_hi) {
+        const int4 v = *reinterpret_cast<const int4*>(kb + p0);
+        const int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ks[2 * t] = (int16_t)(w[t] & 0xffff);
+            ks[2 * t + 1] = (int16_t)((unsigned)w[t] >> 16);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) ks[t] = (p0 + t < p_hi) ? kb[p0 + t] : (int16_t)-1;
+    }
+}
+
 constexpr int PART_THREADS = 1024;
 constexpr int PART_WAVES = PART_THREADS / 64;
 
@@ -92,16 +108,17 @@ __global__ __launch_bounds__(PART_THREADS) void partition_kernel(
     const int p_lo = wv * chunk;
     const int p_hi = min(P, p_lo + chunk);
     const int16_t* kb = key + (size_t)b * P;
+    const bool vec_ok = ((P & 7) == 0);      // every lane's 8-key group is then 16-byte aligned
     const int16_t k_hard = (int16_t)(2 * c), k_easy = (int16_t)(2 * c + 1);
     // pass 1: per-wave totals
     int n_h = 0, n_e = 0;
     for (int p0 = p_lo + lane * 8; p0 < p_hi; p0 += 64 * 8) {
+        int16_t ks[8];
+        load_keys8(kb, p0, p_hi, vec_ok, ks);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const int p = p0 + t;
-            const int16_t k = p < p_hi ? kb[p] : (int16_t)-1;
-            n_h += (k == k_hard);
-            n_e += (k == k_easy);
+            n_h += (ks[t] == k_hard);
+            n_e += (ks[t] == k_easy);
         }
     }
     n_h = wave_sum_i(n_h);
@@ -115,10 +132,9 @@ __global__ __launch_bounds__(PART_THREADS) void partition_kernel(
     for (int p0 = p_lo + lane * 8; p0 - lane * 8 < p_hi; p0 += 64 * 8) {  // wave-uniform trip count
         int16_t ks[8];
         int c_h = 0, c_e = 0;
+        load_keys8(kb, p0, p_hi, vec_ok, ks);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const int p = p0 + t;
-            ks[t] = p < p_hi ? kb[p] : (int16_t)-1;
             c_h += (ks[t] == k_hard);
             c_e += (ks[t] == k_easy);
         }

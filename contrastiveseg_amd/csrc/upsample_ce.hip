@@ -25,6 +25,42 @@ __device__ __forceinline__ void tap(float s, int n_in, int o, int& i0, int& i1, 
     l1 = f - (float)i0;
 }
 
+
+// log-sum-exp over the K bilinearly interpolated logits of one fine pixel (taps o00..o11 into the staged tile).
+// K <= 32: the values are kept in registers, one max pass + one exp per class (no divergent rescale);
+// larger K: online (running max) form. *vt receives the logit of class t (pass t = -1 to skip).
+__device__ __forceinline__ float pixel_lse(const float* __restrict__ tile, int plane, int K, int o00, int o01, int o10,
+                                           int o11, float ly0, float ly1, float lx0, float lx1, int t, float* vt) {
+    if (K <= 32) {
+        float v[32];
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            float x = -INFINITY;
+            if (k < K) {
+                const float* pl = tile + k * plane;
+                x = ly0 * (lx0 * pl[o00] + lx1 * pl[o01]) + ly1 * (lx0 * pl[o10] + lx1 * pl[o11]);
+                if (k == t) *vt = x;
+            }
+            v[k] = x;
+            m = fmaxf(m, x);
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) se += (k < K) ? expf(v[k] - m) : 0.f;
+        return m + logf(se);
+    }
+    float m = -INFINITY, se = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float* pl = tile + k * plane;
+        const float x = ly0 * (lx0 * pl[o00] + lx1 * pl[o01]) + ly1 * (lx0 * pl[o10] + lx1 * pl[o11]);
+        if (k == t) *vt = x;
+        if (x > m) { se = se * expf(m - x) + 1.f; m = x; }
+        else se += expf(x - m);
+    }
+    return m + logf(se);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------
@@ -67,16 +103,10 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ s
                 const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
                 const int o00 = (y0 - ry0) * cols_max + (x0 - rx0), o01 = (y0 - ry0) * cols_max + (x1 - rx0);
                 const int o10 = (y1 - ry0) * cols_max + (x0 - rx0), o11 = (y1 - ry0) * cols_max + (x1 - rx0);
-                float m = -INFINITY, se = 0.f, vt = 0.f;
-                for (int k = 0; k < d.K; ++k) {
-                    const float* pl = smem + k * plane;
-                    const float v = ly0 * (lx0 * pl[o00] + lx1 * pl[o01]) + ly1 * (lx0 * pl[o10] + lx1 * pl[o11]);
-                    if (k == t) vt = v;
-                    if (v > m) { se = se * expf(m - v) + 1.f; m = v; }
-                    else se += expf(v - m);
-                }
+                float vt = 0.f;
+                const float lse = pixel_lse(smem, plane, d.K, o00, o01, o10, o11, ly0, ly1, lx0, lx1, t, &vt);
                 const float wt = weight ? weight[t] : 1.f;
-                wnll = wt * (m + logf(se) - vt);
+                wnll = wt * (lse - vt);
                 wsum = wt;
             }
         }
@@ -211,14 +241,8 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ s
             const float ly1 = yl1[fy], lx1 = xl1[fx], ly0 = 1.f - ly1, lx0 = 1.f - lx1;
             const int o00 = (y0 - sr0) * SR + (x0 - sc0), o01 = (y0 - sr0) * SR + (x1 - sc0);
             const int o10 = (y1 - sr0) * SR + (x0 - sc0), o11 = (y1 - sr0) * SR + (x1 - sc0);
-            float m = -INFINITY, se = 0.f;
-            for (int k = 0; k < d.K; ++k) {
-                const float* pl = seg_t + k * plane;
-                const float v = ly0 * (lx0 * pl[o00] + lx1 * pl[o01]) + ly1 * (lx0 * pl[o10] + lx1 * pl[o11]);
-                if (v > m) { se = se * expf(m - v) + 1.f; m = v; }
-                else se += expf(v - m);
-            }
-            lse = m + logf(se);
+            float unused;
+            lse = pixel_lse(seg_t, plane, d.K, o00, o01, o10, o11, ly0, ly1, lx0, lx1, -1, &unused);
             coef = (weight ? weight[t] : 1.f) * gscale;
         }
         f_lse[e] = lse; f_coef[e] = coef; f_tgt[e] = t;
