@@ -313,3 +313,27 @@ def test_side_stream_mining_is_equivalent():
         assert r[0] == res[0][0]
         assert np.array_equal(r[1], res[0][1])
         assert np.array_equal(r[2], res[0][2]) and np.array_equal(r[3], res[0][3])
+
+
+def test_contrast_bank_reference_config_size():
+    """configs/cityscapes/H_48_D_4_MEM.json of the reference: memory_size 5000 -> 190 000 bank columns, max_views 1,
+    tau 0.07, <= 152 anchors. Bank mode (in place) must equal plain mode on the packed copy and the float64 oracle."""
+    dev = _dev()
+    from contrastiveseg_amd import kernels as Kk
+    rs = np.random.RandomState(9)
+    N, Kc, ms, D = 152, 19, 5000, 256
+    A = torch.from_numpy(_rand_unit(rs, N, D)).to(dev).requires_grad_(True)
+    y = torch.from_numpy(rs.randint(0, Kc, size=N).astype(np.int32)).to(dev)
+    sq = torch.from_numpy(_rand_unit(rs, Kc * ms, D).reshape(Kc, ms, D)).to(dev)
+    pq = torch.from_numpy(_rand_unit(rs, Kc * ms, D).reshape(Kc, ms, D)).to(dev)
+    l_bank = Kk.ContrastOnAnchors.apply(A, y, "bank", 0.07, 0.07, None, None, sq, pq)
+    (g_bank,) = torch.autograd.grad(l_bank, A)
+    queue = np.concatenate([sq.cpu().numpy(), pq.cpu().numpy()], axis=1)
+    want, dX = O.contrastive_mem(A.detach().cpu().numpy().reshape(N, 1, D), y.cpu().numpy(), queue, 0.07, 0.07,
+                                 return_grad=True)
+    assert abs(float(l_bank) - want) <= 2e-5 * abs(want), (float(l_bank), want)
+    assert np.allclose(g_bank.cpu().numpy(), dX.reshape(N, D), rtol=2e-3, atol=1e-7)
+    Xp, yp = O.sample_negative(queue)
+    l_plain = Kk.ContrastOnAnchors.apply(A, y, "plain", 0.07, 0.07, torch.from_numpy(Xp.astype(np.float32)).to(dev),
+                                         torch.from_numpy(yp.astype(np.int32)).to(dev), None, None)
+    assert abs(float(l_bank) - float(l_plain)) <= 1e-6 * abs(float(l_plain))

@@ -1,0 +1,103 @@
+"""Host-side drop-in surface: Configer / CLI override scheme (reference configer.py:47-145, main_contrastive.py:31-164),
+checkpoint interchange with the reference (module_runner.py:78-119, 168-226), optimizer / lr policy
+(optim_scheduler.py:46-98, trainer_contrastive.py:163-175). CPU only."""
+import os
+
+import pytest
+import torch
+
+from oracle import ref_shim
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cli_overrides_and_free_form_pairs():
+    from contrastiveseg_amd.lib.utils.tools.configer import Configer
+    from contrastiveseg_amd.main_contrastive import build_parser
+    args = build_parser().parse_args(["--configs", os.path.join(ROOT, "configs/cityscapes/H_48_D_4.json"), "--phase", "train",
+                                      "--model_name", "hrnet_w48_mem", "--loss_type", "mem_contrast_ce_loss",
+                                      "--max_iters", "123", "contrast.temperature", "0.07", "contrast.with_memory",
+                                      "True", "network.new_key", "[1, 2]", "data.tag", "plain-string"])
+    cfg = Configer(args_parser=args)
+    assert cfg.get("network", "model_name") == "hrnet_w48_mem"            # 'section:key' dest overrides the JSON
+    assert cfg.get("loss", "loss_type") == "mem_contrast_ce_loss"
+    assert cfg.get("solver", "max_iters") == 123
+    assert cfg.get("lr", "base_lr") == 0.01                                # None-valued flags keep the JSON value
+    assert cfg.get("contrast", "temperature") == 0.07                      # literal_eval'ed free-form pairs
+    assert cfg.get("contrast", "with_memory") is True
+    assert cfg.get("network", "new_key") == [1, 2]
+    assert cfg.get("data", "tag") == "plain-string"
+    assert cfg.get("phase") == "train" and cfg.exists("contrast", "loss_weight")
+    cfg.add(["iters"], 0)
+    cfg.plus_one("iters")
+    assert cfg.get("iters") == 1
+
+
+def _trainer(tmp=None, **over):
+    from contrastiveseg_amd.lib.utils.tools.configer import Configer
+    from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
+    cfg = Configer(configs=os.path.join(ROOT, "configs", "synthetic", "R_18_D_8_tiny.json"))
+    cfg.add(["network", "pretrained"], None)
+    cfg.add(["network", "resume"], over.get("resume"))
+    cfg.add(["gpu"], None)
+    cfg.update(["lr", "nbb_mult"], 10.0)
+    if tmp is not None:
+        cfg.update(["checkpoints", "checkpoints_dir"], str(tmp))
+        cfg.get("checkpoints")["checkpoints_root"] = None
+        cfg.add(["project_dir"], str(tmp))
+    return Trainer(cfg, train_loader=[]), cfg
+
+
+def test_param_groups_and_poly_schedule(monkeypatch):
+    from oracle import cpu_port
+    cpu_port.install(monkeypatch)
+    tr, cfg = _trainer()
+    g = tr.optimizer.param_groups
+    assert len(g) == 2 and g[0]["lr"] == 0.01 and abs(g[1]["lr"] - 0.1) < 1e-12     # backbone / head * nbb_mult
+    n_bb = sum(1 for k, _ in tr.seg_net.named_parameters() if "backbone" in k)
+    assert len(g[0]["params"]) == n_bb and len(g[0]["params"]) + len(g[1]["params"]) == len(list(tr.seg_net.parameters()))
+    assert g[0]["momentum"] == 0.9 and g[0]["weight_decay"] == 0.0005
+    tr.scheduler.step(50)
+    assert abs(tr.optimizer.param_groups[0]["lr"] - 0.01 * (1 - 50 / 100) ** 0.9) < 1e-12
+
+
+def test_checkpoint_roundtrip(tmp_path, monkeypatch):
+    from oracle import cpu_port
+    cpu_port.install(monkeypatch)
+    tr, cfg = _trainer(tmp_path)
+    cfg.update(["performance"], 0.5)
+    tr.module_runner.save_net(tr.seg_net, save_mode="performance")
+    name = cfg.get("checkpoints", "checkpoints_name")
+    paths = [os.path.join(dp, f) for dp, _, fs in os.walk(str(tmp_path)) for f in fs]
+    assert any(p.endswith("_latest.pth") for p in paths) and any(p.endswith("_max_performance.pth") for p in paths)
+    ck = torch.load([p for p in paths if p.endswith("_latest.pth")][0], map_location="cpu", weights_only=False)
+    assert set(ck) == {"config_dict", "state_dict"}                        # the reference's checkpoint format
+    tr2, _ = _trainer(resume=[p for p in paths if p.endswith("_latest.pth")][0])
+    for (k1, v1), (k2, v2) in zip(tr.seg_net.state_dict().items(), tr2.seg_net.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
+def test_reference_checkpoint_loads_unchanged(tmp_path, monkeypatch):
+    """A checkpoint written by the reference model ('module.' prefix of its DDP wrapper included) resumes here."""
+    from oracle import cpu_port
+    cpu_port.install(monkeypatch)
+    ref_shim.install()
+    from lib.models.model_manager import ModelManager as RefManager
+    torch.manual_seed(1)
+    ref = RefManager(ref_shim.configer(num_classes=19, model_name="hrnet_w48_contrast", backbone="hrnet48")) \
+        .semantic_segmentor()
+    path = os.path.join(str(tmp_path), "ref.pth")
+    torch.save({"config_dict": {}, "state_dict": {"module." + k: v for k, v in ref.state_dict().items()}}, path)
+    from contrastiveseg_amd.lib.models.model_manager import ModelManager
+    from contrastiveseg_amd.lib.utils.tools.configer import Configer
+    from contrastiveseg_amd.segmentor.tools.module_runner import ModuleRunner
+    cfg = Configer(config_dict={"data": {"num_classes": 19}, "gpu": None,
+                                "network": {"backbone": "hrnet48", "model_name": "hrnet_w48_contrast",
+                                            "bn_type": "torchsyncbn", "resume": path, "resume_strict": True,
+                                            "pretrained": None},
+                                "contrast": {"proj_dim": 256}})
+    torch.manual_seed(2)
+    net = ModuleRunner(cfg).load_net(ModelManager(cfg).semantic_segmentor())
+    for k, v in ref.state_dict().items():
+        assert torch.equal(net.state_dict()[k], v), k
