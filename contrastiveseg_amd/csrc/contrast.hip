@@ -4,8 +4,8 @@
 // Restated for parity in oracle/cseg_oracle.py:_contrast_core.
 //
 // Kernels
-//   s_gemm_kernel    S = A . C^T / tau           fp32 MFMA (v_mfma_f32_32x32x2_f32), one wave per 32x32 tile,
-//                                                operands streamed row-contiguously (16 B per lane) from L2
+//   s_gemm_kernel    S = A . C^T / tau           fp32 MFMA (v_mfma_f32_32x32x2_f32), 64x64 tile per block, operand
+//                                                tiles streamed with coalesced 16-B loads and staged in LDS
 //   row_pass_kernel  per anchor row: max, sum of negatives, positive count, mean log-prob of positives
 //   mean_kernel      loss = mean_i row_loss[i]  (fixed-order reduction: results are run-to-run deterministic)
 //   bwd_kernel       dA = dloss/tau . H . C,  H = G (+ G^T in self mode) rebuilt on the fly from S and the row
@@ -46,61 +46,116 @@ struct ColSrc {
         if (mode != 2) return j < M ? labs[j] : -0x7fffffff;
         return j < packed ? 1 + j / (2 * ms) : 0;
     }
+    // row pointers and labels of 4 consecutive columns j..j+3 with ONE integer division in bank mode
+    __device__ __forceinline__ void decode4(int j, const float* (&rp)[4], int (&lb)[4]) const {
+        if (mode != 2) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool ok = j + t < M;
+                rp[t] = ok ? rows + (size_t)(j + t) * D : nullptr;
+                lb[t] = ok ? labs[j + t] : -0x7fffffff;
+            }
+            return;
+        }
+        const int two = 2 * ms;
+        int c = j / two;              // class index - 1 of column j
+        int sl = j - c * two;         // slot inside the class block (segment queue first, then pixel queue)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (j + t < packed) {
+                const int cc = c + 1;
+                rp[t] = sl < ms ? segq + ((size_t)cc * ms + sl) * D : pixq + ((size_t)cc * ms + (sl - ms)) * D;
+                lb[t] = cc;
+            } else {
+                rp[t] = nullptr;      // zero tail of the bank (label 0) or beyond M
+                lb[t] = j + t < M ? 0 : -0x7fffffff;
+            }
+            if (++sl == two) { sl = 0; ++c; }
+        }
+    }
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // ---------------------------------------------------------------------------------------------------------
-// S = A . C^T / tau.  Block = 4 waves, each wave one 32x32 tile. ldS = M rounded up to 32.
+// S = A . C^T / tau.  Block = 4 waves = one 64 x 64 tile of S (2 x 2 waves of 32 x 32). The feature axis is walked
+// in chunks of 64 floats: both operand tiles are streamed from HBM/L2 with fully coalesced 16-byte loads (16 lanes
+// per 256-byte row segment), staged in LDS with a 68-float row stride (conflict-free ds_read_b128 for the
+// row-per-lane fragment reads), and the next chunk is prefetched into registers while the MFMAs of the current one
+// run. Inside a chunk lane half h = lane >> 5 covers features [32h, 32h+32): the reduction order is free as long as
+// A and B agree. ldS = M rounded up to 32.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void s_gemm_kernel(const float* __restrict__ A, int N, ColSrc col, float inv_tau,
-                                                     float* __restrict__ S, int ldS, int nJ, int n_tiles) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + wave;
-    if (t >= n_tiles) return;
-    const int I0 = (t / nJ) * 32, J0 = (t % nJ) * 32;
-    const int h = lane >> 5, r32 = lane & 31;
-    const int D = col.D, Dh = D >> 1;
-    const int i = I0 + r32, j = J0 + r32;
-    const float* ap = i < N ? A + (size_t)i * D + h * Dh : nullptr;
-    const float* cp = col.row(j);
-    if (cp) cp += h * Dh;
+constexpr int SG_T = 64;      // tile edge (rows and columns)
+constexpr int SG_KC = 64;     // features per chunk
+constexpr int SG_LD = 68;     // LDS row stride in floats
 
+__global__ __launch_bounds__(256) void s_gemm_kernel(const float* __restrict__ A, int N, ColSrc col, float inv_tau,
+                                                     float* __restrict__ S, int ldS, int nJb) {
+    __shared__ __attribute__((aligned(16))) float As[SG_T * SG_LD];
+    __shared__ __attribute__((aligned(16))) float Cs[SG_T * SG_LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int I0 = (blockIdx.x / nJb) * SG_T, J0 = (blockIdx.x % nJb) * SG_T;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int h = lane >> 5, r32 = lane & 31;
+    const int D = col.D;
+    // staging assignment: float4 index f = tid + 256*u -> row f>>4, 16-byte column f&15 (16 lanes per row segment)
+    const float* arow[4];
+    const float* crow[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = (tid + 256 * u) >> 4;
+        arow[u] = (I0 + r) < N ? A + (size_t)(I0 + r) * D : nullptr;
+        crow[u] = col.row(J0 + r);
+    }
+    const int c4 = (tid & 15) * 4;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 pa[4], pc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const bool ok = c4 < D;
+        pa[u] = (ok && arow[u]) ? ld4(arow[u] + c4) : z4;
+        pc[u] = (ok && crow[u]) ? ld4(crow[u] + c4) : z4;
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 a_cur[8], c_cur[8], a_nxt[8], c_nxt[8];
+    for (int kc = 0; kc < D; kc += SG_KC) {
+        __syncthreads();                                   // previous chunk's fragment reads are done
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const bool ok = 4 * q < Dh;
-        a_cur[q] = (ok && ap) ? ld4(ap + 4 * q) : z4;
-        c_cur[q] = (ok && cp) ? ld4(cp + 4 * q) : z4;
-    }
-    for (int kc = 0; kc < Dh; kc += 32) {
-        const int kn = kc + 32;
+        for (int u = 0; u < 4; ++u) {
+            const int r = (tid + 256 * u) >> 4;
+            *reinterpret_cast<float4*>(As + r * SG_LD + c4) = pa[u];
+            *reinterpret_cast<float4*>(Cs + r * SG_LD + c4) = pc[u];
+        }
+        __syncthreads();
+        const int kn = kc + SG_KC;
+        if (kn < D) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = kn + c4 < D;
+                pa[u] = (ok && arow[u]) ? ld4(arow[u] + kn + c4) : z4;
+                pc[u] = (ok && crow[u]) ? ld4(crow[u] + kn + c4) : z4;
+            }
+        }
+        const float* ap = As + (wi * 32 + r32) * SG_LD + h * 32;
+        const float* cp = Cs + (wj * 32 + r32) * SG_LD + h * 32;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const bool ok = kn + 4 * q < Dh;
-            a_nxt[q] = (ok && ap) ? ld4(ap + kn + 4 * q) : z4;
-            c_nxt[q] = (ok && cp) ? ld4(cp + kn + 4 * q) : z4;
+            const float4 a4 = *reinterpret_cast<const float4*>(ap + 4 * q);
+            const float4 b4 = *reinterpret_cast<const float4*>(cp + 4 * q);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
         }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].x, c_cur[q].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].y, c_cur[q].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].z, c_cur[q].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].w, c_cur[q].w, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { a_cur[q] = a_nxt[q]; c_cur[q] = c_nxt[q]; }
     }
-    // C layout: this lane holds column j, rows I0 + (r&3) + 8*(r>>2) + 4*h
+    // C layout: this lane holds column j, rows (r&3) + 8*(r>>2) + 4*h of the wave's 32 x 32 tile
+    const int j = J0 + wj * 32 + r32;
     if (j < ldS) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int ii = I0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ii = I0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (ii < N) S[(size_t)ii * ldS + j] = acc[r] * inv_tau;
         }
     }
@@ -174,8 +229,12 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ row
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Backward. grid = (nI * nDt, nsplit); block = 4 waves. Block (I, dt, split) owns column tiles
-// [split*per, (split+1)*per) and its waves interleave them; partial 32x32 tiles are summed through LDS.
+// Backward. grid = (nI * nDt, nsplit); block = 4 waves. Block (I, dt, split) owns one 32 x 32 tile of dA and the column
+// tiles [split*per, (split+1)*per), which its waves interleave; the waves' partial tiles are summed through LDS.
+// H = G (+ G^T) is rebuilt per (row tile, column tile) directly in the MFMA A-operand layout (swapped-operand trick,
+// no LDS round trip). A variant that builds H once per column tile and keeps all 8 feature-tile accumulators in one
+// wave (128 AGPRs, 1 wave/SIMD) measured 1.5-1.8x SLOWER on MI355X (63 vs 35 us at N=912, 262 vs 170 us at
+// 1024x4104): at these sizes the kernel is latency-bound and the many small waves of this layout hide it better.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float grad_elem(float s, float4 st, bool pos, bool neg) {
     // st = {m, Neg, w, R}
@@ -183,46 +242,56 @@ __device__ __forceinline__ float grad_elem(float s, float4 st, bool pos, bool ne
     return pos ? -st.z * st.y / (E + st.y) : (neg ? E * st.z * st.w : 0.f);
 }
 
+constexpr int BW_DT = 4;      // 32-wide feature tiles per wave: H is rebuilt once per BW_DT tiles (2x fewer exp/label
+                              // evaluations than one tile per wave at ~140 VGPRs, still 3 waves per SIMD)
+
 template <bool SELF>
 __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ S, int ldS, int N, ColSrc col,
                                                   const int32_t* __restrict__ a_lab,
                                                   const float* __restrict__ row_stats,
-                                                  const float* __restrict__ d_loss, float inv_tau, int nDt, int nJ,
+                                                  const float* __restrict__ d_loss, float inv_tau, int nDg, int nJ,
                                                   int per_split, float* __restrict__ parts) {
-    __shared__ float red[4][32][33];
+    __shared__ float red[32][BW_DT * 32 + 4];      // waves add their tiles one after the other (fixed order)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int h = lane >> 5, r32 = lane & 31;
-    const int It = blockIdx.x / nDt, dt = blockIdx.x % nDt;
+    const int It = blockIdx.x / nDg, dg = blockIdx.x % nDg;
     const int split = blockIdx.y;
-    const int I0 = It * 32, d0 = dt * 32;
+    const int I0 = It * 32, d0 = dg * (BW_DT * 32);
     const int M = col.M, D = col.D;
     const int i = I0 + r32;
     const bool i_ok = i < N;
     const float4 sti = i_ok ? *reinterpret_cast<const float4*>(row_stats + 4 * (size_t)i)
                             : make_float4(0.f, 1.f, 0.f, 0.f);
     const int yi = i_ok ? a_lab[i] : -0x7ffffffe;
-    const int d = d0 + r32;
-    const bool d_ok = d < D;
-
-    f32x16 acc;
+    const float* safe_row = col.mode == 2 ? col.segq : col.rows;
+    int dl[BW_DT];                      // columns >= D of a partial feature group are never written back: clamp
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int t = 0; t < BW_DT; ++t) dl[t] = min(d0 + t * 32 + r32, D - 1);
+
+    f32x16 acc[BW_DT];
+#pragma unroll
+    for (int t = 0; t < BW_DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const int jt_lo = split * per_split, jt_hi = min(nJ, jt_lo + per_split);
     for (int jt = jt_lo + wave; jt < jt_hi; jt += 4) {
         const int J0 = jt * 32;
         float hv[16];
-        float bv[16];
+        const float* crow[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int jb = J0 + 8 * q + 4 * h;  // this lane's 4 consecutive columns for registers 4q..4q+3
             const float4 s4 = i_ok ? ld4(S + (size_t)i * ldS + jb) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+            const float* rp[4];
+            int lb[4];
+            col.decode4(jb, rp, lb);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int j = jb + t;
                 const bool j_ok = j < M;
-                const int yj = col.label(j);
+                const int yj = lb[t];
                 const bool same = (yj == yi);
                 const bool pos = same && (j != i), neg = !same;
                 float g = grad_elem(sv[t], sti, pos, neg);
@@ -231,26 +300,40 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ S, i
                                             : make_float4(0.f, 1.f, 0.f, 0.f);
                     g += grad_elem(sv[t], stj, pos, neg);
                 }
-                hv[4 * q + t] = (i_ok && j_ok) ? g : 0.f;
-                const float* cr = col.row(j);
-                bv[4 * q + t] = (cr && d_ok) ? cr[d] : 0.f;
+                // a missing row (padding column or the zero tail of the bank) contributes 0 whatever H is: zero H
+                // there and read a valid row instead, so the B-operand loads are unconditional
+                const float* cr = rp[t];
+                hv[4 * q + t] = (i_ok && cr) ? g : 0.f;
+                crow[4 * q + t] = cr ? cr : safe_row;
             }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hv[r], bv[r], acc, 0, 0, 0);
-    }
-    // acc layout: col = d0 + (lane&31), rows I0 + (r&3) + 8*(r>>2) + 4*h
+        for (int t = 0; t < BW_DT; ++t) {
+            float bv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][r32] = acc[r];
-    __syncthreads();
-    const float scale = d_loss[0] * inv_tau;
-    for (int e = threadIdx.x; e < 32 * 32; e += 256) {
-        const int rr = e >> 5, cc = e & 31;
-        const int ii = I0 + rr, dd = d0 + cc;
-        if (ii < N && dd < D) {
-            const float v = red[0][rr][cc] + red[1][rr][cc] + red[2][rr][cc] + red[3][rr][cc];
-            parts[((size_t)split * N + ii) * D + dd] = v * scale;
+            for (int r = 0; r < 16; ++r) bv[r] = crow[r][dl[t]];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(hv[r], bv[r], acc[t], 0, 0, 0);
         }
+    }
+    // acc[t] layout: col = d0 + t*32 + (lane&31), rows I0 + (r&3) + 8*(r>>2) + 4*h
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < BW_DT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* p = &red[(r & 3) + 8 * (r >> 2) + 4 * h][t * 32 + r32];
+                    *p = (w == 0) ? acc[t][r] : *p + acc[t][r];
+                }
+        }
+        __syncthreads();
+    }
+    const float scale = d_loss[0] * inv_tau;
+    for (int e = threadIdx.x; e < 32 * BW_DT * 32; e += 256) {
+        const int rr = e / (BW_DT * 32), cc = e - rr * (BW_DT * 32);
+        const int ii = I0 + rr, dd = d0 + cc;
+        if (ii < N && dd < D) parts[((size_t)split * N + ii) * D + dd] = red[rr][cc] * scale;
     }
 }
 
@@ -286,8 +369,8 @@ int make_col(const cseg_contrast_desc* d, ColSrc* c) {
 inline int round32(int x) { return (x + 31) / 32 * 32; }
 
 inline int bwd_splits(int N, int M, int D) {
-    const int nI = (N + 31) / 32, nDt = (D + 31) / 32, nJ = (M + 31) / 32;
-    int want = (512 + nI * nDt - 1) / (nI * nDt);      // ~2 blocks per CU
+    const int nI = (N + 31) / 32, nDt = (D + BW_DT * 32 - 1) / (BW_DT * 32), nJ = (M + 31) / 32;
+    int want = (768 + nI * nDt - 1) / (nI * nDt);      // ~3 blocks per CU
     int max_split = (nJ + 3) / 4;                       // at least one tile per wave
     int s = want < 1 ? 1 : want;
     if (s > max_split) s = max_split;
@@ -307,10 +390,10 @@ extern "C" int cseg_contrast_fwd(const cseg_contrast_desc* d, float* S_ws, float
     hipStream_t stream = (hipStream_t)stream_;
     ColSrc col;
     if (!make_col(d, &col)) return 0;
-    const int nI = (d->N + 31) / 32, nJ = (d->M + 31) / 32, ldS = round32(d->M);
-    const int n_tiles = nI * nJ;
-    hipLaunchKernelGGL(s_gemm_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, stream, d->anchors, d->N, col,
-                       1.0f / d->temperature, S_ws, ldS, nJ, n_tiles);
+    const int ldS = round32(d->M);
+    const int nIb = (d->N + SG_T - 1) / SG_T, nJb = (d->M + SG_T - 1) / SG_T;
+    hipLaunchKernelGGL(s_gemm_kernel, dim3(nIb * nJb), dim3(256), 0, stream, d->anchors, d->N, col,
+                       1.0f / d->temperature, S_ws, ldS, nJb);
     CSEG_CHECK_LAUNCH("s_gemm_kernel");
     const float coef = d->temperature / d->base_temperature;
     hipLaunchKernelGGL(row_pass_kernel, dim3(d->N), dim3(256), 0, stream, S_ws, ldS, d->N, col, d->a_lab, coef,
@@ -326,7 +409,8 @@ extern "C" int cseg_contrast_bwd(const cseg_contrast_desc* d, const float* S_ws,
     hipStream_t stream = (hipStream_t)stream_;
     ColSrc col;
     if (!make_col(d, &col)) return 0;
-    const int nI = (d->N + 31) / 32, nJ = (d->M + 31) / 32, nDt = (d->D + 31) / 32, ldS = round32(d->M);
+    const int nI = (d->N + 31) / 32, nJ = (d->M + 31) / 32, nDt = (d->D + BW_DT * 32 - 1) / (BW_DT * 32);
+    const int ldS = round32(d->M);
     const int nsplit = bwd_splits(d->N, d->M, d->D);
     const int per_split = (nJ + nsplit - 1) / nsplit;
     dim3 grid(nI * nDt, nsplit);
