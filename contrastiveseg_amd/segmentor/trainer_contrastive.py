@@ -12,6 +12,7 @@ What changes underneath (MI355X-first):
   * data: any iterable yielding {'img', 'labelmap'} dicts; by default a seeded synthetic loader resident in HBM
     (file datasets / cv2 augmentation are out of scope)."""
 import time
+import warnings
 
 import numpy as np
 import torch
@@ -26,6 +27,12 @@ from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
 from contrastiveseg_amd.segmentor.tools.data_helper import DataHelper, SyntheticLoader
 from contrastiveseg_amd.segmentor.tools.module_runner import ModuleRunner
 from contrastiveseg_amd.segmentor.tools.optim_scheduler import OptimScheduler
+
+
+# the reference steps the scheduler with an explicit iteration index before optimizer.step() (:193-196); torch warns
+# about both habits on every call
+warnings.filterwarnings("ignore", message=r"The epoch parameter in `scheduler.step\(\)`")
+warnings.filterwarnings("ignore", message=r"Detected call of `lr_scheduler.step\(\)` before `optimizer.step\(\)`")
 
 
 def _unwrap(net):
