@@ -15,7 +15,8 @@ Besides the contract fields the line carries
   kernels       per hand-written HIP kernel at this workload's shapes: HIP-event time, algorithmic bytes / flops
                  and fraction of its own roofline.
   cpu_baseline  N=1, rank 0 only: CPU port of the same train step (same model classes, oracle/cpu_port.py device
-                half) timed on this box's host cores on a bounded sample (1 image of 3x512x1024, 1 warm-up + 1 step).
+                half) timed on this box's usable host cores on a bounded sample (1 image of 3x512x1024 per step, 1 warm-up +
+                2 timed steps, in a subprocess with a timeout).
 """
 import argparse
 import json

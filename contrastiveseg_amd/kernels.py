@@ -153,9 +153,8 @@ class ContrastOnAnchors(Function):
 
 class PixelContrast(Function):
     """gather(embed NCHW at mined pixels) -> _contrastive -> scalar, fused end to end; backward = contrast
-    backward + scatter of the anchor rows into a zero d_embed (no NHWC copy, no dense N x N temporaries).
-    `grad_scale` multiplies the gradient only (world size in the cross-rank mode, see lib/loss/loss_contrast.py
-    of this package)."""
+    backward + scatter of the anchor rows into a zero d_embed (no NHWC copy, no dense N x N temporaries besides the
+    similarity workspace). mode: 'self' (contrast set = the anchors) | 'bank' (memory queues read in place)."""
 
     @staticmethod
     def forward(ctx, embed, part_idx, sel_pos, a_lab, mode, temperature, base_temperature, segment_queue,
