@@ -45,7 +45,7 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         out = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
         res = x if self.downsample is None else self.downsample(x)
-        return self.relu_in(out + res)
+        return K.fuse_sum_relu([out, res], [])          # residual add + ReLU in one kernel (cseg_fuse_sum)
 
 
 class Bottleneck(nn.Module):
@@ -69,7 +69,7 @@ class Bottleneck(nn.Module):
         out = self.relu(self.bn2(self.conv2(out)))
         out = self.bn3(self.conv3(out))
         res = x if self.downsample is None else self.downsample(x)
-        return self.relu_in(out + res)
+        return K.fuse_sum_relu([out, res], [])          # residual add + ReLU in one kernel (cseg_fuse_sum)
 
 
 def _block_chain(block, inplanes, planes, n, bn_type, momentum):

@@ -186,9 +186,10 @@ def install(monkeypatch_or_none=None):
     import contrastiveseg_amd.lib.loss.loss_contrast_mem as lm
     import contrastiveseg_amd.lib.loss.loss_helper as lh
     import contrastiveseg_amd.lib.models.backbones.hrnet_backbone as hb
+    import contrastiveseg_amd.lib.models.backbones.resnet_backbone as rb
     import contrastiveseg_amd.lib.models.nets.hrnet as nh
     import contrastiveseg_amd.segmentor.trainer_contrastive as tc
-    mods = [lc, lm, lh, nh, hb, tc]
+    mods = [lc, lm, lh, nh, hb, rb, tc]
     saved = [m.K for m in mods]
     for m in mods:
         if monkeypatch_or_none is not None:
