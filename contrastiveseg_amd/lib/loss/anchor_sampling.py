@@ -8,7 +8,8 @@ indices are bit-identical under the same `torch.manual_seed`.
 
 Pure host integer logic: runs on CPU tensors, no kernels, shared by the single-GPU and the cross-rank paths."""
 import numpy as np
-import torch
+
+from contrastiveseg_amd import _host
 
 
 class NeverTouched(Exception):
@@ -66,26 +67,29 @@ def plan_selection(counts, max_samples, max_views, draw_images=None):
     off = np.cumsum(flat, axis=1) - flat                     # exclusive offsets inside each image's partition
     seg_img = np.empty(T, dtype=np.int32)
     seg_cls = np.empty(T, dtype=np.int32)
-    sel = np.empty((T, n_view), dtype=np.int64)
+    sel = np.full((T, n_view), -1, dtype=np.int64)
+    draws = []                                               # (segment, n_hard, keep_hard, n_easy, keep_easy)
     a = 0
     for b in range(B):
         mine = draw_images is None or draw_images[0] <= b < draw_images[1]
         for c in np.nonzero(qual[b])[0]:
             nh, ne = int(cnt[b, c, 0]), int(cnt[b, c, 1])
-            kh, ke = keep_rule(nh, ne, n_view)
-            if not mine:
-                sel[a, :] = -1
-                seg_img[a] = b
-                seg_cls[a] = c
-                a += 1
-                continue
-            perm_h = torch.randperm(nh).numpy()              # :79  (CPU default generator)
-            perm_e = torch.randperm(ne).numpy()              # :81
-            sel[a, :kh] = off[b, 2 * c] + perm_h[:kh]
-            sel[a, kh:] = off[b, 2 * c + 1] + perm_e[:ke]
+            kh, ke = keep_rule(nh, ne, n_view)               # raises like the reference also for foreign segments
             seg_img[a] = b
             seg_cls[a] = c
+            if mine:
+                draws.append((a, nh, kh, ne, ke))
             a += 1
+    if draws:
+        # torch.randperm(num_hard) then torch.randperm(num_easy) per segment (:79-82), same CPU generator, same order,
+        # also for n = 0 -- issued as one native call (contrastiveseg_amd/_host.py)
+        n_list = np.array([[d[1], d[3]] for d in draws], dtype=np.int64).reshape(-1)
+        keep = np.array([[d[2], d[4]] for d in draws], dtype=np.int64).reshape(-1)
+        perms = _host.randperm_prefixes(n_list, keep)
+        for i, (a, nh, kh, ne, ke) in enumerate(draws):
+            b, c = seg_img[a], seg_cls[a]
+            sel[a, :kh] = off[b, 2 * c] + perms[2 * i]
+            sel[a, kh:] = off[b, 2 * c + 1] + perms[2 * i + 1]
     row_off = np.ascontiguousarray(sel.T).reshape(-1).astype(np.int32)     # view-major
     row_img = np.tile(seg_img, n_view)
     row_lab = np.tile(seg_cls, n_view)

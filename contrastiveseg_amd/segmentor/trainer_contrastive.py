@@ -18,6 +18,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from contrastiveseg_amd import _host
 from contrastiveseg_amd import kernels as K
 from contrastiveseg_amd.lib.loss.loss_manager import LossManager
 from contrastiveseg_amd.lib.models.model_manager import ModelManager
@@ -48,24 +49,22 @@ def plan_enqueue(counts, seg_ptr, pix_ptr, memory_size, pixel_update_freq):
     seg_ptr = seg_ptr.copy()
     pix_ptr = pix_ptr.copy()
     seg_last, pix_last = {}, {}
-    for bs in range(B):
-        for lb in range(1, Kc):
-            n = int(counts[bs, lb])
-            if n == 0:
-                continue
-            seg_last[(lb, int(seg_ptr[lb]))] = bs
-            seg_ptr[lb] = (seg_ptr[lb] + 1) % memory_size
-            perm = torch.randperm(n).numpy()
-            k = min(n, pixel_update_freq)
-            ptr = int(pix_ptr[lb])
-            if ptr + k >= memory_size:
-                rows = range(memory_size - k, memory_size)
-                pix_ptr[lb] = 0
-            else:
-                rows = range(ptr, ptr + k)
-                pix_ptr[lb] = (pix_ptr[lb] + 1) % memory_size
-            for r, pos in zip(rows, perm[:k]):
-                pix_last[(lb, r)] = (bs, int(pos))
+    pairs = [(bs, lb, int(counts[bs, lb])) for bs in range(B) for lb in range(1, Kc) if counts[bs, lb] > 0]
+    # torch.randperm(num_pixel) per (image, class) in the reference's order (:127), one native call
+    perms = _host.randperm_prefixes([n for _, _, n in pairs], [min(n, pixel_update_freq) for _, _, n in pairs])
+    for (bs, lb, n), perm in zip(pairs, perms):
+        seg_last[(lb, int(seg_ptr[lb]))] = bs
+        seg_ptr[lb] = (seg_ptr[lb] + 1) % memory_size
+        k = min(n, pixel_update_freq)
+        ptr = int(pix_ptr[lb])
+        if ptr + k >= memory_size:
+            rows = range(memory_size - k, memory_size)
+            pix_ptr[lb] = 0
+        else:
+            rows = range(ptr, ptr + k)
+            pix_ptr[lb] = (pix_ptr[lb] + 1) % memory_size
+        for r, pos in zip(rows, perm):
+            pix_last[(lb, r)] = (bs, int(pos))
     seg_jobs = np.array([(b, lb, row) for (lb, row), b in seg_last.items()], dtype=np.int32).reshape(-1, 3)
     pix_rows = np.array([(b, pos, lb, row) for (lb, row), (b, pos) in pix_last.items()], dtype=np.int32).reshape(-1, 4)
     return seg_jobs, pix_rows, seg_ptr, pix_ptr
