@@ -4,7 +4,6 @@
 // map that accumulates every class at once, and two small row writers. Pointer arithmetic and the CPU randperm
 // stay on the host (contrastiveseg_amd/segmentor/trainer_contrastive.py). HBM-bound; no MFMA.
 #include "cseg_common.h"
-#include <stdarg.h>
 
 namespace {
 
@@ -150,16 +149,3 @@ extern "C" int cseg_queue_write_pixels(const float* keys, int B, int D, int Pk, 
     CSEG_CHECK_LAUNCH("queue_write_pixels_kernel");
     return 1;
 }
-
-// ---- error plumbing shared by the whole library -----------------------------------------------------------
-static thread_local char g_err[512] = "";
-
-void cseg_set_error(const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-}
-
-extern "C" const char* cseg_last_error(void) { return g_err; }
-extern "C" int cseg_abi_version(void) { return 1; }

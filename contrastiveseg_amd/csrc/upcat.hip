@@ -9,7 +9,6 @@ namespace {
 
 struct UpcatMaps {
     const float* x[4];
-    float* dx[4];
     int C[4], h[4], w[4], coff[5];
     int n;
 };
@@ -91,7 +90,7 @@ int fill_maps(UpcatMaps* m, const int* C, const int* hs, const int* ws, int n_ma
     m->n = n_maps;
     m->coff[0] = 0;
     for (int i = 0; i < 4; ++i) {
-        m->x[i] = nullptr; m->dx[i] = nullptr;
+        m->x[i] = nullptr;
         m->C[i] = i < n_maps ? C[i] : 0;
         m->h[i] = i < n_maps ? hs[i] : 1;
         m->w[i] = i < n_maps ? ws[i] : 1;
