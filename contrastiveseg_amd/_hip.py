@@ -47,6 +47,14 @@ SIGNATURES = {
     "cseg_queue_write_segments": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _c_int, _ptr]),
     "cseg_queue_write_pixels": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _c_int,
                                          _ptr]),
+    "cseg_bn_ws_floats": (ctypes.c_size_t, [_c_int, _c_int, _c_int]),
+    "cseg_bn_stats": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
+    "cseg_bn_finalize": (_c_int, [_ptr, _c_int, ctypes.c_double, _c_float, _c_float, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "cseg_bn_stats_finalize": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _c_float, _c_float, _ptr, _ptr, _ptr, _ptr,
+                                        _ptr]),
+    "cseg_bn_apply": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    "cseg_bn_bwd_reduce": (_c_int, [_ptr] * 6 + [_c_int] * 4 + [_ptr] * 5 + [_ptr]),
+    "cseg_bn_bwd_apply": (_c_int, [_ptr] * 6 + [ctypes.c_double, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
 }
 
 _lib = None
@@ -74,6 +82,8 @@ def _check(ok, what):
 
 
 def stream_ptr():
+    """The current HIP stream of the CURRENT device: `dev()` below insists that every tensor lives on that device, so
+    kernel, stream and pointers always agree."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -81,6 +91,10 @@ def dev(t, dtype, what):
     """Validates a tensor that is about to be handed to the kernels as a raw pointer."""
     if not t.is_cuda:
         raise RuntimeError("%s must live on the GPU (got %s): libcseg_hip has no CPU path" % (what, t.device))
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError("%s lives on %s but the current device is cuda:%d: call torch.cuda.set_device(local_rank) "
+                           "(one process per GPU) or wrap the call in torch.cuda.device(tensor.device)"
+                           % (what, t.device, torch.cuda.current_device()))
     if t.dtype != dtype:
         raise RuntimeError("%s must be %s (got %s)" % (what, dtype, t.dtype))
     if not t.is_contiguous():

@@ -1,0 +1,465 @@
+// Fused (Sync)BatchNorm + residual add + ReLU for NCHW fp32 activations -- SURVEY.md section 8 (f2).
+// Reference: ModuleHelper.BNReLU / BatchNorm2d (lib/models/tools/module_helper.py:29-68 -> nn.SyncBatchNorm), the
+// `out = relu(bn(conv(x)))` / `out = relu(bn(conv(x)) + residual)` chains of the HRNet / ResNet blocks
+// (lib/models/backbones/hrnet/hrnet_backbone.py:49-105, resnet/resnet_models.py) and the BNReLU heads.
+// torch runs that as BN (statistics pass + normalise pass), an add kernel and a clamp kernel, each a full-tensor
+// round trip through HBM, and in backward a threshold kernel + BN backward (two more statistics reads + dx pass).
+// Here:
+//   forward   bn_stats (1 read of x)                      -> per-channel (sum, sum of squares) in fp64
+//             [one all-reduce of the packed [C,2] fp64 moments across ranks -- done by the host, SyncBN only]
+//             bn_finalize (C threads)                     -> mean, 1/sqrt(var+eps), running statistics, batch counter
+//             bn_apply (1 read of x [+1 of residual], 1 write): y = relu((x-mean)*invstd*gamma + beta [+ residual])
+//   backward  bn_bwd_reduce (reads dy, x [, out]): sums of dy' and dy'*(x-mean) with the ReLU mask recomputed from x
+//             (or taken from `out` when a residual was added; then dy' is also written once, it IS d_residual)
+//             [one all-reduce of [C,2] fp64 sums -- SyncBN only; d_gamma / d_beta stay rank-local like torch's SyncBN]
+//             bn_bwd_apply (reads dy, x; writes dx)
+// All kernels are HBM-bound streaming passes: 16-byte loads/stores, one (image, channel) plane chunk of 4096 floats
+// per 256-thread block iteration, >= 1024 blocks. Reductions are fixed-order (block partials -> fp64 per-channel sum):
+// run-to-run deterministic. Statistics are accumulated as shifted sums (shift = first element of the channel) so
+// that the fp32 partials do not cancel when |mean| >> std.
+#include "cseg_common.h"
+
+namespace {
+
+constexpr int CHUNK = 4096;      // floats per block iteration (256 threads x 4 x float4)
+constexpr int MAX_SPLITS = 64;   // partials per channel, reduced by one wave
+
+struct BnDims {
+    int B, C, HW;
+    int n_ck;      // chunks per (image, channel) plane
+    int S;         // splits (blocks) per channel in the reduction kernels
+};
+
+__host__ BnDims bn_dims(int B, int C, int HW) {
+    BnDims d;
+    d.B = B; d.C = C; d.HW = HW;
+    d.n_ck = (HW + CHUNK - 1) / CHUNK;
+    const long total = (long)B * d.n_ck;
+    long target = (2048 + C - 1) / C;                    // aim at >= 2048 blocks
+    if (target < 1) target = 1;
+    if (target > MAX_SPLITS) target = MAX_SPLITS;
+    if (target > total) target = total;
+    const long per = (total + target - 1) / target;      // chunks per block
+    d.S = (int)((total + per - 1) / per);
+    return d;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum of two floats; result valid in thread 0
+__device__ __forceinline__ void block_sum2(float& a, float& b, float (*red)[4]) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        b = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward statistics
+// ---------------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, BnDims d, float* __restrict__ partial) {
+    __shared__ float red[2][4];
+    const int c = blockIdx.x % d.C, s = blockIdx.x / d.C;
+    const float shift = x[(size_t)c * d.HW];
+    float s1 = 0.f, s2 = 0.f;
+    const int total = d.B * d.n_ck;
+    for (int q = s; q < total; q += d.S) {
+        const int b = q / d.n_ck, ck = q - b * d.n_ck;
+        const float* p = x + ((size_t)b * d.C + c) * d.HW + (size_t)ck * CHUNK;
+        const int len = min(CHUNK, d.HW - ck * CHUNK);
+        if (VEC) {
+            if (len == CHUNK) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (u * 256 + threadIdx.x) * 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float a0 = v[u].x - shift, a1 = v[u].y - shift, a2 = v[u].z - shift, a3 = v[u].w - shift;
+                    s1 += (a0 + a1) + (a2 + a3);
+                    s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                }
+            } else {
+                for (int i = threadIdx.x * 4; i < len; i += 1024) {
+                    const float4 v = *reinterpret_cast<const float4*>(p + i);
+                    const float a0 = v.x - shift, a1 = v.y - shift, a2 = v.z - shift, a3 = v.w - shift;
+                    s1 += (a0 + a1) + (a2 + a3);
+                    s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < len; i += 256) {
+                const float a = p[i] - shift;
+                s1 += a;
+                s2 += a * a;
+            }
+        }
+    }
+    block_sum2(s1, s2, red);
+    if (threadIdx.x == 0) {
+        partial[((size_t)s * d.C + c) * 2 + 0] = s1;
+        partial[((size_t)s * d.C + c) * 2 + 1] = s2;
+    }
+}
+
+// one wave per channel: partials -> fp64 raw moments (sum x, sum x^2) of this rank's n = B*HW values
+__device__ __forceinline__ void channel_moments(const float* __restrict__ x, const float* __restrict__ partial, BnDims d,
+                                                int c, int lane, double& m0, double& m1) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = lane; s < d.S; s += 64) {
+        s1 += (double)partial[((size_t)s * d.C + c) * 2 + 0];
+        s2 += (double)partial[((size_t)s * d.C + c) * 2 + 1];
+    }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    const double k = (double)x[(size_t)c * d.HW];
+    const double n = (double)d.B * (double)d.HW;
+    m0 = n * k + s1;
+    m1 = s2 + 2.0 * k * s1 + n * k * k;
+}
+
+__global__ __launch_bounds__(256) void bn_moments_kernel(const float* __restrict__ x, const float* __restrict__ partial,
+                                                         BnDims d, double* __restrict__ moments) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= d.C) return;
+    double m0, m1;
+    channel_moments(x, partial, d, c, lane, m0, m1);
+    if (lane == 0) { moments[2 * c] = m0; moments[2 * c + 1] = m1; }
+}
+
+__device__ __forceinline__ void finalize_channel(double m0, double m1, double count, float eps, float momentum,
+                                                 float* running_mean, float* running_var, int c,
+                                                 float* __restrict__ mean_invstd) {
+    const double mean = m0 / count;
+    double var = m1 / count - mean * mean;          // fp64: the cancellation is harmless at 1e-16
+    if (var < 0.0) var = 0.0;
+    mean_invstd[2 * c] = (float)mean;
+    mean_invstd[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    }
+}
+
+// single-rank path: partials -> mean / invstd / running statistics in one launch
+__global__ __launch_bounds__(256) void bn_moments_finalize_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ partial, BnDims d, float eps,
+                                                                  float momentum, float* running_mean, float* running_var,
+                                                                  int64_t* num_batches_tracked,
+                                                                  float* __restrict__ mean_invstd) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (c >= d.C) return;
+    double m0, m1;
+    channel_moments(x, partial, d, c, lane, m0, m1);
+    if (lane == 0)
+        finalize_channel(m0, m1, (double)d.B * (double)d.HW, eps, momentum, running_mean, running_var, c, mean_invstd);
+}
+
+// multi-rank path: globally summed moments -> mean / invstd / running statistics
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ moments, int C, double count, float eps,
+                                                          float momentum, float* running_mean, float* running_var,
+                                                          int64_t* num_batches_tracked, float* __restrict__ mean_invstd) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (c >= C) return;
+    finalize_channel(moments[2 * c], moments[2 * c + 1], count, eps, momentum, running_mean, running_var, c, mean_invstd);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward apply: y = act((x - mean) * (gamma * invstd) + beta [+ residual])
+// ---------------------------------------------------------------------------------------------------------
+template <bool VEC, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                       const float* __restrict__ mean_invstd,
+                                                       const float* __restrict__ weight, const float* __restrict__ bias,
+                                                       BnDims d, int relu, float* __restrict__ y) {
+    const int plane = blockIdx.x / d.n_ck, ck = blockIdx.x - plane * d.n_ck;
+    const int c = plane % d.C;
+    const float mean = mean_invstd[2 * c];
+    const float a = (weight ? weight[c] : 1.f) * mean_invstd[2 * c + 1];
+    const float beta = bias ? bias[c] : 0.f;
+    const size_t base = (size_t)plane * d.HW + (size_t)ck * CHUNK;
+    const int len = min(CHUNK, d.HW - ck * CHUNK);
+    const bool rl = relu != 0;      // NaN-propagating ReLU like torch's clamp: (v < 0) ? 0 : v
+    if (VEC) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = (u * 256 + threadIdx.x) * 4;
+            if (i < len) {
+                const float4 v = *reinterpret_cast<const float4*>(x + base + i);
+                float4 o;
+                o.x = fmaf(v.x - mean, a, beta); o.y = fmaf(v.y - mean, a, beta);
+                o.z = fmaf(v.z - mean, a, beta); o.w = fmaf(v.w - mean, a, beta);
+                if (RES) {
+                    const float4 r = *reinterpret_cast<const float4*>(res + base + i);
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
+                o.x = (rl && o.x < 0.f) ? 0.f : o.x; o.y = (rl && o.y < 0.f) ? 0.f : o.y;
+                o.z = (rl && o.z < 0.f) ? 0.f : o.z; o.w = (rl && o.w < 0.f) ? 0.f : o.w;
+                *reinterpret_cast<float4*>(y + base + i) = o;
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < len; i += 256) {
+            float o = fmaf(x[base + i] - mean, a, beta);
+            if (RES) o += res[base + i];
+            y[base + i] = (rl && o < 0.f) ? 0.f : o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward reduction: sums of dy' and dy' * (x - mean); dy' = dy masked by the ReLU
+//   MODE 0: no activation          MODE 1: mask recomputed from x ((x-mean)*a+beta > 0)
+//   MODE 2: mask from `out` (residual case); dy' is written to g_out (it is also the gradient of the residual)
+// ---------------------------------------------------------------------------------------------------------
+template <bool VEC, int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ out,
+                                                            const float* __restrict__ mean_invstd,
+                                                            const float* __restrict__ weight,
+                                                            const float* __restrict__ bias, BnDims d,
+                                                            float* __restrict__ g_out, float* __restrict__ partial) {
+    __shared__ float red[2][4];
+    const int c = blockIdx.x % d.C, s = blockIdx.x / d.C;
+    const float mean = mean_invstd[2 * c];
+    const float a = (weight ? weight[c] : 1.f) * mean_invstd[2 * c + 1];
+    const float beta = bias ? bias[c] : 0.f;
+    float s0 = 0.f, s1 = 0.f;
+    const int total = d.B * d.n_ck;
+    for (int q = s; q < total; q += d.S) {
+        const int b = q / d.n_ck, ck = q - b * d.n_ck;
+        const size_t base = ((size_t)b * d.C + c) * d.HW + (size_t)ck * CHUNK;
+        const int len = min(CHUNK, d.HW - ck * CHUNK);
+        if (VEC) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = (u * 256 + threadIdx.x) * 4;
+                if (i < len) {
+                    float4 g = *reinterpret_cast<const float4*>(dy + base + i);
+                    const float4 v = *reinterpret_cast<const float4*>(x + base + i);
+                    const float x0 = v.x - mean, x1 = v.y - mean, x2 = v.z - mean, x3 = v.w - mean;
+                    if (MODE == 1) {
+                        g.x = fmaf(x0, a, beta) > 0.f ? g.x : 0.f; g.y = fmaf(x1, a, beta) > 0.f ? g.y : 0.f;
+                        g.z = fmaf(x2, a, beta) > 0.f ? g.z : 0.f; g.w = fmaf(x3, a, beta) > 0.f ? g.w : 0.f;
+                    } else if (MODE == 2) {
+                        const float4 o = *reinterpret_cast<const float4*>(out + base + i);
+                        g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
+                        g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+                        *reinterpret_cast<float4*>(g_out + base + i) = g;
+                    }
+                    s0 += (g.x + g.y) + (g.z + g.w);
+                    s1 += (g.x * x0 + g.y * x1) + (g.z * x2 + g.w * x3);
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < len; i += 256) {
+                float g = dy[base + i];
+                const float xm = x[base + i] - mean;
+                if (MODE == 1) g = fmaf(xm, a, beta) > 0.f ? g : 0.f;
+                if (MODE == 2) { g = out[base + i] > 0.f ? g : 0.f; g_out[base + i] = g; }
+                s0 += g;
+                s1 += g * xm;
+            }
+        }
+    }
+    block_sum2(s0, s1, red);
+    if (threadIdx.x == 0) {
+        partial[((size_t)s * d.C + c) * 2 + 0] = s0;
+        partial[((size_t)s * d.C + c) * 2 + 1] = s1;
+    }
+}
+
+// one wave per channel: partials -> fp64 sums [C,2]; d_gamma = s1 * invstd, d_beta = s0 (rank-local, like torch's SyncBN)
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restrict__ partial, BnDims d,
+                                                          const float* __restrict__ mean_invstd, double* __restrict__ sums,
+                                                          float* __restrict__ d_weight, float* __restrict__ d_bias) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= d.C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int s = lane; s < d.S; s += 64) {
+        s0 += (double)partial[((size_t)s * d.C + c) * 2 + 0];
+        s1 += (double)partial[((size_t)s * d.C + c) * 2 + 1];
+    }
+    s0 = wave_sum_d(s0);
+    s1 = wave_sum_d(s1);
+    if (lane == 0) {
+        sums[2 * c] = s0;
+        sums[2 * c + 1] = s1;
+        if (d_weight) d_weight[c] = (float)(s1 * (double)mean_invstd[2 * c + 1]);
+        if (d_bias) d_bias[c] = (float)s0;
+    }
+}
+
+// dx = a * (dy' - sum(dy')/N - (x-mean) * invstd^2 * sum(dy'*(x-mean))/N);  with frozen statistics (eval) dx = a * dy'
+template <bool VEC, bool MASK>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ mean_invstd,
+                                                           const float* __restrict__ weight,
+                                                           const float* __restrict__ bias, const double* __restrict__ sums,
+                                                           double inv_count, BnDims d, float* __restrict__ dx) {
+    const int plane = blockIdx.x / d.n_ck, ck = blockIdx.x - plane * d.n_ck;
+    const int c = plane % d.C;
+    const float mean = mean_invstd[2 * c], invstd = mean_invstd[2 * c + 1];
+    const float a = (weight ? weight[c] : 1.f) * invstd;
+    const float beta = bias ? bias[c] : 0.f;
+    const float k0 = sums ? (float)(sums[2 * c] * inv_count) : 0.f;
+    const float k1 = sums ? (float)(sums[2 * c + 1] * inv_count * (double)invstd * (double)invstd) : 0.f;
+    const size_t base = (size_t)plane * d.HW + (size_t)ck * CHUNK;
+    const int len = min(CHUNK, d.HW - ck * CHUNK);
+    if (VEC) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = (u * 256 + threadIdx.x) * 4;
+            if (i < len) {
+                float4 g = *reinterpret_cast<const float4*>(dy + base + i);
+                const float4 v = *reinterpret_cast<const float4*>(x + base + i);
+                const float x0 = v.x - mean, x1 = v.y - mean, x2 = v.z - mean, x3 = v.w - mean;
+                if (MASK) {
+                    g.x = fmaf(x0, a, beta) > 0.f ? g.x : 0.f; g.y = fmaf(x1, a, beta) > 0.f ? g.y : 0.f;
+                    g.z = fmaf(x2, a, beta) > 0.f ? g.z : 0.f; g.w = fmaf(x3, a, beta) > 0.f ? g.w : 0.f;
+                }
+                float4 o;
+                o.x = a * (g.x - k0 - x0 * k1); o.y = a * (g.y - k0 - x1 * k1);
+                o.z = a * (g.z - k0 - x2 * k1); o.w = a * (g.w - k0 - x3 * k1);
+                *reinterpret_cast<float4*>(dx + base + i) = o;
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < len; i += 256) {
+            float g = dy[base + i];
+            const float xm = x[base + i] - mean;
+            if (MASK) g = fmaf(xm, a, beta) > 0.f ? g : 0.f;
+            dx[base + i] = a * (g - k0 - xm * k1);
+        }
+    }
+}
+
+bool vec_ok(int HW, const void* p0, const void* p1 = nullptr, const void* p2 = nullptr, const void* p3 = nullptr) {
+    auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return HW % 4 == 0 && al(p0) && al(p1) && al(p2) && al(p3);
+}
+
+int check_dims(const char* who, int B, int C, int HW) {
+    CSEG_REQUIRE(B > 0 && C > 0 && HW > 0 && (long)B * C * ((HW + CHUNK - 1) / CHUNK) < 2147483647L,
+                 "%s: bad shape B=%d C=%d HW=%d", who, B, C, HW);
+    return 1;
+}
+
+}  // namespace
+
+extern "C" size_t cseg_bn_ws_floats(int B, int C, int HW) {
+    if (B <= 0 || C <= 0 || HW <= 0) return 0;
+    const BnDims d = bn_dims(B, C, HW);
+    return (size_t)d.S * C * 2;
+}
+
+extern "C" int cseg_bn_stats(const float* x, int B, int C, int HW, float* ws, double* moments, cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!check_dims("bn_stats", B, C, HW)) return 0;
+    CSEG_REQUIRE(x && ws && moments, "bn_stats: null pointer");
+    const BnDims d = bn_dims(B, C, HW);
+    if (vec_ok(HW, x)) hipLaunchKernelGGL(bn_stats_kernel<true>, dim3(d.S * C), dim3(256), 0, stream, x, d, ws);
+    else hipLaunchKernelGGL(bn_stats_kernel<false>, dim3(d.S * C), dim3(256), 0, stream, x, d, ws);
+    hipLaunchKernelGGL(bn_moments_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, x, ws, d, moments);
+    CSEG_CHECK_LAUNCH("bn_stats");
+    return 1;
+}
+
+extern "C" int cseg_bn_finalize(const double* moments, int C, double count, float eps, float momentum, float* running_mean,
+                                float* running_var, int64_t* num_batches_tracked, float* mean_invstd,
+                                cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CSEG_REQUIRE(moments && mean_invstd && C > 0 && count > 0.0, "bn_finalize: bad arguments");
+    CSEG_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean/var must come together");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, moments, C, count, eps, momentum,
+                       running_mean, running_var, num_batches_tracked, mean_invstd);
+    CSEG_CHECK_LAUNCH("bn_finalize");
+    return 1;
+}
+
+extern "C" int cseg_bn_stats_finalize(const float* x, int B, int C, int HW, float* ws, float eps, float momentum,
+                                      float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                      float* mean_invstd, cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!check_dims("bn_stats_finalize", B, C, HW)) return 0;
+    CSEG_REQUIRE(x && ws && mean_invstd, "bn_stats_finalize: null pointer");
+    CSEG_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
+                 "bn_stats_finalize: running_mean/var must come together");
+    const BnDims d = bn_dims(B, C, HW);
+    if (vec_ok(HW, x)) hipLaunchKernelGGL(bn_stats_kernel<true>, dim3(d.S * C), dim3(256), 0, stream, x, d, ws);
+    else hipLaunchKernelGGL(bn_stats_kernel<false>, dim3(d.S * C), dim3(256), 0, stream, x, d, ws);
+    hipLaunchKernelGGL(bn_moments_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, x, ws, d, eps, momentum,
+                       running_mean, running_var, num_batches_tracked, mean_invstd);
+    CSEG_CHECK_LAUNCH("bn_stats_finalize");
+    return 1;
+}
+
+extern "C" int cseg_bn_apply(const float* x, const float* residual, const float* mean_invstd, const float* weight,
+                             const float* bias, int relu, int B, int C, int HW, float* y, cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!check_dims("bn_apply", B, C, HW)) return 0;
+    CSEG_REQUIRE(x && mean_invstd && y, "bn_apply: null pointer");
+    const BnDims d = bn_dims(B, C, HW);
+    const dim3 grid((unsigned)((long)B * C * d.n_ck));
+    const bool v = vec_ok(HW, x, residual, y);
+#define LAUNCH(V, R) hipLaunchKernelGGL((bn_apply_kernel<V, R>), grid, dim3(256), 0, stream, x, residual, mean_invstd, \
+                                        weight, bias, d, relu, y)
+    if (v) { if (residual) LAUNCH(true, true); else LAUNCH(true, false); }
+    else { if (residual) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    CSEG_CHECK_LAUNCH("bn_apply");
+    return 1;
+}
+
+extern "C" int cseg_bn_bwd_reduce(const float* dy, const float* x, const float* out, const float* mean_invstd,
+                                  const float* weight, const float* bias, int mode, int B, int C, int HW, float* ws,
+                                  float* g_masked, double* sums, float* d_weight, float* d_bias, cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!check_dims("bn_bwd_reduce", B, C, HW)) return 0;
+    CSEG_REQUIRE(dy && x && mean_invstd && ws && sums, "bn_bwd_reduce: null pointer");
+    CSEG_REQUIRE(mode >= 0 && mode <= 2, "bn_bwd_reduce: mode %d", mode);
+    CSEG_REQUIRE(mode != 2 || (out && g_masked), "bn_bwd_reduce: mode 2 needs `out` and `g_masked`");
+    const BnDims d = bn_dims(B, C, HW);
+    const bool v = vec_ok(HW, dy, x, out, g_masked);
+    const dim3 grid(d.S * C);
+#define LAUNCH(V, M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, M>), grid, dim3(256), 0, stream, dy, x, out, mean_invstd, \
+                                        weight, bias, d, g_masked, ws)
+    if (v) { if (mode == 0) LAUNCH(true, 0); else if (mode == 1) LAUNCH(true, 1); else LAUNCH(true, 2); }
+    else { if (mode == 0) LAUNCH(false, 0); else if (mode == 1) LAUNCH(false, 1); else LAUNCH(false, 2); }
+#undef LAUNCH
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, ws, d, mean_invstd, sums, d_weight,
+                       d_bias);
+    CSEG_CHECK_LAUNCH("bn_bwd_reduce");
+    return 1;
+}
+
+extern "C" int cseg_bn_bwd_apply(const float* dy, const float* x, const float* mean_invstd, const float* weight,
+                                 const float* bias, const double* sums, double count, int mask_from_x, int B, int C,
+                                 int HW, float* dx, cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!check_dims("bn_bwd_apply", B, C, HW)) return 0;
+    CSEG_REQUIRE(dy && x && mean_invstd && dx, "bn_bwd_apply: null pointer");
+    CSEG_REQUIRE(sums == nullptr || count > 0.0, "bn_bwd_apply: count must be positive");
+    const BnDims d = bn_dims(B, C, HW);
+    const dim3 grid((unsigned)((long)B * C * d.n_ck));
+    const bool v = vec_ok(HW, dy, x, dx);
+    const double inv = sums ? 1.0 / count : 0.0;
+#define LAUNCH(V, M) hipLaunchKernelGGL((bn_bwd_apply_kernel<V, M>), grid, dim3(256), 0, stream, dy, x, mean_invstd, weight, \
+                                        bias, sums, inv, d, dx)
+    if (v) { if (mask_from_x) LAUNCH(true, true); else LAUNCH(true, false); }
+    else { if (mask_from_x) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    CSEG_CHECK_LAUNCH("bn_bwd_apply");
+    return 1;
+}

@@ -127,6 +127,21 @@ def contrast_backward(desc, saved, d_loss, device):
     return parts
 
 
+def _bank_versions(segment_queue, pixel_queue):
+    return None if segment_queue is None else (segment_queue._version, pixel_queue._version)
+
+
+def _check_bank_unchanged(versions, segment_queue, pixel_queue):
+    """The bank is read IN PLACE by cseg_contrast_fwd and again by cseg_contrast_bwd (no [K*2*ms, D] copy like the
+    reference's torch.cat, loss_contrast_mem.py:221). Raw pointers bypass autograd's own version check, so it is
+    restated here: an in-place update of the queues between forward and backward would silently mix old similarities
+    with new bank rows."""
+    if versions is not None and versions != (segment_queue._version, pixel_queue._version):
+        raise RuntimeError("the memory bank was modified in place between the forward and the backward of the "
+                           "contrastive loss (call _dequeue_and_enqueue AFTER loss.backward(), as "
+                           "Trainer.train_step does, or pass clones of the queues)")
+
+
 class ContrastOnAnchors(Function):
     """loss = _contrastive(anchors, ...) with anchors already gathered ([N,D], view-major rows).
     mode: 'self' | 'plain' | 'bank'. Gradient flows to `anchors` only (the reference gives the bank none,
@@ -142,11 +157,13 @@ class ContrastOnAnchors(Function):
         ctx.desc = desc
         ctx.saved = saved
         ctx.keep = (anchors, a_lab, contrast, c_lab, segment_queue, pixel_queue)  # keep pointers alive
+        ctx.bank_versions = _bank_versions(segment_queue, pixel_queue)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         anchors = ctx.keep[0]
+        _check_bank_unchanged(ctx.bank_versions, ctx.keep[4], ctx.keep[5])
         parts = contrast_backward(ctx.desc, ctx.saved, g, anchors.device)
         return (parts.sum(0) if parts.shape[0] > 1 else parts[0],) + (None,) * 8
 
@@ -167,6 +184,7 @@ class PixelContrast(Function):
         loss, saved = contrast_forward(desc, embed.device)
         ctx.desc, ctx.saved = desc, saved
         ctx.keep = (anchors, a_lab, segment_queue, pixel_queue)
+        ctx.bank_versions = _bank_versions(segment_queue, pixel_queue)
         ctx.sel_pix = sel_pix
         ctx.embed_shape = embed.shape
         ctx.mark_non_differentiable(sel_pix)
@@ -176,6 +194,7 @@ class PixelContrast(Function):
     def backward(ctx, g, _g_sel):
         B, D, h, w = ctx.embed_shape
         dev = ctx.sel_pix.device
+        _check_bank_unchanged(ctx.bank_versions, ctx.keep[2], ctx.keep[3])
         parts = contrast_backward(ctx.desc, ctx.saved, g, dev)
         d_embed = torch.zeros(B, D, h, w, dtype=F32, device=dev)
         _hip.call("cseg_scatter_anchor_grad", _p(parts, F32, "parts"), parts.shape[0], _p(ctx.sel_pix, I32, "sel_pix"),
@@ -305,7 +324,7 @@ class UpsampleCE(Function):
     tensor (lib/loss/loss_contrast.py:180-181, lib/loss/loss_helper.py:169-206)."""
 
     @staticmethod
-    def forward(ctx, seg, target, weight, ignore_index):
+    def forward(ctx, seg, target, weight, ignore_index, status):
         seg = seg.contiguous()
         B, K, h, w = seg.shape
         _, H, W = target.shape
@@ -314,7 +333,8 @@ class UpsampleCE(Function):
         dev = seg.device
         partial = torch.empty(2 * nb, dtype=F32, device=dev)
         out = torch.empty(2, dtype=F32, device=dev)
-        status = torch.zeros(4, dtype=I32, device=dev)
+        if status is None:
+            status = torch.zeros(4, dtype=I32, device=dev)
         wp = _p(weight, F32, "ce_weight") if weight is not None else _null()
         _hip.call("cseg_upsample_ce_fwd", _p(seg, F32, "seg"), _p(target, I64, "target"), wp, int(ignore_index), B, K,
                   h, w, H, W, _p(partial, F32, "partial"), _p(out, F32, "out"), _p(status, I32, "status"),
@@ -322,7 +342,6 @@ class UpsampleCE(Function):
         ctx.save_for_backward(seg, target, out)
         ctx.weight = weight
         ctx.ignore_index = int(ignore_index)
-        ctx.status = status
         return out[0].clone()
 
     @staticmethod
@@ -335,11 +354,14 @@ class UpsampleCE(Function):
         wp = _p(ctx.weight, F32, "ce_weight") if ctx.weight is not None else _null()
         _hip.call("cseg_upsample_ce_bwd", _p(seg, F32, "seg"), _p(target, I64, "target"), wp, ctx.ignore_index, B, K,
                   h, w, H, W, _p(out, F32, "out"), _p(g, F32, "d_loss"), _p(d_seg, F32, "d_seg"), _hip.stream_ptr())
-        return d_seg, None, None, None
+        return d_seg, None, None, None, None
 
 
-def upsample_ce(seg, target, weight=None, ignore_index=-1):
-    return UpsampleCE.apply(seg, target, weight, ignore_index)
+def upsample_ce(seg, target, weight=None, ignore_index=-1, status=None):
+    """`status` (i32 [4], optional, accumulated across calls): status[1] counts label values that are neither
+    `ignore_index` nor in [0, K) -- nn.CrossEntropyLoss would assert on those; here they are dropped from numerator
+    and denominator, and the caller is expected to look at the counter (FSCELoss.bad_label_count)."""
+    return UpsampleCE.apply(seg, target, weight, ignore_index, status)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -371,6 +393,7 @@ def queue_write_segments(sums, counts, job_img, job_cls, job_dst_row, segment_qu
     _hip.call("cseg_queue_write_segments", _p(sums, F32, "sums"), _p(counts, I32, "counts"),
               _p(job_img, I32, "job_img"), _p(job_cls, I32, "job_cls"), _p(job_dst_row, I32, "job_dst_row"),
               job_img.numel(), K, D, _p(segment_queue, F32, "segment_queue"), ms, _hip.stream_ptr())
+    torch.autograd.graph.increment_version(segment_queue)      # written through a raw pointer
 
 
 @torch.no_grad()
@@ -381,3 +404,96 @@ def queue_write_pixels(keys, src_img, src_pos, dst_cls, dst_row, pixel_queue):
     _hip.call("cseg_queue_write_pixels", _p(keys, F32, "keys"), B, D, Pk, _p(src_img, I32, "src_img"),
               _p(src_pos, I32, "src_pos"), _p(dst_cls, I32, "dst_cls"), _p(dst_row, I32, "dst_row"),
               src_img.numel(), _p(pixel_queue, F32, "pixel_queue"), ms, _hip.stream_ptr())
+    torch.autograd.graph.increment_version(pixel_queue)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# fused (Sync)BatchNorm + residual + ReLU primitives (host logic: lib/models/tools/fused_bn.py)
+# ----------------------------------------------------------------------------------------------------------
+F64 = torch.float64
+
+
+def _opt(t, dtype, what):
+    return _p(t, dtype, what) if t is not None else _null()
+
+
+def _bn_dims(x):
+    B, C = x.shape[0], x.shape[1]
+    HW = 1
+    for v in x.shape[2:]:
+        HW *= v
+    return B, C, HW
+
+
+def _bn_ws(B, C, HW, device):
+    return torch.empty(max(1, _hip.lib().cseg_bn_ws_floats(B, C, HW)), dtype=F32, device=device)
+
+
+@torch.no_grad()
+def bn_stats(x):
+    """-> moments [C,2] f64 = (sum x, sum x^2) over this rank's values (the tensor a SyncBN exchange all-reduces)."""
+    B, C, HW = _bn_dims(x)
+    moments = torch.empty(C, 2, dtype=F64, device=x.device)
+    _hip.call("cseg_bn_stats", _p(x, F32, "x"), B, C, HW, _p(_bn_ws(B, C, HW, x.device), F32, "ws"),
+              _p(moments, F64, "moments"), _hip.stream_ptr())
+    return moments
+
+
+@torch.no_grad()
+def bn_finalize(moments, count, eps, momentum, running_mean, running_var, num_batches_tracked):
+    """(global) moments -> mean_invstd [C,2] f32; running statistics / batch counter updated in place."""
+    C = moments.shape[0]
+    mi = torch.empty(C, 2, dtype=F32, device=moments.device)
+    _hip.call("cseg_bn_finalize", _p(moments, F64, "moments"), C, float(count), float(eps), float(momentum),
+              _opt(running_mean, F32, "running_mean"), _opt(running_var, F32, "running_var"),
+              _opt(num_batches_tracked, I64, "num_batches_tracked"), _p(mi, F32, "mean_invstd"), _hip.stream_ptr())
+    return mi
+
+
+@torch.no_grad()
+def bn_stats_finalize(x, eps, momentum, running_mean, running_var, num_batches_tracked):
+    """Single-rank bn_stats + bn_finalize in two launches."""
+    B, C, HW = _bn_dims(x)
+    mi = torch.empty(C, 2, dtype=F32, device=x.device)
+    _hip.call("cseg_bn_stats_finalize", _p(x, F32, "x"), B, C, HW, _p(_bn_ws(B, C, HW, x.device), F32, "ws"),
+              float(eps), float(momentum), _opt(running_mean, F32, "running_mean"),
+              _opt(running_var, F32, "running_var"), _opt(num_batches_tracked, I64, "num_batches_tracked"),
+              _p(mi, F32, "mean_invstd"), _hip.stream_ptr())
+    return mi
+
+
+@torch.no_grad()
+def bn_apply(x, mean_invstd, weight, bias, residual, relu):
+    B, C, HW = _bn_dims(x)
+    y = torch.empty_like(x)
+    _hip.call("cseg_bn_apply", _p(x, F32, "x"), _opt(residual, F32, "residual"), _p(mean_invstd, F32, "mean_invstd"),
+              _opt(weight, F32, "weight"), _opt(bias, F32, "bias"), int(bool(relu)), B, C, HW, _p(y, F32, "y"),
+              _hip.stream_ptr())
+    return y
+
+
+@torch.no_grad()
+def bn_bwd_reduce(dy, x, out, mean_invstd, weight, bias, mode):
+    """-> (sums [C,2] f64, d_weight [C], d_bias [C], g_masked or None). mode: 0 none | 1 ReLU mask from x | 2 from out."""
+    B, C, HW = _bn_dims(x)
+    dev = x.device
+    sums = torch.empty(C, 2, dtype=F64, device=dev)
+    d_weight = torch.empty(C, dtype=F32, device=dev)
+    d_bias = torch.empty(C, dtype=F32, device=dev)
+    g = torch.empty_like(x) if mode == 2 else None
+    _hip.call("cseg_bn_bwd_reduce", _p(dy, F32, "dy"), _p(x, F32, "x"), _opt(out, F32, "out"),
+              _p(mean_invstd, F32, "mean_invstd"), _opt(weight, F32, "weight"), _opt(bias, F32, "bias"), int(mode),
+              B, C, HW, _p(_bn_ws(B, C, HW, dev), F32, "ws"), _opt(g, F32, "g_masked"), _p(sums, F64, "sums"),
+              _p(d_weight, F32, "d_weight"), _p(d_bias, F32, "d_bias"), _hip.stream_ptr())
+    return sums, d_weight, d_bias, g
+
+
+@torch.no_grad()
+def bn_bwd_apply(dy, x, mean_invstd, weight, bias, sums, count, mask_from_x):
+    """sums None = frozen statistics (eval mode)."""
+    B, C, HW = _bn_dims(x)
+    dx = torch.empty_like(x)
+    _hip.call("cseg_bn_bwd_apply", _p(dy, F32, "dy"), _p(x, F32, "x"), _p(mean_invstd, F32, "mean_invstd"),
+              _opt(weight, F32, "weight"), _opt(bias, F32, "bias"), _opt(sums, F64, "sums"), float(count),
+              int(bool(mask_from_x)), B, C, HW, _p(dx, F32, "dx"), _hip.stream_ptr())
+    return dx

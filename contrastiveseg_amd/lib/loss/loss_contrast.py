@@ -11,12 +11,19 @@
   :141-142 NHWC copy, :85-87 gather                       cseg_gather_anchors straight from NCHW
   :91-128 _contrastive                                    cseg_contrast_fwd/bwd (fp32 MFMA)
 
-Data-parallel (one process per GPU, RCCL): with `contrast.cross_rank` (default on when world_size > 1) the
-contrast set is the union of every rank's anchors: counts are all-gathered so all ranks derive the same global
-selection from the same RNG stream, each rank gathers its own rows, rows are all-gathered, and every rank
-evaluates the global loss while back-propagating only into its own embeddings (gradient scaled by world_size so
-that DDP's gradient averaging reproduces the single-process gradient of the global loss). The anchor budget of the
-global set is max_samples * world_size by default (`contrast.cross_rank_budget`: 'per_rank' | 'global')."""
+Data-parallel (one process per GPU, RCCL). Two modes, chosen by `contrast.cross_rank`:
+  * false (the code default = the reference's DDP behaviour): every rank contrasts only the <= max_samples anchors
+    mined from its own images; nothing but DDP's gradient all-reduce crosses ranks.
+  * true (opt-in; set by the shipped HRNet configs because BASELINE.json's multi-GPU configuration asks for it): the
+    contrast set is the union of every rank's anchors: counts are all-gathered so all ranks derive the same global
+    selection from the same RNG stream, each rank gathers its own rows, rows are all-gathered, and every rank
+    evaluates the global loss while back-propagating only into its own embeddings (gradient scaled by world_size so
+    that DDP's gradient averaging reproduces the single-process gradient of the global loss). This CHANGES the
+    objective relative to the reference's DDP run (world x more negatives per anchor); its oracle is the reference's
+    single-process loss on the concatenated global batch. The anchor budget of the global set is
+    max_samples * world_size by default (`contrast.cross_rank_budget`: 'per_rank' | 'global').
+The memory-bank criterion (loss_contrast_mem.py) always contrasts a rank's own anchors against its own copy of the
+bank, as the reference does; `cross_rank` does not apply to it."""
 from abc import ABC
 
 import numpy as np
@@ -66,7 +73,7 @@ class PixelContrastLoss(nn.Module, ABC):
             self.ignore_label = self.configer.get('loss', 'params')['ce_ignore_index']
         self.max_samples = self.configer.get('contrast', 'max_samples')
         self.max_views = self.configer.get('contrast', 'max_views')
-        self.cross_rank = True
+        self.cross_rank = False      # reference parity unless the config opts in (see the module docstring)
         if self.configer.exists('contrast', 'cross_rank'):
             self.cross_rank = bool(self.configer.get('contrast', 'cross_rank'))
         # anchor budget of the cross-rank set: 'per_rank' = max_samples * world_size anchors in total (every rank of
@@ -149,14 +156,11 @@ class PixelContrastLoss(nn.Module, ABC):
         return loss
 
     def _forward_cross_rank(self, feats, cp, P, world):
-        import torch.distributed as dist
         rank = D.get_rank()
         B = feats.shape[0]
         dev = feats.device
         local = torch.cat([cp["counts"].reshape(-1), cp["status"]])      # compute stream (waits on the side stream)
-        gathered = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(gathered, local)                       # RCCL, B*K*2+4 ints per rank
-        host = torch.stack(gathered).cpu()
+        host = D.all_gather_cat(local.unsqueeze(0)).cpu()      # RCCL all-gather, B*K*2+4 ints per rank
         if int(host[:, -4].sum()) != 0:
             raise RuntimeError("PixelContrastLoss: labels outside [0, num_classes) on some rank")
         counts = host[:, :-4].reshape((world * B,) + tuple(cp["counts"].shape[1:])).numpy()
@@ -176,8 +180,7 @@ class PixelContrastLoss(nn.Module, ABC):
         t_max = max(t_r)
         pad = torch.zeros(t_max * V, feats.shape[1], dtype=feats.dtype, device=dev)
         pad[:anchors_l.shape[0]] = anchors_l.detach()
-        bufs = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(bufs, pad)                              # RCCL, <= max_samples x D floats in total
+        bufs = D.all_gather_cat(pad.unsqueeze(0))               # RCCL all-gather, <= max_samples x D floats in total
         pieces = []
         order = np.empty(T * V, dtype=np.int64)                 # global row -> position in cat(pieces)
         base = 0

@@ -32,10 +32,20 @@ class FSCELoss(nn.Module):
             raise NotImplementedError("ce_reduction %r: only the mean reduction of the shipped configs is "
                                       "implemented on the HIP path" % reduction)
         self.register_buffer("weight", weight, persistent=False)
+        self.register_buffer("status", torch.zeros(4, dtype=torch.int32), persistent=False)
         self.ignore_index = ignore_index
 
     def _one(self, inp, target):
-        return K.upsample_ce(inp, target, self.weight, self.ignore_index)
+        return K.upsample_ce(inp, target, self.weight, self.ignore_index, self.status)
+
+    def bad_label_count(self, reset=True):
+        """Labels seen since the last call that are neither `ce_ignore_index` nor a class id: the kernel drops them
+        (nn.CrossEntropyLoss of the reference would assert). One D2H copy: call it where the host syncs anyway
+        (Trainer._display does, and raises)."""
+        n = int(self.status[1])
+        if reset:
+            self.status.zero_()
+        return n
 
     def forward(self, inputs, *targets, weights=None, **kwargs):
         if isinstance(inputs, (tuple, list)):

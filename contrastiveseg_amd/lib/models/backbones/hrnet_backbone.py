@@ -2,8 +2,9 @@
 (lib/models/backbones/hrnet/hrnet_backbone.py:35-574, configs hrnet_config.py:46-73), so reference checkpoints
 load unchanged and the same torch seed gives identical random initialisation.
 
-The network is expressed as data (stage table below) plus three small module kinds; conv / BN / ReLU execute on
-MIOpen through PyTorch-ROCm; the cross-resolution exchange (sum of same-resolution terms + bilinear-upsampled
+The network is expressed as data (stage table below) plus three small module kinds; convolutions execute on
+MIOpen through PyTorch-ROCm, every BatchNorm (+ the ReLU / residual add behind it) on the fused cseg_bn_* kernels
+(lib/models/tools/fused_bn.py); the cross-resolution exchange (sum of same-resolution terms + bilinear-upsampled
 coarse terms + ReLU, reference :271-286) is one HIP kernel per output branch (cseg_fuse_sum_fwd/bwd).
 Factory keys follow lib/models/backbones/hrnet/hrnet_backbone.py:742-803 ('hrnet18' ... 'hrnet64'); BN is hard-wired
 to torch SyncBN with momentum 0.1 exactly as the reference factory does (:773)."""
@@ -17,15 +18,14 @@ STAGES = {2: (1, 4), 3: (4, 4), 4: (3, 4)}
 WIDTHS = {'hrnet18': 18, 'hrnet32': 32, 'hrnet48': 48, 'hrnet64': 64}
 
 
-def _norm(bn_type, c, momentum):
-    return ModuleHelper.BatchNorm2d(bn_type=bn_type)(c, momentum=momentum)
+def _norm(bn_type, c, momentum, act=None):
+    return ModuleHelper.BatchNorm2d(bn_type=bn_type)(c, momentum=momentum, act=act)
 
 
 def _conv_bn(cin, cout, k, stride, bn_type, momentum, relu):
-    layers = [nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=False), _norm(bn_type, cout, momentum)]
-    if relu:
-        layers.append(nn.ReLU(inplace=False))
-    return nn.Sequential(*layers)
+    """conv -> BN [-> ReLU]; the ReLU (stateless third child in the reference) is fused into the norm kernel."""
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=False),
+                         _norm(bn_type, cout, momentum, 'relu' if relu else None))
 
 
 class BasicBlock(nn.Module):
@@ -35,17 +35,15 @@ class BasicBlock(nn.Module):
         super(BasicBlock, self).__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
         self.bn1 = _norm(bn_type, planes, bn_momentum)
-        self.relu = nn.ReLU(inplace=False)
-        self.relu_in = nn.ReLU(inplace=True)
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
         self.bn2 = _norm(bn_type, planes, bn_momentum)
         self.downsample = downsample
         self.stride = stride
 
     def forward(self, x):
-        out = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        out = self.bn1(self.conv1(x), relu=True)                      # BN + ReLU: one statistics pass + one apply pass
         res = x if self.downsample is None else self.downsample(x)
-        return K.fuse_sum_relu([out, res], [])          # residual add + ReLU in one kernel (cseg_fuse_sum)
+        return self.bn2(self.conv2(out), residual=res, relu=True)     # BN + residual add + ReLU in the same apply pass
 
 
 class Bottleneck(nn.Module):
@@ -59,17 +57,14 @@ class Bottleneck(nn.Module):
         self.bn2 = _norm(bn_type, planes, bn_momentum)
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
         self.bn3 = _norm(bn_type, planes * 4, bn_momentum)
-        self.relu = nn.ReLU(inplace=False)
-        self.relu_in = nn.ReLU(inplace=True)
         self.downsample = downsample
         self.stride = stride
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
         res = x if self.downsample is None else self.downsample(x)
-        return K.fuse_sum_relu([out, res], [])          # residual add + ReLU in one kernel (cseg_fuse_sum)
+        return self.bn3(self.conv3(out), residual=res, relu=True)
 
 
 def _block_chain(block, inplanes, planes, n, bn_type, momentum):
@@ -108,7 +103,6 @@ class HighResolutionModule(nn.Module):
                     row.append(nn.Sequential(*steps))
             fuse.append(nn.ModuleList(row))
         self.fuse_layers = nn.ModuleList(fuse) if nb > 1 else None
-        self.relu = nn.ReLU(inplace=False)
 
     def forward(self, x):
         x = [branch(xi) for branch, xi in zip(self.branches, x)]
@@ -129,7 +123,6 @@ class HighResolutionNet(nn.Module):
         self.bn1 = _norm(bn_type, 64, bn_momentum)
         self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
         self.bn2 = _norm(bn_type, 64, bn_momentum)
-        self.relu = nn.ReLU(inplace=False)
         self.layer1 = _block_chain(Bottleneck, 64, 64, 4, bn_type, bn_momentum)
         prev = [256]
         for s in (2, 3, 4):
@@ -156,8 +149,8 @@ class HighResolutionNet(nn.Module):
         return nn.ModuleList(layers)
 
     def forward(self, x):
-        x = self.relu(self.bn1(self.conv1(x)))
-        x = self.relu(self.bn2(self.conv2(x)))
+        x = self.bn1(self.conv1(x), relu=True)
+        x = self.bn2(self.conv2(x), relu=True)
         x = self.layer1(x)
         ys = [x]
         for s in (2, 3, 4):

@@ -2,13 +2,12 @@
 names, construction order and initialisation (lib/models/backbones/resnet/resnet_models.py:107-178,
 resnet_backbone.py:21-118) so checkpoints interchange and equal seeds give equal weights. The classifier head
 (avgpool + fc) of the reference's ResNet is created only to consume the same random numbers and then dropped,
-exactly like the reference's backbone wrappers drop it. conv / BN / ReLU / max-pool run on MIOpen."""
+exactly like the reference's backbone wrappers drop it. Convolutions and max-pool run on MIOpen; BatchNorm with the
+ReLU / residual add behind it on the fused cseg_bn_* kernels (lib/models/tools/fused_bn.py)."""
 import math
 from collections import OrderedDict
 
 import torch.nn as nn
-
-from contrastiveseg_amd import kernels as K
 
 from contrastiveseg_amd.lib.models.tools.module_helper import ModuleHelper
 
@@ -25,17 +24,15 @@ class BasicBlock(nn.Module):
         bn = ModuleHelper.BatchNorm2d(bn_type=bn_type)
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
         self.bn1 = bn(planes)
-        self.relu = nn.ReLU(inplace=False)
-        self.relu_in = nn.ReLU(inplace=True)
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
         self.bn2 = bn(planes)
         self.downsample = downsample
         self.stride = stride
 
     def forward(self, x):
-        out = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        out = self.bn1(self.conv1(x), relu=True)
         res = x if self.downsample is None else self.downsample(x)
-        return K.fuse_sum_relu([out, res], [])          # residual add + ReLU in one kernel (cseg_fuse_sum)
+        return self.bn2(self.conv2(out), residual=res, relu=True)     # BN + residual add + ReLU in one apply pass
 
 
 class Bottleneck(nn.Module):
@@ -50,17 +47,14 @@ class Bottleneck(nn.Module):
         self.bn2 = bn(planes)
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
         self.bn3 = bn(planes * 4)
-        self.relu = nn.ReLU(inplace=False)
-        self.relu_in = nn.ReLU(inplace=True)
         self.downsample = downsample
         self.stride = stride
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
         res = x if self.downsample is None else self.downsample(x)
-        return K.fuse_sum_relu([out, res], [])          # residual add + ReLU in one kernel (cseg_fuse_sum)
+        return self.bn3(self.conv3(out), residual=res, relu=True)
 
 
 class ResNet(nn.Module):
@@ -69,12 +63,12 @@ class ResNet(nn.Module):
         bn = ModuleHelper.BatchNorm2d(bn_type=bn_type)
         self.inplanes = 128 if deep_base else 64
         if deep_base:
-            stem = [('conv1', nn.Conv2d(3, 64, 3, 2, 1, bias=False)), ('bn1', bn(64)), ('relu1', nn.ReLU(inplace=False)),
-                    ('conv2', nn.Conv2d(64, 64, 3, 1, 1, bias=False)), ('bn2', bn(64)), ('relu2', nn.ReLU(inplace=False)),
-                    ('conv3', nn.Conv2d(64, 128, 3, 1, 1, bias=False)), ('bn3', bn(128)),
-                    ('relu3', nn.ReLU(inplace=False))]
+            # the stateless relu1..3 children of the reference's stem are folded into the norm kernels
+            stem = [('conv1', nn.Conv2d(3, 64, 3, 2, 1, bias=False)), ('bn1', bn(64, act='relu')),
+                    ('conv2', nn.Conv2d(64, 64, 3, 1, 1, bias=False)), ('bn2', bn(64, act='relu')),
+                    ('conv3', nn.Conv2d(64, 128, 3, 1, 1, bias=False)), ('bn3', bn(128, act='relu'))]
         else:
-            stem = [('conv1', nn.Conv2d(3, 64, 7, 2, 3, bias=False)), ('bn1', bn(64)), ('relu1', nn.ReLU(inplace=False))]
+            stem = [('conv1', nn.Conv2d(3, 64, 7, 2, 3, bias=False)), ('bn1', bn(64, act='relu'))]
         self.resinit = nn.Sequential(OrderedDict(stem))
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1, ceil_mode=True)
         self.layer1 = self._make_layer(block, 64, layers[0], 1, bn_type)

@@ -1,13 +1,16 @@
 """Norm plug-in of the reference (lib/models/tools/module_helper.py:29-121), restricted to the two branches the
-hot-path configs reach: 'torchbn' -> nn.BatchNorm2d, 'torchsyncbn' -> nn.SyncBatchNorm (global-batch statistics
-over RCCL when a process group exists, plain batch norm otherwise). Pretrained loading mirrors :124-235 for the
-two backbone families of the hot path."""
+hot-path configs reach: 'torchbn' -> FusedBatchNorm2d (an nn.BatchNorm2d), 'torchsyncbn' -> FusedSyncBatchNorm (an
+nn.SyncBatchNorm: global-batch statistics over RCCL when a process group exists, plain batch norm otherwise). Both are
+computed by the cseg_bn_* HIP kernels and can fuse the ReLU / residual add that follows (fused_bn.py); parameters,
+buffers and state_dict keys are those of the torch classes. Pretrained loading mirrors :124-235 for the two backbone
+families of the hot path."""
 import torch
 import torch.nn as nn
 
+from contrastiveseg_amd.lib.models.tools.fused_bn import FusedBatchNorm2d, FusedSyncBatchNorm
 from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
 
-_NORMS = {'torchbn': nn.BatchNorm2d, 'torchsyncbn': nn.SyncBatchNorm}
+_NORMS = {'torchbn': FusedBatchNorm2d, 'torchsyncbn': FusedSyncBatchNorm}
 
 
 class ModuleHelper(object):
@@ -20,7 +23,9 @@ class ModuleHelper(object):
 
     @staticmethod
     def BNReLU(num_features, bn_type=None, **kwargs):
-        return nn.Sequential(ModuleHelper.BatchNorm2d(bn_type)(num_features, **kwargs), nn.ReLU())
+        # reference: nn.Sequential(BN, nn.ReLU()); the ReLU has no state, so folding it into the norm kernel keeps the
+        # state_dict keys ('0.weight', ...) unchanged
+        return nn.Sequential(ModuleHelper.BatchNorm2d(bn_type)(num_features, act='relu', **kwargs))
 
     @staticmethod
     def load_model(model, pretrained=None, all_match=True, network='resnet101'):

@@ -5,16 +5,18 @@ Parallel wrap, MI355X-first: one process per GPU, torch DistributedDataParallel 
 over xGMI. Gradient buckets are reduced on RCCL's own HIP stream while backward keeps producing gradients;
 `gradient_as_bucket_view` removes the grad->bucket copy; the bucket size is a config knob
 (network.ddp_bucket_mb, default 64 MB: xGMI rings are per-link bound, so fewer, larger messages than the
-25 MB NVSwitch-era default). All parameters receive gradients every step (the `loss + 0 * loss_contrast` trick of
-the reference keeps the projection head in the graph during warm-up), so the unused-parameter graph walk the
-reference enables (:66-71) is off. There is no single-process multi-GPU DataParallel path."""
+25 MB NVSwitch-era default). With the shipped model/criterion pairs all parameters receive gradients every step (the
+`loss + 0 * loss_contrast` trick of the reference keeps the projection head in the graph during warm-up), so the
+unused-parameter graph walk the reference always enables (:66-71) is switched on only where it is needed: when the
+model emits an auxiliary output (`seg_aux`: DeepLab's DSN head, the OCR aux head) that the configured criterion does
+not consume, or when `network.ddp_find_unused` says so. There is no single-process multi-GPU DataParallel path."""
 import os
 from collections import OrderedDict
 
 import torch
 import torch.nn as nn
 
-from contrastiveseg_amd.lib.utils.distributed import get_local_rank, get_rank, is_distributed
+from contrastiveseg_amd.lib.utils.distributed import device_index, get_rank, is_distributed
 from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
 
 
@@ -32,7 +34,7 @@ class ModuleRunner(object):
     def device(self):
         if torch.cuda.is_available() and not (self.configer.exists('gpu') and self.configer.get('gpu') is None
                                               and not is_distributed()):
-            return torch.device('cuda', get_local_rank() if is_distributed() else torch.cuda.current_device())
+            return torch.device('cuda', device_index() if is_distributed() else torch.cuda.current_device())
         return torch.device('cpu')
 
     def to_device(self, *params, force_list=False):
@@ -47,15 +49,26 @@ class ModuleRunner(object):
         bucket_mb = 64
         if self.configer.exists('network', 'ddp_bucket_mb'):
             bucket_mb = self.configer.get('network', 'ddp_bucket_mb')
-        find_unused = False          # e.g. deeplab_v3_contrast trained without its auxiliary head needs True
+        find_unused = self._has_unused_parameters()
         if self.configer.exists('network', 'ddp_find_unused'):
             find_unused = bool(self.configer.get('network', 'ddp_find_unused'))
         kwargs = dict(find_unused_parameters=find_unused, gradient_as_bucket_view=True, bucket_cap_mb=bucket_mb,
                       # SyncBN keeps BN buffers identical on all ranks; only the memory queues need rank 0's copy
                       broadcast_buffers=has_queues)
         if next(net.parameters()).is_cuda:
-            kwargs.update(device_ids=[get_local_rank()], output_device=get_local_rank())
+            kwargs.update(device_ids=[device_index()], output_device=device_index())
         return torch.nn.parallel.DistributedDataParallel(net, **kwargs)
+
+    def _has_unused_parameters(self):
+        """True when the model has a head whose output the configured criterion never reads (its parameters would get
+        no gradient and DDP's reducer would wait for them forever): models that emit `seg_aux` paired with a criterion
+        without an auxiliary term. deeplab_v3_contrast's DSN head feeds nothing else; the OCR aux head also feeds the
+        object-context gather, so it is always in the graph."""
+        if not (self.configer.exists('network', 'model_name') and self.configer.exists('loss', 'loss_type')):
+            return False
+        model = self.configer.get('network', 'model_name')
+        loss = self.configer.get('loss', 'loss_type')
+        return model.startswith('deeplab_v3') and 'aux' not in loss
 
     def load_net(self, net):
         net = self.to_device(net)

@@ -204,15 +204,20 @@ class Trainer(object):
 
         t0 = time.time()
         loss = self.pixel_loss(outputs, targets, with_embed=with_embed)
-        if self.with_memory and 'key' in outputs and 'lb_key' in outputs:
-            self._dequeue_and_enqueue(outputs['key'], outputs['lb_key'], segment_queue=net.segment_queue,
-                                      segment_queue_ptr=net.segment_queue_ptr, pixel_queue=net.pixel_queue,
-                                      pixel_queue_ptr=net.pixel_queue_ptr)
         self.loss_time.update(time.time() - t0)
 
         t0 = time.time()
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        if self.with_memory and 'key' in outputs and 'lb_key' in outputs:
+            # The reference enqueues between the loss and backward (:246-251); its loss holds a torch.cat COPY of the
+            # bank, so its gradient is that of the bank as it was during the forward. Here cseg_contrast_bwd re-reads
+            # the bank rows in place, so the in-place enqueue must come after backward: the keys are detached, the
+            # RNG draws are the same, hence bank contents, pointers and gradients are identical to the reference's.
+            # (kernels.PixelContrast.backward raises if the bank was modified in between.)
+            self._dequeue_and_enqueue(outputs['key'], outputs['lb_key'], segment_queue=net.segment_queue,
+                                      segment_queue_ptr=net.segment_queue_ptr, pixel_queue=net.pixel_queue,
+                                      pixel_queue_ptr=net.pixel_queue_ptr)
         self.optimizer.step()
         self.backward_time.update(time.time() - t0)
 
@@ -227,12 +232,19 @@ class Trainer(object):
         """The reference reduces the loss to rank 0 and calls .item() every step (:228-254); that is a host sync per
         step, so here it happens only when the line is printed."""
         c = self.configer
-        disp = self._last_loss.clone()
+        bad = sum((m.status[1] for m in self.pixel_loss.modules() if hasattr(m, 'bad_label_count')),
+                  torch.zeros((), dtype=torch.int32, device=self._last_loss.device))
+        disp = torch.stack([self._last_loss.float(), bad.float()])
         if is_distributed() and get_world_size() > 1:
             import torch.distributed as dist
-            dist.reduce(disp, dst=0)
-            disp = disp / get_world_size()
-        self.train_losses.update(disp.item(), self._last_batch)
+            dist.all_reduce(disp)               # every rank learns about bad labels on any rank
+            disp[0] = disp[0] / get_world_size()
+        disp = disp.tolist()
+        if disp[1] > 0:
+            raise RuntimeError("%d label values were neither ce_ignore_index nor in [0, num_classes): the fused CE "
+                               "kernel dropped them (nn.CrossEntropyLoss would have asserted); fix the label ids or "
+                               "loss.params.ce_ignore_index" % int(disp[1]))
+        self.train_losses.update(disp[0], self._last_batch)
         if not is_distributed() or get_rank() == 0:
             Log.info('Train Epoch: {0}\tTrain Iteration: {1}\t'
                      'Time {batch_time.sum:.3f}s / {2}iters, ({batch_time.avg:.3f})\t'

@@ -134,7 +134,7 @@ def fuse_sum_relu(same, low):
     return F.relu(y)
 
 
-def upsample_ce(seg, target, weight=None, ignore_index=-1):
+def upsample_ce(seg, target, weight=None, ignore_index=-1, status=None):
     pred = F.interpolate(seg, size=target.shape[-2:], mode="bilinear", align_corners=True)   # loss_contrast.py:180
     return F.cross_entropy(pred, target, weight=weight, ignore_index=ignore_index)            # loss_helper.py:186
 
@@ -177,6 +177,82 @@ def queue_write_pixels(keys, src_img, src_pos, dst_cls, dst_row, pixel_queue):
         pixel_queue[c, r] = F.normalize(feat[b, :, p], p=2, dim=0)
 
 
+# ---- fused (Sync)BatchNorm + residual + ReLU primitives (csrc/bn.hip), torch restatement ------------------------
+# What they restate: nn.BatchNorm2d / nn.SyncBatchNorm training forward+backward (module_helper.py:29-68 of the
+# reference -> torch's batch_norm) followed by the add / ReLU of the residual blocks. Statistics in fp64 like the kernel.
+def _bn_flat(x):
+    return x.reshape(x.shape[0], x.shape[1], -1)
+
+
+@torch.no_grad()
+def bn_stats(x):
+    f = _bn_flat(x).double()
+    return torch.stack([f.sum((0, 2)), (f * f).sum((0, 2))], dim=1)
+
+
+@torch.no_grad()
+def bn_finalize(moments, count, eps, momentum, running_mean, running_var, num_batches_tracked):
+    mean = moments[:, 0] / count
+    var = (moments[:, 1] / count - mean * mean).clamp_(min=0.0)
+    if running_mean is not None:
+        unbiased = var * (count / (count - 1.0)) if count > 1 else var
+        running_mean.copy_(((1.0 - momentum) * running_mean.double() + momentum * mean).float())
+        running_var.copy_(((1.0 - momentum) * running_var.double() + momentum * unbiased).float())
+    if num_batches_tracked is not None:
+        num_batches_tracked += 1
+    return torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=1).float()
+
+
+@torch.no_grad()
+def bn_stats_finalize(x, eps, momentum, running_mean, running_var, num_batches_tracked):
+    return bn_finalize(bn_stats(x), float(x.numel() // x.shape[1]), eps, momentum, running_mean, running_var,
+                       num_batches_tracked)
+
+
+def _bn_affine(x, mean_invstd, weight, bias):
+    shape = (1, -1) + (1,) * (x.dim() - 2)
+    a = mean_invstd[:, 1] if weight is None else weight * mean_invstd[:, 1]
+    xm = x - mean_invstd[:, 0].reshape(shape)
+    z = xm * a.reshape(shape)
+    if bias is not None:
+        z = z + bias.reshape(shape)
+    return xm, a, z
+
+
+@torch.no_grad()
+def bn_apply(x, mean_invstd, weight, bias, residual, relu):
+    _, _, z = _bn_affine(x, mean_invstd, weight, bias)
+    if residual is not None:
+        z = z + residual
+    return F.relu(z) if relu else z
+
+
+@torch.no_grad()
+def bn_bwd_reduce(dy, x, out, mean_invstd, weight, bias, mode):
+    xm, _, z = _bn_affine(x, mean_invstd, weight, bias)
+    g = dy
+    if mode == 1:
+        g = dy * (z > 0)
+    elif mode == 2:
+        g = dy * (out > 0)
+    s0 = _bn_flat(g).double().sum((0, 2))
+    s1 = (_bn_flat(g).double() * _bn_flat(xm).double()).sum((0, 2))
+    sums = torch.stack([s0, s1], dim=1)
+    return sums, (s1 * mean_invstd[:, 1].double()).float(), s0.float(), (g if mode == 2 else None)
+
+
+@torch.no_grad()
+def bn_bwd_apply(dy, x, mean_invstd, weight, bias, sums, count, mask_from_x):
+    xm, a, z = _bn_affine(x, mean_invstd, weight, bias)
+    shape = (1, -1) + (1,) * (x.dim() - 2)
+    g = dy * (z > 0) if mask_from_x else dy
+    if sums is None:
+        return g * a.reshape(shape)
+    k0 = (sums[:, 0] / count).float().reshape(shape)
+    k1 = (sums[:, 1] / count * mean_invstd[:, 1].double() ** 2).float().reshape(shape)
+    return a.reshape(shape) * (g - k0 - xm * k1)
+
+
 def install(monkeypatch_or_none=None):
     """Points the product's loss / model / trainer modules at this CPU restatement. TESTS AND THE cpu_baseline LEG
     ONLY. Returns a function that restores the HIP binding."""
@@ -186,10 +262,10 @@ def install(monkeypatch_or_none=None):
     import contrastiveseg_amd.lib.loss.loss_contrast_mem as lm
     import contrastiveseg_amd.lib.loss.loss_helper as lh
     import contrastiveseg_amd.lib.models.backbones.hrnet_backbone as hb
-    import contrastiveseg_amd.lib.models.backbones.resnet_backbone as rb
     import contrastiveseg_amd.lib.models.nets.hrnet as nh
+    import contrastiveseg_amd.lib.models.tools.fused_bn as fb
     import contrastiveseg_amd.segmentor.trainer_contrastive as tc
-    mods = [lc, lm, lh, nh, hb, rb, tc]
+    mods = [lc, lm, lh, nh, hb, tc, fb]
     saved = [m.K for m in mods]
     for m in mods:
         if monkeypatch_or_none is not None:

@@ -57,7 +57,7 @@ LOSS_CASES = {
     "cfg2_full": dict(seed=304, B=8, K=19, H=512, W=1024, stride=4, D=256, blocky=True, n_rect=24,
                       loss="contrast_ce_loss",
                       contrast=dict(max_samples=1024, max_views=100, temperature=0.1, loss_weight=0.1),
-                      ce_weight=CITYSCAPES_W, grads=False, torch_seed=304),
+                      ce_weight=CITYSCAPES_W, grads="subset", torch_seed=304),
     "cfg2_uniform": dict(seed=305, B=8, K=19, H=512, W=1024, stride=4, D=256, blocky=False,
                          loss="contrast_ce_loss",
                          contrast=dict(max_samples=1024, max_views=100, temperature=0.1, loss_weight=0.1),
@@ -141,7 +141,17 @@ def run_loss_case(name, c):
         out["anchor_cls"] = y_.long().numpy()                   # [T]
         out["labels_ds"] = labels.numpy().astype(np.int16)
         out["predict"] = predict.view(B, -1).numpy().astype(np.int16)
-    if c["grads"]:
+    if c["grads"] == "subset":
+        # headline shapes: dense gradients would be 20 + 268 MB; keep a strided slice of d_seg of every image and
+        # every GRAD_ROW_STEP-th anchor row of d_embed (class-major, view order)
+        out["d_seg_s%d" % GRAD_SEG_STEP] = t_seg.grad.numpy()[:, :, ::GRAD_SEG_STEP, ::GRAD_SEG_STEP].copy()
+        g = t_embed.grad.numpy().reshape(embed.shape[0], embed.shape[1], -1)
+        img = out["anchor_img"].reshape(-1)[::GRAD_ROW_STEP]
+        pix = out["anchor_pix"].reshape(-1)[::GRAD_ROW_STEP]
+        out["d_embed_rows_s%d" % GRAD_ROW_STEP] = g[img, :, pix]
+        out["d_embed_abs_sum"] = float(np.abs(t_embed.grad.numpy().astype(np.float64)).sum())
+        out["d_seg_abs_sum"] = float(np.abs(t_seg.grad.numpy().astype(np.float64)).sum())
+    elif c["grads"]:
         out["d_seg"] = t_seg.grad.numpy()
         g = t_embed.grad.numpy().reshape(embed.shape[0], embed.shape[1], -1)
         img = out["anchor_img"].reshape(-1)
@@ -157,6 +167,9 @@ def run_loss_case(name, c):
     print("loss_%s: total %.6f contrast %.6f n_view %d T %d" % (name, out["total"], out["contrast"],
                                                                  out["n_view"], len(out["anchor_cls"])))
 
+
+GRAD_SEG_STEP = 4       # cfg2_full: d_seg[:, :, ::4, ::4]
+GRAD_ROW_STEP = 8       # cfg2_full: every 8th anchor row of d_embed
 
 ENQ_CASES = {
     "enq_a": dict(seed=21, B=3, K=7, H=64, W=128, kstride=4, D=16, network_stride=8, memory_size=9,
@@ -219,12 +232,30 @@ MODEL_CASES = {
     # fp32 rounding differences by up to 1/sqrt(eps) -- an ill-conditioned comparison, not a property of the model
     "deeplab_v3_contrast": dict(backbone="deepbase_resnet101_dilated8", K=19, B=2, H=65, W=97, seed=33, contrast={},
                                 mode="eval"),
+    # train-mode BN with B=6 so that the image-pool BN of the ASPP head sees six values per channel
+    "deeplab_v3_contrast_train": dict(model="deeplab_v3_contrast", backbone="deepbase_resnet101_dilated8", K=19, B=6,
+                                      H=97, W=129, seed=35, contrast={}, spread=True),
+    # THE BENCHED CONFIGURATION (BASELINE.json configs[1]): HRNet-W48 at 3x512x1024, features 128x256. On the GPU this
+    # reaches the same MIOpen solvers as bench.py (shipped miopen_db records active). seg stored dense.
+    "hrnet_w48_contrast_fullres": dict(model="hrnet_w48_contrast", backbone="hrnet48", K=19, B=2, H=512, W=1024,
+                                       seed=34, contrast={}, embed_step=8),
+    # memory-bank wrapper: forward(img, labels) -> seg / embed / key / lb_key (nets/hrnet.py:178-188 of the reference)
+    "hrnet_w48_mem": dict(backbone="hrnet48", K=19, B=2, H=64, W=128, seed=36, with_labels=True,
+                          contrast=dict(with_memory=True, memory_size=16, pixel_update_freq=10)),
 }
 
 
 def model_input(c):
     rs = np.random.RandomState(c["seed"])
-    return rs.standard_normal((c["B"], 3, c["H"], c["W"])).astype(np.float32)
+    x = rs.standard_normal((c["B"], 3, c["H"], c["W"])).astype(np.float32)
+    if c.get("spread"):
+        # per-image contrast and brightness like real photographs: without it the image-level pooled features of
+        # i.i.d. noise images are nearly identical, and a train-mode BN over B such values (ASPP image pooling) divides
+        # rounding noise by a vanishing batch variance -- an ill-conditioned comparison for ANY two implementations
+        gain = np.linspace(0.4, 1.6, c["B"]).astype(np.float32).reshape(-1, 1, 1, 1)
+        bias = np.linspace(-0.8, 0.8, c["B"]).astype(np.float32).reshape(-1, 1, 1, 1)
+        x = x * gain + bias * np.array([1.0, -0.5, 0.25], dtype=np.float32).reshape(1, 3, 1, 1)
+    return x
 
 
 def freeze_dropout(net):
@@ -234,6 +265,11 @@ def freeze_dropout(net):
             m.eval()            # the only stochastic layer; BN stays in train mode (batch statistics)
 
 
+def model_labels(c):
+    rs = np.random.RandomState(c["seed"] + 7)
+    return rs.randint(-1, c["K"], size=(c["B"], c["H"], c["W"])).astype(np.int64)
+
+
 def run_model_case(name, c):
     """Reference model (seed 304 init, train-mode BN, dropout off) forward on a seeded input; stores the logits and a
     strided slice of the embedding. The repo's models are seed-identical (tests/test_models_vs_reference.py), so a
@@ -241,21 +277,158 @@ def run_model_case(name, c):
     import torch
     ref_shim.install()
     from lib.models.model_manager import ModelManager
-    cfg = ref_shim.configer(num_classes=c["K"], model_name=name, backbone=c["backbone"], contrast=c["contrast"])
+    cfg = ref_shim.configer(num_classes=c["K"], model_name=c.get("model", name), backbone=c["backbone"],
+                            contrast=c["contrast"])
     torch.manual_seed(304)
     net = ModelManager(cfg).semantic_segmentor().train()
     freeze_dropout(net)
     if c.get("mode") == "eval":
         net.eval()
     with torch.no_grad():
-        out = net(torch.from_numpy(model_input(c)), with_embed=True)
-    res = {"seg": out["seg"].numpy(), "embed_s4": out["embed"][:, :, ::4, ::4].numpy().copy(),
+        if c.get("with_labels"):
+            out = net(torch.from_numpy(model_input(c)), torch.from_numpy(model_labels(c)), with_embed=True)
+        else:
+            out = net(torch.from_numpy(model_input(c)), with_embed=True)
+    es = c.get("embed_step", 4)
+    res = {"seg": out["seg"].numpy(), "embed_s%d" % es: out["embed"][:, :, ::es, ::es].numpy().copy(),
            "embed_shape": np.array(out["embed"].shape)}
     if "seg_aux" in out:
         res["seg_aux"] = out["seg_aux"].numpy()
+    if "key" in out:
+        assert torch.equal(out["key"], out["embed"]) and torch.equal(out["lb_key"], torch.from_numpy(model_labels(c)))
+        res["has_key"] = np.array(1)
+    # the reference's OWN fp32 rounding noise on this input: same weights and input in fp64 (input widened exactly)
+    net64 = net.double()
+    with torch.no_grad():
+        x64 = torch.from_numpy(model_input(c)).double()
+        out64 = net64(x64, torch.from_numpy(model_labels(c)), with_embed=True) if c.get("with_labels") else \
+            net64(x64, with_embed=True)
+    res["seg_fp32_noise"] = np.array(float((out64["seg"] - out["seg"].double()).abs().max()))
+    res["embed_fp32_noise"] = np.array(float((out64["embed"] - out["embed"].double()).abs().max()))
     np.savez_compressed(os.path.join(OUT, "model_%s.npz" % name), **res)
-    print("model_%s: seg %s absmax %.4f embed %s" % (name, tuple(out["seg"].shape), float(out["seg"].abs().max()),
-                                                      tuple(out["embed"].shape)))
+    print("model_%s: seg %s absmax %.4f embed %s; reference fp32-vs-fp64 noise: seg %.2e embed %.2e" % (
+        name, tuple(out["seg"].shape), float(out["seg"].abs().max()), tuple(out["embed"].shape),
+        float(res["seg_fp32_noise"]), float(res["embed_fp32_noise"])))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# One SGD step through the whole network (backward through the backbone): model + criterion + SGD driven exactly as
+# segmentor/trainer_contrastive.py:204-261 does (forward, loss, [_dequeue_and_enqueue], zero_grad, backward, step),
+# dropout frozen, then a second forward+loss on the same batch. Stored: both losses, gradients and post-step values
+# of a few tensors spread over the network.
+# ---------------------------------------------------------------------------------------------------------------
+STEP_CASES = {
+    "step_hrnet48_contrast": dict(model="hrnet_w48_contrast", backbone="hrnet48", loss="contrast_ce_loss", K=7, B=2,
+                                  H=128, W=256, seed=41, torch_seed=304,
+                                  contrast=dict(max_samples=256, max_views=16, proj_dim=64),
+                                  watch=["backbone.conv1.weight", "backbone.layer1.0.downsample.0.weight",
+                                         "backbone.stage2.0.branches.1.3.bn2.weight",
+                                         "backbone.stage3.1.fuse_layers.2.0.0.0.weight",
+                                         "backbone.stage4.2.fuse_layers.0.3.0.weight",
+                                         "backbone.stage4.0.branches.3.0.conv1.weight",
+                                         "cls_head.0.weight", "cls_head.3.weight", "proj_head.proj.1.0.weight",
+                                         "proj_head.proj.2.weight"]),
+    "step_hrnet48_ocr": dict(model="hrnet_w48_ocr_contrast", backbone="hrnet48", loss="contrast_auxce_loss", K=7, B=2,
+                             H=128, W=192, seed=42, torch_seed=11,
+                             contrast=dict(max_samples=256, max_views=16, proj_dim=64),
+                             watch=["backbone.conv1.weight", "backbone.stage3.0.fuse_layers.1.0.0.0.weight",
+                                    "conv3x3.0.weight", "ocr_distri_head.object_context_block.f_pixel.0.weight",
+                                    "ocr_distri_head.object_context_block.f_object.0.weight",
+                                    "ocr_distri_head.object_context_block.f_up.0.weight",
+                                    "ocr_distri_head.conv_bn_dropout.0.weight", "cls_head.weight", "aux_head.2.weight",
+                                    "proj_head.proj.2.weight"]),
+    "step_hrnet48_mem": dict(model="hrnet_w48_mem", backbone="hrnet48", loss="mem_contrast_ce_loss", K=7, B=2,
+                             H=128, W=256, seed=43, torch_seed=304, network_stride=8,
+                             contrast=dict(max_samples=256, max_views=1, proj_dim=256, with_memory=True,
+                                           memory_size=12, pixel_update_freq=10, loss_weight=1.0),
+                             watch=["encoder_q.backbone.conv1.weight",
+                                    "encoder_q.backbone.stage4.2.fuse_layers.0.3.0.weight",
+                                    "encoder_q.cls_head.0.weight", "encoder_q.proj_head.proj.0.weight",
+                                    "encoder_q.proj_head.proj.2.weight"]),
+    "step_resnet50_deeplab": dict(model="deeplab_v3_contrast", backbone="deepbase_resnet50_dilated8",
+                                  loss="contrast_auxce_loss", K=7, B=4, H=97, W=129, seed=44, torch_seed=5,
+                                  contrast=dict(max_samples=128, max_views=8, proj_dim=64),
+                                  watch=["backbone.resinit.conv1.weight", "backbone.layer2.0.downsample.0.weight",
+                                         "backbone.layer4.2.conv2.weight", "decoder.layer_aspp.b0.0.weight",
+                                         "decoder.layer_aspp.b1.0.weight", "decoder.layer_aspp.b4.1.weight", "decoder.layer_aspp.project.0.weight",
+                                         "decoder.layer_dsn.0.weight", "decoder.refine.2.weight",
+                                         "proj_head.proj.2.weight"]),
+}
+SGD = dict(lr=0.01, momentum=0.9, weight_decay=5e-4)
+
+
+def watch_subset(a, cap=16384):
+    """Every k-th element of the flattened tensor (<= cap values): keeps the golden files small."""
+    flat = np.ascontiguousarray(a).reshape(-1)
+    return flat[::max(1, flat.size // cap)].copy()
+
+
+def step_inputs(c):
+    rs = np.random.RandomState(c["seed"])
+    img = rs.standard_normal((c["B"], 3, c["H"], c["W"])).astype(np.float32)
+    target, _, _ = O.synth_case(c["seed"] + 1, c["B"], c["K"], c["H"], c["W"], 4, 8, blocky=True, n_rect=10)
+    return img, target
+
+
+def run_step_case(name, c):
+    import importlib
+    import torch
+    ref_shim.install()
+    from lib.loss.loss_manager import SEG_LOSS_DICT
+    from lib.models.model_manager import ModelManager
+    cfg = ref_shim.configer(num_classes=c["K"], model_name=c["model"], backbone=c["backbone"], loss_type=c["loss"],
+                            contrast=c["contrast"])
+    torch.manual_seed(304)
+    net = ModelManager(cfg).semantic_segmentor().train()
+    freeze_dropout(net)
+    crit = SEG_LOSS_DICT[c["loss"]](cfg)
+    opt = torch.optim.SGD(net.parameters(), **SGD)
+    img, target = step_inputs(c)
+    img, target = torch.from_numpy(img), torch.from_numpy(target)
+    with_memory = "with_memory" in c["contrast"]
+    if with_memory:
+        for m in ("lib.vis.seg_visualizer", "lib.datasets.data_loader", "segmentor.tools.evaluator"):
+            if m not in sys.modules:
+                stub = types.ModuleType(m)
+                stub.SegVisualizer = object
+                stub.DataLoader = object
+                stub.get_evaluator = lambda *a, **k: None
+                sys.modules[m] = stub
+        tc = importlib.import_module("segmentor.trainer_contrastive")
+        me = types.SimpleNamespace(network_stride=c["network_stride"], memory_size=c["contrast"]["memory_size"],
+                                   pixel_update_freq=c["contrast"]["pixel_update_freq"])
+    named = dict(net.named_parameters())
+    res = {}
+    torch.manual_seed(c["torch_seed"])
+    for it in range(2):
+        if with_memory:
+            out = net(img, target, with_embed=True)
+            out["pixel_queue"], out["pixel_queue_ptr"] = net.pixel_queue, net.pixel_queue_ptr
+            out["segment_queue"], out["segment_queue_ptr"] = net.segment_queue, net.segment_queue_ptr
+        else:
+            out = net(img, with_embed=True)
+        loss = crit(out, target, with_embed=True)
+        res["loss%d" % it] = np.array(float(loss.detach()))
+        if it == 1:
+            break
+        if with_memory:
+            tc.Trainer._dequeue_and_enqueue(me, out["key"], out["lb_key"], segment_queue=net.segment_queue,
+                                            segment_queue_ptr=net.segment_queue_ptr, pixel_queue=net.pixel_queue,
+                                            pixel_queue_ptr=net.pixel_queue_ptr)
+            res["segment_queue_after"] = net.segment_queue.numpy().copy()
+            res["pixel_queue_after"] = net.pixel_queue.numpy().copy()
+        opt.zero_grad()
+        loss.backward()
+        for w in c["watch"]:
+            res["grad/" + w] = watch_subset(named[w].grad.numpy())
+            res["gradnorm/" + w] = np.array(np.sqrt((named[w].grad.numpy().astype(np.float64) ** 2).sum()))
+        before = {w: named[w].detach().numpy().copy() for w in c["watch"]}
+        opt.step()
+        for w in c["watch"]:
+            res["delta/" + w] = watch_subset(named[w].detach().numpy() - before[w])      # the SGD update itself
+    np.savez_compressed(os.path.join(OUT, "%s.npz" % name), **res)
+    print("%s: loss %.6f -> %.6f ; |grad conv1|max %.3e" % (name, res["loss0"], res["loss1"],
+                                                             np.abs(res["grad/" + c["watch"][0]]).max()))
 
 
 def main():
@@ -272,6 +445,9 @@ def main():
     for name, c in MODEL_CASES.items():
         if a.only is None or a.only == name or a.only == "models":
             run_model_case(name, c)
+    for name, c in STEP_CASES.items():
+        if a.only is None or a.only == name or a.only == "steps":
+            run_step_case(name, c)
 
 
 if __name__ == "__main__":

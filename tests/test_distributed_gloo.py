@@ -35,6 +35,7 @@ def _configer(c, budget, max_samples):
     k = dict(proj_dim=c["D"], base_temperature=0.07, use_rmi=False, warmup_iters=0)
     k.update(c["contrast"])
     k["max_samples"] = max_samples
+    k["cross_rank"] = True                   # opt-in (the code default is the reference's per-rank loss)
     k["cross_rank_budget"] = budget
     k["cross_rank_rng"] = "global"           # index-for-index equality with the single-process oracle
     return Configer(config_dict={"data": {"num_classes": c["K"]},
@@ -110,7 +111,7 @@ def _ddp_worker(rank, world, port, q):
     cpu_port.install(None)
     # torch's SyncBatchNorm refuses CPU modules under DDP; on the CPU test bench plain BN stands in for it
     import contrastiveseg_amd.lib.models.tools.module_helper as mh
-    mh._NORMS['torchsyncbn'] = torch.nn.BatchNorm2d
+    mh._NORMS['torchsyncbn'] = mh.FusedBatchNorm2d
     from contrastiveseg_amd.lib.utils.tools.configer import Configer
     from contrastiveseg_amd.segmentor.tools.data_helper import SyntheticLoader
     from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
@@ -213,3 +214,109 @@ def test_cross_rank_local_rng_streams():
         mine = np.nonzero(owner == r)[0]
         rows = (np.arange(plans[0].n_view)[:, None] * plans[0].T + mine[None, :]).reshape(-1)
         assert np.array_equal(res[r][2], sel_pix.numpy()[rows] - r * B * P)
+
+
+def _per_rank_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import cpu_port
+    cpu_port.install(None)
+    from contrastiveseg_amd.lib.loss.loss_contrast import PixelContrastLoss
+    c, (target, seg, embed, _) = _case()
+    B = c["B"] // world
+    sl = slice(rank * B, (rank + 1) * B)
+    cfg = _configer(c, "per_rank", 256)
+    cfg.get("contrast").pop("cross_rank")          # code default: the reference's DDP behaviour
+    crit = PixelContrastLoss(cfg)
+    assert crit.cross_rank is False
+    e = torch.from_numpy(embed[sl]).requires_grad_(True)
+    torch.manual_seed(11)
+    loss = crit(e, torch.from_numpy(target[sl]), seg=torch.from_numpy(seg[sl]))
+    loss.backward()
+    q.put((rank, float(loss.detach()), e.grad.numpy(), crit.last_selection["sel_pix"].numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_default_is_the_references_per_rank_loss():
+    """without `contrast.cross_rank` every rank of a multi-process run computes exactly the loss
+    a single process would compute on that rank's images alone (the reference's DDP objective,
+    trainer_contrastive.py:241): same anchors, same loss, same gradient, no data-path collective."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_per_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle import cpu_port
+    restore = cpu_port.install(None)
+    try:
+        from contrastiveseg_amd.lib.loss.loss_contrast import PixelContrastLoss
+        c, (target, seg, embed, _) = _case()
+        B = c["B"] // world
+        for rank, loss, grad, sel in res:
+            sl = slice(rank * B, (rank + 1) * B)
+            crit = PixelContrastLoss(_configer(c, "per_rank", 256))      # no process group here: plain local loss
+            e = torch.from_numpy(embed[sl]).requires_grad_(True)
+            torch.manual_seed(11)
+            want = crit(e, torch.from_numpy(target[sl]), seg=torch.from_numpy(seg[sl]))
+            want.backward()
+            assert np.array_equal(sel, crit.last_selection["sel_pix"].numpy())
+            assert abs(loss - float(want.detach())) < 1e-6 * max(1.0, abs(float(want.detach())))
+            assert np.allclose(grad, e.grad.numpy(), rtol=1e-5, atol=1e-9)
+    finally:
+        restore()
+
+
+def _syncbn_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import cpu_port
+    cpu_port.install(None)
+    from contrastiveseg_amd.lib.models.tools.fused_bn import FusedSyncBatchNorm
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 12, 10, 18, generator=gen) * 2 + 1
+    g = torch.randn(4, 12, 10, 18, generator=gen)
+    sl = slice(rank * 2, rank * 2 + 2)
+    m = FusedSyncBatchNorm(12).train()
+    xd = x[sl].clone().requires_grad_(True)
+    y = m(xd, relu=True)
+    y.backward(g[sl])
+    q.put((rank, y.detach().numpy(), xd.grad.numpy(), m.weight.grad.numpy(), m.running_var.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fused_syncbn_host_logic_two_ranks_equal_single_process():
+    """FusedSyncBatchNorm's exchange (one all-reduce of the packed fp64 moments forward, one of the gradient sums
+    backward) with the device half replaced by oracle/cpu_port.py: two ranks with half the batch each must reproduce
+    torch.nn.BatchNorm2d + ReLU on the whole batch (what nn.SyncBatchNorm of the reference computes)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 12, 10, 18, generator=gen) * 2 + 1
+    g = torch.randn(4, 12, 10, 18, generator=gen)
+    bn = torch.nn.BatchNorm2d(12).train()
+    xd = x.clone().requires_grad_(True)
+    y = torch.relu(bn(xd))
+    y.backward(g)
+    assert np.abs(np.concatenate([res[0][1], res[1][1]]) - y.detach().numpy()).max() <= 2e-6
+    assert np.abs(np.concatenate([res[0][2], res[1][2]]) - xd.grad.numpy()).max() <= 2e-6
+    assert np.abs(res[0][3] + res[1][3] - bn.weight.grad.numpy()).max() <= 1e-4
+    assert np.abs(res[0][4] - bn.running_var.numpy()).max() <= 1e-6

@@ -1,0 +1,151 @@
+"""One SGD step through the whole network against the reference (tests/golden/step_*.npz, oracle/make_golden.py
+STEP_CASES): the reference's model + criterion + SGD are driven as segmentor/trainer_contrastive.py:204-261 does
+(forward, loss, [_dequeue_and_enqueue], zero_grad, backward, step) and the golden stores the step-1 loss, gradients of
+tensors spread over the network (stem, exchange units, heads), the SGD update of each, and the loss of a second
+forward on the same batch. This pins BACKWARD through the backbone (kernel adjoints wired into autograd: fused
+BN/ReLU/add, exchange sums, upsample+concat, CE, contrast) -- not just "loss finite, weights changed".
+
+  * CPU leg (not gpu): the repo's model classes with the device half replaced by oracle/cpu_port.py -- host wiring.
+  * GPU leg: the product path through the C-ABI. Bars: losses 1e-3 relative; gradients/updates 1e-3 of the tensor's
+    largest entry (and 5e-3 relative to the gradient norm in L2)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_port
+from oracle.make_golden import SGD, STEP_CASES, freeze_dropout, step_inputs, watch_subset
+
+
+def _setup(c, dev):
+    from contrastiveseg_amd.lib.loss.loss_manager import SEG_LOSS_DICT
+    from contrastiveseg_amd.lib.models.model_manager import ModelManager
+    from contrastiveseg_amd.lib.utils.tools.configer import Configer
+    contrast = {"proj_dim": 256, "temperature": 0.1, "base_temperature": 0.07, "max_samples": 1024, "max_views": 100,
+                "loss_weight": 0.1, "use_rmi": False, "use_lovasz": False, "warmup_iters": 0}
+    contrast.update(c["contrast"])
+    cfg = Configer(config_dict={
+        "data": {"num_classes": c["K"]},
+        "network": {"backbone": c["backbone"], "model_name": c["model"], "bn_type": "torchsyncbn", "resume": None,
+                    "pretrained": None, "multi_grid": [1, 1, 1], "stride": c.get("network_stride", 8),
+                    "loss_weights": {"aux_loss": 0.4, "seg_loss": 1.0}},
+        "contrast": contrast,
+        "loss": {"loss_type": c["loss"], "params": {"ce_ignore_index": -1, "ce_reduction": "elementwise_mean"}}})
+    torch.manual_seed(304)
+    net = ModelManager(cfg).semantic_segmentor().train()
+    freeze_dropout(net)
+    net = net.to(dev)
+    crit = SEG_LOSS_DICT[c["loss"]](cfg).to(dev)
+    return cfg, net, crit
+
+
+def _run(c, dev):
+    """Mirrors oracle/make_golden.py:run_step_case with the product's modules (and Trainer._dequeue_and_enqueue)."""
+    from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
+    cfg, net, crit = _setup(c, dev)
+    opt = torch.optim.SGD(net.parameters(), **SGD)
+    img, target = step_inputs(c)
+    img, target = torch.from_numpy(img).to(dev), torch.from_numpy(target).to(dev)
+    with_memory = "with_memory" in c["contrast"]
+    named = dict(net.named_parameters())
+    res = {}
+    torch.manual_seed(c["torch_seed"])
+    for it in range(2):
+        if with_memory:
+            out = net(img, target, with_embed=True)
+            out["pixel_queue"], out["pixel_queue_ptr"] = net.pixel_queue, net.pixel_queue_ptr
+            out["segment_queue"], out["segment_queue_ptr"] = net.segment_queue, net.segment_queue_ptr
+        else:
+            out = net(img, with_embed=True)
+        loss = crit(out, target, with_embed=True)
+        res["loss%d" % it] = float(loss.detach())
+        if it == 1:
+            break
+        opt.zero_grad()
+        loss.backward()
+        if with_memory:
+            # The reference enqueues BEFORE backward (trainer_contrastive.py:246-251) but its loss holds a copy of the
+            # bank (torch.cat), so its gradient is that of the bank as it was during the forward. The product reads the
+            # bank in place and therefore enqueues AFTER backward (Trainer.train_step); bank, pointers and gradients
+            # must still equal the reference's.
+            me = Trainer.__new__(Trainer)
+            me.network_stride, me.memory_size = c["network_stride"], c["contrast"]["memory_size"]
+            me.pixel_update_freq = c["contrast"]["pixel_update_freq"]
+            me._dequeue_and_enqueue(out["key"], out["lb_key"], segment_queue=net.segment_queue,
+                                    segment_queue_ptr=net.segment_queue_ptr, pixel_queue=net.pixel_queue,
+                                    pixel_queue_ptr=net.pixel_queue_ptr)
+            res["segment_queue_after"] = net.segment_queue.cpu().numpy().copy()
+            res["pixel_queue_after"] = net.pixel_queue.cpu().numpy().copy()
+        before = {}
+        for w in c["watch"]:
+            g = named[w].grad.detach().cpu().numpy()
+            res["grad/" + w] = watch_subset(g)
+            res["gradnorm/" + w] = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            before[w] = named[w].detach().cpu().numpy().copy()
+        opt.step()
+        for w in c["watch"]:
+            res["delta/" + w] = watch_subset(named[w].detach().cpu().numpy() - before[w])
+    return res
+
+
+def _compare(res, g, c, loss_rtol, grad_tol, loss1_rtol):
+    assert abs(res["loss0"] - float(g["loss0"])) <= loss_rtol * abs(float(g["loss0"])), (res["loss0"], float(g["loss0"]))
+    worst = {}
+    for w in c["watch"]:
+        for kind in ("grad/", "delta/"):
+            ref = g[kind + w]
+            scale = np.abs(ref).max()
+            err = np.abs(res[kind + w] - ref).max() / scale
+            worst[kind + w] = err
+            assert err <= grad_tol, (kind + w, err, scale)
+        n_ref = float(g["gradnorm/" + w])
+        assert abs(res["gradnorm/" + w] - n_ref) <= 5 * grad_tol * n_ref, (w, res["gradnorm/" + w], n_ref)
+    if "segment_queue_after" in g.files:
+        assert np.abs(res["segment_queue_after"] - g["segment_queue_after"]).max() <= 1e-4
+        assert np.abs(res["pixel_queue_after"] - g["pixel_queue_after"]).max() <= 1e-4
+    # the second loss sees the first step's rounding differences amplified by the update (lr x gradient)
+    assert abs(res["loss1"] - float(g["loss1"])) <= loss1_rtol * abs(float(g["loss1"])), (res["loss1"], float(g["loss1"]))
+    return worst
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name", ["step_hrnet48_contrast", "step_hrnet48_mem", "step_resnet50_deeplab"])
+def test_sgd_step_cpu_port_matches_reference(name, golden_dir, monkeypatch):
+    cpu_port.install(monkeypatch)
+    c = STEP_CASES[name]
+    g = np.load(os.path.join(golden_dir, "%s.npz" % name))
+    _compare(_run(c, torch.device("cpu")), g, c, 1e-5, 2e-4, 1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(STEP_CASES))
+def test_sgd_step_gpu_matches_reference(name, golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    torch.backends.cudnn.benchmark = False
+    c = STEP_CASES[name]
+    g = np.load(os.path.join(golden_dir, "%s.npz" % name))
+    worst = _compare(_run(c, torch.device("cuda:0")), g, c, 1e-3, 1e-3, 1e-3)
+    print(name, "worst rel err", max(worst.values()))
+
+
+@pytest.mark.gpu
+def test_bank_update_between_forward_and_backward_is_rejected():
+    """the bank is read in place by forward and backward; an enqueue in between must not pass
+    silently."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from contrastiveseg_amd import kernels as K
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    A = torch.nn.functional.normalize(torch.randn(64, 32, generator=g), dim=1).to(dev).requires_grad_(True)
+    yl = torch.randint(0, 5, (64,), generator=g).int().to(dev)
+    sq = torch.nn.functional.normalize(torch.randn(5, 8, 32, generator=g), dim=2).to(dev)
+    pq = torch.nn.functional.normalize(torch.randn(5, 8, 32, generator=g), dim=2).to(dev)
+    loss = K.ContrastOnAnchors.apply(A, yl, "bank", 0.1, 0.07, None, None, sq, pq)
+    keys = torch.nn.functional.normalize(torch.randn(1, 32, 4, 4, generator=g), dim=1).to(dev)
+    z = torch.zeros(1, dtype=torch.int32, device=dev)
+    K.queue_write_pixels(keys, z, z, z + 1, z, pq)
+    with pytest.raises(RuntimeError, match="memory bank was modified"):
+        loss.backward()
