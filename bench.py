@@ -1,22 +1,35 @@
 """bench.py -- contrastive train-step throughput on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" = one full contrastive training iteration of `configs/cityscapes/H_48_D_4.json` (BASELINE.json configs[1]:
-HRNet-W48 + contrast_ce_loss, synthetic Cityscapes 3x512x1024, 19 classes, per-GPU batch 8, fp32, tau 0.1,
-max_samples 1024, with_embed on): forward + criterion (HIP kernels) + backward + RCCL gradient all-reduce + SGD, on a
-batch that is already resident in HBM. W untimed warm-up steps, then exactly K timed steps bracketed by
-barrier + synchronize; time = MAX over ranks; rank 0 prints ONE JSON line.
+N > 1: when not already started by torch.distributed.run (no RANK/WORLD_SIZE in the environment) bench.py launches N
+ranks of itself (one per GPU, RCCL over xGMI, rendezvous on 127.0.0.1) and forwards rank 0's JSON line; when the
+driver starts it under `python -m torch.distributed.run ... bench.py --gpus N` it just joins the process group.
+
+A "step" = one full contrastive training iteration of the workload's config: forward + criterion (HIP kernels) +
+backward + RCCL gradient all-reduce + SGD, on a batch that is already resident in HBM. W untimed warm-up steps, then
+exactly K timed steps bracketed by barrier + synchronize; time = MAX over ranks; rank 0 prints ONE JSON line.
+
+Workloads (--workload):
+  cfg2 (default)  BASELINE.json configs[1]/[2]: HRNet-W48 + contrast_ce_loss, synthetic Cityscapes 3x512x1024x19,
+                  global batch 8 (`configs/cityscapes/H_48_D_4.json`), fp32, tau 0.1, max_samples 1024, with_embed on.
+  cfg4            configs[3]: DeepLabV3-R101-d8 + contrast_auxce_loss, 3x512x1024x19, global batch 8.
+  cfg4mem         the same network with the 4096-entry-per-class-pair pixel/segment memory bank (deeplab_v3_mem).
+  cfg5            configs[4]: HRNet-W48-OCR + contrast_auxce_loss, COCO-Stuff shapes 3x520x520x171, global batch 16,
+                  blocky labels (uniform labels cannot be mined at 171 classes).
+Scaling (--scaling): `strong` (default) = the BASELINE configuration: GLOBAL batch fixed (8 resp. 16), split over the
+ranks; `weak` = per-GPU batch fixed at the global batch of the config. With N > 1 and strong scaling the weak-scaling
+throughput is measured as well (fewer steps, after the timed region) and reported under "weak".
 
 Besides the contract fields the line carries
   roofline      whole-step view of the dominant work (dense conv contraction on MIOpen, MFMA-bound in fp32):
-                achieved = images/s x 2.0759 TFLOP/image (counted on the reference)
-                against the fp32 MFMA peak of the N GPUs; step time from HIP events on the compute stream.
+                achieved = images/s x TFLOP/image (counted on the reference) against the fp32
+                MFMA peak of the N GPUs; step time from HIP events on the compute stream; traffic = HBM bytes per step
+                from the committed rocprofv3 PMC passes (profiles/r02_step_pmc.json), null if that file is absent.
   kernels       per hand-written HIP kernel at this workload's shapes: HIP-event time, algorithmic bytes / flops
                  and fraction of its own roofline.
   cpu_baseline  N=1, rank 0 only: CPU port of the same train step (same model classes, oracle/cpu_port.py device
-                half) timed on this box's usable host cores on a bounded sample (1 image of 3x512x1024 per step, 1 warm-up +
-                2 timed steps, in a subprocess with a timeout).
+                half) timed on this box's usable host cores on a bounded sample, in a subprocess with a timeout.
 """
 import argparse
 import json
@@ -29,7 +42,21 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TFLOP_PER_IMAGE = 2.0759          # fwd + loss + bwd, HRNet-W48-contrast @ 3x512x1024
+# fwd + loss + bwd TFLOP per image, counted on the reference
+WORKLOADS = {
+    "cfg2": dict(config="cityscapes/H_48_D_4.json", tflop=2.0759, batch=8, labels="uniform",
+                 name="BASELINE.json configs[1]: HRNet-W48 + contrast_ce_loss, synthetic Cityscapes 3x512x1024x19, "
+                      "tau=0.1, max_samples=1024, with_embed=True, SGD(0.01,0.9,5e-4)"),
+    "cfg4": dict(config="cityscapes/R_101_D_8.json", tflop=4.8077, batch=8, labels="uniform",
+                 name="BASELINE.json configs[3] (bank-free form): DeepLabV3-R101-d8 + contrast_auxce_loss, synthetic "
+                      "Cityscapes 3x512x1024x19"),
+    "cfg4mem": dict(config="cityscapes/R_101_D_8_MEM.json", tflop=4.8077, batch=8, labels="uniform",
+                    name="BASELINE.json configs[3]: DeepLabV3-R101-d8 + mem_contrast_auxce_loss with the per-class "
+                         "pixel/segment memory bank, synthetic Cityscapes 3x512x1024x19"),
+    "cfg5": dict(config="coco_stuff/H_48_D_4.json", tflop=1.5418, batch=16, labels="blocky",
+                 name="BASELINE.json configs[4]: HRNet-W48-OCR + contrast_auxce_loss, synthetic COCO-Stuff "
+                      "3x520x520x171, blocky labels"),
+}
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
@@ -39,10 +66,15 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                   help="weak: per-GPU batch 8 (global 8N); strong: global batch 8 split over the ranks")
-    p.add_argument("--config", default=os.path.join(ROOT, "configs", "cityscapes", "H_48_D_4.json"))
-    p.add_argument("--per-gpu-batch", type=int, default=8)
+    p.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                   help="strong (default, the BASELINE configuration): global batch fixed, split over the ranks; "
+                        "weak: per-GPU batch = the config's global batch")
+    p.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
+    p.add_argument("--config", default=None, help="override the workload's config file")
+    p.add_argument("--global-batch", type=int, default=None, help="override the workload's global batch")
+    p.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; gloo lets several "
+                                                   "ranks share one GPU for a dry run)")
+    p.add_argument("--no-weak", action="store_true", help="skip the extra weak-scaling measurement at N > 1")
     p.add_argument("--miopen-find", type=int, default=0,
                    help="cudnn.benchmark = MIOpen exhaustive find (a 20+ min warm-up on a fresh box); default off: "
                         "immediate mode + the tuned records shipped in contrastiveseg_amd/miopen_db")
@@ -50,16 +82,16 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernels", action="store_true")
     p.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
-    p.add_argument("--labels", choices=["uniform", "blocky"], default="uniform")
+    p.add_argument("--labels", choices=["uniform", "blocky"], default=None)
     return p.parse_args()
 
 
-def build_trainer(args, world, device):
+def build_trainer(args, world, device, global_batch):
     from contrastiveseg_amd.lib.utils.tools.configer import Configer
     from contrastiveseg_amd.segmentor.tools.data_helper import SyntheticLoader
     from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
-    cfg = Configer(configs=args.config)
-    global_batch = args.per_gpu_batch * world if args.scaling == "weak" else args.per_gpu_batch
+    wl = WORKLOADS[args.workload]
+    cfg = Configer(configs=args.config or os.path.join(ROOT, "configs", wl["config"]))
     assert global_batch % world == 0, "global batch %d not divisible by %d ranks" % (global_batch, world)
     cfg.update(["train", "batch_size"], global_batch)
     cfg.update(["contrast", "warmup_iters"], 0)
@@ -70,10 +102,10 @@ def build_trainer(args, world, device):
     cfg.add(["network", "channels_last"], bool(args.channels_last))
     torch.manual_seed(304)
     tr = Trainer(cfg, train_loader=[])
-    loader = SyntheticLoader(cfg, device, length=1, seed=304, mode=args.labels, fixed=True)
+    loader = SyntheticLoader(cfg, device, length=1, seed=304, mode=args.labels or wl["labels"], fixed=True)
     tr.seg_net.train()
     tr.pixel_loss.train()
-    return tr, cfg, next(iter(loader)), global_batch
+    return tr, cfg, next(iter(loader))
 
 
 def time_kernel(fn, iters=20, warm=5):
@@ -192,7 +224,9 @@ def usable_cores():
 
 def cpu_baseline_worker():
     """CPU port of the train step (model classes of this repo on CPU, device half = oracle/cpu_port.py).
-    Runs in its own process (bench.py --cpu-baseline-worker) so that a slow host can be cut off by a timeout."""
+    Runs in its own process (bench.py --cpu-baseline-worker) so that a slow host can be cut off by a timeout.
+    Sample: the BASELINE batch of 8 images per step when the host has the memory for it (the reference needs ~34 GB RSS
+    at bs8), otherwise 2 images per step; 1 warm-up + 2 (bs8: 1) timed steps."""
     from oracle import cpu_port
     from contrastiveseg_amd.lib.utils.tools.configer import Configer
     from contrastiveseg_amd.segmentor.tools.data_helper import SyntheticLoader
@@ -200,8 +234,14 @@ def cpu_baseline_worker():
     cores = usable_cores()
     torch.set_num_threads(cores)
     cpu_port.install(None)
+    try:
+        import psutil
+        avail_gb = psutil.virtual_memory().available / 2 ** 30
+    except Exception:
+        avail_gb = 0.0
+    batch_size = 8 if (avail_gb >= 96 and cores >= 12) else 2
     cfg = Configer(configs=os.path.join(ROOT, "configs", "cityscapes", "H_48_D_4.json"))
-    cfg.update(["train", "batch_size"], 1)
+    cfg.update(["train", "batch_size"], batch_size)
     cfg.update(["contrast", "warmup_iters"], 0)
     cfg.update(["solver", "max_iters"], 10 ** 9)
     cfg.add(["network", "pretrained"], None)
@@ -214,18 +254,18 @@ def cpu_baseline_worker():
     tr.pixel_loss.cpu()
     batch = next(iter(SyntheticLoader(cfg, torch.device("cpu"), length=1, seed=304, mode="uniform")))
     tr.train_step(batch)                       # warm-up
-    n = 2
+    n = 1 if batch_size == 8 else 2
     t0 = time.time()
     for _ in range(n):
         tr.train_step(batch)
     dt = (time.time() - t0) / n
     print("CPU_BASELINE " + json.dumps({
-        "value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-        "sample": "1 image 3x512x1024 per step, fwd+criterion+bwd+SGD, 1 warm-up + %d timed steps, fp32, "
-                  "%.2f s/step" % (n, dt)}))
+        "value": round(batch_size / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+        "sample": "%d images 3x512x1024 per step (BASELINE batch is 8), fwd+criterion+bwd+SGD, 1 warm-up + %d timed "
+                  "step(s), fp32, %.2f s/step, host RAM available %.0f GB" % (batch_size, n, dt, avail_gb)}))
 
 
-def cpu_baseline(timeout_s=240):
+def cpu_baseline(timeout_s=300):
     import subprocess
     env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
     try:
@@ -239,30 +279,14 @@ def cpu_baseline(timeout_s=240):
     return {"error": "cpu baseline failed: " + out.stderr[-400:]}
 
 
-def main():
-    args = parse()
-    if args.cpu_baseline_worker:
-        cpu_baseline_worker()
-        return
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", init_method="env://")
-    torch.backends.cudnn.benchmark = bool(args.miopen_find)
-
-    tr, cfg, batch, global_batch = build_trainer(args, world, device)
-
+def timed_steps(tr, batch, steps, warmup, world, device):
+    """W untimed steps, then K timed steps bracketed by barrier + synchronize. Returns (wall s, HIP-event ms, loss),
+    MAX over ranks."""
     def barrier():
         if world > 1:
             torch.distributed.barrier()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         tr.train_step(batch)
     torch.cuda.synchronize()
     barrier()
@@ -270,7 +294,7 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = tr.train_step(batch)
     e1.record()
     torch.cuda.synchronize()
@@ -282,16 +306,85 @@ def main():
         t = torch.tensor([dt, ev_ms], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt, ev_ms = float(t[0]), float(t[1])
-    final_loss = float(loss)
+    return dt, ev_ms, float(loss)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) through
+    torch.distributed.run on 127.0.0.1 and pass their output through (rank 0 prints the JSON line)."""
+    import subprocess
+    from contrastiveseg_amd.lib.utils.distributed import respawn_command
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and (args.backend or os.environ.get("CSEG_DIST_BACKEND")) != "gloo":
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible (RCCL needs one device per rank; "
+                         "`--backend gloo` lets ranks share a device for a dry run)\n" % (args.gpus, n_dev))
+        sys.exit(2)
+    cmd = respawn_command(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:])
+    sys.exit(subprocess.call(cmd, env=dict(os.environ)))
+
+
+def step_traffic():
+    """HBM bytes per step of the default workload at N=1, from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs; gfx950 FETCH_SIZE x2 for wide coalesced reads per MI355X_MICROARCH.md)."""
+    path = os.path.join(ROOT, "profiles", "r02_step_pmc.json")
+    if not os.path.exists(path):
+        return None, None
+    try:
+        d = json.load(open(path))
+        return d["hbm_bytes_per_step"], "profiles/r02_step_pmc.json (%s)" % d.get("note", "")
+    except Exception:
+        return None, None
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_worker:
+        cpu_baseline_worker()
+        return
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    from contrastiveseg_amd.lib.utils import distributed as D
+    if args.gpus > 1 and not D.launched_by_torchrun():
+        self_launch(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    if args.backend:
+        os.environ["CSEG_DIST_BACKEND"] = args.backend
+    D.setup_process_group()
+    local = D.device_index()
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+
+    wl = WORKLOADS[args.workload]
+    base_batch = args.global_batch or wl["batch"]
+    global_batch = base_batch * world if args.scaling == "weak" else base_batch
+    tr, cfg, batch = build_trainer(args, world, device, global_batch)
+    dt, ev_ms, final_loss = timed_steps(tr, batch, args.steps, args.warmup, world, device)
+
+    weak = None
+    if world > 1 and args.scaling == "strong" and not args.no_weak:
+        # per-GPU work fixed at the config's global batch: separates "the step is too small per GPU" from "the
+        # collectives do not overlap". Fewer steps; outside the timed region of the headline number.
+        del tr, batch
+        torch.cuda.empty_cache()
+        w_steps, w_warm = max(3, args.steps // 2), 2
+        tr2, _, batch2 = build_trainer(args, world, device, base_batch * world)
+        w_dt, _, _ = timed_steps(tr2, batch2, w_steps, w_warm, world, device)
+        weak = {"value": round(base_batch * world * w_steps / w_dt, 3), "unit": "images/sec",
+                "global_batch": base_batch * world, "per_gpu_batch": base_batch, "steps": w_steps, "warmup": w_warm,
+                "ms_per_step": round(w_dt * 1e3 / w_steps, 3)}
+        del tr2, batch2
+        torch.cuda.empty_cache()
 
     kernels = None
-    if rank == 0 and not args.no_kernels:
+    if rank == 0 and not args.no_kernels and args.workload == "cfg2":
         try:
-            kernels = kernel_rooflines(device, args.per_gpu_batch)
+            kernels = kernel_rooflines(device, 8)
         except Exception as e:            # never lose the headline number to a micro-benchmark problem
             kernels = {"error": repr(e)}
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":
         try:
             cpu = cpu_baseline()
         except Exception as e:
@@ -302,27 +395,34 @@ def main():
     if rank == 0:
         ips = global_batch * args.steps / dt
         ips_ev = global_batch * args.steps / (ev_ms * 1e-3)
-        achieved = ips_ev * TFLOP_PER_IMAGE
+        achieved = ips_ev * wl["tflop"]
         peak = PEAK_FP32_MFMA_TFLOPS * world
+        traffic, traffic_src = step_traffic() if (world == 1 and args.workload == "cfg2") else (None, None)
+        W, H = cfg.get("train", "data_transformer")["input_size"]
         line = {
-            "metric": "images/sec contrastive train step, HRNet-W48 1024x512 bs8",
+            "metric": "images/sec contrastive train step, HRNet-W48 1024x512 bs8" if args.workload == "cfg2" else
+                      "images/sec contrastive train step, " + args.workload,
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: HRNet-W48 + contrast_ce_loss, synthetic Cityscapes "
-                                   "3x512x1024x19, tau=0.1, max_samples=1024, with_embed=True, SGD(0.01,0.9,5e-4)",
-                       "model": "hrnet_w48_contrast", "loss": "contrast_ce_loss", "global_batch": global_batch,
-                       "per_gpu_batch": global_batch // world, "input": [3, 512, 1024], "labels": args.labels,
-                       "parallelism": "dp%d" % world, "miopen_find": bool(args.miopen_find),
-                       "channels_last": bool(args.channels_last), "final_loss": round(final_loss, 5)},
+            "config": {"workload": wl["name"], "model": cfg.get("network", "model_name"),
+                       "loss": cfg.get("loss", "loss_type"), "global_batch": global_batch,
+                       "per_gpu_batch": global_batch // world, "input": [3, H, W],
+                       "num_classes": cfg.get("data", "num_classes"), "labels": args.labels or wl["labels"],
+                       "parallelism": "dp%d" % world,
+                       "cross_rank_contrast_set": bool(world > 1 and cfg.exists("contrast", "cross_rank")
+                                                       and cfg.get("contrast", "cross_rank")),
+                       "backend": (torch.distributed.get_backend() if world > 1 else None),
+                       "miopen_find": bool(args.miopen_find), "channels_last": bool(args.channels_last),
+                       "final_loss": round(final_loss, 5)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "note": "whole step: images/s (HIP-event time %.1f ms/step) x %.4f TFLOP/image vs fp32 MFMA "
                                  "peak; per-kernel rooflines of the hand-written HIP kernels under 'kernels'"
-                                 % (ev_ms / args.steps, TFLOP_PER_IMAGE)},
-            "cpu_baseline": cpu, "kernels": kernels,
+                                 % (ev_ms / args.steps, wl["tflop"])},
+            "weak": weak, "cpu_baseline": cpu, "kernels": kernels,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

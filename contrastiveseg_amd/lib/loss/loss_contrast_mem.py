@@ -15,7 +15,7 @@ import torch.nn as nn
 from contrastiveseg_amd import kernels as K
 from contrastiveseg_amd.lib.loss.loss_contrast import PixelContrastLoss as _SelfPixelContrastLoss
 from contrastiveseg_amd.lib.loss.loss_contrast import _counts_to_host
-from contrastiveseg_amd.lib.loss.loss_helper import FSCELoss
+from contrastiveseg_amd.lib.loss.loss_helper import FSAuxCELoss, FSCELoss
 from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
 
 
@@ -71,6 +71,35 @@ class ContrastCELoss(nn.Module, ABC):
         loss = self.seg_criterion(seg, target)
         if segment_queue is not None and pixel_queue is not None:
             loss_contrast = self.contrast_criterion(embedding, target, seg=seg, segment_queue=segment_queue,
+                                                    pixel_queue=pixel_queue, seg_ready=preds.get('seg_ready'))
+        else:
+            loss_contrast = 0
+        if with_embed is True:
+            return loss + self.loss_weight * loss_contrast
+        return loss + 0 * loss_contrast
+
+
+class ContrastAuxCELoss(ContrastCELoss):
+    """FSAuxCELoss([seg_aux, seg]) + the memory-bank contrast term: what loss_contrast_mem.py:234-276 of the reference
+    sets out to be. As written there it is unregistered, reads the key 'embedding' (the models emit 'embed'), never
+    receives the queues and names an un-imported criterion; here it takes the same `preds` dict
+    as the registered memory criterion plus 'seg_aux', registered as 'mem_contrast_auxce_loss' for the DeepLab / OCR
+    memory models (BASELINE.json configs[3] / [4])."""
+
+    def __init__(self, configer=None):
+        super(ContrastAuxCELoss, self).__init__(configer)
+        self.seg_criterion = FSAuxCELoss(configer=configer)
+
+    def forward(self, preds, target, with_embed=False):
+        assert "seg" in preds
+        assert "seg_aux" in preds
+        assert "embed" in preds
+        seg = preds['seg']
+        loss = self.seg_criterion([preds['seg_aux'], seg], target)
+        segment_queue = preds.get('segment_queue')
+        pixel_queue = preds.get('pixel_queue')
+        if segment_queue is not None and pixel_queue is not None:
+            loss_contrast = self.contrast_criterion(preds['embed'], target, seg=seg, segment_queue=segment_queue,
                                                     pixel_queue=pixel_queue, seg_ready=preds.get('seg_ready'))
         else:
             loss_contrast = 0

@@ -1,6 +1,7 @@
 """Loss registry with the reference's keys (lib/loss/loss_manager.py:27-68). Only the criteria of the contrastive
 hot path are registered; every other key of the reference's table is out of scope."""
 from contrastiveseg_amd.lib.loss.loss_contrast import ContrastAuxCELoss, ContrastCELoss
+from contrastiveseg_amd.lib.loss.loss_contrast_mem import ContrastAuxCELoss as MemContrastAuxCELoss
 from contrastiveseg_amd.lib.loss.loss_contrast_mem import ContrastCELoss as MemContrastCELoss
 from contrastiveseg_amd.lib.loss.loss_helper import FSAuxCELoss, FSCELoss
 from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
@@ -11,6 +12,7 @@ SEG_LOSS_DICT = {
     'contrast_auxce_loss': ContrastAuxCELoss,
     'contrast_ce_loss': ContrastCELoss,
     'mem_contrast_ce_loss': MemContrastCELoss,
+    'mem_contrast_auxce_loss': MemContrastAuxCELoss,      # not in the reference's table (loss_contrast_mem.py)
 }
 
 

@@ -1,6 +1,7 @@
 """Model registry with the reference's keys for the contrastive hot path (lib/models/model_manager.py:48-98)."""
-from contrastiveseg_amd.lib.models.nets.deeplab import DeepLabV3Contrast
-from contrastiveseg_amd.lib.models.nets.hrnet import HRNet_W48_CONTRAST, HRNet_W48_MEM, HRNet_W48_OCR_CONTRAST
+from contrastiveseg_amd.lib.models.nets.deeplab import DeepLabV3_MEM, DeepLabV3Contrast
+from contrastiveseg_amd.lib.models.nets.hrnet import (HRNet_W48_CONTRAST, HRNet_W48_MEM, HRNet_W48_OCR_CONTRAST,
+                                                      HRNet_W48_OCR_MEM)
 from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
 
 SEG_MODEL_DICT = {
@@ -8,6 +9,9 @@ SEG_MODEL_DICT = {
     'hrnet_w48_ocr_contrast': HRNet_W48_OCR_CONTRAST,
     'hrnet_w48_mem': HRNet_W48_MEM,
     'deeplab_v3_contrast': DeepLabV3Contrast,
+    # not in the reference's table: buildable forms of BASELINE.json configs[3] / [4] (nets/hrnet.py:ContrastMemoryModel)
+    'deeplab_v3_mem': DeepLabV3_MEM,
+    'hrnet_w48_ocr_mem': HRNet_W48_OCR_MEM,
 }
 
 

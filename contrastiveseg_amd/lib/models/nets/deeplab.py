@@ -32,3 +32,15 @@ class DeepLabV3Contrast(nn.Module):
         embedding = self.proj_head(x[-1])
         seg, seg_aux = self.decoder(x[-4:])
         return {'embed': embedding, 'seg_aux': seg_aux, 'seg': seg}
+
+
+def _memory_model():
+    from contrastiveseg_amd.lib.models.nets.hrnet import ContrastMemoryModel
+
+    class DeepLabV3_MEM(ContrastMemoryModel):
+        """DeepLabV3Contrast + per-class pixel / segment queues: the buildable form of BASELINE.json configs[3]."""
+        ENCODER = DeepLabV3Contrast
+    return DeepLabV3_MEM
+
+
+DeepLabV3_MEM = _memory_model()

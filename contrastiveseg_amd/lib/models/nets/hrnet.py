@@ -71,18 +71,27 @@ class HRNet_W48_OCR_CONTRAST(nn.Module):
         return {'seg': out, 'seg_aux': out_aux, 'embed': emb}
 
 
-class HRNet_W48_MEM(nn.Module):
-    """encoder_q + per-class segment / pixel queues as buffers (so they live in the state_dict, reference :165-171).
-    The momentum key encoder of the reference is dead code (no encoder_k exists, :173-176) and is not carried."""
+class ContrastMemoryModel(nn.Module):
+    """encoder_q + per-class segment / pixel queues as buffers (so they live in the state_dict), the structure of the
+    reference's HRNet_W48_MEM (:153-188) with the encoder as a class attribute. The momentum key encoder of the
+    reference is dead code (no encoder_k exists, :173-176) and is not carried.
 
-    def __init__(self, configer, dim=256, m=0.999, with_masked_ppm=False):
-        super(HRNet_W48_MEM, self).__init__()
+    Subclasses: HRNet_W48_MEM (reference key 'hrnet_w48_mem'); DeepLabV3_MEM and HRNet_W48_OCR_MEM give BASELINE.json
+    configs[3] / [4] (DeepLab + pixel memory bank, OCR + region-level memory) a buildable form -- the reference has no
+    such registry entries ("configs the reference cannot build as written"); they pair with
+    'mem_contrast_auxce_loss'. The segment queue (per-image class-mean embeddings) is the region-level memory."""
+    ENCODER = None
+
+    def __init__(self, configer, dim=None, m=0.999, with_masked_ppm=False):
+        super(ContrastMemoryModel, self).__init__()
         self.configer = configer
         self.m = m
         self.r = self.configer.get('contrast', 'memory_size')
         self.with_masked_ppm = with_masked_ppm
         num_classes = self.configer.get('data', 'num_classes')
-        self.encoder_q = HRNet_W48_CONTRAST(configer)
+        if dim is None:
+            dim = self.configer.get('contrast', 'proj_dim') if self.configer.exists('contrast', 'proj_dim') else 256
+        self.encoder_q = type(self).ENCODER(configer)
         self.register_buffer("segment_queue", torch.randn(num_classes, self.r, dim))
         self.segment_queue = nn.functional.normalize(self.segment_queue, p=2, dim=2)
         self.register_buffer("segment_queue_ptr", torch.zeros(num_classes, dtype=torch.long))
@@ -97,3 +106,15 @@ class HRNet_W48_MEM(nn.Module):
         q = ret['embed']
         ret.update({'key': q.detach(), 'lb_key': lb_q.detach()})
         return ret
+
+
+class HRNet_W48_MEM(ContrastMemoryModel):
+    """reference lib/models/nets/hrnet.py:153-188 (dim defaults to 256 there)"""
+    ENCODER = HRNet_W48_CONTRAST
+
+    def __init__(self, configer, dim=256, m=0.999, with_masked_ppm=False):
+        super(HRNet_W48_MEM, self).__init__(configer, dim=dim, m=m, with_masked_ppm=with_masked_ppm)
+
+
+class HRNet_W48_OCR_MEM(ContrastMemoryModel):
+    ENCODER = HRNet_W48_OCR_CONTRAST

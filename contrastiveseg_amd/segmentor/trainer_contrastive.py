@@ -21,6 +21,7 @@ import torch.nn as nn
 from contrastiveseg_amd import _host
 from contrastiveseg_amd import kernels as K
 from contrastiveseg_amd.lib.loss.loss_manager import LossManager
+from contrastiveseg_amd.lib.metrics.running_score import RunningScore
 from contrastiveseg_amd.lib.models.model_manager import ModelManager
 from contrastiveseg_amd.lib.utils.distributed import get_rank, get_world_size, is_distributed
 from contrastiveseg_amd.lib.utils.tools.average_meter import AverageMeter
@@ -280,36 +281,39 @@ class Trainer(object):
 
     @torch.no_grad()
     def __val(self, data_loader=None):
-        """Validation loss + mIoU from an on-device confusion matrix (reference :306-401 uses cv2 + numpy)."""
+        """Validation loss + mIoU (reference :306-401 -> StandardEvaluator -> RunningScore). Logits are upsampled to the
+        label size (bilinear, align_corners=True -- the reference's evaluator resizes with cv2 INTER_CUBIC on the host,
+        which is outside the hot path), arg-maxed, and accumulated into an on-device confusion matrix with the
+        reference's RunningScore arithmetic (lib/metrics/running_score.py of this package)."""
         self.seg_net.eval()
         self.pixel_loss.eval()
-        Kc = self.configer.get('data', 'num_classes')
-        conf = None
+        score = RunningScore(self.configer, ignore_index=-1)
+        seen = False
         for data_dict in (self.val_loader if data_loader is None else data_loader):
             (inputs, targets), batch_size = self.data_helper.prepare_data(data_dict)
             outputs = self.seg_net(*inputs, is_eval=True)
             self.val_losses.update(self.pixel_loss(outputs, targets).item(), batch_size)
             seg = nn.functional.interpolate(outputs['seg'], size=targets.shape[-2:], mode='bilinear',
                                             align_corners=True)
-            pred = seg.argmax(1)
-            valid = (targets >= 0) & (targets < Kc)
-            idx = targets[valid] * Kc + pred[valid]
-            cm = torch.bincount(idx, minlength=Kc * Kc).reshape(Kc, Kc).double()
-            conf = cm if conf is None else conf + cm
-        if conf is not None:
-            if is_distributed() and get_world_size() > 1:
-                import torch.distributed as dist
-                dist.all_reduce(conf)
-            iou = conf.diag() / (conf.sum(0) + conf.sum(1) - conf.diag()).clamp(min=1)
-            self.configer.update(['performance'], float(iou.mean()))
+            score.update(seg.argmax(1), targets)
+            seen = True
+        if seen:
+            miou = float(score.get_mean_iou())
+            self.last_val_score = score
+            self.configer.update(['performance'], miou)
             self.configer.update(['val_loss'], self.val_losses.avg)
             if self.configer.exists('checkpoints'):
                 self.module_runner.save_net(self.seg_net, save_mode='performance')
                 self.module_runner.save_net(self.seg_net, save_mode='val_loss')
-            Log.info('Val mIoU {:.4f}\tLoss {:.8f}'.format(float(iou.mean()), self.val_losses.avg))
+            Log.info('Val mIoU {:.4f}\tPixel acc {:.4f}\tLoss {:.8f}'.format(miou, float(score.get_pixel_acc()),
+                                                                            self.val_losses.avg))
         self.val_losses.reset()
         self.seg_net.train()
         self.pixel_loss.train()
+
+    def validate(self, data_loader=None):
+        """Public entry to the validation pass (the reference calls the name-mangled __val from train() only)."""
+        return self.__val(data_loader)
 
     def train(self):
         """reference :403-427 (SWA tail omitted: torchcontrib is outside the hot path)."""

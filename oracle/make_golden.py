@@ -447,10 +447,14 @@ def run_step_case(name, c):
         loss.backward()
         res["grad/input"] = watch_subset(img.grad.numpy())
         res["gradnoise/input"] = np.array(np.abs(img.grad.numpy() - grads64["input"]).max() / np.abs(grads64["input"]).max())
+        res["gradnoise_l2/input"] = np.array(np.linalg.norm((img.grad.numpy() - grads64["input"]).ravel())
+                                             / np.linalg.norm(grads64["input"].ravel()))
         for w in c["watch"]:
             res["grad/" + w] = watch_subset(named[w].grad.numpy())
             res["gradnorm/" + w] = np.array(np.sqrt((named[w].grad.numpy().astype(np.float64) ** 2).sum()))
             res["gradnoise/" + w] = np.array(np.abs(named[w].grad.numpy() - grads64[w]).max() / np.abs(grads64[w]).max())
+            res["gradnoise_l2/" + w] = np.array(np.linalg.norm((named[w].grad.numpy() - grads64[w]).ravel())
+                                                / np.linalg.norm(grads64[w].ravel()))
         before = {w: named[w].detach().numpy().copy() for w in c["watch"]}
         opt.step()
         for w in c["watch"]:
@@ -459,6 +463,21 @@ def run_step_case(name, c):
     print("%s: loss %.6f (fp64 %.6f) -> %.6f ; |grad conv1|max %.3e; reference fp32-vs-fp64 gradient noise: %s" % (
         name, res["loss0"], res["loss0_fp64"], res["loss1"], np.abs(res["grad/" + c["watch"][0]]).max(),
         " ".join("%.1e" % float(res["gradnoise/" + w]) for w in ["input"] + list(c["watch"]))))
+
+
+def run_running_score():
+    """Confusion matrix + mean IoU of the reference's RunningScore (lib/metrics/running_score.py:120-215) on the seeded
+    label maps of tests/test_running_score.py::_case."""
+    ref_shim.install()
+    from lib.metrics.running_score import RunningScore
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    from test_running_score import _case
+    true, pred, K = _case()
+    rs = RunningScore(None, num_classes=K, ignore_index=-1)
+    rs.update(pred, true)
+    np.savez_compressed(os.path.join(OUT, "running_score.npz"), confusion=rs.confusion_matrix.astype(np.int64),
+                        mean_iou=np.array(rs.get_mean_iou()), pixel_acc=np.array(rs.get_pixel_acc()))
+    print("running_score: mIoU %.6f acc %.6f" % (rs.get_mean_iou(), rs.get_pixel_acc()))
 
 
 def main():
@@ -478,6 +497,8 @@ def main():
     for name, c in STEP_CASES.items():
         if a.only is None or a.only == name or a.only == "steps":
             run_step_case(name, c)
+    if a.only is None or a.only == "running_score":
+        run_running_score()
 
 
 if __name__ == "__main__":

@@ -140,3 +140,42 @@ def test_config1_plumbing_trainer_steps_on_cpu(monkeypatch):
     losses = [float(tr.train_step(b)) for b in tr.train_loader]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     assert cfg.get("iters") == 3
+
+
+@pytest.mark.parametrize("model,backbone,cfg_file", [
+    ("deeplab_v3_mem", "deepbase_resnet18_dilated8", "cityscapes/R_101_D_8_MEM.json"),
+    ("hrnet_w48_ocr_mem", "hrnet18", "coco_stuff/H_48_D_4_MEM.json")])
+def test_memory_variants_of_baseline_configs_3_and_4_step_on_cpu(model, backbone, cfg_file, monkeypatch):
+    """deeplab_v3_mem / hrnet_w48_ocr_mem + mem_contrast_auxce_loss (the buildable forms of BASELINE.json configs[3]/[4],
+    SURVEY.md section 7): registry, forward(img, labels) contract, aux CE + bank contrast, enqueue, SGD -- host logic
+    with the device half replaced by oracle/cpu_port.py."""
+    cpu_port.install(monkeypatch)
+    from contrastiveseg_amd.lib.utils.tools.configer import Configer
+    from contrastiveseg_amd.segmentor.tools.data_helper import SyntheticLoader
+    from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Configer(configs=os.path.join(root, "configs", cfg_file))
+    assert cfg.get("network", "model_name") == model and cfg.get("loss", "loss_type") == "mem_contrast_auxce_loss"
+    cfg.update(["network", "backbone"], backbone)
+    cfg.update(["network", "bn_type"], "torchbn")
+    cfg.update(["data", "num_classes"], 6)
+    cfg.get("loss", "params").pop("ce_weight", None)
+    cfg.update(["train", "batch_size"], 2)
+    cfg.get("train", "data_transformer")["input_size"] = [96, 64]
+    cfg.update(["contrast", "warmup_iters"], 0)
+    cfg.update(["contrast", "memory_size"], 16)
+    cfg.update(["solver", "max_iters"], 2)
+    cfg.add(["network", "pretrained"], None)
+    cfg.add(["network", "resume"], None)
+    cfg.add(["gpu"], None)
+    torch.manual_seed(304)
+    tr = Trainer(cfg, train_loader=[])
+    loader = SyntheticLoader(cfg, torch.device("cpu"), length=2, mode="blocky")
+    tr.seg_net.train()
+    w0 = next(tr.seg_net.parameters()).detach().clone()
+    losses = [float(tr.train_step(b)) for b in loader]
+    assert all(np.isfinite(losses)), losses
+    assert not torch.equal(w0, next(tr.seg_net.parameters()).detach())
+    assert int(tr.seg_net.pixel_queue_ptr.sum()) > 0
+    assert set(k for k in tr.seg_net.state_dict() if "queue" in k) == {"segment_queue", "segment_queue_ptr",
+                                                                       "pixel_queue", "pixel_queue_ptr"}
