@@ -197,10 +197,30 @@ def kernel_rooflines(device, B, K=19, H=512, W=1024, stride=4, D=256):
     wt = torch.ones(K, device=device)
     sg = seg.clone().requires_grad_(True)
     entry("upsample_ce_fwd", time_kernel(lambda: Kn.upsample_ce(sg, target, wt, -1)),
-          bytes_=B * K * P * 4 + B * H * W * 8)
+          bytes_=B * K * P * 4 + B * H * W * (8 + 4))              # seg + labels in, log-sum-exp out
     l = Kn.upsample_ce(sg, target, wt, -1)
     entry("upsample_ce_bwd", time_kernel(lambda: torch.autograd.grad(l, sg, retain_graph=True)),
-          bytes_=2 * B * K * P * 4 + B * H * W * 8)
+          bytes_=2 * B * K * P * 4 + B * H * W * (8 + 4))
+    del sg, l
+    # fused BatchNorm (+ReLU / +residual): the two dominant activation shapes of the HRNet-W48 step
+    from contrastiveseg_amd.lib.models.tools.fused_bn import FusedBatchNorm2d
+    for C, hh, ww in ((48, h, w), (720, h, w)):
+        bn = FusedBatchNorm2d(C).to(device).train()
+        x = torch.randn(B, C, hh, ww, generator=g).to(device).requires_grad_(True)
+        r = torch.randn(B, C, hh, ww, generator=g).to(device).requires_grad_(True)
+        nb = x.numel() * 4
+        entry("bn_relu_fwd %dch (stats + apply)" % C, time_kernel(lambda: bn(x, relu=True)), bytes_=3 * nb)
+        y = bn(x, relu=True)
+        gy = torch.randn_like(y)
+        entry("bn_relu_bwd %dch (reduce + apply)" % C,
+              time_kernel(lambda: torch.autograd.grad(y, x, gy, retain_graph=True)), bytes_=5 * nb)
+        if C == 48:
+            entry("bn_add_relu_fwd %dch" % C, time_kernel(lambda: bn(x, residual=r, relu=True)), bytes_=4 * nb)
+            y2 = bn(x, residual=r, relu=True)
+            entry("bn_add_relu_bwd %dch" % C,
+                  time_kernel(lambda: torch.autograd.grad(y2, (x, r), gy, retain_graph=True)), bytes_=7 * nb)
+            del y2
+        del bn, x, r, y, gy
     return out
 
 

@@ -40,13 +40,16 @@ SIGNATURES = {
     "cseg_fuse_sum_fwd": (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _c_int] + [_c_int] * 5 + [_ptr, _ptr]),
     "cseg_fuse_sum_bwd": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int] + [_c_int] * 4 + [_ptr, _ptr, _ptr]),
     "cseg_upsample_ce_blocks": (_c_int, [_c_int, _c_int, _c_int]),
-    "cseg_upsample_ce_fwd": (_c_int, [_ptr, _ptr, _ptr, _c_int] + [_c_int] * 6 + [_ptr, _ptr, _ptr, _ptr]),
-    "cseg_upsample_ce_bwd": (_c_int, [_ptr, _ptr, _ptr, _c_int] + [_c_int] * 6 + [_ptr, _ptr, _ptr, _ptr]),
+    "cseg_upsample_ce_fwd": (_c_int, [_ptr, _ptr, _ptr, _c_int] + [_c_int] * 6 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
+    "cseg_upsample_ce_bwd": (_c_int, [_ptr, _ptr, _ptr, _c_int] + [_c_int] * 6 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_queue_count": (_c_int, [_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
     "cseg_queue_class_sums": (_c_int, [_ptr, _ptr] + [_c_int] * 7 + [_ptr, _ptr]),
     "cseg_queue_write_segments": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _c_int, _ptr]),
     "cseg_queue_write_pixels": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _c_int,
                                          _ptr]),
+    "cseg_conv3x3_packed_floats": (ctypes.c_size_t, [_c_int, _c_int]),
+    "cseg_conv3x3_pack_weights": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    "cseg_conv3x3_fwd": (_c_int, [_ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
     "cseg_bn_ws_floats": (ctypes.c_size_t, [_c_int, _c_int, _c_int]),
     "cseg_bn_stats": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "cseg_bn_finalize": (_c_int, [_ptr, _c_int, ctypes.c_double, _c_float, _c_float, _ptr, _ptr, _ptr, _ptr, _ptr]),

@@ -2,21 +2,36 @@
 // weighted cross entropy (ignore index, mean over the sum of weights).
 // Reference: lib/loss/loss_contrast.py:180-181 + lib/loss/loss_helper.py:169-206. The reference materialises the
 // [B,K,H,W] logits (319 MB at bs8) and makes ~3 passes over them forward plus the same again backward; here the
-// coarse logits tile is staged in LDS once per block and the upsampled tensor never exists.
-// HBM-bound (algorithmic bytes: seg + target forward; seg + target + d_seg backward); no MFMA.
-// Both directions are atomics-free, so the loss and the gradient are run-to-run deterministic.
+// upsampled tensor never exists.
+//
+// Work decomposition (round 2; replaces the LDS-tile kernels whose backward ran a serial loop over the K classes with
+// three barriers each): a CELL = the fine pixels of one label row that share the left coarse tap x0 = c (4-5 pixels at
+// the 4.02x upsampling of the HRNet head, 1 at label resolution, <= 17). One lane owns one coarse column c, so the
+// four coarse logits a cell needs per class are loaded with unit stride across the wave straight from L1/L2 -- no LDS
+// tile, no bank conflicts -- the vertical blend is done once per class and every fine pixel costs two FMAs.
+//   forward   one thread per (label row, cell): max pass + sum-exp pass over the classes, log-sum-exp written to a
+//             [B,H,W] buffer for the backward, fixed-order block partials of (weighted nll, weight).
+//   backward  a block = (image, band of R coarse rows, group of KG classes); lane = coarse column. The block marches
+//             down the label rows of its band; per row each lane evaluates g_k = coef * (softmax_k - onehot_k) for
+//             its cell, splits it into the part that lands on column c and the part for column c+1 (handed to the
+//             right neighbour with one DPP shift; one LDS word per wave boundary), and accumulates the two coarse rows
+//             the label row touches in registers (a sliding pair: the march is monotone). Every exp is evaluated once
+//             per (pixel, class), all lanes work on all classes of the group, no atomics: run-to-run deterministic.
+// HBM-bound (algorithmic bytes: seg + target [+ lse] forward; seg + target + lse + d_seg backward); no MFMA.
 #include "cseg_common.h"
 
 namespace {
 
-constexpr int FT_H = 8, FT_W = 32;  // forward: hi-res tile per block (one pixel per thread)
-constexpr int BT = 8;               // backward: low-res tile edge per block
+constexpr int BAND = 4;        // coarse rows per backward block
+constexpr int MAX_PX = 17;     // fine pixels per cell (upsampling factors up to 16x)
 
 struct CeDims {
     int B, K, h, w, H, W;
     float sy, sx;
     int ignore_label;
 };
+
+__host__ __device__ __forceinline__ int tap0(float s, int o) { return (int)(s * (float)o); }
 
 __device__ __forceinline__ void tap(float s, int n_in, int o, int& i0, int& i1, float& l1) {
     const float f = s * (float)o;
@@ -25,89 +40,87 @@ __device__ __forceinline__ void tap(float s, int n_in, int o, int& i0, int& i1, 
     l1 = f - (float)i0;
 }
 
-
-// log-sum-exp over the K bilinearly interpolated logits of one fine pixel (taps o00..o11 into the staged tile).
-// K <= 32: the values are kept in registers, one max pass + one exp per class (no divergent rescale);
-// larger K: online (running max) form. *vt receives the logit of class t (pass t = -1 to skip).
-__device__ __forceinline__ float pixel_lse(const float* __restrict__ tile, int plane, int K, int o00, int o01, int o10,
-                                           int o11, float ly0, float ly1, float lx0, float lx1, int t, float* vt) {
-    if (K <= 32) {
-        float v[32];
-        float m = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            float x = -INFINITY;
-            if (k < K) {
-                const float* pl = tile + k * plane;
-                x = ly0 * (lx0 * pl[o00] + lx1 * pl[o01]) + ly1 * (lx0 * pl[o10] + lx1 * pl[o11]);
-                if (k == t) *vt = x;
-            }
-            v[k] = x;
-            m = fmaxf(m, x);
-        }
-        float se = 0.f;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) se += (k < K) ? expf(v[k] - m) : 0.f;
-        return m + logf(se);
-    }
-    float m = -INFINITY, se = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const float* pl = tile + k * plane;
-        const float x = ly0 * (lx0 * pl[o00] + lx1 * pl[o01]) + ly1 * (lx0 * pl[o10] + lx1 * pl[o11]);
-        if (k == t) *vt = x;
-        if (x > m) { se = se * expf(m - x) + 1.f; m = x; }
-        else se += expf(x - m);
-    }
-    return m + logf(se);
+// smallest o in [0, n_out] with tap0(s, o) >= c (n_out when there is none); tap0 is monotone in o
+__host__ __device__ __forceinline__ int first_with_tap(float s, int n_out, int c) {
+    if (c <= 0) return 0;
+    if (!(s > 0.f)) return n_out;
+    int o = (int)((float)c / s);
+    if (o > n_out) o = n_out;
+    if (o < 0) o = 0;
+    while (o > 0 && tap0(s, o - 1) >= c) --o;
+    while (o < n_out && tap0(s, o) < c) ++o;
+    return o;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------
+template <int PX>
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ seg, const int64_t* __restrict__ target,
-                                                     const float* __restrict__ weight, CeDims d, int rows_max,
-                                                     int cols_max, float* __restrict__ partial,
-                                                     int32_t* __restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [K][rows_max][cols_max]
+                                                     const float* __restrict__ weight, CeDims d, float* __restrict__ lse_out,
+                                                     float* __restrict__ partial, int32_t* __restrict__ status) {
     __shared__ float red[2][4];
-    const int tiles_x = (d.W + FT_W - 1) / FT_W, tiles_y = (d.H + FT_H - 1) / FT_H;
-    int blk = blockIdx.x;
-    const int tx = blk % tiles_x; blk /= tiles_x;
-    const int ty = blk % tiles_y;
-    const int b = blk / tiles_y;
-    const int Y0 = ty * FT_H, X0 = tx * FT_W;
-    const int Yl = min(d.H - 1, Y0 + FT_H - 1), Xl = min(d.W - 1, X0 + FT_W - 1);
-    const int ry0 = (int)(d.sy * (float)Y0), rx0 = (int)(d.sx * (float)X0);
-    const int ry1 = min(d.h - 1, (int)(d.sy * (float)Yl) + 1), rx1 = min(d.w - 1, (int)(d.sx * (float)Xl) + 1);
-    const int nr = ry1 - ry0 + 1, nc = rx1 - rx0 + 1;
-    const int plane = rows_max * cols_max;
-    for (int e = threadIdx.x; e < d.K * nr * nc; e += 256) {
-        const int k = e / (nr * nc), rem = e - k * nr * nc;
-        const int r = rem / nc, c = rem - r * nc;
-        smem[k * plane + r * cols_max + c] = seg[(((size_t)b * d.K + k) * d.h + ry0 + r) * d.w + rx0 + c];
-    }
-    __syncthreads();
-    const int Y = Y0 + (threadIdx.x >> 5), X = X0 + (threadIdx.x & 31);
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n_cells = (long)d.B * d.H * d.w;
     float wnll = 0.f, wsum = 0.f;
-    if (Y < d.H && X < d.W) {
-        const int64_t t64 = target[((size_t)b * d.H + Y) * d.W + X];
-        if (t64 != (int64_t)d.ignore_label) {
-            if (t64 < 0 || t64 >= d.K) {
-                atomicAdd(&status[1], 1);
-            } else {
-                const int t = (int)t64;
-                int y0, y1, x0, x1;
-                float ly1, lx1;
-                tap(d.sy, d.h, Y, y0, y1, ly1);
-                tap(d.sx, d.w, X, x0, x1, lx1);
-                const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-                const int o00 = (y0 - ry0) * cols_max + (x0 - rx0), o01 = (y0 - ry0) * cols_max + (x1 - rx0);
-                const int o10 = (y1 - ry0) * cols_max + (x0 - rx0), o11 = (y1 - ry0) * cols_max + (x1 - rx0);
-                float vt = 0.f;
-                const float lse = pixel_lse(smem, plane, d.K, o00, o01, o10, o11, ly0, ly1, lx0, lx1, t, &vt);
-                const float wt = weight ? weight[t] : 1.f;
-                wnll = wt * (lse - vt);
-                wsum = wt;
+    if (g < n_cells) {
+        const int c = (int)(g % d.w);
+        const long row = g / d.w;
+        const int Y = (int)(row % d.H), b = (int)(row / d.H);
+        const int Xs = first_with_tap(d.sx, d.W, c), Xe = first_with_tap(d.sx, d.W, c + 1);
+        const int n = min(Xe - Xs, PX);
+        if (n > 0) {
+            int y0, y1;
+            float ly1;
+            tap(d.sy, d.h, Y, y0, y1, ly1);
+            const float ly0 = 1.f - ly1;
+            const int c1 = c + (c < d.w - 1 ? 1 : 0);
+            float lx1[PX], m[PX], se[PX], vt[PX];
+            int t[PX];
+            const int64_t* trow = target + ((size_t)b * d.H + Y) * d.W + Xs;
+#pragma unroll
+            for (int p = 0; p < PX; ++p) {
+                lx1[p] = 0.f; m[p] = -INFINITY; se[p] = 0.f; vt[p] = 0.f; t[p] = -1;
+                if (p < n) {
+                    lx1[p] = d.sx * (float)(Xs + p) - (float)c;
+                    const int64_t t64 = trow[p];
+                    if (t64 != (int64_t)d.ignore_label) {
+                        if (t64 < 0 || t64 >= d.K) atomicAdd(&status[1], 1);
+                        else t[p] = (int)t64;
+                    }
+                }
+            }
+            const float* s0 = seg + (((size_t)b * d.K) * d.h + y0) * d.w;
+            const float* s1 = seg + (((size_t)b * d.K) * d.h + y1) * d.w;
+            const size_t plane = (size_t)d.h * d.w;
+            for (int k = 0; k < d.K; ++k) {                       // pass 1: running max
+                const float r0 = ly0 * s0[k * plane + c] + ly1 * s1[k * plane + c];
+                const float r1 = ly0 * s0[k * plane + c1] + ly1 * s1[k * plane + c1];
+#pragma unroll
+                for (int p = 0; p < PX; ++p) m[p] = fmaxf(m[p], fmaf(lx1[p], r1 - r0, r0));
+            }
+            for (int k = 0; k < d.K; ++k) {                       // pass 2: sum of exponentials, target logit
+                const float r0 = ly0 * s0[k * plane + c] + ly1 * s1[k * plane + c];
+                const float r1 = ly0 * s0[k * plane + c1] + ly1 * s1[k * plane + c1];
+#pragma unroll
+                for (int p = 0; p < PX; ++p) {
+                    const float v = fmaf(lx1[p], r1 - r0, r0);
+                    se[p] += __expf(v - m[p]);
+                    vt[p] = (k == t[p]) ? v : vt[p];
+                }
+            }
+            float* lrow = lse_out ? lse_out + ((size_t)b * d.H + Y) * d.W + Xs : nullptr;
+#pragma unroll
+            for (int p = 0; p < PX; ++p) {
+                if (p < n) {
+                    const float lse = m[p] + __logf(se[p]);
+                    if (lrow) lrow[p] = lse;
+                    if (t[p] >= 0) {
+                        const float wt = weight ? weight[t[p]] : 1.f;
+                        wnll += wt * (lse - vt[p]);
+                        wsum += wt;
+                    }
+                }
             }
         }
     }
@@ -116,8 +129,8 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ s
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = wnll; red[1][threadIdx.x >> 6] = wsum; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        partial[2 * (size_t)blockIdx.x + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        partial[2 * (size_t)blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        partial[2 * (size_t)blockIdx.x + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partial[2 * (size_t)blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
 }
 
@@ -139,170 +152,135 @@ __global__ __launch_bounds__(1024) void ce_finish_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// backward: block owns a BT x BT low-res tile of d_seg for one image. It rebuilds the softmax statistics of every
-// hi-res pixel in the tile's footprint once (phase 1), then per class k: (A) d_k = coef * (softmax_k - onehot_k)
-// for every footprint pixel, (B) horizontal adjoint of the bilinear taps, (C) vertical adjoint -> d_seg[k] tile.
-// The separable form keeps all 64 lanes busy and evaluates every exp once; no atomics.
+// backward
 // ---------------------------------------------------------------------------------------------------------
+template <int PX, int KG>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ seg, const int64_t* __restrict__ target,
-                                                     const float* __restrict__ weight, CeDims d, int nY_max,
-                                                     int nX_max, const float* __restrict__ out,
-                                                     const float* __restrict__ d_loss, float* __restrict__ d_seg) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int SR = BT + 2;  // staged seg rows/cols (tile + 1 halo each side)
-    const int plane = SR * SR;
-    const int nF = nY_max * nX_max;
-    float* seg_t = smem;                          // [K][SR][SR]
-    float* f_lse = seg_t + d.K * plane;           // [nF]
-    float* f_coef = f_lse + nF;                   // [nF]
-    int* f_tgt = (int*)(f_coef + nF);             // [nF]
-    float* dk = (float*)(f_tgt + nF);             // [nF]   d_k of the current class
-    float* hrow = dk + nF;                        // [nY_max][BT] horizontally reduced
-    int* yi0 = (int*)(hrow + nY_max * BT);        // [nY_max] y0 of each footprint row
-    float* yl1 = (float*)(yi0 + nY_max);
-    int* xi0 = (int*)(yl1 + nY_max);
-    float* xl1 = (float*)(xi0 + nX_max);
-    __shared__ int rng[4];         // Y_lo, nY, X_lo, nX
-    __shared__ int lo_hi[4][BT];   // per tile row: fy_lo, fy_hi ; per tile col: fx_lo, fx_hi (inclusive)
-
-    const int tiles_x = (d.w + BT - 1) / BT, tiles_y = (d.h + BT - 1) / BT;
+                                                     const float* __restrict__ weight, const float* __restrict__ lse,
+                                                     CeDims d, int n_groups, int n_bands, int halo,
+                                                     const float* __restrict__ out, const float* __restrict__ d_loss,
+                                                     float* __restrict__ d_seg) {
+    __shared__ float xchg[2][4][KG];          // [row parity][wave][class]: hB of the wave's last lane
     int blk = blockIdx.x;
-    const int tx = blk % tiles_x; blk /= tiles_x;
-    const int ty = blk % tiles_y;
-    const int b = blk / tiles_y;
-    const int ys0 = ty * BT, xs0 = tx * BT;
-    const int sr0 = ys0 - 1, sc0 = xs0 - 1;  // staged region origin (may be -1)
-    const int tid = threadIdx.x;
-
-    if (tid == 0) {
-        // hi-res rows whose y0 lies in [ys0-1, ys0+BT-1] (their y0 or y1 tap can hit the tile)
-        int lo = 0, hi = d.H - 1;
-        if (d.sy > 0.f) {
-            lo = max(0, (int)ceilf((float)(ys0 - 1) / d.sy) - 1);
-            while (lo < d.H - 1 && (int)(d.sy * (float)lo) < ys0 - 1) ++lo;
-            hi = min(d.H - 1, (int)floorf((float)(ys0 + BT) / d.sy) + 1);
-            while (hi > 0 && (int)(d.sy * (float)hi) > ys0 + BT - 1) --hi;
-        }
-        rng[0] = lo; rng[1] = max(0, hi - lo + 1);
-        lo = 0; hi = d.W - 1;
-        if (d.sx > 0.f) {
-            lo = max(0, (int)ceilf((float)(xs0 - 1) / d.sx) - 1);
-            while (lo < d.W - 1 && (int)(d.sx * (float)lo) < xs0 - 1) ++lo;
-            hi = min(d.W - 1, (int)floorf((float)(xs0 + BT) / d.sx) + 1);
-            while (hi > 0 && (int)(d.sx * (float)hi) > xs0 + BT - 1) --hi;
-        }
-        rng[2] = lo; rng[3] = max(0, hi - lo + 1);
-    }
-    for (int e = tid; e < d.K * plane; e += 256) {
-        const int k = e / plane, rem = e - k * plane;
-        const int r = sr0 + rem / SR, c = sc0 + rem % SR;
-        float v = 0.f;
-        if (r >= 0 && r < d.h && c >= 0 && c < d.w) v = seg[(((size_t)b * d.K + k) * d.h + r) * d.w + c];
-        seg_t[e] = v;
-    }
-    __syncthreads();
-    const int Y_lo = rng[0], nY = min(rng[1], nY_max), X_lo = rng[2], nX = min(rng[3], nX_max);
-    for (int e = tid; e < nY; e += 256) {
-        int i0, i1; float l1;
-        tap(d.sy, d.h, Y_lo + e, i0, i1, l1);
-        yi0[e] = i0; yl1[e] = l1;
-    }
-    for (int e = tid; e < nX; e += 256) {
-        int i0, i1; float l1;
-        tap(d.sx, d.w, X_lo + e, i0, i1, l1);
-        xi0[e] = i0; xl1[e] = l1;
-    }
-    __syncthreads();
-    // footprint index ranges per tile row / column (y0 in {s-1, s})
-    if (tid < 2 * BT) {
-        const bool is_x = tid >= BT;
-        const int s = (is_x ? xs0 : ys0) + (tid & (BT - 1));
-        const int n = is_x ? nX : nY;
-        const int* i0 = is_x ? xi0 : yi0;
-        int lo = n, hi = -1;
-        for (int f = 0; f < n; ++f) {
-            if (i0[f] >= s - 1 && i0[f] <= s) { lo = min(lo, f); hi = f; }
-        }
-        lo_hi[is_x ? 2 : 0][tid & (BT - 1)] = lo;
-        lo_hi[is_x ? 3 : 1][tid & (BT - 1)] = hi;
-    }
+    const int grp = blk % n_groups; blk /= n_groups;
+    const int band = blk % n_bands; blk /= n_bands;
+    const int n_cb = (d.w + (256 - halo) - 1) / (256 - halo);
+    const int cb = blk % n_cb;
+    const int b = blk / n_cb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = cb * (256 - halo) + tid - halo;                 // this lane's cell / output column
+    const bool cell_ok = c >= 0 && c < d.w;
+    const bool writes = cell_ok && tid >= halo;                   // halo lane only feeds its right neighbour
+    const int k0 = grp * KG;
+    const int ys0 = band * BAND;
+    const int ys_end = min(ys0 + BAND, d.h);                      // rows [ys0, ys_end) are written by this block
     const float gscale = d_loss[0] / out[1];
-    // phase 1: softmax statistics of every footprint pixel
-    for (int e = tid; e < nY * nX; e += 256) {
-        const int fy = e / nX, fx = e - fy * nX;
-        const int Y = Y_lo + fy, X = X_lo + fx;
-        const int64_t t64 = target[((size_t)b * d.H + Y) * d.W + X];
-        float lse = 0.f, coef = 0.f;
-        int t = -1;
-        if (t64 != (int64_t)d.ignore_label && t64 >= 0 && t64 < d.K) {
-            t = (int)t64;
-            const int y0 = yi0[fy], x0 = xi0[fx];
-            const int y1 = y0 + (y0 < d.h - 1 ? 1 : 0), x1 = x0 + (x0 < d.w - 1 ? 1 : 0);
-            const float ly1 = yl1[fy], lx1 = xl1[fx], ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-            const int o00 = (y0 - sr0) * SR + (x0 - sc0), o01 = (y0 - sr0) * SR + (x1 - sc0);
-            const int o10 = (y1 - sr0) * SR + (x0 - sc0), o11 = (y1 - sr0) * SR + (x1 - sc0);
-            float unused;
-            lse = pixel_lse(seg_t, plane, d.K, o00, o01, o10, o11, ly0, ly1, lx0, lx1, -1, &unused);
-            coef = (weight ? weight[t] : 1.f) * gscale;
+
+    const int Xs = cell_ok ? first_with_tap(d.sx, d.W, c) : 0;
+    const int n = cell_ok ? min(first_with_tap(d.sx, d.W, c + 1) - Xs, PX) : 0;
+    const int c1 = c + (c < d.w - 1 ? 1 : 0);
+    float lx1[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) lx1[p] = p < n ? d.sx * (float)(Xs + p) - (float)c : 0.f;
+
+    // label rows whose upper tap lies in [ys0 - 1, ys_end - 1]
+    const int Y_lo = first_with_tap(d.sy, d.H, ys0 - 1), Y_hi = first_with_tap(d.sy, d.H, ys_end);
+    float acc_lo[KG], acc_hi[KG];            // coarse rows y_cur and y_cur + 1
+#pragma unroll
+    for (int j = 0; j < KG; ++j) { acc_lo[j] = 0.f; acc_hi[j] = 0.f; }
+    int y_cur = max(ys0 - 1, 0);
+    if (Y_lo < Y_hi) y_cur = tap0(d.sy, Y_lo);
+
+    auto flush_lo = [&](int row) {
+        if (writes && row >= ys0 && row < ys_end) {
+#pragma unroll
+            for (int j = 0; j < KG; ++j)
+                if (k0 + j < d.K) d_seg[(((size_t)b * d.K + k0 + j) * d.h + row) * d.w + c] = acc_lo[j];
         }
-        f_lse[e] = lse; f_coef[e] = coef; f_tgt[e] = t;
-    }
-    __syncthreads();
-    for (int k = 0; k < d.K; ++k) {
-        const float* pl = seg_t + k * plane;
-        // (A) d_k at every footprint pixel
-        for (int e = tid; e < nY * nX; e += 256) {
-            const float coef = f_coef[e];
-            float dv = 0.f;
-            if (coef != 0.f) {
-                const int fy = e / nX, fx = e - fy * nX;
-                const int y0 = yi0[fy], x0 = xi0[fx];
-                const int y1 = y0 + (y0 < d.h - 1 ? 1 : 0), x1 = x0 + (x0 < d.w - 1 ? 1 : 0);
-                const float ly1 = yl1[fy], lx1 = xl1[fx], ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-                const int o00 = (y0 - sr0) * SR + (x0 - sc0), o01 = (y0 - sr0) * SR + (x1 - sc0);
-                const int o10 = (y1 - sr0) * SR + (x0 - sc0), o11 = (y1 - sr0) * SR + (x1 - sc0);
-                const float v = ly0 * (lx0 * pl[o00] + lx1 * pl[o01]) + ly1 * (lx0 * pl[o10] + lx1 * pl[o11]);
-                dv = coef * (expf(v - f_lse[e]) - (f_tgt[e] == k ? 1.f : 0.f));
-            }
-            dk[e] = dv;
+    };
+
+    for (int Y = Y_lo; Y < Y_hi; ++Y) {
+        int y0, y1;
+        float ly1;
+        tap(d.sy, d.h, Y, y0, y1, ly1);
+        const float ly0 = 1.f - ly1;
+        while (y_cur < y0) {                 // the march is monotone: retire the finished coarse row
+            flush_lo(y_cur);
+#pragma unroll
+            for (int j = 0; j < KG; ++j) { acc_lo[j] = acc_hi[j]; acc_hi[j] = 0.f; }
+            ++y_cur;
         }
-        __syncthreads();
-        // (B) horizontal adjoint: hrow[fy][xl] = sum_fx wx(fx, xs) * d_k[fy][fx]
-        for (int e = tid; e < nY * BT; e += 256) {
-            const int fy = e / BT, xl = e - fy * BT;
-            const int xs = xs0 + xl;
-            float acc = 0.f;
-            for (int fx = lo_hi[2][xl]; fx <= lo_hi[3][xl]; ++fx) {
-                const int x0 = xi0[fx];
-                const int x1 = x0 + (x0 < d.w - 1 ? 1 : 0);
-                const float lx1 = xl1[fx];
-                float wx = 0.f;
-                if (x0 == xs) wx += 1.f - lx1;
-                if (x1 == xs) wx += lx1;
-                acc += wx * dk[fy * nX + fx];
-            }
-            hrow[e] = acc;
-        }
-        __syncthreads();
-        // (C) vertical adjoint -> output tile of class k
-        if (tid < BT * BT) {
-            const int yl = tid / BT, xl = tid - yl * BT;
-            const int ys = ys0 + yl, xs = xs0 + xl;
-            if (ys < d.h && xs < d.w) {
-                float acc = 0.f;
-                for (int fy = lo_hi[0][yl]; fy <= lo_hi[1][yl]; ++fy) {
-                    const int y0 = yi0[fy];
-                    const int y1 = y0 + (y0 < d.h - 1 ? 1 : 0);
-                    const float ly1 = yl1[fy];
-                    float wy = 0.f;
-                    if (y0 == ys) wy += 1.f - ly1;
-                    if (y1 == ys) wy += ly1;
-                    acc += wy * hrow[fy * BT + xl];
+        float coef[PX], ls[PX];
+        int t[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            coef[p] = 0.f; ls[p] = INFINITY; t[p] = -1;      // exp(v - inf) = 0: inactive pixels contribute exactly 0
+            if (p < n) {
+                const size_t o = ((size_t)b * d.H + Y) * d.W + Xs + p;
+                const int64_t t64 = target[o];
+                if (t64 != (int64_t)d.ignore_label && t64 >= 0 && t64 < d.K) {
+                    t[p] = (int)t64;
+                    coef[p] = (weight ? weight[t[p]] : 1.f) * gscale;
+                    ls[p] = lse[o];
                 }
-                d_seg[(((size_t)b * d.K + k) * d.h + ys) * d.w + xs] = acc;
             }
         }
-        // hrow is rewritten only after the next (A)+barrier; dk only after this (B)'s barrier: no extra sync needed
+        float hA[KG], hB[KG];
+#pragma unroll
+        for (int j = 0; j < KG; ++j) {
+            hA[j] = 0.f; hB[j] = 0.f;
+            const int k = k0 + j;
+            if (k < d.K && n > 0) {
+                const float* s0 = seg + (((size_t)b * d.K + k) * d.h + y0) * d.w;
+                const float* s1 = seg + (((size_t)b * d.K + k) * d.h + y1) * d.w;
+                const float r0 = ly0 * s0[c] + ly1 * s1[c];
+                const float r1 = ly0 * s0[c1] + ly1 * s1[c1];
+#pragma unroll
+                for (int p = 0; p < PX; ++p) {
+                    const float v = fmaf(lx1[p], r1 - r0, r0);
+                    const float gk = coef[p] * (__expf(v - ls[p]) - (t[p] == k ? 1.f : 0.f));   // coef = 0: nothing
+                    const float gb = lx1[p] * gk;
+                    hB[j] += gb;                   // lands on column c + 1 (x1 tap)
+                    hA[j] += gk - gb;              // lands on column c     (x0 tap, weight 1 - lx1)
+                }
+            }
+        }
+        // at the right image edge x1 == x0: both taps land on column c
+        if (cell_ok && c == d.w - 1) {
+#pragma unroll
+            for (int j = 0; j < KG; ++j) { hA[j] += hB[j]; hB[j] = 0.f; }
+        }
+        const int par = Y & 1;
+        if (lane == 63) {
+#pragma unroll
+            for (int j = 0; j < KG; ++j) xchg[par][wave][j] = hB[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KG; ++j) {
+            float left = __shfl_up(hB[j], 1, 64);
+            if (lane == 0) left = wave > 0 ? xchg[par][wave - 1][j] : 0.f;
+            const float H = hA[j] + left;
+            if (y1 == y0) acc_lo[j] += H;          // bottom edge: both vertical taps on the same coarse row
+            else { acc_lo[j] += ly0 * H; acc_hi[j] += ly1 * H; }
+        }
+    }
+    flush_lo(y_cur);
+#pragma unroll
+    for (int j = 0; j < KG; ++j) acc_lo[j] = acc_hi[j];
+    flush_lo(y_cur + 1);
+    // coarse rows of the band that no label row touches (cannot happen when upsampling; kept for safety)
+    for (int row = max(y_cur + 2, ys0); row < ys_end; ++row) {
+#pragma unroll
+        for (int j = 0; j < KG; ++j) acc_lo[j] = 0.f;
+        flush_lo(row);
+    }
+    if (Y_lo >= Y_hi) {
+        for (int row = ys0; row < ys_end; ++row) {
+#pragma unroll
+            for (int j = 0; j < KG; ++j) acc_lo[j] = 0.f;
+            flush_lo(row);
+        }
     }
 }
 
@@ -315,24 +293,63 @@ int make_dims(CeDims* d, int B, int K, int h, int w, int H, int W, int ignore_la
     return 1;
 }
 
+// largest number of fine pixels that share one left tap (host side, exact: same float arithmetic as the device)
+int max_cell_px(const CeDims& d) {
+    int best = 0, run = 0, prev = -1;
+    for (int X = 0; X < d.W; ++X) {
+        const int x0 = tap0(d.sx, X);
+        run = (x0 == prev) ? run + 1 : 1;
+        prev = x0;
+        if (run > best) best = run;
+    }
+    return best;
+}
+
+int pick_px(int need) {
+    const int opts[] = {1, 2, 3, 5, 9, 17};
+    for (int o : opts)
+        if (need <= o) return o;
+    return 0;
+}
+
+int pick_kg(int K) {
+    const int opts[] = {8, 6, 5, 4};
+    int best = 4, waste = 1 << 30;
+    for (int o : opts) {
+        const int wst = (K + o - 1) / o * o - K;
+        if (wst < waste) { waste = wst; best = o; }
+    }
+    return best;
+}
+
 }  // namespace
 
 extern "C" int cseg_upsample_ce_blocks(int B, int H, int W) {
-    return B * ((H + FT_H - 1) / FT_H) * ((W + FT_W - 1) / FT_W);
+    // upper bound of the forward grid for any coarse width w <= W (one thread per (label row, coarse column))
+    return (int)(((long)B * H * W + 255) / 256);
 }
 
 extern "C" int cseg_upsample_ce_fwd(const float* seg, const int64_t* target, const float* weight, int ignore_label,
                                     int B, int K, int h, int w, int H, int W, float* partial, float* out,
-                                    int32_t* status, cseg_stream_t stream_) {
+                                    int32_t* status, float* lse, cseg_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CeDims d;
     if (!make_dims(&d, B, K, h, w, H, W, ignore_label)) return 0;
-    const int rows_max = (int)(d.sy * (float)(FT_H - 1)) + 3, cols_max = (int)(d.sx * (float)(FT_W - 1)) + 3;
-    const size_t lds = sizeof(float) * (size_t)K * rows_max * cols_max;
-    CSEG_REQUIRE(lds <= 64 * 1024, "upsample_ce_fwd: K=%d needs %zu B of LDS per block", K, lds);
-    const int n_blocks = cseg_upsample_ce_blocks(B, H, W);
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(n_blocks), dim3(256), lds, stream, seg, target, weight, d, rows_max,
-                       cols_max, partial, status);
+    const int px = pick_px(max_cell_px(d));
+    CSEG_REQUIRE(px > 0, "upsample_ce: %d label pixels share one coarse tap (%d -> %d); at most %d are supported", max_cell_px(d), w, W, MAX_PX);
+    const long n_cells = (long)B * H * w;
+    const int n_blocks = (int)((n_cells + 255) / 256);
+#define LAUNCH(P) hipLaunchKernelGGL(ce_fwd_kernel<P>, dim3(n_blocks), dim3(256), 0, stream, seg, target, weight, d, lse, \
+                                     partial, status)
+    switch (px) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
+        case 5: LAUNCH(5); break;
+        case 9: LAUNCH(9); break;
+        default: LAUNCH(17); break;
+    }
+#undef LAUNCH
     CSEG_CHECK_LAUNCH("ce_fwd_kernel");
     hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(1024), 0, stream, partial, n_blocks, out);
     CSEG_CHECK_LAUNCH("ce_finish_kernel");
@@ -341,26 +358,39 @@ extern "C" int cseg_upsample_ce_fwd(const float* seg, const int64_t* target, con
 
 extern "C" int cseg_upsample_ce_bwd(const float* seg, const int64_t* target, const float* weight, int ignore_label,
                                     int B, int K, int h, int w, int H, int W, const float* out, const float* d_loss,
-                                    float* d_seg, cseg_stream_t stream_) {
+                                    const float* lse, float* d_seg, cseg_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CeDims d;
     if (!make_dims(&d, B, K, h, w, H, W, ignore_label)) return 0;
-    // footprint of BT low-res rows: hi-res rows with y0 in [ys0-1, ys0+BT-1]  ->  at most (BT+1)/sy + 2 rows
-    const int nY_max = d.sy > 0.f ? (int)((float)(BT + 1) / d.sy) + 3 : H;
-    const int nX_max = d.sx > 0.f ? (int)((float)(BT + 1) / d.sx) + 3 : W;
-    const size_t lds = sizeof(float) * ((size_t)K * (BT + 2) * (BT + 2) + 4 * (size_t)nY_max * nX_max +
-                                        (size_t)nY_max * BT + 2 * (size_t)nY_max + 2 * (size_t)nX_max);
-    CSEG_REQUIRE(lds <= 150 * 1024, "upsample_ce_bwd: K=%d scale %dx needs %zu B of LDS per block", K, H / h, lds);
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)ce_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess) {
-            cseg_set_error("upsample_ce_bwd: cannot raise dynamic LDS to %zu", lds);
-            return 0;
-        }
+    CSEG_REQUIRE(lse, "upsample_ce_bwd: needs the log-sum-exp buffer written by cseg_upsample_ce_fwd");
+    const int px = pick_px(max_cell_px(d));
+    CSEG_REQUIRE(px > 0, "upsample_ce: %d label pixels share one coarse tap (%d -> %d); at most %d are supported", max_cell_px(d), w, W, MAX_PX);
+    const int kg = pick_kg(K);
+    const int n_groups = (K + kg - 1) / kg, n_bands = (h + BAND - 1) / BAND;
+    const int halo = w > 256 ? 1 : 0;
+    const int n_cb = (w + (256 - halo) - 1) / (256 - halo);
+    const int threads = n_cb > 1 ? 256 : ((w + 63) / 64) * 64;
+    const long n_blocks = (long)B * n_cb * n_bands * n_groups;
+    CSEG_REQUIRE(n_blocks < 2147483647L, "upsample_ce_bwd: grid too large");
+#define LAUNCH(P, G) hipLaunchKernelGGL((ce_bwd_kernel<P, G>), dim3((unsigned)n_blocks), dim3(threads), 0, stream, seg, target, \
+                                        weight, lse, d, n_groups, n_bands, halo, out, d_loss, d_seg)
+#define BY_KG(P)                                   \
+    switch (kg) {                                  \
+        case 8: LAUNCH(P, 8); break;               \
+        case 6: LAUNCH(P, 6); break;               \
+        case 5: LAUNCH(P, 5); break;               \
+        default: LAUNCH(P, 4); break;              \
     }
-    const int n_blocks = B * ((h + BT - 1) / BT) * ((w + BT - 1) / BT);
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3(n_blocks), dim3(256), lds, stream, seg, target, weight, d, nY_max, nX_max,
-                       out, d_loss, d_seg);
+    switch (px) {
+        case 1: BY_KG(1); break;
+        case 2: BY_KG(2); break;
+        case 3: BY_KG(3); break;
+        case 5: BY_KG(5); break;
+        case 9: BY_KG(9); break;
+        default: BY_KG(17); break;
+    }
+#undef BY_KG
+#undef LAUNCH
     CSEG_CHECK_LAUNCH("ce_bwd_kernel");
     return 1;
 }

@@ -336,24 +336,26 @@ class UpsampleCE(Function):
         if status is None:
             status = torch.zeros(4, dtype=I32, device=dev)
         wp = _p(weight, F32, "ce_weight") if weight is not None else _null()
+        lse = torch.empty(B, H, W, dtype=F32, device=dev)      # per-label-pixel log-sum-exp, reused by the backward
         _hip.call("cseg_upsample_ce_fwd", _p(seg, F32, "seg"), _p(target, I64, "target"), wp, int(ignore_index), B, K,
                   h, w, H, W, _p(partial, F32, "partial"), _p(out, F32, "out"), _p(status, I32, "status"),
-                  _hip.stream_ptr())
-        ctx.save_for_backward(seg, target, out)
+                  _p(lse, F32, "lse"), _hip.stream_ptr())
+        ctx.save_for_backward(seg, target, out, lse)
         ctx.weight = weight
         ctx.ignore_index = int(ignore_index)
         return out[0].clone()
 
     @staticmethod
     def backward(ctx, g):
-        seg, target, out = ctx.saved_tensors
+        seg, target, out, lse = ctx.saved_tensors
         B, K, h, w = seg.shape
         _, H, W = target.shape
         d_seg = torch.empty_like(seg)
         g = g.reshape(1).to(F32).contiguous()
         wp = _p(ctx.weight, F32, "ce_weight") if ctx.weight is not None else _null()
         _hip.call("cseg_upsample_ce_bwd", _p(seg, F32, "seg"), _p(target, I64, "target"), wp, ctx.ignore_index, B, K,
-                  h, w, H, W, _p(out, F32, "out"), _p(g, F32, "d_loss"), _p(d_seg, F32, "d_seg"), _hip.stream_ptr())
+                  h, w, H, W, _p(out, F32, "out"), _p(g, F32, "d_loss"), _p(lse, F32, "lse"), _p(d_seg, F32, "d_seg"),
+              _hip.stream_ptr())
         return d_seg, None, None, None, None
 
 
@@ -497,3 +499,56 @@ def bn_bwd_apply(dy, x, mean_invstd, weight, bias, sums, count, mask_from_x):
               _opt(weight, F32, "weight"), _opt(bias, F32, "bias"), _opt(sums, F64, "sums"), float(count),
               int(bool(mask_from_x)), B, C, HW, _p(dx, F32, "dx"), _hip.stream_ptr())
     return dx
+
+
+# ----------------------------------------------------------------------------------------------------------
+# 3x3 / stride 1 / pad 1 convolution of the narrow HRNet branches (csrc/conv3x3.hip)
+# ----------------------------------------------------------------------------------------------------------
+def conv3x3_eligible(x, weight):
+    """Shapes the MFMA kernel covers: NCHW fp32 on the GPU, 3x3, input channels % 8, output channels % 48 (both ways:
+    backward-data swaps them), width % 4."""
+    if not (x.is_cuda and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4 and x.is_contiguous()):
+        return False
+    co, ci, kh, kw = weight.shape
+    return (kh, kw) == (3, 3) and ci % 48 == 0 and co % 48 == 0 and x.shape[1] == ci and x.shape[3] % 4 == 0
+
+
+@torch.no_grad()
+def _conv3x3_run(x, weight, transpose_flip):
+    co, ci = weight.shape[:2]
+    conv_in, conv_out = (co, ci) if transpose_flip else (ci, co)
+    B, _, H, W = x.shape
+    lib = _hip.lib()
+    wp = torch.empty(lib.cseg_conv3x3_packed_floats(conv_in, conv_out), dtype=F32, device=x.device)
+    _hip.call("cseg_conv3x3_pack_weights", _p(weight, F32, "weight"), co, ci, int(transpose_flip), _p(wp, F32, "wp"),
+              _hip.stream_ptr())
+    y = torch.empty(B, conv_out, H, W, dtype=F32, device=x.device)
+    _hip.call("cseg_conv3x3_fwd", _p(x, F32, "x"), _p(wp, F32, "wp"), B, conv_in, conv_out, H, W, _p(y, F32, "y"),
+              _hip.stream_ptr())
+    return y
+
+
+class Conv3x3(Function):
+    """y = conv2d(x, weight, stride 1, padding 1). Forward and backward-data on the MFMA kernel; the weight gradient is
+    MIOpen's (aten.convolution_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        weight = weight.contiguous()
+        ctx.save_for_backward(x, weight)
+        return _conv3x3_run(x, weight, False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = _conv3x3_run(dy, weight, True) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        return dx, dw
+
+
+def conv3x3(x, weight):
+    return Conv3x3.apply(x, weight)

@@ -11,7 +11,7 @@ to torch SyncBN with momentum 0.1 exactly as the reference factory does (:773)."
 import torch.nn as nn
 
 from contrastiveseg_amd import kernels as K
-from contrastiveseg_amd.lib.models.tools.module_helper import ModuleHelper
+from contrastiveseg_amd.lib.models.tools.module_helper import Conv3x3, ModuleHelper
 
 # width -> per-stage (modules, blocks per branch); channel list is width * (1, 2, 4, 8)[:branches]
 STAGES = {2: (1, 4), 3: (4, 4), 4: (3, 4)}
@@ -33,9 +33,9 @@ class BasicBlock(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, downsample=None, bn_type=None, bn_momentum=0.1):
         super(BasicBlock, self).__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.conv1 = Conv3x3(inplanes, planes, stride)      # an nn.Conv2d; MFMA kernel on the narrow branches
         self.bn1 = _norm(bn_type, planes, bn_momentum)
-        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.conv2 = Conv3x3(planes, planes)
         self.bn2 = _norm(bn_type, planes, bn_momentum)
         self.downsample = downsample
         self.stride = stride

@@ -13,6 +13,25 @@ from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
 _NORMS = {'torchbn': FusedBatchNorm2d, 'torchsyncbn': FusedSyncBatchNorm}
 
 
+class Conv3x3(nn.Conv2d):
+    """nn.Conv2d (same parameters / state_dict) for the bias-free 3x3, stride-1, pad-1 convolutions of the residual
+    branches. Where the hand-written MFMA kernel (csrc/conv3x3.hip) beats MIOpen's best solver -- the narrow HRNet
+    branches: 48 and 96 channels, measured 121 vs 167 us and 113 vs 119 us per forward at the benched shapes,
+    tools/conv3x3_probe.py -- forward and backward-data run on it; every other shape, and the weight gradient, stay on
+    MIOpen exactly like the reference's nn.Conv2d."""
+    MFMA_CHANNELS = (48, 96)
+
+    def __init__(self, inplanes, planes, stride=1):
+        super(Conv3x3, self).__init__(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+
+    def forward(self, x):
+        from contrastiveseg_amd import kernels as K
+        if (x.is_cuda and self.stride == (1, 1) and self.dilation == (1, 1) and self.in_channels == self.out_channels
+                and self.in_channels in self.MFMA_CHANNELS and K.conv3x3_eligible(x, self.weight)):
+            return K.conv3x3(x, self.weight)
+        return super(Conv3x3, self).forward(x)
+
+
 class ModuleHelper(object):
     @staticmethod
     def BatchNorm2d(bn_type='torch', ret_cls=False):

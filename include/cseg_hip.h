@@ -128,15 +128,18 @@ int cseg_fuse_sum_bwd(const float* d_out, const float* out_act, const int* low_h
  *   seg [B,K,h,w], target [B,H,W] i64, weight [K] or NULL
  *   partial [2*n_blocks] f32 workspace, n_blocks = cseg_upsample_ce_blocks(B,H,W)
  *   out [2] f32: out[0] = loss, out[1] = sum of weights of valid pixels; status[1] counts bad targets
+ *   lse [B,H,W] f32: per-label-pixel log-sum-exp of the upsampled logits, written by fwd (nullable there) and read
+ *       by bwd, so that the backward evaluates every exp once and needs no second pass over the classes
  *   bwd: d_loss [1] device scalar; d_seg [B,K,h,w] is overwritten
+ * Upsampling factors up to 16x per axis (H >= h, W >= w).
  * ------------------------------------------------------------------------------------------------ */
 int cseg_upsample_ce_blocks(int B, int H, int W);
 int cseg_upsample_ce_fwd(const float* seg, const int64_t* target, const float* weight, int ignore_label, int B,
                          int K, int h, int w, int H, int W, float* partial, float* out, int32_t* status,
-                         cseg_stream_t stream);
+                         float* lse, cseg_stream_t stream);
 int cseg_upsample_ce_bwd(const float* seg, const int64_t* target, const float* weight, int ignore_label, int B,
                          int K, int h, int w, int H, int W, const float* out, const float* d_loss,
-                         float* d_seg, cseg_stream_t stream);
+                         const float* lse, float* d_seg, cseg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Memory bank update, device part.  Replaces the tensor work of
@@ -197,6 +200,22 @@ int cseg_bn_bwd_reduce(const float* dy, const float* x, const float* out, const 
 int cseg_bn_bwd_apply(const float* dy, const float* x, const float* mean_invstd, const float* weight, const float* bias,
                       const double* sums, double count, int mask_from_x, int B, int C, int HW, float* dx,
                       cseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 3x3 / stride 1 / pad 1 convolution, NCHW fp32, forward and backward-data, for the narrow HRNet branches
+ * (lib/models/backbones/hrnet/hrnet_backbone.py:35-66 BasicBlock conv1/conv2 -> nn.Conv2d -> MIOpen in the reference;
+ * MIOpen's best solver for the 48-channel shape reaches 45-50 TFLOP/s of the 157 TFLOP/s fp32 MFMA peak).
+ * Implicit GEMM on v_mfma_f32_16x16x4_f32, exact fp32 FMA chain.  Cin % 8 == 0, Cout % 48 == 0, W % 4 == 0.
+ *   cseg_conv3x3_pack_weights: w [Cout,Cin,3,3] -> wp (cseg_conv3x3_packed_floats floats) in MFMA lane order;
+ *       transpose_flip = 1 packs the backward-data operator (maps Cout -> Cin channels, taps mirrored);
+ *       cseg_conv3x3_packed_floats(conv_in, conv_out) takes the channel counts of the PACKED operator.
+ *   cseg_conv3x3_fwd: y [B,Cout,H,W] = conv(x [B,Cin,H,W], wp); for backward-data call it with x = dy,
+ *       Cin = forward Cout, Cout = forward Cin and the transpose_flip packing.
+ * ------------------------------------------------------------------------------------------------ */
+size_t cseg_conv3x3_packed_floats(int Cin, int Cout);
+int cseg_conv3x3_pack_weights(const float* w, int Cout, int Cin, int transpose_flip, float* wp, cseg_stream_t stream);
+int cseg_conv3x3_fwd(const float* x, const float* wp, int B, int Cin, int Cout, int H, int W, float* y,
+                     cseg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -249,8 +249,14 @@ def test_fuse_sum_relu_matches_torch():
                 ((a - b).abs() > 1e-4).float().mean().item() < 1e-4, (a - b).abs().max()
 
 
-@pytest.mark.parametrize("B,Kc,h,w,H,W,weighted", [(2, 5, 16, 32, 64, 128, True), (2, 19, 13, 21, 97, 161, False),
-                                                   (1, 171, 17, 9, 65, 33, True), (2, 7, 24, 40, 24, 40, True)])
+@pytest.mark.parametrize("B,Kc,h,w,H,W,weighted", [
+    (2, 5, 16, 32, 64, 128, True), (2, 19, 13, 21, 97, 161, False), (1, 171, 17, 9, 65, 33, True),
+    (2, 7, 24, 40, 24, 40, True),                 # label resolution: one pixel per cell
+    (1, 19, 16, 256, 64, 1024, True),             # one full 256-lane block per coarse row (the benched width)
+    (1, 4, 8, 300, 32, 1200, True),               # wider than a block: overlapping column blocks (halo lane)
+    (1, 3, 5, 7, 64, 96, False),                  # ~16x upsampling: 16 pixels per cell
+    (2, 6, 9, 10, 18, 20, True),                  # ~2x
+    (3, 9, 11, 7, 11, 7, False)])                 # label resolution, odd sizes, several bands
 def test_upsample_ce_matches_torch_and_oracle(B, Kc, h, w, H, W, weighted):
     dev = _dev()
     import torch.nn.functional as F

@@ -150,6 +150,9 @@ def _batches(global_batch, n):
     return out
 
 
+PICK = ("backbone.conv1.weight", "backbone.bn1.running_var", "cls_head.3.weight", "proj_head.proj.2.weight")
+
+
 def _ddp_worker(rank, world, port, q, backend):
     import torch.distributed as dist
     dev = _init(rank, world, port, backend)
@@ -162,15 +165,14 @@ def _ddp_worker(rank, world, port, q, backend):
             m.p = 0.0
     tr.seg_net.train()
     B = 4 // world
-    losses = []
+    losses, picks = [], []
     for img, lab in _batches(4, 2):
         sl = slice(rank * B, (rank + 1) * B)
         losses.append(float(tr.train_step({"img": img[sl].to(dev), "labelmap": lab[sl].to(dev)})))
+        sd = tr.seg_net.module.state_dict()
+        picks.append({k: sd[k].detach().cpu().numpy().copy() for k in PICK})
     torch.cuda.synchronize()
-    sd = tr.seg_net.module.state_dict()
-    pick = {k: sd[k].detach().cpu().numpy() for k in ("backbone.conv1.weight", "backbone.bn1.running_var",
-                                                      "cls_head.3.weight", "proj_head.proj.2.weight")}
-    q.put((rank, losses, pick))
+    q.put((rank, losses, picks))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -183,8 +185,9 @@ def test_ddp_syncbn_two_ranks_equal_single_process(backend):
     on these labels differs from the global mean by < 1e-3 relative."""
     _need(backend)
     res = _spawn(_ddp_worker, 2, backend)
-    for k in res[0][2]:
-        assert np.array_equal(res[0][2][k], res[1][2][k]), "replicas diverged: " + k
+    for step in (0, 1):
+        for k in PICK:
+            assert np.array_equal(res[0][2][step][k], res[1][2][step][k]), "replicas diverged: " + k
     from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
     dev = torch.device("cuda:0")
     torch.manual_seed(304)
@@ -193,15 +196,24 @@ def test_ddp_syncbn_two_ranks_equal_single_process(backend):
         if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
             m.p = 0.0
     tr.seg_net.train()
-    single = [float(tr.train_step({"img": img.to(dev), "labelmap": lab.to(dev)})) for img, lab in _batches(4, 2)]
-    sd = tr.seg_net.state_dict()
+    w0 = {k: tr.seg_net.state_dict()[k].detach().cpu().numpy().copy() for k in PICK}
+    single, after1 = [], None
+    for img, lab in _batches(4, 2):
+        single.append(float(tr.train_step({"img": img.to(dev), "labelmap": lab.to(dev)})))
+        if after1 is None:
+            after1 = {k: tr.seg_net.state_dict()[k].detach().cpu().numpy().copy() for k in PICK}
     # the displayed loss is rank-local in DDP: contrast term global (identical), CE term per-rank -> compare the mean
-    ddp_mean = [0.5 * (res[0][1][i] + res[1][1][i]) for i in range(2)]
-    assert abs(ddp_mean[0] - single[0]) <= 2e-3 * abs(single[0]), (ddp_mean, single)
-    assert np.abs(res[0][2]["backbone.bn1.running_var"] - sd["backbone.bn1.running_var"].cpu().numpy()).max() <= 1e-5
+    ddp_mean = 0.5 * (res[0][1][0] + res[1][1][0])
+    assert abs(ddp_mean - single[0]) <= 2e-3 * abs(single[0]), (ddp_mean, single)
+    ddp1 = res[0][2][0]
+    assert np.abs(ddp1["backbone.bn1.running_var"] - after1["backbone.bn1.running_var"]).max() <= 1e-5
+    # first SGD update: DDP's averaged gradient == the single-process gradient up to the fp32 backward noise of this
+    # network (1e-2 class, tests/test_step_golden.py) and the per-rank-mean CE normalisation
     for k in ("backbone.conv1.weight", "cls_head.3.weight", "proj_head.proj.2.weight"):
-        a, b = res[0][2][k], sd[k].detach().cpu().numpy()
-        assert np.abs(a - b).max() <= 2e-2 * np.abs(b).max(), (k, np.abs(a - b).max(), np.abs(b).max())
+        d_ddp, d_one = ddp1[k] - w0[k], after1[k] - w0[k]
+        err = np.linalg.norm(d_ddp - d_one) / np.linalg.norm(d_one)
+        assert err <= 0.1, (k, err)
+    assert all(np.isfinite(res[0][1])) and np.isfinite(single[1])
 
 
 def test_bench_launches_its_own_ranks():
