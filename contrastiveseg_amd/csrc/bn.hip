@@ -313,7 +313,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float mean = mean_invstd[2 * c], invstd = mean_invstd[2 * c + 1];
     const float a = (weight ? weight[c] : 1.f) * invstd;
     const float beta = bias ? bias[c] : 0.f;
-    const float k0 = sums ? (float)(sums[2 * c] * inv_count) : 0.f;
+    // k0 = mean(dy') is subtracted from EVERY element: a float-rounded k0 would shift all of them by the same ~6e-8*|k0|,
+    // an error that adds up coherently in the weight gradient of the convolution in front (sum_p dx_p * input_p, where
+    // sum_p dx_p = 0 in exact arithmetic). Carry it as hi + lo.
+    const double k0d = sums ? sums[2 * c] * inv_count : 0.0;
+    const float k0 = (float)k0d, k0l = (float)(k0d - (double)k0);
     const float k1 = sums ? (float)(sums[2 * c + 1] * inv_count * (double)invstd * (double)invstd) : 0.f;
     const size_t base = (size_t)plane * d.HW + (size_t)ck * CHUNK;
     const int len = min(CHUNK, d.HW - ck * CHUNK);
@@ -330,8 +334,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                     g.z = fmaf(x2, a, beta) > 0.f ? g.z : 0.f; g.w = fmaf(x3, a, beta) > 0.f ? g.w : 0.f;
                 }
                 float4 o;
-                o.x = a * (g.x - k0 - x0 * k1); o.y = a * (g.y - k0 - x1 * k1);
-                o.z = a * (g.z - k0 - x2 * k1); o.w = a * (g.w - k0 - x3 * k1);
+                o.x = a * ((g.x - k0) - k0l - x0 * k1); o.y = a * ((g.y - k0) - k0l - x1 * k1);
+                o.z = a * ((g.z - k0) - k0l - x2 * k1); o.w = a * ((g.w - k0) - k0l - x3 * k1);
                 *reinterpret_cast<float4*>(dx + base + i) = o;
             }
         }
@@ -340,7 +344,156 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             float g = dy[base + i];
             const float xm = x[base + i] - mean;
             if (MASK) g = fmaf(xm, a, beta) > 0.f ? g : 0.f;
-            dx[base + i] = a * (g - k0 - xm * k1);
+            dx[base + i] = a * ((g - k0) - k0l - xm * k1);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// single-rank fast path: the per-channel finalisation (partials -> mean / invstd, running statistics) is done by
+// wave 0 of every apply block instead of a separate 5-us launch per layer (307 layers per step); the block of image 0,
+// chunk 0 of each channel publishes mean_invstd for the backward and updates the running statistics.
+// ---------------------------------------------------------------------------------------------------------
+struct BnFinalize {
+    const float* partial;
+    float eps, momentum;
+    float* running_mean;
+    float* running_var;
+    int64_t* num_batches_tracked;
+    float* mean_invstd;           // out [C,2]
+};
+
+template <bool VEC, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_fused_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                             BnFinalize f, const float* __restrict__ weight,
+                                                             const float* __restrict__ bias, BnDims d, int relu,
+                                                             float* __restrict__ y) {
+    __shared__ float mi[2];
+    const int plane = blockIdx.x / d.n_ck, ck = blockIdx.x - plane * d.n_ck;
+    const int c = plane % d.C;
+    if (threadIdx.x < 64) {
+        double m0, m1;
+        channel_moments(x, f.partial, d, c, threadIdx.x, m0, m1);
+        if (threadIdx.x == 0) {
+            const double count = (double)d.B * (double)d.HW;
+            const double mean = m0 / count;
+            double var = m1 / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            mi[0] = (float)mean;
+            mi[1] = (float)(1.0 / sqrt(var + (double)f.eps));
+            if (plane == c && ck == 0) {              // image 0, first chunk: the channel's publisher
+                f.mean_invstd[2 * c] = mi[0];
+                f.mean_invstd[2 * c + 1] = mi[1];
+                if (f.running_mean) {
+                    const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+                    f.running_mean[c] = (float)((1.0 - (double)f.momentum) * (double)f.running_mean[c] +
+                                                (double)f.momentum * mean);
+                    f.running_var[c] = (float)((1.0 - (double)f.momentum) * (double)f.running_var[c] +
+                                               (double)f.momentum * unbiased);
+                }
+                if (c == 0 && f.num_batches_tracked) *f.num_batches_tracked += 1;
+            }
+        }
+    }
+    __syncthreads();
+    const float mean = mi[0];
+    const float a = (weight ? weight[c] : 1.f) * mi[1];
+    const float beta = bias ? bias[c] : 0.f;
+    const size_t base = (size_t)plane * d.HW + (size_t)ck * CHUNK;
+    const int len = min(CHUNK, d.HW - ck * CHUNK);
+    const bool rl = relu != 0;
+    if (VEC) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = (u * 256 + threadIdx.x) * 4;
+            if (i < len) {
+                const float4 v = *reinterpret_cast<const float4*>(x + base + i);
+                float4 o;
+                o.x = fmaf(v.x - mean, a, beta); o.y = fmaf(v.y - mean, a, beta);
+                o.z = fmaf(v.z - mean, a, beta); o.w = fmaf(v.w - mean, a, beta);
+                if (RES) {
+                    const float4 r = *reinterpret_cast<const float4*>(res + base + i);
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
+                o.x = (rl && o.x < 0.f) ? 0.f : o.x; o.y = (rl && o.y < 0.f) ? 0.f : o.y;
+                o.z = (rl && o.z < 0.f) ? 0.f : o.z; o.w = (rl && o.w < 0.f) ? 0.f : o.w;
+                *reinterpret_cast<float4*>(y + base + i) = o;
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < len; i += 256) {
+            float o = fmaf(x[base + i] - mean, a, beta);
+            if (RES) o += res[base + i];
+            y[base + i] = (rl && o < 0.f) ? 0.f : o;
+        }
+    }
+}
+
+// backward twin: every bwd-apply block reduces the channel's partial sums itself; the publisher block writes
+// d_weight / d_bias (and the fp64 sums, kept for inspection)
+template <bool VEC, bool MASK>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ mean_invstd,
+                                                                 const float* __restrict__ weight,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ partial, int training,
+                                                                 BnDims d, float* __restrict__ d_weight,
+                                                                 float* __restrict__ d_bias, float* __restrict__ dx) {
+    __shared__ float kk[3];            // k0 (hi), k1, k0 (lo): see bn_bwd_apply_kernel
+    const int plane = blockIdx.x / d.n_ck, ck = blockIdx.x - plane * d.n_ck;
+    const int c = plane % d.C;
+    const float mean = mean_invstd[2 * c], invstd = mean_invstd[2 * c + 1];
+    if (threadIdx.x < 64) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int s = threadIdx.x; s < d.S; s += 64) {
+            s0 += (double)partial[((size_t)s * d.C + c) * 2 + 0];
+            s1 += (double)partial[((size_t)s * d.C + c) * 2 + 1];
+        }
+        s0 = wave_sum_d(s0);
+        s1 = wave_sum_d(s1);
+        if (threadIdx.x == 0) {
+            const double inv = 1.0 / ((double)d.B * (double)d.HW);
+            const double k0d = training ? s0 * inv : 0.0;
+            kk[0] = (float)k0d;
+            kk[2] = (float)(k0d - (double)kk[0]);
+            kk[1] = training ? (float)(s1 * inv * (double)invstd * (double)invstd) : 0.f;
+            if (plane == c && ck == 0) {
+                if (d_weight) d_weight[c] = (float)(s1 * (double)invstd);
+                if (d_bias) d_bias[c] = (float)s0;
+            }
+        }
+    }
+    __syncthreads();
+    const float a = (weight ? weight[c] : 1.f) * invstd;
+    const float beta = bias ? bias[c] : 0.f;
+    const float k0 = kk[0], k1 = kk[1], k0l = kk[2];
+    const size_t base = (size_t)plane * d.HW + (size_t)ck * CHUNK;
+    const int len = min(CHUNK, d.HW - ck * CHUNK);
+    if (VEC) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = (u * 256 + threadIdx.x) * 4;
+            if (i < len) {
+                float4 g = *reinterpret_cast<const float4*>(dy + base + i);
+                const float4 v = *reinterpret_cast<const float4*>(x + base + i);
+                const float x0 = v.x - mean, x1 = v.y - mean, x2 = v.z - mean, x3 = v.w - mean;
+                if (MASK) {
+                    g.x = fmaf(x0, a, beta) > 0.f ? g.x : 0.f; g.y = fmaf(x1, a, beta) > 0.f ? g.y : 0.f;
+                    g.z = fmaf(x2, a, beta) > 0.f ? g.z : 0.f; g.w = fmaf(x3, a, beta) > 0.f ? g.w : 0.f;
+                }
+                float4 o;
+                o.x = a * ((g.x - k0) - k0l - x0 * k1); o.y = a * ((g.y - k0) - k0l - x1 * k1);
+                o.z = a * ((g.z - k0) - k0l - x2 * k1); o.w = a * ((g.w - k0) - k0l - x3 * k1);
+                *reinterpret_cast<float4*>(dx + base + i) = o;
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < len; i += 256) {
+            float g = dy[base + i];
+            const float xm = x[base + i] - mean;
+            if (MASK) g = fmaf(xm, a, beta) > 0.f ? g : 0.f;
+            dx[base + i] = a * ((g - k0) - k0l - xm * k1);
         }
     }
 }
@@ -361,7 +514,7 @@ int check_dims(const char* who, int B, int C, int HW) {
 extern "C" size_t cseg_bn_ws_floats(int B, int C, int HW) {
     if (B <= 0 || C <= 0 || HW <= 0) return 0;
     const BnDims d = bn_dims(B, C, HW);
-    return (size_t)d.S * C * 2;
+    return (size_t)d.S * C * 2 + (size_t)C * 4 + 4;      // partials + room for [C,2] fp64 sums (cseg_bn_bwd without dx)
 }
 
 extern "C" int cseg_bn_stats(const float* x, int B, int C, int HW, float* ws, double* moments, cseg_stream_t stream_) {
@@ -461,5 +614,67 @@ extern "C" int cseg_bn_bwd_apply(const float* dy, const float* x, const float* m
     else { if (mask_from_x) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
     CSEG_CHECK_LAUNCH("bn_bwd_apply");
+    return 1;
+}
+
+// Single-rank training forward in two launches: statistics partials, then apply with the finalisation folded in.
+extern "C" int cseg_bn_fwd(const float* x, const float* residual, const float* weight, const float* bias, int relu, int B,
+                           int C, int HW, float* ws, float eps, float momentum, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, float* mean_invstd, float* y, cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!check_dims("bn_fwd", B, C, HW)) return 0;
+    CSEG_REQUIRE(x && ws && mean_invstd && y, "bn_fwd: null pointer");
+    CSEG_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_fwd: running_mean/var must come together");
+    const BnDims d = bn_dims(B, C, HW);
+    if (vec_ok(HW, x)) hipLaunchKernelGGL(bn_stats_kernel<true>, dim3(d.S * C), dim3(256), 0, stream, x, d, ws);
+    else hipLaunchKernelGGL(bn_stats_kernel<false>, dim3(d.S * C), dim3(256), 0, stream, x, d, ws);
+    BnFinalize f;
+    f.partial = ws; f.eps = eps; f.momentum = momentum; f.running_mean = running_mean; f.running_var = running_var;
+    f.num_batches_tracked = num_batches_tracked; f.mean_invstd = mean_invstd;
+    const dim3 grid((unsigned)((long)B * C * d.n_ck));
+    const bool v = vec_ok(HW, x, residual, y);
+#define LAUNCH(V, R) hipLaunchKernelGGL((bn_apply_fused_kernel<V, R>), grid, dim3(256), 0, stream, x, residual, f, weight, \
+                                        bias, d, relu, y)
+    if (v) { if (residual) LAUNCH(true, true); else LAUNCH(true, false); }
+    else { if (residual) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    CSEG_CHECK_LAUNCH("bn_fwd");
+    return 1;
+}
+
+// Single-rank backward in two launches (mode as in cseg_bn_bwd_reduce; training = 0: frozen statistics).
+extern "C" int cseg_bn_bwd(const float* dy, const float* x, const float* out, const float* mean_invstd,
+                           const float* weight, const float* bias, int mode, int training, int B, int C, int HW, float* ws,
+                           float* g_masked, float* d_weight, float* d_bias, float* dx, cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!check_dims("bn_bwd", B, C, HW)) return 0;
+    CSEG_REQUIRE(dy && x && mean_invstd && ws, "bn_bwd: null pointer");
+    CSEG_REQUIRE(mode >= 0 && mode <= 2, "bn_bwd: mode %d", mode);
+    CSEG_REQUIRE(mode != 2 || (out && g_masked), "bn_bwd: mode 2 needs `out` and `g_masked`");
+    const BnDims d = bn_dims(B, C, HW);
+    {
+        const bool v = vec_ok(HW, dy, x, out, g_masked);
+        const dim3 grid(d.S * C);
+#define LAUNCH(V, M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, M>), grid, dim3(256), 0, stream, dy, x, out, mean_invstd, \
+                                        weight, bias, d, g_masked, ws)
+        if (v) { if (mode == 0) LAUNCH(true, 0); else if (mode == 1) LAUNCH(true, 1); else LAUNCH(true, 2); }
+        else { if (mode == 0) LAUNCH(false, 0); else if (mode == 1) LAUNCH(false, 1); else LAUNCH(false, 2); }
+#undef LAUNCH
+    }
+    if (dx) {
+        const float* g = mode == 2 ? g_masked : dy;
+        const dim3 grid((unsigned)((long)B * C * d.n_ck));
+        const bool v = vec_ok(HW, g, x, dx);
+#define LAUNCH(V, M) hipLaunchKernelGGL((bn_bwd_apply_fused_kernel<V, M>), grid, dim3(256), 0, stream, g, x, mean_invstd, \
+                                        weight, bias, ws, training, d, d_weight, d_bias, dx)
+        if (v) { if (mode == 1) LAUNCH(true, true); else LAUNCH(true, false); }
+        else { if (mode == 1) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    } else {
+        // no input gradient wanted: only the parameter gradients
+        hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, ws, d, mean_invstd,
+                           reinterpret_cast<double*>(ws + (size_t)d.S * C * 2), d_weight, d_bias);
+    }
+    CSEG_CHECK_LAUNCH("bn_bwd");
     return 1;
 }

@@ -552,3 +552,33 @@ class Conv3x3(Function):
 
 def conv3x3(x, weight):
     return Conv3x3.apply(x, weight)
+
+
+@torch.no_grad()
+def bn_fwd(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches_tracked):
+    """Single-rank training forward (2 launches): -> (y, mean_invstd [C,2])."""
+    B, C, HW = _bn_dims(x)
+    mi = torch.empty(C, 2, dtype=F32, device=x.device)
+    y = torch.empty_like(x)
+    _hip.call("cseg_bn_fwd", _p(x, F32, "x"), _opt(residual, F32, "residual"), _opt(weight, F32, "weight"),
+              _opt(bias, F32, "bias"), int(bool(relu)), B, C, HW, _p(_bn_ws(B, C, HW, x.device), F32, "ws"), float(eps),
+              float(momentum), _opt(running_mean, F32, "running_mean"), _opt(running_var, F32, "running_var"),
+              _opt(num_batches_tracked, I64, "num_batches_tracked"), _p(mi, F32, "mean_invstd"), _p(y, F32, "y"),
+              _hip.stream_ptr())
+    return y, mi
+
+
+@torch.no_grad()
+def bn_bwd(dy, x, out, mean_invstd, weight, bias, mode, training, want_dx):
+    """Single-rank backward (2 launches): -> (dx or None, d_weight, d_bias, g_masked or None)."""
+    B, C, HW = _bn_dims(x)
+    dev = x.device
+    d_weight = torch.empty(C, dtype=F32, device=dev)
+    d_bias = torch.empty(C, dtype=F32, device=dev)
+    g = torch.empty_like(x) if mode == 2 else None
+    dx = torch.empty_like(x) if want_dx else None
+    _hip.call("cseg_bn_bwd", _p(dy, F32, "dy"), _p(x, F32, "x"), _opt(out, F32, "out"),
+              _p(mean_invstd, F32, "mean_invstd"), _opt(weight, F32, "weight"), _opt(bias, F32, "bias"), int(mode),
+              int(bool(training)), B, C, HW, _p(_bn_ws(B, C, HW, dev), F32, "ws"), _opt(g, F32, "g_masked"),
+              _p(d_weight, F32, "d_weight"), _p(d_bias, F32, "d_bias"), _opt(dx, F32, "dx"), _hip.stream_ptr())
+    return dx, d_weight, d_bias, g

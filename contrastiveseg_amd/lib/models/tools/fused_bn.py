@@ -42,11 +42,14 @@ class _BNAct(torch.autograd.Function):
                 moments = _all_reduce(K.bn_stats(x), sync_group)
                 count = float(n_local * world)          # equal per-rank batch (data_loader.py:137 splits evenly)
                 mi = K.bn_finalize(moments, count, eps, momentum, running_mean, running_var, num_batches_tracked)
+                y = K.bn_apply(x, mi, weight, bias, residual, relu)
             else:
-                mi = K.bn_stats_finalize(x, eps, momentum, running_mean, running_var, num_batches_tracked)
+                # single rank: statistics + (finalise, running statistics, apply) in two launches
+                y, mi = K.bn_fwd(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var,
+                                 num_batches_tracked)
         else:
             mi = torch.stack([running_mean, torch.rsqrt(running_var + eps)], dim=1).contiguous()
-        y = K.bn_apply(x, mi, weight, bias, residual, relu)
+            y = K.bn_apply(x, mi, weight, bias, residual, relu)
         ctx.meta = (training, relu, residual is not None, count, sync_group)
         ctx.save_for_backward(x, mi, weight, bias, y if (relu and residual is not None) else None)
         return y
@@ -57,16 +60,18 @@ class _BNAct(torch.autograd.Function):
         training, relu, has_res, count, sync_group = ctx.meta
         dy = dy.contiguous()
         mode = 0 if not relu else (2 if has_res else 1)
-        sums, d_weight, d_bias, g = K.bn_bwd_reduce(dy, x, out, mi, weight, bias, mode)
+        if sync_group is None or not training:
+            # single rank (or frozen statistics): reduce + (sums, parameter gradients, dx) in two launches
+            dx, d_weight, d_bias, g = K.bn_bwd(dy, x, out, mi, weight, bias, mode, training, ctx.needs_input_grad[0])
+        else:
+            sums, d_weight, d_bias, g = K.bn_bwd_reduce(dy, x, out, mi, weight, bias, mode)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                sums = _all_reduce(sums, sync_group)
+                dx = K.bn_bwd_apply(g if mode == 2 else dy, x, mi, weight, bias, sums, count, mode == 1)
         d_res = None
         if has_res:
             d_res = g if mode == 2 else dy          # the add passes the (masked) gradient straight through
-        dx = None
-        if ctx.needs_input_grad[0]:
-            if training and sync_group is not None:
-                sums = _all_reduce(sums, sync_group)
-            dx = K.bn_bwd_apply(g if mode == 2 else dy, x, mi, weight, bias, sums if training else None, count,
-                                mode == 1)
         return (dx, d_weight if weight is not None else None, d_bias if bias is not None else None,
                 d_res if ctx.needs_input_grad[3] else None, None, None, None, None, None, None, None, None)
 

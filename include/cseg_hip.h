@@ -186,6 +186,15 @@ int cseg_bn_finalize(const double* moments, int C, double count, float eps, floa
 int cseg_bn_stats_finalize(const float* x, int B, int C, int HW, float* ws, float eps, float momentum,
                            float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean_invstd,
                            cseg_stream_t stream);
+/* single-rank training step in two launches each: cseg_bn_fwd = statistics + (finalise, running statistics, apply);
+ * cseg_bn_bwd = reduce + (sums, d_weight/d_bias, dx); arguments as in the split entry points below; dx may be NULL
+ * (parameter gradients only); training = 0 freezes the statistics (eval-mode backward: dx = w*invstd*dy'). */
+int cseg_bn_fwd(const float* x, const float* residual, const float* weight, const float* bias, int relu, int B, int C,
+                int HW, float* ws, float eps, float momentum, float* running_mean, float* running_var,
+                int64_t* num_batches_tracked, float* mean_invstd, float* y, cseg_stream_t stream);
+int cseg_bn_bwd(const float* dy, const float* x, const float* out, const float* mean_invstd, const float* weight,
+                const float* bias, int mode, int training, int B, int C, int HW, float* ws, float* g_masked,
+                float* d_weight, float* d_bias, float* dx, cseg_stream_t stream);
 /* y = relu?((x - mean) * invstd * weight + bias [+ residual]) */
 int cseg_bn_apply(const float* x, const float* residual, const float* mean_invstd, const float* weight,
                   const float* bias, int relu, int B, int C, int HW, float* y, cseg_stream_t stream);

@@ -242,15 +242,34 @@ def bn_bwd_reduce(dy, x, out, mean_invstd, weight, bias, mode):
 
 
 @torch.no_grad()
+def bn_fwd(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches_tracked):
+    mi = bn_stats_finalize(x, eps, momentum, running_mean, running_var, num_batches_tracked)
+    return bn_apply(x, mi, weight, bias, residual, relu), mi
+
+
+@torch.no_grad()
+def bn_bwd(dy, x, out, mean_invstd, weight, bias, mode, training, want_dx):
+    sums, d_weight, d_bias, g = bn_bwd_reduce(dy, x, out, mean_invstd, weight, bias, mode)
+    dx = None
+    if want_dx:
+        dx = bn_bwd_apply(g if mode == 2 else dy, x, mean_invstd, weight, bias, sums if training else None,
+                          float(x.numel() // x.shape[1]), mode == 1)
+    return dx, d_weight, d_bias, g
+
+
+@torch.no_grad()
 def bn_bwd_apply(dy, x, mean_invstd, weight, bias, sums, count, mask_from_x):
     xm, a, z = _bn_affine(x, mean_invstd, weight, bias)
     shape = (1, -1) + (1,) * (x.dim() - 2)
     g = dy * (z > 0) if mask_from_x else dy
     if sums is None:
         return g * a.reshape(shape)
-    k0 = (sums[:, 0] / count).float().reshape(shape)
+    k0d = sums[:, 0] / count
+    k0 = k0d.float()
+    k0l = (k0d - k0.double()).float().reshape(shape)      # mean(dy') carried as hi + lo, like the kernel
+    k0 = k0.reshape(shape)
     k1 = (sums[:, 1] / count * mean_invstd[:, 1].double() ** 2).float().reshape(shape)
-    return a.reshape(shape) * (g - k0 - xm * k1)
+    return a.reshape(shape) * ((g - k0) - k0l - xm * k1)
 
 
 def install(monkeypatch_or_none=None):

@@ -352,7 +352,7 @@ STEP_CASES = {
                                     "encoder_q.cls_head.0.weight", "encoder_q.proj_head.proj.0.weight",
                                     "encoder_q.proj_head.proj.2.weight"]),
     "step_resnet50_deeplab": dict(model="deeplab_v3_contrast", backbone="deepbase_resnet50_dilated8",
-                                  loss="contrast_auxce_loss", K=7, B=4, H=97, W=129, seed=44, torch_seed=5,
+                                  loss="contrast_auxce_loss", K=7, B=4, H=97, W=129, seed=44, torch_seed=5, spread=True,
                                   contrast=dict(max_samples=128, max_views=8, proj_dim=64),
                                   watch=["backbone.resinit.conv1.weight", "backbone.layer2.0.downsample.0.weight",
                                          "backbone.layer4.2.conv2.weight", "decoder.layer_aspp.b0.0.weight",
@@ -372,6 +372,11 @@ def watch_subset(a, cap=16384):
 def step_inputs(c):
     rs = np.random.RandomState(c["seed"])
     img = rs.standard_normal((c["B"], 3, c["H"], c["W"])).astype(np.float32)
+    if c.get("spread"):
+        # per-image contrast / brightness (see model_input): keeps the B-sample BN of the ASPP image pooling conditioned
+        gain = np.linspace(0.4, 1.6, c["B"]).astype(np.float32).reshape(-1, 1, 1, 1)
+        bias = np.linspace(-0.8, 0.8, c["B"]).astype(np.float32).reshape(-1, 1, 1, 1)
+        img = img * gain + bias * np.array([1.0, -0.5, 0.25], dtype=np.float32).reshape(1, 3, 1, 1)
     target, _, _ = O.synth_case(c["seed"] + 1, c["B"], c["K"], c["H"], c["W"], 4, 8, blocky=True, n_rect=10)
     return img, target
 
