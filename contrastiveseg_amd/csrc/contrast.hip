@@ -9,8 +9,9 @@
 //   row_pass_kernel  per anchor row: max, sum of negatives, positive count, mean log-prob of positives
 //   mean_kernel      loss = mean_i row_loss[i]  (fixed-order reduction: results are run-to-run deterministic)
 //   bwd_kernel       dA = dloss/tau . H . C,  H = G (+ G^T in self mode) rebuilt on the fly from S and the row
-//                    statistics directly in the MFMA A-operand register layout (no LDS round trip), C rows
-//                    streamed from L2 as the B operand; partial sums over column splits go to d_anchor_parts.
+//                    statistics directly in the MFMA A-operand register layout (no LDS round trip), C rows staged
+//                    through wave-private LDS with coalesced 16-byte loads as the B operand; partial sums over
+//                    column splits go to d_anchor_parts.
 //
 // MFMA 32x32x2 f32 layouts (MI355X guide section 3): A: lane l holds A[i=l&31][k=l>>5]; B: B[k=l>>5][j=l&31];
 // C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5) for accumulator register r in [0,16).
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ S, i
                                                   const float* __restrict__ d_loss, float inv_tau, int nDg, int nJ,
                                                   int per_split, float* __restrict__ parts) {
     __shared__ float red[32][BW_DT * 32 + 4];      // waves add their tiles one after the other (fixed order)
+    __shared__ __attribute__((aligned(16))) float cstage[4][32 * 32];   // per wave: 32 contrast rows x 32 features
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int h = lane >> 5, r32 = lane & 31;
     const int It = blockIdx.x / nDg, dg = blockIdx.x % nDg;
@@ -263,10 +265,6 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ S, i
     const float4 sti = i_ok ? *reinterpret_cast<const float4*>(row_stats + 4 * (size_t)i)
                             : make_float4(0.f, 1.f, 0.f, 0.f);
     const int yi = i_ok ? a_lab[i] : -0x7ffffffe;
-    const float* safe_row = col.mode == 2 ? col.segq : col.rows;
-    int dl[BW_DT];                      // columns >= D of a partial feature group are never written back: clamp
-#pragma unroll
-    for (int t = 0; t < BW_DT; ++t) dl[t] = min(d0 + t * 32 + r32, D - 1);
 
     f32x16 acc[BW_DT];
 #pragma unroll
@@ -278,7 +276,13 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ S, i
     for (int jt = jt_lo + wave; jt < jt_hi; jt += 4) {
         const int J0 = jt * 32;
         float hv[16];
-        const float* crow[16];
+        // B operand: the 32 contrast rows of this column tile are staged feature tile by feature tile in a wave-private
+        // LDS block with coalesced 16-byte loads (8 lanes per 128-byte row segment) instead of 16 strided scalar loads
+        // per feature tile; missing rows (padding columns, zero tail of the bank) are staged as zeros.
+        const float* srow[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) srow[u] = col.row(J0 + (lane >> 3) + 8 * u);
+        float* cw = cstage[wave];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int jb = J0 + 8 * q + 4 * h;  // this lane's 4 consecutive columns for registers 4q..4q+3
@@ -300,18 +304,21 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ S, i
                                             : make_float4(0.f, 1.f, 0.f, 0.f);
                     g += grad_elem(sv[t], stj, pos, neg);
                 }
-                // a missing row (padding column or the zero tail of the bank) contributes 0 whatever H is: zero H
-                // there and read a valid row instead, so the B-operand loads are unconditional
-                const float* cr = rp[t];
-                hv[4 * q + t] = (i_ok && cr) ? g : 0.f;
-                crow[4 * q + t] = cr ? cr : safe_row;
+                // a missing row (padding column or the zero tail of the bank) contributes 0 whatever H is
+                hv[4 * q + t] = (i_ok && rp[t]) ? g : 0.f;
             }
         }
 #pragma unroll
         for (int t = 0; t < BW_DT; ++t) {
+            const int dbase = d0 + t * 32 + (lane & 7) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 v = (srow[u] && dbase < D) ? ld4(srow[u] + dbase) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(cw + ((lane >> 3) + 8 * u) * 32 + (lane & 7) * 4) = v;
+            }
             float bv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bv[r] = crow[r][dl[t]];
+            for (int r = 0; r < 16; ++r) bv[r] = cw[(8 * (r >> 2) + 4 * h + (r & 3)) * 32 + r32];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(hv[r], bv[r], acc[t], 0, 0, 0);
         }

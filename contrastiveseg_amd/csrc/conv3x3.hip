@@ -196,6 +196,162 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(const float* __restrict
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient: dW[co][ci][ky][kx] = sum_{b,y,x} dy[b][co][y][x] * x[b][ci][y+ky-1][x+kx-1].
+// GEMM per tap: M = co, N = ci, K = pixels (4 per v_mfma_f32_16x16x4_f32). One block = 6 waves owns a 48 x 48 channel
+// block and a slice of the spatial tiles (2 rows x 64 columns each); wave w = (co tile w % 3, half w / 3 of the 27
+// (ci tile, tap) pairs) keeps 14 (13) accumulators over all its tiles. LDS per tile: x [4 rows][48 ci][pitch 66] (slot
+// 64 = right halo, slot 65 = left halo of the NEXT row, so that column -1 of a row is the element before it) and dy
+// [2 rows][48 co][pitch 66]; pitch 66 = 2 mod 32 makes both operand reads (16 channels x 2 pixel groups per half-wave)
+// conflict-free, and the tap / channel-tile offsets are ds_read immediates. Partials [split][tap][co][ci] are summed in
+// a fixed order by wrw_reduce_kernel: deterministic, no atomics. MIOpen's solver for these shapes is an NHWC
+// implicit-GEMM kernel wrapped in three layout transposes (x, dy in; dW out).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int WR = 2;                        // tile rows
+constexpr int WP = 66;                       // LDS pitch per (row, channel)
+constexpr int WX_FLOATS = (WR + 2) * 48 * WP;   // 12672
+constexpr int WD_FLOATS = WR * 48 * WP;         // 6336
+constexpr int WGUARD = 2;                    // x tile starts 2 floats in: index -1 of the first row stays in bounds
+
+template <int HALF>
+__device__ __forceinline__ void wrw_tile_mfma(const float* __restrict__ xs, const float* __restrict__ ds, int cot, int g,
+                                              int n, f32x4 (&acc)[14]) {
+    constexpr int P0 = HALF * 14;
+    constexpr int NP = HALF == 0 ? 14 : 13;
+#pragma unroll 1
+    for (int r = 0; r < WR; ++r) {
+        const float* da = ds + (r * 48 + cot * 16 + n) * WP + g;          // A: dy[co = n][pixel 4*ks + g]
+        const float* xb = xs + (r * 48 + n) * WP + g - 1;                 // B: x[ci = n][pixel 4*ks + g + kx - 1]
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+            const float a = da[4 * ks];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int pair = P0 + q, cit = pair / 9, tap = pair - 9 * cit;
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const float b = xb[4 * ks + (ky * 48 + cit * 16) * WP + kx];
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int HALF>
+__device__ __forceinline__ void wrw_store(const f32x4 (&acc)[14], float* __restrict__ pbase, int Cout, int Cin) {
+    constexpr int NP = HALF == 0 ? 14 : 13;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int pair = HALF * 14 + q, cit = pair / 9, tap = pair - 9 * cit;
+        float* dst = pbase + (size_t)tap * Cout * Cin + cit * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(size_t)r * Cin] = acc[q][r];
+    }
+}
+
+__global__ __launch_bounds__(384, 3) void conv3x3_wrw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             int B, int Cin, int Cout, int H, int W, int tiles_x,
+                                                             int tiles_y, int n_split, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem + WGUARD;
+    float* ds = smem + WGUARD + WX_FLOATS + 2;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int g = lane >> 4, n = lane & 15;
+    const int cot_w = wave % 3, half = wave / 3;
+    int blk = blockIdx.x;
+    const int split = blk % n_split; blk /= n_split;
+    const int n_cit = Cin / 48;
+    const int cib = blk % n_cit;          // 48-wide input-channel block
+    const int cob = blk / n_cit;          // 48-wide output-channel block
+    const size_t plane = (size_t)H * W;
+    const int n_tiles = B * tiles_y * tiles_x;
+
+    f32x4 acc[14];
+#pragma unroll
+    for (int q = 0; q < 14; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int t = split; t < n_tiles; t += n_split) {
+        int tt = t;
+        const int tx = tt % tiles_x; tt /= tiles_x;
+        const int ty = tt % tiles_y;
+        const int b = tt / tiles_y;
+        const int x0 = tx * 64, y0 = ty * WR;
+        const float* xg = x + ((size_t)b * Cin + cib * 48) * plane;
+        const float* dg = dy + ((size_t)b * Cout + cob * 48) * plane;
+        __syncthreads();                                   // previous tile's operand reads are done
+        // x tile: (WR+2) rows x 48 channels x 16 float4 = 3072 float4, 8 per thread
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int v = tid + 384 * u;
+            const int q = v & 15, rc = v >> 4;             // rc = r * 48 + ci
+            const int r = rc / 48, ci = rc - r * 48;
+            const int yy = y0 + r - 1, xx = x0 + 4 * q;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (yy >= 0 && yy < H && xx < W) val = *reinterpret_cast<const float4*>(xg + (size_t)ci * plane + (size_t)yy * W + xx);
+            float2* dst = reinterpret_cast<float2*>(xs + rc * WP + 4 * q);
+            dst[0] = make_float2(val.x, val.y);
+            dst[1] = make_float2(val.z, val.w);
+        }
+        {   // halos: slot 64 of row rc = x[x0 + 64], slot 65 of row rc - 1 (= index -1 of row rc) = x[x0 - 1]
+            const int rc = tid >> 1, side = tid & 1;       // 192 rows x 2 sides = 384 threads
+            const int r = rc / 48, ci = rc - r * 48;
+            const int yy = y0 + r - 1, xx = side ? x0 + 64 : x0 - 1;
+            float v = 0.f;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = xg[(size_t)ci * plane + (size_t)yy * W + xx];
+            xs[rc * WP + (side ? 64 : -1)] = v;
+        }
+        // dy tile: WR rows x 48 channels x 16 float4 = 1536 float4, 4 per thread
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int v = tid + 384 * u;
+            const int q = v & 15, rc = v >> 4;
+            const int r = rc / 48, co = rc - r * 48;
+            const int yy = y0 + r, xx = x0 + 4 * q;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (yy < H && xx < W) val = *reinterpret_cast<const float4*>(dg + (size_t)co * plane + (size_t)yy * W + xx);
+            float2* dst = reinterpret_cast<float2*>(ds + rc * WP + 4 * q);
+            dst[0] = make_float2(val.x, val.y);
+            dst[1] = make_float2(val.z, val.w);
+        }
+        __syncthreads();
+        if (half == 0) wrw_tile_mfma<0>(xs, ds, cot_w, g, n, acc);
+        else wrw_tile_mfma<1>(xs, ds, cot_w, g, n, acc);
+    }
+    // accumulator q of this wave: pair = half*14 + q -> (ci tile, tap); D[m = co][n = ci], lane: ci = n, co = 4*g + r
+    float* pbase = partial + ((size_t)split * 9 * Cout + cob * 48 + cot_w * 16 + 4 * g) * Cin + cib * 48 + n;
+    if (half == 0) wrw_store<0>(acc, pbase, Cout, Cin);
+    else wrw_store<1>(acc, pbase, Cout, Cin);
+}
+
+// dW[co][ci][tap] = sum over splits of partial[split][tap][co][ci], fixed order
+__global__ __launch_bounds__(256) void wrw_reduce_kernel(const float* __restrict__ partial, int n_split, int Cout, int Cin,
+                                                         float* __restrict__ dw) {
+    const int e = blockIdx.x * 256 + threadIdx.x;          // e = (tap * Cout + co) * Cin + ci
+    const int total = 9 * Cout * Cin;
+    if (e >= total) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int sp = 0;
+    for (; sp + 3 < n_split; sp += 4) {
+        s0 += partial[(size_t)sp * total + e];
+        s1 += partial[(size_t)(sp + 1) * total + e];
+        s2 += partial[(size_t)(sp + 2) * total + e];
+        s3 += partial[(size_t)(sp + 3) * total + e];
+    }
+    for (; sp < n_split; ++sp) s0 += partial[(size_t)sp * total + e];
+    const int ci = e % Cin, rest = e / Cin;
+    const int co = rest % Cout, tap = rest / Cout;
+    dw[((size_t)co * Cin + ci) * 9 + tap] = (s0 + s1) + (s2 + s3);
+}
+
+int wrw_splits(int B, int Cin, int Cout, int H, int W) {
+    const int tiles = B * ((H + WR - 1) / WR) * ((W + 63) / 64);
+    const int blocks_per_split = (Cin / 48) * (Cout / 48);
+    int n = 512 / blocks_per_split;              // ~2 blocks per CU in total
+    if (n < 1) n = 1;
+    if (n > tiles) n = tiles;
+    return n;
+}
+
 }  // namespace
 
 extern "C" size_t cseg_conv3x3_packed_floats(int Cin, int Cout) {
@@ -237,5 +393,40 @@ extern "C" int cseg_conv3x3_fwd(const float* x, const float* wp, int B, int Cin,
         hipLaunchKernelGGL(conv3x3_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, x, wp, Cin, Cout, H, W, tiles_x,
                            tiles_y, y);
     CSEG_CHECK_LAUNCH("conv3x3_kernel");
+    return 1;
+}
+
+extern "C" size_t cseg_conv3x3_wrw_ws_floats(int B, int Cin, int Cout, int H, int W) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || Cin % 48 || Cout % 48) return 0;
+    return (size_t)wrw_splits(B, Cin, Cout, H, W) * 9 * Cin * Cout;
+}
+
+extern "C" int cseg_conv3x3_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, float* ws,
+                                float* dw, cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CSEG_REQUIRE(x && dy && ws && dw, "conv3x3_wrw: null pointer");
+    CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 48 == 0 && Cout % 48 == 0,
+                 "conv3x3_wrw: unsupported shape B=%d Cin=%d Cout=%d %dx%d", B, Cin, Cout, H, W);
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && W % 4 == 0,
+                 "conv3x3_wrw: tensors must be 16-byte aligned and W a multiple of 4");
+    const int tiles_x = (W + 63) / 64, tiles_y = (H + WR - 1) / WR;
+    const int n_split = wrw_splits(B, Cin, Cout, H, W);
+    const int blocks = n_split * (Cin / 48) * (Cout / 48);
+    const size_t lds = sizeof(float) * (WGUARD + WX_FLOATS + 2 + WD_FLOATS + 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv3x3_wrw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            cseg_set_error("conv3x3_wrw: cannot raise dynamic LDS to %zu bytes", lds);
+            return 0;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_wrw_kernel, dim3(blocks), dim3(384), lds, stream, x, dy, B, Cin, Cout, H, W, tiles_x, tiles_y,
+                       n_split, ws);
+    CSEG_CHECK_LAUNCH("conv3x3_wrw_kernel");
+    const int total = 9 * Cin * Cout;
+    hipLaunchKernelGGL(wrw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, ws, n_split, Cout, Cin, dw);
+    CSEG_CHECK_LAUNCH("wrw_reduce_kernel");
     return 1;
 }

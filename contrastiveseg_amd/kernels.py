@@ -528,9 +528,24 @@ def _conv3x3_run(x, weight, transpose_flip):
     return y
 
 
+@torch.no_grad()
+def _conv3x3_wrw(x, dy, co, ci):
+    B, _, H, W = x.shape
+    lib = _hip.lib()
+    ws = torch.empty(lib.cseg_conv3x3_wrw_ws_floats(B, ci, co, H, W), dtype=F32, device=x.device)
+    dw = torch.empty(co, ci, 3, 3, dtype=F32, device=x.device)
+    _hip.call("cseg_conv3x3_wrw", _p(x, F32, "x"), _p(dy, F32, "dy"), B, ci, co, H, W, _p(ws, F32, "ws"),
+              _p(dw, F32, "dw"), _hip.stream_ptr())
+    return dw
+
+
+# Weight gradient on the MFMA kernel only where it beats MIOpen's NHWC implicit-GEMM + 3 layout transposes
+# (tools/conv3x3_probe.py on MI355X: 48 ch 171 vs 185 us; 96 ch 140 vs 140 us; 192 ch 132 vs 123 us)
+CONV3X3_WRW_CHANNELS = (48,)
+
+
 class Conv3x3(Function):
-    """y = conv2d(x, weight, stride 1, padding 1). Forward and backward-data on the MFMA kernel; the weight gradient is
-    MIOpen's (aten.convolution_backward)."""
+    """y = conv2d(x, weight, stride 1, padding 1): forward, backward-data and the weight gradient on the MFMA kernels."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -545,8 +560,11 @@ class Conv3x3(Function):
         dx = _conv3x3_run(dy, weight, True) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
+            if weight.shape[0] == weight.shape[1] and weight.shape[0] in CONV3X3_WRW_CHANNELS:
+                dw = _conv3x3_wrw(x, dy, weight.shape[0], weight.shape[1])
+            else:
+                dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
         return dx, dw
 
 

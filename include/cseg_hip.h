@@ -220,10 +220,17 @@ int cseg_bn_bwd_apply(const float* dy, const float* x, const float* mean_invstd,
  *       cseg_conv3x3_packed_floats(conv_in, conv_out) takes the channel counts of the PACKED operator.
  *   cseg_conv3x3_fwd: y [B,Cout,H,W] = conv(x [B,Cin,H,W], wp); for backward-data call it with x = dy,
  *       Cin = forward Cout, Cout = forward Cin and the transpose_flip packing.
+ *   cseg_conv3x3_wrw: the weight gradient (MIOpen's solver for these shapes is an NHWC implicit-GEMM kernel wrapped in
+ *       three layout transposes).
  * ------------------------------------------------------------------------------------------------ */
 size_t cseg_conv3x3_packed_floats(int Cin, int Cout);
 int cseg_conv3x3_pack_weights(const float* w, int Cout, int Cin, int transpose_flip, float* wp, cseg_stream_t stream);
 int cseg_conv3x3_fwd(const float* x, const float* wp, int B, int Cin, int Cout, int H, int W, float* y,
+                     cseg_stream_t stream);
+/* weight gradient dw [Cout,Cin,3,3] = sum_{b,y,x} dy * shifted x; Cin % 48 == 0, Cout % 48 == 0, W % 4 == 0;
+ * ws: cseg_conv3x3_wrw_ws_floats(...) floats of scratch (per-split partials, summed in a fixed order: deterministic) */
+size_t cseg_conv3x3_wrw_ws_floats(int B, int Cin, int Cout, int H, int W);
+int cseg_conv3x3_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, float* ws, float* dw,
                      cseg_stream_t stream);
 
 #ifdef __cplusplus

@@ -32,11 +32,16 @@ def test_conv3x3_matches_fp64(B, Ci, Co, H, W):
     assert K.conv3x3_eligible(xd, wd)
     y = K.conv3x3(xd, wd)
     y.backward(gy.to(dev))
+    dw_mfma = K._conv3x3_wrw(xd.detach(), gy.to(dev), Co, Ci)        # the MFMA weight-gradient kernel, every shape
     torch.cuda.synchronize()
     tol = 2e-6 * np.sqrt(9 * max(Ci, Co))
     for got, ref in ((y, yr), (xd.grad, xr.grad), (wd.grad, wr.grad)):
         err = float((got.detach().cpu().double() - ref.detach()).abs().max())
         assert err <= tol * max(1.0, float(ref.detach().abs().max())), (err, float(ref.detach().abs().max()))
+    # K of the weight gradient = B*H*W pixels
+    err = float((dw_mfma.cpu().double() - wr.grad).abs().max())
+    assert err <= 2e-6 * np.sqrt(B * H * W) * max(1.0, float(wr.grad.abs().max())), err
+    assert torch.equal(dw_mfma, K._conv3x3_wrw(xd.detach(), gy.to(dev), Co, Ci)), "weight gradient not deterministic"
 
 
 def test_conv3x3_module_dispatch_and_state_dict():

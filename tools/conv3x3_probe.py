@@ -46,7 +46,7 @@ def main():
                           "dx_err": float((xd.grad.cpu().double() - xr.grad).abs().max()),
                           "dw_err": float((wd.grad.cpu().double() - wr.grad).abs().max()),
                           "scale": float(yr.abs().max())}), flush=True)
-    for (B, C, H, W) in [(8, 48, 128, 256), (8, 96, 64, 128), (8, 192, 32, 64), (8, 384, 16, 32), (1, 48, 128, 256)]:
+    for (B, C, H, W) in [(8, 48, 128, 256), (8, 96, 64, 128), (8, 192, 32, 64), (1, 48, 128, 256)]:
         x = torch.randn(B, C, H, W, device=dev, requires_grad=True)
         w = (torch.randn(C, C, 3, 3, device=dev) * 0.05).requires_grad_(True)
         y_m = F.conv2d(x, w, None, 1, 1)
@@ -59,7 +59,14 @@ def main():
              "cseg_fwd_us": round(ev(lambda: K.conv3x3(x, w)), 1),
              "miopen_bwd_data_us": round(ev(lambda: torch.autograd.grad(y_m, x, gy, retain_graph=True)), 1),
              "cseg_bwd_data_us": round(ev(lambda: torch.autograd.grad(y_k, x, gy, retain_graph=True)), 1),
-             "miopen_bwd_weight_us": round(ev(lambda: torch.autograd.grad(y_m, w, gy, retain_graph=True)), 1)}
+             "miopen_bwd_weight_us": round(ev(lambda: torch.autograd.grad(y_m, w, gy, retain_graph=True)), 1),
+             "cseg_bwd_weight_us": round(ev(lambda: K._conv3x3_wrw(x.detach(), gy, C, C)), 1)}
+        dw_m = torch.autograd.grad(y_m, w, gy, retain_graph=True)[0]
+        dw_k = K._conv3x3_wrw(x.detach(), gy, C, C)
+        r["dw_rel_diff_vs_miopen"] = float((dw_k - dw_m).abs().max() / dw_m.abs().max())
+        # pure kernel times of the two data-path kernels (autograd.grad above also runs the weight gradient)
+        r["cseg_fwd_kernel_us"] = round(ev(lambda: K._conv3x3_run(x.detach(), w.detach(), False)), 1)
+        r["cseg_bwd_data_kernel_us"] = round(ev(lambda: K._conv3x3_run(gy, w.detach(), True)), 1)
         r["cseg_fwd_TF"] = round(flops / r["cseg_fwd_us"] * 1e-6, 1)
         r["miopen_fwd_TF"] = round(flops / r["miopen_fwd_us"] * 1e-6, 1)
         print(json.dumps(r), flush=True)
