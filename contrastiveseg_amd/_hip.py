@@ -52,6 +52,7 @@ SIGNATURES = {
     "cseg_conv3x3_fwd": (_c_int, [_ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
     "cseg_conv3x3_wrw_ws_floats": (ctypes.c_size_t, [_c_int] * 5),
     "cseg_conv3x3_wrw": (_c_int, [_ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
+    "cseg_augment_batch": (_c_int, [_ptr, _ptr, _ptr, _ptr] + [_c_int] * 5 + [_c_float, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_bn_ws_floats": (ctypes.c_size_t, [_c_int, _c_int, _c_int]),
     "cseg_bn_stats": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "cseg_bn_finalize": (_c_int, [_ptr, _c_int, ctypes.c_double, _c_float, _c_float, _ptr, _ptr, _ptr, _ptr, _ptr]),

@@ -600,3 +600,28 @@ def bn_bwd(dy, x, out, mean_invstd, weight, bias, mode, training, want_dx):
               int(bool(training)), B, C, HW, _p(_bn_ws(B, C, HW, dev), F32, "ws"), _opt(g, F32, "g_masked"),
               _p(d_weight, F32, "d_weight"), _p(d_bias, F32, "d_bias"), _opt(dx, F32, "dx"), _hip.stream_ptr())
     return dx, d_weight, d_bias, g
+
+
+# ----------------------------------------------------------------------------------------------------------
+# GPU data pipeline (csrc/augment.hip); host logic: lib/datasets/tools/gpu_aug.py
+# ----------------------------------------------------------------------------------------------------------
+AUG_PARAM_INTS = 12
+
+
+@torch.no_grad()
+def augment_batch(img_u8, lab_u8, lut, params, out_hw, div_value, mean, std):
+    """img_u8 [B,Hs,Ws,3] u8, lab_u8 [B,Hs,Ws] u8 or None, lut i16 [256] or None, params i32 [B,AUG_PARAM_INTS]
+    (host tensor is uploaded) -> (img f32 [B,3,Ht,Wt], labelmap i64 [B,Ht,Wt] or None)."""
+    B, Hs, Ws, _ = img_u8.shape
+    Ht, Wt = out_hw
+    dev = img_u8.device
+    params = params.to(dev, non_blocking=True)
+    out = torch.empty(B, 3, Ht, Wt, dtype=F32, device=dev)
+    out_lab = torch.empty(B, Ht, Wt, dtype=I64, device=dev) if lab_u8 is not None else None
+    mean3 = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    std3 = (ctypes.c_float * 3)(*[float(v) for v in std])
+    U8 = torch.uint8
+    _hip.call("cseg_augment_batch", _p(img_u8, U8, "img"), _opt(lab_u8, U8, "labelmap"), _opt(lut, I16, "lut"),
+              _p(params, I32, "params"), B, Hs, Ws, Ht, Wt, float(div_value), mean3, std3, _p(out, F32, "out_img"),
+              _opt(out_lab, I64, "out_lab"), _hip.stream_ptr())
+    return out, out_lab

@@ -233,6 +233,23 @@ size_t cseg_conv3x3_wrw_ws_floats(int B, int Cin, int Cout, int H, int W);
 int cseg_conv3x3_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, float* ws, float* dw,
                      cseg_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * GPU data pipeline: random resize (cv2 INTER_CUBIC image / INTER_NEAREST label) -> random
+ * crop -> horizontal flip -> brightness shift -> ToTensor + Normalize(div, mean, std) + label look-up + ReLabel(255,-1)
+ * -> collate padding to the fixed input size, as ONE kernel over the output batch.  Replaces the per-sample CPU chain
+ * lib/datasets/tools/cv2_aug_transforms.py:143-209, 305-443, 504-603 + lib/datasets/tools/transforms.py:15-103 +
+ * lib/datasets/tools/collate.py:37-175.  The random decisions are drawn by the host in the reference's order and passed
+ * as CSEG_AUG_PARAM_INTS int32 per image:
+ *   [0] Wr [1] Hr resized size; [2] x_off [3] y_off crop origin in the resized image; [4] tw [5] th crop size;
+ *   [6] flip (0/1); [7] brightness shift (0 = skipped); [8] left_pad [9] up_pad (collate); [10..11] reserved.
+ *   img [B,Hs,Ws,3] u8 (channel order preserved), lab [B,Hs,Ws] u8 or NULL, lut [256] i16 or NULL (raw id -> train id,
+ *   255 = ignore), out_img [B,3,Ht,Wt] f32, out_lab [B,Ht,Wt] i64 (255 -> -1) or NULL.
+ * ------------------------------------------------------------------------------------------------ */
+#define CSEG_AUG_PARAM_INTS 12
+int cseg_augment_batch(const uint8_t* img, const uint8_t* lab, const int16_t* lut, const int32_t* params, int B, int Hs,
+                       int Ws, int Ht, int Wt, float div_value, const float* mean3, const float* std3, float* out_img,
+                       int64_t* out_lab, cseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,114 @@
+"""Host half of the GPU data pipeline: the random decisions of
+contrastiveseg_amd/lib/datasets/tools/gpu_aug.py against the REFERENCE'S OWN transform classes
+(lib/datasets/tools/cv2_aug_transforms.py, cv2 stubbed -- it is not installed) under the same `random.seed`: resized size,
+crop origin and size, flip and brightness shift of every sample must be identical, i.e. Python's `random` stream is
+consumed in the reference's order. Runs where /root/reference exists. The collate pads follow collate.py:108-121."""
+import random
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from oracle import ref_shim
+
+TRANS = {"trans_seq": ["random_resize", "random_crop", "random_hflip", "random_brightness"],
+         "random_brightness": {"ratio": 0.7, "shift_value": 10},
+         "random_hflip": {"ratio": 0.5, "swap_pair": []},
+         "random_resize": {"ratio": 0.9, "method": "random", "scale_range": [0.5, 2.0], "aspect_range": [0.9, 1.1]},
+         "random_crop": {"ratio": 1.0, "crop_size": [200, 120], "method": "random", "allow_outside_center": False}}
+
+
+def _configer(cls):
+    return cls(config_dict={
+        "data": {"num_classes": 19, "input_mode": "BGR", "image_tool": "cv2"},
+        "train": {"data_transformer": {"size_mode": "fix_size", "input_size": [200, 120], "align_method": "only_pad",
+                                       "pad_mode": "random"}},
+        "train_trans": TRANS, "val_trans": {"trans_seq": []},
+        "normalize": {"div_value": 255.0, "mean_value": [0.485, 0.456, 0.406], "mean": [0.485, 0.456, 0.406],
+                      "std": [0.229, 0.224, 0.225]}})
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
+def test_decisions_match_reference_transform_classes():
+    ref_shim.install()
+    cv2 = sys.modules["cv2"]
+    cv2.INTER_CUBIC, cv2.INTER_NEAREST = 2, 0
+    cv2.resize = lambda x, size, interpolation=None: np.full((size[1], size[0]) + x.shape[2:], 128, dtype=x.dtype)
+    cv2.flip = lambda x, code: x
+    import collections
+    import collections.abc
+    import importlib
+    if not hasattr(collections, "Iterable"):
+        collections.Iterable = collections.abc.Iterable      # the reference predates Python 3.10 (:519)
+    aug = importlib.import_module("lib.datasets.tools.cv2_aug_transforms")
+    from lib.utils.tools.configer import Configer as RefConfiger
+    log = []
+    orig = aug._BaseTransform._process
+
+    def spy(self, img, data_dict, skip, *args, **kw):
+        out_img, out = orig(self, img, data_dict, skip, *args, **kw)
+        log[-1].append((type(self).__name__, bool(skip), args, out_img.shape, int(out_img.reshape(-1)[0])))
+        return out_img, out
+    aug._BaseTransform._process = spy
+    try:
+        compose = aug.CV2AugCompose(_configer(RefConfiger), split="train")
+        sizes = [(256, 160), (200, 120), (333, 217), (150, 100), (512, 256)] * 6
+        random.seed(1234)
+        for (w, h) in sizes:
+            log.append([])
+            compose(np.full((h, w, 3), 128, np.uint8), labelmap=np.zeros((h, w), np.float32))
+    finally:
+        aug._BaseTransform._process = orig
+    from contrastiveseg_amd.lib.datasets.tools.gpu_aug import GPUAugCompose
+    from contrastiveseg_amd.lib.utils.tools.configer import Configer
+    mine = GPUAugCompose(_configer(Configer), split="train")
+    random.seed(1234)
+    n_flip = n_skip = 0
+    for (w, h), entries in zip(sizes, log):
+        p = mine.draw(w, h)
+        by = {e[0]: e for e in entries}
+        _, skip, args, shape, _ = by["RandomResize"]
+        Wr, Hr = (w, h) if skip else args[0]
+        assert (p.Wr, p.Hr) == (Wr, Hr)
+        n_skip += skip
+        _, skip, args, shape, _ = by["RandomCrop"]
+        assert not skip and (args[0], args[1]) == (p.y_off, p.x_off) and tuple(args[2]) == (p.tw, p.th)
+        assert shape[:2] == (p.th, p.tw)
+        assert by["RandomHFlip"][1] == (not p.flip)
+        n_flip += p.flip
+        _, skip, _, _, value = by["RandomBrightness"]
+        assert value - 128 == p.shift and (skip == (p.shift == 0) or not skip)
+    assert 0 < n_flip < len(sizes) and n_skip > 0          # both branches of the coins were exercised
+
+
+def test_collate_pads_and_unsupported_configs():
+    from contrastiveseg_amd.lib.datasets.tools.gpu_aug import GPUBatchTransform
+    from contrastiveseg_amd.lib.utils.tools.configer import Configer
+    t = GPUBatchTransform(_configer(Configer))
+    random.seed(7)
+    rows = t.plan([(150, 100), (512, 256)]).numpy()
+    for r in rows:
+        Wr, Hr, x, y, tw, th, flip, shift, left, up = r[:10]
+        assert 0 <= x and x + tw <= Wr and 0 <= y and y + th <= Hr and tw <= 200 and th <= 120
+        assert 0 <= left <= 200 - tw and 0 <= up <= 120 - th
+    bad = _configer(Configer)
+    bad.get("train_trans")["trans_seq"] = ["random_rotate"]
+    with pytest.raises(NotImplementedError):
+        GPUBatchTransform(bad)
+
+
+def test_oracle_resampling_rules():
+    """Properties of the restated cv2 rules: identity size is a copy, cubic weights sum to 1 and reproduce constants,
+    nearest picks floor(dst * scale), a 2x integer upscale of a ramp stays monotone."""
+    from oracle import aug_oracle as A
+    rs = np.random.RandomState(0)
+    img = rs.randint(0, 256, size=(9, 13, 3)).astype(np.uint8)
+    assert np.array_equal(A.resize_cubic_u8(img, (13, 9)), img)
+    const = np.full((7, 5, 3), 77, np.uint8)
+    assert np.array_equal(A.resize_cubic_u8(const, (11, 16)), np.full((16, 11, 3), 77, np.uint8))
+    lab = np.arange(6 * 4).reshape(6, 4).astype(np.uint8)
+    up = A.resize_nearest(lab, (8, 12))
+    assert up.shape == (12, 8) and np.array_equal(up[::2, ::2], lab)
+    w = A.cubic_weights(np.linspace(0, 1, 11))
+    assert np.allclose(w.sum(-1), 1.0)
