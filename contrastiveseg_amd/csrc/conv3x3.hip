@@ -63,48 +63,53 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     wp[e] = v;
 }
 
-template <int VARIANT>
+// Persistent over output tiles: block b walks tiles b, b + gridDim.x, ...; the (tile, chunk) pairs form one software
+// pipeline, so the first chunk of the next tile is already in flight while the last chunk of the current one runs and
+// the output stores of a tile overlap the MFMAs of the next (prologue / epilogue are paid once per block, not per tile).
 __global__ __launch_bounds__(256, 3) void conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                          int Cin, int Cout, int H, int W, int tiles_x, int tiles_y,
-                                                         float* __restrict__ y) {
+                                                         int n_tiles, float* __restrict__ y) {
     __shared__ __attribute__((aligned(16))) float xs[2][CHUNK_FLOATS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = lane >> 4, n = lane & 15;
-    int blk = blockIdx.x;
-    const int tx = blk % tiles_x; blk /= tiles_x;
-    const int ty = blk % tiles_y; blk /= tiles_y;
     const int n_cot = Cout / CO_T;
-    const int cot = blk % n_cot;
-    const int b = blk / n_cot;
-    const int x0 = tx * TC, y0 = ty * TR;
     const int n_chunks = Cin / CK;
     const size_t plane = (size_t)H * W;
-    const float* xb = x + (size_t)b * Cin * plane;
+
+    // tile index -> (image b, channel tile cot, tile row ty, tile column tx); x is fastest so that neighbouring blocks
+    // share halo rows in L2
+    auto decode = [&](int t, int& b, int& cot, int& y0, int& x0) {
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y; t /= tiles_y;
+        cot = t % n_cot;
+        b = t / n_cot;
+        x0 = tx * TC; y0 = ty * TR;
+    };
 
     // ---- staging assignment: 48 (channel, row) pairs per chunk; 16 float4 per pair + 2 halo scalars
-    // vector part: v = tid + 256*u, u < 3  ->  pair = v >> 4, quad = v & 15
-    // scalar part: tid < 96 -> pair = tid >> 1, side = tid & 1
     float4 pv[3];
     float ps = 0.f;
-    auto issue_loads = [&](int chunk) {
-        const float* xc = xb + (size_t)chunk * CK * plane;
+    auto issue_loads = [&](int t, int chunk) {
+        int b, cot, y0, x0;
+        decode(t, b, cot, y0, x0);
+        const float* xc = x + ((size_t)b * Cin + (size_t)chunk * CK) * plane;
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int v = tid + 256 * u;
             const int pair = v >> 4, q = v & 15;
             const int ci = pair / XROWS, r = pair - ci * XROWS;
             const int yy = y0 + r - 1, xx = x0 + 4 * q;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 tt = make_float4(0.f, 0.f, 0.f, 0.f);
             if (yy >= 0 && yy < H) {
                 const float* p = xc + (size_t)ci * plane + (size_t)yy * W + xx;
-                if (xx + 3 < W) t = *reinterpret_cast<const float4*>(p);
+                if (xx + 3 < W) tt = *reinterpret_cast<const float4*>(p);
                 else {
-                    if (xx < W) t.x = p[0];
-                    if (xx + 1 < W) t.y = p[1];
-                    if (xx + 2 < W) t.z = p[2];
+                    if (xx < W) tt.x = p[0];
+                    if (xx + 1 < W) tt.y = p[1];
+                    if (xx + 2 < W) tt.z = p[2];
                 }
             }
-            pv[u] = t;
+            pv[u] = tt;
         }
         ps = 0.f;
         if (tid < 2 * CK * XROWS) {
@@ -133,69 +138,76 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(const float* __restrict
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    issue_loads(0);
+    int t = blockIdx.x;
+    if (t >= n_tiles) return;
+    issue_loads(t, 0);
     store_lds(0);
     __syncthreads();
 
     // this lane's A-operand base: channel g of a quad, row = wave (+ky), column = 3 + n (+kx + 16*mt)
     const int a_base = (g * XROWS + wave) * LDW + 3 + n;
-    const float* wbase = wp + ((size_t)cot * n_chunks) * (KSTEPS * 3 * 64) + lane;
-
-    for (int c = 0; c < n_chunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < n_chunks) issue_loads(c + 1);
-        const float* wc = wbase + (size_t)c * (KSTEPS * 3 * 64);
-        const float* xa = &xs[buf][a_base];
-        float wr[VARIANT == 1 ? KSTEPS * 3 : 1];
-        if (VARIANT == 1) {               // all B operands of the chunk in flight before the first MFMA
+    int buf = 0;
+    while (t < n_tiles) {
+        int b, cot, y0, x0;
+        decode(t, b, cot, y0, x0);
+        const float* wbase = wp + ((size_t)cot * n_chunks) * (KSTEPS * 3 * 64) + lane;
+        const int t_next = t + gridDim.x;
+        for (int c = 0; c < n_chunks; ++c) {
+            const bool last = c + 1 == n_chunks;
+            const bool more = !last || t_next < n_tiles;
+            if (more) issue_loads(last ? t_next : t, last ? 0 : c + 1);
+            const float* wc = wbase + (size_t)c * (KSTEPS * 3 * 64);
+            const float* xa = &xs[buf][a_base];
 #pragma unroll
-            for (int i = 0; i < KSTEPS * 3; ++i) wr[i] = wc[i * 64];
-        }
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - 3 * ky;
+                for (int cq = 0; cq < 2; ++cq) {
+                    const int ks = tap * 2 + cq;
+                    const float b0 = wc[(ks * 3 + 0) * 64], b1 = wc[(ks * 3 + 1) * 64], b2 = wc[(ks * 3 + 2) * 64];
+                    const int off = (cq * 4 * XROWS + ky) * LDW + kx;
 #pragma unroll
-            for (int cq = 0; cq < 2; ++cq) {
-                const int ks = tap * 2 + cq;
-                const float b0 = VARIANT == 1 ? wr[ks * 3 + 0] : wc[(ks * 3 + 0) * 64];
-                const float b1 = VARIANT == 1 ? wr[ks * 3 + 1] : wc[(ks * 3 + 1) * 64];
-                const float b2 = VARIANT == 1 ? wr[ks * 3 + 2] : wc[(ks * 3 + 2) * 64];
-                const int off = (cq * 4 * XROWS + ky) * LDW + kx;
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const float a = xa[off + 16 * mt];
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[mt][0], 0, 0, 0);
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[mt][1], 0, 0, 0);
-                    acc[mt][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2, acc[mt][2], 0, 0, 0);
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const float a = xa[off + 16 * mt];
+                        acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[mt][0], 0, 0, 0);
+                        acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[mt][1], 0, 0, 0);
+                        acc[mt][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2, acc[mt][2], 0, 0, 0);
+                    }
                 }
             }
-        }
-        if (c + 1 < n_chunks) store_lds(buf ^ 1);
-        __syncthreads();
-    }
-
-    // accumulator layout: D[m = 4*g + r][n]: pixel column x0 + 16*mt + 4*g + r, channel cot*48 + 16*nt + n
-    const int yy = y0 + wave;
-    if (yy < H) {
+            if (last) {
+                // accumulator layout: D[m = 4*g + r][n]: pixel column x0 + 16*mt + 4*g + r, channel cot*48 + 16*nt + n
+                const int yy = y0 + wave;
+                if (yy < H) {
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) {
-            const int co = cot * CO_T + nt * 16 + n;
-            float* orow = y + (((size_t)b * Cout + co) * H + yy) * W;
+                    for (int nt = 0; nt < 3; ++nt) {
+                        const int co = cot * CO_T + nt * 16 + n;
+                        float* orow = y + (((size_t)b * Cout + co) * H + yy) * W;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int xx = x0 + 16 * mt + 4 * g;
-                const f32x4 v = acc[mt][nt];
-                if (xx + 3 < W) *reinterpret_cast<float4*>(orow + xx) = make_float4(v[0], v[1], v[2], v[3]);
-                else {
-                    if (xx < W) orow[xx] = v[0];
-                    if (xx + 1 < W) orow[xx + 1] = v[1];
-                    if (xx + 2 < W) orow[xx + 2] = v[2];
+                        for (int mt = 0; mt < 4; ++mt) {
+                            const int xx = x0 + 16 * mt + 4 * g;
+                            const f32x4 v = acc[mt][nt];
+                            if (xx + 3 < W) *reinterpret_cast<float4*>(orow + xx) = make_float4(v[0], v[1], v[2], v[3]);
+                            else {
+                                if (xx < W) orow[xx] = v[0];
+                                if (xx + 1 < W) orow[xx + 1] = v[1];
+                                if (xx + 2 < W) orow[xx + 2] = v[2];
+                            }
+                        }
+                    }
                 }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            if (more) store_lds(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
         }
+        t = t_next;
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------------------
 // Weight gradient: dW[co][ci][ky][kx] = sum_{b,y,x} dy[b][co][y][x] * x[b][ci][y+ky-1][x+kx-1].
@@ -383,15 +395,14 @@ extern "C" int cseg_conv3x3_fwd(const float* x, const float* wp, int B, int Cin,
     CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && W % 4 == 0,
                  "conv3x3: tensors must be 16-byte aligned and W a multiple of 4");
     const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
-    const long blocks = (long)B * (Cout / CO_T) * tiles_y * tiles_x;
-    CSEG_REQUIRE(blocks < 2147483647L, "conv3x3: grid too large");
-    static const int variant = getenv("CSEG_CONV3X3_VARIANT") ? atoi(getenv("CSEG_CONV3X3_VARIANT")) : 0;
-    if (variant == 1)
-        hipLaunchKernelGGL(conv3x3_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, x, wp, Cin, Cout, H, W, tiles_x,
-                           tiles_y, y);
-    else
-        hipLaunchKernelGGL(conv3x3_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, x, wp, Cin, Cout, H, W, tiles_x,
-                           tiles_y, y);
+    const long n_tiles = (long)B * (Cout / CO_T) * tiles_y * tiles_x;
+    CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3: grid too large");
+    // persistent blocks: at most `tpb` tiles each (CSEG_CONV3X3_TPB, default 2), never fewer than 512 blocks
+    static const int tpb = getenv("CSEG_CONV3X3_TPB") ? atoi(getenv("CSEG_CONV3X3_TPB")) : 2;
+    long blocks = (n_tiles + (tpb > 0 ? tpb : 1) - 1) / (tpb > 0 ? tpb : 1);
+    if (blocks < 512) blocks = n_tiles < 512 ? n_tiles : 512;
+    hipLaunchKernelGGL(conv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, wp, Cin, Cout, H, W, tiles_x,
+                       tiles_y, (int)n_tiles, y);
     CSEG_CHECK_LAUNCH("conv3x3_kernel");
     return 1;
 }

@@ -427,8 +427,20 @@ def _bn_dims(x):
     return B, C, HW
 
 
+_BN_WS = {}      # (device index, stream) -> scratch, grown on demand
+
+
 def _bn_ws(B, C, HW, device):
-    return torch.empty(max(1, _hip.lib().cseg_bn_ws_floats(B, C, HW)), dtype=F32, device=device)
+    """Reduction scratch of the BN kernels. Every kernel that writes it is followed on the SAME stream by the kernel that
+    reads it, so one buffer per (device, stream) serves all layers (saves two allocator round trips per BN call: the
+    step issues ~600 of them and is host-bound at small per-GPU batches)."""
+    need = max(1, _hip.lib().cseg_bn_ws_floats(B, C, HW))
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else (-1, 0)
+    buf = _BN_WS.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 1 << 16), dtype=F32, device=device)
+        _BN_WS[key] = buf
+    return buf
 
 
 @torch.no_grad()
@@ -591,8 +603,8 @@ def bn_bwd(dy, x, out, mean_invstd, weight, bias, mode, training, want_dx):
     """Single-rank backward (2 launches): -> (dx or None, d_weight, d_bias, g_masked or None)."""
     B, C, HW = _bn_dims(x)
     dev = x.device
-    d_weight = torch.empty(C, dtype=F32, device=dev)
-    d_bias = torch.empty(C, dtype=F32, device=dev)
+    d_wb = torch.empty(2, C, dtype=F32, device=dev)
+    d_weight, d_bias = d_wb[0], d_wb[1]
     g = torch.empty_like(x) if mode == 2 else None
     dx = torch.empty_like(x) if want_dx else None
     _hip.call("cseg_bn_bwd", _p(dy, F32, "dy"), _p(x, F32, "x"), _opt(out, F32, "out"),

@@ -11,6 +11,7 @@ What changes underneath (MI355X-first):
     on the host;
   * data: any iterable yielding {'img', 'labelmap'} dicts; by default a seeded synthetic loader resident in HBM
     (file datasets / cv2 augmentation are out of scope)."""
+import os
 import time
 import warnings
 
@@ -108,8 +109,21 @@ class Trainer(object):
         self.optimizer, self.scheduler = self.optim_scheduler.init_optimizer(params_group)
 
         if self.train_loader is None:
-            self.train_loader = SyntheticLoader(self.configer, self.module_runner.device(),
-                                                length=self.configer.get('solver', 'max_iters'))
+            data_dir = self.configer.get('data', 'data_dir') if self.configer.exists('data', 'data_dir') else None
+            if isinstance(data_dir, (list, tuple)):
+                data_dir = data_dir[0] if data_dir else None
+            if data_dir and os.path.isdir(os.path.join(data_dir, 'train', 'image')):
+                # files on disk: host decodes, the GPU augments / normalises / collates (lib/datasets/data_loader.py)
+                from contrastiveseg_amd.lib.datasets.data_loader import DataLoader
+                self.configer.update(['data', 'data_dir'], data_dir)
+                loader = DataLoader(self.configer, self.module_runner.device())
+                self.train_loader = loader.get_trainloader()
+                if self.val_loader is None and os.path.isdir(os.path.join(data_dir, 'val', 'image')) \
+                        and self.configer.exists('val', 'data_transformer'):
+                    self.val_loader = loader.get_valloader()
+            else:
+                self.train_loader = SyntheticLoader(self.configer, self.module_runner.device(),
+                                                    length=self.configer.get('solver', 'max_iters'))
         self.pixel_loss = self.module_runner.to_device(self.loss_manager.get_seg_loss())
 
         self.with_contrast = True if self.configer.exists("contrast") else False

@@ -272,6 +272,21 @@ def bn_bwd_apply(dy, x, mean_invstd, weight, bias, sums, count, mask_from_x):
     return a.reshape(shape) * ((g - k0) - k0l - xm * k1)
 
 
+# ---- GPU data pipeline (csrc/augment.hip), restated through the forward chain of oracle/aug_oracle.py -------------
+@torch.no_grad()
+def augment_batch(img_u8, lab_u8, lut, params, out_hw, div_value, mean, std):
+    from oracle import aug_oracle
+    Ht, Wt = out_hw
+    imgs, labs = [], []
+    for b in range(img_u8.shape[0]):
+        im, lb = aug_oracle.apply_chain(img_u8[b].numpy(), None if lab_u8 is None else lab_u8[b].numpy(),
+                                        params[b].numpy(), (Wt, Ht), div_value, mean, std,
+                                        None if lut is None else lut.numpy())
+        imgs.append(torch.from_numpy(im))
+        labs.append(None if lb is None else torch.from_numpy(lb))
+    return torch.stack(imgs), (None if lab_u8 is None else torch.stack(labs))
+
+
 def install(monkeypatch_or_none=None):
     """Points the product's loss / model / trainer modules at this CPU restatement. TESTS AND THE cpu_baseline LEG
     ONLY. Returns a function that restores the HIP binding."""
@@ -283,8 +298,9 @@ def install(monkeypatch_or_none=None):
     import contrastiveseg_amd.lib.models.backbones.hrnet_backbone as hb
     import contrastiveseg_amd.lib.models.nets.hrnet as nh
     import contrastiveseg_amd.lib.models.tools.fused_bn as fb
+    import contrastiveseg_amd.lib.datasets.tools.gpu_aug as ga
     import contrastiveseg_amd.segmentor.trainer_contrastive as tc
-    mods = [lc, lm, lh, nh, hb, tc, fb]
+    mods = [lc, lm, lh, nh, hb, tc, fb, ga]
     saved = [m.K for m in mods]
     for m in mods:
         if monkeypatch_or_none is not None:

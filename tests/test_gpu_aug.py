@@ -104,3 +104,10 @@ def test_gpu_batch_transform_end_to_end():
         want_img, want_lab = A.apply_chain(img[b], lab[b], rows[b], (128, 64), DIV, MEAN, STD, lut)
         assert np.array_equal(out["labelmap"][b].cpu().numpy(), want_lab)
         assert np.abs(out["img"][b].cpu().numpy() - want_img).max() <= 1.0 / DIV / min(STD) * 1.001 + 1e-6
+
+
+def test_folder_loader_feeds_the_trainer_on_gpu(tmp_path):
+    """Files -> PIL decode -> pinned upload on a side stream -> cseg_augment_batch -> Trainer (train + validation)."""
+    _dev()
+    from test_gpu_aug_host import run_folder_trainer
+    run_folder_trainer(tmp_path, cpu=False)

@@ -112,3 +112,83 @@ def test_oracle_resampling_rules():
     assert up.shape == (12, 8) and np.array_equal(up[::2, ::2], lab)
     w = A.cubic_weights(np.linspace(0, 1, 11))
     assert np.allclose(w.sum(-1), 1.0)
+
+
+def make_folder_dataset(tmp_path, ids, rs):
+    from PIL import Image
+    for split, n in (("train", 5), ("val", 2)):
+        (tmp_path / split / "image").mkdir(parents=True)
+        (tmp_path / split / "label").mkdir(parents=True)
+        for i in range(n):
+            Image.fromarray(rs.randint(0, 256, size=(96, 160, 3)).astype(np.uint8)).save(
+                str(tmp_path / split / "image" / ("f%02d.png" % i)))
+            lab = np.full((96, 160), 255, np.uint8)
+            for _ in range(8):
+                y, x = rs.randint(0, 96), rs.randint(0, 160)
+                lab[y:y + 40, x:x + 60] = ids[rs.randint(0, len(ids))]
+            Image.fromarray(lab).save(str(tmp_path / split / "label" / ("f%02d.png" % i)))
+
+
+def folder_trainer_config(tmp_path, ids, cpu):
+    import os
+    from contrastiveseg_amd.lib.utils.tools.configer import Configer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Configer(configs=os.path.join(root, "configs", "synthetic", "R_18_D_8_tiny.json"))
+    cfg.add(["network", "pretrained"], None)
+    cfg.add(["network", "resume"], None)
+    if cpu:
+        cfg.add(["gpu"], None)
+    cfg.update(["network", "bn_type"], "torchbn")
+    cfg.add(["data", "data_dir"], str(tmp_path))
+    cfg.add(["data", "label_list"], ids)
+    cfg.update(["data", "num_classes"], 5)
+    cfg.get("loss", "params").pop("ce_weight", None)
+    cfg.update(["train", "batch_size"], 2)
+    cfg.get("train", "data_transformer").update({"input_size": [96, 64], "align_method": "only_pad", "pad_mode": "random"})
+    cfg.update(["val"], {"batch_size": 2, "data_transformer": {"size_mode": "fix_size", "input_size": [160, 96],
+                                                               "align_method": "only_pad"}})
+    cfg.add(["val_trans"], {"trans_seq": []})
+    cfg.add(["train_trans"], {"trans_seq": ["random_resize", "random_crop", "random_hflip", "random_brightness"],
+                              "random_brightness": {"ratio": 1.0, "shift_value": 10},
+                              "random_hflip": {"ratio": 0.5, "swap_pair": []},
+                              "random_resize": {"ratio": 1.0, "method": "random", "scale_range": [0.75, 1.5],
+                                                "aspect_range": [0.9, 1.1]},
+                              "random_crop": {"ratio": 1.0, "crop_size": [96, 64], "method": "random",
+                                              "allow_outside_center": False}})
+    cfg.update(["contrast", "max_views"], 3)
+    cfg.update(["contrast", "warmup_iters"], 0)
+    cfg.update(["solver", "max_iters"], 2)
+    cfg.update(["solver", "test_interval"], 10 ** 9)
+    cfg.get("checkpoints")["checkpoints_root"] = str(tmp_path)      # validation saves checkpoints: keep them out of the repo
+    return cfg
+
+
+def run_folder_trainer(tmp_path, cpu):
+    import torch
+    from contrastiveseg_amd.lib.datasets.data_loader import GPUAugLoader
+    from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
+    ids = [7, 8, 11, 12, 13]
+    make_folder_dataset(tmp_path, ids, np.random.RandomState(0))
+    cfg = folder_trainer_config(tmp_path, ids, cpu)
+    random.seed(5)
+    torch.manual_seed(304)
+    tr = Trainer(cfg)
+    assert isinstance(tr.train_loader, GPUAugLoader) and len(tr.train_loader) == 2
+    assert isinstance(tr.val_loader, GPUAugLoader)
+    batch = next(iter(tr.train_loader))
+    assert batch["img"].shape == (2, 3, 64, 96) and batch["labelmap"].shape == (2, 64, 96)
+    assert int(batch["labelmap"].min()) >= -1 and int(batch["labelmap"].max()) <= 4
+    vb = next(iter(tr.val_loader))
+    assert vb["img"].shape == (2, 3, 96, 160)          # validation: no augmentation, normalise + encode only
+    tr.train()                                          # 2 SGD steps, then the final validation pass
+    assert cfg.get("iters") == 2 and 0.0 <= cfg.get("performance") <= 1.0
+    return tr
+
+
+def test_folder_loader_feeds_the_trainer_on_cpu(tmp_path, monkeypatch):
+    """Reference directory layout (default_loader.py:108-200) -> FolderSource (PIL decode) -> GPUAugLoader -> Trainer:
+    the loaders are picked up from `data.data_dir`, batches have the fixed input size and encoded labels, two SGD steps and
+    a validation pass run. Device half = oracle/cpu_port.py."""
+    from oracle import cpu_port
+    cpu_port.install(monkeypatch)
+    run_folder_trainer(tmp_path, cpu=True)
