@@ -335,24 +335,33 @@ __global__ __launch_bounds__(384, 3) void conv3x3_wrw_kernel(const float* __rest
     else wrw_store<1>(acc, pbase, Cout, Cin);
 }
 
-// dW[co][ci][tap] = sum over splits of partial[split][tap][co][ci], fixed order
+// dW[co][ci][tap] = sum over splits of partial[split][tap][co][ci], fixed order. Block = 64 consecutive outputs x 4
+// waves; wave w sums the splits = w (mod 4) with four loads in flight, the four partial sums are added in wave order.
 __global__ __launch_bounds__(256) void wrw_reduce_kernel(const float* __restrict__ partial, int n_split, int Cout, int Cin,
                                                          float* __restrict__ dw) {
-    const int e = blockIdx.x * 256 + threadIdx.x;          // e = (tap * Cout + co) * Cin + ci
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;                  // e = (tap * Cout + co) * Cin + ci
     const int total = 9 * Cout * Cin;
-    if (e >= total) return;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int sp = 0;
-    for (; sp + 3 < n_split; sp += 4) {
-        s0 += partial[(size_t)sp * total + e];
-        s1 += partial[(size_t)(sp + 1) * total + e];
-        s2 += partial[(size_t)(sp + 2) * total + e];
-        s3 += partial[(size_t)(sp + 3) * total + e];
+    if (e < total) {
+        int sp = wave;
+        for (; sp + 12 < n_split; sp += 16) {
+            s0 += partial[(size_t)sp * total + e];
+            s1 += partial[(size_t)(sp + 4) * total + e];
+            s2 += partial[(size_t)(sp + 8) * total + e];
+            s3 += partial[(size_t)(sp + 12) * total + e];
+        }
+        for (; sp < n_split; sp += 4) s0 += partial[(size_t)sp * total + e];
     }
-    for (; sp < n_split; ++sp) s0 += partial[(size_t)sp * total + e];
-    const int ci = e % Cin, rest = e / Cin;
-    const int co = rest % Cout, tap = rest / Cout;
-    dw[((size_t)co * Cin + ci) * 9 + tap] = (s0 + s1) + (s2 + s3);
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && e < total) {
+        const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        const int ci = e % Cin, rest = e / Cin;
+        const int co = rest % Cout, tap = rest / Cout;
+        dw[((size_t)co * Cin + ci) * 9 + tap] = v;
+    }
 }
 
 int wrw_splits(int B, int Cin, int Cout, int H, int W) {
@@ -437,7 +446,7 @@ extern "C" int cseg_conv3x3_wrw(const float* x, const float* dy, int B, int Cin,
                        n_split, ws);
     CSEG_CHECK_LAUNCH("conv3x3_wrw_kernel");
     const int total = 9 * Cin * Cout;
-    hipLaunchKernelGGL(wrw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, ws, n_split, Cout, Cin, dw);
+    hipLaunchKernelGGL(wrw_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, ws, n_split, Cout, Cin, dw);
     CSEG_CHECK_LAUNCH("wrw_reduce_kernel");
     return 1;
 }

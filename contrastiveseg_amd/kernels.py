@@ -552,8 +552,11 @@ def _conv3x3_wrw(x, dy, co, ci):
 
 
 # Weight gradient on the MFMA kernel only where it beats MIOpen's NHWC implicit-GEMM + 3 layout transposes
-# (tools/conv3x3_probe.py on MI355X: 48 ch 171 vs 185 us; 96 ch 140 vs 140 us; 192 ch 132 vs 123 us)
-CONV3X3_WRW_CHANNELS = (48,)
+# (tools/conv3x3_probe.py on MI355X, bs 8: 48 ch 141 vs 182 us; 96 ch 133 vs 139 us; 192 ch 132 vs 123 us)
+CONV3X3_WRW_CHANNELS = (48, 96)
+# Forward on the MFMA kernel only when there are enough 4x64 output tiles to fill the chip (bs 8: 1024 tiles, 114 vs
+# 168 us; one image: 128 tiles on 256 CUs, 35 vs 25 us -> MIOpen). Backward-data and the weight gradient win at both.
+CONV3X3_MIN_FWD_TILES = 256
 
 
 class Conv3x3(Function):
@@ -563,6 +566,10 @@ class Conv3x3(Function):
     def forward(ctx, x, weight):
         weight = weight.contiguous()
         ctx.save_for_backward(x, weight)
+        B, _, H, W = x.shape
+        n_tiles = B * (weight.shape[0] // 48) * ((H + 3) // 4) * ((W + 63) // 64)
+        if n_tiles < CONV3X3_MIN_FWD_TILES:
+            return torch.nn.functional.conv2d(x, weight, None, 1, 1)          # MIOpen (same math, fp32)
         return _conv3x3_run(x, weight, False)
 
     @staticmethod

@@ -46,7 +46,7 @@ def main():
                           "dx_err": float((xd.grad.cpu().double() - xr.grad).abs().max()),
                           "dw_err": float((wd.grad.cpu().double() - wr.grad).abs().max()),
                           "scale": float(yr.abs().max())}), flush=True)
-    for (B, C, H, W) in [(8, 48, 128, 256), (8, 96, 64, 128), (8, 192, 32, 64), (1, 48, 128, 256)]:
+    for (B, C, H, W) in [(8, 48, 128, 256), (8, 96, 64, 128), (1, 48, 128, 256)]:
         x = torch.randn(B, C, H, W, device=dev, requires_grad=True)
         w = (torch.randn(C, C, 3, 3, device=dev) * 0.05).requires_grad_(True)
         y_m = F.conv2d(x, w, None, 1, 1)
