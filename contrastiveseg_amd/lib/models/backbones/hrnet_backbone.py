@@ -11,6 +11,7 @@ to torch SyncBN with momentum 0.1 exactly as the reference factory does (:773)."
 import torch.nn as nn
 
 from contrastiveseg_amd import kernels as K
+from contrastiveseg_amd.lib.models.tools.fused_bn import bn_act_group
 from contrastiveseg_amd.lib.models.tools.module_helper import Conv3x3, ModuleHelper
 
 # width -> per-stage (modules, blocks per branch); channel list is width * (1, 2, 4, 8)[:branches]
@@ -104,10 +105,53 @@ class HighResolutionModule(nn.Module):
             fuse.append(nn.ModuleList(row))
         self.fuse_layers = nn.ModuleList(fuse) if nb > 1 else None
 
+    def _sync_active(self):
+        bn = self.branches[0][0].bn1
+        return self.training and getattr(bn, '_sync_group', lambda: None)() is not None
+
+    def _branches_lockstep(self, x):
+        """The branches are independent residual chains of equal length: run them block by block side by side, so that
+        the BN sites of one depth share ONE statistics all-reduce per direction (fused_bn.bn_act_group)."""
+        x = list(x)
+        for k in range(len(self.branches[0])):
+            blocks = [branch[k] for branch in self.branches]
+            c1 = [blk.conv1(xi) for blk, xi in zip(blocks, x)]
+            y1 = bn_act_group([(blk.bn1, c, None, True) for blk, c in zip(blocks, c1)])
+            c2 = [blk.conv2(y) for blk, y in zip(blocks, y1)]
+            res = [xi if blk.downsample is None else blk.downsample(xi) for blk, xi in zip(blocks, x)]
+            x = bn_act_group([(blk.bn2, c, r, True) for blk, c, r in zip(blocks, c2, res)])
+        return x
+
+    def _exchange_lockstep(self, x):
+        """All (output i <- input j) conv+BN paths of the exchange unit, advanced one conv+BN at a time across paths."""
+        chains = {}                                   # (i, j) -> list of Sequential(conv, bn)
+        for i, row in enumerate(self.fuse_layers):
+            for j in range(self.num_branches):
+                if j == i:
+                    continue
+                chains[(i, j)] = [row[j]] if j > i else list(row[j])
+        cur = {key: x[key[1]] for key in chains}
+        for depth in range(max(len(c) for c in chains.values())):
+            keys = [key for key, c in chains.items() if len(c) > depth]
+            convs = [chains[key][depth][0](cur[key]) for key in keys]
+            outs = bn_act_group([(chains[key][depth][1], c, None, None) for key, c in zip(keys, convs)])
+            for key, o in zip(keys, outs):
+                cur[key] = o
+        outs = []
+        for i in range(len(self.fuse_layers)):
+            same = [x[j] if j == i else cur[(i, j)] for j in range(i + 1)]
+            low = [cur[(i, j)] for j in range(i + 1, self.num_branches)]
+            outs.append(K.fuse_sum_relu(same, low))
+        return outs
+
     def forward(self, x):
-        x = [branch(xi) for branch, xi in zip(self.branches, x)]
+        sync = self._sync_active()
+        x = self._branches_lockstep(x) if (sync and self.num_branches > 1) else \
+            [branch(xi) for branch, xi in zip(self.branches, x)]
         if self.num_branches == 1:
             return x
+        if sync:
+            return self._exchange_lockstep(x)
         outs = []
         for i, row in enumerate(self.fuse_layers):
             same = [x[j] if j == i else row[j](x[j]) for j in range(i + 1)]     # finer branches arrive strided

@@ -76,6 +76,89 @@ class _BNAct(torch.autograd.Function):
                 d_res if ctx.needs_input_grad[3] else None, None, None, None, None, None, None, None, None)
 
 
+class _BNActGroup(torch.autograd.Function):
+    """Several independent SyncBN(+residual)(+ReLU) sites evaluated together so that their statistics travel in ONE
+    all-reduce per direction: the moments [sum C_i, 2] (fp64) of all sites are concatenated forward, the gradient sums
+    backward. Used for BN sites that sit at the same depth of parallel HRNet branches / exchange paths (they have no data
+    dependence on each other), which cuts the SyncBN collectives of an HRNet-W48 step from 2 x 307 to about 2 x 130.
+    Training mode with a process group only; the single-rank path keeps the two-launch per-site kernels."""
+
+    @staticmethod
+    def forward(ctx, meta, sync_group, *tensors):
+        # meta: per site (running_mean, running_var, num_batches_tracked, relu, momentum, eps)
+        # tensors: per site x, weight, bias, residual (None allowed for weight / bias / residual)
+        n = len(meta)
+        world = torch.distributed.get_world_size(sync_group)
+        xs, moments = [], []
+        for i in range(n):
+            x = tensors[4 * i].contiguous()
+            xs.append(x)
+            moments.append(K.bn_stats(x))
+        packed = _all_reduce(torch.cat(moments, dim=0), sync_group)
+        outs, saved, counts = [], [], []
+        off = 0
+        for i in range(n):
+            rm, rv, nbt, relu, momentum, eps = meta[i]
+            x, w, b, r = xs[i], tensors[4 * i + 1], tensors[4 * i + 2], tensors[4 * i + 3]
+            C = x.shape[1]
+            count = float((x.numel() // C) * world)
+            mi = K.bn_finalize(packed[off:off + C].contiguous(), count, eps, momentum, rm, rv, nbt)
+            off += C
+            r = None if r is None else r.contiguous()
+            y = K.bn_apply(x, mi, w, b, r, relu)
+            outs.append(y)
+            counts.append(count)
+            saved += [x, mi, w, b, y if (relu and r is not None) else None]
+        ctx.meta = [(m[3], tensors[4 * i + 3] is not None) for i, m in enumerate(meta)]
+        ctx.counts, ctx.sync_group = counts, sync_group
+        ctx.save_for_backward(*saved)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        saved = ctx.saved_tensors
+        n = len(ctx.meta)
+        red = []
+        for i in range(n):
+            x, mi, w, b, out = saved[5 * i:5 * i + 5]
+            relu, has_res = ctx.meta[i]
+            mode = 0 if not relu else (2 if has_res else 1)
+            dy = dys[i].contiguous()
+            sums, d_w, d_b, g = K.bn_bwd_reduce(dy, x, out, mi, w, b, mode)
+            red.append((dy, mode, sums, d_w, d_b, g))
+        packed = _all_reduce(torch.cat([r[2] for r in red], dim=0), ctx.sync_group)
+        grads = [None, None]
+        off = 0
+        for i in range(n):
+            x, mi, w, b, out = saved[5 * i:5 * i + 5]
+            dy, mode, _, d_w, d_b, g = red[i]
+            C = x.shape[1]
+            dx = None
+            if ctx.needs_input_grad[2 + 4 * i]:
+                dx = K.bn_bwd_apply(g if mode == 2 else dy, x, mi, w, b, packed[off:off + C].contiguous(),
+                                    ctx.counts[i], mode == 1)
+            off += C
+            d_res = (g if mode == 2 else dy) if (ctx.meta[i][1] and ctx.needs_input_grad[2 + 4 * i + 3]) else None
+            grads += [dx, d_w if w is not None else None, d_b if b is not None else None, d_res]
+        return tuple(grads)
+
+
+def bn_act_group(sites):
+    """sites: list of (bn module, x, residual or None, relu or None). Returns the list of outputs. Sites whose module is
+    not in synchronised training mode (single rank, eval) are evaluated one by one through the module itself."""
+    groups = [bn._sync_group() if (bn.training and isinstance(bn, FusedSyncBatchNorm)) else None for bn, _, _, _ in sites]
+    if len(sites) < 2 or any(g is None for g in groups) or any(g is not groups[0] for g in groups):
+        return [bn(x, residual=r, relu=relu) for bn, x, r, relu in sites]
+    meta, tensors = [], []
+    for bn, x, r, relu in sites:
+        if x.dim() != 4 or bn.momentum is None or not bn.track_running_stats:
+            return [b_(x_, residual=r_, relu=l_) for b_, x_, r_, l_ in sites]
+        relu = (bn.act == 'relu') if relu is None else bool(relu)
+        meta.append((bn.running_mean, bn.running_var, bn.num_batches_tracked, relu, float(bn.momentum), float(bn.eps)))
+        tensors += [x, bn.weight, bn.bias, r]
+    return list(_BNActGroup.apply(meta, groups[0], *tensors))
+
+
 class _FusedMixin(object):
     """forward(x, residual=None, relu=None): relu=None -> the module's own default (`self.act == 'relu'`)."""
     act = None

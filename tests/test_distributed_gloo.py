@@ -320,3 +320,80 @@ def test_fused_syncbn_host_logic_two_ranks_equal_single_process():
     assert np.abs(np.concatenate([res[0][2], res[1][2]]) - xd.grad.numpy()).max() <= 2e-6
     assert np.abs(res[0][3] + res[1][3] - bn.weight.grad.numpy()).max() <= 1e-4
     assert np.abs(res[0][4] - bn.running_var.numpy()).max() <= 1e-6
+
+
+def _hrnet_sync_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import cpu_port
+    cpu_port.install(None)
+    from contrastiveseg_amd.lib.models.backbones.hrnet_backbone import HighResolutionNet
+    calls = {"n": 0}
+    real = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls["n"] += 1
+        return real(t, *a, **k)
+    dist.all_reduce = counting
+    torch.manual_seed(304)
+    net = HighResolutionNet(18, bn_type="torchsyncbn").train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 3, 64, 64, generator=g)
+    xs = x[rank * 2:rank * 2 + 2].clone().requires_grad_(True)
+    outs = net(xs)
+    n_fwd = calls["n"]
+    sum(o.square().mean() for o in outs).backward()
+    n_bwd = calls["n"] - n_fwd
+    grads = {k: p.grad.numpy() for k, p in net.named_parameters() if k in (
+        "conv1.weight", "stage3.1.branches.2.3.bn2.weight", "stage4.2.fuse_layers.0.3.0.weight",
+        "stage4.0.fuse_layers.3.0.1.0.weight")}
+    n_bn = sum(1 for m in net.modules() if isinstance(m, torch.nn.SyncBatchNorm))
+    q.put((rank, [o.detach().numpy() for o in outs], xs.grad.numpy(), grads, n_fwd, n_bwd, n_bn,
+           net.stage4[2].branches[3][3].bn2.running_var.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hrnet_grouped_syncbn_equals_single_process_and_batches_the_exchanges():
+    """HRNet encoder, 2 ranks x 2 images, FusedSyncBatchNorm with the exchanges of parallel branches / exchange paths
+    grouped (hrnet_backbone.HighResolutionModule lockstep path): outputs, input gradients and summed parameter gradients
+    equal one process on the 4 images with plain batch statistics; the number of all-reduces per direction is well
+    below the number of BN layers (one per BN without grouping)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hrnet_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle import cpu_port
+    restore = cpu_port.install(None)
+    try:
+        from contrastiveseg_amd.lib.models.backbones.hrnet_backbone import HighResolutionNet
+        torch.manual_seed(304)
+        net = HighResolutionNet(18, bn_type="torchbn").train()
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(4, 3, 64, 64, generator=g).requires_grad_(True)
+        outs = net(x)
+        # each rank took the mean over ITS outputs: the sum of the two rank losses = 2 x the global-batch mean
+        (2.0 * sum(o.square().mean() for o in outs)).backward()
+        named = dict(net.named_parameters())
+    finally:
+        restore()
+    n_fwd, n_bwd, n_bn = res[0][4], res[0][5], res[0][6]
+    assert n_fwd == n_bwd and n_fwd < 0.5 * n_bn, (n_fwd, n_bwd, n_bn)
+    for b in range(len(outs)):
+        got = np.concatenate([res[0][1][b], res[1][1][b]])
+        assert np.abs(got - outs[b].detach().numpy()).max() <= 2e-4 * max(1.0, float(outs[b].abs().max()))
+    gx = np.concatenate([res[0][2], res[1][2]])
+    assert np.abs(gx - x.grad.numpy()).max() <= 2e-3 * float(x.grad.abs().max())
+    for k in res[0][3]:
+        tot = res[0][3][k] + res[1][3][k]
+        ref = named[k].grad.numpy()
+        assert np.abs(tot - ref).max() <= 5e-3 * np.abs(ref).max() + 1e-7, (k, np.abs(tot - ref).max(), np.abs(ref).max())
+    assert np.abs(res[0][7] - net.stage4[2].branches[3][3].bn2.running_var.detach().numpy()).max() <= 1e-5
