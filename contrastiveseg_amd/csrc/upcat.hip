@@ -13,42 +13,71 @@ struct UpcatMaps {
     int n;
 };
 
-// grid = (ceil(h0*w0/4 / 256), Ctot, B): the source map is block-uniform.
-__global__ __launch_bounds__(256) void upcat_fwd_kernel(UpcatMaps m, int Ctot, float* __restrict__ out) {
+// grid = (column tiles x row tiles, Ctot, B): the source map is block-uniform. A block covers 16 rows x 256 columns:
+// thread = (column quad, row group) and walks 4 consecutive rows, so the horizontal taps (float->int conversions, edge
+// clamps, weights) are computed once per thread and reused for every row; the output is written with 16-byte
+// non-temporal stores (755 MB at bs8: it does not fit any cache and is read back only by the head convolution).
+constexpr int UP_ROWS = 4;
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void store_nt4(float* p, float a, float b, float c, float d) {
+    __builtin_nontemporal_store((v4f){a, b, c, d}, reinterpret_cast<v4f*>(p));
+}
+
+__global__ __launch_bounds__(256) void upcat_fwd_kernel(UpcatMaps m, int Ctot, int tiles_x, float* __restrict__ out) {
     const int c = blockIdx.y, b = blockIdx.z;
     const int h0 = m.h[0], w0 = m.w[0];
-    const int w4 = w0 >> 2;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= h0 * w4) return;
-    const int y = e / w4, x = (e - y * w4) * 4;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x = (tx * 64 + (threadIdx.x & 63)) * 4;
+    const int yb = ty * (4 * UP_ROWS) + (threadIdx.x >> 6) * UP_ROWS;
+    if (x >= w0 || yb >= h0) return;
     int mi = 0;
 #pragma unroll
     for (int k = 1; k < 4; ++k) if (k < m.n && c >= m.coff[k]) mi = k;
     const int cm = c - m.coff[mi];
-    float4 v;
+    float* orow = out + (((size_t)b * Ctot + c) * h0 + yb) * w0 + x;
     if (mi == 0) {
-        v = *reinterpret_cast<const float4*>(m.x[0] + (((size_t)b * m.C[0] + cm) * h0 + y) * w0 + x);
-    } else {
-        const int hs = m.h[mi], ws = m.w[mi];
-        const float sy = ac_scale(hs, h0), sx = ac_scale(ws, w0);
-        const float fy = sy * (float)y;
-        const int y0 = (int)fy;
-        const int y1 = y0 + (y0 < hs - 1 ? 1 : 0);
-        const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
-        const float* r0 = m.x[mi] + (((size_t)b * m.C[mi] + cm) * hs + y0) * ws;
-        const float* r1 = m.x[mi] + (((size_t)b * m.C[mi] + cm) * hs + y1) * ws;
-        float o[4];
+        const float* irow = m.x[0] + (((size_t)b * m.C[0] + cm) * h0 + yb) * w0 + x;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float fx = sx * (float)(x + t);
-            const int x0 = (int)fx;
-            const int x1 = x0 + (x0 < ws - 1 ? 1 : 0);
-            const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
-            o[t] = ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+        for (int r = 0; r < UP_ROWS; ++r) {
+            if (yb + r < h0) {
+                const float4 v = *reinterpret_cast<const float4*>(irow + (size_t)r * w0);
+                store_nt4(orow + (size_t)r * w0, v.x, v.y, v.z, v.w);
+            }
         }
-        v = make_float4(o[0], o[1], o[2], o[3]);
+        return;
     }
-    *reinterpret_cast<float4*>(out + (((size_t)b * Ctot + c) * h0 + y) * w0 + x) = v;
+    const int hs = m.h[mi], ws = m.w[mi];
+    const float sy = ac_scale(hs, h0), sx = ac_scale(ws, w0);
+    int x0[4], x1[4];
+    float lx1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float fx = sx * (float)(x + t);
+        x0[t] = (int)fx;
+        x1[t] = x0[t] + (x0[t] < ws - 1 ? 1 : 0);
+        lx1[t] = fx - (float)x0[t];
+    }
+    const float* plane = m.x[mi] + ((size_t)b * m.C[mi] + cm) * hs * ws;
+#pragma unroll
+    for (int r = 0; r < UP_ROWS; ++r) {
+        const int y = yb + r;
+        if (y < h0) {
+            const float fy = sy * (float)y;
+            const int y0 = (int)fy;
+            const int y1 = y0 + (y0 < hs - 1 ? 1 : 0);
+            const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+            const float* r0 = plane + (size_t)y0 * ws;
+            const float* r1 = plane + (size_t)y1 * ws;
+            float o[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float lx0 = 1.f - lx1[t];
+                o[t] = ly0 * (lx0 * r0[x0[t]] + lx1[t] * r0[x1[t]]) + ly1 * (lx0 * r1[x0[t]] + lx1[t] * r1[x1[t]]);
+            }
+            store_nt4(orow + (size_t)r * w0, o[0], o[1], o[2], o[3]);
+        }
+    }
 }
 
 // scalar fallback when w0 % 4 != 0
@@ -111,8 +140,9 @@ extern "C" int cseg_upcat_fwd(const float* const* xs, const int* C, const int* h
     const int Ctot = m.coff[n_maps], h0 = hs[0], w0 = ws[0];
     CSEG_REQUIRE(Ctot <= 65535 && B <= 65535, "upcat: grid too large");
     if (w0 % 4 == 0) {
-        dim3 grid((h0 * (w0 / 4) + 255) / 256, Ctot, B);
-        hipLaunchKernelGGL(upcat_fwd_kernel, grid, dim3(256), 0, stream, m, Ctot, out);
+        const int tiles_x = (w0 / 4 + 63) / 64, tiles_y = (h0 + 4 * UP_ROWS - 1) / (4 * UP_ROWS);
+        dim3 grid(tiles_x * tiles_y, Ctot, B);
+        hipLaunchKernelGGL(upcat_fwd_kernel, grid, dim3(256), 0, stream, m, Ctot, tiles_x, out);
     } else {
         dim3 grid((h0 * w0 + 255) / 256, Ctot, B);
         hipLaunchKernelGGL(upcat_fwd_scalar_kernel, grid, dim3(256), 0, stream, m, Ctot, out);
