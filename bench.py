@@ -109,33 +109,14 @@ def build_trainer(args, world, device, global_batch):
 
 
 def time_kernel(fn, iters=20, warm=5):
-    """HIP-event time per call in us. The calls are captured into a hipGraph (torch.cuda.CUDAGraph) and replayed, so
-    that the figure is device time of the op's kernels -- several of these ops are a few tens of microseconds long and an
-    eager Python loop would be measuring the host's launch rate instead. Falls back to the eager loop if capture is not
-    possible for an op."""
+    """HIP-event time per call in us over an eager loop. Ops of a few tens of microseconds are bounded by the host's
+    launch rate here (Python + ctypes + allocator, 20-50 us per call); their device time is in the rocprofv3 kernel
+    statistics under profiles/ (hipGraph replay of these loops was tried and crashed inside the autograd engine on
+    ROCm 7.2, so the loop stays eager)."""
     for _ in range(warm):
         fn()
-    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    try:
-        graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            fn()                                   # allocator warm-up on the capture stream
-        torch.cuda.current_stream().wait_stream(side)
-        with torch.cuda.graph(graph):
-            for _ in range(iters):
-                fn()
-        graph.replay()
-        torch.cuda.synchronize()
-        e0.record()
-        graph.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / iters      # us
-    except Exception:
-        torch.cuda.synchronize()
+    torch.cuda.synchronize()
     e0.record()
     for _ in range(iters):
         fn()
