@@ -15,10 +15,8 @@
 //             down the label rows of its band; per row each lane evaluates g_k = coef * (softmax_k - onehot_k) for
 //             its cell, splits it into the part that lands on column c and the part for column c+1 (handed to the
 //             right neighbour with one DPP shift; one LDS word per wave boundary), and accumulates the two coarse rows
-//             the label row touches in registers (a sliding pair: the march is monotone). The labels and the
-//             log-sum-exp of a label row are loaded coalesced one row ahead and staged in LDS (double buffered; a cell's
-//             4-5 pixels would otherwise be 40-byte-stride loads). Every exp is evaluated once per (pixel, class), all
-//             lanes work on all classes of the group, no atomics: run-to-run deterministic.
+//             the label row touches in registers (a sliding pair: the march is monotone). Every exp is evaluated once
+//             per (pixel, class), all lanes work on all classes of the group, no atomics: run-to-run deterministic.
 // HBM-bound (algorithmic bytes: seg + target [+ lse] forward; seg + target + lse + d_seg backward); no MFMA.
 #include "cseg_common.h"
 
@@ -159,13 +157,9 @@ __global__ __launch_bounds__(1024) void ce_finish_kernel(const float* __restrict
 template <int PX, int KG>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ seg, const int64_t* __restrict__ target,
                                                      const float* __restrict__ weight, const float* __restrict__ lse,
-                                                     CeDims d, int n_groups, int n_bands, int halo, int px_cap,
+                                                     CeDims d, int n_groups, int n_bands, int halo,
                                                      const float* __restrict__ out, const float* __restrict__ d_loss,
                                                      float* __restrict__ d_seg) {
-    // label-row staging, double buffered: [2][px_cap] log-sum-exp (+inf = inactive) then [2][px_cap] class id (int16)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* ls_s = smem;
-    short* t_s = reinterpret_cast<short*>(smem + 2 * px_cap);
     __shared__ float xchg[2][4][KG];          // [row parity][wave][class]: hB of the wave's last lane
     int blk = blockIdx.x;
     const int grp = blk % n_groups; blk /= n_groups;
@@ -173,9 +167,8 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ s
     const int n_cb = (d.w + (256 - halo) - 1) / (256 - halo);
     const int cb = blk % n_cb;
     const int b = blk / n_cb;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
-    const int c_first = cb * (256 - halo) - halo;                 // cell of lane 0 (may be -1)
-    const int c = c_first + tid;                                  // this lane's cell / output column
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = cb * (256 - halo) + tid - halo;                 // this lane's cell / output column
     const bool cell_ok = c >= 0 && c < d.w;
     const bool writes = cell_ok && tid >= halo;                   // halo lane only feeds its right neighbour
     const int k0 = grp * KG;
@@ -189,10 +182,6 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ s
     float lx1[PX];
 #pragma unroll
     for (int p = 0; p < PX; ++p) lx1[p] = p < n ? d.sx * (float)(Xs + p) - (float)c : 0.f;
-    // label pixels covered by the cells of this block: [Xb0, Xb0 + n_px)
-    const int Xb0 = first_with_tap(d.sx, d.W, max(c_first, 0));
-    const int n_px = min(first_with_tap(d.sx, d.W, min(c_first + nthr, d.w)) - Xb0, px_cap);
-    const int cell_off = Xs - Xb0;
 
     // label rows whose upper tap lies in [ys0 - 1, ys_end - 1]
     const int Y_lo = first_with_tap(d.sy, d.H, ys0 - 1), Y_hi = first_with_tap(d.sy, d.H, ys_end);
@@ -209,37 +198,8 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ s
                 if (k0 + j < d.K) d_seg[(((size_t)b * d.K + k0 + j) * d.h + row) * d.w + c] = acc_lo[j];
         }
     };
-    // coalesced loads of one label row (consecutive lanes = consecutive pixels), issued one row ahead of their use
-    float rl[PX];
-    int rt[PX];
-    auto stage_load = [&](int Y) {
-        const size_t row = ((size_t)b * d.H + Y) * d.W + Xb0;
-#pragma unroll
-        for (int p = 0; p < PX; ++p) {
-            const int i = tid + p * nthr;
-            rl[p] = INFINITY; rt[p] = -1;
-            if (i < n_px) {
-                const int64_t t64 = target[row + i];
-                if (t64 != (int64_t)d.ignore_label && t64 >= 0 && t64 < d.K) { rt[p] = (int)t64; rl[p] = lse[row + i]; }
-            }
-        }
-    };
-    auto stage_store = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < PX; ++p) {
-            const int i = tid + p * nthr;
-            if (i < n_px) { ls_s[buf * px_cap + i] = rl[p]; t_s[buf * px_cap + i] = (short)rt[p]; }
-        }
-    };
-    if (Y_lo < Y_hi) {
-        stage_load(Y_lo);
-        stage_store(0);
-    }
-    __syncthreads();
 
     for (int Y = Y_lo; Y < Y_hi; ++Y) {
-        const int buf = (Y - Y_lo) & 1;
-        if (Y + 1 < Y_hi) stage_load(Y + 1);
         int y0, y1;
         float ly1;
         tap(d.sy, d.h, Y, y0, y1, ly1);
@@ -256,9 +216,13 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ s
         for (int p = 0; p < PX; ++p) {
             coef[p] = 0.f; ls[p] = INFINITY; t[p] = -1;      // exp(v - inf) = 0: inactive pixels contribute exactly 0
             if (p < n) {
-                t[p] = (int)t_s[buf * px_cap + cell_off + p];
-                ls[p] = ls_s[buf * px_cap + cell_off + p];
-                if (t[p] >= 0) coef[p] = (weight ? weight[t[p]] : 1.f) * gscale;
+                const size_t o = ((size_t)b * d.H + Y) * d.W + Xs + p;
+                const int64_t t64 = target[o];
+                if (t64 != (int64_t)d.ignore_label && t64 >= 0 && t64 < d.K) {
+                    t[p] = (int)t64;
+                    coef[p] = (weight ? weight[t[p]] : 1.f) * gscale;
+                    ls[p] = lse[o];
+                }
             }
         }
         float hA[KG], hB[KG];
@@ -291,7 +255,6 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ s
 #pragma unroll
             for (int j = 0; j < KG; ++j) xchg[par][wave][j] = hB[j];
         }
-        if (Y + 1 < Y_hi) stage_store(buf ^ 1);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < KG; ++j) {
@@ -409,20 +372,8 @@ extern "C" int cseg_upsample_ce_bwd(const float* seg, const int64_t* target, con
     const int threads = n_cb > 1 ? 256 : ((w + 63) / 64) * 64;
     const long n_blocks = (long)B * n_cb * n_bands * n_groups;
     CSEG_REQUIRE(n_blocks < 2147483647L, "upsample_ce_bwd: grid too large");
-    // label pixels one column block covers (staged per label row in LDS), maximum over the column blocks
-    int px_cap = 1;
-    for (int cbi = 0; cbi < n_cb; ++cbi) {
-        const int c_first = cbi * (256 - halo) - halo;
-        const int lo = first_with_tap(d.sx, W, c_first > 0 ? c_first : 0);
-        const int hi = first_with_tap(d.sx, W, c_first + threads < w ? c_first + threads : w);
-        if (hi - lo > px_cap) px_cap = hi - lo;
-    }
-    px_cap = (px_cap + 3) & ~3;
-    CSEG_REQUIRE(px_cap <= threads * px, "upsample_ce_bwd: internal staging bound violated (%d > %d)", px_cap, threads * px);
-    const size_t lds = (size_t)px_cap * 2 * (sizeof(float) + sizeof(short));
-    CSEG_REQUIRE(lds <= 60 * 1024, "upsample_ce_bwd: label row of %d pixels needs %zu B of LDS", px_cap, lds);
-#define LAUNCH(P, G) hipLaunchKernelGGL((ce_bwd_kernel<P, G>), dim3((unsigned)n_blocks), dim3(threads), lds, stream, seg, target, \
-                                        weight, lse, d, n_groups, n_bands, halo, px_cap, out, d_loss, d_seg)
+#define LAUNCH(P, G) hipLaunchKernelGGL((ce_bwd_kernel<P, G>), dim3((unsigned)n_blocks), dim3(threads), 0, stream, seg, target, \
+                                        weight, lse, d, n_groups, n_bands, halo, out, d_loss, d_seg)
 #define BY_KG(P)                                   \
     switch (kg) {                                  \
         case 8: LAUNCH(P, 8); break;               \
