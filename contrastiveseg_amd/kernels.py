@@ -19,6 +19,13 @@ def _null():
     return ctypes.c_void_p(None)
 
 
+def _pf(t):
+    """Raw pointer of a tensor this module has just allocated itself (device, dtype and layout known by construction):
+    skips the four checks of _hip.dev(). The step issues ~1000 calls into the BN / convolution entry points and is
+    host-launch-bound at small per-GPU batches; user-facing tensors (x, dy, residual, weights) are still validated."""
+    return ctypes.c_void_p(t.data_ptr())
+
+
 # ----------------------------------------------------------------------------------------------------------
 # anchor mining
 # ----------------------------------------------------------------------------------------------------------
@@ -532,11 +539,10 @@ def _conv3x3_run(x, weight, transpose_flip):
     B, _, H, W = x.shape
     lib = _hip.lib()
     wp = torch.empty(lib.cseg_conv3x3_packed_floats(conv_in, conv_out), dtype=F32, device=x.device)
-    _hip.call("cseg_conv3x3_pack_weights", _p(weight, F32, "weight"), co, ci, int(transpose_flip), _p(wp, F32, "wp"),
-              _hip.stream_ptr())
+    sp = _hip.stream_ptr()
+    _hip.call("cseg_conv3x3_pack_weights", _p(weight, F32, "weight"), co, ci, int(transpose_flip), _pf(wp), sp)
     y = torch.empty(B, conv_out, H, W, dtype=F32, device=x.device)
-    _hip.call("cseg_conv3x3_fwd", _p(x, F32, "x"), _p(wp, F32, "wp"), B, conv_in, conv_out, H, W, _p(y, F32, "y"),
-              _hip.stream_ptr())
+    _hip.call("cseg_conv3x3_fwd", _p(x, F32, "x"), _pf(wp), B, conv_in, conv_out, H, W, _pf(y), sp)
     return y
 
 
@@ -546,8 +552,8 @@ def _conv3x3_wrw(x, dy, co, ci):
     lib = _hip.lib()
     ws = torch.empty(lib.cseg_conv3x3_wrw_ws_floats(B, ci, co, H, W), dtype=F32, device=x.device)
     dw = torch.empty(co, ci, 3, 3, dtype=F32, device=x.device)
-    _hip.call("cseg_conv3x3_wrw", _p(x, F32, "x"), _p(dy, F32, "dy"), B, ci, co, H, W, _p(ws, F32, "ws"),
-              _p(dw, F32, "dw"), _hip.stream_ptr())
+    _hip.call("cseg_conv3x3_wrw", _p(x, F32, "x"), _p(dy, F32, "dy"), B, ci, co, H, W, _pf(ws), _pf(dw),
+              _hip.stream_ptr())
     return dw
 
 
@@ -598,10 +604,9 @@ def bn_fwd(x, weight, bias, residual, relu, eps, momentum, running_mean, running
     mi = torch.empty(C, 2, dtype=F32, device=x.device)
     y = torch.empty_like(x)
     _hip.call("cseg_bn_fwd", _p(x, F32, "x"), _opt(residual, F32, "residual"), _opt(weight, F32, "weight"),
-              _opt(bias, F32, "bias"), int(bool(relu)), B, C, HW, _p(_bn_ws(B, C, HW, x.device), F32, "ws"), float(eps),
+              _opt(bias, F32, "bias"), int(bool(relu)), B, C, HW, _pf(_bn_ws(B, C, HW, x.device)), float(eps),
               float(momentum), _opt(running_mean, F32, "running_mean"), _opt(running_var, F32, "running_var"),
-              _opt(num_batches_tracked, I64, "num_batches_tracked"), _p(mi, F32, "mean_invstd"), _p(y, F32, "y"),
-              _hip.stream_ptr())
+              _opt(num_batches_tracked, I64, "num_batches_tracked"), _pf(mi), _pf(y), _hip.stream_ptr())
     return y, mi
 
 
@@ -614,10 +619,10 @@ def bn_bwd(dy, x, out, mean_invstd, weight, bias, mode, training, want_dx):
     d_weight, d_bias = d_wb[0], d_wb[1]
     g = torch.empty_like(x) if mode == 2 else None
     dx = torch.empty_like(x) if want_dx else None
-    _hip.call("cseg_bn_bwd", _p(dy, F32, "dy"), _p(x, F32, "x"), _opt(out, F32, "out"),
-              _p(mean_invstd, F32, "mean_invstd"), _opt(weight, F32, "weight"), _opt(bias, F32, "bias"), int(mode),
-              int(bool(training)), B, C, HW, _p(_bn_ws(B, C, HW, dev), F32, "ws"), _opt(g, F32, "g_masked"),
-              _p(d_weight, F32, "d_weight"), _p(d_bias, F32, "d_bias"), _opt(dx, F32, "dx"), _hip.stream_ptr())
+    _hip.call("cseg_bn_bwd", _p(dy, F32, "dy"), _pf(x), _pf(out) if out is not None else _null(),
+              _pf(mean_invstd), _opt(weight, F32, "weight"), _opt(bias, F32, "bias"), int(mode),
+              int(bool(training)), B, C, HW, _pf(_bn_ws(B, C, HW, dev)), _pf(g) if g is not None else _null(),
+              _pf(d_weight), _pf(d_bias), _pf(dx) if dx is not None else _null(), _hip.stream_ptr())
     return dx, d_weight, d_bias, g
 
 
