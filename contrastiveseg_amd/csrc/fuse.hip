@@ -17,86 +17,50 @@ struct FuseArgs {
     int C, h, w;
 };
 
-// VEC: block = 64 column quads x 4 row groups, every thread walks FS_ROWS consecutive rows of its column quad so that the
-// horizontal taps of the coarse terms (float->int conversions, edge clamps, weights) are computed once per thread.
-constexpr int FS_ROWS = 4;
-
 template <bool VEC>
-__global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a, int relu, int tiles_x, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a, int relu, float* __restrict__ out) {
+    constexpr int V = VEC ? 4 : 1;
     const int c = blockIdx.y, b = blockIdx.z;
-    if (!VEC) {
-        const int e = blockIdx.x * 256 + threadIdx.x;
-        if (e >= a.h * a.w) return;
-        const int y = e / a.w, x = e - y * a.w;
-        const size_t off = (((size_t)b * a.C + c) * a.h + y) * a.w + x;
-        float acc = 0.f;
-        for (int s = 0; s < a.n_same; ++s) acc += a.same[s][off];
-        for (int l = 0; l < a.n_low; ++l) {
-            const int hs = a.lh[l], ws = a.lw[l];
-            const float fy = ac_scale(hs, a.h) * (float)y, fx = ac_scale(ws, a.w) * (float)x;
-            const int y0 = (int)fy, x0 = (int)fx;
-            const int y1 = y0 + (y0 < hs - 1 ? 1 : 0), x1 = x0 + (x0 < ws - 1 ? 1 : 0);
-            const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
-            const float* r0 = a.low[l] + (((size_t)b * a.C + c) * hs + y0) * ws;
-            const float* r1 = a.low[l] + (((size_t)b * a.C + c) * hs + y1) * ws;
-            acc += ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
-        }
-        out[off] = relu ? fmaxf(acc, 0.f) : acc;
-        return;
-    }
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int x = (tx * 64 + (threadIdx.x & 63)) * 4;
-    const int yb = ty * (4 * FS_ROWS) + (threadIdx.x >> 6) * FS_ROWS;
-    if (x >= a.w || yb >= a.h) return;
-    int x0[3][4], x1[3][4];
-    float lx1[3][4];
+    const int wv = a.w / V;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.h * wv) return;
+    const int y = e / wv, x = (e - y * wv) * V;
+    const size_t off = (((size_t)b * a.C + c) * a.h + y) * a.w + x;
+    float acc[V];
 #pragma unroll
-    for (int l = 0; l < 3; ++l) {
-        if (l < a.n_low) {
-            const float sx = ac_scale(a.lw[l], a.w);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float fx = sx * (float)(x + t);
-                x0[l][t] = (int)fx;
-                x1[l][t] = x0[l][t] + (x0[l][t] < a.lw[l] - 1 ? 1 : 0);
-                lx1[l][t] = fx - (float)x0[l][t];
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < FS_ROWS; ++r) {
-        const int y = yb + r;
-        if (y >= a.h) break;
-        const size_t off = (((size_t)b * a.C + c) * a.h + y) * a.w + x;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < a.n_same; ++s) {
+    for (int t = 0; t < V; ++t) acc[t] = 0.f;
+    for (int s = 0; s < a.n_same; ++s) {
+        if (VEC) {
             const float4 v = *reinterpret_cast<const float4*>(a.same[s] + off);
-            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+            acc[0] += v.x; acc[1 % V] += v.y; acc[2 % V] += v.z; acc[3 % V] += v.w;
+        } else {
+            acc[0] += a.same[s][off];
         }
-#pragma unroll
-        for (int l = 0; l < 3; ++l) {
-            if (l < a.n_low) {
-                const int hs = a.lh[l], ws = a.lw[l];
-                const float fy = ac_scale(hs, a.h) * (float)y;
-                const int y0 = (int)fy;
-                const int y1 = y0 + (y0 < hs - 1 ? 1 : 0);
-                const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
-                const float* r0 = a.low[l] + (((size_t)b * a.C + c) * hs + y0) * ws;
-                const float* r1 = a.low[l] + (((size_t)b * a.C + c) * hs + y1) * ws;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float lx0 = 1.f - lx1[l][t];
-                    acc[t] += ly0 * (lx0 * r0[x0[l][t]] + lx1[l][t] * r0[x1[l][t]]) +
-                              ly1 * (lx0 * r1[x0[l][t]] + lx1[l][t] * r1[x1[l][t]]);
-                }
-            }
-        }
-        if (relu) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = fmaxf(acc[t], 0.f);
-        }
-        *reinterpret_cast<float4*>(out + off) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
+    for (int l = 0; l < a.n_low; ++l) {
+        const int hs = a.lh[l], ws = a.lw[l];
+        const float sy = ac_scale(hs, a.h), sx = ac_scale(ws, a.w);
+        const float fy = sy * (float)y;
+        const int y0 = (int)fy;
+        const int y1 = y0 + (y0 < hs - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+        const float* r0 = a.low[l] + (((size_t)b * a.C + c) * hs + y0) * ws;
+        const float* r1 = a.low[l] + (((size_t)b * a.C + c) * hs + y1) * ws;
+#pragma unroll
+        for (int t = 0; t < V; ++t) {
+            const float fx = sx * (float)(x + t);
+            const int x0 = (int)fx;
+            const int x1 = x0 + (x0 < ws - 1 ? 1 : 0);
+            const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+            acc[t] += ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+        }
+    }
+    if (relu) {
+#pragma unroll
+        for (int t = 0; t < V; ++t) acc[t] = fmaxf(acc[t], 0.f);
+    }
+    if (VEC) *reinterpret_cast<float4*>(out + off) = make_float4(acc[0], acc[1 % V], acc[2 % V], acc[3 % V]);
+    else out[off] = acc[0];
 }
 
 __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ d_out, const float* __restrict__ act,
@@ -136,12 +100,11 @@ extern "C" int cseg_fuse_sum_fwd(const float* const* same, int n_same, const flo
                                     "fuse_sum: coarse term %d is %dx%d for a %dx%d output", i, low_h[i], low_w[i], h, w);
     }
     if (w % 4 == 0) {
-        const int tiles_x = (w / 4 + 63) / 64, tiles_y = (h + 4 * FS_ROWS - 1) / (4 * FS_ROWS);
-        dim3 grid(tiles_x * tiles_y, C, B);
-        hipLaunchKernelGGL(fuse_sum_kernel<true>, grid, dim3(256), 0, stream, a, relu, tiles_x, out);
+        dim3 grid((h * (w / 4) + 255) / 256, C, B);
+        hipLaunchKernelGGL(fuse_sum_kernel<true>, grid, dim3(256), 0, stream, a, relu, out);
     } else {
         dim3 grid((h * w + 255) / 256, C, B);
-        hipLaunchKernelGGL(fuse_sum_kernel<false>, grid, dim3(256), 0, stream, a, relu, 1, out);
+        hipLaunchKernelGGL(fuse_sum_kernel<false>, grid, dim3(256), 0, stream, a, relu, out);
     }
     CSEG_CHECK_LAUNCH("fuse_sum_kernel");
     return 1;
