@@ -101,3 +101,51 @@ def test_reference_checkpoint_loads_unchanged(tmp_path, monkeypatch):
     net = ModuleRunner(cfg).load_net(ModelManager(cfg).semantic_segmentor())
     for k, v in ref.state_dict().items():
         assert torch.equal(net.state_dict()[k], v), k
+
+
+def test_distributed_flag_respawns_one_rank_per_gpu(monkeypatch):
+    """`main_contrastive.py --distributed --gpu 0 1 2` (reference lib/utils/distributed.py:27-69): not yet a rank ->
+    start one rank per listed GPU through torch.distributed.run on 127.0.0.1 and exit with the launcher's status; already
+    a rank (torchrun environment) -> join the process group instead of respawning."""
+    import subprocess
+    import types
+    from contrastiveseg_amd.lib.utils import distributed as D
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    seen = {}
+
+    class FakeProc(object):
+        returncode = 0
+
+        def __init__(self, cmd, env=None):
+            seen["cmd"], seen["env"] = cmd, env
+
+        def wait(self):
+            return 0
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    args = types.SimpleNamespace(distributed=True, gpu=[0, 1, 2], local_rank=-1)
+    with pytest.raises(SystemExit) as e:
+        D.handle_distributed(args, module="contrastiveseg_amd.main_contrastive",
+                             argv=["--configs", "x.json", "--distributed", "--gpu", "0", "1", "2"])
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-u", "-m", "torch.distributed.run"] and "--nproc-per-node" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "3" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("-m", 3) + 1] == "contrastiveseg_amd.main_contrastive" and cmd[-4:] == ["--gpu", "0", "1", "2"]
+    assert seen["env"]["HIP_VISIBLE_DEVICES"] == "0,1,2"
+    # a rank started by torchrun joins instead of respawning
+    called = {}
+    monkeypatch.setattr(D, "setup_process_group", lambda backend=None: called.setdefault("joined", True))
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("WORLD_SIZE", "3")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    D.handle_distributed(args, module="contrastiveseg_amd.main_contrastive", argv=[])
+    assert called.get("joined")
+    # without --distributed the process is pinned to the listed GPUs (reference :28-30)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    args2 = types.SimpleNamespace(distributed=False, gpu=[2], local_rank=-1)
+    D.handle_distributed(args2, module="m", argv=[])
+    import os
+    assert os.environ.get("HIP_VISIBLE_DEVICES") == "2"
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
