@@ -387,11 +387,18 @@ def main():
     wl = WORKLOADS[args.workload]
     base_batch = args.global_batch or wl["batch"]
     global_batch = base_batch * world if args.scaling == "weak" else base_batch
+    t_start = time.perf_counter()
     tr, cfg, batch = build_trainer(args, world, device, global_batch)
     dt, ev_ms, final_loss = timed_steps(tr, batch, args.steps, args.warmup, world, device)
+    elapsed = torch.tensor([time.perf_counter() - t_start], device=device)
+    if world > 1:
+        torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)      # same decision on every rank
 
     weak = None
-    if world > 1 and args.scaling == "strong" and not args.no_weak:
+    # extra weak-scaling pass: RCCL runs only (the gloo dry run shares one GPU between the ranks and says nothing about
+    # scaling), and only when the headline measurement itself was quick, so the whole invocation stays within minutes
+    if (world > 1 and args.scaling == "strong" and not args.no_weak and torch.distributed.get_backend() == "nccl"
+            and float(elapsed) < 180.0):
         # per-GPU work fixed at the config's global batch: separates "the step is too small per GPU" from "the
         # collectives do not overlap". Fewer steps; outside the timed region of the headline number.
         del tr, batch

@@ -232,5 +232,6 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 2
-    assert d["weak"] is not None and d["weak"]["global_batch"] == 4
+    if torch.cuda.device_count() >= 2:
+        assert d["weak"] is not None and d["weak"]["global_batch"] == 4      # extra weak pass: RCCL runs only
     assert d["value"] > 0 and np.isfinite(d["config"]["final_loss"])
