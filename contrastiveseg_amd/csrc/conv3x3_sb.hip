@@ -1,0 +1,409 @@
+// 3x3 / stride 1 / pad 1 convolution, NCHW fp32 in and out, evaluated on the BF16 matrix cores with split operands
+// ("bf16x6"): every fp32 operand is written as hi + mid + lo with three bf16 pieces (8 + 8 + 8 mantissa bits: the
+// split is exact for normal numbers), and the product a*b is accumulated in fp32 from the six piece products whose
+// weight is >= 2^-16 of the leading one:
+//        a*b ~= a0*b0 + (a0*b1 + a1*b0) + (a0*b2 + a1*b1 + a2*b0)            (dropped: 2^-24 and below)
+// Products of bf16 pieces are exact in fp32 and the MFMA accumulates in fp32, so the result is in the fp32 rounding
+// class: on the reference HRNet-W48 the logits deviate from the fp64 evaluation by 2.1e-5 (plain fp32: 4.3e-5; three
+// terms only: 1.4e-3; the reference's own TF32 default on Ampere-class GPUs: 9.6e-2) -- tools/split_bf16_probe.py.
+// Why: gfx950's fp32 MFMA runs at 1/16 of the bf16 rate (157 vs 2500 TFLOP/s). Six bf16 MFMAs per fp32-equivalent
+// product put the bound at 2500/6 = 417 TFLOP/s of fp32-equivalent work, 2.65x the fp32 MFMA roofline that bounds
+// MIOpen's kernels (the 720->720 head convolution runs there at 0.78-0.83 of that roof already).
+//
+// Mapping (one block = 8 waves = 4 image rows x 64 columns x NT*16 output channels; two waves per row split the
+// channel tiles):
+//   GEMM M = pixels, N = output channels, K = input channels x 9 taps, v_mfma_f32_16x16x32_bf16.
+//   K-step = 32 k-values = one tap x 32 consecutive input channels (lane group g = lane/16 owns channels 8g..8g+7);
+//       a trailing 16-channel chunk (720 = 22*32 + 16, 48 = 32 + 16) pairs two taps per K-step instead (groups 0,1 =
+//       first tap, groups 2,3 = second tap; the ninth tap is paired with zero weights).
+//   A operand: the fp32 input patch of a 32-channel chunk (6 rows x 66 columns incl. halo) is split while it is staged:
+//       LDS image [piece][channel octet][row][column] of 16-byte cells (8 bf16 of one pixel) -- a lane's fragment is one
+//       ds_read_b128, consecutive lanes read consecutive cells (conflict-free), and the tap offset is a whole number of
+//       cells, so shifted reads stay aligned.
+//   B operand: weights pre-split and pre-packed by cseg_conv3x3_sb_pack_weights in lane order per (channel tile, K-step,
+//       column tile, piece); the block streams one K-step (NT*3 KB) ahead through a double-buffered LDS stage.
+//   C: 4 pixel tiles x NT channel tiles of 16x16 per wave; six MFMAs per (pixel tile, channel tile, K-step), smallest
+//       terms first. Lane holds 4 consecutive pixels of one channel per accumulator -> 16-byte stores.
+// Backward-data is the same kernel on weights packed transposed and mirrored.
+// Status: opt-in (CSEG_CONV3X3_SPLIT_BF16=1); the fp32-MFMA kernel of conv3x3.hip and MIOpen remain the default path.
+#include "cseg_common.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TR = 4;                 // output rows per block (one per wave)
+constexpr int TC = 64;                // output columns per block
+constexpr int XROWS = TR + 2;
+constexpr int XCOLS = TC + 2;         // cell 0 = column x0 - 1
+constexpr int CELLS = XROWS * XCOLS;  // 396 pixels per (piece, octet)
+constexpr int A_CELLS = 3 * 4 * CELLS;
+constexpr int A_ITEMS = 4 * CELLS;    // (octet, pixel) staging items of a 32-channel chunk
+constexpr int AU = (A_ITEMS + 511) / 512;     // staging items per thread (512 threads)
+
+__host__ __device__ constexpr int steps_of(int Cin) { return (Cin / 32) * 9 + ((Cin & 31) ? 5 : 0); }
+
+__device__ __forceinline__ void split3(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const __bf16 bh = (__bf16)v;
+    const float r1 = v - (float)bh;            // exact
+    const __bf16 bm = (__bf16)r1;
+    const float r2 = r1 - (float)bm;           // exact
+    const __bf16 bl = (__bf16)r2;
+    h = __builtin_bit_cast(unsigned short, bh);
+    m = __builtin_bit_cast(unsigned short, bm);
+    l = __builtin_bit_cast(unsigned short, bl);
+}
+
+__device__ __forceinline__ void split8(const float (&v)[8], uint4& h, uint4& m, uint4& l) {
+    unsigned short hs[8], ms[8], ls[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split3(v[j], hs[j], ms[j], ls[j]);
+    h = make_uint4(hs[0] | ((unsigned)hs[1] << 16), hs[2] | ((unsigned)hs[3] << 16), hs[4] | ((unsigned)hs[5] << 16),
+                   hs[6] | ((unsigned)hs[7] << 16));
+    m = make_uint4(ms[0] | ((unsigned)ms[1] << 16), ms[2] | ((unsigned)ms[3] << 16), ms[4] | ((unsigned)ms[5] << 16),
+                   ms[6] | ((unsigned)ms[7] << 16));
+    l = make_uint4(ls[0] | ((unsigned)ls[1] << 16), ls[2] | ((unsigned)ls[3] << 16), ls[4] | ((unsigned)ls[5] << 16),
+                   ls[6] | ((unsigned)ls[7] << 16));
+}
+
+// Packed weights: Wp[co_tile][kstep][nt][piece][lane] of uint4 (8 bf16, element j), lane = 16*g + n:
+//   full K-step (chunk c, tap t):  value(co = (co_tile*NT + nt)*16 + n, ci = 32c + 8g + j, tap t)
+//   tail K-step q (last 16 channels): ci = 32*n_full + 8*(g&1) + j, tap = 2q + (g>>1)   (zero when tap > 8)
+__global__ __launch_bounds__(256) void pack_weights_sb_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                                              int transpose_flip, int NT, uint4* __restrict__ wp, int total) {
+    const int e = blockIdx.x * 256 + threadIdx.x;          // one thread per (co_tile, kstep, nt, lane)
+    if (e >= total) return;
+    const int conv_in = transpose_flip ? Cout : Cin;
+    const int n_full = conv_in / 32, n_steps = steps_of(conv_in);
+    int r = e;
+    const int lane = r & 63; r >>= 6;
+    const int nt = r % NT; r /= NT;
+    const int ks = r % n_steps;
+    const int co_tile = r / n_steps;
+    const int g = lane >> 4, n = lane & 15;
+    const int oc = (co_tile * NT + nt) * 16 + n;           // output channel of THIS convolution
+    int tap, ic0;
+    if (ks < n_full * 9) { tap = ks % 9; ic0 = (ks / 9) * 32 + 8 * g; }
+    else { tap = 2 * (ks - n_full * 9) + (g >> 1); ic0 = n_full * 32 + 8 * (g & 1); }
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ic = ic0 + j;                            // input channel of THIS convolution
+        float t = 0.f;
+        if (tap <= 8) {
+            if (!transpose_flip) t = w[((size_t)oc * Cin + ic) * 9 + tap];            // w[co][ci][ky][kx]
+            else t = w[((size_t)ic * Cin + oc) * 9 + (8 - tap)];                      // w[co=ic][ci=oc][2-ky][2-kx]
+        }
+        v[j] = t;
+    }
+    uint4 h, m, l;
+    split8(v, h, m, l);
+    uint4* dst = wp + (((size_t)(co_tile * n_steps + ks) * NT + nt) * 3) * 64 + lane;
+    dst[0] = h; dst[64] = m; dst[128] = l;
+}
+
+// One K-step of a wave: 4 pixel tiles x NTW channel tiles x 6 piece products. `ap` = this lane's cell in the hi-piece
+// image (octet, row, tap and column already applied), `bp` = this lane's slot in the staged B step.
+template <int NTW, int NTMAX>
+__device__ __forceinline__ void sb_kstep(const uint4* __restrict__ ap, const uint4* __restrict__ bp,
+                                         f32x4 (&acc)[4][NTMAX]) {
+    bf16x8 a[4][3];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            a[mt][p] = __builtin_bit_cast(bf16x8, ap[p * 4 * CELLS + 16 * mt]);
+        }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, bp[(nt * 3 + 0) * 64]);
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, bp[(nt * 3 + 1) * 64]);
+        const bf16x8 b2 = __builtin_bit_cast(bf16x8, bp[(nt * 3 + 2) * 64]);
+        // term-major, smallest terms first: the four pixel tiles between two MFMAs on the same accumulator hide the
+        // dependent-accumulator latency
+#define SB_TERM(P, Q)                                                                                     \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                      \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][P], Q, acc[mt][nt], 0, 0, 0);
+        SB_TERM(2, b0)
+        SB_TERM(0, b2)
+        SB_TERM(1, b1)
+        SB_TERM(1, b0)
+        SB_TERM(0, b1)
+        SB_TERM(0, b0)
+#undef SB_TERM
+    }
+}
+
+// accumulator layout: D[m = 4*g + r][n]: pixel column x0 + 16*mt + 4*g + r, channel co0 + 16*nt + n
+template <int NTW, int NTMAX>
+__device__ __forceinline__ void sb_store(const f32x4 (&acc)[4][NTMAX], float* __restrict__ ybc,
+                                         const float* __restrict__ bias, int co0, size_t plane, int yy, int x0, int W,
+                                         int g, int n) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        float* orow = ybc + (size_t)(co0 + nt * 16 + n) * plane + (size_t)yy * W;
+        const float bv = bias ? bias[co0 + nt * 16 + n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int xx = x0 + 16 * mt + 4 * g;
+            f32x4 v = acc[mt][nt];
+            v += bv;
+            if (xx + 3 < W) *reinterpret_cast<float4*>(orow + xx) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+                if (xx < W) orow[xx] = v[0];
+                if (xx + 1 < W) orow[xx + 1] = v[1];
+                if (xx + 2 < W) orow[xx + 2] = v[2];
+            }
+        }
+    }
+}
+
+// 8 waves: wave = (row = wave & 3, half = wave >> 2); the two halves split the NT channel tiles (NT0 + NT1), so each
+// SIMD hosts one wave of either half (2 waves per SIMD: one issues MFMAs while the other waits on LDS).
+// GLDS: the B stage is filled by LDS-DMA (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16, which is exactly
+// the packed lane order) instead of a register round trip -- no VGPRs held across the MFMAs of the step.
+template <int NT, bool GLDS>
+__global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
+                                                            const float* __restrict__ bias, int Cin, int Cout, int H,
+                                                            int W, int tiles_x, int tiles_y, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_sb[];
+    uint4* As = smem_sb;                           // [piece 3][octet 4][CELLS]
+    uint4* Bs = smem_sb + A_CELLS;                 // [2][NT*3*64]
+    constexpr int BSTEP = NT * 3 * 64;             // uint4 per K-step
+    constexpr int BU = (BSTEP + 511) / 512;
+    constexpr int NT0 = (NT + 1) / 2, NT1 = NT - NT0;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row = wave & 3, half = wave >> 2;
+    const int g = lane >> 4, n = lane & 15;
+    const int n_cot = Cout / (NT * 16);
+    const size_t plane = (size_t)H * W;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    const int cot = t % n_cot;
+    const int b = t / n_cot;
+    const int x0 = tx * TC, y0 = ty * TR;
+
+    const int n_full = Cin / 32;
+    const int n_chunks = n_full + ((Cin & 31) ? 1 : 0);
+    const int n_steps = steps_of(Cin);
+    const uint4* wbase = wp + (size_t)cot * n_steps * BSTEP;
+
+    uint4 bpre[BU];
+    auto b_issue = [&](int ks) {
+#pragma unroll
+        for (int u = 0; u < BU; ++u) {
+            const int idx = tid + 512 * u;
+            bpre[u] = wbase[(size_t)ks * BSTEP + (idx < BSTEP ? idx : BSTEP - 1)];      // clamped: always defined
+        }
+    };
+    auto b_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < BU; ++u) {
+            const int idx = tid + 512 * u;
+            if (idx < BSTEP) Bs[buf * BSTEP + idx] = bpre[u];
+        }
+    };
+
+    // A staging: item = (octet, patch pixel); 8 channel loads each (coalesced along the row), branch-free: the address
+    // is clamped into the tensor and the value masked
+    auto b_glds = [&](int ks, int buf) {
+#pragma unroll
+        for (int i = 0; i < (NT * 3 + 7) / 8; ++i) {
+            const int r = wave + 8 * i;                  // one 1 KB row (channel tile, piece) per wave instruction
+            if (r < NT * 3)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(wbase + (size_t)ks * BSTEP + r * 64 + lane),
+                    (__attribute__((address_space(3))) void*)(Bs + buf * BSTEP + r * 64), 16, 0, 0);
+        }
+    };
+
+    float apre[AU][8];
+    auto a_item = [&](int u, int chunk, int& oct, int& rc, bool& ok) {
+        const int n_oct = chunk < n_full ? 4 : 2;
+        const int item = tid + 512 * u;
+        oct = item / CELLS; rc = item - oct * CELLS;
+        const int r = rc / XCOLS, col = rc - r * XCOLS;
+        const int yy = y0 + r - 1, xx = x0 + col - 1;
+        ok = oct < n_oct && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    };
+    auto a_issue = [&](int chunk) {
+        const int n_oct = chunk < n_full ? 4 : 2;
+        const float* xc = x + ((size_t)b * Cin + (size_t)chunk * 32) * plane;
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            int oct, rc;
+            bool ok;
+            a_item(u, chunk, oct, rc, ok);
+            const int r = rc / XCOLS, col = rc - r * XCOLS;
+            const int octc = min(oct, n_oct - 1), yc = min(max(y0 + r - 1, 0), H - 1), xcl = min(max(x0 + col - 1, 0), W - 1);
+            const float* p = xc + (size_t)(octc * 8) * plane + (size_t)yc * W + xcl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) apre[u][j] = p[(size_t)j * plane];      // raw; masked when it is stored
+        }
+    };
+    auto a_store = [&](int chunk) {
+        const int n_oct = chunk < n_full ? 4 : 2;
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            int oct, rc;
+            bool ok;
+            a_item(u, chunk, oct, rc, ok);
+            if (oct < n_oct) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = ok ? apre[u][j] : 0.f;       // zero padding / outside the tensor
+                uint4 h, m, l;
+                split8(v, h, m, l);
+                const int item = oct * CELLS + rc;
+                As[item] = h;
+                As[4 * CELLS + item] = m;
+                As[8 * CELLS + item] = l;
+            }
+        }
+    };
+
+    f32x4 acc[4][NT0];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT0; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    a_issue(0);
+    if (GLDS) b_glds(0, 0);
+    else b_issue(0);
+    a_store(0);
+    if (!GLDS) b_store(0);
+    __syncthreads();
+
+    const uint4* a_lane = As + row * XCOLS + n;                        // + octet / tap offset per K-step
+    const uint4* b_lane = Bs + (half ? NT0 * 3 * 64 : 0) + lane;       // + buffer offset per K-step
+    int ks = 0, buf = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        const bool full = c < n_full;
+        const int steps = full ? 9 : 5;
+#pragma unroll 1
+        for (int s = 0; s < steps; ++s) {
+            const bool more = ks + 1 < n_steps;
+            if (more) {
+                if (GLDS) b_glds(ks + 1, buf ^ 1);      // that buffer was last read in step ks - 1 (barrier since)
+                else b_issue(ks + 1);
+            }
+            if (s == steps - 3 && c + 1 < n_chunks) a_issue(c + 1);
+            int a_off;
+            if (full) {
+                const int ky = s / 3, kx = s - 3 * ky;
+                a_off = g * CELLS + ky * XCOLS + kx;
+            } else {
+                // the ninth tap is paired with a tenth that does not exist: its packed weights are zero, so whatever
+                // (finite) patch values those lanes read contribute nothing
+                const int tap = min(2 * s + (g >> 1), 8);
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                a_off = (g & 1) * CELLS + ky * XCOLS + kx;
+            }
+            if (half == 0) sb_kstep<NT0, NT0>(a_lane + a_off, b_lane + buf * BSTEP, acc);
+            else if (NT1 > 0) sb_kstep<NT1, NT0>(a_lane + a_off, b_lane + buf * BSTEP, acc);
+            if (more && !GLDS) b_store(buf ^ 1);
+            if (s == steps - 1 && c + 1 < n_chunks) {
+                __syncthreads();                    // every wave is done with this chunk's patch
+                a_store(c + 1);
+            }
+            __syncthreads();
+            buf ^= 1;
+            ++ks;
+        }
+    }
+
+    const int yy = y0 + row;
+    if (yy < H) {
+        float* ybc = y + (size_t)b * Cout * plane;
+        const int co0 = cot * NT * 16;
+        if (half == 0) sb_store<NT0, NT0>(acc, ybc, bias, co0, plane, yy, x0, W, g, n);
+        else if (NT1 > 0) sb_store<NT1, NT0>(acc, ybc, bias, co0 + NT0 * 16, plane, yy, x0, W, g, n);
+    }
+}
+
+// channel tiles per block: the largest of {9, 6, 3} x 16 that divides Cout
+int pick_nt(int Cout) {
+    if (Cout % 144 == 0) return 9;
+    if (Cout % 96 == 0) return 6;
+    if (Cout % 48 == 0) return 3;
+    return 0;
+}
+
+template <int NT, bool GLDS>
+int launch_sb(const float* x, const uint4* wp, const float* bias, int B, int Cin, int Cout, int H, int W, float* y,
+              hipStream_t stream) {
+    const size_t lds = sizeof(uint4) * (A_CELLS + 2 * NT * 3 * 64);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv3x3_sb_kernel<NT, GLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            cseg_set_error("conv3x3_sb: cannot raise dynamic LDS to %zu bytes", lds);
+            return 0;
+        }
+        attr_set = true;
+    }
+    const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
+    const long n_tiles = (long)B * (Cout / (NT * 16)) * tiles_y * tiles_x;
+    CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb: grid too large");
+    hipLaunchKernelGGL((conv3x3_sb_kernel<NT, GLDS>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, Cin, Cout, H, W, tiles_x,
+                       tiles_y, y);
+    CSEG_CHECK_LAUNCH("conv3x3_sb_kernel");
+    return 1;
+}
+
+}  // namespace
+
+extern "C" size_t cseg_conv3x3_sb_packed_bytes(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0 || Cin % 16 || pick_nt(Cout) == 0) return 0;
+    return (size_t)(Cout / 16) * steps_of(Cin) * 3 * 64 * sizeof(uint4);
+}
+
+extern "C" int cseg_conv3x3_sb_pack_weights(const float* w, int Cout, int Cin, int transpose_flip, void* wp,
+                                            cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    // transpose_flip: w is still the forward's [Cout, Cin, 3, 3]; the packed operator maps Cout -> Cin channels
+    const int conv_in = transpose_flip ? Cout : Cin, conv_out = transpose_flip ? Cin : Cout;
+    CSEG_REQUIRE(w && wp, "conv3x3_sb_pack_weights: null pointer");
+    const int NT = pick_nt(conv_out);
+    CSEG_REQUIRE(conv_in % 16 == 0 && NT > 0,
+                 "conv3x3_sb: needs input channels %% 16 == 0 and output channels %% 48 == 0 (got %d -> %d)", conv_in, conv_out);
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0, "conv3x3_sb_pack_weights: packed buffer must be 16-byte aligned");
+    const long total = (long)(conv_out / 16) * steps_of(conv_in) * 64;
+    CSEG_REQUIRE(total < 2147483647L, "conv3x3_sb_pack_weights: too large");
+    hipLaunchKernelGGL(pack_weights_sb_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, Cout, Cin,
+                       transpose_flip, NT, (uint4*)wp, (int)total);
+    CSEG_CHECK_LAUNCH("conv3x3_sb_pack_weights");
+    return 1;
+}
+
+extern "C" int cseg_conv3x3_sb_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H,
+                                   int W, float* y, cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CSEG_REQUIRE(x && wp && y, "conv3x3_sb: null pointer");
+    const int NT = pick_nt(Cout);
+    CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && NT > 0,
+                 "conv3x3_sb: unsupported shape B=%d Cin=%d Cout=%d %dx%d", B, Cin, Cout, H, W);
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && W % 4 == 0,
+                 "conv3x3_sb: packed weights / output must be 16-byte aligned and W a multiple of 4");
+    const uint4* wq = (const uint4*)wp;
+    // CSEG_CONV3X3_SB_GLDS=0: stage B through registers instead of LDS-DMA
+    const char* glds_env = getenv("CSEG_CONV3X3_SB_GLDS");       // read per call: tests switch it inside one process
+    const bool glds = !(glds_env && atoi(glds_env) == 0);
+    if (glds) {
+        switch (NT) {
+            case 9: return launch_sb<9, true>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
+            case 6: return launch_sb<6, true>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
+            default: return launch_sb<3, true>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
+        }
+    }
+    switch (NT) {
+        case 9: return launch_sb<9, false>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
+        case 6: return launch_sb<6, false>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
+        default: return launch_sb<3, false>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
+    }
+}

@@ -3,6 +3,8 @@ ops (lib/extensions/cc_attention/functions.py:20-47): a torch.autograd.Function 
 raw pointers + the current stream, and raises RuntimeError on a 0 return. No CPU path."""
 import ctypes
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -595,6 +597,69 @@ class Conv3x3(Function):
 
 def conv3x3(x, weight):
     return Conv3x3.apply(x, weight)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# The same convolution on the BF16 matrix cores with split operands (csrc/conv3x3_sb.hip): opt-in
+# ----------------------------------------------------------------------------------------------------------
+CONV3X3_SPLIT_BF16 = os.environ.get("CSEG_CONV3X3_SPLIT_BF16", "0") == "1"
+
+
+def conv3x3_sb_eligible(x, weight):
+    """NCHW fp32 on the GPU, 3x3, channels % 48 both ways (forward needs Cin % 16 and Cout % 48, backward-data the
+    mirror image), width % 4."""
+    if not (x.is_cuda and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4 and x.is_contiguous()):
+        return False
+    co, ci, kh, kw = weight.shape
+    return (kh, kw) == (3, 3) and ci % 48 == 0 and co % 48 == 0 and x.shape[1] == ci and x.shape[3] % 4 == 0
+
+
+@torch.no_grad()
+def conv3x3_sb_run(x, weight, transpose_flip=False, bias=None):
+    """y = conv2d(x, weight, bias, 1, 1) (transpose_flip: the backward-data operator of that convolution applied to x)
+    through the split-bf16 MFMA kernel."""
+    co, ci = weight.shape[:2]
+    conv_in, conv_out = (co, ci) if transpose_flip else (ci, co)
+    B, _, H, W = x.shape
+    lib = _hip.lib()
+    n_bytes = lib.cseg_conv3x3_sb_packed_bytes(conv_in, conv_out)
+    if n_bytes == 0:
+        raise RuntimeError("conv3x3_sb: unsupported channel counts %d -> %d" % (conv_in, conv_out))
+    wp = torch.empty(n_bytes, dtype=torch.uint8, device=x.device)
+    sp = _hip.stream_ptr()
+    _hip.call("cseg_conv3x3_sb_pack_weights", _p(weight, F32, "weight"), co, ci, int(transpose_flip), wp.data_ptr(), sp)
+    y = torch.empty(B, conv_out, H, W, dtype=F32, device=x.device)
+    _hip.call("cseg_conv3x3_sb_fwd", _p(x, F32, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H, W,
+              _pf(y), sp)
+    return y
+
+
+class Conv3x3SplitBF16(Function):
+    """y = conv2d(x, weight, bias, stride 1, padding 1): forward and backward-data on the split-bf16 MFMA kernel, the
+    weight / bias gradients on MIOpen (fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        weight = weight.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return conv3x3_sb_run(x, weight, False, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = conv3x3_sb_run(dy, weight, True) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            _, dw, db = torch.ops.aten.convolution_backward(
+                dy, x, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                [False, bool(ctx.needs_input_grad[1]), bool(ctx.has_bias and ctx.needs_input_grad[2])])
+        return dx, dw, db
+
+
+def conv3x3_split_bf16(x, weight, bias=None):
+    return Conv3x3SplitBF16.apply(x, weight, bias)
 
 
 @torch.no_grad()

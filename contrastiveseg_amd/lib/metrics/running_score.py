@@ -41,7 +41,8 @@ class RunningScore(object):
             hist = torch.zeros(self.n_classes, self.n_classes, dtype=torch.int64)
         if D.is_distributed() and D.get_world_size() > 1:
             import torch.distributed as dist
-            hist = hist.clone()
+            # RCCL reduces device tensors only; gloo takes either
+            hist = hist.cuda() if dist.get_backend() == "nccl" and not hist.is_cuda else hist.clone()
             dist.all_reduce(hist)
         self.reduced_confusion_matrix = hist.cpu().numpy().astype(np.float64)
 

@@ -234,6 +234,24 @@ int cseg_conv3x3_wrw(const float* x, const float* dy, int B, int Cin, int Cout, 
                      cseg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The same convolution (3x3 / stride 1 / pad 1, NCHW fp32 in and out) on the BF16 matrix cores with split operands
+ * ("bf16x6"): every fp32 operand = hi + mid + lo bf16 pieces (exact), the six piece products down to 2^-16 of the leading
+ * one are accumulated in fp32 by v_mfma_f32_16x16x32_bf16 -- fp32-class accuracy (tools/split_bf16_probe.py) at up to
+ * 2500/6 = 417 TFLOP/s of fp32-equivalent work instead of the 157 TFLOP/s fp32 MFMA rate.  Replaces nn.Conv2d -> MIOpen
+ * for the 720 -> 720 head convolution (lib/models/nets/hrnet.py:72-77 of the reference) and the HRNet branch
+ * convolutions.  Cin % 16 == 0, Cout % 48 == 0, W % 4 == 0.  Opt-in (CSEG_CONV3X3_SPLIT_BF16=1) until it has been
+ * through the full parity suite on hardware.
+ *   cseg_conv3x3_sb_pack_weights: w [Cout,Cin,3,3] -> wp (cseg_conv3x3_sb_packed_bytes bytes, 16-byte aligned): split and
+ *       laid out in MFMA lane order; transpose_flip = 1 packs the backward-data operator (maps Cout -> Cin channels);
+ *       cseg_conv3x3_sb_packed_bytes(conv_in, conv_out) takes the channel counts of the PACKED operator.
+ *   cseg_conv3x3_sb_fwd: y [B,Cout,H,W] = conv(x [B,Cin,H,W], wp) (+ bias[Cout] when not NULL).
+ * ------------------------------------------------------------------------------------------------ */
+size_t cseg_conv3x3_sb_packed_bytes(int Cin, int Cout);
+int cseg_conv3x3_sb_pack_weights(const float* w, int Cout, int Cin, int transpose_flip, void* wp, cseg_stream_t stream);
+int cseg_conv3x3_sb_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
+                        float* y, cseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * GPU data pipeline: random resize (cv2 INTER_CUBIC image / INTER_NEAREST label) -> random
  * crop -> horizontal flip -> brightness shift -> ToTensor + Normalize(div, mean, std) + label look-up + ReLabel(255,-1)
  * -> collate padding to the fixed input size, as ONE kernel over the output batch.  Replaces the per-sample CPU chain

@@ -1,0 +1,71 @@
+"""Split-bf16 ("bf16x6") 3x3 convolution on the BF16 matrix cores (csrc/conv3x3_sb.hip) against an fp64 convolution.
+The path is opt-in; these tests run when CSEG_TEST_SPLIT_BF16=1 (the default GPU suite covers the default kernels)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("CSEG_TEST_SPLIT_BF16") != "1", reason="opt-in path: CSEG_TEST_SPLIT_BF16=1")]
+
+CASES = [  # B, Cin, Cout, H, W
+    (1, 48, 48, 5, 8),          # one full 32-channel chunk + the 16-channel tail, one partial tile
+    (2, 48, 48, 9, 68),         # ragged tiles in both directions
+    (2, 96, 96, 16, 64),        # NT = 6
+    (1, 144, 144, 4, 64),       # NT = 9, tail chunk
+    (1, 720, 720, 8, 64),       # the head's channel count (22 full chunks + tail, 5 channel tiles of 144)
+    (1, 192, 48, 7, 36),        # Cin != Cout
+]
+
+
+def _inputs(B, ci, co, H, W, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, ci, H, W, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (3.0 * ci ** 0.5)
+    b = torch.randn(co, generator=g)
+    return x, w, b
+
+
+def _bound(ref64, got, fp32):
+    """fp32 rounding class: no worse than 4x the deviation of a plain fp32 convolution, floor 2e-6 of the output scale."""
+    scale = float(ref64.abs().max())
+    err = float((got.double() - ref64).abs().max())
+    base = float((fp32.double() - ref64).abs().max())
+    return err, max(4.0 * base, 2e-6 * scale)
+
+
+@pytest.mark.parametrize("glds", ["1", "0"])
+@pytest.mark.parametrize("case", CASES)
+def test_forward_matches_fp64(case, glds, monkeypatch):
+    from contrastiveseg_amd import kernels as K
+    monkeypatch.setenv("CSEG_CONV3X3_SB_GLDS", glds)
+    B, ci, co, H, W = case
+    x, w, b = _inputs(*case)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    assert K.conv3x3_sb_eligible(xd, wd)
+    got = K.conv3x3_sb_run(xd, wd, False, bd).cpu()
+    fp32 = F.conv2d(xd, wd, bd, 1, 1).cpu()
+    err, tol = _bound(ref, got, fp32)
+    assert err <= tol, (case, glds, err, tol)
+    got_nb = K.conv3x3_sb_run(xd, wd, False, None).cpu()
+    assert float((got_nb.double() - (ref - b.double().view(1, -1, 1, 1))).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_autograd_matches_fp64(case):
+    from contrastiveseg_amd import kernels as K
+    B, ci, co, H, W = case
+    x, w, b = _inputs(*case, seed=1)
+    dy = torch.randn(B, co, H, W, generator=torch.Generator().manual_seed(2))
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+    F.conv2d(x64, w64, b64, 1, 1).backward(dy.double())
+    xd, wd, bd = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    K.conv3x3_split_bf16(xd, wd, bd).backward(dy.cuda())
+    xr, wr, br = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    F.conv2d(xr, wr, br, 1, 1).backward(dy.cuda())
+    for name, g64, got, fp32 in (("dx", x64.grad, xd.grad, xr.grad), ("dw", w64.grad, wd.grad, wr.grad),
+                                 ("db", b64.grad, bd.grad, br.grad)):
+        err, tol = _bound(g64, got.cpu(), fp32.cpu())
+        assert err <= tol, (case, name, err, tol)
