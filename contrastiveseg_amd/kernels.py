@@ -602,7 +602,11 @@ def conv3x3(x, weight):
 # ----------------------------------------------------------------------------------------------------------
 # The same convolution on the BF16 matrix cores with split operands (csrc/conv3x3_sb.hip): opt-in
 # ----------------------------------------------------------------------------------------------------------
+# module-level switch (read at call time by the modules, so bench.py / tests can flip it inside one process)
 CONV3X3_SPLIT_BF16 = os.environ.get("CSEG_CONV3X3_SPLIT_BF16", "0") == "1"
+# bias-free residual-branch convolutions that move to the split kernel when the switch is on (measured on MI355X at the
+# benched shapes, tools/conv3x3_sb_probe.py: 96 ch 70 vs 101 us; 48 ch 99 vs 106 us on the fp32-MFMA kernel)
+CONV3X3_SB_BRANCH_CHANNELS = (48, 96)
 
 
 def conv3x3_sb_eligible(x, weight):
@@ -634,9 +638,20 @@ def conv3x3_sb_run(x, weight, transpose_flip=False, bias=None):
     return y
 
 
+# Forward / backward-data go to the split-bf16 kernel only when its grid fills the chip (4x64-pixel tiles x channel tiles of
+# 144 / 96 / 48); smaller problems stay on MIOpen
+CONV3X3_SB_MIN_TILES = 256
+
+
+def conv3x3_sb_tiles(x, c_out):
+    nt16 = 144 if c_out % 144 == 0 else 96 if c_out % 96 == 0 else 48
+    return x.shape[0] * (c_out // nt16) * ((x.shape[2] + 3) // 4) * ((x.shape[3] + 63) // 64)
+
+
 class Conv3x3SplitBF16(Function):
-    """y = conv2d(x, weight, bias, stride 1, padding 1): forward and backward-data on the split-bf16 MFMA kernel, the
-    weight / bias gradients on MIOpen (fp32)."""
+    """y = conv2d(x, weight, bias, stride 1, padding 1): forward and backward-data on the split-bf16 MFMA kernel; the
+    weight gradient on the fp32-MFMA kernel where that one is used today (bias-free 48/96-channel branches), otherwise
+    on MIOpen together with the bias gradient."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -651,10 +666,15 @@ class Conv3x3SplitBF16(Function):
         dy = dy.contiguous()
         dx = conv3x3_sb_run(dy, weight, True) if ctx.needs_input_grad[0] else None
         dw = db = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            _, dw, db = torch.ops.aten.convolution_backward(
-                dy, x, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                [False, bool(ctx.needs_input_grad[1]), bool(ctx.has_bias and ctx.needs_input_grad[2])])
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_db:
+            co, ci = weight.shape[:2]
+            if not ctx.has_bias and co == ci and co in CONV3X3_WRW_CHANNELS:
+                dw = _conv3x3_wrw(x, dy, co, ci)
+            else:
+                _, dw, db = torch.ops.aten.convolution_backward(
+                    dy, x, weight, [co] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                    [False, bool(ctx.needs_input_grad[1]), bool(want_db)])
         return dx, dw, db
 
 

@@ -10,7 +10,7 @@ from contrastiveseg_amd import kernels as K
 from contrastiveseg_amd.lib.models.backbones.backbone_selector import BackboneSelector
 from contrastiveseg_amd.lib.models.modules.projection import ProjectionHead
 from contrastiveseg_amd.lib.models.modules.spatial_ocr_block import SpatialGather_Module, SpatialOCR_Module
-from contrastiveseg_amd.lib.models.tools.module_helper import ModuleHelper
+from contrastiveseg_amd.lib.models.tools.module_helper import HeadConv3x3, ModuleHelper
 
 
 class HRNet_W48_CONTRAST(nn.Module):
@@ -22,7 +22,7 @@ class HRNet_W48_CONTRAST(nn.Module):
         self.proj_dim = self.configer.get('contrast', 'proj_dim')
         in_channels = self.backbone.num_features          # 720 = 48 + 96 + 192 + 384 for W48
         self.cls_head = nn.Sequential(
-            nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1),
+            HeadConv3x3(in_channels),
             ModuleHelper.BNReLU(in_channels, bn_type=self.configer.get('network', 'bn_type')),
             nn.Dropout2d(0.10),
             nn.Conv2d(in_channels, self.num_classes, kernel_size=1, stride=1, padding=0, bias=False))
@@ -56,7 +56,7 @@ class HRNet_W48_OCR_CONTRAST(nn.Module):
                                                  dropout=0.05, bn_type=bn_type)
         self.cls_head = nn.Conv2d(512, self.num_classes, kernel_size=1, stride=1, padding=0, bias=True)
         self.aux_head = nn.Sequential(
-            nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1),
+            HeadConv3x3(in_channels),
             ModuleHelper.BNReLU(in_channels, bn_type=bn_type),
             nn.Conv2d(in_channels, self.num_classes, kernel_size=1, stride=1, padding=0, bias=True))
         self.proj_head = ProjectionHead(dim_in=in_channels, proj_dim=self.proj_dim)

@@ -26,10 +26,31 @@ class Conv3x3(nn.Conv2d):
 
     def forward(self, x):
         from contrastiveseg_amd import kernels as K
-        if (x.is_cuda and self.stride == (1, 1) and self.dilation == (1, 1) and self.in_channels == self.out_channels
-                and self.in_channels in self.MFMA_CHANNELS and K.conv3x3_eligible(x, self.weight)):
-            return K.conv3x3(x, self.weight)
+        if x.is_cuda and self.stride == (1, 1) and self.dilation == (1, 1) and self.in_channels == self.out_channels:
+            if (K.CONV3X3_SPLIT_BF16 and self.in_channels in K.CONV3X3_SB_BRANCH_CHANNELS
+                    and K.conv3x3_sb_eligible(x, self.weight)
+                    and K.conv3x3_sb_tiles(x, self.out_channels) >= K.CONV3X3_SB_MIN_TILES):
+                return K.conv3x3_split_bf16(x, self.weight)
+            if self.in_channels in self.MFMA_CHANNELS and K.conv3x3_eligible(x, self.weight):
+                return K.conv3x3(x, self.weight)
         return super(Conv3x3, self).forward(x)
+
+
+class HeadConv3x3(nn.Conv2d):
+    """nn.Conv2d(C, C, 3, 1, 1) with bias (same parameters / state_dict) for the 720 -> 720 convolution in front of the
+    classifier (44 % of the forward FLOPs of HRNet-W48-contrast). With kernels.CONV3X3_SPLIT_BF16 on, forward and
+    backward-data run on the split-bf16 MFMA kernel (csrc/conv3x3_sb.hip: 11.0 vs 19.8 ms per direction at bs 8,
+    128x256); otherwise, and for shapes it does not cover, this is the reference's nn.Conv2d on MIOpen."""
+
+    def __init__(self, channels):
+        super(HeadConv3x3, self).__init__(channels, channels, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, x):
+        from contrastiveseg_amd import kernels as K
+        if (x.is_cuda and K.CONV3X3_SPLIT_BF16 and K.conv3x3_sb_eligible(x, self.weight)
+                and K.conv3x3_sb_tiles(x, self.out_channels) >= K.CONV3X3_SB_MIN_TILES):
+            return K.conv3x3_split_bf16(x, self.weight, self.bias)
+        return super(HeadConv3x3, self).forward(x)
 
 
 class ModuleHelper(object):
