@@ -59,6 +59,8 @@ WORKLOADS = {
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense; a split-bf16 ("bf16x6") product costs six bf16 MFMAs
+PEAK_SPLIT_BF16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
 def parse():
@@ -79,6 +81,11 @@ def parse():
                    help="cudnn.benchmark = MIOpen exhaustive find (a 20+ min warm-up on a fresh box); default off: "
                         "immediate mode + the tuned records shipped in contrastiveseg_amd/miopen_db")
     p.add_argument("--channels-last", type=int, default=0)
+    p.add_argument("--conv-arith", choices=["default", "fp32", "split_bf16"], default="default",
+                   help="3x3 convolutions of the head / 48-96 channel branches: fp32 (MIOpen + fp32-MFMA kernel) or "
+                        "split-bf16 x6 on the BF16 matrix cores (fp32-class accuracy); default = the package default")
+    p.add_argument("--no-fp32-pass", action="store_true",
+                   help="skip the extra measurement of the same step with --conv-arith fp32")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernels", action="store_true")
     p.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -229,6 +236,17 @@ def kernel_rooflines(device, B, K=19, H=512, W=1024, stride=4, D=256):
                   time_kernel(lambda: torch.autograd.grad(y2, (x, r), gy, retain_graph=True)), bytes_=7 * nb)
             del y2
         del bn, x, r, y, gy
+    # split-bf16 3x3 convolution at the head's shape (forward = backward-data): fp32-equivalent flops vs 2500/6 TF/s
+    C = 720
+    xh = torch.randn(B, C, h, w, device=device)
+    wh = torch.randn(C, C, 3, 3, device=device) / (3.0 * C ** 0.5)
+    us = time_kernel(lambda: Kn.conv3x3_sb_run(xh, wh, False), iters=5, warm=2)
+    fl = 2.0 * B * h * w * C * C * 9
+    out["conv3x3_split_bf16 720->720 (pack + conv)"] = {
+        "us": round(us, 1), "bound": "mfma", "flops": int(fl), "achieved_TFLOPs": round(fl / us * 1e-6, 1),
+        "peak_TFLOPs": round(PEAK_SPLIT_BF16_TFLOPS, 1), "frac": round(fl / us * 1e-6 / PEAK_SPLIT_BF16_TFLOPS, 4),
+        "note": "fp32-equivalent flops; six v_mfma_f32_16x16x32_bf16 per product; MIOpen fp32 at this shape: 19.8 ms"}
+    del xh, wh
     return out
 
 
@@ -384,6 +402,11 @@ def main():
     device = torch.device("cuda", local)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
+    from contrastiveseg_amd import kernels as Kn
+    if args.conv_arith != "default":
+        Kn.CONV3X3_SPLIT_BF16 = args.conv_arith == "split_bf16"
+    split_on = bool(Kn.CONV3X3_SPLIT_BF16)
+
     wl = WORKLOADS[args.workload]
     base_batch = args.global_batch or wl["batch"]
     global_batch = base_batch * world if args.scaling == "weak" else base_batch
@@ -393,6 +416,18 @@ def main():
     elapsed = torch.tensor([time.perf_counter() - t_start], device=device)
     if world > 1:
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)      # same decision on every rank
+
+    # the same step with the 3x3 convolutions on the pure fp32 path (MIOpen + fp32-MFMA kernel), same trainer, same
+    # batch: what the split-bf16 kernels buy, measured under the same clock
+    fp32_pass = None
+    if split_on and not args.no_fp32_pass:
+        Kn.CONV3X3_SPLIT_BF16 = False
+        f_steps = max(3, args.steps // 2)
+        f_dt, _, _ = timed_steps(tr, batch, f_steps, 2, world, device)
+        Kn.CONV3X3_SPLIT_BF16 = True
+        fp32_pass = {"value": round(global_batch * f_steps / f_dt, 3), "unit": "images/sec", "steps": f_steps, "warmup": 2,
+                     "ms_per_step": round(f_dt * 1e3 / f_steps, 3),
+                     "conv3x3_arithmetic": "fp32 (MIOpen + fp32-MFMA kernel)"}
 
     weak = None
     # extra weak-scaling pass: RCCL runs only (the gloo dry run shares one GPU between the ranks and says nothing about
@@ -448,14 +483,21 @@ def main():
                        "cross_rank_contrast_set": bool(world > 1 and cfg.exists("contrast", "cross_rank")
                                                        and cfg.get("contrast", "cross_rank")),
                        "backend": (torch.distributed.get_backend() if world > 1 else None),
+                       "conv3x3_arithmetic": ("split-bf16 x6 on the BF16 matrix cores (fp32 in/out, six bf16 piece "
+                                              "products per fp32 product, fp32 accumulate; fp32-class accuracy: "
+                                              "tools/split_bf16_probe.py, tests/test_gpu_conv3x3_sb.py) for the "
+                                              "720->720 head convolution and the 48/96-channel branches, forward + "
+                                              "backward-data; everything else fp32") if split_on else "fp32",
                        "miopen_find": bool(args.miopen_find), "channels_last": bool(args.channels_last),
                        "final_loss": round(final_loss, 5)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "note": "whole step: images/s (HIP-event time %.1f ms/step) x %.4f TFLOP/image vs fp32 MFMA "
-                                 "peak; per-kernel rooflines of the hand-written HIP kernels under 'kernels'"
+                         "note": "whole step: images/s (HIP-event time %.1f ms/step) x %.4f TFLOP/image of fp32-equivalent "
+                                 "work vs the fp32 MFMA peak (the roof of a pure fp32 implementation; the split-bf16 "
+                                 "convolutions run on the bf16 pipe at 6 MFMAs per product, roof 2500/6 = 417 TF/s for "
+                                 "that share of the work); per-kernel rooflines under 'kernels'"
                                  % (ev_ms / args.steps, wl["tflop"])},
-            "weak": weak, "cpu_baseline": cpu, "kernels": kernels,
+            "fp32_conv_path": fp32_pass, "weak": weak, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -25,7 +25,10 @@
 //   C: 4 pixel tiles x NT channel tiles of 16x16 per wave; six MFMAs per (pixel tile, channel tile, K-step), smallest
 //       terms first. Lane holds 4 consecutive pixels of one channel per accumulator -> 16-byte stores.
 // Backward-data is the same kernel on weights packed transposed and mirrored.
-// Status: opt-in (CSEG_CONV3X3_SPLIT_BF16=1); the fp32-MFMA kernel of conv3x3.hip and MIOpen remain the default path.
+// Measured on MI355X (tools/conv3x3_sb_probe.py, profiles/r02_conv3x3_split_bf16_probe.jsonl): 720->720 at 8x128x256
+// 10.97 ms forward / 10.93 ms backward-data incl. weight packing = 223 TFLOP/s fp32-equivalent (0.53 of 417) vs MIOpen's
+// fp32 kernel 19.81 ms (123.5 TFLOP/s); 96 ch 70 vs 101 us; 48 ch 99 vs 106 us (fp32-MFMA kernel) / 141 us (MIOpen).
+// Switch: kernels.CONV3X3_SPLIT_BF16 (env CSEG_CONV3X3_SPLIT_BF16, default 1; 0 = the fp32 MFMA / MIOpen path).
 #include "cseg_common.h"
 #include <stdlib.h>
 

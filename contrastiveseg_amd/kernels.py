@@ -600,10 +600,10 @@ def conv3x3(x, weight):
 
 
 # ----------------------------------------------------------------------------------------------------------
-# The same convolution on the BF16 matrix cores with split operands (csrc/conv3x3_sb.hip): opt-in
+# The same convolution on the BF16 matrix cores with split operands (csrc/conv3x3_sb.hip); on by default
 # ----------------------------------------------------------------------------------------------------------
 # module-level switch (read at call time by the modules, so bench.py / tests can flip it inside one process)
-CONV3X3_SPLIT_BF16 = os.environ.get("CSEG_CONV3X3_SPLIT_BF16", "0") == "1"
+CONV3X3_SPLIT_BF16 = os.environ.get("CSEG_CONV3X3_SPLIT_BF16", "1") == "1"
 # bias-free residual-branch convolutions that move to the split kernel when the switch is on (measured on MI355X at the
 # benched shapes, tools/conv3x3_sb_probe.py: 96 ch 70 vs 101 us; 48 ch 99 vs 106 us on the fp32-MFMA kernel)
 CONV3X3_SB_BRANCH_CHANNELS = (48, 96)

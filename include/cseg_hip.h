@@ -239,8 +239,8 @@ int cseg_conv3x3_wrw(const float* x, const float* dy, int B, int Cin, int Cout, 
  * one are accumulated in fp32 by v_mfma_f32_16x16x32_bf16 -- fp32-class accuracy (tools/split_bf16_probe.py) at up to
  * 2500/6 = 417 TFLOP/s of fp32-equivalent work instead of the 157 TFLOP/s fp32 MFMA rate.  Replaces nn.Conv2d -> MIOpen
  * for the 720 -> 720 head convolution (lib/models/nets/hrnet.py:72-77 of the reference) and the HRNet branch
- * convolutions.  Cin % 16 == 0, Cout % 48 == 0, W % 4 == 0.  Opt-in (CSEG_CONV3X3_SPLIT_BF16=1) until it has been
- * through the full parity suite on hardware.
+ * convolutions.  Cin % 16 == 0, Cout % 48 == 0, W % 4 == 0.  The host side uses it by default
+ * (CSEG_CONV3X3_SPLIT_BF16=0 switches back to fp32 MFMA / MIOpen).
  *   cseg_conv3x3_sb_pack_weights: w [Cout,Cin,3,3] -> wp (cseg_conv3x3_sb_packed_bytes bytes, 16-byte aligned): split and
  *       laid out in MFMA lane order; transpose_flip = 1 packs the backward-data operator (maps Cout -> Cin channels);
  *       cseg_conv3x3_sb_packed_bytes(conv_in, conv_out) takes the channel counts of the PACKED operator.
