@@ -1,0 +1,320 @@
+// Weight gradient of the 3x3 / stride 1 / pad 1 convolution on the BF16 matrix cores with split operands ("bf16x6",
+// see conv3x3_sb.hip for the arithmetic):  dW[co][ci][ky][kx] = sum_{b,y,x} dy[b][co][y][x] * x[b][ci][y+ky-1][x+kx-1].
+// GEMM per tap: M = co, N = ci, K = pixels -- the contraction index is the contiguous dimension of both NCHW operands,
+// so a lane's fragment (8 consecutive k) is 8 consecutive pixels of one channel: one aligned ds_read_b128 from an LDS
+// image [piece][channel][pixel] of bf16.
+//
+// Block = 8 waves = a 48 (co) x 64 (ci) channel block x all 9 taps, fed with row segments of 64 pixels:
+//   wave = (ci tile = wave & 3, K-slice = wave >> 2); a K-slice is 32 pixels = one K-step of v_mfma_f32_16x16x32_bf16.
+//   Per row-step a wave loads 3 co tiles x 3 pieces of dy (9 reads) and, per filter row ky, 3 pieces of its x row
+//   (one b128 + one b32 each): the three horizontal taps are the same 10 pixels shifted by 0 / 1 / 2 elements, built in
+//   registers (v_alignbit for the odd shift, a register rename for the even one) instead of three shifted LDS copies.
+//   27 accumulators (9 taps x 3 co tiles), 162 MFMAs per wave and row-step, term-major so that 9 independent
+//   accumulators separate two MFMAs on the same one.
+//   x rows live in a 3-slot ring per K-slice (row r in slot (r + 3) % 3): walking down a run of rows stages ONE new x row
+//   and one dy row per step; both are fetched into registers before the MFMAs of the current row and split + written
+//   to LDS after them (two barriers per row-step; the image is single-buffered: 113 KB).
+//   At the end the two K-slices of a channel tile are summed through LDS and the block writes its partial
+//   [split][tap][co][ci]; splits are summed in a fixed order by a second kernel: deterministic, no atomics.
+// Work split: unit = (image, 64-pixel column segment, run of ROWS_PER_UNIT rows); split s takes units s, s + n_split, ...
+// Status: written and index-checked against a numpy lane model in round 2, NOT yet run on hardware (the round's GPU
+// budget was spent); opt-in through kernels.CONV3X3_SB_WRW, off by default.
+#include "cseg_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int CO_B = 48, CI_B = 64, SEG = 64;
+constexpr int XP = 40;                 // LDS pitch of one x row (bf16 elements): entry i = pixel x0s - 1 + i, i < 34
+constexpr int DP = 72;                 // LDS pitch of one dy row segment (64 pixels + pad)
+constexpr int XS_ELEMS = 2 * 3 * CI_B * 3 * XP;      // [slice][piece][ci][ring slot][XP]
+constexpr int DS_ELEMS = 3 * CO_B * DP;              // [piece][co][DP]
+constexpr int ROWS_PER_UNIT = 8;
+
+__device__ __forceinline__ int xs_idx(int s, int p, int ci, int slot, int i) { return (((s * 3 + p) * CI_B + ci) * 3 + slot) * XP + i; }
+__device__ __forceinline__ int ds_idx(int p, int co, int i) { return (p * CO_B + co) * DP + i; }
+
+__device__ __forceinline__ void split3w(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const __bf16 bh = (__bf16)v;
+    const float r1 = v - (float)bh;
+    const __bf16 bm = (__bf16)r1;
+    const float r2 = r1 - (float)bm;
+    const __bf16 bl = (__bf16)r2;
+    h = __builtin_bit_cast(unsigned short, bh);
+    m = __builtin_bit_cast(unsigned short, bm);
+    l = __builtin_bit_cast(unsigned short, bl);
+}
+
+__device__ __forceinline__ void split8w(const float (&v)[8], uint4& h, uint4& m, uint4& l) {
+    unsigned short hs[8], ms[8], ls[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split3w(v[j], hs[j], ms[j], ls[j]);
+    h = make_uint4(hs[0] | ((unsigned)hs[1] << 16), hs[2] | ((unsigned)hs[3] << 16), hs[4] | ((unsigned)hs[5] << 16),
+                   hs[6] | ((unsigned)hs[7] << 16));
+    m = make_uint4(ms[0] | ((unsigned)ms[1] << 16), ms[2] | ((unsigned)ms[3] << 16), ms[4] | ((unsigned)ms[5] << 16),
+                   ms[6] | ((unsigned)ms[7] << 16));
+    l = make_uint4(ls[0] | ((unsigned)ls[1] << 16), ls[2] | ((unsigned)ls[3] << 16), ls[4] | ((unsigned)ls[5] << 16),
+                   ls[6] | ((unsigned)ls[7] << 16));
+}
+
+__global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                int B, int Cin, int Cout, int H, int W, int n_split,
+                                                                float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_w[];
+    unsigned short* xs = smem_w;
+    unsigned short* ds = smem_w + XS_ELEMS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int sl = wave & 3, ksl = wave >> 2;          // ci tile of the block, K-slice
+    const int g = lane >> 4, n = lane & 15;
+    int blk = blockIdx.x;
+    const int split = blk % n_split; blk /= n_split;
+    const int n_cib = (Cin + CI_B - 1) / CI_B;
+    const int cib = blk % n_cib;
+    const int cob = blk / n_cib;
+    const size_t plane = (size_t)H * W;
+    const int segs = W / SEG;
+    const int runs = (H + ROWS_PER_UNIT - 1) / ROWS_PER_UNIT;
+    const int n_units = B * segs * runs;
+    const bool tile_ok = cib * CI_B + sl * 16 < Cin;   // ragged last channel block: this wave has no tile
+
+    f32x4 acc[9][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- staging: x row items (slice, ci, octet of 8 entries; 5 octets cover the 34 entries), dy row items (co, octet)
+    float xpre[2][8], dpre[8];
+    auto x_item = [&](int u, int& s, int& ci, int& q) {
+        const int item = tid + 512 * u;                // 640 items
+        q = item % 5;
+        ci = (item / 5) % CI_B;
+        s = item / (5 * CI_B);                         // 0, 1 (>= 2: no item)
+    };
+    auto x_issue = [&](int b, int x0, int row) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int s, ci, q;
+            x_item(u, s, ci, q);
+            const int cic = min(cib * CI_B + ci, Cin - 1), rowc = min(max(row, 0), H - 1), sc = min(s, 1);
+            const float* p = x + ((size_t)b * Cin + cic) * plane + (size_t)rowc * W;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int px = x0 + 32 * sc - 1 + 8 * q + j;
+                xpre[u][j] = p[min(max(px, 0), W - 1)];                 // raw; masked when it is stored
+            }
+        }
+    };
+    auto x_store = [&](int x0, int row) {
+        const int slot = (row + 3) % 3;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int s, ci, q;
+            x_item(u, s, ci, q);
+            if (s < 2) {
+                const bool ch_ok = cib * CI_B + ci < Cin && row >= 0 && row < H;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = 8 * q + j, px = x0 + 32 * s - 1 + i;
+                    v[j] = (ch_ok && i < 34 && px >= 0 && px < W) ? xpre[u][j] : 0.f;
+                }
+                uint4 h, m, l;
+                split8w(v, h, m, l);
+                *reinterpret_cast<uint4*>(xs + xs_idx(s, 0, ci, slot, 8 * q)) = h;
+                *reinterpret_cast<uint4*>(xs + xs_idx(s, 1, ci, slot, 8 * q)) = m;
+                *reinterpret_cast<uint4*>(xs + xs_idx(s, 2, ci, slot, 8 * q)) = l;
+            }
+        }
+    };
+    auto d_issue = [&](int b, int x0, int row) {
+        const int item = min(tid, CO_B * 8 - 1);       // 384 items: (co, octet)
+        const int co = item >> 3, q = item & 7;
+        const float* p = dy + (((size_t)b * Cout + cob * CO_B + co) * H + min(row, H - 1)) * W + x0 + 8 * q;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dpre[j] = p[j];
+    };
+    auto d_store = [&](int row) {
+        if (tid < CO_B * 8) {
+            const int co = tid >> 3, q = tid & 7;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = row < H ? dpre[j] : 0.f;
+            uint4 h, m, l;
+            split8w(v, h, m, l);
+            *reinterpret_cast<uint4*>(ds + ds_idx(0, co, 8 * q)) = h;
+            *reinterpret_cast<uint4*>(ds + ds_idx(1, co, 8 * q)) = m;
+            *reinterpret_cast<uint4*>(ds + ds_idx(2, co, 8 * q)) = l;
+        }
+    };
+
+    // ---- one row-step of this wave: output row `row` of the segment, K-slice ksl
+    auto compute = [&](int row) {
+        bf16x8 a[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                a[c][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ds + ds_idx(p, c * 16 + n, 32 * ksl + 8 * g)));
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int slot = (row + ky - 1 + 3) % 3;
+            bf16x8 bfr[3][3];                          // [kx][piece]
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const unsigned short* src = xs + xs_idx(ksl, p, sl * 16 + n, slot, 8 * g);
+                const uint4 c4 = *reinterpret_cast<const uint4*>(src);              // entries 8g .. 8g+7   (kx = 0)
+                const unsigned nx = *reinterpret_cast<const unsigned*>(src + 8);    // entries 8g+8, 8g+9
+                const uint4 s1 = make_uint4(__builtin_amdgcn_alignbit(c4.y, c4.x, 16), __builtin_amdgcn_alignbit(c4.z, c4.y, 16),
+                                            __builtin_amdgcn_alignbit(c4.w, c4.z, 16), __builtin_amdgcn_alignbit(nx, c4.w, 16));
+                const uint4 s2 = make_uint4(c4.y, c4.z, c4.w, nx);
+                bfr[0][p] = __builtin_bit_cast(bf16x8, c4);
+                bfr[1][p] = __builtin_bit_cast(bf16x8, s1);
+                bfr[2][p] = __builtin_bit_cast(bf16x8, s2);
+            }
+#define SBW_TERM(P, Q)                                                                                          \
+    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) _Pragma("unroll") for (int c = 0; c < 3; ++c)             \
+        acc[ky * 3 + kx][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[c][P], bfr[kx][Q], acc[ky * 3 + kx][c], 0, 0, 0);
+            SBW_TERM(2, 0)
+            SBW_TERM(0, 2)
+            SBW_TERM(1, 1)
+            SBW_TERM(1, 0)
+            SBW_TERM(0, 1)
+            SBW_TERM(0, 0)
+#undef SBW_TERM
+        }
+    };
+
+    for (int unit = split; unit < n_units; unit += n_split) {
+        int t = unit;
+        const int run = t % runs; t /= runs;
+        const int seg = t % segs;
+        const int b = t / segs;
+        const int x0 = seg * SEG, ya = run * ROWS_PER_UNIT, yb = min(ya + ROWS_PER_UNIT, H);
+        // prologue: x rows ya-1, ya, ya+1 and dy row ya (the previous unit's last barrier has released the image)
+#pragma unroll 1
+        for (int r = ya - 1; r <= ya + 1; ++r) {
+            x_issue(b, x0, r);
+            x_store(x0, r);
+        }
+        d_issue(b, x0, ya);
+        d_store(ya);
+        __syncthreads();
+#pragma unroll 1
+        for (int row = ya; row < yb; ++row) {
+            const bool more = row + 1 < yb;
+            if (more) {
+                x_issue(b, x0, row + 2);
+                d_issue(b, x0, row + 1);
+            }
+            if (tile_ok) compute(row);
+            __syncthreads();                           // all reads of this row-step are done
+            if (more) {
+                x_store(x0, row + 2);                  // slot of row - 1
+                d_store(row + 1);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- sum the two K-slices of every channel tile through LDS (the operand image is dead), then write the partial
+    float* red = reinterpret_cast<float*>(smem_w);     // [ci tile 4][27][64 lanes][4]
+    if (ksl == 1 && tile_ok) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                *reinterpret_cast<f32x4*>(red + (((sl * 27) + t * 3 + c) * 64 + lane) * 4) = acc[t][c];
+    }
+    __syncthreads();
+    if (ksl == 0 && tile_ok) {
+        const int ci = cib * CI_B + sl * 16 + n;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const f32x4 o = *reinterpret_cast<const f32x4*>(red + (((sl * 27) + t * 3 + c) * 64 + lane) * 4);
+                const f32x4 v = acc[t][c] + o;
+                // D[m = 4g + r][n]: co = cob*48 + 16c + 4g + r, ci = this lane's column
+                float* dst = partial + (((size_t)split * 9 + t) * Cout + cob * CO_B + c * 16 + 4 * g) * Cin + ci;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(size_t)r * Cin] = v[r];
+            }
+    }
+}
+
+// dW[co][ci][tap] = sum over splits of partial[split][tap][co][ci], fixed order (same scheme as conv3x3.hip)
+__global__ __launch_bounds__(256) void sb_wrw_reduce_kernel(const float* __restrict__ partial, int n_split, int Cout, int Cin,
+                                                            float* __restrict__ dw) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;                  // e = (tap * Cout + co) * Cin + ci
+    const int total = 9 * Cout * Cin;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < total) {
+        int sp = wave;
+        for (; sp + 12 < n_split; sp += 16) {
+            s0 += partial[(size_t)sp * total + e];
+            s1 += partial[(size_t)(sp + 4) * total + e];
+            s2 += partial[(size_t)(sp + 8) * total + e];
+            s3 += partial[(size_t)(sp + 12) * total + e];
+        }
+        for (; sp < n_split; sp += 4) s0 += partial[(size_t)sp * total + e];
+    }
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && e < total) {
+        const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        const int ci = e % Cin, rest = e / Cin;
+        const int co = rest % Cout, tap = rest / Cout;
+        dw[((size_t)co * Cin + ci) * 9 + tap] = v;
+    }
+}
+
+int sb_wrw_splits(int B, int Cin, int Cout, int H, int W) {
+    const int units = B * (W / SEG) * ((H + ROWS_PER_UNIT - 1) / ROWS_PER_UNIT);
+    const int pairs = ((Cin + CI_B - 1) / CI_B) * (Cout / CO_B);
+    int n = (768 + pairs - 1) / pairs;               // ~3 blocks per CU in total
+    if (n > 256) n = 256;                            // bounds the partial buffer (256 x 9 x Cout x Cin floats)
+    if (n > units) n = units;
+    if (n < 1) n = 1;
+    return n;
+}
+
+}  // namespace
+
+extern "C" size_t cseg_conv3x3_sb_wrw_ws_floats(int B, int Cin, int Cout, int H, int W) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || Cin % 16 || Cout % CO_B || W % SEG) return 0;
+    return (size_t)sb_wrw_splits(B, Cin, Cout, H, W) * 9 * Cin * Cout;
+}
+
+extern "C" int cseg_conv3x3_sb_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, float* ws,
+                                   float* dw, cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CSEG_REQUIRE(x && dy && ws && dw, "conv3x3_sb_wrw: null pointer");
+    CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % CO_B == 0 && W % SEG == 0,
+                 "conv3x3_sb_wrw: unsupported shape B=%d Cin=%d Cout=%d %dx%d (needs Cin %% 16, Cout %% 48, W %% 64)", B, Cin,
+                 Cout, H, W);
+    const int n_split = sb_wrw_splits(B, Cin, Cout, H, W);
+    const long blocks = (long)n_split * ((Cin + CI_B - 1) / CI_B) * (Cout / CO_B);
+    CSEG_REQUIRE(blocks < 2147483647L && (long)9 * Cin * Cout < 2147483647L, "conv3x3_sb_wrw: grid too large");
+    const size_t lds = sizeof(unsigned short) * (XS_ELEMS + DS_ELEMS);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv3x3_sb_wrw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            cseg_set_error("conv3x3_sb_wrw: cannot raise dynamic LDS to %zu bytes", lds);
+            return 0;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_sb_wrw_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, x, dy, B, Cin, Cout, H, W,
+                       n_split, ws);
+    CSEG_CHECK_LAUNCH("conv3x3_sb_wrw_kernel");
+    const int total = 9 * Cin * Cout;
+    hipLaunchKernelGGL(sb_wrw_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, ws, n_split, Cout, Cin, dw);
+    CSEG_CHECK_LAUNCH("sb_wrw_reduce_kernel");
+    return 1;
+}

@@ -648,6 +648,32 @@ def conv3x3_sb_tiles(x, c_out):
     return x.shape[0] * (c_out // nt16) * ((x.shape[2] + 3) // 4) * ((x.shape[3] + 63) // 64)
 
 
+# Weight gradient on the split-bf16 kernel (csrc/conv3x3_sb_wrw.hip): written and index-checked in round 2, first hardware
+# run pending -> off unless CSEG_CONV3X3_SB_WRW=1
+CONV3X3_SB_WRW = os.environ.get("CSEG_CONV3X3_SB_WRW", "0") == "1"
+
+
+def conv3x3_sb_wrw_eligible(x, dy):
+    return (x.is_cuda and x.dtype == F32 and dy.dtype == F32 and x.is_contiguous() and dy.is_contiguous()
+            and x.shape[1] % 16 == 0 and dy.shape[1] % 48 == 0 and x.shape[3] % 64 == 0)
+
+
+@torch.no_grad()
+def conv3x3_sb_wrw(x, dy):
+    """dw [Cout,Cin,3,3] of conv2d(x, w, stride 1, padding 1) for the output gradient dy, split-bf16 MFMA kernel."""
+    B, ci, H, W = x.shape
+    co = dy.shape[1]
+    lib = _hip.lib()
+    n = lib.cseg_conv3x3_sb_wrw_ws_floats(B, ci, co, H, W)
+    if n == 0:
+        raise RuntimeError("conv3x3_sb_wrw: unsupported shape %s x %s" % (tuple(x.shape), tuple(dy.shape)))
+    ws = torch.empty(n, dtype=F32, device=x.device)
+    dw = torch.empty(co, ci, 3, 3, dtype=F32, device=x.device)
+    _hip.call("cseg_conv3x3_sb_wrw", _p(x, F32, "x"), _p(dy, F32, "dy"), B, ci, co, H, W, _pf(ws), _pf(dw),
+              _hip.stream_ptr())
+    return dw
+
+
 class Conv3x3SplitBF16(Function):
     """y = conv2d(x, weight, bias, stride 1, padding 1): forward and backward-data on the split-bf16 MFMA kernel; the
     weight gradient on the fp32-MFMA kernel where that one is used today (bias-free 48/96-channel branches), otherwise
@@ -669,7 +695,10 @@ class Conv3x3SplitBF16(Function):
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_db:
             co, ci = weight.shape[:2]
-            if not ctx.has_bias and co == ci and co in CONV3X3_WRW_CHANNELS:
+            if CONV3X3_SB_WRW and conv3x3_sb_wrw_eligible(x, dy):
+                dw = conv3x3_sb_wrw(x, dy) if ctx.needs_input_grad[1] else None
+                db = dy.sum((0, 2, 3)) if want_db else None
+            elif not ctx.has_bias and co == ci and co in CONV3X3_WRW_CHANNELS:
                 dw = _conv3x3_wrw(x, dy, co, ci)
             else:
                 _, dw, db = torch.ops.aten.convolution_backward(

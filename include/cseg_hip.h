@@ -251,6 +251,15 @@ int cseg_conv3x3_sb_pack_weights(const float* w, int Cout, int Cin, int transpos
 int cseg_conv3x3_sb_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
                         float* y, cseg_stream_t stream);
 
+/* weight gradient of the same convolution on the split-bf16 path: dw [Cout,Cin,3,3] = sum_{b,y,x} dy * shifted x.
+ * Cin % 16 == 0, Cout % 48 == 0, W % 64 == 0.  ws: cseg_conv3x3_sb_wrw_ws_floats(...) floats of scratch (per-split
+ * partials, summed in a fixed order: deterministic).  Replaces MIOpen's NHWC implicit-GEMM weight-gradient kernels
+ * (+ 3 layout transposes) behind nn.Conv2d.  Written in round 2, first hardware run pending: the host side keeps it
+ * opt-in (kernels.CONV3X3_SB_WRW). */
+size_t cseg_conv3x3_sb_wrw_ws_floats(int B, int Cin, int Cout, int H, int W);
+int cseg_conv3x3_sb_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, float* ws, float* dw,
+                        cseg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * GPU data pipeline: random resize (cv2 INTER_CUBIC image / INTER_NEAREST label) -> random
  * crop -> horizontal flip -> brightness shift -> ToTensor + Normalize(div, mean, std) + label look-up + ReLabel(255,-1)

@@ -1,5 +1,7 @@
 """Split-bf16 ("bf16x6") 3x3 convolution on the BF16 matrix cores (csrc/conv3x3_sb.hip) against an fp64 convolution,
 with MIOpen's fp32 convolution of the same operands as the yardstick for "fp32 rounding class"."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -69,3 +71,33 @@ def test_autograd_matches_fp64(case):
                                  ("db", b64.grad, bd.grad, br.grad)):
         err, tol = _bound(g64, got.cpu(), fp32.cpu())
         assert err <= tol, (case, name, err, tol)
+
+
+WRW_CASES = [  # B, Cin, Cout, H, W
+    (1, 48, 48, 5, 64),         # ragged 64-wide channel block (3 of 4 tiles), one run
+    (2, 16, 48, 9, 128),        # two column segments, two runs (8 + 1 rows)
+    (1, 80, 96, 3, 64),         # two channel blocks each way
+    (2, 96, 96, 16, 64),
+    (1, 720, 720, 8, 64),       # the head's channel count
+]
+
+
+@pytest.mark.skipif(os.environ.get("CSEG_TEST_SB_WRW") != "1",
+                    reason="split-bf16 weight gradient: first hardware run pending (CSEG_TEST_SB_WRW=1)")
+@pytest.mark.parametrize("case", WRW_CASES)
+def test_weight_gradient_matches_fp64(case):
+    from contrastiveseg_amd import kernels as K
+    B, ci, co, H, W = case
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, ci, H, W, generator=g)
+    dy = torch.randn(B, co, H, W, generator=g)
+    w64 = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w64, None, 1, 1).backward(dy.double())
+    xd, dyd = x.cuda(), dy.cuda()
+    assert K.conv3x3_sb_wrw_eligible(xd, dyd)
+    got = K.conv3x3_sb_wrw(xd, dyd)
+    wr = torch.zeros(co, ci, 3, 3, device="cuda", requires_grad=True)
+    F.conv2d(xd, wr, None, 1, 1).backward(dyd)
+    err, tol = _bound(w64.grad, got.cpu(), wr.grad.cpu())
+    assert err <= tol, (case, err, tol)
+    assert torch.equal(got, K.conv3x3_sb_wrw(xd, dyd)), "weight gradient not deterministic"
