@@ -55,6 +55,8 @@ SIGNATURES = {
     "cseg_conv3x3_sb_packed_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
     "cseg_conv3x3_sb_pack_weights": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr]),
     "cseg_conv3x3_sb_fwd": (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    "cseg_conv3x3_sb_pack_weights_nt": (_c_int, [_ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    "cseg_conv3x3_sb_fwd_nt": (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
     "cseg_conv3x3_sb_wrw_ws_floats": (ctypes.c_size_t, [_c_int] * 5),
     "cseg_conv3x3_sb_wrw": (_c_int, [_ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "cseg_augment_batch": (_c_int, [_ptr, _ptr, _ptr, _ptr] + [_c_int] * 5 + [_c_float, _ptr, _ptr, _ptr, _ptr, _ptr]),

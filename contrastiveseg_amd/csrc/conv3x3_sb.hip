@@ -331,6 +331,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
 
 // channel tiles per block: the largest of {9, 6, 3} x 16 that divides Cout
 int pick_nt(int Cout) {
+    const char* e = getenv("CSEG_CONV3X3_SB_NT");          // tuning override (must divide Cout / 16)
+    if (e) {
+        const int nt = atoi(e);
+        if ((nt == 3 || nt == 6 || nt == 9) && Cout % (nt * 16) == 0) return nt;
+    }
     if (Cout % 144 == 0) return 9;
     if (Cout % 96 == 0) return 6;
     if (Cout % 48 == 0) return 3;
@@ -361,19 +366,21 @@ int launch_sb(const float* x, const uint4* wp, const float* bias, int B, int Cin
 
 }  // namespace
 
+namespace {
+bool nt_ok(int nt, int Cout) { return (nt == 3 || nt == 6 || nt == 9) && Cout % (nt * 16) == 0; }
+}  // namespace
+
 extern "C" size_t cseg_conv3x3_sb_packed_bytes(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0 || Cin % 16 || pick_nt(Cout) == 0) return 0;
     return (size_t)(Cout / 16) * steps_of(Cin) * 3 * 64 * sizeof(uint4);
 }
 
-extern "C" int cseg_conv3x3_sb_pack_weights(const float* w, int Cout, int Cin, int transpose_flip, void* wp,
-                                            cseg_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static int pack_impl(const float* w, int Cout, int Cin, int transpose_flip, int NT, void* wp, hipStream_t stream) {
     // transpose_flip: w is still the forward's [Cout, Cin, 3, 3]; the packed operator maps Cout -> Cin channels
     const int conv_in = transpose_flip ? Cout : Cin, conv_out = transpose_flip ? Cin : Cout;
     CSEG_REQUIRE(w && wp, "conv3x3_sb_pack_weights: null pointer");
-    const int NT = pick_nt(conv_out);
-    CSEG_REQUIRE(conv_in % 16 == 0 && NT > 0,
+    if (NT == 0) NT = pick_nt(conv_out);
+    CSEG_REQUIRE(conv_in % 16 == 0 && NT > 0 && nt_ok(NT, conv_out),
                  "conv3x3_sb: needs input channels %% 16 == 0 and output channels %% 48 == 0 (got %d -> %d)", conv_in, conv_out);
     CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0, "conv3x3_sb_pack_weights: packed buffer must be 16-byte aligned");
     const long total = (long)(conv_out / 16) * steps_of(conv_in) * 64;
@@ -384,12 +391,24 @@ extern "C" int cseg_conv3x3_sb_pack_weights(const float* w, int Cout, int Cin, i
     return 1;
 }
 
-extern "C" int cseg_conv3x3_sb_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H,
-                                   int W, float* y, cseg_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+extern "C" int cseg_conv3x3_sb_pack_weights(const float* w, int Cout, int Cin, int transpose_flip, void* wp,
+                                            cseg_stream_t stream_) {
+    return pack_impl(w, Cout, Cin, transpose_flip, 0, wp, (hipStream_t)stream_);
+}
+
+// explicit channel tiles per block (3, 6 or 9; must divide conv_out / 16): lets the caller trade the block's reuse of the
+// staged patch against the number of blocks (192 channels at 8x32x64: NT = 3 gives 256 blocks, 81 vs 113 us at NT = 6)
+extern "C" int cseg_conv3x3_sb_pack_weights_nt(const float* w, int Cout, int Cin, int transpose_flip, int nt, void* wp,
+                                               cseg_stream_t stream_) {
+    CSEG_REQUIRE(nt == 3 || nt == 6 || nt == 9, "conv3x3_sb_pack_weights_nt: nt must be 3, 6 or 9 (got %d)", nt);
+    return pack_impl(w, Cout, Cin, transpose_flip, nt, wp, (hipStream_t)stream_);
+}
+
+static int fwd_impl(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int NT,
+                    float* y, hipStream_t stream) {
     CSEG_REQUIRE(x && wp && y, "conv3x3_sb: null pointer");
-    const int NT = pick_nt(Cout);
-    CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && NT > 0,
+    if (NT == 0) NT = pick_nt(Cout);
+    CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && NT > 0 && nt_ok(NT, Cout),
                  "conv3x3_sb: unsupported shape B=%d Cin=%d Cout=%d %dx%d", B, Cin, Cout, H, W);
     CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && W % 4 == 0,
                  "conv3x3_sb: packed weights / output must be 16-byte aligned and W a multiple of 4");
@@ -409,4 +428,15 @@ extern "C" int cseg_conv3x3_sb_fwd(const float* x, const void* wp, const float* 
         case 6: return launch_sb<6, false>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
         default: return launch_sb<3, false>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
     }
+}
+
+extern "C" int cseg_conv3x3_sb_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H,
+                                   int W, float* y, cseg_stream_t stream_) {
+    return fwd_impl(x, wp, bias, B, Cin, Cout, H, W, 0, y, (hipStream_t)stream_);
+}
+
+extern "C" int cseg_conv3x3_sb_fwd_nt(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H,
+                                      int W, int nt, float* y, cseg_stream_t stream_) {
+    CSEG_REQUIRE(nt == 3 || nt == 6 || nt == 9, "conv3x3_sb_fwd_nt: nt must be 3, 6 or 9 (got %d)", nt);
+    return fwd_impl(x, wp, bias, B, Cin, Cout, H, W, nt, y, (hipStream_t)stream_);
 }

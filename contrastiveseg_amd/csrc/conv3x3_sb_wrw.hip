@@ -17,8 +17,12 @@
 //   At the end the two K-slices of a channel tile are summed through LDS and the block writes its partial
 //   [split][tap][co][ci]; splits are summed in a fixed order by a second kernel: deterministic, no atomics.
 // Work split: unit = (image, 64-pixel column segment, run of ROWS_PER_UNIT rows); split s takes units s, s + n_split, ...
-// Status: written and index-checked against a numpy lane model in round 2, NOT yet run on hardware (the round's GPU
-// budget was spent); opt-in through kernels.CONV3X3_SB_WRW, off by default.
+// Measured on MI355X (tools/conv3x3_sb_wrw_probe.py, profiles/r02_conv3x3_split_bf16_wrw_probe.jsonl), kernel + reduction:
+// 48 ch @8x128x256 108 us (fp32-MFMA kernel 164, MIOpen 201); 96 ch @8x64x128 112 us (152 / 148); 720 ch @8x128x256
+// 17.6 ms vs MIOpen 19.5 ms -- at 720 channels the 48x64 channel block re-reads both operands 12-15 times and the kernel
+// is bandwidth-bound; a wider block / XCD-local ordering of the blocks that share pixels is the next step.
+// Parity vs fp64 and determinism: tests/test_gpu_conv3x3_sb.py. Host side: opt-in (kernels.CONV3X3_SB_WRW) until the
+// one-SGD-step goldens have run on it.
 #include "cseg_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

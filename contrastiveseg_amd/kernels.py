@@ -606,7 +606,10 @@ def conv3x3(x, weight):
 CONV3X3_SPLIT_BF16 = os.environ.get("CSEG_CONV3X3_SPLIT_BF16", "1") == "1"
 # bias-free residual-branch convolutions that move to the split kernel when the switch is on (measured on MI355X at the
 # benched shapes, tools/conv3x3_sb_probe.py: 96 ch 70 vs 101 us; 48 ch 99 vs 106 us on the fp32-MFMA kernel)
-CONV3X3_SB_BRANCH_CHANNELS = (48, 96)
+CONV3X3_SB_BRANCH_CHANNELS = tuple(int(c) for c in os.environ.get("CSEG_CONV3X3_SB_CHANNELS", "48,96").split(","))
+# channel counts that go through the explicit-tiling entry points (conv3x3_sb_pick_nt); 48 / 96 / 720 keep the library's
+# default tiling, which is what the parity suite ran on
+CONV3X3_SB_PICK_NT_CHANNELS = (192, 384)
 
 
 def conv3x3_sb_eligible(x, weight):
@@ -618,10 +621,22 @@ def conv3x3_sb_eligible(x, weight):
     return (kh, kw) == (3, 3) and ci % 48 == 0 and co % 48 == 0 and x.shape[1] == ci and x.shape[3] % 4 == 0
 
 
+def conv3x3_sb_pick_nt(x, c_out):
+    """16-channel tiles per block: the largest of 9 / 6 / 3 that still gives the grid >= 256 blocks (one per CU), else
+    the smallest that divides the channel count. Measured at 192 channels, 8x32x64: nt 3 (256 blocks) 81 us, nt 6 (128
+    blocks) 113 us; at 96 channels, 8x64x128: nt 6 (256 blocks) 70 us, nt 3 89 us."""
+    cands = [nt for nt in (9, 6, 3) if c_out % (16 * nt) == 0]
+    spatial = x.shape[0] * ((x.shape[2] + 3) // 4) * ((x.shape[3] + 63) // 64)
+    for nt in cands:
+        if spatial * (c_out // (16 * nt)) >= 256:
+            return nt
+    return cands[-1]
+
+
 @torch.no_grad()
-def conv3x3_sb_run(x, weight, transpose_flip=False, bias=None):
+def conv3x3_sb_run(x, weight, transpose_flip=False, bias=None, nt=0):
     """y = conv2d(x, weight, bias, 1, 1) (transpose_flip: the backward-data operator of that convolution applied to x)
-    through the split-bf16 MFMA kernel."""
+    through the split-bf16 MFMA kernel. nt = 0: the library's default channel tiling; 3 / 6 / 9: explicit."""
     co, ci = weight.shape[:2]
     conv_in, conv_out = (co, ci) if transpose_flip else (ci, co)
     B, _, H, W = x.shape
@@ -631,10 +646,16 @@ def conv3x3_sb_run(x, weight, transpose_flip=False, bias=None):
         raise RuntimeError("conv3x3_sb: unsupported channel counts %d -> %d" % (conv_in, conv_out))
     wp = torch.empty(n_bytes, dtype=torch.uint8, device=x.device)
     sp = _hip.stream_ptr()
-    _hip.call("cseg_conv3x3_sb_pack_weights", _p(weight, F32, "weight"), co, ci, int(transpose_flip), wp.data_ptr(), sp)
     y = torch.empty(B, conv_out, H, W, dtype=F32, device=x.device)
-    _hip.call("cseg_conv3x3_sb_fwd", _p(x, F32, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H, W,
-              _pf(y), sp)
+    if nt:
+        _hip.call("cseg_conv3x3_sb_pack_weights_nt", _p(weight, F32, "weight"), co, ci, int(transpose_flip), int(nt),
+                  wp.data_ptr(), sp)
+        _hip.call("cseg_conv3x3_sb_fwd_nt", _p(x, F32, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H,
+                  W, int(nt), _pf(y), sp)
+    else:
+        _hip.call("cseg_conv3x3_sb_pack_weights", _p(weight, F32, "weight"), co, ci, int(transpose_flip), wp.data_ptr(), sp)
+        _hip.call("cseg_conv3x3_sb_fwd", _p(x, F32, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H, W,
+                  _pf(y), sp)
     return y
 
 
@@ -648,8 +669,9 @@ def conv3x3_sb_tiles(x, c_out):
     return x.shape[0] * (c_out // nt16) * ((x.shape[2] + 3) // 4) * ((x.shape[3] + 63) // 64)
 
 
-# Weight gradient on the split-bf16 kernel (csrc/conv3x3_sb_wrw.hip): written and index-checked in round 2, first hardware
-# run pending -> off unless CSEG_CONV3X3_SB_WRW=1
+# Weight gradient on the split-bf16 kernel (csrc/conv3x3_sb_wrw.hip): kernel-level parity and timings are in (48 ch 108 vs
+# 164 us on the fp32-MFMA kernel, 96 ch 112 vs 152 us, 720 ch 17.6 vs 19.5 ms on MIOpen); the step-level goldens have not
+# run on it yet -> off unless CSEG_CONV3X3_SB_WRW=1
 CONV3X3_SB_WRW = os.environ.get("CSEG_CONV3X3_SB_WRW", "0") == "1"
 
 
@@ -684,13 +706,16 @@ class Conv3x3SplitBF16(Function):
         weight = weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return conv3x3_sb_run(x, weight, False, bias)
+        ctx.pick = weight.shape[0] in CONV3X3_SB_PICK_NT_CHANNELS
+        return conv3x3_sb_run(x, weight, False, bias, conv3x3_sb_pick_nt(x, weight.shape[0]) if ctx.pick else 0)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = conv3x3_sb_run(dy, weight, True) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = conv3x3_sb_run(dy, weight, True, None, conv3x3_sb_pick_nt(dy, weight.shape[1]) if ctx.pick else 0)
         dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_db:

@@ -250,12 +250,19 @@ size_t cseg_conv3x3_sb_packed_bytes(int Cin, int Cout);
 int cseg_conv3x3_sb_pack_weights(const float* w, int Cout, int Cin, int transpose_flip, void* wp, cseg_stream_t stream);
 int cseg_conv3x3_sb_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
                         float* y, cseg_stream_t stream);
+/* the same two calls with an explicit number of 16-channel tiles per block (nt = 3, 6 or 9; must divide conv_out / 16;
+ * pack and forward must use the same nt): smaller nt = more blocks for small feature maps (192 channels at 8x32x64:
+ * nt 3 -> 256 blocks, 81 us; nt 6 -> 128 blocks, 113 us). */
+int cseg_conv3x3_sb_pack_weights_nt(const float* w, int Cout, int Cin, int transpose_flip, int nt, void* wp,
+                                    cseg_stream_t stream);
+int cseg_conv3x3_sb_fwd_nt(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int nt,
+                           float* y, cseg_stream_t stream);
 
 /* weight gradient of the same convolution on the split-bf16 path: dw [Cout,Cin,3,3] = sum_{b,y,x} dy * shifted x.
  * Cin % 16 == 0, Cout % 48 == 0, W % 64 == 0.  ws: cseg_conv3x3_sb_wrw_ws_floats(...) floats of scratch (per-split
  * partials, summed in a fixed order: deterministic).  Replaces MIOpen's NHWC implicit-GEMM weight-gradient kernels
- * (+ 3 layout transposes) behind nn.Conv2d.  Written in round 2, first hardware run pending: the host side keeps it
- * opt-in (kernels.CONV3X3_SB_WRW). */
+ * (+ 3 layout transposes) behind nn.Conv2d: 48 ch 108 vs 201 us, 96 ch 112 vs 148 us, 720 ch 17.6 vs 19.5 ms.  The host
+ * side keeps it opt-in (kernels.CONV3X3_SB_WRW) until the one-SGD-step goldens have run on it. */
 size_t cseg_conv3x3_sb_wrw_ws_floats(int B, int Cin, int Cout, int H, int W);
 int cseg_conv3x3_sb_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, float* ws, float* dw,
                         cseg_stream_t stream);

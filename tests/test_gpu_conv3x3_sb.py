@@ -1,7 +1,5 @@
 """Split-bf16 ("bf16x6") 3x3 convolution on the BF16 matrix cores (csrc/conv3x3_sb.hip) against an fp64 convolution,
 with MIOpen's fp32 convolution of the same operands as the yardstick for "fp32 rounding class"."""
-import os
-
 import pytest
 import torch
 import torch.nn.functional as F
@@ -82,8 +80,6 @@ WRW_CASES = [  # B, Cin, Cout, H, W
 ]
 
 
-@pytest.mark.skipif(os.environ.get("CSEG_TEST_SB_WRW") != "1",
-                    reason="split-bf16 weight gradient: first hardware run pending (CSEG_TEST_SB_WRW=1)")
 @pytest.mark.parametrize("case", WRW_CASES)
 def test_weight_gradient_matches_fp64(case):
     from contrastiveseg_amd import kernels as K
@@ -101,3 +97,17 @@ def test_weight_gradient_matches_fp64(case):
     err, tol = _bound(w64.grad, got.cpu(), wr.grad.cpu())
     assert err <= tol, (case, err, tol)
     assert torch.equal(got, K.conv3x3_sb_wrw(xd, dyd)), "weight gradient not deterministic"
+
+
+@pytest.mark.parametrize("nt", [3, 6])
+def test_explicit_channel_tiling_matches_default(nt):
+    """cseg_conv3x3_sb_*_nt: same convolution whatever the number of channel tiles per block."""
+    from contrastiveseg_amd import kernels as K
+    x, w, b = _inputs(2, 96, 96, 9, 68, seed=5)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    got = K.conv3x3_sb_run(xd, wd, False, bd, nt=nt).cpu()
+    err, tol = _bound(ref, got, F.conv2d(xd, wd, bd, 1, 1).cpu())
+    assert err <= tol, (nt, err, tol)
+    dx = K.conv3x3_sb_run(xd, wd, True, None, nt=nt).cpu()
+    assert float((dx - K.conv3x3_sb_run(xd, wd, True).cpu()).abs().max()) <= 1e-5
