@@ -24,6 +24,7 @@
 // Parity vs fp64 and determinism: tests/test_gpu_conv3x3_sb.py. Host side: opt-in (kernels.CONV3X3_SB_WRW) until the
 // one-SGD-step goldens have run on it.
 #include "cseg_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -249,6 +250,226 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Version 2: producer / consumer waves. Version 1 above spends a third of a row-step with every wave splitting and
+// storing operands between two barriers (no MFMA can issue then) and fetches them with 24 scalar loads per thread.
+// Here waves 0-3 only compute -- one ci tile each, the full 64-pixel segment = 2 K-steps, 324 MFMAs per row-step, one
+// compute wave per SIMD -- and waves 4-7 only stage: aligned float4 loads (the x row is stored from pixel x0 - 4, so
+// that every chunk is 16-byte aligned and lies fully inside or outside the image), split, 8-byte LDS writes into the
+// free slot of a 4-slot x ring / the other dy buffer, one tick ahead of the consumers. One barrier per row-step; the
+// staging VALU work runs on the same SIMDs underneath the MFMAs. Horizontal taps: entries 8g + kx + 3 .. + 10 of the row
+// image = two aligned cells shifted by 3 / 4 / 5 elements (five v_alignbit per piece).
+// LDS: x [piece][ci 64][slot 4][72] with a per-channel stride of 148 dwords (= 4 * odd: the 16 lanes of a b128 read
+// fall on 16 distinct bank quads), dy [2][piece][co 48][72]: 155 KB.
+// Status: index-checked against the numpy lane model; first hardware run pending (CSEG_CONV3X3_SB_WRW_V=2 selects it).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int X2_CH = 296;                          // elements per (piece, ci): 4 slots x 72 + 8 pad  (148 dwords)
+constexpr int X2_ELEMS = 3 * CI_B * X2_CH;
+constexpr int D2_ELEMS = 2 * 3 * CO_B * DP;
+constexpr int RPU2 = 16;
+
+__device__ __forceinline__ int x2_idx(int p, int ci, int slot, int i) { return (p * CI_B + ci) * X2_CH + slot * 72 + i; }
+__device__ __forceinline__ int d2_idx(int buf, int p, int co, int i) { return ((buf * 3 + p) * CO_B + co) * DP + i; }
+
+__device__ __forceinline__ void split4w(const float4& v, uint2& h, uint2& m, uint2& l) {
+    unsigned short hs[4], ms[4], ls[4];
+    split3w(v.x, hs[0], ms[0], ls[0]);
+    split3w(v.y, hs[1], ms[1], ls[1]);
+    split3w(v.z, hs[2], ms[2], ls[2]);
+    split3w(v.w, hs[3], ms[3], ls[3]);
+    h = make_uint2(hs[0] | ((unsigned)hs[1] << 16), hs[2] | ((unsigned)hs[3] << 16));
+    m = make_uint2(ms[0] | ((unsigned)ms[1] << 16), ms[2] | ((unsigned)ms[3] << 16));
+    l = make_uint2(ls[0] | ((unsigned)ls[1] << 16), ls[2] | ((unsigned)ls[3] << 16));
+}
+
+__global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 int B, int Cin, int Cout, int H, int W, int n_split,
+                                                                 float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_w[];
+    unsigned short* xs = smem_w;
+    unsigned short* ds = smem_w + X2_ELEMS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const bool loader = wave >= 4;
+    const int lt = tid - 256;                          // loader thread index
+    const int g = lane >> 4, n = lane & 15;
+    int blk = blockIdx.x;
+    const int split = blk % n_split; blk /= n_split;
+    const int n_cib = (Cin + CI_B - 1) / CI_B;
+    const int cib = blk % n_cib;
+    const int cob = blk / n_cib;
+    const size_t plane = (size_t)H * W;
+    const int segs = W / SEG;
+    const int runs = (H + RPU2 - 1) / RPU2;
+    const int n_units = B * segs * runs;
+    const bool tile_ok = !loader && cib * CI_B + wave * 16 < Cin;
+
+    // ---- loader side. x row: 64 ci x 18 chunks of 4 entries (entry i = pixel x0 - 4 + i); dy row: 48 co x 16 chunks
+    auto x_load = [&](int b, int x0, int row, float4 (&v)[5]) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int item = min(lt + 256 * u, CI_B * 18 - 1);
+            const int ci = item / 18, c = item - ci * 18;
+            const int px = x0 - 4 + 4 * c;
+            const int cic = min(cib * CI_B + ci, Cin - 1), rowc = min(max(row, 0), H - 1), pxc = min(max(px, 0), W - 4);
+            v[u] = *reinterpret_cast<const float4*>(x + ((size_t)b * Cin + cic) * plane + (size_t)rowc * W + pxc);
+        }
+    };
+    auto x_put = [&](int x0, int row, int slot, const float4 (&v)[5]) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int item = lt + 256 * u;
+            if (item < CI_B * 18) {
+                const int ci = item / 18, c = item - ci * 18;
+                const int px = x0 - 4 + 4 * c;
+                const bool ok = cib * CI_B + ci < Cin && row >= 0 && row < H && px >= 0 && px < W;
+                const float4 t = ok ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                uint2 h, m, l;
+                split4w(t, h, m, l);
+                *reinterpret_cast<uint2*>(xs + x2_idx(0, ci, slot, 4 * c)) = h;
+                *reinterpret_cast<uint2*>(xs + x2_idx(1, ci, slot, 4 * c)) = m;
+                *reinterpret_cast<uint2*>(xs + x2_idx(2, ci, slot, 4 * c)) = l;
+            }
+        }
+    };
+    auto d_load = [&](int b, int x0, int row, float4 (&v)[3]) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int item = lt + 256 * u;             // 768 items exactly
+            const int co = item >> 4, c = item & 15;
+            v[u] = *reinterpret_cast<const float4*>(dy + (((size_t)b * Cout + cob * CO_B + co) * H + min(row, H - 1)) * W + x0 + 4 * c);
+        }
+    };
+    auto d_put = [&](int buf, const float4 (&v)[3]) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int item = lt + 256 * u;
+            const int co = item >> 4, c = item & 15;
+            uint2 h, m, l;
+            split4w(v[u], h, m, l);
+            *reinterpret_cast<uint2*>(ds + d2_idx(buf, 0, co, 4 * c)) = h;
+            *reinterpret_cast<uint2*>(ds + d2_idx(buf, 1, co, 4 * c)) = m;
+            *reinterpret_cast<uint2*>(ds + d2_idx(buf, 2, co, 4 * c)) = l;
+        }
+    };
+
+    // ---- consumer side: output row with x rows in slots s0 (row - 1), s0 + 1, s0 + 2 (mod 4), dy in buffer `buf`
+    auto compute = [&](int s0, int buf, f32x4 (&acc)[9][3]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[3][3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    a[c][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ds + d2_idx(buf, p, c * 16 + n, 32 * ks + 8 * g)));
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int slot = (s0 + ky) & 3;
+                bf16x8 bfr[3][3];                      // [kx][piece]
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const unsigned short* src = xs + x2_idx(p, wave * 16 + n, slot, 32 * ks + 8 * g);
+                    const uint4 c0 = *reinterpret_cast<const uint4*>(src);          // entries e .. e+7    (d0..d3)
+                    const uint4 c1 = *reinterpret_cast<const uint4*>(src + 8);      // entries e+8 .. e+15 (d4..d7)
+                    const unsigned a21 = __builtin_amdgcn_alignbit(c0.z, c0.y, 16), a32 = __builtin_amdgcn_alignbit(c0.w, c0.z, 16),
+                                   a43 = __builtin_amdgcn_alignbit(c1.x, c0.w, 16), a54 = __builtin_amdgcn_alignbit(c1.y, c1.x, 16),
+                                   a65 = __builtin_amdgcn_alignbit(c1.z, c1.y, 16);
+                    bfr[0][p] = __builtin_bit_cast(bf16x8, make_uint4(a21, a32, a43, a54));     // entries e+3 .. e+10 (kx = 0)
+                    bfr[1][p] = __builtin_bit_cast(bf16x8, make_uint4(c0.z, c0.w, c1.x, c1.y)); // entries e+4 .. e+11
+                    bfr[2][p] = __builtin_bit_cast(bf16x8, make_uint4(a32, a43, a54, a65));     // entries e+5 .. e+12
+                }
+#define SBW_TERM(P, Q)                                                                                          \
+    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) _Pragma("unroll") for (int c = 0; c < 3; ++c)             \
+        acc[ky * 3 + kx][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[c][P], bfr[kx][Q], acc[ky * 3 + kx][c], 0, 0, 0);
+                SBW_TERM(2, 0)
+                SBW_TERM(0, 2)
+                SBW_TERM(1, 1)
+                SBW_TERM(1, 0)
+                SBW_TERM(0, 1)
+                SBW_TERM(0, 0)
+#undef SBW_TERM
+            }
+        }
+    };
+
+    auto unit_dims = [&](int unit, int& b, int& x0, int& ya, int& yb) {
+        int t = unit;
+        const int run = t % runs; t /= runs;
+        const int seg = t % segs;
+        b = t / segs;
+        x0 = seg * SEG; ya = run * RPU2; yb = min(ya + RPU2, H);
+    };
+
+    // The two roles run separate loops (separate register budgets: staging registers on one side, 27 accumulators on the
+    // other) that execute the SAME sequence of barriers: one after the prologue of a unit, one per row.
+    if (loader) {
+        for (int unit = split; unit < n_units; unit += n_split) {
+            int b, x0, ya, yb;
+            unit_dims(unit, b, x0, ya, yb);
+            float4 xv[5], dv[3];
+            {   // prologue tick (the previous unit's last barrier has released the image): x rows ya-1, ya, ya+1 -> slots
+                // 0, 1, 2; dy row ya -> buffer 0; then the loads of the first steady tick are put in flight
+                float4 x0v[5], x1v[5];
+                x_load(b, x0, ya - 1, x0v);
+                x_load(b, x0, ya, x1v);
+                x_load(b, x0, ya + 1, xv);
+                d_load(b, x0, ya, dv);
+                x_put(x0, ya - 1, 0, x0v);
+                x_put(x0, ya, 1, x1v);
+                x_put(x0, ya + 1, 2, xv);
+                d_put(0, dv);
+            }
+            if (ya + 1 < yb) {
+                x_load(b, x0, ya + 2, xv);
+                d_load(b, x0, ya + 1, dv);
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int row = ya; row < yb; ++row) {
+                const int k = row - ya;                // x row r of the unit lives in slot (r - ya + 1) & 3
+                if (row + 1 < yb) {
+                    x_put(x0, row + 2, (k + 3) & 3, xv);           // the slot that held row - 2
+                    d_put((k + 1) & 1, dv);
+                    if (row + 2 < yb) {
+                        x_load(b, x0, row + 3, xv);
+                        d_load(b, x0, row + 2, dv);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        f32x4 acc[9][3];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int unit = split; unit < n_units; unit += n_split) {
+            int b, x0, ya, yb;
+            unit_dims(unit, b, x0, ya, yb);
+            __syncthreads();
+#pragma unroll 1
+            for (int row = ya; row < yb; ++row) {
+                const int k = row - ya;
+                if (tile_ok) compute(k & 3, k & 1, acc);
+                __syncthreads();
+            }
+        }
+        if (tile_ok) {
+            const int ci = cib * CI_B + wave * 16 + n;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    // D[m = 4g + r][n]: co = cob*48 + 16c + 4g + r, ci = this lane's column
+                    float* dst = partial + (((size_t)split * 9 + t) * Cout + cob * CO_B + c * 16 + 4 * g) * Cin + ci;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[(size_t)r * Cin] = acc[t][c][r];
+                }
+        }
+    }
+}
+
 // dW[co][ci][tap] = sum over splits of partial[split][tap][co][ci], fixed order (same scheme as conv3x3.hip)
 __global__ __launch_bounds__(256) void sb_wrw_reduce_kernel(const float* __restrict__ partial, int n_split, int Cout, int Cin,
                                                             float* __restrict__ dw) {
@@ -277,8 +498,14 @@ __global__ __launch_bounds__(256) void sb_wrw_reduce_kernel(const float* __restr
     }
 }
 
+int sb_wrw_version() {
+    const char* e = getenv("CSEG_CONV3X3_SB_WRW_V");
+    return e && atoi(e) == 2 ? 2 : 1;
+}
+
 int sb_wrw_splits(int B, int Cin, int Cout, int H, int W) {
-    const int units = B * (W / SEG) * ((H + ROWS_PER_UNIT - 1) / ROWS_PER_UNIT);
+    const int rpu = sb_wrw_version() == 2 ? RPU2 : ROWS_PER_UNIT;
+    const int units = B * (W / SEG) * ((H + rpu - 1) / rpu);
     const int pairs = ((Cin + CI_B - 1) / CI_B) * (Cout / CO_B);
     int n = (768 + pairs - 1) / pairs;               // ~3 blocks per CU in total
     if (n > 256) n = 256;                            // bounds the partial buffer (256 x 9 x Cout x Cin floats)
@@ -304,19 +531,37 @@ extern "C" int cseg_conv3x3_sb_wrw(const float* x, const float* dy, int B, int C
     const int n_split = sb_wrw_splits(B, Cin, Cout, H, W);
     const long blocks = (long)n_split * ((Cin + CI_B - 1) / CI_B) * (Cout / CO_B);
     CSEG_REQUIRE(blocks < 2147483647L && (long)9 * Cin * Cout < 2147483647L, "conv3x3_sb_wrw: grid too large");
-    const size_t lds = sizeof(unsigned short) * (XS_ELEMS + DS_ELEMS);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_sb_wrw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess) {
-            cseg_set_error("conv3x3_sb_wrw: cannot raise dynamic LDS to %zu bytes", lds);
-            return 0;
+    if (sb_wrw_version() == 2) {
+        CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0,
+                     "conv3x3_sb_wrw: tensors must be 16-byte aligned");
+        const size_t lds2 = sizeof(unsigned short) * (X2_ELEMS + D2_ELEMS);
+        static bool attr2_set = false;
+        if (!attr2_set) {
+            if (hipFuncSetAttribute((const void*)conv3x3_sb_wrw2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds2) != hipSuccess) {
+                cseg_set_error("conv3x3_sb_wrw: cannot raise dynamic LDS to %zu bytes", lds2);
+                return 0;
+            }
+            attr2_set = true;
         }
-        attr_set = true;
+        hipLaunchKernelGGL(conv3x3_sb_wrw2_kernel, dim3((unsigned)blocks), dim3(512), lds2, stream, x, dy, B, Cin, Cout, H, W,
+                           n_split, ws);
+        CSEG_CHECK_LAUNCH("conv3x3_sb_wrw2_kernel");
+    } else {
+        const size_t lds = sizeof(unsigned short) * (XS_ELEMS + DS_ELEMS);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)conv3x3_sb_wrw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) {
+                cseg_set_error("conv3x3_sb_wrw: cannot raise dynamic LDS to %zu bytes", lds);
+                return 0;
+            }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(conv3x3_sb_wrw_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, x, dy, B, Cin, Cout, H, W,
+                           n_split, ws);
+        CSEG_CHECK_LAUNCH("conv3x3_sb_wrw_kernel");
     }
-    hipLaunchKernelGGL(conv3x3_sb_wrw_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, x, dy, B, Cin, Cout, H, W,
-                       n_split, ws);
-    CSEG_CHECK_LAUNCH("conv3x3_sb_wrw_kernel");
     const int total = 9 * Cin * Cout;
     hipLaunchKernelGGL(sb_wrw_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, ws, n_split, Cout, Cin, dw);
     CSEG_CHECK_LAUNCH("sb_wrw_reduce_kernel");

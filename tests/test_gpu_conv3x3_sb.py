@@ -1,5 +1,7 @@
 """Split-bf16 ("bf16x6") 3x3 convolution on the BF16 matrix cores (csrc/conv3x3_sb.hip) against an fp64 convolution,
 with MIOpen's fp32 convolution of the same operands as the yardstick for "fp32 rounding class"."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -80,9 +82,12 @@ WRW_CASES = [  # B, Cin, Cout, H, W
 ]
 
 
-@pytest.mark.parametrize("case", WRW_CASES)
-def test_weight_gradient_matches_fp64(case):
+@pytest.mark.parametrize("version", ["1", pytest.param("2", marks=pytest.mark.skipif(
+    os.environ.get("CSEG_TEST_SB_WRW_V2") != "1", reason="producer/consumer version: first hardware run pending"))])
+@pytest.mark.parametrize("case", WRW_CASES + [(2, 48, 48, 40, 128)])
+def test_weight_gradient_matches_fp64(case, version, monkeypatch):
     from contrastiveseg_amd import kernels as K
+    monkeypatch.setenv("CSEG_CONV3X3_SB_WRW_V", version)
     B, ci, co, H, W = case
     g = torch.Generator().manual_seed(3)
     x = torch.randn(B, ci, H, W, generator=g)

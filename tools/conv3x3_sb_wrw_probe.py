@@ -42,7 +42,11 @@ def main():
         def miopen():
             return torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                        [False, True, False])[1]
-        rows = [("split_bf16 wrw", timeit(lambda: K.conv3x3_sb_wrw(x, dy), iters)), ("miopen fp32 wrw", timeit(miopen, iters))]
+        rows = []
+        for v in ("1", "2"):
+            os.environ["CSEG_CONV3X3_SB_WRW_V"] = v
+            rows.append(("split_bf16 wrw v%s" % v, timeit(lambda: K.conv3x3_sb_wrw(x, dy), iters)))
+        rows.append(("miopen fp32 wrw", timeit(miopen, iters)))
         if C in (48, 96):
             rows.append(("fp32-MFMA wrw", timeit(lambda: K._conv3x3_wrw(x, dy, C, C), iters)))
         ref = miopen()
