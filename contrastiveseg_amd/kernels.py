@@ -736,6 +736,75 @@ def conv3x3_split_bf16(x, weight, bias=None):
     return Conv3x3SplitBF16.apply(x, weight, bias)
 
 
+# ----------------------------------------------------------------------------------------------------------
+# 1x1 convolution on the BF16 matrix cores with split operands (csrc/conv1x1_sb.hip): first hardware run pending -> opt-in
+# ----------------------------------------------------------------------------------------------------------
+CONV1X1_SPLIT_BF16 = os.environ.get("CSEG_CONV1X1_SPLIT_BF16", "0") == "1"
+CONV1X1_SB_MIN_TILES = 256
+
+
+def conv1x1_sb_eligible(x, weight):
+    """NCHW fp32 on the GPU, 1x1, Cin % 16 and Cout % 48|64 in both directions (backward-data swaps them), H*W % 4."""
+    if not (x.is_cuda and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4 and x.is_contiguous()):
+        return False
+    co, ci, kh, kw = weight.shape
+    ok = lambda c: c % 48 == 0 or c % 64 == 0
+    return (kh, kw) == (1, 1) and ok(ci) and ok(co) and x.shape[1] == ci and (x.shape[2] * x.shape[3]) % 4 == 0
+
+
+def conv1x1_sb_tiles(x, c_out):
+    nt16 = next(16 * nt for nt in (9, 8, 6, 4, 3) if c_out % (16 * nt) == 0)
+    return x.shape[0] * (c_out // nt16) * ((x.shape[2] * x.shape[3] + 255) // 256)
+
+
+@torch.no_grad()
+def conv1x1_sb_run(x, weight, transpose=False, bias=None):
+    """y = conv2d(x, weight[Cout,Cin,1,1], bias) (transpose: the backward-data operator applied to x)."""
+    co, ci = weight.shape[:2]
+    conv_in, conv_out = (co, ci) if transpose else (ci, co)
+    B, _, H, W = x.shape
+    lib = _hip.lib()
+    n_bytes = lib.cseg_conv1x1_sb_packed_bytes(conv_in, conv_out)
+    if n_bytes == 0:
+        raise RuntimeError("conv1x1_sb: unsupported channel counts %d -> %d" % (conv_in, conv_out))
+    wp = torch.empty(n_bytes, dtype=torch.uint8, device=x.device)
+    sp = _hip.stream_ptr()
+    _hip.call("cseg_conv1x1_sb_pack_weights", _p(weight, F32, "weight"), co, ci, int(transpose), wp.data_ptr(), sp)
+    y = torch.empty(B, conv_out, H, W, dtype=F32, device=x.device)
+    _hip.call("cseg_conv1x1_sb_fwd", _p(x, F32, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H * W,
+              _pf(y), sp)
+    return y
+
+
+class Conv1x1SplitBF16(Function):
+    """y = conv2d(x, weight, bias) for a 1x1 kernel: forward and backward-data on the split-bf16 MFMA kernel, weight / bias
+    gradients on MIOpen / rocBLAS (fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        weight = weight.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return conv1x1_sb_run(x, weight, False, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = conv1x1_sb_run(dy, weight, True) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_db:
+            _, dw, db = torch.ops.aten.convolution_backward(
+                dy, x, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                [False, bool(ctx.needs_input_grad[1]), bool(want_db)])
+        return dx, dw, db
+
+
+def conv1x1_split_bf16(x, weight, bias=None):
+    return Conv1x1SplitBF16.apply(x, weight, bias)
+
+
 @torch.no_grad()
 def bn_fwd(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches_tracked):
     """Single-rank training forward (2 launches): -> (y, mean_invstd [C,2])."""

@@ -268,6 +268,18 @@ int cseg_conv3x3_sb_wrw(const float* x, const float* dy, int B, int Cin, int Cou
                         cseg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * 1x1 / stride 1 convolution (NCHW fp32 in and out) on the BF16 matrix cores with split operands (bf16x6, fp32-class
+ * accuracy): the projection head of lib/models/modules/projection.py:8-24 (720 -> 720 -> 256) and the pointwise layers of
+ * the encoder; nn.Conv2d(k=1) -> rocBLAS / MIOpen fp32 in the reference.  Cin % 16 == 0, Cout % 48 == 0 or % 64 == 0,
+ * H*W % 4 == 0.  transpose = 1 packs the backward-data operator (maps Cout -> Cin channels).  Written and index-checked in
+ * round 2, first hardware run pending: the host side keeps it opt-in (kernels.CONV1X1_SPLIT_BF16).
+ * ------------------------------------------------------------------------------------------------ */
+size_t cseg_conv1x1_sb_packed_bytes(int Cin, int Cout);
+int cseg_conv1x1_sb_pack_weights(const float* w, int Cout, int Cin, int transpose, void* wp, cseg_stream_t stream);
+int cseg_conv1x1_sb_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int HW, float* y,
+                        cseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * GPU data pipeline: random resize (cv2 INTER_CUBIC image / INTER_NEAREST label) -> random
  * crop -> horizontal flip -> brightness shift -> ToTensor + Normalize(div, mean, std) + label look-up + ReLabel(255,-1)
  * -> collate padding to the fixed input size, as ONE kernel over the output batch.  Replaces the per-sample CPU chain

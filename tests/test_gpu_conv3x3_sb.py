@@ -116,3 +116,38 @@ def test_explicit_channel_tiling_matches_default(nt):
     assert err <= tol, (nt, err, tol)
     dx = K.conv3x3_sb_run(xd, wd, True, None, nt=nt).cpu()
     assert float((dx - K.conv3x3_sb_run(xd, wd, True).cpu()).abs().max()) <= 1e-5
+
+
+ONE_CASES = [  # B, Cin, Cout, H, W
+    (1, 48, 64, 10, 30),        # ragged pixel tile (300 pixels), 16-channel tail
+    (2, 144, 48, 16, 16),
+    (1, 720, 720, 8, 64),       # projection head, first layer
+    (1, 720, 256, 8, 64),       # projection head, second layer (NT = 8)
+    (2, 64, 256, 12, 20),       # layer1 bottleneck expansion
+]
+
+
+@pytest.mark.skipif(os.environ.get("CSEG_TEST_SB_1X1") != "1", reason="1x1 split-bf16 kernel: first hardware run pending")
+@pytest.mark.parametrize("case", ONE_CASES)
+def test_pointwise_matches_fp64(case):
+    from contrastiveseg_amd import kernels as K
+    B, ci, co, H, W = case
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, ci, H, W, generator=g)
+    w = torch.randn(co, ci, 1, 1, generator=g) / ci ** 0.5
+    b = torch.randn(co, generator=g)
+    dy = torch.randn(B, co, H, W, generator=g)
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+    y64 = F.conv2d(x64, w64, b64)
+    y64.backward(dy.double())
+    xd, wd, bd = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    assert K.conv1x1_sb_eligible(xd, wd)
+    y = K.conv1x1_split_bf16(xd, wd, bd)
+    y.backward(dy.cuda())
+    xr, wr, br = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br)
+    yr.backward(dy.cuda())
+    for name, t64, got, fp32 in (("y", y64.detach(), y.detach(), yr.detach()), ("dx", x64.grad, xd.grad, xr.grad),
+                                 ("dw", w64.grad, wd.grad, wr.grad), ("db", b64.grad, bd.grad, br.grad)):
+        err, tol = _bound(t64, got.cpu(), fp32.cpu())
+        assert err <= tol, (case, name, err, tol)
