@@ -62,6 +62,8 @@ SIGNATURES = {
     "cseg_conv1x1_sb_packed_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
     "cseg_conv1x1_sb_pack_weights": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr]),
     "cseg_conv1x1_sb_fwd": (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    "cseg_conv1x1_sb_wrw_ws_floats": (ctypes.c_size_t, [_c_int] * 4),
+    "cseg_conv1x1_sb_wrw": (_c_int, [_ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "cseg_augment_batch": (_c_int, [_ptr, _ptr, _ptr, _ptr] + [_c_int] * 5 + [_c_float, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_bn_ws_floats": (ctypes.c_size_t, [_c_int, _c_int, _c_int]),
     "cseg_bn_stats": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),

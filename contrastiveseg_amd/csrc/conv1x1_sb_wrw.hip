@@ -1,0 +1,243 @@
+// Weight gradient of the 1x1 convolution on the BF16 matrix cores with split operands (bf16x6, see conv3x3_sb.hip):
+//   dW[co][ci] = sum_{b,p} dy[b][co][p] * x[b][ci][p]        (p = pixel of the H*W plane)
+// A GEMM whose contraction index (pixels) is the contiguous dimension of both NCHW operands: fragments are 8 consecutive
+// pixels of one channel, read with one ds_read_b128 from [piece][channel][pixel] bf16 images -- no transposition.
+// Reference site: nn.Conv2d(720, 720, 1) / (720, 256, 1) of the projection head (lib/models/modules/projection.py:8-24);
+// MIOpen's fp32 weight gradient for 720 -> 720 at 8x128x256 takes 5.7 ms = 48 TFLOP/s
+// (profiles/r02_conv_layout_probe_nchw_vs_channels_last.jsonl).
+//
+// Block = 8 waves on a 144 (co) x 128 (ci) channel block: waves 0-3 compute (2 co halves of 5 + 4 tiles x 2 ci halves of
+// 4 tiles: 20 accumulators, 120 MFMAs per 32-pixel stage), waves 4-7 stage: aligned float4 loads of the next 32 pixels of
+// all 272 channels, split into three bf16 pieces, 8-byte LDS writes into the other buffer; one barrier per stage
+// (producer / consumer roles in separate loops with the same barrier sequence, as in conv3x3_sb_wrw2_kernel).
+// Split-K over (image, 32-pixel stage) units, contiguous range per split; partial [split][co][ci] summed in a fixed
+// order by a second kernel: deterministic.
+// Status: index-checked against a numpy lane model; first hardware run pending -> opt-in (kernels.CONV1X1_SB_WRW).
+#include "cseg_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int CO_T = 144, CI_T = 128, STG = 32;      // channel block, pixels per stage
+constexpr int PITCH = 40;                            // bf16 elements per (piece, channel) row: 32 + 8 pad (20 dwords = 4 * odd)
+constexpr int DY_ELEMS = 3 * CO_T * PITCH;           // one dy buffer
+constexpr int X_ELEMS = 3 * CI_T * PITCH;            // one x buffer
+constexpr int CH_ALL = CO_T + CI_T;                  // 272 channel rows per stage
+
+__device__ __forceinline__ void split3q(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const __bf16 bh = (__bf16)v;
+    const float r1 = v - (float)bh;
+    const __bf16 bm = (__bf16)r1;
+    const float r2 = r1 - (float)bm;
+    const __bf16 bl = (__bf16)r2;
+    h = __builtin_bit_cast(unsigned short, bh);
+    m = __builtin_bit_cast(unsigned short, bm);
+    l = __builtin_bit_cast(unsigned short, bl);
+}
+
+__device__ __forceinline__ void split4q(const float4& v, uint2& h, uint2& m, uint2& l) {
+    unsigned short hs[4], ms[4], ls[4];
+    split3q(v.x, hs[0], ms[0], ls[0]);
+    split3q(v.y, hs[1], ms[1], ls[1]);
+    split3q(v.z, hs[2], ms[2], ls[2]);
+    split3q(v.w, hs[3], ms[3], ls[3]);
+    h = make_uint2(hs[0] | ((unsigned)hs[1] << 16), hs[2] | ((unsigned)hs[3] << 16));
+    m = make_uint2(ms[0] | ((unsigned)ms[1] << 16), ms[2] | ((unsigned)ms[3] << 16));
+    l = make_uint2(ls[0] | ((unsigned)ls[1] << 16), ls[2] | ((unsigned)ls[3] << 16));
+}
+
+constexpr int LD_ITEMS = CH_ALL * 8;                 // float4 chunks per stage: 272 rows x 8 chunks of 4 pixels
+constexpr int LD_U = (LD_ITEMS + 255) / 256;         // per loader thread (9)
+
+__global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                int B, int Cin, int Cout, int plane_i, int n_split,
+                                                                float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_q[];
+    unsigned short* ds = smem_q;                       // [2][piece][co 144][PITCH]
+    unsigned short* xs = smem_q + 2 * DY_ELEMS;        // [2][piece][ci 128][PITCH]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const bool loader = wave >= 4;
+    const int lt = tid - 256;
+    const int g = lane >> 4, n = lane & 15;
+    int blk = blockIdx.x;
+    const int split = blk % n_split; blk /= n_split;
+    const int n_cib = (Cin + CI_T - 1) / CI_T;
+    const int cib = blk % n_cib;
+    const int cob = blk / n_cib;
+    const size_t plane = (size_t)plane_i;
+    const int stages_per_img = plane_i / STG;
+    const long n_units = (long)B * stages_per_img;
+    const long u_lo = n_units * split / n_split, u_hi = n_units * (split + 1) / n_split;     // this split's stages
+
+    if (loader) {
+        // item = (channel row r of the 272, chunk c of 8): rows 0..143 = dy channels cob*144 + r, rows 144..271 = x channels
+        auto load = [&](long unit, float4 (&v)[LD_U]) {
+            const int b = (int)(unit / stages_per_img);
+            const size_t p0 = (size_t)(unit % stages_per_img) * STG;
+#pragma unroll
+            for (int u = 0; u < LD_U; ++u) {
+                const int item = min(lt + 256 * u, LD_ITEMS - 1);
+                const int r = item >> 3, c = item & 7;
+                const float* src;
+                if (r < CO_T) src = dy + ((size_t)b * Cout + min(cob * CO_T + r, Cout - 1)) * plane;
+                else src = x + ((size_t)b * Cin + min(cib * CI_T + r - CO_T, Cin - 1)) * plane;
+                v[u] = *reinterpret_cast<const float4*>(src + p0 + 4 * c);
+            }
+        };
+        auto put = [&](int buf, const float4 (&v)[LD_U]) {
+#pragma unroll
+            for (int u = 0; u < LD_U; ++u) {
+                const int item = lt + 256 * u;
+                if (item < LD_ITEMS) {
+                    const int r = item >> 3, c = item & 7;
+                    const bool is_dy = r < CO_T;
+                    const bool ok = is_dy ? cob * CO_T + r < Cout : cib * CI_T + r - CO_T < Cin;
+                    const float4 t = ok ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    uint2 h, m, l;
+                    split4q(t, h, m, l);
+                    unsigned short* base = is_dy ? ds + buf * DY_ELEMS + r * PITCH + 4 * c
+                                                 : xs + buf * X_ELEMS + (r - CO_T) * PITCH + 4 * c;
+                    const int pstride = is_dy ? CO_T * PITCH : CI_T * PITCH;
+                    *reinterpret_cast<uint2*>(base) = h;
+                    *reinterpret_cast<uint2*>(base + pstride) = m;
+                    *reinterpret_cast<uint2*>(base + 2 * pstride) = l;
+                }
+            }
+        };
+        float4 v[LD_U];
+        if (u_lo < u_hi) {
+            load(u_lo, v);
+            put(0, v);
+            if (u_lo + 1 < u_hi) load(u_lo + 1, v);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (long unit = u_lo; unit < u_hi; ++unit) {
+            const int k = (int)(unit - u_lo);
+            if (unit + 1 < u_hi) {
+                put((k + 1) & 1, v);                   // that buffer was last read in stage k - 1 (barrier since)
+                if (unit + 2 < u_hi) load(unit + 2, v);
+            }
+            __syncthreads();
+        }
+    } else {
+        const int mh = wave & 1, nh = wave >> 1;       // co half (tiles 0-4 / 5-8), ci half (tiles 0-3 / 4-7)
+        const int cot0 = mh ? 5 : 0, cit0 = nh * 4;
+        f32x4 acc[5][4];
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+#pragma unroll 1
+        for (long unit = u_lo; unit < u_hi; ++unit) {
+            const int buf = (int)(unit - u_lo) & 1;
+            bf16x8 bf[4][3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bf[c][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
+                        xs + buf * X_ELEMS + (p * CI_T + (cit0 + c) * 16 + n) * PITCH + 8 * g));
+#pragma unroll
+            for (int a = 0; a < 5; ++a) {
+                if (a == 4 && mh) break;               // the upper co half has four tiles
+                bf16x8 af[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
+                        ds + buf * DY_ELEMS + (p * CO_T + (cot0 + a) * 16 + n) * PITCH + 8 * g));
+#define Q_TERM(P, Q)                                                                                      \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                         \
+        acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P], bf[c][Q], acc[a][c], 0, 0, 0);
+                Q_TERM(2, 0)
+                Q_TERM(0, 2)
+                Q_TERM(1, 1)
+                Q_TERM(1, 0)
+                Q_TERM(0, 1)
+                Q_TERM(0, 0)
+#undef Q_TERM
+            }
+            __syncthreads();
+        }
+        // D[m = 4g + r][n]: co = cob*144 + (cot0 + a)*16 + 4g + r, ci = cib*128 + (cit0 + c)*16 + n
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+            if (a == 4 && mh) break;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ci = cib * CI_T + (cit0 + c) * 16 + n;
+                const int co = cob * CO_T + (cot0 + a) * 16 + 4 * g;
+                if (ci < Cin) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < Cout) partial[((size_t)split * Cout + co + r) * Cin + ci] = acc[a][c][r];
+                }
+            }
+        }
+    }
+}
+
+// dW[co][ci] = sum over splits of partial[split][co][ci], fixed order
+__global__ __launch_bounds__(256) void sb_wrw1_reduce_kernel(const float* __restrict__ partial, int n_split, int total,
+                                                             float* __restrict__ dw) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    float s0 = 0.f, s1 = 0.f;
+    int sp = 0;
+    for (; sp + 1 < n_split; sp += 2) {
+        s0 += partial[(size_t)sp * total + e];
+        s1 += partial[(size_t)(sp + 1) * total + e];
+    }
+    if (sp < n_split) s0 += partial[(size_t)sp * total + e];
+    dw[e] = s0 + s1;
+}
+
+int wrw1_splits(int B, int Cin, int Cout, int plane) {
+    const long units = (long)B * (plane / STG);
+    const int pairs = ((Cin + CI_T - 1) / CI_T) * ((Cout + CO_T - 1) / CO_T);
+    long n = (768 + pairs - 1) / pairs;              // ~3 blocks per CU in total
+    if (n > 64) n = 64;
+    if (n > units) n = units;
+    if (n < 1) n = 1;
+    return (int)n;
+}
+
+}  // namespace
+
+extern "C" size_t cseg_conv1x1_sb_wrw_ws_floats(int B, int Cin, int Cout, int HW) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || HW <= 0 || Cin % 16 || Cout % 16 || HW % STG) return 0;
+    return (size_t)wrw1_splits(B, Cin, Cout, HW) * Cin * Cout;
+}
+
+extern "C" int cseg_conv1x1_sb_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int HW, float* ws, float* dw,
+                                   cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CSEG_REQUIRE(x && dy && ws && dw, "conv1x1_sb_wrw: null pointer");
+    CSEG_REQUIRE(B > 0 && HW > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0 && HW % STG == 0,
+                 "conv1x1_sb_wrw: unsupported shape B=%d Cin=%d Cout=%d HW=%d (needs channels %% 16, H*W %% 32)", B, Cin, Cout, HW);
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0,
+                 "conv1x1_sb_wrw: tensors must be 16-byte aligned");
+    const int n_split = wrw1_splits(B, Cin, Cout, HW);
+    const long blocks = (long)n_split * ((Cin + CI_T - 1) / CI_T) * ((Cout + CO_T - 1) / CO_T);
+    CSEG_REQUIRE(blocks < 2147483647L && (long)Cin * Cout < 2147483647L, "conv1x1_sb_wrw: grid too large");
+    const size_t lds = sizeof(unsigned short) * 2 * (DY_ELEMS + X_ELEMS);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv1x1_sb_wrw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            cseg_set_error("conv1x1_sb_wrw: cannot raise dynamic LDS to %zu bytes", lds);
+            return 0;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv1x1_sb_wrw_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, x, dy, B, Cin, Cout, HW, n_split,
+                       ws);
+    CSEG_CHECK_LAUNCH("conv1x1_sb_wrw_kernel");
+    const int total = Cin * Cout;
+    hipLaunchKernelGGL(sb_wrw1_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, ws, n_split, total, dw);
+    CSEG_CHECK_LAUNCH("sb_wrw1_reduce_kernel");
+    return 1;
+}

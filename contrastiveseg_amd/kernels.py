@@ -776,6 +776,29 @@ def conv1x1_sb_run(x, weight, transpose=False, bias=None):
     return y
 
 
+CONV1X1_SB_WRW = os.environ.get("CSEG_CONV1X1_SB_WRW", "0") == "1"
+
+
+def conv1x1_sb_wrw_eligible(x, dy):
+    return (x.is_cuda and x.dtype == F32 and dy.dtype == F32 and x.is_contiguous() and dy.is_contiguous()
+            and x.shape[1] % 16 == 0 and dy.shape[1] % 16 == 0 and (x.shape[2] * x.shape[3]) % 32 == 0)
+
+
+@torch.no_grad()
+def conv1x1_sb_wrw(x, dy):
+    """dw [Cout,Cin,1,1] of a 1x1 convolution for the output gradient dy, split-bf16 MFMA kernel."""
+    B, ci, H, W = x.shape
+    co = dy.shape[1]
+    lib = _hip.lib()
+    n = lib.cseg_conv1x1_sb_wrw_ws_floats(B, ci, co, H * W)
+    if n == 0:
+        raise RuntimeError("conv1x1_sb_wrw: unsupported shape %s x %s" % (tuple(x.shape), tuple(dy.shape)))
+    ws = torch.empty(n, dtype=F32, device=x.device)
+    dw = torch.empty(co, ci, 1, 1, dtype=F32, device=x.device)
+    _hip.call("cseg_conv1x1_sb_wrw", _p(x, F32, "x"), _p(dy, F32, "dy"), B, ci, co, H * W, _pf(ws), _pf(dw), _hip.stream_ptr())
+    return dw
+
+
 class Conv1x1SplitBF16(Function):
     """y = conv2d(x, weight, bias) for a 1x1 kernel: forward and backward-data on the split-bf16 MFMA kernel, weight / bias
     gradients on MIOpen / rocBLAS (fp32)."""
@@ -794,7 +817,10 @@ class Conv1x1SplitBF16(Function):
         dx = conv1x1_sb_run(dy, weight, True) if ctx.needs_input_grad[0] else None
         dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] or want_db:
+        if CONV1X1_SB_WRW and conv1x1_sb_wrw_eligible(x, dy):
+            dw = conv1x1_sb_wrw(x, dy) if ctx.needs_input_grad[1] else None
+            db = dy.sum((0, 2, 3)) if want_db else None
+        elif ctx.needs_input_grad[1] or want_db:
             _, dw, db = torch.ops.aten.convolution_backward(
                 dy, x, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                 [False, bool(ctx.needs_input_grad[1]), bool(want_db)])

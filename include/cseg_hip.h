@@ -278,6 +278,12 @@ size_t cseg_conv1x1_sb_packed_bytes(int Cin, int Cout);
 int cseg_conv1x1_sb_pack_weights(const float* w, int Cout, int Cin, int transpose, void* wp, cseg_stream_t stream);
 int cseg_conv1x1_sb_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int HW, float* y,
                         cseg_stream_t stream);
+/* weight gradient of the 1x1 convolution on the same path: dw [Cout,Cin] = sum_{b,p} dy[b][co][p] * x[b][ci][p].
+ * Cin % 16 == 0, Cout % 16 == 0, H*W % 32 == 0; ws: cseg_conv1x1_sb_wrw_ws_floats(...) floats (per-split partials, fixed
+ * order of summation).  Opt-in on the host side (kernels.CONV1X1_SB_WRW), first hardware run pending. */
+size_t cseg_conv1x1_sb_wrw_ws_floats(int B, int Cin, int Cout, int HW);
+int cseg_conv1x1_sb_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int HW, float* ws, float* dw,
+                        cseg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GPU data pipeline: random resize (cv2 INTER_CUBIC image / INTER_NEAREST label) -> random

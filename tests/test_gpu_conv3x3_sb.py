@@ -151,3 +151,22 @@ def test_pointwise_matches_fp64(case):
                                  ("dw", w64.grad, wd.grad, wr.grad), ("db", b64.grad, bd.grad, br.grad)):
         err, tol = _bound(t64, got.cpu(), fp32.cpu())
         assert err <= tol, (case, name, err, tol)
+
+
+@pytest.mark.skipif(os.environ.get("CSEG_TEST_SB_1X1") != "1", reason="1x1 split-bf16 kernels: first hardware run pending")
+@pytest.mark.parametrize("case", [(2, 48, 64, 8, 8), (1, 144, 160, 8, 12), (1, 720, 720, 8, 64), (1, 720, 256, 8, 64),
+                                  (2, 64, 256, 16, 16)])
+def test_pointwise_weight_gradient_matches_fp64(case):
+    from contrastiveseg_amd import kernels as K
+    B, ci, co, H, W = case
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, ci, H, W, generator=g)
+    dy = torch.randn(B, co, H, W, generator=g)
+    ref = torch.einsum("bohw,bchw->oc", dy.double(), x.double()).reshape(co, ci, 1, 1)
+    xd, dyd = x.cuda(), dy.cuda()
+    assert K.conv1x1_sb_wrw_eligible(xd, dyd)
+    got = K.conv1x1_sb_wrw(xd, dyd)
+    fp32 = torch.einsum("bohw,bchw->oc", dyd, xd).reshape(co, ci, 1, 1)
+    err, tol = _bound(ref, got.cpu(), fp32.cpu())
+    assert err <= tol, (case, err, tol)
+    assert torch.equal(got, K.conv1x1_sb_wrw(xd, dyd)), "weight gradient not deterministic"

@@ -40,6 +40,7 @@ def main():
         flops = 2.0 * B * H * W * ci * co
         rows = [("split_bf16 fwd (pack + conv)", timeit(lambda: K.conv1x1_sb_run(x, w, False))),
                 ("split_bf16 bwd_data (pack + conv)", timeit(lambda: K.conv1x1_sb_run(dy, w, True))),
+                ("split_bf16 bwd_weight (kernel + reduction)", timeit(lambda: K.conv1x1_sb_wrw(x, dy))),
                 ("fp32 fwd (torch)", timeit(lambda: F.conv2d(x, w))),
                 ("fp32 bwd_data (torch)", timeit(lambda: torch.ops.aten.convolution_backward(
                     dy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0])),

@@ -15,7 +15,7 @@ CSEG_TEST_SB_WRW_V2=1 CSEG_TEST_SB_1X1=1 timeout 300 python -m pytest tests/test
 timeout 200 python tools/conv3x3_sb_wrw_probe.py > $O/wrw_probe.jsonl 2> $O/wrw_probe.err; cat $O/wrw_probe.jsonl
 timeout 200 python tools/conv1x1_sb_probe.py > $O/c1_probe.jsonl 2> $O/c1_probe.err; cat $O/c1_probe.jsonl
 GOLD="tests/test_models_golden.py tests/test_step_golden.py tests/test_gpu_train_step.py"
-for cfg in "CSEG_CONV3X3_SB_WRW=1" "CSEG_CONV3X3_SB_WRW=1 CSEG_CONV3X3_SB_WRW_V=2" "CSEG_CONV3X3_SB_CHANNELS=48,96,192" "CSEG_CONV1X1_SPLIT_BF16=1"; do
+for cfg in "CSEG_CONV3X3_SB_WRW=1" "CSEG_CONV3X3_SB_WRW=1 CSEG_CONV3X3_SB_WRW_V=2" "CSEG_CONV3X3_SB_CHANNELS=48,96,192" "CSEG_CONV1X1_SPLIT_BF16=1" "CSEG_CONV1X1_SPLIT_BF16=1 CSEG_CONV1X1_SB_WRW=1"; do
   tag=$(echo "$cfg" | tr ' =,' '___')
   env $cfg timeout 400 python -m pytest $GOLD -q -x -m gpu > $O/gold_$tag.log 2>&1; echo "$cfg: $(tail -1 $O/gold_$tag.log)"
   env $cfg timeout 200 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-kernels --no-fp32-pass > $O/bench_$tag.json 2> $O/bench_$tag.err
