@@ -73,6 +73,7 @@ def test_autograd_matches_fp64(case):
         assert err <= tol, (case, name, err, tol)
 
 
+# (2, 48, 48, 40, 128): several runs and segments per split -- add once it has run on hardware
 WRW_CASES = [  # B, Cin, Cout, H, W
     (1, 48, 48, 5, 64),         # ragged 64-wide channel block (3 of 4 tiles), one run
     (2, 16, 48, 9, 128),        # two column segments, two runs (8 + 1 rows)
@@ -84,7 +85,7 @@ WRW_CASES = [  # B, Cin, Cout, H, W
 
 @pytest.mark.parametrize("version", ["1", pytest.param("2", marks=pytest.mark.skipif(
     os.environ.get("CSEG_TEST_SB_WRW_V2") != "1", reason="producer/consumer version: first hardware run pending"))])
-@pytest.mark.parametrize("case", WRW_CASES + [(2, 48, 48, 40, 128)])
+@pytest.mark.parametrize("case", WRW_CASES)
 def test_weight_gradient_matches_fp64(case, version, monkeypatch):
     from contrastiveseg_amd import kernels as K
     monkeypatch.setenv("CSEG_CONV3X3_SB_WRW_V", version)
@@ -104,6 +105,7 @@ def test_weight_gradient_matches_fp64(case, version, monkeypatch):
     assert torch.equal(got, K.conv3x3_sb_wrw(xd, dyd)), "weight gradient not deterministic"
 
 
+@pytest.mark.skipif(os.environ.get("CSEG_TEST_SB_NT") != "1", reason="explicit-tiling entry points: first hardware run pending")
 @pytest.mark.parametrize("nt", [3, 6])
 def test_explicit_channel_tiling_matches_default(nt):
     """cseg_conv3x3_sb_*_nt: same convolution whatever the number of channel tiles per block."""

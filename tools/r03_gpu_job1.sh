@@ -11,7 +11,7 @@ O=$R/gpurun_out/r03a
 mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests -m gpu -q --timeout 1200 > $O/gputest_default.log 2>&1; tail -3 $O/gputest_default.log
-CSEG_TEST_SB_WRW_V2=1 CSEG_TEST_SB_1X1=1 timeout 300 python -m pytest tests/test_gpu_conv3x3_sb.py -q > $O/sb_kernels.log 2>&1; tail -5 $O/sb_kernels.log | cut -c1-300
+CSEG_TEST_SB_WRW_V2=1 CSEG_TEST_SB_1X1=1 CSEG_TEST_SB_NT=1 timeout 300 python -m pytest tests/test_gpu_conv3x3_sb.py -q > $O/sb_kernels.log 2>&1; tail -5 $O/sb_kernels.log | cut -c1-300
 timeout 200 python tools/conv3x3_sb_wrw_probe.py > $O/wrw_probe.jsonl 2> $O/wrw_probe.err; cat $O/wrw_probe.jsonl
 timeout 200 python tools/conv1x1_sb_probe.py > $O/c1_probe.jsonl 2> $O/c1_probe.err; cat $O/c1_probe.jsonl
 GOLD="tests/test_models_golden.py tests/test_step_golden.py tests/test_gpu_train_step.py"
