@@ -225,7 +225,7 @@ def test_bench_launches_its_own_ranks():
     backend = [] if torch.cuda.device_count() >= 2 else ["--backend", "gloo"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--no-kernels", "--no-cpu-baseline", "--global-batch", "2"] + backend,
+                          "--no-kernels", "--no-cpu-baseline", "--no-fp32-pass", "--global-batch", "2"] + backend,
                          env=env, capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
