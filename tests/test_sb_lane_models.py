@@ -405,3 +405,26 @@ def test_pointwise_weight_gradient_index_logic(case):
     rs = np.random.RandomState(4)
     x, dy = rs.standard_normal((B, Cin, P)), rs.standard_normal((B, Cout, P))
     assert np.abs(q_model(x, dy, ns) - np.einsum("bop,bcp->oc", dy, x)).max() < 1e-10
+
+
+# ---------------------------------------------------------------- host-side dispatch heuristics (contrastiveseg_amd/kernels.py)
+def test_host_tiling_heuristics():
+    import torch
+    from contrastiveseg_amd import kernels as K
+    meta = lambda *s: torch.empty(*s, device="meta")
+    # channel tiles per block: largest tiling that still gives >= 256 blocks
+    assert K.conv3x3_sb_pick_nt(meta(8, 192, 32, 64), 192) == 3          # 128 blocks at nt 6 (measured 113 us) vs 256 at nt 3 (81 us)
+    assert K.conv3x3_sb_pick_nt(meta(8, 96, 64, 128), 96) == 6           # 256 blocks at nt 6 (70 us; nt 3: 89 us)
+    assert K.conv3x3_sb_pick_nt(meta(8, 720, 128, 256), 720) == 9
+    assert K.conv3x3_sb_pick_nt(meta(8, 48, 128, 256), 48) == 3
+    assert K.conv3x3_sb_pick_nt(meta(1, 384, 16, 32), 384) == 3          # never fills the chip: smallest tiling
+    # grid sizes used for the "does it fill the chip" gate
+    assert K.conv3x3_sb_tiles(meta(8, 720, 128, 256), 720) == 8 * 5 * 32 * 4
+    assert K.conv3x3_sb_tiles(meta(2, 48, 16, 32), 48) == 2 * 1 * 4 * 1 < K.CONV3X3_SB_MIN_TILES
+    assert K.conv1x1_sb_tiles(meta(8, 720, 128, 256), 256) == 8 * 2 * 128
+    assert K.conv1x1_sb_tiles(meta(8, 720, 128, 256), 720) == 8 * 5 * 128
+    # defaults: split-bf16 forward / backward-data on; the kernels that have not been through the step goldens off
+    assert isinstance(K.CONV3X3_SPLIT_BF16, bool) and K.CONV3X3_SB_BRANCH_CHANNELS[:2] == (48, 96)
+    import os
+    if "CSEG_CONV3X3_SB_WRW" not in os.environ and "CSEG_CONV1X1_SPLIT_BF16" not in os.environ:
+        assert not K.CONV3X3_SB_WRW and not K.CONV1X1_SPLIT_BF16 and not K.CONV1X1_SB_WRW
