@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from contrastiveseg_amd import kernels as K
 from contrastiveseg_amd.lib.models.tools.fused_bn import bn_act_group
-from contrastiveseg_amd.lib.models.tools.module_helper import Conv3x3, ModuleHelper
+from contrastiveseg_amd.lib.models.tools.module_helper import Conv1x1, Conv3x3, ModuleHelper
 
 # width -> per-stage (modules, blocks per branch); channel list is width * (1, 2, 4, 8)[:branches]
 STAGES = {2: (1, 4), 3: (4, 4), 4: (3, 4)}
@@ -25,7 +25,11 @@ def _norm(bn_type, c, momentum, act=None):
 
 def _conv_bn(cin, cout, k, stride, bn_type, momentum, relu):
     """conv -> BN [-> ReLU]; the ReLU (stateless third child in the reference) is fused into the norm kernel."""
-    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=False),
+    if k == 1 and stride == 1:
+        conv = Conv1x1(cin, cout, bias=False)
+    else:
+        conv = nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=False)
+    return nn.Sequential(conv,
                          _norm(bn_type, cout, momentum, 'relu' if relu else None))
 
 
@@ -52,11 +56,11 @@ class Bottleneck(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, downsample=None, bn_type=None, bn_momentum=0.1):
         super(Bottleneck, self).__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.conv1 = Conv1x1(inplanes, planes, bias=False)
         self.bn1 = _norm(bn_type, planes, bn_momentum)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
         self.bn2 = _norm(bn_type, planes, bn_momentum)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.conv3 = Conv1x1(planes, planes * 4, bias=False)
         self.bn3 = _norm(bn_type, planes * 4, bn_momentum)
         self.downsample = downsample
         self.stride = stride

@@ -7,29 +7,14 @@ match the reference so checkpoints and seeds interchange; the 1x1 convolutions a
 import torch.nn as nn
 import torch.nn.functional as F
 
-from contrastiveseg_amd.lib.models.tools.module_helper import ModuleHelper
+from contrastiveseg_amd.lib.models.tools.module_helper import Conv1x1, ModuleHelper
 from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
 
 _KINDS = ('linear', 'convmlp')
 
 
-class Pointwise(nn.Conv2d):
-    """nn.Conv2d(cin, cout, 1) (same parameters / state_dict). With kernels.CONV1X1_SPLIT_BF16 on, forward and
-    backward-data of the shapes the split-bf16 kernel covers (csrc/conv1x1_sb.hip) run there; otherwise rocBLAS / MIOpen."""
-
-    def __init__(self, cin, cout):
-        super(Pointwise, self).__init__(cin, cout, kernel_size=1)
-
-    def forward(self, x):
-        from contrastiveseg_amd import kernels as K
-        if (x.is_cuda and K.CONV1X1_SPLIT_BF16 and K.conv1x1_sb_eligible(x, self.weight)
-                and K.conv1x1_sb_tiles(x, self.out_channels) >= K.CONV1X1_SB_MIN_TILES):
-            return K.conv1x1_split_bf16(x, self.weight, self.bias)
-        return super(Pointwise, self).forward(x)
-
-
 def _pointwise(cin, cout):
-    return Pointwise(cin, cout)
+    return Conv1x1(cin, cout)            # an nn.Conv2d(cin, cout, 1); split-bf16 kernel when switched on
 
 
 class ProjectionHead(nn.Module):

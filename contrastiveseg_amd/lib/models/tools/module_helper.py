@@ -53,6 +53,22 @@ class HeadConv3x3(nn.Conv2d):
         return super(HeadConv3x3, self).forward(x)
 
 
+class Conv1x1(nn.Conv2d):
+    """nn.Conv2d(cin, cout, 1) (same parameters / state_dict). With kernels.CONV1X1_SPLIT_BF16 on, forward and
+    backward-data of the shapes the split-bf16 kernel covers (csrc/conv1x1_sb.hip) run there -- and the weight gradient
+    with kernels.CONV1X1_SB_WRW -- otherwise this is the reference's pointwise convolution on rocBLAS / MIOpen."""
+
+    def __init__(self, cin, cout, bias=True):
+        super(Conv1x1, self).__init__(cin, cout, kernel_size=1, bias=bias)
+
+    def forward(self, x):
+        from contrastiveseg_amd import kernels as K
+        if (x.is_cuda and K.CONV1X1_SPLIT_BF16 and K.conv1x1_sb_eligible(x, self.weight)
+                and K.conv1x1_sb_tiles(x, self.out_channels) >= K.CONV1X1_SB_MIN_TILES):
+            return K.conv1x1_split_bf16(x, self.weight, self.bias)
+        return super(Conv1x1, self).forward(x)
+
+
 class ModuleHelper(object):
     @staticmethod
     def BatchNorm2d(bn_type='torch', ret_cls=False):
