@@ -151,6 +151,37 @@ def _check_bank_unchanged(versions, segment_queue, pixel_queue):
                            "Trainer.train_step does, or pass clones of the queues)")
 
 
+# Row-sparse hand-over of the embedding gradient (opt-in, first hardware run pending): the contrastive term touches
+# <= max_samples pixels of the [B,D,h,w] embedding, so its gradient is N rows and the rest zeros. With the switch on, the
+# projection head (lib/models/modules/projection.py) tags the embedding it returns with a SparseGradSlot; the loss'
+# backward deposits (rows, pixel indices) there and returns a zero tensor WITHOUT storage (stride 0) as the dense
+# gradient, and the head's backward works on the N rows only (no 268 MB memset + scatter, no dense normalise / 1x1
+# backward at bs 8). Any other consumer of the embedding simply adds a real dense gradient, which the head detects.
+SPARSE_EMBED_GRAD = os.environ.get("CSEG_SPARSE_EMBED_GRAD", "0") == "1"
+
+
+class SparseGradSlot(object):
+    __slots__ = ("deposits", "_sentinel")
+
+    def __init__(self):
+        self.deposits = []          # [(rows [n,D] f32, sel_pix [n] i32 = b * P + pixel)]
+        self._sentinel = None
+
+    def deposit(self, rows, sel_pix, shape):
+        """Stores the rows and returns the storage-free stand-in for the dense gradient of an embedding of `shape`."""
+        self.deposits.append((rows, sel_pix))
+        self._sentinel = rows.new_zeros((1,) * len(shape)).expand(shape)
+        return self._sentinel
+
+    def is_standin(self, g):
+        s = self._sentinel
+        return s is not None and g.data_ptr() == s.data_ptr() and not any(g.stride())
+
+    def take(self):
+        d, self.deposits, self._sentinel = self.deposits, [], None
+        return d
+
+
 class ContrastOnAnchors(Function):
     """loss = _contrastive(anchors, ...) with anchors already gathered ([N,D], view-major rows).
     mode: 'self' | 'plain' | 'bank'. Gradient flows to `anchors` only (the reference gives the bank none,
@@ -184,10 +215,11 @@ class PixelContrast(Function):
 
     @staticmethod
     def forward(ctx, embed, part_idx, sel_pos, a_lab, mode, temperature, base_temperature, segment_queue,
-                pixel_queue):
+                pixel_queue, slot=None):
         if not embed.is_contiguous():
             embed = embed.contiguous()
         anchors, sel_pix = gather_anchors(embed, part_idx, sel_pos)
+        ctx.slot = slot
         m = {"self": 0, "bank": 2}[mode]
         desc = _desc(m, anchors, a_lab, temperature, base_temperature, None, None, segment_queue, pixel_queue)
         loss, saved = contrast_forward(desc, embed.device)
@@ -205,22 +237,26 @@ class PixelContrast(Function):
         dev = ctx.sel_pix.device
         _check_bank_unchanged(ctx.bank_versions, ctx.keep[2], ctx.keep[3])
         parts = contrast_backward(ctx.desc, ctx.saved, g, dev)
+        if ctx.slot is not None:
+            rows = parts.sum(0) if parts.shape[0] > 1 else parts[0]
+            return (ctx.slot.deposit(rows, ctx.sel_pix, ctx.embed_shape),) + (None,) * 9
         d_embed = torch.zeros(B, D, h, w, dtype=F32, device=dev)
         _hip.call("cseg_scatter_anchor_grad", _p(parts, F32, "parts"), parts.shape[0], _p(ctx.sel_pix, I32, "sel_pix"),
                   parts.shape[1], D, h * w, 1.0, _p(d_embed, F32, "d_embed"), _hip.stream_ptr())
-        return (d_embed,) + (None,) * 8
+        return (d_embed,) + (None,) * 9
 
 
 class GatherAnchors(Function):
     """anchors = embed[b, :, pix] rows (differentiable): used when the contrast set is assembled across ranks."""
 
     @staticmethod
-    def forward(ctx, embed, part_idx, sel_pos):
+    def forward(ctx, embed, part_idx, sel_pos, slot=None):
         if not embed.is_contiguous():
             embed = embed.contiguous()
         anchors, sel_pix = gather_anchors(embed, part_idx, sel_pos)
         ctx.sel_pix = sel_pix
         ctx.embed_shape = embed.shape
+        ctx.slot = slot
         ctx.mark_non_differentiable(sel_pix)
         return anchors, sel_pix
 
@@ -228,10 +264,12 @@ class GatherAnchors(Function):
     def backward(ctx, g, _):
         B, D, h, w = ctx.embed_shape
         g = g.contiguous()
+        if ctx.slot is not None:
+            return ctx.slot.deposit(g, ctx.sel_pix, ctx.embed_shape), None, None, None
         d_embed = torch.zeros(B, D, h, w, dtype=F32, device=g.device)
         _hip.call("cseg_scatter_anchor_grad", _p(g, F32, "d_anchors"), 1, _p(ctx.sel_pix, I32, "sel_pix"),
                   g.shape[0], D, h * w, 1.0, _p(d_embed, F32, "d_embed"), _hip.stream_ptr())
-        return d_embed, None, None
+        return d_embed, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------------------

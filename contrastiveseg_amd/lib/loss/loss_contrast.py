@@ -62,6 +62,12 @@ def _counts_to_host(cp):
     return counts
 
 
+def _grad_slot(embed):
+    """kernels.SparseGradSlot the projection head attached to the embedding it produced (row-sparse backward, opt-in:
+    lib/models/modules/projection.py), or None = the dense zero-filled gradient."""
+    return getattr(embed, '_cseg_grad_slot', None)
+
+
 class PixelContrastLoss(nn.Module, ABC):
     def __init__(self, configer):
         super(PixelContrastLoss, self).__init__()
@@ -151,7 +157,7 @@ class PixelContrastLoss(nn.Module, ABC):
         sel_pos = torch.from_numpy(plan.row_img.astype(np.int32) * P + plan.row_off).to(dev, non_blocking=True)
         a_lab = torch.from_numpy(plan.row_lab.astype(np.int32)).to(dev, non_blocking=True)
         loss, sel_pix = K.PixelContrast.apply(feats, cp["part_idx"], sel_pos, a_lab, "self", self.temperature,
-                                              self.base_temperature, None, None)
+                                              self.base_temperature, None, None, _grad_slot(feats))
         self.last_selection = {"sel_pix": sel_pix, "plan": plan}
         return loss
 
@@ -176,7 +182,7 @@ class PixelContrastLoss(nn.Module, ABC):
         rows_local = (np.arange(V)[:, None] * T + mine[None, :]).reshape(-1)
         sel_pos = torch.from_numpy(((plan.row_img[rows_local] - rank * B) * P + plan.row_off[rows_local])
                                    .astype(np.int32)).to(dev)
-        anchors_l, sel_pix = K.GatherAnchors.apply(feats, cp["part_idx"], sel_pos)
+        anchors_l, sel_pix = K.GatherAnchors.apply(feats, cp["part_idx"], sel_pos, _grad_slot(feats))
         t_max = max(t_r)
         pad = torch.zeros(t_max * V, feats.shape[1], dtype=feats.dtype, device=dev)
         pad[:anchors_l.shape[0]] = anchors_l.detach()

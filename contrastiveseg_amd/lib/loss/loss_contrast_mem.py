@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from contrastiveseg_amd import kernels as K
 from contrastiveseg_amd.lib.loss.loss_contrast import PixelContrastLoss as _SelfPixelContrastLoss
-from contrastiveseg_amd.lib.loss.loss_contrast import _counts_to_host
+from contrastiveseg_amd.lib.loss.loss_contrast import _counts_to_host, _grad_slot
 from contrastiveseg_amd.lib.loss.loss_helper import FSAuxCELoss, FSCELoss
 from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
 
@@ -39,7 +39,7 @@ class PixelContrastLoss(_SelfPixelContrastLoss):
         a_lab = torch.from_numpy(plan.row_lab.astype(np.int32)).to(dev, non_blocking=True)
         loss, sel_pix = K.PixelContrast.apply(feats, cp["part_idx"], sel_pos, a_lab, "bank", self.temperature,
                                               self.base_temperature, segment_queue.contiguous(),
-                                              pixel_queue.contiguous())
+                                              pixel_queue.contiguous(), _grad_slot(feats))
         self.last_selection = {"sel_pix": sel_pix, "plan": plan}
         return loss
 

@@ -26,30 +26,57 @@ def _all_reduce(t, group):
     return t
 
 
+def bn_forward(x, weight, bias, residual, running_mean, running_var, num_batches_tracked, training, relu, momentum, eps,
+               sync_group):
+    """Device half of one BN(+residual)(+ReLU) site -> (y, mean_invstd [C,2], count). x / residual contiguous.
+    sync_group: None = local statistics; otherwise the process group whose ranks share statistics."""
+    n_local = x.numel() // x.shape[1]
+    count = float(n_local)
+    if training:
+        if sync_group is not None:
+            world = torch.distributed.get_world_size(sync_group)
+            moments = _all_reduce(K.bn_stats(x), sync_group)
+            count = float(n_local * world)          # equal per-rank batch (data_loader.py:137 splits evenly)
+            mi = K.bn_finalize(moments, count, eps, momentum, running_mean, running_var, num_batches_tracked)
+            y = K.bn_apply(x, mi, weight, bias, residual, relu)
+        else:
+            # single rank: statistics + (finalise, running statistics, apply) in two launches
+            y, mi = K.bn_fwd(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var,
+                             num_batches_tracked)
+    else:
+        mi = torch.stack([running_mean, torch.rsqrt(running_var + eps)], dim=1).contiguous()
+        y = K.bn_apply(x, mi, weight, bias, residual, relu)
+    return y, mi, count
+
+
+def bn_backward(dy, x, out, mi, weight, bias, relu, has_res, training, count, sync_group, want_dx):
+    """Adjoint of bn_forward -> (dx or None, d_weight, d_bias, gradient of the residual or None). dy contiguous; `out` is
+    the forward's output when a residual was added under the ReLU (the mask cannot be rebuilt from x then)."""
+    mode = 0 if not relu else (2 if has_res else 1)
+    if sync_group is None or not training:
+        # single rank (or frozen statistics): reduce + (sums, parameter gradients, dx) in two launches
+        dx, d_weight, d_bias, g = K.bn_bwd(dy, x, out, mi, weight, bias, mode, training, want_dx)
+    else:
+        sums, d_weight, d_bias, g = K.bn_bwd_reduce(dy, x, out, mi, weight, bias, mode)
+        dx = None
+        if want_dx:
+            sums = _all_reduce(sums, sync_group)
+            dx = K.bn_bwd_apply(g if mode == 2 else dy, x, mi, weight, bias, sums, count, mode == 1)
+    d_res = None
+    if has_res:
+        d_res = g if mode == 2 else dy          # the add passes the (masked) gradient straight through
+    return dx, d_weight, d_bias, d_res
+
+
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, num_batches_tracked, training, relu,
                 momentum, eps, sync_group):
-        """sync_group: None = local statistics; otherwise the process group whose ranks share statistics."""
         x = x.contiguous()
         if residual is not None:
             residual = residual.contiguous()
-        n_local = x.numel() // x.shape[1]
-        count = float(n_local)
-        if training:
-            if sync_group is not None:
-                world = torch.distributed.get_world_size(sync_group)
-                moments = _all_reduce(K.bn_stats(x), sync_group)
-                count = float(n_local * world)          # equal per-rank batch (data_loader.py:137 splits evenly)
-                mi = K.bn_finalize(moments, count, eps, momentum, running_mean, running_var, num_batches_tracked)
-                y = K.bn_apply(x, mi, weight, bias, residual, relu)
-            else:
-                # single rank: statistics + (finalise, running statistics, apply) in two launches
-                y, mi = K.bn_fwd(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var,
-                                 num_batches_tracked)
-        else:
-            mi = torch.stack([running_mean, torch.rsqrt(running_var + eps)], dim=1).contiguous()
-            y = K.bn_apply(x, mi, weight, bias, residual, relu)
+        y, mi, count = bn_forward(x, weight, bias, residual, running_mean, running_var, num_batches_tracked, training,
+                                  relu, momentum, eps, sync_group)
         ctx.meta = (training, relu, residual is not None, count, sync_group)
         ctx.save_for_backward(x, mi, weight, bias, y if (relu and residual is not None) else None)
         return y
@@ -58,20 +85,8 @@ class _BNAct(torch.autograd.Function):
     def backward(ctx, dy):
         x, mi, weight, bias, out = ctx.saved_tensors
         training, relu, has_res, count, sync_group = ctx.meta
-        dy = dy.contiguous()
-        mode = 0 if not relu else (2 if has_res else 1)
-        if sync_group is None or not training:
-            # single rank (or frozen statistics): reduce + (sums, parameter gradients, dx) in two launches
-            dx, d_weight, d_bias, g = K.bn_bwd(dy, x, out, mi, weight, bias, mode, training, ctx.needs_input_grad[0])
-        else:
-            sums, d_weight, d_bias, g = K.bn_bwd_reduce(dy, x, out, mi, weight, bias, mode)
-            dx = None
-            if ctx.needs_input_grad[0]:
-                sums = _all_reduce(sums, sync_group)
-                dx = K.bn_bwd_apply(g if mode == 2 else dy, x, mi, weight, bias, sums, count, mode == 1)
-        d_res = None
-        if has_res:
-            d_res = g if mode == 2 else dy          # the add passes the (masked) gradient straight through
+        dx, d_weight, d_bias, d_res = bn_backward(dy.contiguous(), x, out, mi, weight, bias, relu, has_res, training,
+                                                  count, sync_group, ctx.needs_input_grad[0])
         return (dx, d_weight if weight is not None else None, d_bias if bias is not None else None,
                 d_res if ctx.needs_input_grad[3] else None, None, None, None, None, None, None, None, None)
 

@@ -1,0 +1,223 @@
+"""Row-sparse backward of the projection head (lib/models/modules/projection.py:_SparseTail, opt-in switch
+kernels.SPARSE_EMBED_GRAD) against the dense autograd route, on CPU with the device ops of oracle/cpu_port.py injected:
+same forward, same gradients for the head input and every head parameter, through the plain criterion, the memory-bank
+criterion and with a second (dense) consumer of the embedding."""
+import numpy as np
+import pytest
+import torch
+
+from contrastiveseg_amd import kernels as Kn
+from contrastiveseg_amd.lib.loss.loss_manager import SEG_LOSS_DICT
+from contrastiveseg_amd.lib.models.modules.projection import ProjectionHead
+from contrastiveseg_amd.lib.utils.tools.configer import Configer
+from oracle import cpu_port
+from oracle import cseg_oracle as O
+
+
+def _cfg(K, D, loss_type):
+    return Configer(config_dict={
+        "data": {"num_classes": K}, "network": {"loss_weights": {"aux_loss": 0.4, "seg_loss": 1.0}},
+        "contrast": {"proj_dim": D, "temperature": 0.1, "base_temperature": 0.07, "max_samples": 96, "max_views": 8,
+                     "loss_weight": 0.1, "use_rmi": False, "memory_size": 6},
+        "loss": {"loss_type": loss_type, "params": {"ce_ignore_index": -1, "ce_reduction": "elementwise_mean"}}})
+
+
+def _run(monkeypatch, sparse, loss_type, extra_consumer=False, train_bn=True, seed=5):
+    monkeypatch.setattr(Kn, "SPARSE_EMBED_GRAD", sparse)
+    K, D, C = 5, 16, 24
+    target, seg, _ = O.synth_case(seed, 2, K, 32, 64, 4, D)
+    torch.manual_seed(11)
+    head = ProjectionHead(C, D, bn_type='torchbn')
+    head.train(train_bn)
+    if not train_bn:
+        with torch.no_grad():
+            head.proj[1][0].running_mean.normal_(0, 0.3)
+            head.proj[1][0].running_var.uniform_(0.5, 1.5)
+    feats = torch.randn(2, C, 8, 16, generator=torch.Generator().manual_seed(3)).requires_grad_(True)
+    crit = SEG_LOSS_DICT[loss_type](_cfg(K, D, loss_type))
+    embed = head(feats)
+    assert (getattr(embed, "_cseg_grad_slot", None) is not None) == bool(sparse)
+    preds = {"seg": torch.from_numpy(seg).requires_grad_(True), "embed": embed}
+    if loss_type.startswith("mem"):
+        g = torch.Generator().manual_seed(9)
+        preds["segment_queue"] = torch.nn.functional.normalize(torch.randn(K, 6, D, generator=g), dim=2)
+        preds["pixel_queue"] = torch.nn.functional.normalize(torch.randn(K, 6, D, generator=g), dim=2)
+    torch.manual_seed(304)
+    loss = crit(preds, torch.from_numpy(target), with_embed=True)
+    if extra_consumer:
+        wgt = torch.randn(embed.shape, generator=torch.Generator().manual_seed(4))
+        loss = loss + 1e-3 * (embed * wgt).sum()
+    loss.backward()
+    out = {"loss": loss.detach(), "embed": embed.detach(), "d_feats": feats.grad}
+    out.update({"d_" + n: p.grad for n, p in head.named_parameters()})
+    out["running_mean"] = head.proj[1][0].running_mean.clone()
+    return out
+
+
+@pytest.mark.parametrize("loss_type", ["contrast_ce_loss", "mem_contrast_ce_loss"])
+@pytest.mark.parametrize("extra_consumer", [False, True])
+@pytest.mark.parametrize("train_bn", [True, False])
+def test_sparse_route_equals_dense_autograd(monkeypatch, loss_type, extra_consumer, train_bn):
+    cpu_port.install(monkeypatch)
+    dense = _run(monkeypatch, False, loss_type, extra_consumer, train_bn)
+    sparse = _run(monkeypatch, True, loss_type, extra_consumer, train_bn)
+    assert torch.equal(dense["embed"], sparse["embed"])
+    assert torch.equal(dense["running_mean"], sparse["running_mean"])
+    assert float(dense["loss"]) == float(sparse["loss"])
+    grads = [k for k in dense if k.startswith("d_")]
+    floor = 1e-3 * max(float(dense[k].abs().max()) for k in grads)
+    for k in grads:
+        assert sparse[k] is not None, k
+        ref = dense[k]
+        err = float((sparse[k] - ref).abs().max())
+        if k == "d_proj.0.bias" and train_bn:
+            # a bias in front of a training-mode BN has an exactly-zero gradient: both routes return the rounding noise
+            # of summing d(conv output) over all pixels
+            assert max(err, float(ref.abs().max())) <= 1e-3 * floor, (k, err, float(ref.abs().max()))
+            continue
+        assert err <= 2e-5 * max(float(ref.abs().max()), floor), (k, err, float(ref.abs().max()))
+        assert float(ref.abs().max()) > 0, k
+
+
+def test_standin_has_no_storage_and_is_recognised():
+    slot = Kn.SparseGradSlot()
+    rows = torch.ones(3, 4)
+    s = slot.deposit(rows, torch.tensor([0, 5, 9], dtype=torch.int32), (2, 4, 2, 3))
+    assert s.shape == (2, 4, 2, 3) and not any(s.stride()) and float(s.abs().sum()) == 0.0
+    assert slot.is_standin(s) and not slot.is_standin(torch.zeros(2, 4, 2, 3))
+    assert not slot.is_standin(s + s)                       # what autograd produces when two consumers add up
+    (r, sel), = slot.take()
+    assert r is rows and sel.tolist() == [0, 5, 9] and slot.take() == [] and not slot.is_standin(s)
+
+
+def test_switch_is_off_by_default():
+    import os
+    assert Kn.SPARSE_EMBED_GRAD == (os.environ.get("CSEG_SPARSE_EMBED_GRAD", "0") == "1")
+
+
+# ---- two ranks (gloo): SyncBN statistics sums of the sparse route are all-reduced, and the cross-rank criterion deposits
+# through GatherAnchors ------------------------------------------------------------------------------------------------
+def _two_rank_worker(rank, world, port, q):
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cpu_port.install(None)
+    from contrastiveseg_amd.lib.loss.loss_contrast import PixelContrastLoss
+    K, D, C = 5, 16, 24
+    target, seg, _ = O.synth_case(5, 4, K, 32, 64, 4, D)
+    sl = slice(2 * rank, 2 * rank + 2)
+    cfg = _cfg(K, D, "contrast_ce_loss")
+    cfg.add(["contrast", "cross_rank"], True)
+    cfg.add(["contrast", "cross_rank_rng"], "global")
+    out = {}
+    for sparse in (False, True):
+        Kn.SPARSE_EMBED_GRAD = sparse
+        torch.manual_seed(11)
+        head = ProjectionHead(C, D, bn_type='torchsyncbn').train()
+        feats = torch.randn(4, C, 8, 16, generator=torch.Generator().manual_seed(3))[sl].clone().requires_grad_(True)
+        embed = head(feats)
+        assert (getattr(embed, "_cseg_grad_slot", None) is not None) == sparse
+        torch.manual_seed(304)
+        loss = PixelContrastLoss(cfg)(embed, torch.from_numpy(target[sl]), seg=torch.from_numpy(seg[sl]))
+        loss.backward()
+        out[sparse] = [float(loss.detach()), feats.grad.numpy()] + [p.grad.numpy() for p in head.parameters()]
+    q.put((rank, out[False], out[True]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_syncbn_and_cross_rank_deposit():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, dense, sparse in res:
+        assert dense[0] == sparse[0]
+        scale = max(float(np.abs(t).max()) for t in dense[1:])
+        for i, (a, b) in enumerate(zip(dense[1:], sparse[1:])):
+            # (proj.0.bias: only the SUM over ranks of this gradient is zero under SyncBN; the rank-local value is not)
+            assert float(np.abs(a - b).max()) <= 2e-5 * max(float(np.abs(a).max()), 1e-3 * scale), (rank, i)
+
+
+@pytest.mark.parametrize("cfg_file,model_over", [("synthetic/R_18_D_8_tiny.json", {}),
+                                                  ("cityscapes/R_101_D_8_MEM.json", {"backbone": "deepbase_resnet18_dilated8"})])
+def test_trainer_steps_identically_with_the_sparse_route(cfg_file, model_over, monkeypatch):
+    """Whole train steps (model -> preds dict -> criterion -> backward -> SGD) with the switch off and on: the slot travels
+    on the embedding tensor through the model's output dict (and the memory model's `ret.update`), the deposits are
+    consumed, and the first-step gradients of every convolution / BN weight agree."""
+    import os
+    cpu_port.install(monkeypatch)
+    from contrastiveseg_amd.segmentor.tools.data_helper import SyntheticLoader
+    from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    taken = []
+    real_take = Kn.SparseGradSlot.take
+
+    def spy(self):
+        d = real_take(self)
+        taken.append(len(d))
+        return d
+    monkeypatch.setattr(Kn.SparseGradSlot, "take", spy)
+    weights = {}
+    for sparse in (False, True):
+        monkeypatch.setattr(Kn, "SPARSE_EMBED_GRAD", sparse)
+        cfg = Configer(configs=os.path.join(root, "configs", cfg_file))
+        for k, v in model_over.items():
+            cfg.update(["network", k], v)
+        cfg.update(["network", "bn_type"], "torchbn")
+        if cfg.get("data", "num_classes") > 6:
+            cfg.update(["data", "num_classes"], 6)
+            cfg.get("loss", "params").pop("ce_weight", None)
+        cfg.update(["train", "batch_size"], 2)
+        cfg.get("train", "data_transformer")["input_size"] = [96, 64]
+        cfg.update(["contrast", "warmup_iters"], 0)
+        cfg.update(["contrast", "max_views"], 6)
+        if cfg.exists("contrast", "memory_size"):
+            cfg.update(["contrast", "memory_size"], 16)
+        cfg.update(["solver", "max_iters"], 2)
+        cfg.add(["network", "pretrained"], None)
+        cfg.add(["network", "resume"], None)
+        cfg.add(["gpu"], None)
+        torch.manual_seed(304)
+        tr = Trainer(cfg, train_loader=[])
+        tr.seg_net.train()
+        for m in tr.seg_net.modules():
+            if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
+                m.p = 0.0
+        torch.manual_seed(7)
+        losses, grads = [], None
+        for b in SyntheticLoader(cfg, torch.device("cpu"), length=2, seed=1, mode="blocky"):
+            losses.append(float(tr.train_step(b)))
+            if grads is None:
+                grads = {k: p.grad.detach().clone() for k, p in tr.seg_net.named_parameters() if p.grad is not None}
+        weights[sparse] = (losses, {k: v.detach().clone() for k, v in tr.seg_net.state_dict().items()
+                                    if v.dtype.is_floating_point and "queue" not in k}, grads)
+    assert taken == [1, 1], taken                     # one deposit consumed per step, on the sparse run only
+    assert abs(weights[False][0][0] - weights[True][0][0]) <= 1e-6 * abs(weights[False][0][0])
+    # convolution / BN weights only: the zero-initialised biases in front of training-mode BNs have zero gradients and
+    # hold nothing but rounding noise on either route
+    worst = max((float((weights[True][1][k] - ref).norm() / ref.norm().clamp_min(1e-12)), k)
+                for k, ref in weights[False][1].items() if k.endswith(".weight"))
+    print("worst relative L2 difference of a weight tensor after two steps:", worst)
+    gworst = max((float((weights[True][2][k] - ref).norm() / ref.norm().clamp_min(1e-12)), k)
+                 for k, ref in weights[False][2].items() if k.endswith(".weight"))
+    print("worst relative L2 difference of a first-step gradient:", gworst)
+    # the routes differ by summation order only (1e-6 on the first gradient); the second step sees that difference through
+    # a freshly initialised network whose backward amplifies perturbations -> sanity bound only
+    assert gworst[0] <= 1e-5, gworst
+    assert worst[0] <= 5e-3, worst
