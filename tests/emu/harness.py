@@ -1,0 +1,132 @@
+"""TEST INFRASTRUCTURE. ctypes binding of tests/emu/_build/libcseg_emu.so (kernel sources of contrastiveseg_amd/csrc compiled
+for the host against the CPU emulation of wave64 / LDS / MFMA, see hip/hip_runtime.h) with numpy arrays as the "device"
+buffers, plus float64 references of the convolutions."""
+import ctypes
+
+import numpy as np
+
+from . import build_emu
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build_emu.build())
+        for name in ("cseg_conv3x3_sb_packed_bytes", "cseg_conv1x1_sb_packed_bytes", "cseg_conv3x3_sb_wrw_ws_floats",
+                     "cseg_conv1x1_sb_wrw_ws_floats"):
+            getattr(_LIB, name).restype = ctypes.c_size_t
+        _LIB.cseg_last_error.restype = ctypes.c_char_p
+    return _LIB
+
+
+def aligned(shape, dtype=np.float32, fill=None):
+    """16-byte aligned array (the entry points check the alignment they vectorise on), NaN-filled unless told otherwise
+    so that elements a kernel fails to write are visible."""
+    n = int(np.prod(shape))
+    item = np.dtype(dtype).itemsize
+    raw = np.zeros(n * item + 64, dtype=np.uint8)
+    off = (-raw.ctypes.data) % 16
+    a = raw[off:off + n * item].view(dtype).reshape(shape)
+    if fill is None:
+        fill = np.nan if np.issubdtype(np.dtype(dtype), np.floating) else 0
+    a[...] = fill
+    return a
+
+
+def dev(a):
+    """Copy of `a` in an aligned fp32 buffer."""
+    out = aligned(a.shape, np.float32, 0.0)
+    out[...] = a
+    return out
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def call(name, *args):
+    if getattr(lib(), name)(*args) != 1:
+        raise RuntimeError("%s: %s" % (name, lib().cseg_last_error().decode()))
+
+
+# ---- entry points ------------------------------------------------------------------------------------------------------
+def conv3x3_sb(x, w, bias=None, transpose_flip=False, nt=0):
+    co, ci = w.shape[:2]
+    conv_in, conv_out = (co, ci) if transpose_flip else (ci, co)
+    B, _, H, W = x.shape
+    n = lib().cseg_conv3x3_sb_packed_bytes(conv_in, conv_out)
+    assert n > 0
+    wp = aligned((n,), np.uint8, 0xFF)
+    y = aligned((B, conv_out, H, W))
+    xd, wd, bd = dev(x), dev(w), (None if bias is None else dev(bias))
+    if nt:
+        call("cseg_conv3x3_sb_pack_weights_nt", ptr(wd), co, ci, int(transpose_flip), nt, ptr(wp), None)
+        call("cseg_conv3x3_sb_fwd_nt", ptr(xd), ptr(wp), ptr(bd), B, conv_in, conv_out, H, W, nt, ptr(y), None)
+    else:
+        call("cseg_conv3x3_sb_pack_weights", ptr(wd), co, ci, int(transpose_flip), ptr(wp), None)
+        call("cseg_conv3x3_sb_fwd", ptr(xd), ptr(wp), ptr(bd), B, conv_in, conv_out, H, W, ptr(y), None)
+    return y
+
+
+def conv3x3_sb_wrw(x, dy):
+    B, ci, H, W = x.shape
+    co = dy.shape[1]
+    n = lib().cseg_conv3x3_sb_wrw_ws_floats(B, ci, co, H, W)
+    assert n > 0
+    ws, dw = aligned((n,)), aligned((co, ci, 3, 3))
+    call("cseg_conv3x3_sb_wrw", ptr(dev(x)), ptr(dev(dy)), B, ci, co, H, W, ptr(ws), ptr(dw), None)
+    return dw
+
+
+def conv1x1_sb(x, w, bias=None, transpose=False):
+    co, ci = w.shape[:2]
+    conv_in, conv_out = (co, ci) if transpose else (ci, co)
+    B, _, H, W = x.shape
+    n = lib().cseg_conv1x1_sb_packed_bytes(conv_in, conv_out)
+    assert n > 0
+    wp = aligned((n,), np.uint8, 0xFF)
+    y = aligned((B, conv_out, H, W))
+    call("cseg_conv1x1_sb_pack_weights", ptr(dev(w)), co, ci, int(transpose), ptr(wp), None)
+    call("cseg_conv1x1_sb_fwd", ptr(dev(x)), ptr(wp), ptr(None if bias is None else dev(bias)), B, conv_in, conv_out, H * W,
+         ptr(y), None)
+    return y
+
+
+def conv1x1_sb_wrw(x, dy):
+    B, ci, H, W = x.shape
+    co = dy.shape[1]
+    n = lib().cseg_conv1x1_sb_wrw_ws_floats(B, ci, co, H * W)
+    assert n > 0
+    ws, dw = aligned((n,)), aligned((co, ci, 1, 1))
+    call("cseg_conv1x1_sb_wrw", ptr(dev(x)), ptr(dev(dy)), B, ci, co, H * W, ptr(ws), ptr(dw), None)
+    return dw
+
+
+# ---- float64 references ------------------------------------------------------------------------------------------------
+def ref_conv3x3(x, w, bias=None):
+    B, ci, H, W = x.shape
+    xp = np.zeros((B, ci, H + 2, W + 2))
+    xp[:, :, 1:-1, 1:-1] = x
+    y = np.zeros((B, w.shape[0], H, W))
+    for ky in range(3):
+        for kx in range(3):
+            y += np.einsum("bchw,oc->bohw", xp[:, :, ky:ky + H, kx:kx + W], w[:, :, ky, kx].astype(np.float64))
+    return y if bias is None else y + bias.astype(np.float64)[None, :, None, None]
+
+
+def ref_conv3x3_bwd_data(dy, w):
+    """dx of conv3x3 (stride 1, pad 1): correlation with the transposed, mirrored weights."""
+    return ref_conv3x3(dy, np.ascontiguousarray(w.transpose(1, 0, 2, 3)[:, :, ::-1, ::-1]))
+
+
+def ref_conv3x3_wrw(x, dy):
+    B, ci, H, W = x.shape
+    xp = np.zeros((B, ci, H + 2, W + 2))
+    xp[:, :, 1:-1, 1:-1] = x
+    dw = np.zeros((dy.shape[1], ci, 3, 3))
+    for ky in range(3):
+        for kx in range(3):
+            dw[:, :, ky, kx] = np.einsum("bohw,bchw->oc", dy.astype(np.float64), xp[:, :, ky:ky + H, kx:kx + W])
+    return dw

@@ -1,0 +1,141 @@
+// TEST INFRASTRUCTURE -- CPU emulation of the execution model the split-bf16 kernels are written against, so that the
+// kernel SOURCES under contrastiveseg_amd/csrc can be run functionally in `-m "not gpu"` tests on a machine without a GPU.
+// This header stands in for <hip/hip_runtime.h> when tests/emu/build_emu.py compiles a .hip file for the host
+// (x86-64 clang, -I tests/emu first on the include path). Nothing here is part of the product.
+//
+// Model: one kernel launch = blocks executed one after the other; the threads of a block are fibers (ucontext) run by a
+// cooperative scheduler, wave by wave (64 consecutive threads). A thread runs until it reaches
+//   __syncthreads()                      -> block barrier: released when every live thread of the block has arrived
+//   a wave-level operation (MFMA, shfl)  -> wave rendezvous: the 64 lanes exchange registers, then continue
+// Threads that return drop out of the barriers, as exited waves do on the hardware. A pass of the scheduler in which no
+// thread makes progress is a deadlock (divergent barrier) and aborts with a message.
+// The order in which waves are scheduled between two block barriers is a launch parameter (ascending, descending or a
+// seeded shuffle: CSEG_EMU_WAVE_ORDER): a result that depends on it exposes a missing barrier between a producer and a
+// consumer wave.
+// Emulated device operations (semantics from the CDNA3/4 ISA guides; the MFMA operand layout is additionally pinned by
+// kernels that have passed parity on an MI355X and must keep passing here):
+//   v_mfma_f32_16x16x32_bf16   A[i][k]: lane i + 16*(k/8), element k%8;  B[k][j]: lane j + 16*(k/8), element k%8;
+//                              D[i][j]: lane j + 16*(i/4), register i%4; fp32 accumulation in k order
+//   global_load_lds_dwordx4    LDS[base + 16*lane .. +15] = *global pointer of the lane (base is wave-uniform)
+//   v_alignbit_b32, __shfl_xor / __shfl_up (width 64)
+// Dynamic LDS is one 160 KB buffer, filled with 0xFF (bf16 / fp32 NaN patterns) before every block so that a read of a
+// cell no thread has written shows up in the result; a launch asking for more than 160 KB fails like the hardware does.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local   // block-scope arrays (one block runs per OS thread); `extern __shared__` lines are
+                                         // rewritten by build_emu.py to point at emu::dyn_lds()
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct emu_uint3 { unsigned x, y, z; };
+
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) float2 { float x, y; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+using std::max;
+using std::min;
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorLaunchFailure = 719 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+
+namespace emu {
+constexpr int WAVE = 64;
+constexpr int LDS_BYTES = 160 * 1024;
+extern thread_local emu_uint3 t_threadIdx, t_blockIdx;
+extern thread_local dim3 t_blockDim, t_gridDim;
+unsigned char* dyn_lds();
+int lane_id();
+void block_barrier();
+constexpr int XSTRIDE = 64;
+// wave rendezvous: every live lane of the calling thread's wave deposits `bytes` (<= XSTRIDE) from `mine` into slot `lane`
+// of the wave's exchange area ([64][XSTRIDE] bytes) and receives a pointer to the area once all lanes have arrived;
+// wave_release() is the second rendezvous of the operation: no lane starts its next exchange before all have read.
+const unsigned char* wave_exchange(const void* mine, int bytes);
+void wave_release();
+template <class T>
+inline const T& slot(const unsigned char* area, int lane) { return *reinterpret_cast<const T*>(area + (size_t)lane * XSTRIDE); }
+hipError_t launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body);
+hipError_t last_error();
+}  // namespace emu
+
+#define threadIdx (emu::t_threadIdx)
+#define blockIdx (emu::t_blockIdx)
+#define blockDim (emu::t_blockDim)
+#define gridDim (emu::t_gridDim)
+
+static inline void __syncthreads() { emu::block_barrier(); }
+static inline hipError_t hipGetLastError() { return emu::last_error(); }
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "emulated launch failure"; }
+template <class F>
+static inline hipError_t hipFuncSetAttribute(F, int, int bytes) { return bytes <= emu::LDS_BYTES ? hipSuccess : hipErrorLaunchFailure; }
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+    emu::launch((grid), (block), (lds), [=]() { kernel(__VA_ARGS__); })
+
+// ---- device operations ---------------------------------------------------------------------------------------------------
+typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+
+static inline emu_f32x4 emu_mfma_f32_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c, int, int, int) {
+    struct Ops { emu_bf16x8 a, b; } mine{a, b};
+    const unsigned char* all = emu::wave_exchange(&mine, sizeof(Ops));
+    const int lane = emu::lane_id(), j = lane & 15, g = lane >> 4;
+    emu_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k)
+            acc += (float)emu::slot<Ops>(all, i + 16 * (k >> 3)).a[k & 7] * (float)emu::slot<Ops>(all, j + 16 * (k >> 3)).b[k & 7];
+        d[r] = acc;
+    }
+    emu::wave_release();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_f32_16x16x32_bf16
+
+static inline unsigned emu_alignbit(unsigned hi, unsigned lo, unsigned shift) {
+    return (unsigned)((((uint64_t)hi << 32) | lo) >> (shift & 31));
+}
+#define __builtin_amdgcn_alignbit emu_alignbit
+
+// global_load_lds: the LDS operand is the wave-uniform base, every lane lands at base + lane * size
+static inline void emu_global_load_lds(const void* gptr, void* lds_base, unsigned size, int, int) {
+    memcpy(static_cast<unsigned char*>(lds_base) + (size_t)emu::lane_id() * size, gptr, size);
+}
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) \
+    emu_global_load_lds((const void*)(g), (void*)(l), (size), (off), (aux))
+
+template <class T>
+static inline T emu_shfl_from(T v, int src_lane_or_neg) {
+    const unsigned char* all = emu::wave_exchange(&v, sizeof(T));
+    const T out = (src_lane_or_neg >= 0 && src_lane_or_neg < emu::WAVE) ? emu::slot<T>(all, src_lane_or_neg) : v;
+    emu::wave_release();
+    return out;
+}
+template <class T>
+static inline T __shfl_xor(T v, int mask, int = 64) { return emu_shfl_from(v, emu::lane_id() ^ mask); }
+template <class T>
+static inline T __shfl_up(T v, int delta, int = 64) { return emu_shfl_from(v, emu::lane_id() - delta); }
+template <class T>
+static inline T __shfl(T v, int src, int = 64) { return emu_shfl_from(v, src & 63); }

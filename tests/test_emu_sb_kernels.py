@@ -1,0 +1,121 @@
+"""The split-bf16 kernel SOURCES (contrastiveseg_amd/csrc/conv3x3_sb.hip, conv3x3_sb_wrw.hip, conv1x1_sb.hip,
+conv1x1_sb_wrw.hip) executed on the CPU emulation of wave64 / LDS / MFMA in tests/emu, against float64 convolutions.
+
+Two groups:
+  * kernels that HAVE passed parity on an MI355X (3x3 forward / backward-data with both B-staging variants, weight gradient
+    version 1): they pin the emulator -- MFMA operand layout, LDS-DMA addressing, barrier semantics;
+  * kernels written after the round's GPU budget was spent (weight gradient version 2 with producer / consumer waves,
+    the 1x1 forward / backward-data kernel, the 1x1 weight gradient, the explicit channel tilings): functionally verified
+    here, source line for source line, before their first hardware run.
+Every case also runs with the waves of a block scheduled in descending order: a result that depends on the order in which
+waves reach a point between two barriers is a missing barrier."""
+import numpy as np
+import pytest
+
+from tests.emu import harness as E
+
+
+def _bound(ref, k_len):
+    """fp32-class bound: split-bf16 keeps terms down to 2^-16 of the leading one; accumulation is fp32 over k_len products."""
+    return 3e-6 * np.sqrt(k_len) * max(1.0, float(np.abs(ref).max()))
+
+
+def _rand(shape, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+@pytest.fixture(params=["asc", "desc"])
+def wave_order(request, monkeypatch):
+    monkeypatch.setenv("CSEG_EMU_WAVE_ORDER", request.param)
+    return request.param
+
+
+FWD_CASES = [  # B, Cin, Cout, H, W
+    (1, 48, 48, 6, 68),        # ragged tiles both ways, 16-channel tail (48 = 32 + 16), NT = 3
+    (2, 16, 96, 4, 64),        # tail-only K loop, NT = 6
+    (1, 64, 144, 5, 24),       # two full chunks, NT = 9, narrow map
+]
+
+
+@pytest.mark.parametrize("case", FWD_CASES)
+@pytest.mark.parametrize("glds", ["1", "0"])
+def test_conv3x3_forward_and_backward_data(case, glds, wave_order, monkeypatch):
+    """Hardware-verified kernel: pins the emulator."""
+    monkeypatch.setenv("CSEG_CONV3X3_SB_GLDS", glds)
+    B, ci, co, H, W = case
+    x, w, b = _rand((B, ci, H, W), 1), _rand((co, ci, 3, 3), 2, 1.0 / (3 * ci ** 0.5)), _rand((co,), 3)
+    y = E.conv3x3_sb(x, w, b)
+    ref = E.ref_conv3x3(x, w, b)
+    assert not np.isnan(y).any()
+    assert np.abs(y - ref).max() <= _bound(ref, 9 * ci)
+    if ci % 48 == 0 and co % 16 == 0:
+        dy = _rand((B, co, H, W), 4)
+        dx = E.conv3x3_sb(dy, w, None, transpose_flip=True)
+        ref = E.ref_conv3x3_bwd_data(dy, w)
+        assert np.abs(dx - ref).max() <= _bound(ref, 9 * co)
+
+
+@pytest.mark.parametrize("nt", [3, 6])
+def test_conv3x3_explicit_channel_tiling(nt, wave_order):
+    """cseg_conv3x3_sb_*_nt (first hardware run pending): same convolution whatever the channel tiles per block."""
+    B, ci, co, H, W = 1, 48, 96, 5, 40
+    x, w = _rand((B, ci, H, W), 5), _rand((co, ci, 3, 3), 6, 1.0 / (3 * ci ** 0.5))
+    y = E.conv3x3_sb(x, w, None, nt=nt)
+    ref = E.ref_conv3x3(x, w)
+    assert np.abs(y - ref).max() <= _bound(ref, 9 * ci)
+    assert np.array_equal(y, E.conv3x3_sb(x, w, None)) or np.abs(y - E.conv3x3_sb(x, w, None)).max() <= 1e-5
+
+
+WRW_CASES = [  # B, Cin, Cout, H, W
+    (1, 48, 48, 5, 64),        # ragged 64-wide channel block (3 of 4 tiles), one run
+    (2, 16, 48, 9, 128),       # two column segments, several runs / units per split
+    (1, 80, 96, 3, 64),        # two channel blocks each way
+]
+
+
+@pytest.mark.parametrize("case", WRW_CASES)
+@pytest.mark.parametrize("version", ["1", "2"])
+def test_conv3x3_weight_gradient(case, version, wave_order, monkeypatch):
+    """Version 1 is hardware-verified; version 2 (producer / consumer waves, 4-slot ring) is verified here first."""
+    monkeypatch.setenv("CSEG_CONV3X3_SB_WRW_V", version)
+    B, ci, co, H, W = case
+    x, dy = _rand((B, ci, H, W), 7), _rand((B, co, H, W), 8)
+    dw = E.conv3x3_sb_wrw(x, dy)
+    ref = E.ref_conv3x3_wrw(x, dy)
+    assert not np.isnan(dw).any()
+    assert np.abs(dw - ref).max() <= _bound(ref, B * H * W)
+
+
+ONE_CASES = [  # B, Cin, Cout, H, W
+    (1, 48, 64, 10, 30),       # ragged pixel tile (300 pixels), 16-channel tail, NT = 4
+    (2, 144, 48, 16, 16),      # NT = 3, five K-steps with a tail
+    (1, 64, 256, 4, 20),       # NT = 8 (the projection head's second layer), 80 pixels
+    (1, 32, 144, 6, 44),       # NT = 9
+]
+
+
+@pytest.mark.parametrize("case", ONE_CASES)
+def test_conv1x1_forward_and_backward_data(case, wave_order):
+    B, ci, co, H, W = case
+    x, w, b = _rand((B, ci, H, W), 9), _rand((co, ci, 1, 1), 10, 1.0 / ci ** 0.5), _rand((co,), 11)
+    y = E.conv1x1_sb(x, w, b)
+    ref = np.einsum("bchw,oc->bohw", x.astype(np.float64), w[:, :, 0, 0].astype(np.float64)) + b.astype(np.float64)[None, :, None, None]
+    assert not np.isnan(y).any()
+    assert np.abs(y - ref).max() <= _bound(ref, ci)
+    if ci % 48 and ci % 64:
+        return                                   # backward-data needs the INPUT channel count to tile (48 | 64)
+    dy = _rand((B, co, H, W), 12)
+    dx = E.conv1x1_sb(dy, w, None, transpose=True)
+    ref = np.einsum("bohw,oc->bchw", dy.astype(np.float64), w[:, :, 0, 0].astype(np.float64))
+    assert not np.isnan(dx).any()
+    assert np.abs(dx - ref).max() <= _bound(ref, co)
+
+
+@pytest.mark.parametrize("case", [(2, 48, 64, 8, 8), (1, 144, 160, 8, 12), (2, 64, 256, 16, 16), (1, 16, 16, 4, 8)])
+def test_conv1x1_weight_gradient(case, wave_order):
+    B, ci, co, H, W = case
+    x, dy = _rand((B, ci, H, W), 13), _rand((B, co, H, W), 14)
+    dw = E.conv1x1_sb_wrw(x, dy)
+    ref = np.einsum("bohw,bchw->oc", dy.astype(np.float64), x.astype(np.float64)).reshape(co, ci, 1, 1)
+    assert not np.isnan(dw).any()
+    assert np.abs(dw - ref).max() <= _bound(ref, B * H * W)
