@@ -9,10 +9,15 @@ Two groups:
     here, source line for source line, before their first hardware run.
 Every case also runs with the waves of a block scheduled in descending order: a result that depends on the order in which
 waves reach a point between two barriers is a missing barrier."""
+import os
+
 import numpy as np
 import pytest
 
+from tests.emu import build_emu
 from tests.emu import harness as E
+
+pytestmark = pytest.mark.skipif(not os.path.exists(build_emu.CLANG), reason="host clang++ of the ROCm toolchain not found")
 
 
 def _bound(ref, k_len):
@@ -119,3 +124,39 @@ def test_conv1x1_weight_gradient(case, wave_order):
     ref = np.einsum("bohw,bchw->oc", dy.astype(np.float64), x.astype(np.float64)).reshape(co, ci, 1, 1)
     assert not np.isnan(dw).any()
     assert np.abs(dw - ref).max() <= _bound(ref, B * H * W)
+
+
+# ---- the head's channel count (720 = 22 x 32 + 16: many chunks, then the tail), one spatial tile each ------------------
+@pytest.mark.slow
+def test_head_width_one_tile_each(monkeypatch):
+    monkeypatch.setenv("CSEG_EMU_WAVE_ORDER", "shuffle:7")
+    C = 720
+    x, w, b = _rand((1, C, 4, 64), 21), _rand((C, C, 3, 3), 22, 1.0 / (3 * C ** 0.5)), _rand((C,), 23)
+    y = E.conv3x3_sb(x, w, b)
+    ref = E.ref_conv3x3(x, w, b)
+    assert np.abs(y - ref).max() <= _bound(ref, 9 * C)
+    w1, w2 = _rand((C, C, 1, 1), 24, 1.0 / C ** 0.5), _rand((256, C, 1, 1), 25, 1.0 / C ** 0.5)
+    for wt in (w1, w2):                               # projection head: 720 -> 720 (NT = 9), 720 -> 256 (NT = 8)
+        y = E.conv1x1_sb(x, wt, None)
+        ref = np.einsum("bchw,oc->bohw", x.astype(np.float64), wt[:, :, 0, 0].astype(np.float64))
+        assert np.abs(y - ref).max() <= _bound(ref, C)
+    dz = _rand((1, 256, 4, 64), 26)
+    dx = E.conv1x1_sb(dz, w2, None, transpose=True)    # 256 -> 720
+    ref = np.einsum("bohw,oc->bchw", dz.astype(np.float64), w2[:, :, 0, 0].astype(np.float64))
+    assert np.abs(dx - ref).max() <= _bound(ref, 256)
+    dw = E.conv1x1_sb_wrw(x, dz)
+    ref = np.einsum("bohw,bchw->oc", dz.astype(np.float64), x.astype(np.float64)).reshape(256, C, 1, 1)
+    assert np.abs(dw - ref).max() <= _bound(ref, 256)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("version", ["1", "2"])
+def test_head_width_weight_gradient(version, monkeypatch):
+    monkeypatch.setenv("CSEG_EMU_WAVE_ORDER", "shuffle:3")
+    monkeypatch.setenv("CSEG_CONV3X3_SB_WRW_V", version)
+    C = 720
+    x, dy = _rand((1, C, 3, 64), 27), _rand((1, C, 3, 64), 28)
+    dw = E.conv3x3_sb_wrw(x, dy)
+    ref = E.ref_conv3x3_wrw(x, dy)
+    assert not np.isnan(dw).any()
+    assert np.abs(dw - ref).max() <= _bound(ref, 3 * 64)
