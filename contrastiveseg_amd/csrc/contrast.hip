@@ -316,6 +316,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ S, i
                 const float4 v = (srow[u] && dbase < D) ? ld4(srow[u] + dbase) : make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(cw + ((lane >> 3) + 8 * u) * 32 + (lane & 7) * 4) = v;
             }
+            CSEG_WAVE_LOCKSTEP();
             float bv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) bv[r] = cw[(8 * (r >> 2) + 4 * h + (r & 3)) * 32 + r32];

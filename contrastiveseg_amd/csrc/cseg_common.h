@@ -7,6 +7,14 @@
 
 #define CSEG_WAVE 64
 
+// Marks a point where the lanes of ONE wave hand data to each other through LDS and rely on the wave executing in
+// lockstep (writes of all 64 lanes have been issued, in order, before any lane's read): nothing is emitted on the
+// hardware. The CPU emulation of the execution model used by the tests (tests/emu) runs lanes one after the other between
+// rendezvous points and compiles this into a wave rendezvous.
+#ifndef CSEG_WAVE_LOCKSTEP
+#define CSEG_WAVE_LOCKSTEP() ((void)0)
+#endif
+
 void cseg_set_error(const char* fmt, ...);
 
 // reference convention: 1 = ok, 0 = error (lib/extensions/cc_attention/src/ca.cu:199-204)

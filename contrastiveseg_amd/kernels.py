@@ -21,6 +21,12 @@ def _null():
     return ctypes.c_void_p(None)
 
 
+def _on_device(t):
+    """Lives where the library's kernels can read it (the GPU). The emulated-device tests (tests/emu/inject.py) replace
+    this together with _hip.dev; the product itself has no CPU path."""
+    return t.is_cuda
+
+
 def _pf(t):
     """Raw pointer of a tensor this module has just allocated itself (device, dtype and layout known by construction):
     skips the four checks of _hip.dev(). The step issues ~1000 calls into the BN / convolution entry points and is
@@ -566,7 +572,7 @@ def bn_bwd_apply(dy, x, mean_invstd, weight, bias, sums, count, mask_from_x):
 def conv3x3_eligible(x, weight):
     """Shapes the MFMA kernel covers: NCHW fp32 on the GPU, 3x3, input channels % 8, output channels % 48 (both ways:
     backward-data swaps them), width % 4."""
-    if not (x.is_cuda and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4 and x.is_contiguous()):
+    if not (_on_device(x) and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4 and x.is_contiguous()):
         return False
     co, ci, kh, kw = weight.shape
     return (kh, kw) == (3, 3) and ci % 48 == 0 and co % 48 == 0 and x.shape[1] == ci and x.shape[3] % 4 == 0
@@ -653,7 +659,7 @@ CONV3X3_SB_PICK_NT_CHANNELS = (192, 384)
 def conv3x3_sb_eligible(x, weight):
     """NCHW fp32 on the GPU, 3x3, channels % 48 both ways (forward needs Cin % 16 and Cout % 48, backward-data the
     mirror image), width % 4."""
-    if not (x.is_cuda and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4 and x.is_contiguous()):
+    if not (_on_device(x) and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4 and x.is_contiguous()):
         return False
     co, ci, kh, kw = weight.shape
     return (kh, kw) == (3, 3) and ci % 48 == 0 and co % 48 == 0 and x.shape[1] == ci and x.shape[3] % 4 == 0
@@ -714,7 +720,7 @@ CONV3X3_SB_WRW = os.environ.get("CSEG_CONV3X3_SB_WRW", "0") == "1"
 
 
 def conv3x3_sb_wrw_eligible(x, dy):
-    return (x.is_cuda and x.dtype == F32 and dy.dtype == F32 and x.is_contiguous() and dy.is_contiguous()
+    return (_on_device(x) and x.dtype == F32 and dy.dtype == F32 and x.is_contiguous() and dy.is_contiguous()
             and x.shape[1] % 16 == 0 and dy.shape[1] % 48 == 0 and x.shape[3] % 64 == 0)
 
 
@@ -783,7 +789,7 @@ CONV1X1_SB_MIN_TILES = 256
 
 def conv1x1_sb_eligible(x, weight):
     """NCHW fp32 on the GPU, 1x1, Cin % 16 and Cout % 48|64 in both directions (backward-data swaps them), H*W % 4."""
-    if not (x.is_cuda and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4 and x.is_contiguous()):
+    if not (_on_device(x) and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4 and x.is_contiguous()):
         return False
     co, ci, kh, kw = weight.shape
     ok = lambda c: c % 48 == 0 or c % 64 == 0
@@ -818,7 +824,7 @@ CONV1X1_SB_WRW = os.environ.get("CSEG_CONV1X1_SB_WRW", "0") == "1"
 
 
 def conv1x1_sb_wrw_eligible(x, dy):
-    return (x.is_cuda and x.dtype == F32 and dy.dtype == F32 and x.is_contiguous() and dy.is_contiguous()
+    return (_on_device(x) and x.dtype == F32 and dy.dtype == F32 and x.is_contiguous() and dy.is_contiguous()
             and x.shape[1] % 16 == 0 and dy.shape[1] % 16 == 0 and (x.shape[2] * x.shape[3]) % 32 == 0)
 
 

@@ -12,9 +12,13 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "contrastiveseg_amd", "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 OUT = os.path.join(OUT_DIR, "libcseg_emu.so")
-SOURCES = ["cabi.hip", "conv3x3_sb.hip", "conv3x3_sb_wrw.hip", "conv1x1_sb.hip", "conv1x1_sb_wrw.hip"]
+SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 CLANG = os.environ.get("CSEG_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-_DYN = re.compile(r"extern\s+__shared__\s+__attribute__\(\(aligned\(16\)\)\)\s+([\w ]+?)\s+(\w+)\[\];")
+_DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(16\)\)\)\s+)?([\w ]+?)\s+(\w+)\[\];")
+
+
+def _rewrite(text):
+    return _DYN.sub(lambda m: "%s* %s = reinterpret_cast<%s*>(emu::dyn_lds());" % (m.group(1), m.group(2), m.group(1)), text)
 
 
 def _deps():
@@ -27,12 +31,15 @@ def build(force=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in _deps()):
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    flags = ["-std=c++20", "-O1", "-g", "-fPIC", "-pthread", "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include"),
+    for h in os.listdir(CSRC):                       # headers that declare dynamic LDS get the same rewrite
+        if h.endswith(".h"):
+            with open(os.path.join(OUT_DIR, h), "w") as f:
+                f.write('#line 1 "%s"\n' % os.path.join(CSRC, h) + _rewrite(open(os.path.join(CSRC, h)).read()))
+    flags = ["-std=c++20", "-O1", "-g", "-fPIC", "-pthread", "-I", HERE, "-I", OUT_DIR, "-I", CSRC, "-I", os.path.join(ROOT, "include"),
              "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unknown-pragmas", "-Wno-pass-failed"]
     objs, procs = [], []
     for name in SOURCES:
-        text = open(os.path.join(CSRC, name)).read()
-        text, n = _DYN.subn(lambda m: "%s* %s = reinterpret_cast<%s*>(emu::dyn_lds());" % (m.group(1), m.group(2), m.group(1)), text)
+        text = _rewrite(open(os.path.join(CSRC, name)).read())
         gen = os.path.join(OUT_DIR, name.replace(".hip", "_emu.cpp"))
         with open(gen, "w") as f:
             f.write('#line 1 "%s"\n' % os.path.join(CSRC, name) + text)

@@ -30,6 +30,7 @@
 #include <cstring>
 #include <functional>
 
+#define CSEG_WAVE_LOCKSTEP() emu::wave_sync()
 #define __global__
 #define __device__
 #define __host__
@@ -46,6 +47,10 @@ struct emu_uint3 { unsigned x, y, z; };
 
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(8) int2 { int x, y; };
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(8) float2 { float x, y; };
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
@@ -74,6 +79,7 @@ constexpr int XSTRIDE = 64;
 // wave_release() is the second rendezvous of the operation: no lane starts its next exchange before all have read.
 const unsigned char* wave_exchange(const void* mine, int bytes);
 void wave_release();
+inline void wave_sync() { wave_exchange(nullptr, 0); }      // CSEG_WAVE_LOCKSTEP(): lockstep hand-over through LDS
 template <class T>
 inline const T& slot(const unsigned char* area, int lane) { return *reinterpret_cast<const T*>(area + (size_t)lane * XSTRIDE); }
 hipError_t launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body);
@@ -125,6 +131,70 @@ static inline void emu_global_load_lds(const void* gptr, void* lds_base, unsigne
 }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) \
     emu_global_load_lds((const void*)(g), (void*)(l), (size), (off), (aux))
+
+// v_mfma_f32_32x32x2_f32: A[i][k] lane i + 32k, B[k][j] lane j + 32k, D[i][j] lane j + 32*((i/4)%2), register i%4 + 4*(i/8)
+template <class V16>
+static inline V16 emu_mfma_f32_32x32x2f32(float a, float b, V16 c, int, int, int) {
+    struct Ops { float a, b; } mine{a, b};
+    const unsigned char* all = emu::wave_exchange(&mine, sizeof(Ops));
+    const int lane = emu::lane_id(), j = lane & 31, h = lane >> 5;
+    V16 d = c;
+    for (int v = 0; v < 16; ++v) {
+        const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
+        float acc = c[v];
+        for (int k = 0; k < 2; ++k) acc += emu::slot<Ops>(all, i + 32 * k).a * emu::slot<Ops>(all, j + 32 * k).b;
+        d[v] = acc;
+    }
+    emu::wave_release();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_f32_32x32x2f32
+
+// v_mfma_f32_16x16x4_f32: A[i][k] lane i + 16k, B[k][j] lane j + 16k, D[i][j] lane j + 16*(i/4), register i%4
+template <class V4>
+static inline V4 emu_mfma_f32_16x16x4f32(float a, float b, V4 c, int, int, int) {
+    struct Ops { float a, b; } mine{a, b};
+    const unsigned char* all = emu::wave_exchange(&mine, sizeof(Ops));
+    const int lane = emu::lane_id(), j = lane & 15, g = lane >> 4;
+    V4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc += emu::slot<Ops>(all, i + 16 * k).a * emu::slot<Ops>(all, j + 16 * k).b;
+        d[r] = acc;
+    }
+    emu::wave_release();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_f32_16x16x4f32
+
+// atomics: blocks run concurrently on several OS threads, the threads of one block never do
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+template <class F, class I>
+static inline F emu_atomic_add_fp(F* p, F v) {
+    I* ip = reinterpret_cast<I*>(p);
+    I old = __atomic_load_n(ip, __ATOMIC_RELAXED);
+    for (;;) {
+        F f;
+        memcpy(&f, &old, sizeof f);
+        f += v;
+        I want;
+        memcpy(&want, &f, sizeof f);
+        if (__atomic_compare_exchange_n(ip, &old, want, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+            memcpy(&f, &old, sizeof f);
+            return f;
+        }
+    }
+}
+static inline float atomicAdd(float* p, float v) { return emu_atomic_add_fp<float, uint32_t>(p, v); }
+static inline double atomicAdd(double* p, double v) { return emu_atomic_add_fp<double, uint64_t>(p, v); }
+static inline hipError_t hipMemsetAsync(void* p, int value, size_t bytes, hipStream_t) { memset(p, value, bytes); return hipSuccess; }
+static inline float emu_fast_expf(float x) { return expf(x); }
+static inline float emu_fast_logf(float x) { return logf(x); }
+#define __expf emu_fast_expf          // (glibc's math.h declares functions with these names)
+#define __logf emu_fast_logf
 
 template <class T>
 static inline T emu_shfl_from(T v, int src_lane_or_neg) {
