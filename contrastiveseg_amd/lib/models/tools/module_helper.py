@@ -26,7 +26,7 @@ class Conv3x3(nn.Conv2d):
 
     def forward(self, x):
         from contrastiveseg_amd import kernels as K
-        if x.is_cuda and self.stride == (1, 1) and self.dilation == (1, 1) and self.in_channels == self.out_channels:
+        if K._on_device(x) and self.stride == (1, 1) and self.dilation == (1, 1) and self.in_channels == self.out_channels:
             if (K.CONV3X3_SPLIT_BF16 and self.in_channels in K.CONV3X3_SB_BRANCH_CHANNELS
                     and K.conv3x3_sb_eligible(x, self.weight)
                     and K.conv3x3_sb_tiles(x, self.out_channels) >= K.CONV3X3_SB_MIN_TILES):
@@ -47,7 +47,7 @@ class HeadConv3x3(nn.Conv2d):
 
     def forward(self, x):
         from contrastiveseg_amd import kernels as K
-        if (x.is_cuda and K.CONV3X3_SPLIT_BF16 and K.conv3x3_sb_eligible(x, self.weight)
+        if (K._on_device(x) and K.CONV3X3_SPLIT_BF16 and K.conv3x3_sb_eligible(x, self.weight)
                 and K.conv3x3_sb_tiles(x, self.out_channels) >= K.CONV3X3_SB_MIN_TILES):
             return K.conv3x3_split_bf16(x, self.weight, self.bias)
         return super(HeadConv3x3, self).forward(x)
@@ -63,7 +63,7 @@ class Conv1x1(nn.Conv2d):
 
     def forward(self, x):
         from contrastiveseg_amd import kernels as K
-        if (x.is_cuda and K.CONV1X1_SPLIT_BF16 and K.conv1x1_sb_eligible(x, self.weight)
+        if (K._on_device(x) and K.CONV1X1_SPLIT_BF16 and K.conv1x1_sb_eligible(x, self.weight)
                 and K.conv1x1_sb_tiles(x, self.out_channels) >= K.CONV1X1_SB_MIN_TILES):
             return K.conv1x1_split_bf16(x, self.weight, self.bias)
         return super(Conv1x1, self).forward(x)

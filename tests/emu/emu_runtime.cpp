@@ -1,6 +1,8 @@
 // TEST INFRASTRUCTURE -- fiber scheduler behind tests/emu/hip/hip_runtime.h (see the model described there).
 #include <hip/hip_runtime.h>
+#if !defined(__x86_64__)
 #include <ucontext.h>
+#endif
 
 #include <atomic>
 #include <memory>
@@ -17,8 +19,56 @@ thread_local dim3 t_blockDim, t_gridDim;
 namespace {
 constexpr size_t STACK_BYTES = 192 * 1024;
 
+// Context switch between fibers. x86-64: save / restore the callee-saved registers by hand (tens of nanoseconds; every
+// emulated MFMA costs 128 switches per wave, and swapcontext() spends most of its time in a signal-mask system call);
+// elsewhere: ucontext.
+#if defined(__x86_64__)
+extern "C" void emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl emu_switch
+    .type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size emu_switch, .-emu_switch
+)");
+struct Context { void* sp = nullptr; };
+inline void ctx_switch(Context& from, Context& to) { emu_switch(&from.sp, to.sp); }
+inline void ctx_make(Context& c, char* stack, size_t bytes, void (*entry)()) {
+    uintptr_t top = (reinterpret_cast<uintptr_t>(stack) + bytes) & ~uintptr_t(15);
+    void** sp = reinterpret_cast<void**>(top - 8);          // as if `entry` had been called: rsp = 8 (mod 16) at its first instruction
+    *--sp = reinterpret_cast<void*>(entry);                 // popped by `ret`
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;            // rbp rbx r12 r13 r14 r15
+    c.sp = sp;
+}
+#else
+struct Context { ucontext_t uc; };
+inline void ctx_switch(Context& from, Context& to) { swapcontext(&from.uc, &to.uc); }
+inline void ctx_make(Context& c, char* stack, size_t bytes, void (*entry)()) {
+    getcontext(&c.uc);
+    c.uc.uc_stack.ss_sp = stack;
+    c.uc.uc_stack.ss_size = bytes;
+    c.uc.uc_link = nullptr;
+    makecontext(&c.uc, entry, 0);
+}
+#endif
+
 struct Fiber {
-    ucontext_t ctx;
+    Context ctx;
     bool started = false, done = false;
     bool at_bar = false;                        // waiting at the block barrier
 };
@@ -31,7 +81,7 @@ struct BlockState {
     std::vector<Fiber> fibers;
     std::vector<WaveState> waves;
     std::unique_ptr<char[]> stacks;             // not zero-filled: pages are touched only as deep as the fibers go
-    ucontext_t sched;
+    Context sched;
     const std::function<void()>* body = nullptr;
     int n_threads = 0, cur = -1, live = 0, bar_arrived = 0;
     unsigned bar_gen = 0;
@@ -46,7 +96,7 @@ std::atomic<int> g_last_error{hipSuccess};
 
 void yield_to_scheduler() {
     Fiber& f = B->fibers[B->cur];
-    swapcontext(&f.ctx, &B->sched);
+    ctx_switch(f.ctx, B->sched);
 }
 
 void release_block_barrier() {
@@ -69,7 +119,8 @@ void fiber_main() {
     if (b->live > 0 && b->bar_arrived == b->live) release_block_barrier();
     if (w.live > 0 && w.arrived == w.live) { w.arrived = 0; ++w.gen; }
     if (w.live > 0 && w.rel_arrived == w.live) { w.rel_arrived = 0; ++w.rel_gen; }
-    swapcontext(&f.ctx, &b->sched);
+    ctx_switch(f.ctx, b->sched);
+    abort();                                    // a finished fiber is never resumed
 }
 
 void resume(int t) {
@@ -81,13 +132,9 @@ void resume(int t) {
     if (!f.started) {
         f.started = true;
         ++B->events;
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = B->stacks.get() + (size_t)t * STACK_BYTES;
-        f.ctx.uc_stack.ss_size = STACK_BYTES;
-        f.ctx.uc_link = &B->sched;
-        makecontext(&f.ctx, (void (*)())fiber_main, 0);
+        ctx_make(f.ctx, B->stacks.get() + (size_t)t * STACK_BYTES, STACK_BYTES, fiber_main);
     }
-    swapcontext(&B->sched, &f.ctx);
+    ctx_switch(B->sched, f.ctx);
     B->cur = -1;
 }
 

@@ -146,3 +146,41 @@ AUG = _cases("test_gpu_aug", "test_augment_kernel_matches_forward_chain", lambda
 @pytest.mark.parametrize("kw", AUG, ids=_ids(AUG))
 def test_augment_kernel_matches_forward_chain(kw, monkeypatch):
     _replay(monkeypatch, "test_gpu_aug", "test_augment_kernel_matches_forward_chain", kw)
+
+
+# ---- split-bf16 convolutions: the GPU tests of tests/test_gpu_conv3x3_sb.py (they call .cuda() directly) -------------------
+def _replay_sb(monkeypatch, func, kw, env=()):
+    inject.install(monkeypatch)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    for k, v in env:
+        monkeypatch.setenv(k, v)
+    mod = importlib.import_module("test_gpu_conv3x3_sb")
+    fn = getattr(mod, func)
+    if "monkeypatch" in fn.__code__.co_varnames[:fn.__code__.co_argcount]:
+        kw = dict(kw, monkeypatch=monkeypatch)
+    fn(**kw)
+
+
+_SMALL = lambda kw: kw["case"][1] <= 192          # (the 720-channel case runs in tests/test_emu_sb_kernels.py, marked slow)
+SB_AUTO = _cases("test_gpu_conv3x3_sb", "test_autograd_matches_fp64", _SMALL)
+
+
+@pytest.mark.parametrize("wrw", ["0", "1", "2"])
+@pytest.mark.parametrize("kw", SB_AUTO, ids=_ids(SB_AUTO))
+def test_sb_autograd_matches_fp64(kw, wrw, monkeypatch):
+    """Conv3x3SplitBF16 end to end (forward, backward-data, weight / bias gradient) with the weight gradient on MIOpen's
+    stand-in (0), the split-bf16 kernel version 1 and version 2."""
+    from contrastiveseg_amd import kernels as K
+    monkeypatch.setattr(K, "CONV3X3_SB_WRW", wrw != "0")
+    _replay_sb(monkeypatch, "test_autograd_matches_fp64", kw, [("CSEG_CONV3X3_SB_WRW_V", wrw)] if wrw != "0" else [])
+
+
+SB_ONE = _cases("test_gpu_conv3x3_sb", "test_pointwise_matches_fp64", _SMALL)
+
+
+@pytest.mark.parametrize("wrw", [False, True])
+@pytest.mark.parametrize("kw", SB_ONE, ids=_ids(SB_ONE))
+def test_sb_pointwise_autograd_matches_fp64(kw, wrw, monkeypatch):
+    from contrastiveseg_amd import kernels as K
+    monkeypatch.setattr(K, "CONV1X1_SB_WRW", wrw)
+    _replay_sb(monkeypatch, "test_pointwise_matches_fp64", kw)
