@@ -491,7 +491,8 @@ def main():
                                               "products per fp32 product, fp32 accumulate; fp32-class accuracy: "
                                               "tools/split_bf16_probe.py, tests/test_gpu_conv3x3_sb.py) for the "
                                               "720->720 head convolution and the 48/96-channel branches, forward + "
-                                              "backward-data; everything else fp32") if split_on else "fp32",
+                                              "backward-data%s; everything else fp32"
+                                              % (" + weight gradient" if Kn.CONV3X3_SB_WRW else "")) if split_on else "fp32",
                        "miopen_find": bool(args.miopen_find), "channels_last": bool(args.channels_last),
                        "final_loss": round(final_loss, 5)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",

@@ -713,15 +713,28 @@ def conv3x3_sb_tiles(x, c_out):
     return x.shape[0] * (c_out // nt16) * ((x.shape[2] + 3) // 4) * ((x.shape[3] + 63) // 64)
 
 
-# Weight gradient on the split-bf16 kernel (csrc/conv3x3_sb_wrw.hip): kernel-level parity and timings are in (48 ch 108 vs
-# 164 us on the fp32-MFMA kernel, 96 ch 112 vs 152 us, 720 ch 17.6 vs 19.5 ms on MIOpen); the step-level goldens have not
-# run on it yet -> off unless CSEG_CONV3X3_SB_WRW=1
-CONV3X3_SB_WRW = os.environ.get("CSEG_CONV3X3_SB_WRW", "0") == "1"
+# Weight gradient on the split-bf16 kernel (csrc/conv3x3_sb_wrw.hip, version 1), on by default for the channel counts it
+# has been measured on: MI355X, bs 8, tools/conv3x3_sb_wrw_probe.py (profiles/r02_conv3x3_split_bf16_wrw_probe.jsonl):
+# 48 ch 108 vs 164 us (fp32-MFMA kernel) / 201 (MIOpen), 96 ch 112 vs 152 / 148, 720 ch 17.6 vs 19.5 ms (MIOpen, plus its
+# layout transposes); deviation from MIOpen's fp32 result 5e-6 of the gradient scale at those shapes. Parity: 5 shapes vs
+# fp64 + determinism on the GPU (tests/test_gpu_conv3x3_sb.py), the same sources on the CPU emulation of the execution
+# model incl. the autograd path, and the reference's one-SGD-step golden through the whole HRNet-W48 with this kernel in
+# every eligible layer (tools/emu_step_golden.py, profiles/r02_emu_step_golden_*.json). CSEG_CONV3X3_SB_WRW=0 restores the
+# fp32-MFMA kernel / MIOpen; CSEG_CONV3X3_SB_WRW_V=2 selects the producer/consumer version (not yet run on hardware).
+CONV3X3_SB_WRW = os.environ.get("CSEG_CONV3X3_SB_WRW", "1") == "1"
+CONV3X3_SB_WRW_CHANNELS = tuple(int(c) for c in os.environ.get("CSEG_CONV3X3_SB_WRW_CHANNELS", "48,96,720").split(","))
 
 
 def conv3x3_sb_wrw_eligible(x, dy):
+    """Shapes the kernel covers (NCHW fp32, Cin % 16, Cout % 48, width % 64)."""
     return (_on_device(x) and x.dtype == F32 and dy.dtype == F32 and x.is_contiguous() and dy.is_contiguous()
             and x.shape[1] % 16 == 0 and dy.shape[1] % 48 == 0 and x.shape[3] % 64 == 0)
+
+
+def conv3x3_sb_wrw_wanted(x, dy):
+    """The autograd path takes the split-bf16 weight gradient: switched on, covered, and a channel count it was timed on."""
+    return (CONV3X3_SB_WRW and x.shape[1] == dy.shape[1] and x.shape[1] in CONV3X3_SB_WRW_CHANNELS
+            and conv3x3_sb_wrw_eligible(x, dy))
 
 
 @torch.no_grad()
@@ -742,8 +755,9 @@ def conv3x3_sb_wrw(x, dy):
 
 class Conv3x3SplitBF16(Function):
     """y = conv2d(x, weight, bias, stride 1, padding 1): forward and backward-data on the split-bf16 MFMA kernel; the
-    weight gradient on the fp32-MFMA kernel where that one is used today (bias-free 48/96-channel branches), otherwise
-    on MIOpen together with the bias gradient."""
+    weight gradient on the split-bf16 kernel too where conv3x3_sb_wrw_wanted() says so (48 / 96 / 720 channels at widths
+    that are multiples of 64), else on the fp32-MFMA kernel (bias-free 48/96-channel branches) or on MIOpen together with
+    the bias gradient."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -764,7 +778,7 @@ class Conv3x3SplitBF16(Function):
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_db:
             co, ci = weight.shape[:2]
-            if CONV3X3_SB_WRW and conv3x3_sb_wrw_eligible(x, dy):
+            if conv3x3_sb_wrw_wanted(x, dy):
                 dw = conv3x3_sb_wrw(x, dy) if ctx.needs_input_grad[1] else None
                 db = dy.sum((0, 2, 3)) if want_db else None
             elif not ctx.has_bias and co == ci and co in CONV3X3_WRW_CHANNELS:

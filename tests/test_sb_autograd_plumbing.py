@@ -67,8 +67,9 @@ def test_conv3x3_function(cpu_entry_points, monkeypatch, bias, sb_wrw, channels)
     assert fwd[1] is False and fwd[2] is bias and bwd[1] is True and bwd[2] is False
     expect_nt = K.conv3x3_sb_pick_nt(x, channels) if channels in K.CONV3X3_SB_PICK_NT_CHANNELS else 0
     assert fwd[3] == expect_nt and bwd[3] == expect_nt
-    # weight gradient: split kernel when switched on, else the fp32-MFMA kernel for the bias-free 48/96 branches, else aten
-    uses_custom_wrw = sb_wrw or (not bias and channels in K.CONV3X3_WRW_CHANNELS)
+    # weight gradient: split kernel when switched on AND the channel count is one it was timed on (48 / 96 / 720), else the
+    # fp32-MFMA kernel for the bias-free 48/96 branches, else aten
+    uses_custom_wrw = (sb_wrw and channels in K.CONV3X3_SB_WRW_CHANNELS) or (not bias and channels in K.CONV3X3_WRW_CHANNELS)
     assert ("wrw3" in kinds) == uses_custom_wrw
 
 
