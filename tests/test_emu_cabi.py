@@ -184,3 +184,14 @@ def test_sb_pointwise_autograd_matches_fp64(kw, wrw, monkeypatch):
     from contrastiveseg_amd import kernels as K
     monkeypatch.setattr(K, "CONV1X1_SB_WRW", wrw)
     _replay_sb(monkeypatch, "test_pointwise_matches_fp64", kw)
+
+
+# ---- row-sparse projection-head backward with the PRODUCT's deposit path (kernels.PixelContrast / GatherAnchors) ---------
+@pytest.mark.parametrize("loss_type", ["contrast_ce_loss", "mem_contrast_ce_loss"])
+def test_sparse_embed_route_equals_dense_route(loss_type, monkeypatch):
+    """tests/test_gpu_sparse_embed.py at the head's real width (720 -> 720 -> 256, 19 classes, up to 1024 anchors): HIP BN,
+    mining, contrast and CE sources on the emulator, torch's CPU GEMMs standing in for rocBLAS."""
+    inject.install(monkeypatch)
+    mod = importlib.import_module("test_gpu_sparse_embed")
+    monkeypatch.setattr(mod, "_dev", lambda: torch.device("cpu"))
+    mod.test_sparse_route_equals_dense_route_on_the_gpu(loss_type, monkeypatch)
