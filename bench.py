@@ -504,6 +504,15 @@ def main():
                                  % (ev_ms / args.steps, wl["tflop"])},
             "fp32_conv_path": fp32_pass, "weak": weak, "cpu_baseline": cpu, "kernels": kernels,
         }
+        # the single kernel with the largest share of the step (13 % in profiles/r02_step_steady_kernel_stats_split_bf16.csv),
+        # timed live above with HIP events: its own roofline next to the whole-step one
+        dom = (kernels or {}).get("conv3x3_split_bf16 720->720 (pack + conv)")
+        if isinstance(dom, dict) and all(k in dom for k in ("achieved_TFLOPs", "peak_TFLOPs", "frac", "us", "flops")):
+            line["roofline"]["dominant_kernel"] = {
+                "name": "conv3x3_sb_kernel<9> (720->720 head convolution, forward = backward-data)", "bound": "mfma",
+                "achieved": dom["achieved_TFLOPs"], "peak": dom["peak_TFLOPs"], "unit": "TFLOP/s fp32-equivalent "
+                "(six bf16 MFMAs per product: peak = 2500 / 6)", "frac": dom["frac"], "us_per_launch": dom["us"],
+                "algorithmic_flops_per_launch": dom["flops"]}
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
