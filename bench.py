@@ -490,9 +490,12 @@ def main():
                        "conv3x3_arithmetic": ("split-bf16 x6 on the BF16 matrix cores (fp32 in/out, six bf16 piece "
                                               "products per fp32 product, fp32 accumulate; fp32-class accuracy: "
                                               "tools/split_bf16_probe.py, tests/test_gpu_conv3x3_sb.py) for the "
-                                              "720->720 head convolution and the 48/96-channel branches, forward + "
+                                              "720->720 head convolution and the %s-channel branches, forward + "
                                               "backward-data%s; everything else fp32"
-                                              % (" + weight gradient" if Kn.CONV3X3_SB_WRW else "")) if split_on else "fp32",
+                                              % ("/".join(str(c) for c in Kn.CONV3X3_SB_BRANCH_CHANNELS),
+                                                 (" + weight gradient (%s channels)"
+                                                  % "/".join(str(c) for c in Kn.CONV3X3_SB_WRW_CHANNELS))
+                                                 if Kn.CONV3X3_SB_WRW else "")) if split_on else "fp32",
                        "miopen_find": bool(args.miopen_find), "channels_last": bool(args.channels_last),
                        "final_loss": round(final_loss, 5)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",

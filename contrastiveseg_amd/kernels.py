@@ -649,8 +649,10 @@ def conv3x3(x, weight):
 # module-level switch (read at call time by the modules, so bench.py / tests can flip it inside one process)
 CONV3X3_SPLIT_BF16 = os.environ.get("CSEG_CONV3X3_SPLIT_BF16", "1") == "1"
 # bias-free residual-branch convolutions that move to the split kernel when the switch is on (measured on MI355X at the
-# benched shapes, tools/conv3x3_sb_probe.py: 96 ch 70 vs 101 us; 48 ch 99 vs 106 us on the fp32-MFMA kernel)
-CONV3X3_SB_BRANCH_CHANNELS = tuple(int(c) for c in os.environ.get("CSEG_CONV3X3_SB_CHANNELS", "48,96").split(","))
+# benched shapes, tools/conv3x3_sb_probe.py: 96 ch 70 vs 101 us; 48 ch 99 vs 106 us on the fp32-MFMA kernel; 192 ch at
+# 8x32x64 with 3 channel tiles per block 81 / 78 us forward / backward-data vs 98-117 us on MIOpen's Winograd kernel,
+# profiles/r02_conv3x3_split_bf16_nt_probe.jsonl). 384 channels (16x32 maps) can be added but waste half of every tile.
+CONV3X3_SB_BRANCH_CHANNELS = tuple(int(c) for c in os.environ.get("CSEG_CONV3X3_SB_CHANNELS", "48,96,192").split(","))
 # channel counts that go through the explicit-tiling entry points (conv3x3_sb_pick_nt); 48 / 96 / 720 keep the library's
 # default tiling, which is what the parity suite ran on
 CONV3X3_SB_PICK_NT_CHANNELS = (192, 384)
@@ -709,7 +711,11 @@ CONV3X3_SB_MIN_TILES = 256
 
 
 def conv3x3_sb_tiles(x, c_out):
-    nt16 = 144 if c_out % 144 == 0 else 96 if c_out % 96 == 0 else 48
+    """Blocks of the launch: with the tiling the call will really use (explicit for CONV3X3_SB_PICK_NT_CHANNELS)."""
+    if c_out in CONV3X3_SB_PICK_NT_CHANNELS:
+        nt16 = 16 * conv3x3_sb_pick_nt(x, c_out)
+    else:
+        nt16 = 144 if c_out % 144 == 0 else 96 if c_out % 96 == 0 else 48
     return x.shape[0] * (c_out // nt16) * ((x.shape[2] + 3) // 4) * ((x.shape[3] + 63) // 64)
 
 

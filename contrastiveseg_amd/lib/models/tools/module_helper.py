@@ -15,10 +15,13 @@ _NORMS = {'torchbn': FusedBatchNorm2d, 'torchsyncbn': FusedSyncBatchNorm}
 
 class Conv3x3(nn.Conv2d):
     """nn.Conv2d (same parameters / state_dict) for the bias-free 3x3, stride-1, pad-1 convolutions of the residual
-    branches. Where the hand-written MFMA kernel (csrc/conv3x3.hip) beats MIOpen's best solver -- the narrow HRNet
-    branches: 48 and 96 channels, measured 121 vs 167 us and 113 vs 119 us per forward at the benched shapes,
-    tools/conv3x3_probe.py -- forward and backward-data run on it; every other shape, and the weight gradient, stay on
-    MIOpen exactly like the reference's nn.Conv2d."""
+    branches. Routes, in this order, for shapes whose launch fills the chip:
+      * kernels.CONV3X3_SPLIT_BF16 (default) and a channel count in kernels.CONV3X3_SB_BRANCH_CHANNELS (48 / 96 / 192):
+        forward and backward-data on the split-bf16 MFMA kernel (csrc/conv3x3_sb.hip), weight gradient on the split-bf16
+        kernel (48 / 96 at widths % 64), the fp32-MFMA kernel or MIOpen (kernels.Conv3x3SplitBF16);
+      * 48 / 96 channels otherwise: the fp32-MFMA kernel (csrc/conv3x3.hip: 121 vs 167 us and 113 vs 119 us per forward
+        against MIOpen at the benched shapes, tools/conv3x3_probe.py);
+      * everything else: the reference's nn.Conv2d on MIOpen."""
     MFMA_CHANNELS = (48, 96)
 
     def __init__(self, inplanes, planes, stride=1):

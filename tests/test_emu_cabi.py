@@ -260,3 +260,44 @@ def test_train_steps_on_the_emulated_device_equal_the_torch_restatement(case, mo
     # (gradients of these freshly initialised networks differ by ~1e-2 between two fp32 evaluation orders -- the reference
     # against its own fp64 evaluation included; a wrong adjoint moves this by O(1))
     assert float((w - ref_w).norm() / ref_w.norm()) <= 5e-3
+
+
+# ---- module-level dispatch of the residual-branch convolutions (module_helper.Conv3x3 / HeadConv3x3) -----------------------
+@pytest.mark.parametrize("channels,hw", [(48, (8, 64)), (96, (6, 36)), (192, (5, 64)), (192, (4, 20))])
+def test_conv3x3_module_routes_to_the_split_kernels(channels, hw, monkeypatch):
+    """nn.Conv2d semantics of the module whatever the route: forward / backward-data on the split-bf16 kernel (192 channels
+    through the explicit-tiling entry points, exactly as _hip.SIGNATURES declares them), weight gradient on the split-bf16
+    kernel (48 / 96 at widths % 64), the fp32-MFMA kernel or aten."""
+    import torch.nn.functional as F
+    from contrastiveseg_amd import kernels as K
+    from contrastiveseg_amd.lib.models.tools.module_helper import Conv3x3
+    inject.install(monkeypatch)
+    monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
+    calls = []
+    for name in ("conv3x3_sb_run", "conv3x3_sb_wrw", "_conv3x3_wrw"):
+        monkeypatch.setattr(K, name, (lambda fn, name: lambda *a, **k: (calls.append((name, k.get("nt", a[4] if len(a) > 4 else 0)
+                                                                                      if name == "conv3x3_sb_run" else None)),
+                                                                        fn(*a, **k))[1])(getattr(K, name), name))
+    g = torch.Generator().manual_seed(channels)
+    conv = Conv3x3(channels, channels)
+    x = torch.randn(2, channels, *hw, generator=g).requires_grad_(True)
+    dy = torch.randn(2, channels, *hw, generator=g)
+    y = conv(x)
+    y.backward(dy)
+    x64 = x.detach().double().requires_grad_(True)
+    w64 = conv.weight.detach().double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, None, 1, 1)
+    y64.backward(dy.double())
+    assert float((y.detach().double() - y64.detach()).abs().max()) <= 4e-6 * float(y64.abs().max()) * max(1.0, (9 * channels) ** 0.5 / 8)
+    assert [c[0] for c in calls[:2]] == ["conv3x3_sb_run", "conv3x3_sb_run"]
+    if channels in K.CONV3X3_SB_PICK_NT_CHANNELS:
+        assert calls[0][1] == calls[1][1] == K.conv3x3_sb_pick_nt(x, channels) and calls[0][1] in (3, 6)
+    wrw_route = [c[0] for c in calls[2:]]
+    if channels in K.CONV3X3_SB_WRW_CHANNELS and hw[1] % 64 == 0:
+        assert wrw_route == ["conv3x3_sb_wrw"]
+    elif channels in K.CONV3X3_WRW_CHANNELS:
+        assert wrw_route == ["_conv3x3_wrw"]
+    else:
+        assert wrw_route == []
+    for got, ref in ((x.grad, x64.grad), (conv.weight.grad, w64.grad)):
+        assert float((got.double() - ref).abs().max()) <= 4e-6 * float(ref.abs().max()) * max(1.0, (9 * channels) ** 0.5 / 8)

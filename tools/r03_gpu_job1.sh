@@ -25,8 +25,8 @@ if [ "$stage" = "a" ]; then
   timeout 200 python tools/conv3x3_sb_probe.py > $O/c3_probe.jsonl 2> $O/c3_probe.err; cat $O/c3_probe.jsonl
   exit 0
 fi
-SWITCHES=("CSEG_CONV3X3_SB_WRW=0" "CSEG_CONV3X3_SB_WRW_V=2" "CSEG_CONV3X3_SB_CHANNELS=48,96,192"
-          "CSEG_CONV3X3_SB_CHANNELS=48,96,192 CSEG_CONV3X3_SB_WRW_CHANNELS=48,96,192,720"
+SWITCHES=("CSEG_CONV3X3_SB_WRW=0" "CSEG_CONV3X3_SB_WRW_V=2" "CSEG_CONV3X3_SB_CHANNELS=48,96"
+          "CSEG_CONV3X3_SB_WRW_CHANNELS=48,96,192,720"
           "CSEG_CONV3X3_SB_CHANNELS=48,96,192,384" "CSEG_CONV1X1_SPLIT_BF16=1" "CSEG_CONV1X1_SPLIT_BF16=1 CSEG_CONV1X1_SB_WRW=1"
           "CSEG_SPARSE_EMBED_GRAD=1")
 if [ $# -gt 0 ]; then SWITCHES=("$@"); fi
