@@ -250,6 +250,73 @@ def kernel_rooflines(device, B, K=19, H=512, W=1024, stride=4, D=256):
     return out
 
 
+def conv_arith_note(Kn, split_on):
+    """config.conv3x3_arithmetic of the JSON line: which convolutions run in which arithmetic in this process."""
+    if not split_on:
+        return "fp32"
+    wrw = ""
+    if Kn.CONV3X3_SB_WRW:
+        wrw = " + weight gradient (%s channels)" % "/".join(str(c) for c in Kn.CONV3X3_SB_WRW_CHANNELS)
+    return ("split-bf16 x6 on the BF16 matrix cores (fp32 in/out, six bf16 piece products per fp32 product, fp32 "
+            "accumulate; fp32-class accuracy: tools/split_bf16_probe.py, tests/test_gpu_conv3x3_sb.py) for the 720->720 "
+            "head convolution and the %s-channel branches, forward + backward-data%s; everything else fp32"
+            % ("/".join(str(c) for c in Kn.CONV3X3_SB_BRANCH_CHANNELS), wrw))
+
+
+def dominant_kernel(kernels):
+    """roofline.dominant_kernel: the single kernel with the largest share of the step (13 % in
+    profiles/r02_step_steady_kernel_stats_split_bf16.csv), timed live by kernel_rooflines() with HIP events."""
+    dom = (kernels or {}).get("conv3x3_split_bf16 720->720 (pack + conv)")
+    if not (isinstance(dom, dict) and all(k in dom for k in ("achieved_TFLOPs", "peak_TFLOPs", "frac", "us", "flops"))):
+        return None
+    return {"name": "conv3x3_sb_kernel<9> (720->720 head convolution, forward = backward-data)", "bound": "mfma",
+            "achieved": dom["achieved_TFLOPs"], "peak": dom["peak_TFLOPs"],
+            "unit": "TFLOP/s fp32-equivalent (six bf16 MFMAs per product: peak = 2500 / 6)", "frac": dom["frac"],
+            "us_per_launch": dom["us"], "algorithmic_flops_per_launch": dom["flops"]}
+
+
+def assemble_line(args, wl, cfg, world, global_batch, dt, ev_ms, final_loss, split_on, Kn, backend, fp32_pass, weak, cpu,
+                  kernels):
+    """The ONE JSON line of the contract (pure function of the measurements: exercised on CPU by
+    tests/test_host_surface.py so that a formatting slip cannot cost a GPU run its result)."""
+    ips = global_batch * args.steps / dt
+    ips_ev = global_batch * args.steps / (ev_ms * 1e-3)
+    achieved = ips_ev * wl["tflop"]
+    peak = PEAK_FP32_MFMA_TFLOPS * world
+    traffic, traffic_src = step_traffic() if (world == 1 and args.workload == "cfg2") else (None, None)
+    W, H = cfg.get("train", "data_transformer")["input_size"]
+    line = {
+        "metric": "images/sec contrastive train step, HRNet-W48 1024x512 bs8" if args.workload == "cfg2" else
+                  "images/sec contrastive train step, " + args.workload,
+        "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+        "config": {"workload": wl["name"], "model": cfg.get("network", "model_name"),
+                   "loss": cfg.get("loss", "loss_type"), "global_batch": global_batch,
+                   "per_gpu_batch": global_batch // world, "input": [3, H, W],
+                   "num_classes": cfg.get("data", "num_classes"), "labels": args.labels or wl["labels"],
+                   "parallelism": "dp%d" % world,
+                   "cross_rank_contrast_set": bool(world > 1 and cfg.exists("contrast", "cross_rank")
+                                                   and cfg.get("contrast", "cross_rank")),
+                   "backend": backend,
+                   "conv3x3_arithmetic": conv_arith_note(Kn, split_on),
+                   "miopen_find": bool(args.miopen_find), "channels_last": bool(args.channels_last),
+                   "final_loss": round(final_loss, 5)},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "note": "whole step: images/s (HIP-event time %.1f ms/step) x %.4f TFLOP/image of fp32-equivalent "
+                             "work vs the fp32 MFMA peak (the roof of a pure fp32 implementation; the split-bf16 "
+                             "convolutions run on the bf16 pipe at 6 MFMAs per product, roof 2500/6 = 417 TF/s for "
+                             "that share of the work); per-kernel rooflines under 'kernels'"
+                             % (ev_ms / args.steps, wl["tflop"])},
+        "fp32_conv_path": fp32_pass, "weak": weak, "cpu_baseline": cpu, "kernels": kernels,
+    }
+    dom = dominant_kernel(kernels)
+    if dom is not None:
+        line["roofline"]["dominant_kernel"] = dom
+    return line
+
+
 def usable_cores():
     """Cores this process may really use: affinity mask and cgroup CPU quota, not the host's core count."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -467,55 +534,8 @@ def main():
         torch.distributed.barrier()
 
     if rank == 0:
-        ips = global_batch * args.steps / dt
-        ips_ev = global_batch * args.steps / (ev_ms * 1e-3)
-        achieved = ips_ev * wl["tflop"]
-        peak = PEAK_FP32_MFMA_TFLOPS * world
-        traffic, traffic_src = step_traffic() if (world == 1 and args.workload == "cfg2") else (None, None)
-        W, H = cfg.get("train", "data_transformer")["input_size"]
-        line = {
-            "metric": "images/sec contrastive train step, HRNet-W48 1024x512 bs8" if args.workload == "cfg2" else
-                      "images/sec contrastive train step, " + args.workload,
-            "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
-            "config": {"workload": wl["name"], "model": cfg.get("network", "model_name"),
-                       "loss": cfg.get("loss", "loss_type"), "global_batch": global_batch,
-                       "per_gpu_batch": global_batch // world, "input": [3, H, W],
-                       "num_classes": cfg.get("data", "num_classes"), "labels": args.labels or wl["labels"],
-                       "parallelism": "dp%d" % world,
-                       "cross_rank_contrast_set": bool(world > 1 and cfg.exists("contrast", "cross_rank")
-                                                       and cfg.get("contrast", "cross_rank")),
-                       "backend": (torch.distributed.get_backend() if world > 1 else None),
-                       "conv3x3_arithmetic": ("split-bf16 x6 on the BF16 matrix cores (fp32 in/out, six bf16 piece "
-                                              "products per fp32 product, fp32 accumulate; fp32-class accuracy: "
-                                              "tools/split_bf16_probe.py, tests/test_gpu_conv3x3_sb.py) for the "
-                                              "720->720 head convolution and the %s-channel branches, forward + "
-                                              "backward-data%s; everything else fp32"
-                                              % ("/".join(str(c) for c in Kn.CONV3X3_SB_BRANCH_CHANNELS),
-                                                 (" + weight gradient (%s channels)"
-                                                  % "/".join(str(c) for c in Kn.CONV3X3_SB_WRW_CHANNELS))
-                                                 if Kn.CONV3X3_SB_WRW else "")) if split_on else "fp32",
-                       "miopen_find": bool(args.miopen_find), "channels_last": bool(args.channels_last),
-                       "final_loss": round(final_loss, 5)},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "note": "whole step: images/s (HIP-event time %.1f ms/step) x %.4f TFLOP/image of fp32-equivalent "
-                                 "work vs the fp32 MFMA peak (the roof of a pure fp32 implementation; the split-bf16 "
-                                 "convolutions run on the bf16 pipe at 6 MFMAs per product, roof 2500/6 = 417 TF/s for "
-                                 "that share of the work); per-kernel rooflines under 'kernels'"
-                                 % (ev_ms / args.steps, wl["tflop"])},
-            "fp32_conv_path": fp32_pass, "weak": weak, "cpu_baseline": cpu, "kernels": kernels,
-        }
-        # the single kernel with the largest share of the step (13 % in profiles/r02_step_steady_kernel_stats_split_bf16.csv),
-        # timed live above with HIP events: its own roofline next to the whole-step one
-        dom = (kernels or {}).get("conv3x3_split_bf16 720->720 (pack + conv)")
-        if isinstance(dom, dict) and all(k in dom for k in ("achieved_TFLOPs", "peak_TFLOPs", "frac", "us", "flops")):
-            line["roofline"]["dominant_kernel"] = {
-                "name": "conv3x3_sb_kernel<9> (720->720 head convolution, forward = backward-data)", "bound": "mfma",
-                "achieved": dom["achieved_TFLOPs"], "peak": dom["peak_TFLOPs"], "unit": "TFLOP/s fp32-equivalent "
-                "(six bf16 MFMAs per product: peak = 2500 / 6)", "frac": dom["frac"], "us_per_launch": dom["us"],
-                "algorithmic_flops_per_launch": dom["flops"]}
+        line = assemble_line(args, wl, cfg, world, global_batch, dt, ev_ms, final_loss, split_on, Kn,
+                             torch.distributed.get_backend() if world > 1 else None, fp32_pass, weak, cpu, kernels)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

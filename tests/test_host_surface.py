@@ -149,3 +149,35 @@ def test_distributed_flag_respawns_one_rank_per_gpu(monkeypatch):
     import os
     assert os.environ.get("HIP_VISIBLE_DEVICES") == "2"
     monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+
+
+def test_bench_line_is_assembled_from_measurements(monkeypatch):
+    """bench.assemble_line / conv_arith_note / dominant_kernel: the JSON line of the contract from fake measurements, for
+    every workload, with and without the optional objects (a formatting slip here would cost a GPU run its only output)."""
+    import json
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from contrastiveseg_amd import kernels as Kn
+    from contrastiveseg_amd.lib.utils.tools.configer import Configer
+    for workload, wl in bench.WORKLOADS.items():
+        cfg = Configer(configs=os.path.join(root, "configs", wl["config"]))
+        for world, split_on, extras in ((1, True, True), (8, False, False)):
+            args = types.SimpleNamespace(steps=10, warmup=3, scaling="strong", workload=workload, labels=None, miopen_find=0,
+                                         channels_last=0)
+            kernels = {"conv3x3_split_bf16 720->720 (pack + conv)": {"us": 10970.0, "bound": "mfma", "flops": 2446118092800,
+                                                                     "achieved_TFLOPs": 223.0, "peak_TFLOPs": 416.7,
+                                                                     "frac": 0.535}} if extras else {"error": "boom"}
+            line = bench.assemble_line(args, wl, cfg, world, wl["batch"], 1.766, 1765.0, 2.34567, split_on, Kn,
+                                       "nccl" if world > 1 else None, {"value": 40.0} if extras else None, None,
+                                       {"value": 0.2, "cores": 16, "kind": "port"} if extras else None, kernels)
+            back = json.loads(json.dumps(line))
+            for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                assert key in back, key
+            assert back["n_gpus"] == world and abs(back["value"] - wl["batch"] * 10 / 1.766) < 1e-2
+            assert abs(back["roofline"]["frac"] - back["roofline"]["achieved"] / back["roofline"]["peak"]) < 1e-3
+            assert ("dominant_kernel" in back["roofline"]) == extras
+            assert ("split-bf16" in back["config"]["conv3x3_arithmetic"]) == split_on
