@@ -181,3 +181,34 @@ def test_bench_line_is_assembled_from_measurements(monkeypatch):
             assert abs(back["roofline"]["frac"] - back["roofline"]["achieved"] / back["roofline"]["peak"]) < 1e-3
             assert ("dominant_kernel" in back["roofline"]) == extras
             assert ("split-bf16" in back["config"]["conv3x3_arithmetic"]) == split_on
+
+
+def test_bench_guard_repeats_once_with_the_hardware_measured_routes(monkeypatch, capfd):
+    """bench.run_guarded: a first attempt that dies (or exits 3 on a non-finite loss) is repeated once with SAFE_ROUTES and
+    the reason in CSEG_BENCH_ROUTE_FALLBACK; a clean first attempt is not repeated; explicit route switches or
+    CSEG_BENCH_GUARD=0 disable the guard."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    for k in list(bench.SAFE_ROUTES) + ["CSEG_BENCH_GUARD", "CSEG_BENCH_ROUTE_FALLBACK", "CSEG_BENCH_GUARDED"]:
+        monkeypatch.delenv(k, raising=False)
+    assert bench.guard_enabled()
+    show = "import os; print(os.environ.get('CSEG_BENCH_GUARDED'), os.environ.get('CSEG_CONV3X3_SB_WRW'), " \
+           "os.environ.get('CSEG_CONV3X3_SB_CHANNELS'), os.environ.get('CSEG_BENCH_ROUTE_FALLBACK'))"
+    attempts = []
+
+    def cmd(attempt, first_rc):
+        attempts.append(attempt)
+        return [sys.executable, "-c", ("import sys; sys.exit(%d)" % first_rc) if (attempt == 0 and first_rc) else show]
+    assert bench.run_guarded(lambda a: cmd(a, 3)) == 0
+    out = capfd.readouterr()
+    assert attempts == [0, 1] and "1 0 48,96 the first attempt" in out.out and "exit code 3" in out.err
+    attempts.clear()
+    assert bench.run_guarded(lambda a: cmd(a, 0)) == 0
+    assert attempts == [0] and "1 None None None" in capfd.readouterr().out
+    monkeypatch.setenv("CSEG_CONV3X3_SB_WRW", "1")
+    assert not bench.guard_enabled()
+    monkeypatch.delenv("CSEG_CONV3X3_SB_WRW")
+    monkeypatch.setenv("CSEG_BENCH_GUARD", "0")
+    assert not bench.guard_enabled()

@@ -10,6 +10,7 @@
 #     4. step-level goldens with one switch on at a time
 #     5. a bench line for each switch
 export TMPDIR=/tmp
+export CSEG_BENCH_GUARD=0      # job scripts choose the routes themselves: no automatic re-run
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r03a
 mkdir -p $O

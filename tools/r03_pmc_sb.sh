@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 3: stall / LDS / MFMA counters of the split-bf16 kernels at the benched shapes (one pass per counter set: 8 SQ slots).
 export TMPDIR=/tmp
+export CSEG_BENCH_GUARD=0      # job scripts choose the routes themselves: no automatic re-run
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r03pmc
 mkdir -p $O
