@@ -707,7 +707,7 @@ def conv3x3_sb_run(x, weight, transpose_flip=False, bias=None, nt=0):
 
 # Forward / backward-data go to the split-bf16 kernel only when its grid fills the chip (4x64-pixel tiles x channel tiles of
 # 144 / 96 / 48); smaller problems stay on MIOpen
-CONV3X3_SB_MIN_TILES = 256
+CONV3X3_SB_MIN_TILES = int(os.environ.get("CSEG_SB_MIN_TILES", "256"))     # 1 = route even tiny problems (parity runs)
 
 
 def conv3x3_sb_tiles(x, c_out):
@@ -804,7 +804,7 @@ def conv3x3_split_bf16(x, weight, bias=None):
 # 1x1 convolution on the BF16 matrix cores with split operands (csrc/conv1x1_sb.hip): first hardware run pending -> opt-in
 # ----------------------------------------------------------------------------------------------------------
 CONV1X1_SPLIT_BF16 = os.environ.get("CSEG_CONV1X1_SPLIT_BF16", "0") == "1"
-CONV1X1_SB_MIN_TILES = 256
+CONV1X1_SB_MIN_TILES = int(os.environ.get("CSEG_SB_MIN_TILES", "256"))
 
 
 def conv1x1_sb_eligible(x, weight):
