@@ -118,3 +118,55 @@ def _head_case(monkeypatch, B, H, W):
     for name, got, ref in (("dw", conv.weight.grad, ref_w), ("db", conv.bias.grad, ref_b)):
         scale = float(ref.abs().max())
         assert float((got - ref).abs().max()) <= 4e-5 * scale, (name, float((got - ref).abs().max()), scale)
+
+
+# ---- first hardware evidence that costs the builder no GPU minutes: these run in the driver's round-end pass, last ----------
+REPORT = {}          # printed as one line by tests/conftest.py at the end of the session (lands in the driver's log tail)
+
+
+def _first_run(name, body):
+    """Runs `body`; a failure is recorded in REPORT and reported as xfail (these are first hardware runs of things that are
+    NOT the default configuration: the information is the point, the suite's verdict stays about the defaults)."""
+    try:
+        body()
+    except Exception as e:                        # noqa: BLE001 -- anything, incl. assertion errors
+        REPORT[name] = "FAIL " + repr(e)[:140]
+        pytest.xfail("%s: %r" % (name, e))
+    REPORT.setdefault(name, "ok")
+
+
+def test_step_golden_with_the_split_kernels_engaged(monkeypatch, golden_dir):
+    """tests/test_step_golden.py at its own shapes never reaches the split-bf16 kernels on the GPU (the grid-fill thresholds
+    keep launches of fewer than 256 blocks on MIOpen). Here the thresholds are lifted, so the reference's one-SGD-step
+    golden (fp64 truth, noise-aware bounds) runs through the default kernel set: split-bf16 forward / backward-data on the
+    48 / 96 / 192-channel branches and the head, split-bf16 weight gradient where the width allows. The CPU emulation of the
+    execution model passes this with gradients at 0.2-1.3 x the reference's own fp32 noise (bound 8 x)."""
+    import numpy as np
+    import os
+    from contrastiveseg_amd import kernels as K
+    import test_step_golden as T
+    from oracle.make_golden import STEP_CASES
+    _dev()
+    monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
+    calls = _spy(monkeypatch, K, ["conv3x3_sb_run", "conv3x3_sb_wrw"])
+    torch.backends.cudnn.benchmark = False
+
+    def body():
+        c = STEP_CASES["step_hrnet48_contrast"]
+        g = np.load(os.path.join(golden_dir, "step_hrnet48_contrast.npz"))
+        res = T._run(c, torch.device("cuda:0"))
+        REPORT["step_sb_calls"] = [len([x for x in calls if x[0] == n]) for n in ("conv3x3_sb_run", "conv3x3_sb_wrw")]
+        assert REPORT["step_sb_calls"][0] > 300 and REPORT["step_sb_calls"][1] > 30
+        worst = T._compare(res, g, c, 1e-3, 1e-3, 5e-2)
+        REPORT["step_sb_worst_x_noise"] = round(max(v[0] / max(float(g["gradnoise_l2/" + k]), 1e-30)
+                                                    for k, v in worst.items()), 2)
+    _first_run("step_sb", body)
+
+
+@pytest.mark.parametrize("loss_type", ["contrast_ce_loss", "mem_contrast_ce_loss"])
+def test_row_sparse_embedding_gradient_first_hardware_run(loss_type, monkeypatch):
+    """The opt-in row-sparse backward of the projection head (torch ops + the HIP BN / contrast kernels, no new device
+    code): dense route vs sparse route on the GPU at the head's real width (body: tests/test_gpu_sparse_embed.py)."""
+    import test_gpu_sparse_embed as S
+    _dev()
+    _first_run("sparse_" + loss_type.split("_")[0], lambda: S.test_sparse_route_equals_dense_route_on_the_gpu(loss_type, monkeypatch))
