@@ -21,14 +21,35 @@ def lib():
     return _LIB
 
 
+_PAGE = 4096
+_KEEP = []           # mmap objects backing the guarded arrays (kept alive for the session)
+
+
 def aligned(shape, dtype=np.float32, fill=None):
-    """16-byte aligned array (the entry points check the alignment they vectorise on), NaN-filled unless told otherwise
-    so that elements a kernel fails to write are visible."""
+    """A "device" buffer: its last byte sits right in front of an inaccessible page and an inaccessible page precedes
+    its first page, so a kernel that reads or writes past the end of a tensor (CSEG_EMU_GUARD=front: in front of it) dies with SIGSEGV
+    here instead of with a memory-access fault on the GPU. NaN-filled unless told otherwise so that elements a kernel
+    fails to write are visible. 16-byte aligned when the byte size is a multiple of 16 (the entry points check what
+    they vectorise on); other sizes are padded at the FRONT."""
+    import ctypes
+    import mmap
     n = int(np.prod(shape))
     item = np.dtype(dtype).itemsize
-    raw = np.zeros(n * item + 64, dtype=np.uint8)
-    off = (-raw.ctypes.data) % 16
-    a = raw[off:off + n * item].view(dtype).reshape(shape)
+    nbytes = max(16, (n * item + 15) // 16 * 16)
+    pages = (nbytes + _PAGE - 1) // _PAGE
+    m = mmap.mmap(-1, (pages + 2) * _PAGE)
+    base = ctypes.addressof(ctypes.c_char.from_buffer(m))
+    libc = ctypes.CDLL(None, use_errno=True)
+    for off in (0, (pages + 1) * _PAGE):
+        if libc.mprotect(ctypes.c_void_p(base + off), ctypes.c_size_t(_PAGE), 0) != 0:
+            raise OSError(ctypes.get_errno(), "mprotect")
+    _KEEP.append(m)
+    import os
+    if os.environ.get("CSEG_EMU_GUARD") == "front":          # first byte right behind the leading inaccessible page
+        a = np.frombuffer(m, dtype=np.uint8, count=n * item, offset=_PAGE).view(dtype).reshape(shape)
+    else:                                                    # default: last byte right in front of the trailing one
+        start = (pages + 1) * _PAGE - nbytes
+        a = np.frombuffer(m, dtype=np.uint8, count=nbytes, offset=start)[nbytes - n * item:].view(dtype).reshape(shape)
     if fill is None:
         fill = np.nan if np.issubdtype(np.dtype(dtype), np.floating) else 0
     a[...] = fill
