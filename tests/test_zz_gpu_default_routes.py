@@ -124,15 +124,23 @@ def _head_case(monkeypatch, B, H, W):
 REPORT = {}          # printed as one line by tests/conftest.py at the end of the session (lands in the driver's log tail)
 
 
-def _first_run(name, body):
-    """Runs `body`; a failure is recorded in REPORT and reported as xfail (these are first hardware runs of things that are
-    NOT the default configuration: the information is the point, the suite's verdict stays about the defaults)."""
+def _attempt(name, body):
+    """Runs `body`; a failure is recorded in REPORT instead of raised. -> the exception or None."""
     try:
         body()
     except Exception as e:                        # noqa: BLE001 -- anything, incl. assertion errors
         REPORT[name] = "FAIL " + repr(e)[:140]
-        pytest.xfail("%s: %r" % (name, e))
+        return e
     REPORT.setdefault(name, "ok")
+    return None
+
+
+def _first_run(name, body):
+    """A failure is reported as xfail (these are first hardware runs of things that are NOT the default configuration: the
+    information is the point, the suite's verdict stays about the defaults)."""
+    e = _attempt(name, body)
+    if e is not None:
+        pytest.xfail("%s: %r" % (name, e))
 
 
 def test_step_golden_with_the_split_kernels_engaged(monkeypatch, golden_dir):
@@ -170,3 +178,74 @@ def test_row_sparse_embedding_gradient_first_hardware_run(loss_type, monkeypatch
     import test_gpu_sparse_embed as S
     _dev()
     _first_run("sparse_" + loss_type.split("_")[0], lambda: S.test_sparse_route_equals_dense_route_on_the_gpu(loss_type, monkeypatch))
+
+
+# ---- kernels that have never run on hardware: first run in CHILD processes (a fault or a hang there costs this test, not the
+# session), parity first, then the probes whose timings decide whether they become defaults in round 3 ------------------------
+def _child(cmd, env, timeout):
+    import os
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                         start_new_session=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        out, _ = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, _ = p.communicate()
+        return None, out
+    return p.returncode, out
+
+
+def _probe_rows(out):
+    import json
+    rows = []
+    for line in out.splitlines():
+        if line.startswith("{"):
+            try:
+                rows.append(json.loads(line))
+            except ValueError:
+                pass
+    return rows
+
+
+def test_unverified_kernels_first_hardware_run():
+    """Weight gradient version 2 (producer / consumer waves), the 1x1 forward / backward-data / weight-gradient kernels and the
+    explicit channel tilings: verified on the CPU emulation of the execution model (sources, both wave orders, guard pages
+    around every buffer), never run on a GPU. Here: their gated parity tests, then tools/conv3x3_sb_wrw_probe.py and
+    tools/conv1x1_sb_probe.py; results go into the CSEG_ZZ line."""
+    import sys
+    _dev()
+
+    def parity():
+        rc, out = _child([sys.executable, "-m", "pytest", "tests/test_gpu_conv3x3_sb.py", "-q", "-x", "-k",
+                          "weight_gradient or pointwise or explicit"],
+                         {"CSEG_TEST_SB_WRW_V2": "1", "CSEG_TEST_SB_1X1": "1", "CSEG_TEST_SB_NT": "1"}, 240)
+        tail = [l for l in out.strip().splitlines() if l.strip()][-1][:80] if out.strip() else ""
+        REPORT["new_kernels_parity"] = ("rc=%s " % rc) + tail
+        assert rc == 0, out[-1500:]
+    failed = [_attempt("new_kernels", parity)]
+
+    def wrw_probe():
+        rc, out = _child([sys.executable, "tools/conv3x3_sb_wrw_probe.py"], {}, 200)
+        rows = _probe_rows(out)
+        us = {}
+        for r in rows:
+            if "us" in r:
+                us.setdefault(r["shape"].split("_")[1], {})[r["kernel"].replace("split_bf16 wrw ", "").split(" ")[0]] = int(r["us"])
+        REPORT["wrw_us"] = us                      # {channels: {v1, v2, miopen, fp32-MFMA}}
+        assert rc == 0 and us, out[-800:]
+    failed.append(_attempt("wrw_probe", wrw_probe))
+
+    def c1_probe():
+        rc, out = _child([sys.executable, "tools/conv1x1_sb_probe.py"], {}, 200)
+        us = {}
+        for r in _probe_rows(out):
+            if "us" in r:
+                key = "sb" if r["kernel"].startswith("split") else "t"
+                us.setdefault(r["shape"].split("_", 1)[1], {}).setdefault(key, []).append(int(r["us"]))
+        REPORT["c1_us"] = us                       # {cin_cout: {sb: [fwd, bwd, wrw], t(orch): [fwd, bwd, wrw]}}
+        assert rc == 0 and us, out[-800:]
+    failed.append(_attempt("c1_probe", c1_probe))
+    if any(e is not None for e in failed):
+        pytest.xfail("; ".join(repr(e)[:200] for e in failed if e is not None))
