@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 3, first GPU calls: everything round 2 wrote after its GPU budget ran out. Two stages so that the second can be
+# Round 3, first GPU calls: everything round 2 wrote after its GPU budget ran out. READ FIRST: the CSEG_ZZ line in the tail of
+# GPUTEST_r02.json (tests/test_zz_gpu_default_routes.py ran these pieces once in the driver's round-end pass). Two stages so that the second can be
 # trimmed to the switches whose kernels passed the first:
 #   tools/r03_gpu_job1.sh a     (~15 GPU-min)
 #     1. the full GPU suite on the defaults (sanity of the tree as committed)
