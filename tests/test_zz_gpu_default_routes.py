@@ -252,14 +252,13 @@ def test_unverified_kernels_first_hardware_run():
 
 
 def test_optin_whole_step_timings():
-    """bench.py (5 timed steps, no extras) in child processes with the opt-in pieces switched on one group at a time: the
+    """bench.py (4 timed steps, no extras) in child processes with the opt-in pieces switched on one group at a time: the
     whole-step numbers that decide round 3's defaults, measured in the driver's pass. Recorded in CSEG_ZZ as ms/step."""
     import json
     import sys
     _dev()
     groups = {
         "default": {},
-        "wrw2": {"CSEG_CONV3X3_SB_WRW_V": "2"},
         "c1": {"CSEG_CONV1X1_SPLIT_BF16": "1", "CSEG_CONV1X1_SB_WRW": "1"},
         "sparse": {"CSEG_SPARSE_EMBED_GRAD": "1"},
         "all": {"CSEG_CONV3X3_SB_WRW_V": "2", "CSEG_CONV1X1_SPLIT_BF16": "1", "CSEG_CONV1X1_SB_WRW": "1",
@@ -268,7 +267,7 @@ def test_optin_whole_step_timings():
     ms, failed = {}, []
     for name, env in groups.items():
         def body(name=name, env=env):
-            rc, out = _child([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--no-kernels", "--no-cpu-baseline",
+            rc, out = _child([sys.executable, "bench.py", "--steps", "4", "--warmup", "2", "--no-kernels", "--no-cpu-baseline",
                               "--no-fp32-pass"], dict(env, CSEG_BENCH_GUARD="0"), 300)
             lines = [l for l in out.splitlines() if l.startswith("{")]
             assert rc == 0 and lines, "rc=%s %s" % (rc, out[-600:])
