@@ -279,3 +279,52 @@ def test_optin_whole_step_timings():
     REPORT["step_ms"] = ms
     if any(e is not None for e in failed):
         pytest.xfail("; ".join(repr(e)[:200] for e in failed if e is not None))
+
+
+_FAMILIES = [("conv3x3_sb_kernel<9", "sb9"), ("conv3x3_sb_kernel<6", "sb6"), ("conv3x3_sb_kernel<3", "sb3"),
+             ("conv3x3_sb_wrw", "sbwrw"), ("sb_wrw_reduce", "sbwrw"), ("pack_weights_sb", "sbpack"), ("conv1x1_sb", "sb1x1"),
+             ("conv3x3_wrw_kernel", "f32wrw"), ("wrw_reduce_kernel", "f32wrw"), ("conv3x3_kernel", "f32conv"),
+             ("igemm_wrw", "mi_wrw"), ("igemm_fwd", "mi_ig"), ("igemm_bwd", "mi_ig"), ("miopenSp3AsmConv", "mi_wino"),
+             ("batched_transpose", "transp"), ("SubTensorOp", "transp"), ("Cijk_", "rocblas"), ("bn_", "bn"),
+             ("elementwise", "eltw"), ("multi_tensor", "eltw"), ("reduce_kernel", "eltw")]
+
+
+def family_ms_per_step(trace_csv, ms_per_step, steps):
+    """Kernel time per family (ms per step) over the last `steps` steps of a rocprofv3 kernel trace."""
+    import csv
+    rows = list(csv.DictReader(open(trace_csv)))
+    t_end = max(int(r["End_Timestamp"]) for r in rows)
+    win = steps * ms_per_step * 1e6
+    acc = {}
+    for r in rows:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if s >= t_end - win:
+            fam = next((short for key, short in _FAMILIES if key in r["Kernel_Name"]), "other")
+            acc[fam] = acc.get(fam, 0) + (e - s)
+    return {k: round(v / 1e6 / steps, 1) for k, v in sorted(acc.items(), key=lambda kv: -kv[1])}
+
+
+def test_kernel_trace_of_the_default_step(tmp_path):
+    """rocprofv3 --kernel-trace around a short bench.py run of the default configuration (child process): kernel time per
+    family and step in CSEG_ZZ -- the per-kernel picture of the step as it is at the end of round 2."""
+    import glob
+    import json
+    import os
+    import sys
+    _dev()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def body():
+        out_dir = str(tmp_path / "kt")
+        rc, out = _child(["rocprofv3", "--kernel-trace", "-d", out_dir, "-o", "kt", "--output-format", "csv", "--",
+                          sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "3", "--no-cpu-baseline",
+                          "--no-kernels", "--no-fp32-pass"], {"CSEG_BENCH_GUARD": "0", "TMPDIR": "/tmp"}, 300)
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        traces = glob.glob(os.path.join(out_dir, "**", "*kernel_trace.csv"), recursive=True)
+        assert rc == 0 and lines and traces, "rc=%s traces=%d %s" % (rc, len(traces), out[-500:])
+        ms = json.loads(lines[-1])["ms_per_step"]
+        REPORT["trace_ms"] = dict(family_ms_per_step(traces[0], ms, 3), step=round(ms, 1))
+    e = _attempt("trace", body)
+    REPORT.pop("trace", None) if e is None else None
+    if e is not None:
+        pytest.xfail(repr(e)[:300])
