@@ -124,21 +124,23 @@ def _head_case(monkeypatch, B, H, W):
 REPORT = {}          # printed as one line by tests/conftest.py at the end of the session (lands in the driver's log tail)
 
 
-def _attempt(name, body):
-    """Runs `body`; a failure is recorded in REPORT instead of raised. -> the exception or None."""
+def _attempt(name, body, mark_ok=False):
+    """Runs `body`; a failure is recorded in REPORT instead of raised. -> the exception or None. (The line has to stay
+    short: a success leaves only the data `body` put into REPORT, plus "ok" when asked.)"""
     try:
         body()
     except Exception as e:                        # noqa: BLE001 -- anything, incl. assertion errors
         REPORT[name] = "FAIL " + repr(e)[:140]
         return e
-    REPORT.setdefault(name, "ok")
+    if mark_ok:
+        REPORT[name] = "ok"
     return None
 
 
-def _first_run(name, body):
+def _first_run(name, body, mark_ok=False):
     """A failure is reported as xfail (these are first hardware runs of things that are NOT the default configuration: the
     information is the point, the suite's verdict stays about the defaults)."""
-    e = _attempt(name, body)
+    e = _attempt(name, body, mark_ok)
     if e is not None:
         pytest.xfail("%s: %r" % (name, e))
 
@@ -177,7 +179,8 @@ def test_row_sparse_embedding_gradient_first_hardware_run(loss_type, monkeypatch
     code): dense route vs sparse route on the GPU at the head's real width (body: tests/test_gpu_sparse_embed.py)."""
     import test_gpu_sparse_embed as S
     _dev()
-    _first_run("sparse_" + loss_type.split("_")[0], lambda: S.test_sparse_route_equals_dense_route_on_the_gpu(loss_type, monkeypatch))
+    _first_run("sparse_" + loss_type.split("_")[0], lambda: S.test_sparse_route_equals_dense_route_on_the_gpu(loss_type, monkeypatch),
+               mark_ok=True)
 
 
 # ---- kernels that have never run on hardware: first run in CHILD processes (a fault or a hang there costs this test, not the
@@ -275,7 +278,6 @@ def test_optin_whole_step_timings():
             assert d["config"]["final_loss"] == d["config"]["final_loss"]
             ms[name] = round(d["ms_per_step"], 1)
         failed.append(_attempt("step_" + name, body))
-        REPORT.pop("step_" + name, None) if failed[-1] is None else None
     REPORT["step_ms"] = ms
     if any(e is not None for e in failed):
         pytest.xfail("; ".join(repr(e)[:200] for e in failed if e is not None))
@@ -325,6 +327,5 @@ def test_kernel_trace_of_the_default_step(tmp_path):
         ms = json.loads(lines[-1])["ms_per_step"]
         REPORT["trace_ms"] = dict(family_ms_per_step(traces[0], ms, 3), step=round(ms, 1))
     e = _attempt("trace", body)
-    REPORT.pop("trace", None) if e is None else None
     if e is not None:
         pytest.xfail(repr(e)[:300])
