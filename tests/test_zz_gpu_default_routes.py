@@ -267,11 +267,13 @@ def test_optin_whole_step_timings():
         "all": {"CSEG_CONV3X3_SB_WRW_V": "2", "CSEG_CONV1X1_SPLIT_BF16": "1", "CSEG_CONV1X1_SB_WRW": "1",
                 "CSEG_SPARSE_EMBED_GRAD": "1"},
     }
+    groups["b1"] = {}                        # one image per GPU: what a rank of the 8-GPU strong-scaling run computes
     ms, failed = {}, []
     for name, env in groups.items():
         def body(name=name, env=env):
+            extra = ["--global-batch", "1", "--steps", "8"] if name == "b1" else []
             rc, out = _child([sys.executable, "bench.py", "--steps", "4", "--warmup", "2", "--no-kernels", "--no-cpu-baseline",
-                              "--no-fp32-pass"], dict(env, CSEG_BENCH_GUARD="0"), 300)
+                              "--no-fp32-pass"] + extra, dict(env, CSEG_BENCH_GUARD="0"), 300)
             lines = [l for l in out.splitlines() if l.startswith("{")]
             assert rc == 0 and lines, "rc=%s %s" % (rc, out[-600:])
             d = json.loads(lines[-1])
