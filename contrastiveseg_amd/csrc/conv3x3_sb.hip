@@ -167,7 +167,13 @@ __device__ __forceinline__ void sb_store(const f32x4 (&acc)[4][NTMAX], float* __
 // SIMD hosts one wave of either half (2 waves per SIMD: one issues MFMAs while the other waits on LDS).
 // GLDS: the B stage is filled by LDS-DMA (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16, which is exactly
 // the packed lane order) instead of a register round trip -- no VGPRs held across the MFMAs of the step.
-template <int NT, bool GLDS>
+// VAR (tuning variants, 0 = the kernel as it was verified and timed on the MI355X):
+//   bit 0: the patch loads are buffer loads -- (the chunk's channel planes as a buffer resource in SGPRs) + (channel plane as
+//          scalar offset) + (one 32-bit per-lane offset per staging item) -- instead of 8 full 64-bit per-lane pointers per item. At NT = 9 the 64-bit form needs
+//          64 VGPRs for addresses alone, the kernel sits at the 256-register limit with 26 spilled VGPRs, and every chunk
+//          starts with 13 serialized scratch reloads (hipcc -S: "Folded Reload" under .LBB1_23) while both waves of a SIMD
+//          wait. Index-identical to VAR 0 (same elements, same order); first hardware run pending -> CSEG_CONV3X3_SB_VAR=1.
+template <int NT, bool GLDS, int VAR = 0>
 __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                             const float* __restrict__ bias, int Cin, int Cout, int H,
                                                             int W, int tiles_x, int tiles_y, float* __restrict__ y) {
@@ -243,9 +249,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
             a_item(u, chunk, oct, rc, ok);
             const int r = rc / XCOLS, col = rc - r * XCOLS;
             const int octc = min(oct, n_oct - 1), yc = min(max(y0 + r - 1, 0), H - 1), xcl = min(max(x0 + col - 1, 0), W - 1);
-            const float* p = xc + (size_t)(octc * 8) * plane + (size_t)yc * W + xcl;
+            if constexpr (VAR & 1) {
+                // buffer_load_dword v, v_off, s[rsrc], s_soff offen: the chunk's 32 channel planes as one buffer resource
+                // (SGPRs), the channel plane as scalar offset, ONE per-lane byte offset per item
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)xc, 0, (int)((size_t)n_oct * 8 * plane * sizeof(float)), 0x00020000);
+                const int off = (octc * 8 * (int)plane + yc * W + xcl) * (int)sizeof(float);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) apre[u][j] = p[(size_t)j * plane];      // raw; masked when it is stored
+                for (int j = 0; j < 8; ++j)
+                    apre[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                               rs, off, j * (int)plane * (int)sizeof(float), 0));
+            } else {
+                const float* p = xc + (size_t)(octc * 8) * plane + (size_t)yc * W + xcl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) apre[u][j] = p[(size_t)j * plane];      // raw; masked when it is stored
+            }
         }
     };
     auto a_store = [&](int chunk) {
@@ -342,13 +360,13 @@ int pick_nt(int Cout) {
     return 0;
 }
 
-template <int NT, bool GLDS>
+template <int NT, bool GLDS, int VAR = 0>
 int launch_sb(const float* x, const uint4* wp, const float* bias, int B, int Cin, int Cout, int H, int W, float* y,
               hipStream_t stream) {
     const size_t lds = sizeof(uint4) * (A_CELLS + 2 * NT * 3 * 64);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_sb_kernel<NT, GLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        if (hipFuncSetAttribute((const void*)conv3x3_sb_kernel<NT, GLDS, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess) {
             cseg_set_error("conv3x3_sb: cannot raise dynamic LDS to %zu bytes", lds);
             return 0;
@@ -358,7 +376,7 @@ int launch_sb(const float* x, const uint4* wp, const float* bias, int B, int Cin
     const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
     const long n_tiles = (long)B * (Cout / (NT * 16)) * tiles_y * tiles_x;
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb: grid too large");
-    hipLaunchKernelGGL((conv3x3_sb_kernel<NT, GLDS>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, Cin, Cout, H, W, tiles_x,
+    hipLaunchKernelGGL((conv3x3_sb_kernel<NT, GLDS, VAR>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, Cin, Cout, H, W, tiles_x,
                        tiles_y, y);
     CSEG_CHECK_LAUNCH("conv3x3_sb_kernel");
     return 1;
@@ -416,6 +434,16 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, int B, in
     // CSEG_CONV3X3_SB_GLDS=0: stage B through registers instead of LDS-DMA
     const char* glds_env = getenv("CSEG_CONV3X3_SB_GLDS");       // read per call: tests switch it inside one process
     const bool glds = !(glds_env && atoi(glds_env) == 0);
+    const char* var_env = getenv("CSEG_CONV3X3_SB_VAR");         // tuning variants of the kernel (see the template comment)
+    const int var = var_env ? atoi(var_env) : 0;
+    CSEG_REQUIRE(var == 0 || (var == 1 && (long)H * W * 32 * 4 < 2147483647L), "conv3x3_sb: unsupported CSEG_CONV3X3_SB_VAR=%d", var);
+    if (glds && var == 1) {
+        switch (NT) {
+            case 9: return launch_sb<9, true, 1>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
+            case 6: return launch_sb<6, true, 1>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
+            default: return launch_sb<3, true, 1>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
+        }
+    }
     if (glds) {
         switch (NT) {
             case 9: return launch_sb<9, true>(x, wq, bias, B, Cin, Cout, H, W, y, stream);

@@ -196,6 +196,21 @@ static inline float emu_fast_logf(float x) { return logf(x); }
 #define __expf emu_fast_expf          // (glibc's math.h declares functions with these names)
 #define __logf emu_fast_logf
 
+// raw buffer loads: resource = (base, bytes); an offset past the end returns 0 like the hardware's range check
+struct emu_buffer_rsrc { const unsigned char* base; unsigned num_records; };
+typedef emu_buffer_rsrc __amdgpu_buffer_rsrc_t;
+static inline emu_buffer_rsrc emu_make_buffer_rsrc(void* p, short, int num_records, int) {
+    return emu_buffer_rsrc{static_cast<const unsigned char*>(p), (unsigned)num_records};
+}
+static inline int emu_raw_buffer_load_b32(emu_buffer_rsrc r, int voffset, int soffset, int) {
+    const unsigned o = (unsigned)voffset + (unsigned)soffset;
+    int v = 0;
+    if ((uint64_t)o + 4 <= r.num_records) memcpy(&v, r.base + o, 4);
+    return v;
+}
+#define __builtin_amdgcn_make_buffer_rsrc emu_make_buffer_rsrc
+#define __builtin_amdgcn_raw_buffer_load_b32 emu_raw_buffer_load_b32
+
 template <class T>
 static inline T emu_shfl_from(T v, int src_lane_or_neg) {
     const unsigned char* all = emu::wave_exchange(&v, sizeof(T));

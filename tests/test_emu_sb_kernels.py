@@ -43,10 +43,12 @@ FWD_CASES = [  # B, Cin, Cout, H, W
 
 
 @pytest.mark.parametrize("case", FWD_CASES)
-@pytest.mark.parametrize("glds", ["1", "0"])
-def test_conv3x3_forward_and_backward_data(case, glds, wave_order, monkeypatch):
-    """Hardware-verified kernel: pins the emulator."""
+@pytest.mark.parametrize("glds,var", [("1", "0"), ("0", "0"), ("1", "1")])
+def test_conv3x3_forward_and_backward_data(case, glds, var, wave_order, monkeypatch):
+    """var 0: the hardware-verified kernel (pins the emulator). var 1: the buffer-load addressing of the patch (no spills at
+    9 channel tiles per block), first hardware run pending."""
     monkeypatch.setenv("CSEG_CONV3X3_SB_GLDS", glds)
+    monkeypatch.setenv("CSEG_CONV3X3_SB_VAR", var)
     B, ci, co, H, W = case
     x, w, b = _rand((B, ci, H, W), 1), _rand((co, ci, 3, 3), 2, 1.0 / (3 * ci ** 0.5)), _rand((co,), 3)
     y = E.conv3x3_sb(x, w, b)
@@ -132,9 +134,12 @@ def test_head_width_one_tile_each(monkeypatch):
     monkeypatch.setenv("CSEG_EMU_WAVE_ORDER", "shuffle:7")
     C = 720
     x, w, b = _rand((1, C, 4, 64), 21), _rand((C, C, 3, 3), 22, 1.0 / (3 * C ** 0.5)), _rand((C,), 23)
-    y = E.conv3x3_sb(x, w, b)
     ref = E.ref_conv3x3(x, w, b)
-    assert np.abs(y - ref).max() <= _bound(ref, 9 * C)
+    for var in ("0", "1"):                            # 1 = buffer-load addressing of the patch
+        monkeypatch.setenv("CSEG_CONV3X3_SB_VAR", var)
+        y = E.conv3x3_sb(x, w, b)
+        assert np.abs(y - ref).max() <= _bound(ref, 9 * C)
+    monkeypatch.delenv("CSEG_CONV3X3_SB_VAR")
     w1, w2 = _rand((C, C, 1, 1), 24, 1.0 / C ** 0.5), _rand((256, C, 1, 1), 25, 1.0 / C ** 0.5)
     for wt in (w1, w2):                               # projection head: 720 -> 720 (NT = 9), 720 -> 256 (NT = 8)
         y = E.conv1x1_sb(x, wt, None)

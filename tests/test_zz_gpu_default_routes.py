@@ -240,6 +240,22 @@ def test_unverified_kernels_first_hardware_run():
         assert rc == 0 and us, out[-800:]
     failed.append(_attempt("wrw_probe", wrw_probe))
 
+    def fwd_probe():
+        rc, out = _child([sys.executable, "tools/conv3x3_sb_probe.py", "head_720", "branch_48", "branch_96"], {}, 200)
+        us, err = {}, {}
+        for r in _probe_rows(out):
+            ch = r["shape"].split("_")[1]
+            if "us" in r and "glds=0" not in r["kernel"] and "fp32-MFMA" not in r["kernel"]:
+                key = "v1" if "var=1" in r["kernel"] else "mi" if "miopen" in r["kernel"] else "v0"
+                us.setdefault(ch, {}).setdefault(key, []).append(int(r["us"]))
+            if "max_abs_err_vs_fp64" in r:
+                e = r["max_abs_err_vs_fp64"]
+                err[ch] = round(e["split_bf16_var1"] / max(e["split_bf16"], 1e-30), 2)
+        REPORT["fwd_us"] = us                      # {channels: {v0: [fwd, bwd], v1: [fwd, bwd], mi: [fwd]}}; v1 = buffer loads
+        REPORT["fwd_v1_err_ratio"] = err           # error of variant 1 vs fp64 relative to variant 0's (1.0 = same)
+        assert rc == 0 and us, out[-800:]
+    failed.append(_attempt("fwd_probe", fwd_probe))
+
     def c1_probe():
         rc, out = _child([sys.executable, "tools/conv1x1_sb_probe.py"], {}, 200)
         us = {}
