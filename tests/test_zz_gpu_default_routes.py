@@ -278,10 +278,11 @@ def test_optin_whole_step_timings():
     _dev()
     groups = {
         "default": {},
+        "var1": {"CSEG_CONV3X3_SB_VAR": "1"},
         "c1": {"CSEG_CONV1X1_SPLIT_BF16": "1", "CSEG_CONV1X1_SB_WRW": "1"},
         "sparse": {"CSEG_SPARSE_EMBED_GRAD": "1"},
         "all": {"CSEG_CONV3X3_SB_WRW_V": "2", "CSEG_CONV1X1_SPLIT_BF16": "1", "CSEG_CONV1X1_SB_WRW": "1",
-                "CSEG_SPARSE_EMBED_GRAD": "1"},
+                "CSEG_SPARSE_EMBED_GRAD": "1", "CSEG_CONV3X3_SB_VAR": "1"},
     }
     groups["b1"] = {}                        # one image per GPU: what a rank of the 8-GPU strong-scaling run computes
     ms, failed = {}, []
