@@ -35,7 +35,24 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// conv3x3_sb16.hip: the small-channel variant (16-channel chunks, two blocks per CU), reached under CSEG_CONV3X3_SB_VAR=2
+namespace cseg_sb16 {
+size_t packed_bytes(int Cin, int Cout);
+int pack(const float* w, int Cout, int Cin, int transpose_flip, int NT, void* wp, hipStream_t stream);
+int fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int NT, float* y,
+        hipStream_t stream);
+}  // namespace cseg_sb16
+
 namespace {
+
+// CSEG_CONV3X3_SB_VAR: 0 = the kernel as verified and timed on the MI355X; 1 = buffer-load addressing of the patch (template
+// comment below); 2 = conv3x3_sb16.hip for convolutions with at most 192 output channels (3 channel tiles per block unless
+// the caller asks for 6), everything else as 1. Read per call: tests and probes switch it inside one process.
+int sb_variant() {
+    const char* e = getenv("CSEG_CONV3X3_SB_VAR");
+    return e ? atoi(e) : 0;
+}
+bool use_sb16(int conv_out) { return sb_variant() == 2 && conv_out <= 192 && conv_out % 48 == 0; }
 
 constexpr int TR = 4;                 // output rows per block (one per wave)
 constexpr int TC = 64;                // output columns per block
@@ -390,6 +407,7 @@ bool nt_ok(int nt, int Cout) { return (nt == 3 || nt == 6 || nt == 9) && Cout % 
 
 extern "C" size_t cseg_conv3x3_sb_packed_bytes(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0 || Cin % 16 || pick_nt(Cout) == 0) return 0;
+    if (use_sb16(Cout)) return cseg_sb16::packed_bytes(Cin, Cout);
     return (size_t)(Cout / 16) * steps_of(Cin) * 3 * 64 * sizeof(uint4);
 }
 
@@ -397,6 +415,7 @@ static int pack_impl(const float* w, int Cout, int Cin, int transpose_flip, int 
     // transpose_flip: w is still the forward's [Cout, Cin, 3, 3]; the packed operator maps Cout -> Cin channels
     const int conv_in = transpose_flip ? Cout : Cin, conv_out = transpose_flip ? Cin : Cout;
     CSEG_REQUIRE(w && wp, "conv3x3_sb_pack_weights: null pointer");
+    if (use_sb16(conv_out)) return cseg_sb16::pack(w, Cout, Cin, transpose_flip, NT == 6 ? 6 : 3, wp, stream);
     if (NT == 0) NT = pick_nt(conv_out);
     CSEG_REQUIRE(conv_in % 16 == 0 && NT > 0 && nt_ok(NT, conv_out),
                  "conv3x3_sb: needs input channels %% 16 == 0 and output channels %% 48 == 0 (got %d -> %d)", conv_in, conv_out);
@@ -425,6 +444,11 @@ extern "C" int cseg_conv3x3_sb_pack_weights_nt(const float* w, int Cout, int Cin
 static int fwd_impl(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int NT,
                     float* y, hipStream_t stream) {
     CSEG_REQUIRE(x && wp && y, "conv3x3_sb: null pointer");
+    if (use_sb16(Cout)) {
+        CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && W % 4 == 0,
+                     "conv3x3_sb: packed weights / output must be 16-byte aligned and W a multiple of 4");
+        return cseg_sb16::fwd(x, wp, bias, B, Cin, Cout, H, W, NT == 6 ? 6 : 3, y, stream);
+    }
     if (NT == 0) NT = pick_nt(Cout);
     CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && NT > 0 && nt_ok(NT, Cout),
                  "conv3x3_sb: unsupported shape B=%d Cin=%d Cout=%d %dx%d", B, Cin, Cout, H, W);
@@ -434,10 +458,10 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, int B, in
     // CSEG_CONV3X3_SB_GLDS=0: stage B through registers instead of LDS-DMA
     const char* glds_env = getenv("CSEG_CONV3X3_SB_GLDS");       // read per call: tests switch it inside one process
     const bool glds = !(glds_env && atoi(glds_env) == 0);
-    const char* var_env = getenv("CSEG_CONV3X3_SB_VAR");         // tuning variants of the kernel (see the template comment)
-    const int var = var_env ? atoi(var_env) : 0;
-    CSEG_REQUIRE(var == 0 || (var == 1 && (long)H * W * 32 * 4 < 2147483647L), "conv3x3_sb: unsupported CSEG_CONV3X3_SB_VAR=%d", var);
-    if (glds && var == 1) {
+    const int var = sb_variant();                                // tuning variants of the kernel (see the template comment)
+    CSEG_REQUIRE(var == 0 || ((var == 1 || var == 2) && (long)H * W * 32 * 4 < 2147483647L),
+                 "conv3x3_sb: unsupported CSEG_CONV3X3_SB_VAR=%d", var);
+    if (glds && var >= 1) {
         switch (NT) {
             case 9: return launch_sb<9, true, 1>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
             case 6: return launch_sb<6, true, 1>(x, wq, bias, B, Cin, Cout, H, W, y, stream);

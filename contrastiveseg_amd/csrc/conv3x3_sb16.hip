@@ -1,0 +1,327 @@
+// 3x3 / stride 1 / pad 1 split-bf16 convolution, variant for SMALL channel counts (CSEG_CONV3X3_SB_VAR=2, opt-in, first
+// hardware run pending): the kernel of conv3x3_sb.hip with 16-channel chunks instead of 32-channel ones.
+// Why: at 48 / 96 / 192 channels conv3x3_sb_kernel<3|6> runs at 0.26-0.37 of its roof (95 / 62 / 80 us per launch at the
+// benched shapes, 29 ms per step in total). A block there owns 76 KB of LDS for the split patch of a 32-channel chunk, so
+// ONE block fits a CU, and its phases -- wait for the patch loads, split + store, 9 + 5 barrier-separated K-steps of 24-48
+// MFMAs per wave, store -- have nothing to overlap with. With 16-channel chunks the patch image is 38 KB, a block needs
+// 56 KB (3 channel tiles) / 75 KB (6), the patch loads are buffer loads (one 32-bit offset per staging item: the kernel
+// fits 128 VGPRs), and TWO blocks share a CU: one block's barriers and staging overlap the other's MFMAs.
+// Every chunk is processed like the 16-channel tail of the original: a K-step = two taps x 16 channels (lane groups 0,1 =
+// first tap, 2,3 = second; the ninth tap pairs with zero weights), 5 K-steps per chunk, (Cin / 16) * 5 in total (15 instead
+// of 14 at 48 channels). Packing, fragment layout, B streaming (LDS-DMA, double-buffered) and the epilogue are the same.
+// Entry points: the cseg_conv3x3_sb_* family dispatches here when CSEG_CONV3X3_SB_VAR=2 (packing and forward must run under
+// the same setting; kernels.conv3x3_sb_run does both back to back).
+#include "cseg_common.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TR = 4;                 // output rows per block (one per wave)
+constexpr int TC = 64;                // output columns per block
+constexpr int XROWS = TR + 2;
+constexpr int XCOLS = TC + 2;         // cell 0 = column x0 - 1
+constexpr int CELLS = XROWS * XCOLS;  // 396 pixels per (piece, octet)
+constexpr int NOCT = 2;               // channel octets per chunk
+constexpr int A_CELLS = 3 * NOCT * CELLS;
+constexpr int A_ITEMS = NOCT * CELLS; // (octet, pixel) staging items of a 16-channel chunk
+constexpr int AU = (A_ITEMS + 511) / 512;     // staging items per thread (512 threads): 2
+constexpr int STEPS = 5;              // K-steps per chunk: taps (0,1) (2,3) (4,5) (6,7) (8,-)
+
+__host__ __device__ constexpr int steps16(int Cin) { return (Cin / 16) * STEPS; }
+
+__device__ __forceinline__ void split3(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const __bf16 bh = (__bf16)v;
+    const float r1 = v - (float)bh;            // exact
+    const __bf16 bm = (__bf16)r1;
+    const float r2 = r1 - (float)bm;           // exact
+    const __bf16 bl = (__bf16)r2;
+    h = __builtin_bit_cast(unsigned short, bh);
+    m = __builtin_bit_cast(unsigned short, bm);
+    l = __builtin_bit_cast(unsigned short, bl);
+}
+
+__device__ __forceinline__ void split8(const float (&v)[8], uint4& h, uint4& m, uint4& l) {
+    unsigned short hs[8], ms[8], ls[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split3(v[j], hs[j], ms[j], ls[j]);
+    h = make_uint4(hs[0] | ((unsigned)hs[1] << 16), hs[2] | ((unsigned)hs[3] << 16), hs[4] | ((unsigned)hs[5] << 16),
+                   hs[6] | ((unsigned)hs[7] << 16));
+    m = make_uint4(ms[0] | ((unsigned)ms[1] << 16), ms[2] | ((unsigned)ms[3] << 16), ms[4] | ((unsigned)ms[5] << 16),
+                   ms[6] | ((unsigned)ms[7] << 16));
+    l = make_uint4(ls[0] | ((unsigned)ls[1] << 16), ls[2] | ((unsigned)ls[3] << 16), ls[4] | ((unsigned)ls[5] << 16),
+                   ls[6] | ((unsigned)ls[7] << 16));
+}
+
+// Packed weights: Wp[co_tile][kstep][nt][piece][lane] of uint4 (8 bf16, element j), lane = 16*g + n; K-step ks = 5*chunk + q:
+//   value(co = (co_tile*NT + nt)*16 + n, ci = 16*chunk + 8*(g&1) + j, tap = 2q + (g>>1))   (zero when tap > 8)
+__global__ __launch_bounds__(256) void pack_weights_sb16_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                                                int transpose_flip, int NT, uint4* __restrict__ wp, int total) {
+    const int e = blockIdx.x * 256 + threadIdx.x;          // one thread per (co_tile, kstep, nt, lane)
+    if (e >= total) return;
+    const int conv_in = transpose_flip ? Cout : Cin;
+    const int n_steps = steps16(conv_in);
+    int r = e;
+    const int lane = r & 63; r >>= 6;
+    const int nt = r % NT; r /= NT;
+    const int ks = r % n_steps;
+    const int co_tile = r / n_steps;
+    const int g = lane >> 4, n = lane & 15;
+    const int oc = (co_tile * NT + nt) * 16 + n;           // output channel of THIS convolution
+    const int chunk = ks / STEPS, q = ks - chunk * STEPS;
+    const int tap = 2 * q + (g >> 1), ic0 = 16 * chunk + 8 * (g & 1);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ic = ic0 + j;                            // input channel of THIS convolution
+        float t = 0.f;
+        if (tap <= 8) {
+            if (!transpose_flip) t = w[((size_t)oc * Cin + ic) * 9 + tap];            // w[co][ci][ky][kx]
+            else t = w[((size_t)ic * Cin + oc) * 9 + (8 - tap)];                      // w[co=ic][ci=oc][2-ky][2-kx]
+        }
+        v[j] = t;
+    }
+    uint4 h, m, l;
+    split8(v, h, m, l);
+    uint4* dst = wp + (((size_t)(co_tile * n_steps + ks) * NT + nt) * 3) * 64 + lane;
+    dst[0] = h; dst[64] = m; dst[128] = l;
+}
+
+// One K-step of a wave: 4 pixel tiles x NTW channel tiles x 6 piece products (see conv3x3_sb.hip:sb_kstep)
+template <int NTW, int NTMAX>
+__device__ __forceinline__ void sb16_kstep(const uint4* __restrict__ ap, const uint4* __restrict__ bp,
+                                           f32x4 (&acc)[4][NTMAX]) {
+    bf16x8 a[4][3];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            a[mt][p] = __builtin_bit_cast(bf16x8, ap[p * NOCT * CELLS + 16 * mt]);
+        }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, bp[(nt * 3 + 0) * 64]);
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, bp[(nt * 3 + 1) * 64]);
+        const bf16x8 b2 = __builtin_bit_cast(bf16x8, bp[(nt * 3 + 2) * 64]);
+#define SB16_TERM(P, Q)                                                                                   \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                      \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][P], Q, acc[mt][nt], 0, 0, 0);
+        SB16_TERM(2, b0)
+        SB16_TERM(0, b2)
+        SB16_TERM(1, b1)
+        SB16_TERM(1, b0)
+        SB16_TERM(0, b1)
+        SB16_TERM(0, b0)
+#undef SB16_TERM
+    }
+}
+
+// accumulator layout: D[m = 4*g + r][n]: pixel column x0 + 16*mt + 4*g + r, channel co0 + 16*nt + n
+template <int NTW, int NTMAX>
+__device__ __forceinline__ void sb16_store(const f32x4 (&acc)[4][NTMAX], float* __restrict__ ybc,
+                                           const float* __restrict__ bias, int co0, size_t plane, int yy, int x0, int W,
+                                           int g, int n) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        float* orow = ybc + (size_t)(co0 + nt * 16 + n) * plane + (size_t)yy * W;
+        const float bv = bias ? bias[co0 + nt * 16 + n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int xx = x0 + 16 * mt + 4 * g;
+            f32x4 v = acc[mt][nt];
+            v += bv;
+            if (xx + 3 < W) *reinterpret_cast<float4*>(orow + xx) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+                if (xx < W) orow[xx] = v[0];
+                if (xx + 1 < W) orow[xx + 1] = v[1];
+                if (xx + 2 < W) orow[xx + 2] = v[2];
+            }
+        }
+    }
+}
+
+// 8 waves: wave = (row = wave & 3, half = wave >> 2); the halves split the NT channel tiles. Two blocks per CU = 4 waves per
+// SIMD (the second launch-bounds argument of HIP is waves per execution unit): 128 VGPRs.
+template <int NT>
+__global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
+                                                              const float* __restrict__ bias, int Cin, int Cout, int H,
+                                                              int W, int tiles_x, int tiles_y, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_s16[];
+    uint4* As = smem_s16;                          // [piece 3][octet 2][CELLS]
+    uint4* Bs = smem_s16 + A_CELLS;                // [2][NT*3*64]
+    constexpr int BSTEP = NT * 3 * 64;             // uint4 per K-step
+    constexpr int NT0 = (NT + 1) / 2, NT1 = NT - NT0;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row = wave & 3, half = wave >> 2;
+    const int g = lane >> 4, n = lane & 15;
+    const int n_cot = Cout / (NT * 16);
+    const size_t plane = (size_t)H * W;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    const int cot = t % n_cot;
+    const int b = t / n_cot;
+    const int x0 = tx * TC, y0 = ty * TR;
+
+    const int n_chunks = Cin / 16;
+    const int n_steps = n_chunks * STEPS;
+    const uint4* wbase = wp + (size_t)cot * n_steps * BSTEP;
+
+    auto b_glds = [&](int ks, int buf) {
+#pragma unroll
+        for (int i = 0; i < (NT * 3 + 7) / 8; ++i) {
+            const int r = wave + 8 * i;                  // one 1 KB row (channel tile, piece) per wave instruction
+            if (r < NT * 3)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(wbase + (size_t)ks * BSTEP + r * 64 + lane),
+                    (__attribute__((address_space(3))) void*)(Bs + buf * BSTEP + r * 64), 16, 0, 0);
+        }
+    };
+
+    // A staging: item = (octet, patch pixel); 8 channel loads each (coalesced along the row), branch-free: the address is
+    // clamped into the tensor and the value masked when it is stored
+    float apre[AU][8];
+    auto a_item = [&](int u, int& oct, int& rc, bool& ok) {
+        const int item = tid + 512 * u;
+        oct = item / CELLS; rc = item - oct * CELLS;
+        const int r = rc / XCOLS, col = rc - r * XCOLS;
+        const int yy = y0 + r - 1, xx = x0 + col - 1;
+        ok = oct < NOCT && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    };
+    auto a_issue = [&](int chunk) {
+        const float* xc = x + ((size_t)b * Cin + (size_t)chunk * 16) * plane;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xc, 0, (int)(16 * plane * sizeof(float)),
+                                                                            0x00020000);
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            int oct, rc;
+            bool ok;
+            a_item(u, oct, rc, ok);
+            const int r = rc / XCOLS, col = rc - r * XCOLS;
+            const int octc = min(oct, NOCT - 1), yc = min(max(y0 + r - 1, 0), H - 1), xcl = min(max(x0 + col - 1, 0), W - 1);
+            const int off = (octc * 8 * (int)plane + yc * W + xcl) * (int)sizeof(float);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                apre[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                           rs, off, j * (int)plane * (int)sizeof(float), 0));
+        }
+    };
+    auto a_store = [&]() {
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            int oct, rc;
+            bool ok;
+            a_item(u, oct, rc, ok);
+            if (oct < NOCT) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = ok ? apre[u][j] : 0.f;       // zero padding / outside the tensor
+                uint4 h, m, l;
+                split8(v, h, m, l);
+                const int item = oct * CELLS + rc;
+                As[item] = h;
+                As[NOCT * CELLS + item] = m;
+                As[2 * NOCT * CELLS + item] = l;
+            }
+        }
+    };
+
+    f32x4 acc[4][NT0];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT0; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    a_issue(0);
+    b_glds(0, 0);
+    a_store();
+    __syncthreads();
+
+    const uint4* a_lane = As + row * XCOLS + n;                        // + octet / tap offset per K-step
+    const uint4* b_lane = Bs + (half ? NT0 * 3 * 64 : 0) + lane;       // + buffer offset per K-step
+    int ks = 0, buf = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+#pragma unroll 1
+        for (int s = 0; s < STEPS; ++s) {
+            const bool more = ks + 1 < n_steps;
+            if (more) b_glds(ks + 1, buf ^ 1);          // that buffer was last read in step ks - 1 (barrier since)
+            if (s == STEPS - 3 && c + 1 < n_chunks) a_issue(c + 1);
+            // the ninth tap is paired with a tenth that does not exist: its packed weights are zero, so whatever (finite)
+            // patch values those lanes read contribute nothing
+            const int tap = min(2 * s + (g >> 1), 8);
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int a_off = (g & 1) * CELLS + ky * XCOLS + kx;
+            if (half == 0) sb16_kstep<NT0, NT0>(a_lane + a_off, b_lane + buf * BSTEP, acc);
+            else if (NT1 > 0) sb16_kstep<NT1, NT0>(a_lane + a_off, b_lane + buf * BSTEP, acc);
+            if (s == STEPS - 1 && c + 1 < n_chunks) {
+                __syncthreads();                    // every wave is done with this chunk's patch
+                a_store();
+            }
+            __syncthreads();
+            buf ^= 1;
+            ++ks;
+        }
+    }
+
+    const int yy = y0 + row;
+    if (yy < H) {
+        float* ybc = y + (size_t)b * Cout * plane;
+        const int co0 = cot * NT * 16;
+        if (half == 0) sb16_store<NT0, NT0>(acc, ybc, bias, co0, plane, yy, x0, W, g, n);
+        else if (NT1 > 0) sb16_store<NT1, NT0>(acc, ybc, bias, co0 + NT0 * 16, plane, yy, x0, W, g, n);
+    }
+}
+
+template <int NT>
+int launch_sb16(const float* x, const uint4* wp, const float* bias, int B, int Cin, int Cout, int H, int W, float* y,
+                hipStream_t stream) {
+    const size_t lds = sizeof(uint4) * (A_CELLS + 2 * NT * 3 * 64);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv3x3_sb16_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            cseg_set_error("conv3x3_sb16: cannot raise dynamic LDS to %zu bytes", lds);
+            return 0;
+        }
+        attr_set = true;
+    }
+    const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
+    const long n_tiles = (long)B * (Cout / (NT * 16)) * tiles_y * tiles_x;
+    CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb16: grid too large");
+    hipLaunchKernelGGL((conv3x3_sb16_kernel<NT>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, Cin, Cout, H, W,
+                       tiles_x, tiles_y, y);
+    CSEG_CHECK_LAUNCH("conv3x3_sb16_kernel");
+    return 1;
+}
+
+}  // namespace
+
+// Reached from the cseg_conv3x3_sb_* entry points of conv3x3_sb.hip under CSEG_CONV3X3_SB_VAR=2 (NT = 3 or 6).
+namespace cseg_sb16 {
+
+size_t packed_bytes(int Cin, int Cout) { return (size_t)(Cout / 16) * steps16(Cin) * 3 * 64 * sizeof(uint4); }
+
+int pack(const float* w, int Cout, int Cin, int transpose_flip, int NT, void* wp, hipStream_t stream) {
+    const int conv_in = transpose_flip ? Cout : Cin, conv_out = transpose_flip ? Cin : Cout;
+    CSEG_REQUIRE((NT == 3 || NT == 6) && conv_out % (NT * 16) == 0 && conv_in % 16 == 0,
+                 "conv3x3_sb16: needs 3 or 6 channel tiles per block (got %d) and input channels %% 16 == 0", NT);
+    const long total = (long)(conv_out / 16) * steps16(conv_in) * 64;
+    CSEG_REQUIRE(total < 2147483647L, "conv3x3_sb16 pack: too large");
+    hipLaunchKernelGGL(pack_weights_sb16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, Cout, Cin,
+                       transpose_flip, NT, (uint4*)wp, (int)total);
+    CSEG_CHECK_LAUNCH("conv3x3_sb16 pack");
+    return 1;
+}
+
+int fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int NT, float* y,
+        hipStream_t stream) {
+    CSEG_REQUIRE((NT == 3 || NT == 6) && Cout % (NT * 16) == 0 && Cin % 16 == 0 && (long)H * W * 16 * 4 < 2147483647L,
+                 "conv3x3_sb16: unsupported shape Cin=%d Cout=%d %dx%d with %d channel tiles per block", Cin, Cout, H, W, NT);
+    if (NT == 6) return launch_sb16<6>(x, (const uint4*)wp, bias, B, Cin, Cout, H, W, y, stream);
+    return launch_sb16<3>(x, (const uint4*)wp, bias, B, Cin, Cout, H, W, y, stream);
+}
+
+}  // namespace cseg_sb16

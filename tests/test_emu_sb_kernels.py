@@ -43,10 +43,11 @@ FWD_CASES = [  # B, Cin, Cout, H, W
 
 
 @pytest.mark.parametrize("case", FWD_CASES)
-@pytest.mark.parametrize("glds,var", [("1", "0"), ("0", "0"), ("1", "1")])
+@pytest.mark.parametrize("glds,var", [("1", "0"), ("0", "0"), ("1", "1"), ("1", "2")])
 def test_conv3x3_forward_and_backward_data(case, glds, var, wave_order, monkeypatch):
     """var 0: the hardware-verified kernel (pins the emulator). var 1: the buffer-load addressing of the patch (no spills at
-    9 channel tiles per block), first hardware run pending."""
+    9 channel tiles per block); var 2: conv3x3_sb16.hip (16-channel chunks, two blocks per CU) for up to 192 output channels.
+    Both: first hardware run pending."""
     monkeypatch.setenv("CSEG_CONV3X3_SB_GLDS", glds)
     monkeypatch.setenv("CSEG_CONV3X3_SB_VAR", var)
     B, ci, co, H, W = case
@@ -62,8 +63,10 @@ def test_conv3x3_forward_and_backward_data(case, glds, var, wave_order, monkeypa
         assert np.abs(dx - ref).max() <= _bound(ref, 9 * co)
 
 
+@pytest.mark.parametrize("var", ["0", "2"])
 @pytest.mark.parametrize("nt", [3, 6])
-def test_conv3x3_explicit_channel_tiling(nt, wave_order):
+def test_conv3x3_explicit_channel_tiling(nt, var, wave_order, monkeypatch):
+    monkeypatch.setenv("CSEG_CONV3X3_SB_VAR", var)
     """cseg_conv3x3_sb_*_nt (first hardware run pending): same convolution whatever the channel tiles per block."""
     B, ci, co, H, W = 1, 48, 96, 5, 40
     x, w = _rand((B, ci, H, W), 5), _rand((co, ci, 3, 3), 6, 1.0 / (3 * ci ** 0.5))

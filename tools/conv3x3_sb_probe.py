@@ -52,11 +52,20 @@ def main():
                 us = timeit(lambda: K.conv3x3_sb_run(x, w, flip), iters)
                 rows.append(("split_bf16 glds=%s %s (incl. weight packing)" % (glds, tag), us))
         os.environ["CSEG_CONV3X3_SB_GLDS"] = "1"
-        os.environ["CSEG_CONV3X3_SB_VAR"] = "1"           # buffer-load addressing of the patch (no spills at NT = 9)
-        for flip, tag in ((False, "fwd"), (True, "bwd_data")):
-            rows.append(("split_bf16 var=1 %s (incl. weight packing)" % tag, timeit(lambda: K.conv3x3_sb_run(x, w, flip), iters)))
-        e_v1 = float((K.conv3x3_sb_run(x[:1].contiguous(), w, False).double() - F.conv2d(x[:1].double(), w.double(), None, 1, 1)).abs().max())
+        e_var = {}
+        # variant 1: buffer-load addressing of the patch (no spills at NT = 9); variant 2: 16-channel chunks + two blocks per
+        # CU for <= 192 channels (csrc/conv3x3_sb16.hip), variant 1 above that
+        for var in ("1", "2"):
+            if var == "2" and C > 192:
+                continue
+            os.environ["CSEG_CONV3X3_SB_VAR"] = var
+            for flip, tag in ((False, "fwd"), (True, "bwd_data")):
+                rows.append(("split_bf16 var=%s %s (incl. weight packing)" % (var, tag),
+                             timeit(lambda: K.conv3x3_sb_run(x, w, flip), iters)))
+            e_var[var] = float((K.conv3x3_sb_run(x[:1].contiguous(), w, False).double()
+                                - F.conv2d(x[:1].double(), w.double(), None, 1, 1)).abs().max())
         del os.environ["CSEG_CONV3X3_SB_VAR"]
+        e_v1 = e_var["1"]
         rows.append(("miopen fp32 fwd", timeit(lambda: F.conv2d(x, w, None, 1, 1), iters)))
         if C in (48, 96, 192):
             rows.append(("fp32-MFMA kernel fwd (incl. weight packing)", timeit(lambda: K._conv3x3_run(x, w, False), iters)))
@@ -66,7 +75,7 @@ def main():
         for tag, us in rows:
             print(json.dumps({"shape": name, "dims": [B, C, H, W], "kernel": tag, "us": round(us, 1),
                               "fp32_equiv_TFLOPs": round(flops / us / 1e6, 1)}), flush=True)
-        print(json.dumps({"shape": name, "max_abs_err_vs_fp64": {"split_bf16": e_sb, "split_bf16_var1": e_v1, "miopen_fp32": e_32},
+        print(json.dumps({"shape": name, "max_abs_err_vs_fp64": {"split_bf16": e_sb, "split_bf16_var1": e_v1, "split_bf16_var2": e_var.get("2"), "miopen_fp32": e_32},
                           "out_absmax": float(ref.abs().max())}), flush=True)
 
 
