@@ -8,6 +8,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+SESSION_T0 = __import__("time").time()          # tests/test_zz_gpu_default_routes.py budgets its optional steps against this
 
 
 def pytest_configure(config):
