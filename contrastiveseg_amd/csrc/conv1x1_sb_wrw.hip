@@ -57,7 +57,8 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_q[];
     unsigned short* ds = smem_q;                       // [2][piece][co 144][PITCH]
     unsigned short* xs = smem_q + 2 * DY_ELEMS;        // [2][piece][ci 128][PITCH]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // readfirstlane: the role split below must be a SCALAR branch (the wave index is uniform, which the compiler cannot see)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const bool loader = wave >= 4;
     const int lt = tid - 256;
     const int g = lane >> 4, n = lane & 15;

@@ -288,7 +288,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_w[];
     unsigned short* xs = smem_w;
     unsigned short* ds = smem_w + X2_ELEMS;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // readfirstlane: the role split below must be a SCALAR branch (the wave index is uniform, which the compiler cannot see)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const bool loader = wave >= 4;
     const int lt = tid - 256;                          // loader thread index
     const int g = lane >> 4, n = lane & 15;

@@ -224,3 +224,5 @@ template <class T>
 static inline T __shfl_up(T v, int delta, int = 64) { return emu_shfl_from(v, emu::lane_id() - delta); }
 template <class T>
 static inline T __shfl(T v, int src, int = 64) { return emu_shfl_from(v, src & 63); }
+static inline int emu_readfirstlane(int v) { return emu_shfl_from(v, 0); }       // all lanes are active in these kernels
+#define __builtin_amdgcn_readfirstlane emu_readfirstlane
