@@ -301,3 +301,77 @@ def test_conv3x3_module_routes_to_the_split_kernels(channels, hw, monkeypatch):
         assert wrw_route == []
     for got, ref in ((x.grad, x64.grad), (conv.weight.grad, w64.grad)):
         assert float((got.double() - ref).abs().max()) <= 4e-6 * float(ref.abs().max()) * max(1.0, (9 * channels) ** 0.5 / 8)
+
+
+# ---- two ranks over gloo, device half = the HIP sources on the emulator ---------------------------------------------------
+def _spawn(worker, n=2):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, n, port, q)) for r in range(n)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(n)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_two_rank_syncbn_exchange_on_the_emulated_device(monkeypatch):
+    """tests/test_gpu_bn.py::test_fused_syncbn_two_ranks_on_one_gpu_equal_single_process with the emulated device: two ranks with
+    half the batch each == one process with the whole batch (outputs, input / residual gradients, running statistics; the
+    rank-local parameter gradients add up)."""
+    import numpy as np
+    from tests.emu import workers
+    from contrastiveseg_amd.lib.models.tools.fused_bn import FusedBatchNorm2d
+    res = _spawn(workers.syncbn_worker)
+    inject.install(monkeypatch)
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 24, 20, 36, generator=gen) * 2 + 1
+    r = torch.randn(4, 24, 20, 36, generator=gen)
+    g = torch.randn(4, 24, 20, 36, generator=gen)
+    m = FusedBatchNorm2d(24).train()
+    with torch.no_grad():
+        m.weight.copy_(torch.linspace(0.5, 1.5, 24))
+        m.bias.copy_(torch.linspace(-1, 1, 24))
+    xd, rd = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    y = m(xd, residual=rd, relu=True)
+    y.backward(g)
+    assert np.abs(np.concatenate([res[0][1], res[1][1]]) - y.detach().numpy()).max() <= 1e-6
+    assert np.abs(np.concatenate([res[0][2], res[1][2]]) - xd.grad.numpy()).max() <= 1e-6
+    assert np.array_equal(np.concatenate([res[0][3], res[1][3]]), rd.grad.numpy())
+    assert np.abs(res[0][4] + res[1][4] - m.weight.grad.numpy()).max() <= 1e-4
+    assert np.abs(res[0][5] + res[1][5] - m.bias.grad.numpy()).max() <= 1e-4
+    for k in (0, 1):
+        assert np.abs(res[k][6] - m.running_mean.numpy()).max() <= 1e-6
+        assert np.abs(res[k][7] - m.running_var.numpy()).max() <= 1e-6
+
+
+def test_two_rank_cross_rank_contrast_on_the_emulated_device(monkeypatch):
+    """tests/test_distributed_gloo.py's oracle (the single-process loss on the concatenated global batch) against two ranks
+    whose device half is the HIP sources: same loss, local gradient / world == the single-process gradient slice."""
+    import numpy as np
+    from tests.emu import workers
+    sys.path.insert(0, HERE)
+    from test_distributed_gloo import _case, _configer
+    res = _spawn(workers.cross_rank_worker)
+    inject.install(monkeypatch)
+    from contrastiveseg_amd.lib.loss.loss_contrast import PixelContrastLoss
+    c, (target, seg, embed, _) = _case()
+    crit = PixelContrastLoss(_configer(c, "global", 256))
+    e = torch.from_numpy(embed).requires_grad_(True)
+    torch.manual_seed(11)
+    want = crit(e, torch.from_numpy(target), seg=torch.from_numpy(seg))
+    want.backward()
+    B = c["B"] // 2
+    for rank, loss, grad, n in res:
+        assert n == crit.last_selection["plan"].N
+        assert abs(loss - float(want.detach())) < 1e-5 * max(1.0, abs(float(want.detach())))
+        ref = e.grad.numpy()[rank * B:(rank + 1) * B]
+        assert np.allclose(grad / 2, ref, rtol=1e-4, atol=1e-8), np.abs(grad / 2 - ref).max()
