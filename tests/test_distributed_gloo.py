@@ -322,12 +322,35 @@ def test_fused_syncbn_host_logic_two_ranks_equal_single_process():
     assert np.abs(res[0][4] - bn.running_var.numpy()).max() <= 1e-6
 
 
+def _install_device_half():
+    """CSEG_TEST_DEVICE_HALF=emu: the HIP sources on the CPU emulation of the execution model (tests/emu); default: the
+    torch restatement oracle/cpu_port.py. -> a function that undoes the installation."""
+    if os.environ.get("CSEG_TEST_DEVICE_HALF") == "emu":
+        from tests.emu import inject
+
+        class _Patch(object):
+            def __init__(self):
+                self.saved = []
+
+            def setattr(self, obj, name, value):
+                self.saved.append((obj, name, getattr(obj, name)))
+                setattr(obj, name, value)
+
+            def undo(self):
+                for obj, name, value in reversed(self.saved):
+                    setattr(obj, name, value)
+        patch = _Patch()
+        inject.install(patch)
+        return patch.undo
+    from oracle import cpu_port
+    return cpu_port.install(None)
+
+
 def _hrnet_sync_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from oracle import cpu_port
-    cpu_port.install(None)
+    _install_device_half()
     from contrastiveseg_amd.lib.models.backbones.hrnet_backbone import HighResolutionNet
     calls = {"n": 0}
     real = dist.all_reduce
@@ -355,11 +378,19 @@ def _hrnet_sync_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_hrnet_grouped_syncbn_equals_single_process_and_batches_the_exchanges():
+@pytest.mark.parametrize("device_half", ["cpu_port", "emu"])
+def test_hrnet_grouped_syncbn_equals_single_process_and_batches_the_exchanges(device_half, monkeypatch):
     """HRNet encoder, 2 ranks x 2 images, FusedSyncBatchNorm with the exchanges of parallel branches / exchange paths
     grouped (hrnet_backbone.HighResolutionModule lockstep path): outputs, input gradients and summed parameter gradients
     equal one process on the 4 images with plain batch statistics; the number of all-reduces per direction is well
-    below the number of BN layers (one per BN without grouping)."""
+    below the number of BN layers (one per BN without grouping). device_half: the torch restatement, or the HIP sources
+    (BN statistics / finalise / apply / backward kernels, exchange-unit fusion) on the emulator."""
+    if device_half == "emu":
+        from tests.emu import build_emu
+        if not os.path.exists(build_emu.CLANG):
+            pytest.skip("host clang++ of the ROCm toolchain not found")
+        build_emu.build()                       # before the ranks start: they must not race to build it
+    monkeypatch.setenv("CSEG_TEST_DEVICE_HALF", device_half)
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -371,8 +402,7 @@ def test_hrnet_grouped_syncbn_equals_single_process_and_batches_the_exchanges():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    from oracle import cpu_port
-    restore = cpu_port.install(None)
+    restore = _install_device_half()
     try:
         from contrastiveseg_amd.lib.models.backbones.hrnet_backbone import HighResolutionNet
         torch.manual_seed(304)
@@ -391,9 +421,18 @@ def test_hrnet_grouped_syncbn_equals_single_process_and_batches_the_exchanges():
         got = np.concatenate([res[0][1][b], res[1][1][b]])
         assert np.abs(got - outs[b].detach().numpy()).max() <= 2e-4 * max(1.0, float(outs[b].abs().max()))
     gx = np.concatenate([res[0][2], res[1][2]])
-    assert np.abs(gx - x.grad.numpy()).max() <= 2e-3 * float(x.grad.abs().max())
-    for k in res[0][3]:
-        tot = res[0][3][k] + res[1][3][k]
-        ref = named[k].grad.numpy()
-        assert np.abs(tot - ref).max() <= 5e-3 * np.abs(ref).max() + 1e-7, (k, np.abs(tot - ref).max(), np.abs(ref).max())
+    if device_half == "emu":
+        # The kernels' blockwise partial sums depend on the grid (half batch vs whole batch), so the two evaluations differ
+        # in rounding from the first BN on, and backward through this freshly initialised encoder amplifies that to the
+        # 1e-2 level (the reference against its own fp64 evaluation: 1e-2 .. 7e-2). Relative L2 here.
+        rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+        assert rel(gx, x.grad.numpy()) <= 5e-2, rel(gx, x.grad.numpy())
+        for k in res[0][3]:
+            assert rel(res[0][3][k] + res[1][3][k], named[k].grad.numpy()) <= 5e-2, (k, rel(res[0][3][k] + res[1][3][k], named[k].grad.numpy()))
+    else:
+        assert np.abs(gx - x.grad.numpy()).max() <= 2e-3 * float(x.grad.abs().max())
+        for k in res[0][3]:
+            tot = res[0][3][k] + res[1][3][k]
+            ref = named[k].grad.numpy()
+            assert np.abs(tot - ref).max() <= 5e-3 * np.abs(ref).max() + 1e-7, (k, np.abs(tot - ref).max(), np.abs(ref).max())
     assert np.abs(res[0][7] - net.stage4[2].branches[3][3].bn2.running_var.detach().numpy()).max() <= 1e-5
