@@ -17,6 +17,10 @@ CLANG = os.environ.get("CSEG_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 _DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(16\)\)\)\s+)?([\w ]+?)\s+(\w+)\[\];")
 
 
+class EmuBuildError(RuntimeError):
+    """The host toolchain could not build the emulated library (tests that need it skip with this message)."""
+
+
 def _rewrite(text):
     return _DYN.sub(lambda m: "%s* %s = reinterpret_cast<%s*>(emu::dyn_lds());" % (m.group(1), m.group(2), m.group(1)), text)
 
@@ -30,6 +34,8 @@ def _deps():
 def build(force=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in _deps()):
         return OUT
+    if not os.path.exists(CLANG):
+        raise EmuBuildError("host clang++ of the ROCm toolchain not found at %s" % CLANG)
     os.makedirs(OUT_DIR, exist_ok=True)
     for h in os.listdir(CSRC):                       # headers that declare dynamic LDS get the same rewrite
         if h.endswith(".h"):
@@ -49,8 +55,9 @@ def build(force=False):
     procs.append(("emu_runtime.cpp", subprocess.Popen([CLANG] + flags + ["-c", os.path.join(HERE, "emu_runtime.cpp"), "-o", rt])))
     for name, p in procs:
         if p.wait() != 0:
-            raise RuntimeError("host compilation of %s for the emulator failed" % name)
-    subprocess.check_call([CLANG, "-shared", "-pthread", "-o", OUT] + objs + [rt])
+            raise EmuBuildError("host compilation of %s for the emulator failed" % name)
+    if subprocess.call([CLANG, "-shared", "-pthread", "-o", OUT] + objs + [rt]) != 0:
+        raise EmuBuildError("linking libcseg_emu.so failed")
     return OUT
 
 

@@ -13,7 +13,12 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = ctypes.CDLL(build_emu.build())
+        try:
+            path = build_emu.build()
+        except build_emu.EmuBuildError as e:           # an environment without the host toolchain: not a test failure
+            import pytest
+            pytest.skip(str(e))
+        _LIB = ctypes.CDLL(path)
         for name in ("cseg_conv3x3_sb_packed_bytes", "cseg_conv1x1_sb_packed_bytes", "cseg_conv3x3_sb_wrw_ws_floats",
                      "cseg_conv1x1_sb_wrw_ws_floats"):
             getattr(_LIB, name).restype = ctypes.c_size_t

@@ -11,7 +11,12 @@ from . import build_emu
 
 def install(monkeypatch):
     from contrastiveseg_amd import _hip
-    handle = ctypes.CDLL(build_emu.build())
+    try:
+        path = build_emu.build()
+    except build_emu.EmuBuildError as e:               # an environment without the host toolchain: not a test failure
+        import pytest
+        pytest.skip(str(e))
+    handle = ctypes.CDLL(path)
     for name, (res, args) in _hip.SIGNATURES.items():
         fn = getattr(handle, name)
         fn.restype = res

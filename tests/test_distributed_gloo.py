@@ -389,7 +389,10 @@ def test_hrnet_grouped_syncbn_equals_single_process_and_batches_the_exchanges(de
         from tests.emu import build_emu
         if not os.path.exists(build_emu.CLANG):
             pytest.skip("host clang++ of the ROCm toolchain not found")
-        build_emu.build()                       # before the ranks start: they must not race to build it
+        try:
+            build_emu.build()                   # before the ranks start: they must not race to build it
+        except build_emu.EmuBuildError as e:
+            pytest.skip(str(e))
     monkeypatch.setenv("CSEG_TEST_DEVICE_HALF", device_half)
     world = 2
     ctx = mp.get_context("spawn")
