@@ -379,3 +379,12 @@ def test_two_rank_cross_rank_contrast_on_the_emulated_device(monkeypatch):
         assert abs(loss - float(want.detach())) < 1e-5 * max(1.0, abs(float(want.detach())))
         ref = e.grad.numpy()[rank * B:(rank + 1) * B]
         assert np.allclose(grad / 2, ref, rtol=1e-4, atol=1e-8), np.abs(grad / 2 - ref).max()
+
+
+# ---- BASELINE.json's headline contrast shape and the reference config's bank size, on the emulator ------------------------
+@pytest.mark.slow
+def test_contrast_at_the_headline_and_reference_bank_sizes(monkeypatch):
+    """1024 anchors x 4104 bank columns x 256-d (BASELINE.json), and the reference's own memory configuration (152 anchors x
+    190 000 columns): bank mode read in place == plain mode on the packed copy == the float64 oracle, gradients included."""
+    _replay(monkeypatch, "test_gpu_kernels", "test_contrast_headline_shape_properties", {})
+    _replay(monkeypatch, "test_gpu_kernels", "test_contrast_bank_reference_config_size", {})
