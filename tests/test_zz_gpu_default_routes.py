@@ -244,11 +244,14 @@ def test_unverified_kernels_first_hardware_run():
     _dev()
 
     def parity():
-        rc, out = _child([sys.executable, "-m", "pytest", "tests/test_gpu_conv3x3_sb.py", "-q", "-x", "-k",
+        rc, out = _child([sys.executable, "-m", "pytest", "tests/test_gpu_conv3x3_sb.py", "-q", "-k",
                           "weight_gradient or pointwise or explicit"],
                          {"CSEG_TEST_SB_WRW_V2": "1", "CSEG_TEST_SB_1X1": "1", "CSEG_TEST_SB_NT": "1"}, 240)
         tail = [l for l in out.strip().splitlines() if l.strip()][-1][:80] if out.strip() else ""
+        failed_ids = [l.split("::", 1)[1][:60] for l in out.splitlines() if l.startswith("FAILED ") and "::" in l][:6]
         REPORT["new_kernels_parity"] = ("rc=%s " % rc) + tail
+        if failed_ids:
+            REPORT["new_kernels_failed"] = failed_ids
         assert rc == 0, out[-1500:]
     failed = [_attempt("new_kernels", parity) if _within_budget("new_kernels") else None]
 
