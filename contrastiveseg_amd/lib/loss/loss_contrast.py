@@ -150,7 +150,7 @@ class PixelContrastLoss(nn.Module, ABC):
         P = h * w
         cp = self._mine(feats, labels, predict, seg, seg_ready)
         world = D.get_world_size()
-        if world > 1 and self.cross_rank:
+        if (world > 1 or D.exercise_single_rank()) and self.cross_rank:
             return self._forward_cross_rank(feats, cp, P, world)
         plan = self._plan(_counts_to_host(cp))
         dev = feats.device

@@ -18,6 +18,14 @@ def is_distributed():
     return dist.is_available() and dist.is_initialized()
 
 
+def exercise_single_rank():
+    """CSEG_DIST_SINGLE_RANK=1: take the multi-rank code paths (SyncBN exchange, cross-rank contrast set, all-gather) even in
+    a process group of ONE rank. A 1-GPU box cannot host two RCCL ranks, but it can host one: with this switch every
+    collective of this code runs through RCCL on the device (tools/rccl_single_rank_check.py). Off by default: with one
+    rank the exchanges are identities and only cost launches."""
+    return os.environ.get("CSEG_DIST_SINGLE_RANK") == "1" and is_distributed()
+
+
 def get_world_size():
     return dist.get_world_size() if is_distributed() else 1
 
@@ -107,7 +115,7 @@ def all_gather_cat(t):
     'nccl' backend; on gloo with device tensors (no device all-gather there) each rank fills its own slot of a zero
     buffer and the slots are summed by all-reduce -- same bytes on the wire for the tiny buffers this path moves."""
     world = get_world_size()
-    if world == 1:
+    if world == 1 and not exercise_single_rank():
         return t
     t = t.contiguous()
     if dist.get_backend() == "nccl" or not t.is_cuda:

@@ -388,3 +388,22 @@ def test_contrast_at_the_headline_and_reference_bank_sizes(monkeypatch):
     190 000 columns): bank mode read in place == plain mode on the packed copy == the float64 oracle, gradients included."""
     _replay(monkeypatch, "test_gpu_kernels", "test_contrast_headline_shape_properties", {})
     _replay(monkeypatch, "test_gpu_kernels", "test_contrast_bank_reference_config_size", {})
+
+
+def test_single_rank_process_group_takes_the_multi_rank_paths():
+    """tools/rccl_single_rank_check.py on gloo with the emulated device half: with CSEG_DIST_SINGLE_RANK=1 a process group of
+    one rank goes through the SyncBN exchange and the cross-rank contrast set (collectives counted) and reproduces the local
+    paths. On the GPU box the same script runs on RCCL (tests/test_zz_gpu_default_routes.py)."""
+    import json
+    import subprocess
+    try:
+        build_emu.build()
+    except build_emu.EmuBuildError as e:
+        pytest.skip(str(e))
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_single_rank_check.py"), "--backend", "gloo", "--emu"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-1500:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ok"] and d["syncbn_all_reduces"] == 2 and d["cross_rank_collectives"] >= 2

@@ -206,6 +206,27 @@ def test_row_sparse_embedding_gradient_first_hardware_run(loss_type, monkeypatch
                mark_ok=True)
 
 
+def test_every_collective_through_rccl_with_one_rank():
+    """tools/rccl_single_rank_check.py in a child: a process group of ONE RCCL rank on this GPU with the multi-rank code paths
+    forced on (CSEG_DIST_SINGLE_RANK=1) -- the packed fp64 all-reduces of FusedSyncBatchNorm, the counts / anchor all-gathers
+    of the cross-rank contrast set and DDP's bucket all-reduce run as RCCL operations and must reproduce the local paths
+    (with one rank every exchange is an identity). The builder's boxes have one GPU: this is as close to RCCL as they get."""
+    import json
+    import sys
+    _dev()
+    if not _within_budget("rccl1"):
+        pytest.skip("time budget")
+
+    def body():
+        rc, out = _child([sys.executable, "tools/rccl_single_rank_check.py", "--backend", "nccl"], {}, 180)
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        assert rc == 0 and lines, "rc=%s %s" % (rc, out[-700:])
+        d = json.loads(lines[-1])
+        assert d.get("ok") and d.get("backend") == "nccl"
+        REPORT["rccl1"] = [d["syncbn_all_reduces"], d["cross_rank_collectives"], d["ddp"]]
+    _first_run("rccl1", body)
+
+
 # ---- kernels that have never run on hardware: first run in CHILD processes (a fault or a hang there costs this test, not the
 # session), parity first, then the probes whose timings decide whether they become defaults in round 3 ------------------------
 def _child(cmd, env, timeout):

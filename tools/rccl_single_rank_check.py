@@ -1,0 +1,137 @@
+"""Every collective of this code through the process-group backend with ONE rank on one device.
+
+A 1-GPU box cannot host two RCCL ranks (RCCL refuses the same device twice), but it can host one. With
+CSEG_DIST_SINGLE_RANK=1 the multi-rank code paths are taken in a process group of one rank, so on `--backend nccl` the
+packed fp64 all-reduces of FusedSyncBatchNorm, the counts / anchor all-gathers of the cross-rank contrast set and DDP's
+bucket all-reduce all execute as RCCL operations on the GPU. With one rank every exchange is an identity, so each result
+must equal the local path exactly: that is what is checked. One JSON line.
+
+    python tools/rccl_single_rank_check.py --backend nccl          (GPU box)
+    python tools/rccl_single_rank_check.py --backend gloo --emu    (no GPU: device half = the HIP sources on the emulator)
+"""
+import argparse
+import json
+import os
+import socket
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class _Patch(object):
+    def setattr(self, obj, name, value):
+        setattr(obj, name, value)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--emu", action="store_true")
+    a = ap.parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      CSEG_DIST_SINGLE_RANK="1")
+    if a.emu:
+        from tests.emu import inject
+        inject.install(_Patch())
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+    dist.init_process_group(a.backend, rank=0, world_size=1)
+    from contrastiveseg_amd.lib.utils import distributed as D
+    assert D.exercise_single_rank()
+    out = {"backend": dist.get_backend(), "device": str(dev)}
+    n_coll = {"n": 0}
+    for name in ("all_reduce", "all_gather_into_tensor", "all_gather"):
+        def wrap(fn, name=name):
+            def f(*args, **kw):
+                n_coll["n"] += 1
+                return fn(*args, **kw)
+            return f
+        setattr(dist, name, wrap(getattr(dist, name)))
+
+    # (1) FusedSyncBatchNorm (+ residual + ReLU): statistics and gradient sums through the backend == local BN
+    from contrastiveseg_amd.lib.models.tools.fused_bn import FusedBatchNorm2d, FusedSyncBatchNorm
+    gen = torch.Generator().manual_seed(7)
+    x = (torch.randn(4, 24, 20, 36, generator=gen) * 2 + 1)
+    r = torch.randn(4, 24, 20, 36, generator=gen)
+    g = torch.randn(4, 24, 20, 36, generator=gen)
+    res = []
+    for cls in (FusedSyncBatchNorm, FusedBatchNorm2d):
+        m = cls(24).to(dev).train()
+        with torch.no_grad():
+            m.weight.copy_(torch.linspace(0.5, 1.5, 24))
+            m.bias.copy_(torch.linspace(-1, 1, 24))
+        xd, rd = x.clone().to(dev).requires_grad_(True), r.clone().to(dev).requires_grad_(True)
+        before = n_coll["n"]
+        y = m(xd, residual=rd, relu=True)
+        y.backward(g.to(dev))
+        res.append((y.detach().cpu(), xd.grad.cpu(), rd.grad.cpu(), m.weight.grad.cpu(), m.running_var.cpu(), n_coll["n"] - before))
+    assert res[0][5] == 2 and res[1][5] == 0, (res[0][5], res[1][5])          # one all-reduce per direction vs none
+    for a_, b_ in zip(res[0][:5], res[1][:5]):
+        assert float((a_ - b_).abs().max()) <= 1e-6 * max(1.0, float(b_.abs().max()))
+    out["syncbn_all_reduces"] = res[0][5]
+
+    # (2) cross-rank contrast set with one rank == the per-rank loss on the same batch (global budget, global RNG order)
+    from oracle.make_golden import LOSS_CASES, case_inputs
+    from contrastiveseg_amd.lib.loss.loss_contrast import PixelContrastLoss
+    from contrastiveseg_amd.lib.utils.tools.configer import Configer
+    c = dict(LOSS_CASES["mid_self"])
+    target, seg, embed, _ = case_inputs(c)
+    vals = []
+    for cross in (True, False):
+        k = dict(proj_dim=c["D"], base_temperature=0.07, use_rmi=False, warmup_iters=0)
+        k.update(c["contrast"])
+        k.update(max_samples=256, cross_rank=cross, cross_rank_budget="global", cross_rank_rng="global")
+        crit = PixelContrastLoss(Configer(config_dict={
+            "data": {"num_classes": c["K"]}, "network": {"loss_weights": {"aux_loss": 0.4, "seg_loss": 1.0}}, "contrast": k,
+            "loss": {"loss_type": "contrast_ce_loss", "params": {"ce_ignore_index": -1, "ce_reduction": "elementwise_mean"}}}))
+        e = torch.from_numpy(embed).to(dev).requires_grad_(True)
+        torch.manual_seed(11)
+        before = n_coll["n"]
+        loss = crit(e, torch.from_numpy(target).to(dev), seg=torch.from_numpy(seg).to(dev))
+        loss.backward()
+        vals.append((float(loss.detach()), e.grad.cpu().numpy(), n_coll["n"] - before))
+    assert vals[0][2] >= 2 and vals[1][2] == 0, (vals[0][2], vals[1][2])     # counts + anchors gathered vs nothing
+    assert abs(vals[0][0] - vals[1][0]) <= 1e-6 * abs(vals[1][0]), (vals[0][0], vals[1][0])
+    assert np.allclose(vals[0][1], vals[1][1], rtol=1e-5, atol=1e-9)
+    out["cross_rank_collectives"] = vals[0][2]
+
+    # (3) DDP around a small conv + FusedSyncBN net: the bucket all-reduce through the backend, gradients == no DDP
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 24, 3, padding=1), FusedSyncBatchNorm(24, act='relu'),
+                              torch.nn.Conv2d(24, 5, 1)).to(dev).train()
+    ref = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    xi = torch.randn(2, 3, 16, 24, generator=gen).to(dev)
+
+    def grads(model):
+        for p in model.parameters():
+            p.grad = None
+        model(xi).square().mean().backward()
+        return [p.grad.detach().cpu().clone() for p in model.parameters()]
+    plain = grads(net)
+    net.load_state_dict(ref)
+    if a.emu:                                     # torch's DDP refuses SyncBatchNorm modules on the CPU
+        out["ddp"] = "skipped on cpu"
+    else:
+        ddp = torch.nn.parallel.DistributedDataParallel(net, device_ids=[0], output_device=0, gradient_as_bucket_view=True)
+        got = grads(ddp)
+        for a_, b_ in zip(got, plain):
+            assert float((a_ - b_).abs().max()) <= 1e-6 * max(1.0, float(b_.abs().max()))
+        out["ddp"] = "ok"
+    dist.barrier()
+    dist.destroy_process_group()
+    out["ok"] = True
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
