@@ -14,11 +14,18 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+REPORT = {}          # printed as one line by tests/conftest.py at the end of the session (lands in the driver's log tail)
 
 
 def _dev():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    if "dev" not in REPORT:
+        try:
+            p = torch.cuda.get_device_properties(0)
+            REPORT["dev"] = [p.name[:24], p.multi_processor_count, int(getattr(p, "clock_rate", 0) // 1000)]
+        except Exception:                           # noqa: BLE001 -- informational only
+            pass
     return torch.device("cuda:0")
 
 
@@ -123,8 +130,6 @@ def _head_case(monkeypatch, B, H, W):
 
 
 # ---- first hardware evidence that costs the builder no GPU minutes: these run in the driver's round-end pass, last ----------
-REPORT = {}          # printed as one line by tests/conftest.py at the end of the session (lands in the driver's log tail)
-
 
 OPTIONAL_BUDGET_S = 1000      # optional steps start only while the session is younger than this (driver limit: 1800 s)
 
