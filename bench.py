@@ -439,8 +439,15 @@ def run_guarded(cmd_for_attempt):
     """cmd_for_attempt(i) -> argv. Attempt 0 with the defaults; on a non-zero exit, attempt 1 with SAFE_ROUTES."""
     import subprocess
     env = dict(os.environ, CSEG_BENCH_GUARDED="1")
-    rc = subprocess.call(cmd_for_attempt(0), env=env)
+    first = subprocess.run(cmd_for_attempt(0), env=env, stdout=subprocess.PIPE, text=True)      # stderr passes through
+    sys.stdout.write(first.stdout)
+    sys.stdout.flush()
+    rc = first.returncode
     if rc == 0:
+        return 0
+    if any(l.startswith("{") and '"metric"' in l for l in first.stdout.splitlines()):
+        # the measurement finished and printed its line; only the teardown failed: nothing to repeat
+        sys.stderr.write("bench.py: exit code %d AFTER the result line was printed (teardown); keeping that result\n" % rc)
         return 0
     sys.stderr.write("bench.py: the run with the default routes ended with exit code %d; repeating once with %s\n"
                      % (rc, " ".join("%s=%s" % kv for kv in sorted(SAFE_ROUTES.items()))))

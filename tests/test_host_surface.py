@@ -207,6 +207,12 @@ def test_bench_guard_repeats_once_with_the_hardware_measured_routes(monkeypatch,
     attempts.clear()
     assert bench.run_guarded(lambda a: cmd(a, 0)) == 0
     assert attempts == [0] and "1 None None None" in capfd.readouterr().out
+    # a run that printed its result line and then died in teardown is not repeated
+    attempts.clear()
+    late = "import sys; print('{\"metric\": \"m\", \"value\": 1}'); sys.stdout.flush(); sys.exit(139)"
+    assert bench.run_guarded(lambda a: (attempts.append(a), [sys.executable, "-c", late])[1]) == 0
+    got = capfd.readouterr()
+    assert attempts == [0] and got.out.count('"metric"') == 1 and "teardown" in got.err
     monkeypatch.setenv("CSEG_CONV3X3_SB_WRW", "1")
     assert not bench.guard_enabled()
     monkeypatch.delenv("CSEG_CONV3X3_SB_WRW")
