@@ -48,11 +48,18 @@ namespace {
 // CSEG_CONV3X3_SB_VAR: 0 = the kernel as verified and timed on the MI355X; 1 = buffer-load addressing of the patch (template
 // comment below); 2 = conv3x3_sb16.hip for convolutions with at most 192 output channels (3 channel tiles per block unless
 // the caller asks for 6), everything else as 1. Read per call: tests and probes switch it inside one process.
+// Unset = the per-shape choice measured on the MI355X in the round-2 driver pass (GPUTEST_r02.json, fwd_us): the 16-channel-chunk
+// kernel at 48 / 192 output channels (67-78 vs 95-105 us), buffer-load addressing everywhere else (head 9.8 vs 11.0 ms, 96
+// channels 60 vs 64 us).
 int sb_variant() {
     const char* e = getenv("CSEG_CONV3X3_SB_VAR");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : -1;
 }
-bool use_sb16(int conv_out) { return sb_variant() == 2 && conv_out <= 192 && conv_out % 48 == 0; }
+bool use_sb16(int conv_out) {
+    const int v = sb_variant();
+    if (v == 2) return conv_out <= 192 && conv_out % 48 == 0;
+    return v < 0 && (conv_out == 48 || conv_out == 192);
+}
 
 constexpr int TR = 4;                 // output rows per block (one per wave)
 constexpr int TC = 64;                // output columns per block
@@ -458,7 +465,8 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, int B, in
     // CSEG_CONV3X3_SB_GLDS=0: stage B through registers instead of LDS-DMA
     const char* glds_env = getenv("CSEG_CONV3X3_SB_GLDS");       // read per call: tests switch it inside one process
     const bool glds = !(glds_env && atoi(glds_env) == 0);
-    const int var = sb_variant();                                // tuning variants of the kernel (see the template comment)
+    int var = sb_variant();                                      // tuning variants of the kernel (see the template comment)
+    if (var < 0) var = (long)H * W * 32 * 4 < 2147483647L ? 1 : 0;     // default: buffer-load addressing when the offsets fit
     CSEG_REQUIRE(var == 0 || ((var == 1 || var == 2) && (long)H * W * 32 * 4 < 2147483647L),
                  "conv3x3_sb: unsupported CSEG_CONV3X3_SB_VAR=%d", var);
     if (glds && var >= 1) {

@@ -157,13 +157,14 @@ def _check_bank_unchanged(versions, segment_queue, pixel_queue):
                            "Trainer.train_step does, or pass clones of the queues)")
 
 
-# Row-sparse hand-over of the embedding gradient (opt-in, first hardware run pending): the contrastive term touches
+# Row-sparse hand-over of the embedding gradient (default since round 3: parity "ok" and 166.9 -> 163.3 ms/step in the round-2
+# driver pass, GPUTEST_r02.json; CSEG_SPARSE_EMBED_GRAD=0 restores the dense route): the contrastive term touches
 # <= max_samples pixels of the [B,D,h,w] embedding, so its gradient is N rows and the rest zeros. With the switch on, the
 # projection head (lib/models/modules/projection.py) tags the embedding it returns with a SparseGradSlot; the loss'
 # backward deposits (rows, pixel indices) there and returns a zero tensor WITHOUT storage (stride 0) as the dense
 # gradient, and the head's backward works on the N rows only (no 268 MB memset + scatter, no dense normalise / 1x1
 # backward at bs 8). Any other consumer of the embedding simply adds a real dense gradient, which the head detects.
-SPARSE_EMBED_GRAD = os.environ.get("CSEG_SPARSE_EMBED_GRAD", "0") == "1"
+SPARSE_EMBED_GRAD = os.environ.get("CSEG_SPARSE_EMBED_GRAD", "1") == "1"
 
 
 class SparseGradSlot(object):
@@ -728,7 +729,7 @@ def conv3x3_sb_tiles(x, c_out):
 # every eligible layer (tools/emu_step_golden.py, profiles/r02_emu_step_golden_*.json). CSEG_CONV3X3_SB_WRW=0 restores the
 # fp32-MFMA kernel / MIOpen; CSEG_CONV3X3_SB_WRW_V=2 selects the producer/consumer version (not yet run on hardware).
 CONV3X3_SB_WRW = os.environ.get("CSEG_CONV3X3_SB_WRW", "1") == "1"
-CONV3X3_SB_WRW_CHANNELS = tuple(int(c) for c in os.environ.get("CSEG_CONV3X3_SB_WRW_CHANNELS", "48,96,720").split(","))
+CONV3X3_SB_WRW_CHANNELS = tuple(int(c) for c in os.environ.get("CSEG_CONV3X3_SB_WRW_CHANNELS", "48,96,192,720").split(","))
 
 
 def conv3x3_sb_wrw_eligible(x, dy):
@@ -803,7 +804,7 @@ def conv3x3_split_bf16(x, weight, bias=None):
 # ----------------------------------------------------------------------------------------------------------
 # 1x1 convolution on the BF16 matrix cores with split operands (csrc/conv1x1_sb.hip): first hardware run pending -> opt-in
 # ----------------------------------------------------------------------------------------------------------
-CONV1X1_SPLIT_BF16 = os.environ.get("CSEG_CONV1X1_SPLIT_BF16", "0") == "1"
+CONV1X1_SPLIT_BF16 = os.environ.get("CSEG_CONV1X1_SPLIT_BF16", "1") == "1"
 CONV1X1_SB_MIN_TILES = int(os.environ.get("CSEG_SB_MIN_TILES", "256"))
 
 
@@ -840,12 +841,19 @@ def conv1x1_sb_run(x, weight, transpose=False, bias=None):
     return y
 
 
-CONV1X1_SB_WRW = os.environ.get("CSEG_CONV1X1_SB_WRW", "0") == "1"
+# weight gradient on the split kernel where it won in the round-2 driver pass (720x720: 2.98 vs 5.75 ms, 720x256: 0.96 vs 1.31 ms
+# on MIOpen; the 64 <-> 256 bottleneck convolutions lost: 0.30 vs 0.22 ms) -> both channel counts >= CONV1X1_SB_WRW_MIN_CH
+CONV1X1_SB_WRW = os.environ.get("CSEG_CONV1X1_SB_WRW", "1") == "1"
+CONV1X1_SB_WRW_MIN_CH = int(os.environ.get("CSEG_CONV1X1_SB_WRW_MIN_CH", "256"))
 
 
 def conv1x1_sb_wrw_eligible(x, dy):
     return (_on_device(x) and x.dtype == F32 and dy.dtype == F32 and x.is_contiguous() and dy.is_contiguous()
             and x.shape[1] % 16 == 0 and dy.shape[1] % 16 == 0 and (x.shape[2] * x.shape[3]) % 32 == 0)
+
+
+def conv1x1_sb_wrw_wanted(x, dy):
+    return (CONV1X1_SB_WRW and min(x.shape[1], dy.shape[1]) >= CONV1X1_SB_WRW_MIN_CH and conv1x1_sb_wrw_eligible(x, dy))
 
 
 @torch.no_grad()
@@ -881,7 +889,7 @@ class Conv1x1SplitBF16(Function):
         dx = conv1x1_sb_run(dy, weight, True) if ctx.needs_input_grad[0] else None
         dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if CONV1X1_SB_WRW and conv1x1_sb_wrw_eligible(x, dy):
+        if conv1x1_sb_wrw_wanted(x, dy):
             dw = conv1x1_sb_wrw(x, dy) if ctx.needs_input_grad[1] else None
             db = dy.sum((0, 2, 3)) if want_db else None
         elif ctx.needs_input_grad[1] or want_db:

@@ -77,6 +77,7 @@ def test_conv3x3_function(cpu_entry_points, monkeypatch, bias, sb_wrw, channels)
 @pytest.mark.parametrize("sb_wrw", [False, True])
 def test_conv1x1_function(cpu_entry_points, monkeypatch, bias, sb_wrw):
     monkeypatch.setattr(K, "CONV1X1_SB_WRW", sb_wrw)
+    monkeypatch.setattr(K, "CONV1X1_SB_WRW_MIN_CH", 16)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(2, 48, 4, 8, generator=g)
     w = torch.randn(64, 48, 1, 1, generator=g) / 7

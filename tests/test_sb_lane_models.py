@@ -423,10 +423,11 @@ def test_host_tiling_heuristics():
     assert K.conv3x3_sb_tiles(meta(2, 48, 16, 32), 48) == 2 * 1 * 4 * 1 < K.CONV3X3_SB_MIN_TILES
     assert K.conv1x1_sb_tiles(meta(8, 720, 128, 256), 256) == 8 * 2 * 128
     assert K.conv1x1_sb_tiles(meta(8, 720, 128, 256), 720) == 8 * 5 * 128
-    # defaults: split-bf16 forward / backward-data and the weight gradient (version 1, the channel counts it was timed on)
-    # on; the kernels that have not run on hardware off
+    # defaults (round 3): every split kernel that won its hardware timing in the round-2 driver pass is on
     assert isinstance(K.CONV3X3_SPLIT_BF16, bool) and K.CONV3X3_SB_BRANCH_CHANNELS[:2] == (48, 96)
     import os
     if not any(k.startswith("CSEG_CONV") for k in os.environ):
-        assert K.CONV3X3_SB_WRW and K.CONV3X3_SB_WRW_CHANNELS == (48, 96, 720)
-        assert not K.CONV1X1_SPLIT_BF16 and not K.CONV1X1_SB_WRW and not K.SPARSE_EMBED_GRAD
+        assert K.CONV3X3_SB_WRW and K.CONV3X3_SB_WRW_CHANNELS == (48, 96, 192, 720)
+        assert K.CONV1X1_SPLIT_BF16 and K.CONV1X1_SB_WRW and K.CONV1X1_SB_WRW_MIN_CH == 256
+        if "CSEG_SPARSE_EMBED_GRAD" not in os.environ:
+            assert K.SPARSE_EMBED_GRAD

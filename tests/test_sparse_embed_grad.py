@@ -90,9 +90,9 @@ def test_standin_has_no_storage_and_is_recognised():
     assert r is rows and sel.tolist() == [0, 5, 9] and slot.take() == [] and not slot.is_standin(s)
 
 
-def test_switch_is_off_by_default():
+def test_switch_is_on_by_default():
     import os
-    assert Kn.SPARSE_EMBED_GRAD == (os.environ.get("CSEG_SPARSE_EMBED_GRAD", "0") == "1")
+    assert Kn.SPARSE_EMBED_GRAD == (os.environ.get("CSEG_SPARSE_EMBED_GRAD", "1") == "1")
 
 
 # ---- two ranks (gloo): SyncBN statistics sums of the sparse route are all-reduced, and the cross-rank criterion deposits

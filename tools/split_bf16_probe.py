@@ -25,6 +25,17 @@ def split3(t):
     return hi, mid, lo
 
 
+def split_h2(t):
+    """two fp16 pieces of t * 2^k (k puts max|t| into [2^14, 2^15)): hi = rn16(t s), lo = rn16(t s - hi); -> hi, lo, 1/s"""
+    amax = float(t.abs().max())
+    k = 14 - int(np.floor(np.log2(amax))) if amax > 0 else 0
+    s = 2.0 ** k
+    ts = t * s
+    hi = ts.half().float()
+    lo = (ts - hi).half().float()
+    return hi, lo, 1.0 / s
+
+
 def tf32(t):
     i = t.contiguous().view(torch.int32)
     i = (i + 0x1000) & ~0x1FFF          # round to nearest at 10 explicit mantissa bits
@@ -44,6 +55,14 @@ def conv_forward(self, x, w, b):
         return F.conv2d(a, ww, bias, self.stride, self.padding, self.dilation, self.groups)
     if mode == "tf32":
         return c(tf32(x), tf32(w), b)
+    if mode in ("fp16x3", "fp16x4"):
+        xh, xl, xi = split_h2(x)
+        wh, wl, wi = split_h2(w)
+        out = c(xl, wh) + c(xh, wl)
+        if mode == "fp16x4":
+            out = out + c(xl, wl)
+        out = (out + c(xh, wh)) * (xi * wi)
+        return out if b is None else out + b.view(1, -1, 1, 1)
     xh, xm, xl = split3(x)
     wh, wm, wl = split3(w)
     if mode == "bf16x1":
@@ -68,7 +87,7 @@ def main():
     torch.nn.Conv2d._conv_forward = conv_forward
     outs = {}
     with torch.no_grad():
-        for mode in ("fp32", "tf32", "bf16x1", "bf16x3", "bf16x6"):
+        for mode in ("fp32", "tf32", "bf16x1", "bf16x3", "bf16x6", "fp16x3", "fp16x4"):
             MODE["v"] = mode
             o = net(x, with_embed=True)
             outs[mode] = (o["seg"].double(), o["embed"].double())
