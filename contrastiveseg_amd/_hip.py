@@ -64,6 +64,15 @@ SIGNATURES = {
     "cseg_conv1x1_sb_fwd": (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
     "cseg_conv1x1_sb_wrw_ws_floats": (ctypes.c_size_t, [_c_int] * 4),
     "cseg_conv1x1_sb_wrw": (_c_int, [_ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
+    "cseg_amax_f32": (_c_int, [_ptr, ctypes.c_long, _ptr, _ptr]),
+    "cseg_conv3x3_split_packed_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int]),
+    "cseg_conv3x3_split_pack": (_c_int, [_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
+    "cseg_conv3x3_split_fwd": (_c_int, [_ptr, _ptr, _ptr] + [_c_int] * 7 + [_ptr, _ptr, _ptr, _ptr]),
+    "cseg_conv3x3_split_wrw": (_c_int, [_ptr, _ptr] + [_c_int] * 6 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
+    "cseg_conv1x1_split_packed_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int]),
+    "cseg_conv1x1_split_pack": (_c_int, [_ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
+    "cseg_conv1x1_split_fwd": (_c_int, [_ptr, _ptr, _ptr] + [_c_int] * 5 + [_ptr, _ptr, _ptr, _ptr]),
+    "cseg_conv1x1_split_wrw": (_c_int, [_ptr, _ptr] + [_c_int] * 5 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_augment_batch": (_c_int, [_ptr, _ptr, _ptr, _ptr] + [_c_int] * 5 + [_c_float, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_bn_ws_floats": (ctypes.c_size_t, [_c_int, _c_int, _c_int]),
     "cseg_bn_stats": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),

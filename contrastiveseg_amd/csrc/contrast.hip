@@ -320,6 +320,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ S, i
             float bv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) bv[r] = cw[(8 * (r >> 2) + 4 * h + (r & 3)) * 32 + r32];
+            CSEG_WAVE_LOCKSTEP();                      // the next feature tile's stores must not overtake these reads
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(hv[r], bv[r], acc[t], 0, 0, 0);
         }

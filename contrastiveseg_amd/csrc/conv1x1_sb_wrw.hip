@@ -13,50 +13,35 @@
 // Split-K over (image, 32-pixel stage) units, contiguous range per split; partial [split][co][ci] summed in a fixed
 // order by a second kernel: deterministic.
 // Status: index-checked against a numpy lane model; first hardware run pending -> opt-in (kernels.CONV1X1_SB_WRW).
-#include "cseg_common.h"
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Round 3: default for channel counts >= 256 (720 x 720: 2.98 vs 5.75 ms on MIOpen in the round-2 driver pass); written against
+// the arithmetic traits of cseg_split.h (bf16x6 and f16x3).
+#include "cseg_split.h"
 
 namespace {
 
 constexpr int CO_T = 144, CI_T = 128, STG = 32;      // channel block, pixels per stage
 constexpr int PITCH = 40;                            // bf16 elements per (piece, channel) row: 32 + 8 pad (20 dwords = 4 * odd)
-constexpr int DY_ELEMS = 3 * CO_T * PITCH;           // one dy buffer
-constexpr int X_ELEMS = 3 * CI_T * PITCH;            // one x buffer
+__host__ __device__ constexpr int dy_elems(int np) { return np * CO_T * PITCH; }      // one dy buffer
+__host__ __device__ constexpr int x_elems(int np) { return np * CI_T * PITCH; }       // one x buffer
 constexpr int CH_ALL = CO_T + CI_T;                  // 272 channel rows per stage
-
-__device__ __forceinline__ void split3q(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
-    const __bf16 bh = (__bf16)v;
-    const float r1 = v - (float)bh;
-    const __bf16 bm = (__bf16)r1;
-    const float r2 = r1 - (float)bm;
-    const __bf16 bl = (__bf16)r2;
-    h = __builtin_bit_cast(unsigned short, bh);
-    m = __builtin_bit_cast(unsigned short, bm);
-    l = __builtin_bit_cast(unsigned short, bl);
-}
-
-__device__ __forceinline__ void split4q(const float4& v, uint2& h, uint2& m, uint2& l) {
-    unsigned short hs[4], ms[4], ls[4];
-    split3q(v.x, hs[0], ms[0], ls[0]);
-    split3q(v.y, hs[1], ms[1], ls[1]);
-    split3q(v.z, hs[2], ms[2], ls[2]);
-    split3q(v.w, hs[3], ms[3], ls[3]);
-    h = make_uint2(hs[0] | ((unsigned)hs[1] << 16), hs[2] | ((unsigned)hs[3] << 16));
-    m = make_uint2(ms[0] | ((unsigned)ms[1] << 16), ms[2] | ((unsigned)ms[3] << 16));
-    l = make_uint2(ls[0] | ((unsigned)ls[1] << 16), ls[2] | ((unsigned)ls[3] << 16));
-}
 
 constexpr int LD_ITEMS = CH_ALL * 8;                 // float4 chunks per stage: 272 rows x 8 chunks of 4 pixels
 constexpr int LD_U = (LD_ITEMS + 255) / 256;         // per loader thread (9)
 
+template <class AR>
 __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                 int B, int Cin, int Cout, int plane_i, int n_split,
+                                                                const unsigned* __restrict__ amax_x,
+                                                                const unsigned* __restrict__ amax_dy,
                                                                 float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_q[];
+    constexpr int NP = AR::NP;
+    constexpr int DY_ELEMS = dy_elems(NP), X_ELEMS = x_elems(NP);
+    typedef typename AR::frag_t frag_t;
     unsigned short* ds = smem_q;                       // [2][piece][co 144][PITCH]
     unsigned short* xs = smem_q + 2 * DY_ELEMS;        // [2][piece][ci 128][PITCH]
+    const unsigned ex = AR::SCALED ? split_amax_exp(amax_x) : 141u, ed = AR::SCALED ? split_amax_exp(amax_dy) : 141u;
+    const float xscale = split_scale_of(ex), dscale = split_scale_of(ed);      // 1 for the unscaled arithmetic
     // readfirstlane: the role split below must be a SCALAR branch (the wave index is uniform, which the compiler cannot see)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const bool loader = wave >= 4;
@@ -96,14 +81,13 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
                     const bool is_dy = r < CO_T;
                     const bool ok = is_dy ? cob * CO_T + r < Cout : cib * CI_T + r - CO_T < Cin;
                     const float4 t = ok ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    uint2 h, m, l;
-                    split4q(t, h, m, l);
+                    uint2 cells[NP];
+                    split_cells4<AR>(t, is_dy ? dscale : xscale, cells);
                     unsigned short* base = is_dy ? ds + buf * DY_ELEMS + r * PITCH + 4 * c
                                                  : xs + buf * X_ELEMS + (r - CO_T) * PITCH + 4 * c;
                     const int pstride = is_dy ? CO_T * PITCH : CI_T * PITCH;
-                    *reinterpret_cast<uint2*>(base) = h;
-                    *reinterpret_cast<uint2*>(base + pstride) = m;
-                    *reinterpret_cast<uint2*>(base + 2 * pstride) = l;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(base + q * pstride) = cells[q];
                 }
             }
         };
@@ -135,35 +119,30 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
 #pragma unroll 1
         for (long unit = u_lo; unit < u_hi; ++unit) {
             const int buf = (int)(unit - u_lo) & 1;
-            bf16x8 bf[4][3];
+            frag_t bf[4][NP];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    bf[c][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
+                for (int p = 0; p < NP; ++p)
+                    bf[c][p] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(
                         xs + buf * X_ELEMS + (p * CI_T + (cit0 + c) * 16 + n) * PITCH + 8 * g));
 #pragma unroll
             for (int a = 0; a < 5; ++a) {
                 if (a == 4 && mh) break;               // the upper co half has four tiles
-                bf16x8 af[3];
+                frag_t af[NP];
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    af[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
+                for (int p = 0; p < NP; ++p)
+                    af[p] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(
                         ds + buf * DY_ELEMS + (p * CO_T + (cot0 + a) * 16 + n) * PITCH + 8 * g));
-#define Q_TERM(P, Q)                                                                                      \
-    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                         \
-        acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P], bf[c][Q], acc[a][c], 0, 0, 0);
-                Q_TERM(2, 0)
-                Q_TERM(0, 2)
-                Q_TERM(1, 1)
-                Q_TERM(1, 0)
-                Q_TERM(0, 1)
-                Q_TERM(0, 0)
-#undef Q_TERM
+#pragma unroll
+                for (int t = 0; t < AR::NTERMS; ++t)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[a][c] = AR::mfma(af[AR::ta(t)], bf[c][AR::tb(t)], acc[a][c]);
             }
             __syncthreads();
         }
         // D[m = 4g + r][n]: co = cob*144 + (cot0 + a)*16 + 4g + r, ci = cib*128 + (cit0 + c)*16 + n
+        const float unscale = split_unscale_of(ex) * split_unscale_of(ed);
 #pragma unroll
         for (int a = 0; a < 5; ++a) {
             if (a == 4 && mh) break;
@@ -174,7 +153,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
                 if (ci < Cin) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (co + r < Cout) partial[((size_t)split * Cout + co + r) * Cin + ci] = acc[a][c][r];
+                        if (co + r < Cout) partial[((size_t)split * Cout + co + r) * Cin + ci] = acc[a][c][r] * unscale;
                 }
             }
         }
@@ -213,32 +192,55 @@ extern "C" size_t cseg_conv1x1_sb_wrw_ws_floats(int B, int Cin, int Cout, int HW
     return (size_t)wrw1_splits(B, Cin, Cout, HW) * Cin * Cout;
 }
 
-extern "C" int cseg_conv1x1_sb_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int HW, float* ws, float* dw,
-                                   cseg_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    CSEG_REQUIRE(x && dy && ws && dw, "conv1x1_sb_wrw: null pointer");
-    CSEG_REQUIRE(B > 0 && HW > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0 && HW % STG == 0,
-                 "conv1x1_sb_wrw: unsupported shape B=%d Cin=%d Cout=%d HW=%d (needs channels %% 16, H*W %% 32)", B, Cin, Cout, HW);
-    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0,
-                 "conv1x1_sb_wrw: tensors must be 16-byte aligned");
-    const int n_split = wrw1_splits(B, Cin, Cout, HW);
-    const long blocks = (long)n_split * ((Cin + CI_T - 1) / CI_T) * ((Cout + CO_T - 1) / CO_T);
-    CSEG_REQUIRE(blocks < 2147483647L && (long)Cin * Cout < 2147483647L, "conv1x1_sb_wrw: grid too large");
-    const size_t lds = sizeof(unsigned short) * 2 * (DY_ELEMS + X_ELEMS);
+namespace {
+template <class AR>
+int launch_wrw1(const float* x, const float* dy, int B, int Cin, int Cout, int HW, int n_split, long blocks, const unsigned* amax_x,
+                const unsigned* amax_dy, float* ws, hipStream_t stream) {
+    const size_t lds = sizeof(unsigned short) * 2 * (dy_elems(AR::NP) + x_elems(AR::NP));
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv1x1_sb_wrw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        if (hipFuncSetAttribute((const void*)conv1x1_sb_wrw_kernel<AR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess) {
             cseg_set_error("conv1x1_sb_wrw: cannot raise dynamic LDS to %zu bytes", lds);
             return 0;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv1x1_sb_wrw_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, x, dy, B, Cin, Cout, HW, n_split,
-                       ws);
+    hipLaunchKernelGGL(conv1x1_sb_wrw_kernel<AR>, dim3((unsigned)blocks), dim3(512), lds, stream, x, dy, B, Cin, Cout, HW, n_split,
+                       amax_x, amax_dy, ws);
     CSEG_CHECK_LAUNCH("conv1x1_sb_wrw_kernel");
+    return 1;
+}
+
+int wrw1_impl(const float* x, const float* dy, int B, int Cin, int Cout, int HW, int arith, const unsigned* amax_x,
+              const unsigned* amax_dy, float* ws, float* dw, hipStream_t stream) {
+    CSEG_REQUIRE(x && dy && ws && dw, "conv1x1_sb_wrw: null pointer");
+    CSEG_REQUIRE(B > 0 && HW > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0 && HW % STG == 0,
+                 "conv1x1_sb_wrw: unsupported shape B=%d Cin=%d Cout=%d HW=%d (needs channels %% 16, H*W %% 32)", B, Cin, Cout, HW);
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0,
+                 "conv1x1_sb_wrw: tensors must be 16-byte aligned");
+    CSEG_REQUIRE(arith == CSEG_ARITH_BF16X6 || (arith == CSEG_ARITH_F16X3 && amax_x && amax_dy),
+                 "conv1x1 split wrw: arithmetic %d needs max|x| and max|dy|", arith);
+    const int n_split = wrw1_splits(B, Cin, Cout, HW);
+    const long blocks = (long)n_split * ((Cin + CI_T - 1) / CI_T) * ((Cout + CO_T - 1) / CO_T);
+    CSEG_REQUIRE(blocks < 2147483647L && (long)Cin * Cout < 2147483647L, "conv1x1_sb_wrw: grid too large");
+    const int ok = arith == CSEG_ARITH_F16X3
+                       ? launch_wrw1<SplitF16x3>(x, dy, B, Cin, Cout, HW, n_split, blocks, amax_x, amax_dy, ws, stream)
+                       : launch_wrw1<SplitBF16x6>(x, dy, B, Cin, Cout, HW, n_split, blocks, amax_x, amax_dy, ws, stream);
+    if (!ok) return 0;
     const int total = Cin * Cout;
     hipLaunchKernelGGL(sb_wrw1_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, ws, n_split, total, dw);
     CSEG_CHECK_LAUNCH("sb_wrw1_reduce_kernel");
     return 1;
+}
+}  // namespace
+
+extern "C" int cseg_conv1x1_sb_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int HW, float* ws, float* dw,
+                                   cseg_stream_t stream_) {
+    return wrw1_impl(x, dy, B, Cin, Cout, HW, CSEG_ARITH_BF16X6, nullptr, nullptr, ws, dw, (hipStream_t)stream_);
+}
+
+extern "C" int cseg_conv1x1_split_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int HW, int arith,
+                                      const unsigned* amax_x, const unsigned* amax_dy, float* ws, float* dw, cseg_stream_t stream_) {
+    return wrw1_impl(x, dy, B, Cin, Cout, HW, arith, amax_x, amax_dy, ws, dw, (hipStream_t)stream_);
 }

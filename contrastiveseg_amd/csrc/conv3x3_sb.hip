@@ -29,18 +29,20 @@
 // 10.97 ms forward / 10.93 ms backward-data incl. weight packing = 223 TFLOP/s fp32-equivalent (0.53 of 417) vs MIOpen's
 // fp32 kernel 19.81 ms (123.5 TFLOP/s); 96 ch 70 vs 101 us; 48 ch 99 vs 106 us (fp32-MFMA kernel) / 141 us (MIOpen).
 // Switch: kernels.CONV3X3_SPLIT_BF16 (env CSEG_CONV3X3_SPLIT_BF16, default 1; 0 = the fp32 MFMA / MIOpen path).
-#include "cseg_common.h"
+// Round 3: the kernel is written against the arithmetic traits of cseg_split.h and instantiated for both forms -- bf16x6 (above)
+// and f16x3 (two scaled fp16 pieces, three MFMAs per product, roof 2500 / 3 = 833 TFLOP/s of fp32-equivalent work). The f16x3
+// form needs max|x| and max|w| (device pointers, bit patterns; cseg_amax_f32): the patch is scaled while it is split, the weights
+// while they are packed, and the epilogue multiplies the accumulators by the inverse power of two.
+#include "cseg_split.h"
 #include <stdlib.h>
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // conv3x3_sb16.hip: the small-channel variant (16-channel chunks, two blocks per CU), reached under CSEG_CONV3X3_SB_VAR=2
 namespace cseg_sb16 {
-size_t packed_bytes(int Cin, int Cout);
-int pack(const float* w, int Cout, int Cin, int transpose_flip, int NT, void* wp, hipStream_t stream);
-int fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int NT, float* y,
-        hipStream_t stream);
+size_t packed_bytes(int arith, int Cin, int Cout);
+int pack(const float* w, int Cout, int Cin, int transpose_flip, int NT, int arith, const unsigned* amax_w, void* wp,
+         hipStream_t stream);
+int fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int NT, int arith,
+        const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream);
 }  // namespace cseg_sb16
 
 namespace {
@@ -66,40 +68,18 @@ constexpr int TC = 64;                // output columns per block
 constexpr int XROWS = TR + 2;
 constexpr int XCOLS = TC + 2;         // cell 0 = column x0 - 1
 constexpr int CELLS = XROWS * XCOLS;  // 396 pixels per (piece, octet)
-constexpr int A_CELLS = 3 * 4 * CELLS;
 constexpr int A_ITEMS = 4 * CELLS;    // (octet, pixel) staging items of a 32-channel chunk
 constexpr int AU = (A_ITEMS + 511) / 512;     // staging items per thread (512 threads)
 
 __host__ __device__ constexpr int steps_of(int Cin) { return (Cin / 32) * 9 + ((Cin & 31) ? 5 : 0); }
 
-__device__ __forceinline__ void split3(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
-    const __bf16 bh = (__bf16)v;
-    const float r1 = v - (float)bh;            // exact
-    const __bf16 bm = (__bf16)r1;
-    const float r2 = r1 - (float)bm;           // exact
-    const __bf16 bl = (__bf16)r2;
-    h = __builtin_bit_cast(unsigned short, bh);
-    m = __builtin_bit_cast(unsigned short, bm);
-    l = __builtin_bit_cast(unsigned short, bl);
-}
-
-__device__ __forceinline__ void split8(const float (&v)[8], uint4& h, uint4& m, uint4& l) {
-    unsigned short hs[8], ms[8], ls[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) split3(v[j], hs[j], ms[j], ls[j]);
-    h = make_uint4(hs[0] | ((unsigned)hs[1] << 16), hs[2] | ((unsigned)hs[3] << 16), hs[4] | ((unsigned)hs[5] << 16),
-                   hs[6] | ((unsigned)hs[7] << 16));
-    m = make_uint4(ms[0] | ((unsigned)ms[1] << 16), ms[2] | ((unsigned)ms[3] << 16), ms[4] | ((unsigned)ms[5] << 16),
-                   ms[6] | ((unsigned)ms[7] << 16));
-    l = make_uint4(ls[0] | ((unsigned)ls[1] << 16), ls[2] | ((unsigned)ls[3] << 16), ls[4] | ((unsigned)ls[5] << 16),
-                   ls[6] | ((unsigned)ls[7] << 16));
-}
-
 // Packed weights: Wp[co_tile][kstep][nt][piece][lane] of uint4 (8 bf16, element j), lane = 16*g + n:
 //   full K-step (chunk c, tap t):  value(co = (co_tile*NT + nt)*16 + n, ci = 32c + 8g + j, tap t)
 //   tail K-step q (last 16 channels): ci = 32*n_full + 8*(g&1) + j, tap = 2q + (g>>1)   (zero when tap > 8)
+template <class AR>
 __global__ __launch_bounds__(256) void pack_weights_sb_kernel(const float* __restrict__ w, int Cout, int Cin,
-                                                              int transpose_flip, int NT, uint4* __restrict__ wp, int total) {
+                                                              int transpose_flip, int NT, const unsigned* __restrict__ amax_w,
+                                                              uint4* __restrict__ wp, int total) {
     const int e = blockIdx.x * 256 + threadIdx.x;          // one thread per (co_tile, kstep, nt, lane)
     if (e >= total) return;
     const int conv_in = transpose_flip ? Cout : Cin;
@@ -125,41 +105,35 @@ __global__ __launch_bounds__(256) void pack_weights_sb_kernel(const float* __res
         }
         v[j] = t;
     }
-    uint4 h, m, l;
-    split8(v, h, m, l);
-    uint4* dst = wp + (((size_t)(co_tile * n_steps + ks) * NT + nt) * 3) * 64 + lane;
-    dst[0] = h; dst[64] = m; dst[128] = l;
+    uint4 cells[AR::NP];
+    split_cells8<AR>(v, AR::SCALED ? split_scale_of(split_amax_exp(amax_w)) : 1.f, cells);
+    uint4* dst = wp + (((size_t)(co_tile * n_steps + ks) * NT + nt) * AR::NP) * 64 + lane;
+#pragma unroll
+    for (int p = 0; p < AR::NP; ++p) dst[64 * p] = cells[p];
 }
 
 // One K-step of a wave: 4 pixel tiles x NTW channel tiles x 6 piece products. `ap` = this lane's cell in the hi-piece
 // image (octet, row, tap and column already applied), `bp` = this lane's slot in the staged B step.
-template <int NTW, int NTMAX>
+template <class AR, int NTW, int NTMAX>
 __device__ __forceinline__ void sb_kstep(const uint4* __restrict__ ap, const uint4* __restrict__ bp,
                                          f32x4 (&acc)[4][NTMAX]) {
-    bf16x8 a[4][3];
+    typedef typename AR::frag_t frag_t;
+    frag_t a[4][AR::NP];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            a[mt][p] = __builtin_bit_cast(bf16x8, ap[p * 4 * CELLS + 16 * mt]);
-        }
+        for (int p = 0; p < AR::NP; ++p) a[mt][p] = __builtin_bit_cast(frag_t, ap[p * 4 * CELLS + 16 * mt]);
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-        const bf16x8 b0 = __builtin_bit_cast(bf16x8, bp[(nt * 3 + 0) * 64]);
-        const bf16x8 b1 = __builtin_bit_cast(bf16x8, bp[(nt * 3 + 1) * 64]);
-        const bf16x8 b2 = __builtin_bit_cast(bf16x8, bp[(nt * 3 + 2) * 64]);
+        frag_t b[AR::NP];
+#pragma unroll
+        for (int p = 0; p < AR::NP; ++p) b[p] = __builtin_bit_cast(frag_t, bp[(nt * AR::NP + p) * 64]);
         // term-major, smallest terms first: the four pixel tiles between two MFMAs on the same accumulator hide the
         // dependent-accumulator latency
-#define SB_TERM(P, Q)                                                                                     \
-    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                      \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][P], Q, acc[mt][nt], 0, 0, 0);
-        SB_TERM(2, b0)
-        SB_TERM(0, b2)
-        SB_TERM(1, b1)
-        SB_TERM(1, b0)
-        SB_TERM(0, b1)
-        SB_TERM(0, b0)
-#undef SB_TERM
+#pragma unroll
+        for (int t = 0; t < AR::NTERMS; ++t)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = AR::mfma(a[mt][AR::ta(t)], b[AR::tb(t)], acc[mt][nt]);
     }
 }
 
@@ -167,7 +141,7 @@ __device__ __forceinline__ void sb_kstep(const uint4* __restrict__ ap, const uin
 template <int NTW, int NTMAX>
 __device__ __forceinline__ void sb_store(const f32x4 (&acc)[4][NTMAX], float* __restrict__ ybc,
                                          const float* __restrict__ bias, int co0, size_t plane, int yy, int x0, int W,
-                                         int g, int n) {
+                                         int g, int n, float unscale) {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         float* orow = ybc + (size_t)(co0 + nt * 16 + n) * plane + (size_t)yy * W;
@@ -175,7 +149,7 @@ __device__ __forceinline__ void sb_store(const f32x4 (&acc)[4][NTMAX], float* __
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int xx = x0 + 16 * mt + 4 * g;
-            f32x4 v = acc[mt][nt];
+            f32x4 v = acc[mt][nt] * unscale;
             v += bv;
             if (xx + 3 < W) *reinterpret_cast<float4*>(orow + xx) = make_float4(v[0], v[1], v[2], v[3]);
             else {
@@ -197,14 +171,20 @@ __device__ __forceinline__ void sb_store(const f32x4 (&acc)[4][NTMAX], float* __
 //          64 VGPRs for addresses alone, the kernel sits at the 256-register limit with 26 spilled VGPRs, and every chunk
 //          starts with 13 serialized scratch reloads (hipcc -S: "Folded Reload" under .LBB1_23) while both waves of a SIMD
 //          wait. Index-identical to VAR 0 (same elements, same order); first hardware run pending -> CSEG_CONV3X3_SB_VAR=1.
-template <int NT, bool GLDS, int VAR = 0>
+template <class AR, int NT, bool GLDS, int VAR = 0>
 __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                             const float* __restrict__ bias, int Cin, int Cout, int H,
-                                                            int W, int tiles_x, int tiles_y, float* __restrict__ y) {
+                                                            int W, int tiles_x, int tiles_y,
+                                                            const unsigned* __restrict__ amax_x,
+                                                            const unsigned* __restrict__ amax_w, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_sb[];
-    uint4* As = smem_sb;                           // [piece 3][octet 4][CELLS]
-    uint4* Bs = smem_sb + A_CELLS;                 // [2][NT*3*64]
-    constexpr int BSTEP = NT * 3 * 64;             // uint4 per K-step
+    constexpr int NP = AR::NP;
+    constexpr int A_CELLS = NP * 4 * CELLS;
+    uint4* As = smem_sb;                           // [piece NP][octet 4][CELLS]
+    uint4* Bs = smem_sb + A_CELLS;                 // [2][NT*NP*64]
+    constexpr int BSTEP = NT * NP * 64;            // uint4 per K-step
+    const unsigned ex = AR::SCALED ? split_amax_exp(amax_x) : 141u, ew = AR::SCALED ? split_amax_exp(amax_w) : 141u;
+    const float xscale = split_scale_of(ex);       // 1 for the unscaled arithmetic
     constexpr int BU = (BSTEP + 511) / 512;
     constexpr int NT0 = (NT + 1) / 2, NT1 = NT - NT0;
 
@@ -245,9 +225,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
     // is clamped into the tensor and the value masked
     auto b_glds = [&](int ks, int buf) {
 #pragma unroll
-        for (int i = 0; i < (NT * 3 + 7) / 8; ++i) {
+        for (int i = 0; i < (NT * NP + 7) / 8; ++i) {
             const int r = wave + 8 * i;                  // one 1 KB row (channel tile, piece) per wave instruction
-            if (r < NT * 3)
+            if (r < NT * NP)
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void*)(wbase + (size_t)ks * BSTEP + r * 64 + lane),
                     (__attribute__((address_space(3))) void*)(Bs + buf * BSTEP + r * 64), 16, 0, 0);
@@ -301,12 +281,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = ok ? apre[u][j] : 0.f;       // zero padding / outside the tensor
-                uint4 h, m, l;
-                split8(v, h, m, l);
+                uint4 cells[NP];
+                split_cells8<AR>(v, xscale, cells);
                 const int item = oct * CELLS + rc;
-                As[item] = h;
-                As[4 * CELLS + item] = m;
-                As[8 * CELLS + item] = l;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) As[p * 4 * CELLS + item] = cells[p];
             }
         }
     };
@@ -325,7 +304,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
     __syncthreads();
 
     const uint4* a_lane = As + row * XCOLS + n;                        // + octet / tap offset per K-step
-    const uint4* b_lane = Bs + (half ? NT0 * 3 * 64 : 0) + lane;       // + buffer offset per K-step
+    const uint4* b_lane = Bs + (half ? NT0 * NP * 64 : 0) + lane;      // + buffer offset per K-step
     int ks = 0, buf = 0;
     for (int c = 0; c < n_chunks; ++c) {
         const bool full = c < n_full;
@@ -349,8 +328,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
                 const int ky = tap / 3, kx = tap - 3 * ky;
                 a_off = (g & 1) * CELLS + ky * XCOLS + kx;
             }
-            if (half == 0) sb_kstep<NT0, NT0>(a_lane + a_off, b_lane + buf * BSTEP, acc);
-            else if (NT1 > 0) sb_kstep<NT1, NT0>(a_lane + a_off, b_lane + buf * BSTEP, acc);
+            if (half == 0) sb_kstep<AR, NT0, NT0>(a_lane + a_off, b_lane + buf * BSTEP, acc);
+            else if (NT1 > 0) sb_kstep<AR, NT1, NT0>(a_lane + a_off, b_lane + buf * BSTEP, acc);
             if (more && !GLDS) b_store(buf ^ 1);
             if (s == steps - 1 && c + 1 < n_chunks) {
                 __syncthreads();                    // every wave is done with this chunk's patch
@@ -366,8 +345,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
     if (yy < H) {
         float* ybc = y + (size_t)b * Cout * plane;
         const int co0 = cot * NT * 16;
-        if (half == 0) sb_store<NT0, NT0>(acc, ybc, bias, co0, plane, yy, x0, W, g, n);
-        else if (NT1 > 0) sb_store<NT1, NT0>(acc, ybc, bias, co0 + NT0 * 16, plane, yy, x0, W, g, n);
+        const float unscale = split_unscale_of(ex) * split_unscale_of(ew);
+        if (half == 0) sb_store<NT0, NT0>(acc, ybc, bias, co0, plane, yy, x0, W, g, n, unscale);
+        else if (NT1 > 0) sb_store<NT1, NT0>(acc, ybc, bias, co0 + NT0 * 16, plane, yy, x0, W, g, n, unscale);
     }
 }
 
@@ -384,13 +364,13 @@ int pick_nt(int Cout) {
     return 0;
 }
 
-template <int NT, bool GLDS, int VAR = 0>
-int launch_sb(const float* x, const uint4* wp, const float* bias, int B, int Cin, int Cout, int H, int W, float* y,
-              hipStream_t stream) {
-    const size_t lds = sizeof(uint4) * (A_CELLS + 2 * NT * 3 * 64);
+template <class AR, int NT, bool GLDS, int VAR = 0>
+int launch_sb(const float* x, const uint4* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
+              const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream) {
+    const size_t lds = sizeof(uint4) * (AR::NP * 4 * CELLS + 2 * NT * AR::NP * 64);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_sb_kernel<NT, GLDS, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        if (hipFuncSetAttribute((const void*)conv3x3_sb_kernel<AR, NT, GLDS, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess) {
             cseg_set_error("conv3x3_sb: cannot raise dynamic LDS to %zu bytes", lds);
             return 0;
@@ -400,8 +380,8 @@ int launch_sb(const float* x, const uint4* wp, const float* bias, int B, int Cin
     const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
     const long n_tiles = (long)B * (Cout / (NT * 16)) * tiles_y * tiles_x;
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb: grid too large");
-    hipLaunchKernelGGL((conv3x3_sb_kernel<NT, GLDS, VAR>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, Cin, Cout, H, W, tiles_x,
-                       tiles_y, y);
+    hipLaunchKernelGGL((conv3x3_sb_kernel<AR, NT, GLDS, VAR>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, Cin, Cout, H, W, tiles_x,
+                       tiles_y, amax_x, amax_w, y);
     CSEG_CHECK_LAUNCH("conv3x3_sb_kernel");
     return 1;
 }
@@ -410,34 +390,46 @@ int launch_sb(const float* x, const uint4* wp, const float* bias, int B, int Cin
 
 namespace {
 bool nt_ok(int nt, int Cout) { return (nt == 3 || nt == 6 || nt == 9) && Cout % (nt * 16) == 0; }
+bool arith_ok(int arith) { return arith == CSEG_ARITH_BF16X6 || arith == CSEG_ARITH_F16X3; }
+int np_of(int arith) { return arith == CSEG_ARITH_F16X3 ? 2 : 3; }
 }  // namespace
 
-extern "C" size_t cseg_conv3x3_sb_packed_bytes(int Cin, int Cout) {
-    if (Cin <= 0 || Cout <= 0 || Cin % 16 || pick_nt(Cout) == 0) return 0;
-    if (use_sb16(Cout)) return cseg_sb16::packed_bytes(Cin, Cout);
-    return (size_t)(Cout / 16) * steps_of(Cin) * 3 * 64 * sizeof(uint4);
+extern "C" size_t cseg_conv3x3_split_packed_bytes(int arith, int Cin, int Cout) {
+    if (!arith_ok(arith) || Cin <= 0 || Cout <= 0 || Cin % 16 || pick_nt(Cout) == 0) return 0;
+    if (use_sb16(Cout)) return cseg_sb16::packed_bytes(arith, Cin, Cout);
+    return (size_t)(Cout / 16) * steps_of(Cin) * np_of(arith) * 64 * sizeof(uint4);
 }
 
-static int pack_impl(const float* w, int Cout, int Cin, int transpose_flip, int NT, void* wp, hipStream_t stream) {
+extern "C" size_t cseg_conv3x3_sb_packed_bytes(int Cin, int Cout) {
+    return cseg_conv3x3_split_packed_bytes(CSEG_ARITH_BF16X6, Cin, Cout);
+}
+
+static int pack_impl(const float* w, int Cout, int Cin, int transpose_flip, int NT, int arith, const unsigned* amax_w, void* wp,
+                     hipStream_t stream) {
     // transpose_flip: w is still the forward's [Cout, Cin, 3, 3]; the packed operator maps Cout -> Cin channels
     const int conv_in = transpose_flip ? Cout : Cin, conv_out = transpose_flip ? Cin : Cout;
     CSEG_REQUIRE(w && wp, "conv3x3_sb_pack_weights: null pointer");
-    if (use_sb16(conv_out)) return cseg_sb16::pack(w, Cout, Cin, transpose_flip, NT == 6 ? 6 : 3, wp, stream);
+    CSEG_REQUIRE(arith_ok(arith) && (arith == CSEG_ARITH_BF16X6 || amax_w), "conv3x3 split pack: arithmetic %d needs max|w|", arith);
+    if (use_sb16(conv_out)) return cseg_sb16::pack(w, Cout, Cin, transpose_flip, NT == 6 ? 6 : 3, arith, amax_w, wp, stream);
     if (NT == 0) NT = pick_nt(conv_out);
     CSEG_REQUIRE(conv_in % 16 == 0 && NT > 0 && nt_ok(NT, conv_out),
                  "conv3x3_sb: needs input channels %% 16 == 0 and output channels %% 48 == 0 (got %d -> %d)", conv_in, conv_out);
     CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0, "conv3x3_sb_pack_weights: packed buffer must be 16-byte aligned");
     const long total = (long)(conv_out / 16) * steps_of(conv_in) * 64;
     CSEG_REQUIRE(total < 2147483647L, "conv3x3_sb_pack_weights: too large");
-    hipLaunchKernelGGL(pack_weights_sb_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, Cout, Cin,
-                       transpose_flip, NT, (uint4*)wp, (int)total);
+    if (arith == CSEG_ARITH_F16X3)
+        hipLaunchKernelGGL(pack_weights_sb_kernel<SplitF16x3>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, Cout, Cin,
+                           transpose_flip, NT, amax_w, (uint4*)wp, (int)total);
+    else
+        hipLaunchKernelGGL(pack_weights_sb_kernel<SplitBF16x6>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, Cout, Cin,
+                           transpose_flip, NT, amax_w, (uint4*)wp, (int)total);
     CSEG_CHECK_LAUNCH("conv3x3_sb_pack_weights");
     return 1;
 }
 
 extern "C" int cseg_conv3x3_sb_pack_weights(const float* w, int Cout, int Cin, int transpose_flip, void* wp,
                                             cseg_stream_t stream_) {
-    return pack_impl(w, Cout, Cin, transpose_flip, 0, wp, (hipStream_t)stream_);
+    return pack_impl(w, Cout, Cin, transpose_flip, 0, CSEG_ARITH_BF16X6, nullptr, wp, (hipStream_t)stream_);
 }
 
 // explicit channel tiles per block (3, 6 or 9; must divide conv_out / 16): lets the caller trade the block's reuse of the
@@ -445,16 +437,25 @@ extern "C" int cseg_conv3x3_sb_pack_weights(const float* w, int Cout, int Cin, i
 extern "C" int cseg_conv3x3_sb_pack_weights_nt(const float* w, int Cout, int Cin, int transpose_flip, int nt, void* wp,
                                                cseg_stream_t stream_) {
     CSEG_REQUIRE(nt == 3 || nt == 6 || nt == 9, "conv3x3_sb_pack_weights_nt: nt must be 3, 6 or 9 (got %d)", nt);
-    return pack_impl(w, Cout, Cin, transpose_flip, nt, wp, (hipStream_t)stream_);
+    return pack_impl(w, Cout, Cin, transpose_flip, nt, CSEG_ARITH_BF16X6, nullptr, wp, (hipStream_t)stream_);
 }
 
-static int fwd_impl(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int NT,
-                    float* y, hipStream_t stream) {
+// nt = 0: the library's channel tiling. arith: CSEG_ARITH_BF16X6 (amax_w may be null) | CSEG_ARITH_F16X3 (amax_w = max|w| bits)
+extern "C" int cseg_conv3x3_split_pack(const float* w, int Cout, int Cin, int transpose_flip, int nt, int arith,
+                                       const unsigned* amax_w, void* wp, cseg_stream_t stream_) {
+    CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9, "conv3x3_split_pack: nt must be 0, 3, 6 or 9 (got %d)", nt);
+    return pack_impl(w, Cout, Cin, transpose_flip, nt, arith, amax_w, wp, (hipStream_t)stream_);
+}
+
+static int fwd_impl(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int NT, int arith,
+                    const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream) {
     CSEG_REQUIRE(x && wp && y, "conv3x3_sb: null pointer");
+    CSEG_REQUIRE(arith_ok(arith) && (arith == CSEG_ARITH_BF16X6 || (amax_x && amax_w)),
+                 "conv3x3 split: arithmetic %d needs max|x| and max|w|", arith);
     if (use_sb16(Cout)) {
         CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && W % 4 == 0,
                      "conv3x3_sb: packed weights / output must be 16-byte aligned and W a multiple of 4");
-        return cseg_sb16::fwd(x, wp, bias, B, Cin, Cout, H, W, NT == 6 ? 6 : 3, y, stream);
+        return cseg_sb16::fwd(x, wp, bias, B, Cin, Cout, H, W, NT == 6 ? 6 : 3, arith, amax_x, amax_w, y, stream);
     }
     if (NT == 0) NT = pick_nt(Cout);
     CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && NT > 0 && nt_ok(NT, Cout),
@@ -469,34 +470,67 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, int B, in
     if (var < 0) var = (long)H * W * 32 * 4 < 2147483647L ? 1 : 0;     // default: buffer-load addressing when the offsets fit
     CSEG_REQUIRE(var == 0 || ((var == 1 || var == 2) && (long)H * W * 32 * 4 < 2147483647L),
                  "conv3x3_sb: unsupported CSEG_CONV3X3_SB_VAR=%d", var);
-    if (glds && var >= 1) {
-        switch (NT) {
-            case 9: return launch_sb<9, true, 1>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
-            case 6: return launch_sb<6, true, 1>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
-            default: return launch_sb<3, true, 1>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
-        }
+#define SB_LAUNCH(AR, G, V)                                                                                            \
+    switch (NT) {                                                                                                      \
+        case 9: return launch_sb<AR, 9, G, V>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);             \
+        case 6: return launch_sb<AR, 6, G, V>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);             \
+        default: return launch_sb<AR, 3, G, V>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);            \
     }
-    if (glds) {
-        switch (NT) {
-            case 9: return launch_sb<9, true>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
-            case 6: return launch_sb<6, true>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
-            default: return launch_sb<3, true>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
-        }
+    if (arith == CSEG_ARITH_F16X3) {
+        // one form only: LDS-DMA for the weights, buffer-load addressing of the patch when the offsets fit 32 bits
+        if (var >= 1) { SB_LAUNCH(SplitF16x3, true, 1) }
+        SB_LAUNCH(SplitF16x3, true, 0)
     }
-    switch (NT) {
-        case 9: return launch_sb<9, false>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
-        case 6: return launch_sb<6, false>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
-        default: return launch_sb<3, false>(x, wq, bias, B, Cin, Cout, H, W, y, stream);
-    }
+    if (glds && var >= 1) { SB_LAUNCH(SplitBF16x6, true, 1) }
+    if (glds) { SB_LAUNCH(SplitBF16x6, true, 0) }
+    SB_LAUNCH(SplitBF16x6, false, 0)
+#undef SB_LAUNCH
 }
 
 extern "C" int cseg_conv3x3_sb_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H,
                                    int W, float* y, cseg_stream_t stream_) {
-    return fwd_impl(x, wp, bias, B, Cin, Cout, H, W, 0, y, (hipStream_t)stream_);
+    return fwd_impl(x, wp, bias, B, Cin, Cout, H, W, 0, CSEG_ARITH_BF16X6, nullptr, nullptr, y, (hipStream_t)stream_);
 }
 
 extern "C" int cseg_conv3x3_sb_fwd_nt(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H,
                                       int W, int nt, float* y, cseg_stream_t stream_) {
     CSEG_REQUIRE(nt == 3 || nt == 6 || nt == 9, "conv3x3_sb_fwd_nt: nt must be 3, 6 or 9 (got %d)", nt);
-    return fwd_impl(x, wp, bias, B, Cin, Cout, H, W, nt, y, (hipStream_t)stream_);
+    return fwd_impl(x, wp, bias, B, Cin, Cout, H, W, nt, CSEG_ARITH_BF16X6, nullptr, nullptr, y, (hipStream_t)stream_);
+}
+
+extern "C" int cseg_conv3x3_split_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
+                                      int nt, int arith, const unsigned* amax_x, const unsigned* amax_w, float* y,
+                                      cseg_stream_t stream_) {
+    CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9, "conv3x3_split_fwd: nt must be 0, 3, 6 or 9 (got %d)", nt);
+    return fwd_impl(x, wp, bias, B, Cin, Cout, H, W, nt, arith, amax_x, amax_w, y, (hipStream_t)stream_);
+}
+
+// ---- max|x| of a tensor, accumulated into *amax_bits (bit pattern of a non-negative float; the caller zeroes it) ------------
+namespace {
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ amax_bits) {
+    __shared__ unsigned red[4];
+    const long n4 = n >> 2;
+    unsigned m = 0;
+    const uint4* x4 = reinterpret_cast<const uint4*>(x);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const uint4 v = x4[i];
+        m = max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, reinterpret_cast<const unsigned*>(x)[(n4 << 2) + threadIdx.x] & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax_bits, max(max(red[0], red[1]), max(red[2], red[3])));
+}
+}  // namespace
+
+extern "C" int cseg_amax_f32(const float* x, long n, unsigned* amax_bits, cseg_stream_t stream_) {
+    CSEG_REQUIRE(x && amax_bits && n > 0, "amax: null pointer / empty tensor");
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "amax: tensor must be 16-byte aligned");
+    long blocks = ((n >> 2) + 256 * 8 - 1) / (256 * 8);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, x, n, amax_bits);
+    CSEG_CHECK_LAUNCH("amax_kernel");
+    return 1;
 }

@@ -11,11 +11,9 @@
 // of 14 at 48 channels). Packing, fragment layout, B streaming (LDS-DMA, double-buffered) and the epilogue are the same.
 // Entry points: the cseg_conv3x3_sb_* family dispatches here when CSEG_CONV3X3_SB_VAR=2 (packing and forward must run under
 // the same setting; kernels.conv3x3_sb_run does both back to back).
-#include "cseg_common.h"
+// Round 3: default for 48 / 192 output channels; written against the arithmetic traits of cseg_split.h (bf16x6 and f16x3).
+#include "cseg_split.h"
 #include <stdlib.h>
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -25,40 +23,18 @@ constexpr int XROWS = TR + 2;
 constexpr int XCOLS = TC + 2;         // cell 0 = column x0 - 1
 constexpr int CELLS = XROWS * XCOLS;  // 396 pixels per (piece, octet)
 constexpr int NOCT = 2;               // channel octets per chunk
-constexpr int A_CELLS = 3 * NOCT * CELLS;
 constexpr int A_ITEMS = NOCT * CELLS; // (octet, pixel) staging items of a 16-channel chunk
 constexpr int AU = (A_ITEMS + 511) / 512;     // staging items per thread (512 threads): 2
 constexpr int STEPS = 5;              // K-steps per chunk: taps (0,1) (2,3) (4,5) (6,7) (8,-)
 
 __host__ __device__ constexpr int steps16(int Cin) { return (Cin / 16) * STEPS; }
 
-__device__ __forceinline__ void split3(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
-    const __bf16 bh = (__bf16)v;
-    const float r1 = v - (float)bh;            // exact
-    const __bf16 bm = (__bf16)r1;
-    const float r2 = r1 - (float)bm;           // exact
-    const __bf16 bl = (__bf16)r2;
-    h = __builtin_bit_cast(unsigned short, bh);
-    m = __builtin_bit_cast(unsigned short, bm);
-    l = __builtin_bit_cast(unsigned short, bl);
-}
-
-__device__ __forceinline__ void split8(const float (&v)[8], uint4& h, uint4& m, uint4& l) {
-    unsigned short hs[8], ms[8], ls[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) split3(v[j], hs[j], ms[j], ls[j]);
-    h = make_uint4(hs[0] | ((unsigned)hs[1] << 16), hs[2] | ((unsigned)hs[3] << 16), hs[4] | ((unsigned)hs[5] << 16),
-                   hs[6] | ((unsigned)hs[7] << 16));
-    m = make_uint4(ms[0] | ((unsigned)ms[1] << 16), ms[2] | ((unsigned)ms[3] << 16), ms[4] | ((unsigned)ms[5] << 16),
-                   ms[6] | ((unsigned)ms[7] << 16));
-    l = make_uint4(ls[0] | ((unsigned)ls[1] << 16), ls[2] | ((unsigned)ls[3] << 16), ls[4] | ((unsigned)ls[5] << 16),
-                   ls[6] | ((unsigned)ls[7] << 16));
-}
-
 // Packed weights: Wp[co_tile][kstep][nt][piece][lane] of uint4 (8 bf16, element j), lane = 16*g + n; K-step ks = 5*chunk + q:
 //   value(co = (co_tile*NT + nt)*16 + n, ci = 16*chunk + 8*(g&1) + j, tap = 2q + (g>>1))   (zero when tap > 8)
+template <class AR>
 __global__ __launch_bounds__(256) void pack_weights_sb16_kernel(const float* __restrict__ w, int Cout, int Cin,
-                                                                int transpose_flip, int NT, uint4* __restrict__ wp, int total) {
+                                                                int transpose_flip, int NT, const unsigned* __restrict__ amax_w,
+                                                                uint4* __restrict__ wp, int total) {
     const int e = blockIdx.x * 256 + threadIdx.x;          // one thread per (co_tile, kstep, nt, lane)
     if (e >= total) return;
     const int conv_in = transpose_flip ? Cout : Cin;
@@ -83,38 +59,32 @@ __global__ __launch_bounds__(256) void pack_weights_sb16_kernel(const float* __r
         }
         v[j] = t;
     }
-    uint4 h, m, l;
-    split8(v, h, m, l);
-    uint4* dst = wp + (((size_t)(co_tile * n_steps + ks) * NT + nt) * 3) * 64 + lane;
-    dst[0] = h; dst[64] = m; dst[128] = l;
+    uint4 cells[AR::NP];
+    split_cells8<AR>(v, AR::SCALED ? split_scale_of(split_amax_exp(amax_w)) : 1.f, cells);
+    uint4* dst = wp + (((size_t)(co_tile * n_steps + ks) * NT + nt) * AR::NP) * 64 + lane;
+#pragma unroll
+    for (int p = 0; p < AR::NP; ++p) dst[64 * p] = cells[p];
 }
 
 // One K-step of a wave: 4 pixel tiles x NTW channel tiles x 6 piece products (see conv3x3_sb.hip:sb_kstep)
-template <int NTW, int NTMAX>
+template <class AR, int NTW, int NTMAX>
 __device__ __forceinline__ void sb16_kstep(const uint4* __restrict__ ap, const uint4* __restrict__ bp,
                                            f32x4 (&acc)[4][NTMAX]) {
-    bf16x8 a[4][3];
+    typedef typename AR::frag_t frag_t;
+    frag_t a[4][AR::NP];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            a[mt][p] = __builtin_bit_cast(bf16x8, ap[p * NOCT * CELLS + 16 * mt]);
-        }
+        for (int p = 0; p < AR::NP; ++p) a[mt][p] = __builtin_bit_cast(frag_t, ap[p * NOCT * CELLS + 16 * mt]);
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-        const bf16x8 b0 = __builtin_bit_cast(bf16x8, bp[(nt * 3 + 0) * 64]);
-        const bf16x8 b1 = __builtin_bit_cast(bf16x8, bp[(nt * 3 + 1) * 64]);
-        const bf16x8 b2 = __builtin_bit_cast(bf16x8, bp[(nt * 3 + 2) * 64]);
-#define SB16_TERM(P, Q)                                                                                   \
-    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                      \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][P], Q, acc[mt][nt], 0, 0, 0);
-        SB16_TERM(2, b0)
-        SB16_TERM(0, b2)
-        SB16_TERM(1, b1)
-        SB16_TERM(1, b0)
-        SB16_TERM(0, b1)
-        SB16_TERM(0, b0)
-#undef SB16_TERM
+        frag_t b[AR::NP];
+#pragma unroll
+        for (int p = 0; p < AR::NP; ++p) b[p] = __builtin_bit_cast(frag_t, bp[(nt * AR::NP + p) * 64]);
+#pragma unroll
+        for (int t = 0; t < AR::NTERMS; ++t)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = AR::mfma(a[mt][AR::ta(t)], b[AR::tb(t)], acc[mt][nt]);
     }
 }
 
@@ -122,7 +92,7 @@ __device__ __forceinline__ void sb16_kstep(const uint4* __restrict__ ap, const u
 template <int NTW, int NTMAX>
 __device__ __forceinline__ void sb16_store(const f32x4 (&acc)[4][NTMAX], float* __restrict__ ybc,
                                            const float* __restrict__ bias, int co0, size_t plane, int yy, int x0, int W,
-                                           int g, int n) {
+                                           int g, int n, float unscale) {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         float* orow = ybc + (size_t)(co0 + nt * 16 + n) * plane + (size_t)yy * W;
@@ -130,7 +100,7 @@ __device__ __forceinline__ void sb16_store(const f32x4 (&acc)[4][NTMAX], float* 
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int xx = x0 + 16 * mt + 4 * g;
-            f32x4 v = acc[mt][nt];
+            f32x4 v = acc[mt][nt] * unscale;
             v += bv;
             if (xx + 3 < W) *reinterpret_cast<float4*>(orow + xx) = make_float4(v[0], v[1], v[2], v[3]);
             else {
@@ -144,14 +114,20 @@ __device__ __forceinline__ void sb16_store(const f32x4 (&acc)[4][NTMAX], float* 
 
 // 8 waves: wave = (row = wave & 3, half = wave >> 2); the halves split the NT channel tiles. Two blocks per CU = 4 waves per
 // SIMD (the second launch-bounds argument of HIP is waves per execution unit): 128 VGPRs.
-template <int NT>
+template <class AR, int NT>
 __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                               const float* __restrict__ bias, int Cin, int Cout, int H,
-                                                              int W, int tiles_x, int tiles_y, float* __restrict__ y) {
+                                                              int W, int tiles_x, int tiles_y,
+                                                              const unsigned* __restrict__ amax_x,
+                                                              const unsigned* __restrict__ amax_w, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s16[];
-    uint4* As = smem_s16;                          // [piece 3][octet 2][CELLS]
-    uint4* Bs = smem_s16 + A_CELLS;                // [2][NT*3*64]
-    constexpr int BSTEP = NT * 3 * 64;             // uint4 per K-step
+    constexpr int NP = AR::NP;
+    constexpr int A_CELLS = NP * NOCT * CELLS;
+    uint4* As = smem_s16;                          // [piece NP][octet 2][CELLS]
+    uint4* Bs = smem_s16 + A_CELLS;                // [2][NT*NP*64]
+    constexpr int BSTEP = NT * NP * 64;            // uint4 per K-step
+    const unsigned ex = AR::SCALED ? split_amax_exp(amax_x) : 141u, ew = AR::SCALED ? split_amax_exp(amax_w) : 141u;
+    const float xscale = split_scale_of(ex);       // 1 for the unscaled arithmetic
     constexpr int NT0 = (NT + 1) / 2, NT1 = NT - NT0;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -172,9 +148,9 @@ __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(cons
 
     auto b_glds = [&](int ks, int buf) {
 #pragma unroll
-        for (int i = 0; i < (NT * 3 + 7) / 8; ++i) {
+        for (int i = 0; i < (NT * NP + 7) / 8; ++i) {
             const int r = wave + 8 * i;                  // one 1 KB row (channel tile, piece) per wave instruction
-            if (r < NT * 3)
+            if (r < NT * NP)
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void*)(wbase + (size_t)ks * BSTEP + r * 64 + lane),
                     (__attribute__((address_space(3))) void*)(Bs + buf * BSTEP + r * 64), 16, 0, 0);
@@ -219,12 +195,11 @@ __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(cons
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = ok ? apre[u][j] : 0.f;       // zero padding / outside the tensor
-                uint4 h, m, l;
-                split8(v, h, m, l);
+                uint4 cells[NP];
+                split_cells8<AR>(v, xscale, cells);
                 const int item = oct * CELLS + rc;
-                As[item] = h;
-                As[NOCT * CELLS + item] = m;
-                As[2 * NOCT * CELLS + item] = l;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) As[p * NOCT * CELLS + item] = cells[p];
             }
         }
     };
@@ -241,7 +216,7 @@ __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(cons
     __syncthreads();
 
     const uint4* a_lane = As + row * XCOLS + n;                        // + octet / tap offset per K-step
-    const uint4* b_lane = Bs + (half ? NT0 * 3 * 64 : 0) + lane;       // + buffer offset per K-step
+    const uint4* b_lane = Bs + (half ? NT0 * NP * 64 : 0) + lane;      // + buffer offset per K-step
     int ks = 0, buf = 0;
     for (int c = 0; c < n_chunks; ++c) {
 #pragma unroll 1
@@ -254,8 +229,8 @@ __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(cons
             const int tap = min(2 * s + (g >> 1), 8);
             const int ky = tap / 3, kx = tap - 3 * ky;
             const int a_off = (g & 1) * CELLS + ky * XCOLS + kx;
-            if (half == 0) sb16_kstep<NT0, NT0>(a_lane + a_off, b_lane + buf * BSTEP, acc);
-            else if (NT1 > 0) sb16_kstep<NT1, NT0>(a_lane + a_off, b_lane + buf * BSTEP, acc);
+            if (half == 0) sb16_kstep<AR, NT0, NT0>(a_lane + a_off, b_lane + buf * BSTEP, acc);
+            else if (NT1 > 0) sb16_kstep<AR, NT1, NT0>(a_lane + a_off, b_lane + buf * BSTEP, acc);
             if (s == STEPS - 1 && c + 1 < n_chunks) {
                 __syncthreads();                    // every wave is done with this chunk's patch
                 a_store();
@@ -270,18 +245,19 @@ __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(cons
     if (yy < H) {
         float* ybc = y + (size_t)b * Cout * plane;
         const int co0 = cot * NT * 16;
-        if (half == 0) sb16_store<NT0, NT0>(acc, ybc, bias, co0, plane, yy, x0, W, g, n);
-        else if (NT1 > 0) sb16_store<NT1, NT0>(acc, ybc, bias, co0 + NT0 * 16, plane, yy, x0, W, g, n);
+        const float unscale = split_unscale_of(ex) * split_unscale_of(ew);
+        if (half == 0) sb16_store<NT0, NT0>(acc, ybc, bias, co0, plane, yy, x0, W, g, n, unscale);
+        else if (NT1 > 0) sb16_store<NT1, NT0>(acc, ybc, bias, co0 + NT0 * 16, plane, yy, x0, W, g, n, unscale);
     }
 }
 
-template <int NT>
-int launch_sb16(const float* x, const uint4* wp, const float* bias, int B, int Cin, int Cout, int H, int W, float* y,
-                hipStream_t stream) {
-    const size_t lds = sizeof(uint4) * (A_CELLS + 2 * NT * 3 * 64);
+template <class AR, int NT>
+int launch_sb16(const float* x, const uint4* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
+                const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream) {
+    const size_t lds = sizeof(uint4) * (AR::NP * NOCT * CELLS + 2 * NT * AR::NP * 64);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_sb16_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        if (hipFuncSetAttribute((const void*)conv3x3_sb16_kernel<AR, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess) {
             cseg_set_error("conv3x3_sb16: cannot raise dynamic LDS to %zu bytes", lds);
             return 0;
@@ -291,37 +267,49 @@ int launch_sb16(const float* x, const uint4* wp, const float* bias, int B, int C
     const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
     const long n_tiles = (long)B * (Cout / (NT * 16)) * tiles_y * tiles_x;
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb16: grid too large");
-    hipLaunchKernelGGL((conv3x3_sb16_kernel<NT>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, Cin, Cout, H, W,
-                       tiles_x, tiles_y, y);
+    hipLaunchKernelGGL((conv3x3_sb16_kernel<AR, NT>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, Cin, Cout, H, W,
+                       tiles_x, tiles_y, amax_x, amax_w, y);
     CSEG_CHECK_LAUNCH("conv3x3_sb16_kernel");
     return 1;
 }
 
 }  // namespace
 
-// Reached from the cseg_conv3x3_sb_* entry points of conv3x3_sb.hip under CSEG_CONV3X3_SB_VAR=2 (NT = 3 or 6).
+// Reached from the cseg_conv3x3_sb_* / cseg_conv3x3_split_* entry points of conv3x3_sb.hip (NT = 3 or 6).
 namespace cseg_sb16 {
 
-size_t packed_bytes(int Cin, int Cout) { return (size_t)(Cout / 16) * steps16(Cin) * 3 * 64 * sizeof(uint4); }
+size_t packed_bytes(int arith, int Cin, int Cout) {
+    return (size_t)(Cout / 16) * steps16(Cin) * (arith == CSEG_ARITH_F16X3 ? 2 : 3) * 64 * sizeof(uint4);
+}
 
-int pack(const float* w, int Cout, int Cin, int transpose_flip, int NT, void* wp, hipStream_t stream) {
+int pack(const float* w, int Cout, int Cin, int transpose_flip, int NT, int arith, const unsigned* amax_w, void* wp,
+         hipStream_t stream) {
     const int conv_in = transpose_flip ? Cout : Cin, conv_out = transpose_flip ? Cin : Cout;
     CSEG_REQUIRE((NT == 3 || NT == 6) && conv_out % (NT * 16) == 0 && conv_in % 16 == 0,
                  "conv3x3_sb16: needs 3 or 6 channel tiles per block (got %d) and input channels %% 16 == 0", NT);
     const long total = (long)(conv_out / 16) * steps16(conv_in) * 64;
     CSEG_REQUIRE(total < 2147483647L, "conv3x3_sb16 pack: too large");
-    hipLaunchKernelGGL(pack_weights_sb16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, Cout, Cin,
-                       transpose_flip, NT, (uint4*)wp, (int)total);
+    if (arith == CSEG_ARITH_F16X3)
+        hipLaunchKernelGGL(pack_weights_sb16_kernel<SplitF16x3>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, Cout,
+                           Cin, transpose_flip, NT, amax_w, (uint4*)wp, (int)total);
+    else
+        hipLaunchKernelGGL(pack_weights_sb16_kernel<SplitBF16x6>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, Cout,
+                           Cin, transpose_flip, NT, amax_w, (uint4*)wp, (int)total);
     CSEG_CHECK_LAUNCH("conv3x3_sb16 pack");
     return 1;
 }
 
-int fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int NT, float* y,
-        hipStream_t stream) {
+int fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int NT, int arith,
+        const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream) {
     CSEG_REQUIRE((NT == 3 || NT == 6) && Cout % (NT * 16) == 0 && Cin % 16 == 0 && (long)H * W * 16 * 4 < 2147483647L,
                  "conv3x3_sb16: unsupported shape Cin=%d Cout=%d %dx%d with %d channel tiles per block", Cin, Cout, H, W, NT);
-    if (NT == 6) return launch_sb16<6>(x, (const uint4*)wp, bias, B, Cin, Cout, H, W, y, stream);
-    return launch_sb16<3>(x, (const uint4*)wp, bias, B, Cin, Cout, H, W, y, stream);
+    const uint4* wq = (const uint4*)wp;
+    if (arith == CSEG_ARITH_F16X3) {
+        if (NT == 6) return launch_sb16<SplitF16x3, 6>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+        return launch_sb16<SplitF16x3, 3>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+    }
+    if (NT == 6) return launch_sb16<SplitBF16x6, 6>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+    return launch_sb16<SplitBF16x6, 3>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
 }
 
 }  // namespace cseg_sb16

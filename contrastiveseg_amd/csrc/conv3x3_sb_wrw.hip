@@ -23,11 +23,11 @@
 // is bandwidth-bound; a wider block / XCD-local ordering of the blocks that share pixels is the next step.
 // Parity vs fp64 and determinism: tests/test_gpu_conv3x3_sb.py. Host side: opt-in (kernels.CONV3X3_SB_WRW) until the
 // one-SGD-step goldens have run on it.
-#include "cseg_common.h"
+// Round 3: version 2 (below) is the default and is written against the arithmetic traits of cseg_split.h -- bf16x6 and f16x3
+// (two scaled fp16 pieces, three MFMAs per product; x is scaled by 2^kx, dy by 2^kd while they are split, the partial sums are
+// multiplied by 2^-(kx + kd) when they are written). Version 1 stays bf16x6.
+#include "cseg_split.h"
 #include <stdlib.h>
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -41,27 +41,10 @@ constexpr int ROWS_PER_UNIT = 8;
 __device__ __forceinline__ int xs_idx(int s, int p, int ci, int slot, int i) { return (((s * 3 + p) * CI_B + ci) * 3 + slot) * XP + i; }
 __device__ __forceinline__ int ds_idx(int p, int co, int i) { return (p * CO_B + co) * DP + i; }
 
-__device__ __forceinline__ void split3w(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
-    const __bf16 bh = (__bf16)v;
-    const float r1 = v - (float)bh;
-    const __bf16 bm = (__bf16)r1;
-    const float r2 = r1 - (float)bm;
-    const __bf16 bl = (__bf16)r2;
-    h = __builtin_bit_cast(unsigned short, bh);
-    m = __builtin_bit_cast(unsigned short, bm);
-    l = __builtin_bit_cast(unsigned short, bl);
-}
-
 __device__ __forceinline__ void split8w(const float (&v)[8], uint4& h, uint4& m, uint4& l) {
-    unsigned short hs[8], ms[8], ls[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) split3w(v[j], hs[j], ms[j], ls[j]);
-    h = make_uint4(hs[0] | ((unsigned)hs[1] << 16), hs[2] | ((unsigned)hs[3] << 16), hs[4] | ((unsigned)hs[5] << 16),
-                   hs[6] | ((unsigned)hs[7] << 16));
-    m = make_uint4(ms[0] | ((unsigned)ms[1] << 16), ms[2] | ((unsigned)ms[3] << 16), ms[4] | ((unsigned)ms[5] << 16),
-                   ms[6] | ((unsigned)ms[7] << 16));
-    l = make_uint4(ls[0] | ((unsigned)ls[1] << 16), ls[2] | ((unsigned)ls[3] << 16), ls[4] | ((unsigned)ls[5] << 16),
-                   ls[6] | ((unsigned)ls[7] << 16));
+    uint4 c[3];
+    split_cells8<SplitBF16x6>(v, 1.f, c);
+    h = c[0]; m = c[1]; l = c[2];
 }
 
 __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -264,40 +247,49 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw_kernel(const float* __r
 // Status: index-checked against the numpy lane model; first hardware run pending (CSEG_CONV3X3_SB_WRW_V=2 selects it).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int X2_CH = 296;                          // elements per (piece, ci): 4 slots x 72 + 8 pad  (148 dwords)
-constexpr int X2_ELEMS = 3 * CI_B * X2_CH;
-constexpr int D2_ELEMS = 2 * 3 * CO_B * DP;
 constexpr int RPU2 = 16;
+__host__ __device__ constexpr int x2_elems(int np) { return np * CI_B * X2_CH; }
+__host__ __device__ constexpr int d2_elems(int np) { return 2 * np * CO_B * DP; }
 
 __device__ __forceinline__ int x2_idx(int p, int ci, int slot, int i) { return (p * CI_B + ci) * X2_CH + slot * 72 + i; }
-__device__ __forceinline__ int d2_idx(int buf, int p, int co, int i) { return ((buf * 3 + p) * CO_B + co) * DP + i; }
+template <int NP>
+__device__ __forceinline__ int d2_idx(int buf, int p, int co, int i) { return ((buf * NP + p) * CO_B + co) * DP + i; }
 
-__device__ __forceinline__ void split4w(const float4& v, uint2& h, uint2& m, uint2& l) {
-    unsigned short hs[4], ms[4], ls[4];
-    split3w(v.x, hs[0], ms[0], ls[0]);
-    split3w(v.y, hs[1], ms[1], ls[1]);
-    split3w(v.z, hs[2], ms[2], ls[2]);
-    split3w(v.w, hs[3], ms[3], ls[3]);
-    h = make_uint2(hs[0] | ((unsigned)hs[1] << 16), hs[2] | ((unsigned)hs[3] << 16));
-    m = make_uint2(ms[0] | ((unsigned)ms[1] << 16), ms[2] | ((unsigned)ms[3] << 16));
-    l = make_uint2(ls[0] | ((unsigned)ls[1] << 16), ls[2] | ((unsigned)ls[3] << 16));
-}
-
+template <class AR>
 __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                  int B, int Cin, int Cout, int H, int W, int n_split,
+                                                                 int SC, int SI, const unsigned* __restrict__ amax_x,
+                                                                 const unsigned* __restrict__ amax_dy,
                                                                  float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_w[];
+    constexpr int NP = AR::NP;
+    typedef typename AR::frag_t frag_t;
     unsigned short* xs = smem_w;
-    unsigned short* ds = smem_w + X2_ELEMS;
+    unsigned short* ds = smem_w + x2_elems(NP);
+    const unsigned ex = AR::SCALED ? split_amax_exp(amax_x) : 141u, ed = AR::SCALED ? split_amax_exp(amax_dy) : 141u;
+    const float xscale = split_scale_of(ex), dscale = split_scale_of(ed);      // 1 for the unscaled arithmetic
     // readfirstlane: the role split below must be a SCALAR branch (the wave index is uniform, which the compiler cannot see)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const bool loader = wave >= 4;
     const int lt = tid - 256;                          // loader thread index
     const int g = lane >> 4, n = lane & 15;
-    int blk = blockIdx.x;
-    const int split = blk % n_split; blk /= n_split;
+    // XCD-aware block order. Block b runs on XCD b % 8 (observed on gfx950; only speed depends on it). The blocks of one XCD
+    // walk the (pixel split, channel block) grid group by group: a group = SC x SI channel blocks of the SAME pixel range, which
+    // run side by side on that XCD's CUs and share their dy rows (SI times) and x rows (SC times) through its L2. At 720
+    // channels (15 x 12 channel blocks, groups of 5 x 6) a block's share of the HBM traffic drops from 112 to 21 channels.
     const int n_cib = (Cin + CI_B - 1) / CI_B;
-    const int cib = blk % n_cib;
-    const int cob = blk / n_cib;
+    int split, cib, cob;
+    {
+        const int n_cob = Cout / CO_B;
+        const int n_si = n_cib / SI, gsz = SC * SI, n_groups = n_split * (n_cob / SC) * n_si;
+        const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+        const int grp = (l / gsz) * 8 + xcd, j = l % gsz;
+        if (grp >= n_groups) return;                   // the grid is rounded up to 8 x groups-per-XCD x group size
+        split = grp % n_split;
+        const int st = grp / n_split;
+        cib = (st % n_si) * SI + j % SI;
+        cob = (st / n_si) * SC + j / SI;
+    }
     const size_t plane = (size_t)H * W;
     const int segs = W / SEG;
     const int runs = (H + RPU2 - 1) / RPU2;
@@ -324,11 +316,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
                 const int px = x0 - 4 + 4 * c;
                 const bool ok = cib * CI_B + ci < Cin && row >= 0 && row < H && px >= 0 && px < W;
                 const float4 t = ok ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-                uint2 h, m, l;
-                split4w(t, h, m, l);
-                *reinterpret_cast<uint2*>(xs + x2_idx(0, ci, slot, 4 * c)) = h;
-                *reinterpret_cast<uint2*>(xs + x2_idx(1, ci, slot, 4 * c)) = m;
-                *reinterpret_cast<uint2*>(xs + x2_idx(2, ci, slot, 4 * c)) = l;
+                uint2 cells[NP];
+                split_cells4<AR>(t, xscale, cells);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(xs + x2_idx(p, ci, slot, 4 * c)) = cells[p];
             }
         }
     };
@@ -345,11 +336,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
         for (int u = 0; u < 3; ++u) {
             const int item = lt + 256 * u;
             const int co = item >> 4, c = item & 15;
-            uint2 h, m, l;
-            split4w(v[u], h, m, l);
-            *reinterpret_cast<uint2*>(ds + d2_idx(buf, 0, co, 4 * c)) = h;
-            *reinterpret_cast<uint2*>(ds + d2_idx(buf, 1, co, 4 * c)) = m;
-            *reinterpret_cast<uint2*>(ds + d2_idx(buf, 2, co, 4 * c)) = l;
+            uint2 cells[NP];
+            split_cells4<AR>(v[u], dscale, cells);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(ds + d2_idx<NP>(buf, p, co, 4 * c)) = cells[p];
         }
     };
 
@@ -357,38 +347,36 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
     auto compute = [&](int s0, int buf, f32x4 (&acc)[9][3]) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[3][3];
+            frag_t a[3][NP];
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    a[c][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ds + d2_idx(buf, p, c * 16 + n, 32 * ks + 8 * g)));
+                for (int p = 0; p < NP; ++p)
+                    a[c][p] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(ds + d2_idx<NP>(buf, p, c * 16 + n, 32 * ks + 8 * g)));
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int slot = (s0 + ky) & 3;
-                bf16x8 bfr[3][3];                      // [kx][piece]
+                frag_t bfr[3][NP];                     // [kx][piece]
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < NP; ++p) {
                     const unsigned short* src = xs + x2_idx(p, wave * 16 + n, slot, 32 * ks + 8 * g);
                     const uint4 c0 = *reinterpret_cast<const uint4*>(src);          // entries e .. e+7    (d0..d3)
                     const uint4 c1 = *reinterpret_cast<const uint4*>(src + 8);      // entries e+8 .. e+15 (d4..d7)
                     const unsigned a21 = __builtin_amdgcn_alignbit(c0.z, c0.y, 16), a32 = __builtin_amdgcn_alignbit(c0.w, c0.z, 16),
                                    a43 = __builtin_amdgcn_alignbit(c1.x, c0.w, 16), a54 = __builtin_amdgcn_alignbit(c1.y, c1.x, 16),
                                    a65 = __builtin_amdgcn_alignbit(c1.z, c1.y, 16);
-                    bfr[0][p] = __builtin_bit_cast(bf16x8, make_uint4(a21, a32, a43, a54));     // entries e+3 .. e+10 (kx = 0)
-                    bfr[1][p] = __builtin_bit_cast(bf16x8, make_uint4(c0.z, c0.w, c1.x, c1.y)); // entries e+4 .. e+11
-                    bfr[2][p] = __builtin_bit_cast(bf16x8, make_uint4(a32, a43, a54, a65));     // entries e+5 .. e+12
+                    bfr[0][p] = __builtin_bit_cast(frag_t, make_uint4(a21, a32, a43, a54));     // entries e+3 .. e+10 (kx = 0)
+                    bfr[1][p] = __builtin_bit_cast(frag_t, make_uint4(c0.z, c0.w, c1.x, c1.y)); // entries e+4 .. e+11
+                    bfr[2][p] = __builtin_bit_cast(frag_t, make_uint4(a32, a43, a54, a65));     // entries e+5 .. e+12
                 }
-#define SBW_TERM(P, Q)                                                                                          \
-    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) _Pragma("unroll") for (int c = 0; c < 3; ++c)             \
-        acc[ky * 3 + kx][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[c][P], bfr[kx][Q], acc[ky * 3 + kx][c], 0, 0, 0);
-                SBW_TERM(2, 0)
-                SBW_TERM(0, 2)
-                SBW_TERM(1, 1)
-                SBW_TERM(1, 0)
-                SBW_TERM(0, 1)
-                SBW_TERM(0, 0)
-#undef SBW_TERM
+                // term-major, smallest terms first; nine independent accumulators between two MFMAs on the same one
+#pragma unroll
+                for (int t = 0; t < AR::NTERMS; ++t)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            acc[ky * 3 + kx][c] = AR::mfma(a[c][AR::ta(t)], bfr[kx][AR::tb(t)], acc[ky * 3 + kx][c]);
             }
         }
     };
@@ -458,6 +446,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
         }
         if (tile_ok) {
             const int ci = cib * CI_B + wave * 16 + n;
+            const float unscale = split_unscale_of(ex) * split_unscale_of(ed);
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -465,7 +454,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
                     // D[m = 4g + r][n]: co = cob*48 + 16c + 4g + r, ci = this lane's column
                     float* dst = partial + (((size_t)split * 9 + t) * Cout + cob * CO_B + c * 16 + 4 * g) * Cin + ci;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dst[(size_t)r * Cin] = acc[t][c][r];
+                    for (int r = 0; r < 4; ++r) dst[(size_t)r * Cin] = acc[t][c][r] * unscale;
                 }
         }
     }
@@ -522,32 +511,66 @@ extern "C" size_t cseg_conv3x3_sb_wrw_ws_floats(int B, int Cin, int Cout, int H,
     return (size_t)sb_wrw_splits(B, Cin, Cout, H, W) * 9 * Cin * Cout;
 }
 
-extern "C" int cseg_conv3x3_sb_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, float* ws,
-                                   float* dw, cseg_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+namespace {
+
+// group shape of the XCD-aware block order: SC | n_cob, SI | n_cib, SC * SI <= 32 (the CUs of one XCD), fewest distinct
+// channels per block
+void sb_wrw_group(int n_cob, int n_cib, int& SC, int& SI) {
+    SC = SI = 1;
+    double best = CO_B + CI_B;
+    for (int sc = 1; sc <= n_cob; ++sc) {
+        if (n_cob % sc) continue;
+        for (int si = 1; si <= n_cib && sc * si <= 32; ++si) {
+            if (n_cib % si) continue;
+            const double per_block = (double)(sc * CO_B + si * CI_B) / (sc * si);
+            if (per_block < best - 1e-9) { best = per_block; SC = sc; SI = si; }
+        }
+    }
+}
+
+template <class AR>
+int launch_wrw2(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, int n_split, const unsigned* amax_x,
+                const unsigned* amax_dy, float* ws, hipStream_t stream) {
+    const size_t lds2 = sizeof(unsigned short) * (x2_elems(AR::NP) + d2_elems(AR::NP));
+    static bool attr2_set = false;
+    if (!attr2_set) {
+        if (hipFuncSetAttribute((const void*)conv3x3_sb_wrw2_kernel<AR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) !=
+            hipSuccess) {
+            cseg_set_error("conv3x3_sb_wrw: cannot raise dynamic LDS to %zu bytes", lds2);
+            return 0;
+        }
+        attr2_set = true;
+    }
+    const int n_cob = Cout / CO_B, n_cib = (Cin + CI_B - 1) / CI_B;
+    int SC, SI;
+    sb_wrw_group(n_cob, n_cib, SC, SI);
+    const long n_groups = (long)n_split * (n_cob / SC) * (n_cib / SI);
+    const long blocks = ((n_groups + 7) / 8) * 8 * SC * SI;
+    CSEG_REQUIRE(blocks < 2147483647L, "conv3x3_sb_wrw: grid too large");
+    hipLaunchKernelGGL(conv3x3_sb_wrw2_kernel<AR>, dim3((unsigned)blocks), dim3(512), lds2, stream, x, dy, B, Cin, Cout, H, W,
+                       n_split, SC, SI, amax_x, amax_dy, ws);
+    CSEG_CHECK_LAUNCH("conv3x3_sb_wrw2_kernel");
+    return 1;
+}
+
+int wrw_impl(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, int arith, const unsigned* amax_x,
+             const unsigned* amax_dy, float* ws, float* dw, hipStream_t stream) {
     CSEG_REQUIRE(x && dy && ws && dw, "conv3x3_sb_wrw: null pointer");
     CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % CO_B == 0 && W % SEG == 0,
                  "conv3x3_sb_wrw: unsupported shape B=%d Cin=%d Cout=%d %dx%d (needs Cin %% 16, Cout %% 48, W %% 64)", B, Cin,
                  Cout, H, W);
+    CSEG_REQUIRE(arith == CSEG_ARITH_BF16X6 || (arith == CSEG_ARITH_F16X3 && amax_x && amax_dy),
+                 "conv3x3 split wrw: arithmetic %d needs max|x| and max|dy|", arith);
     const int n_split = sb_wrw_splits(B, Cin, Cout, H, W);
     const long blocks = (long)n_split * ((Cin + CI_B - 1) / CI_B) * (Cout / CO_B);
     CSEG_REQUIRE(blocks < 2147483647L && (long)9 * Cin * Cout < 2147483647L, "conv3x3_sb_wrw: grid too large");
-    if (sb_wrw_version() == 2) {
+    if (arith == CSEG_ARITH_F16X3 || sb_wrw_version() == 2) {
         CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0,
                      "conv3x3_sb_wrw: tensors must be 16-byte aligned");
-        const size_t lds2 = sizeof(unsigned short) * (X2_ELEMS + D2_ELEMS);
-        static bool attr2_set = false;
-        if (!attr2_set) {
-            if (hipFuncSetAttribute((const void*)conv3x3_sb_wrw2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds2) != hipSuccess) {
-                cseg_set_error("conv3x3_sb_wrw: cannot raise dynamic LDS to %zu bytes", lds2);
-                return 0;
-            }
-            attr2_set = true;
-        }
-        hipLaunchKernelGGL(conv3x3_sb_wrw2_kernel, dim3((unsigned)blocks), dim3(512), lds2, stream, x, dy, B, Cin, Cout, H, W,
-                           n_split, ws);
-        CSEG_CHECK_LAUNCH("conv3x3_sb_wrw2_kernel");
+        const int ok = arith == CSEG_ARITH_F16X3
+                           ? launch_wrw2<SplitF16x3>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream)
+                           : launch_wrw2<SplitBF16x6>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream);
+        if (!ok) return 0;
     } else {
         const size_t lds = sizeof(unsigned short) * (XS_ELEMS + DS_ELEMS);
         static bool attr_set = false;
@@ -567,4 +590,19 @@ extern "C" int cseg_conv3x3_sb_wrw(const float* x, const float* dy, int B, int C
     hipLaunchKernelGGL(sb_wrw_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, ws, n_split, Cout, Cin, dw);
     CSEG_CHECK_LAUNCH("sb_wrw_reduce_kernel");
     return 1;
+}
+
+}  // namespace
+
+extern "C" int cseg_conv3x3_sb_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, float* ws,
+                                   float* dw, cseg_stream_t stream_) {
+    return wrw_impl(x, dy, B, Cin, Cout, H, W, CSEG_ARITH_BF16X6, nullptr, nullptr, ws, dw, (hipStream_t)stream_);
+}
+
+// arith: CSEG_ARITH_BF16X6 | CSEG_ARITH_F16X3 (then amax_x / amax_dy = max|x| / max|dy| bit patterns, cseg_amax_f32); workspace:
+// cseg_conv3x3_sb_wrw_ws_floats
+extern "C" int cseg_conv3x3_split_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, int arith,
+                                      const unsigned* amax_x, const unsigned* amax_dy, float* ws, float* dw,
+                                      cseg_stream_t stream_) {
+    return wrw_impl(x, dy, B, Cin, Cout, H, W, arith, amax_x, amax_dy, ws, dw, (hipStream_t)stream_);
 }

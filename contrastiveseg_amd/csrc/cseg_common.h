@@ -8,11 +8,17 @@
 #define CSEG_WAVE 64
 
 // Marks a point where the lanes of ONE wave hand data to each other through LDS and rely on the wave executing in
-// lockstep (writes of all 64 lanes have been issued, in order, before any lane's read): nothing is emitted on the
-// hardware. The CPU emulation of the execution model used by the tests (tests/emu) runs lanes one after the other between
-// rendezvous points and compiles this into a wave rendezvous.
+// lockstep (the LDS writes of all 64 lanes have been issued, in order, before any lane's read). On the hardware no
+// instruction is needed for that, but the COMPILER must not move LDS accesses across the point: a wavefront-scope release
+// fence plus a wave barrier (both are scheduling constraints only -- no code is emitted for them on gfx950). The CPU emulation
+// of the execution model used by the tests (tests/emu) runs lanes one after the other between rendezvous points and compiles
+// this into a wave rendezvous.
 #ifndef CSEG_WAVE_LOCKSTEP
-#define CSEG_WAVE_LOCKSTEP() ((void)0)
+#define CSEG_WAVE_LOCKSTEP()                                  \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+    } while (0)
 #endif
 
 void cseg_set_error(const char* fmt, ...);

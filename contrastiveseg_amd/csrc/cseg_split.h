@@ -1,0 +1,101 @@
+// Split-operand arithmetic of the matrix-core convolutions: an fp32 operand is written as a short sum of 16-bit pieces,
+// the product of two operands is accumulated in fp32 from the piece products that matter. Two forms:
+//
+//   SplitBF16x6 ("bf16x6", round 2): three bf16 pieces (8 + 8 + 8 mantissa bits, exact split), six products
+//       a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0); dropped terms <= 3 * 2^-24 of the product. Roof 2500 / 6 = 417 TFLOP/s.
+//   SplitF16x3 ("f16x3", round 3): two fp16 pieces of the operand scaled by a power of two (11 + 11 mantissa bits:
+//       hi = rn16(s x), lo = rn16(s x - hi), |s x - hi - lo| <= 2^-22 |s x|), three products a0b0 + (a0b1 + a1b0); the
+//       dropped a1b1 is <= 2^-22 of the product. Roof 2500 / 3 = 833 TFLOP/s of fp32-equivalent work.
+//       The scale s = 2^k is chosen per TENSOR from max|x| so that max|s x| lies in [2^14, 2^15) (fp16 overflows at
+//       2^16): a power of two changes no mantissa bit, and it is undone exactly in the epilogue (acc * 2^-(ka + kb)).
+//       fp16 keeps subnormals (checked on the MI355X: tools/probes/mfma_f16_probe.hip), so an element that is 2^17 times
+//       smaller than the tensor's maximum still has a lo piece with an absolute error of 2^-25 (scaled units), i.e. a
+//       relative error <= 2^-22 of that element; smaller elements lose relative precision gradually, but their absolute
+//       error stays <= 2^-40 of the tensor's maximum.
+//   Accuracy of the whole network in either arithmetic, fp64 as truth (tools/split_bf16_probe.py, reference HRNet-W48,
+//   max |logit error| at |logit| <= 1.97): fp32 4.3e-5, bf16x6 2.1e-5, f16x3 5.1e-5 (rms 9.6e-6 vs fp32's 9.1e-6),
+//   bf16x3 1.4e-3, TF32 9.6e-2. Both forms are dominated by the fp32 accumulation, like fp32 itself.
+//
+// A kernel is written once against the traits below: AR::NP pieces per operand, AR::NTERMS MFMAs per (A tile, B tile,
+// K-step), term t multiplies A piece AR::ta(t) with B piece AR::tb(t) (smallest terms first).
+#pragma once
+#include "cseg_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+
+// max|x| of a tensor is handed around as the BIT PATTERN of that non-negative float (monotone as an unsigned integer, so a
+// plain atomicMax accumulates it). Scale of the f16x3 split: 2^k with k = 14 - floor(log2 max|x|).
+__device__ __forceinline__ unsigned split_amax_exp(const unsigned* __restrict__ amax_bits) {
+    unsigned e = (amax_bits ? *amax_bits : 0x3f800000u) >> 23 & 0xffu;          // biased exponent of max|x|
+    return e < 15u ? 15u : (e > 253u ? 253u : e);                                // all-zero / tiny / non-finite tensors: any finite scale
+}
+__device__ __forceinline__ float split_scale_of(unsigned e) { return __builtin_bit_cast(float, (268u - e) << 23); }     // 2^(141 - e)
+__device__ __forceinline__ float split_unscale_of(unsigned e) { return __builtin_bit_cast(float, (e - 14u) << 23); }    // 2^(e - 141)
+
+struct SplitBF16x6 {
+    static constexpr int ID = CSEG_ARITH_BF16X6;
+    static constexpr int NP = 3, NTERMS = 6;
+    static constexpr bool SCALED = false;
+    typedef bf16x8 frag_t;
+    __host__ __device__ static constexpr int ta(int t) { return t == 0 ? 2 : t == 1 ? 0 : t == 2 ? 1 : t == 3 ? 1 : 0; }
+    __host__ __device__ static constexpr int tb(int t) { return t == 0 ? 0 : t == 1 ? 2 : t == 2 ? 1 : t == 3 ? 0 : t == 4 ? 1 : 0; }
+    __device__ static __forceinline__ f32x4 mfma(frag_t a, frag_t b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ void split(float v, float /*scale*/, unsigned short (&p)[3]) {
+        const __bf16 bh = (__bf16)v;
+        const float r1 = v - (float)bh;            // exact
+        const __bf16 bm = (__bf16)r1;
+        const float r2 = r1 - (float)bm;           // exact
+        const __bf16 bl = (__bf16)r2;
+        p[0] = __builtin_bit_cast(unsigned short, bh);
+        p[1] = __builtin_bit_cast(unsigned short, bm);
+        p[2] = __builtin_bit_cast(unsigned short, bl);
+    }
+};
+
+struct SplitF16x3 {
+    static constexpr int ID = CSEG_ARITH_F16X3;
+    static constexpr int NP = 2, NTERMS = 3;
+    static constexpr bool SCALED = true;
+    typedef f16x8 frag_t;
+    __host__ __device__ static constexpr int ta(int t) { return t == 0 ? 1 : 0; }
+    __host__ __device__ static constexpr int tb(int t) { return t == 1 ? 1 : 0; }
+    __device__ static __forceinline__ f32x4 mfma(frag_t a, frag_t b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ void split(float v, float scale, unsigned short (&p)[2]) {
+        const float t = v * scale;                 // exact (power of two)
+        const _Float16 h = (_Float16)t;
+        const _Float16 l = (_Float16)(t - (float)h);
+        p[0] = __builtin_bit_cast(unsigned short, h);
+        p[1] = __builtin_bit_cast(unsigned short, l);
+    }
+};
+
+// eight values -> AR::NP cells of 16 bytes (element j of piece p in half-word j of out[p])
+template <class AR>
+__device__ __forceinline__ void split_cells8(const float (&v)[8], float scale, uint4 (&out)[AR::NP]) {
+    unsigned short s[8][AR::NP];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) AR::split(v[j], scale, s[j]);
+#pragma unroll
+    for (int p = 0; p < AR::NP; ++p)
+        out[p] = make_uint4(s[0][p] | ((unsigned)s[1][p] << 16), s[2][p] | ((unsigned)s[3][p] << 16),
+                            s[4][p] | ((unsigned)s[5][p] << 16), s[6][p] | ((unsigned)s[7][p] << 16));
+}
+
+// four values -> AR::NP cells of 8 bytes
+template <class AR>
+__device__ __forceinline__ void split_cells4(const float4& v, float scale, uint2 (&out)[AR::NP]) {
+    unsigned short s[4][AR::NP];
+    AR::split(v.x, scale, s[0]);
+    AR::split(v.y, scale, s[1]);
+    AR::split(v.z, scale, s[2]);
+    AR::split(v.w, scale, s[3]);
+#pragma unroll
+    for (int p = 0; p < AR::NP; ++p) out[p] = make_uint2(s[0][p] | ((unsigned)s[1][p] << 16), s[2][p] | ((unsigned)s[3][p] << 16));
+}

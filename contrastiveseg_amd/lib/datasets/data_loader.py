@@ -62,17 +62,48 @@ class FolderSource(object):
         self.batch_size, self.shuffle, self.drop_last = batch_size, shuffle, drop_last
         self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
         self.epoch = 0
+        self.seed = configer.get('seed') if configer.exists('seed') and configer.get('seed') is not None else 0
+
+    def set_epoch(self, epoch):
+        """torch.utils.data.DistributedSampler.set_epoch: the permutation of an epoch is a function of (seed, epoch) only."""
+        self.epoch = int(epoch)
+
+    def shard(self, epoch=None):
+        """This rank's sample indices for one epoch, the way the reference's DistributedSampler (lib/datasets/data_loader.py:81-82
+        of the reference -> torch.utils.data.distributed.DistributedSampler) produces them: a permutation drawn from a PRIVATE
+        generator seeded with seed + epoch (identical on every rank, untouched by the randperm calls of the anchor sampling / the
+        memory bank, which advance the global CPU generator by rank-dependent amounts), cut to a multiple of world x batch when
+        drop_last (train), padded by wrapping around otherwise, so that every rank yields the same number of batches (a rank with
+        fewer forward calls would hang DDP's collectives), then strided by rank."""
+        n, world, rank = len(self.pairs), get_world_size(), get_rank()
+        epoch = self.epoch if epoch is None else epoch
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(int(self.seed) + int(epoch))
+            order = torch.randperm(n, generator=g).tolist()
+        else:
+            order = list(range(n))
+        chunk = world * self.batch_size
+        if self.drop_last:
+            order = order[:(n // chunk) * chunk]
+        else:
+            total = ((n + world - 1) // world) * world
+            order = order + order[:total - n]              # n >= 1, total - n < world <= ... wraps once at most for n >= world
+            while len(order) < total:
+                order = order + order[:total - len(order)]
+        return order[rank::world]
 
     def __len__(self):
-        n = len(self.pairs) // get_world_size()
-        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+        n, world = len(self.pairs), get_world_size()
+        if self.drop_last:
+            return n // (world * self.batch_size)
+        per_rank = (n + world - 1) // world
+        return (per_rank + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
-        n = len(self.pairs)
-        order = torch.randperm(n).tolist() if self.shuffle else list(range(n))
-        order = order[get_rank()::get_world_size()]
-        self.epoch += 1
-        for i in range(0, len(order) - (self.batch_size - 1 if self.drop_last else 0), self.batch_size):
+        order = self.shard()
+        self.epoch += 1                                    # a caller that never calls set_epoch still gets a new permutation
+        for i in range(0, len(order), self.batch_size):
             items = list(self.pool.map(lambda k: _decode(self.pairs[k], self.bgr), order[i:i + self.batch_size]))
             if len({it[0].shape for it in items}) != 1:
                 raise RuntimeError('images of one batch differ in size; the accelerated loader needs a common size')
@@ -115,7 +146,8 @@ class GPUAugLoader(object):
     def __init__(self, configer, source, device, split='train'):
         self.source, self.device = source, device
         self.transform = GPUBatchTransform(configer, split)
-        self.sampler = None
+        # the trainer calls `loader.sampler.set_epoch(epoch)` like the reference does (trainer_contrastive.py:183-184)
+        self.sampler = source if hasattr(source, 'set_epoch') else None
         self._stream = None
 
     def __len__(self):

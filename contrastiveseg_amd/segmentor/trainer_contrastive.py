@@ -302,7 +302,6 @@ class Trainer(object):
         self.seg_net.eval()
         self.pixel_loss.eval()
         score = RunningScore(self.configer, ignore_index=-1)
-        seen = False
         for data_dict in (self.val_loader if data_loader is None else data_loader):
             (inputs, targets), batch_size = self.data_helper.prepare_data(data_dict)
             outputs = self.seg_net(*inputs, is_eval=True)
@@ -310,7 +309,10 @@ class Trainer(object):
             seg = nn.functional.interpolate(outputs['seg'], size=targets.shape[-2:], mode='bilinear',
                                             align_corners=True)
             score.update(seg.argmax(1), targets)
-            seen = True
+        # every rank joins the all-reduce, whether or not its validation shard held a batch (a rank that skipped it would
+        # leave the others waiting); "was anything validated" is then read off the REDUCED matrix, identically on all ranks
+        score.reduce_scores()
+        seen = float(score.reduced_confusion_matrix.sum()) > 0
         if seen:
             miou = float(score.get_mean_iou())
             self.last_val_score = score

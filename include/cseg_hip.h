@@ -286,6 +286,39 @@ int cseg_conv1x1_sb_wrw(const float* x, const float* dy, int B, int Cin, int Cou
                         cseg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Round 3 (ABI 3): the split-operand convolutions with a selectable arithmetic.  Same operators, same layouts, same reference
+ * sites as the cseg_conv3x3_sb_* / cseg_conv1x1_sb_* entry points above (nn.Conv2d -> cuDNN/MIOpen fp32 in the reference:
+ * lib/models/nets/hrnet.py:72-77, lib/models/backbones/hrnet/hrnet_backbone.py:35-66, lib/models/modules/projection.py:18-20);
+ * those are now wrappers with arith = CSEG_ARITH_BF16X6.
+ *   CSEG_ARITH_BF16X6  three bf16 pieces per operand, six MFMAs per product (roof 2500/6 = 417 TFLOP/s fp32-equivalent)
+ *   CSEG_ARITH_F16X3   two fp16 pieces of the operand scaled by a power of two, three MFMAs per product (roof 833 TFLOP/s);
+ *                      same fp32-class accuracy (csrc/cseg_split.h).  The scale comes from max|tensor|, which the caller
+ *                      supplies as a DEVICE pointer to the bit pattern of that float (one uint32; cseg_amax_f32 accumulates
+ *                      it with atomicMax into a word the caller has zeroed; several tensors may share one word).  With
+ *                      BF16X6 the amax pointers may be NULL.
+ * pack and forward / weight gradient of one operator must use the same arith (and nt).  nt = 0: the library's tiling.
+ * ------------------------------------------------------------------------------------------------ */
+#define CSEG_ARITH_BF16X6 0
+#define CSEG_ARITH_F16X3 1
+int cseg_amax_f32(const float* x, long n, unsigned* amax_bits, cseg_stream_t stream);
+size_t cseg_conv3x3_split_packed_bytes(int arith, int Cin, int Cout);
+int cseg_conv3x3_split_pack(const float* w, int Cout, int Cin, int transpose_flip, int nt, int arith, const unsigned* amax_w,
+                            void* wp, cseg_stream_t stream);
+int cseg_conv3x3_split_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int nt,
+                           int arith, const unsigned* amax_x, const unsigned* amax_w, float* y, cseg_stream_t stream);
+/* ws: cseg_conv3x3_sb_wrw_ws_floats(...) */
+int cseg_conv3x3_split_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, int arith,
+                           const unsigned* amax_x, const unsigned* amax_dy, float* ws, float* dw, cseg_stream_t stream);
+size_t cseg_conv1x1_split_packed_bytes(int arith, int Cin, int Cout);
+int cseg_conv1x1_split_pack(const float* w, int Cout, int Cin, int transpose, int arith, const unsigned* amax_w, void* wp,
+                            cseg_stream_t stream);
+int cseg_conv1x1_split_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int HW, int arith,
+                           const unsigned* amax_x, const unsigned* amax_w, float* y, cseg_stream_t stream);
+/* ws: cseg_conv1x1_sb_wrw_ws_floats(...) */
+int cseg_conv1x1_split_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int HW, int arith, const unsigned* amax_x,
+                           const unsigned* amax_dy, float* ws, float* dw, cseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * GPU data pipeline: random resize (cv2 INTER_CUBIC image / INTER_NEAREST label) -> random
  * crop -> horizontal flip -> brightness shift -> ToTensor + Normalize(div, mean, std) + label look-up + ReLabel(255,-1)
  * -> collate padding to the fixed input size, as ONE kernel over the output batch.  Replaces the per-sample CPU chain

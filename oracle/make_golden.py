@@ -58,6 +58,20 @@ LOSS_CASES = {
                       loss="contrast_ce_loss",
                       contrast=dict(max_samples=1024, max_views=100, temperature=0.1, loss_weight=0.1),
                       ce_weight=CITYSCAPES_W, grads="subset", torch_seed=304),
+    # BASELINE.json configs[3] / [4] criteria (row g of the coverage table): FSAuxCELoss + the memory-bank contrast term. The
+    # reference registers no such criterion (its loss_contrast_mem.ContrastAuxCELoss is broken), so the
+    # golden COMPOSES the reference's own pieces (RefMemAuxCE below): DeepLab feature size 65x129 with the 4104-column bank of
+    # configs/cityscapes/R_101_D_8_MEM.json, and the OCR / COCO-Stuff shape 130x130 with 171 classes.
+    "mem_aux_deeplab": dict(seed=18, B=2, K=19, H=512, W=1024, stride=8, D=64, blocky=True, n_rect=24, hw=(65, 129),
+                            loss="mem_contrast_auxce_loss",
+                            contrast=dict(max_samples=1024, max_views=1, temperature=0.07, loss_weight=1.0,
+                                          with_memory=True, memory_size=108, pixel_update_freq=10),
+                            ce_weight=CITYSCAPES_W, grads=True, torch_seed=304),
+    "mem_aux_ocr": dict(seed=19, B=2, K=171, H=520, W=520, stride=4, D=64, blocky=True, n_rect=10, hw=(130, 130),
+                        loss="mem_contrast_auxce_loss",
+                        contrast=dict(max_samples=1024, max_views=4, temperature=0.07, loss_weight=1.0,
+                                      with_memory=True, memory_size=8, pixel_update_freq=10),
+                        ce_weight=None, grads="subset", torch_seed=11),
     "cfg2_uniform": dict(seed=305, B=8, K=19, H=512, W=1024, stride=4, D=256, blocky=False,
                          loss="contrast_ce_loss",
                          contrast=dict(max_samples=1024, max_views=100, temperature=0.1, loss_weight=0.1),
@@ -78,9 +92,9 @@ def case_inputs(c):
         embed = (e / np.sqrt((e.astype(np.float64) ** 2).sum(1, keepdims=True))).astype(np.float32)
     extra = {}
     rs = np.random.RandomState(c["seed"] + 2000)
-    if c["loss"] == "contrast_auxce_loss":
+    if c["loss"] in ("contrast_auxce_loss", "mem_contrast_auxce_loss"):
         extra["seg_aux"] = (seg * 0.5 + rs.standard_normal(seg.shape) * 1.0).astype(np.float32)
-    if c["loss"] == "mem_contrast_ce_loss":
+    if c["loss"].startswith("mem_"):
         ms = c["contrast"]["memory_size"]
         for name in ("segment_queue", "pixel_queue"):
             q = rs.standard_normal((c["K"], ms, c["D"])).astype(np.float32)
@@ -88,13 +102,45 @@ def case_inputs(c):
     return target, seg, embed, extra
 
 
+def ref_mem_auxce(cfg):
+    """FSAuxCELoss + memory-bank PixelContrastLoss, composed from the reference's own classes exactly as its two registered
+    criteria compose theirs: the segmentation part of lib/loss/loss_contrast.py:ContrastAuxCELoss.forward (:213-234: both
+    heads upsampled to the label size, FSAuxCELoss([aux, seg])) and the contrast part of
+    lib/loss/loss_contrast_mem.py:ContrastCELoss.forward (:198-231: queue = cat(segment, pixel), predict = argmax seg)."""
+    import torch
+    import torch.nn.functional as F
+    from lib.loss.loss_helper import FSAuxCELoss
+    from lib.loss.loss_contrast_mem import PixelContrastLoss
+
+    class RefMemAuxCE(torch.nn.Module):
+        def __init__(self):
+            super(RefMemAuxCE, self).__init__()
+            self.loss_weight = cfg.get('contrast', 'loss_weight')
+            self.seg_criterion = FSAuxCELoss(configer=cfg)
+            self.contrast_criterion = PixelContrastLoss(configer=cfg)
+
+        def forward(self, preds, target, with_embed=False):
+            h, w = target.size(1), target.size(2)
+            seg, seg_aux = preds['seg'], preds['seg_aux']
+            pred = F.interpolate(input=seg, size=(h, w), mode='bilinear', align_corners=True)
+            pred_aux = F.interpolate(input=seg_aux, size=(h, w), mode='bilinear', align_corners=True)
+            loss = self.seg_criterion([pred_aux, pred], target)
+            queue = torch.cat((preds['segment_queue'], preds['pixel_queue']), dim=1)
+            _, predict = torch.max(seg, 1)
+            loss_contrast = self.contrast_criterion(preds['embed'], target, predict, queue)
+            if with_embed is True:
+                return loss + self.loss_weight * loss_contrast
+            return loss + 0 * loss_contrast
+    return RefMemAuxCE()
+
+
 def run_loss_case(name, c):
     import torch
     ref_shim.install()
     from lib.loss.loss_manager import SEG_LOSS_DICT
-    cfg = ref_shim.configer(num_classes=c["K"], loss_type=c["loss"], contrast=c["contrast"],
-                            ce_weight=c["ce_weight"])
-    crit = SEG_LOSS_DICT[c["loss"]](cfg)
+    cfg = ref_shim.configer(num_classes=c["K"], loss_type=c["loss"] if c["loss"] in SEG_LOSS_DICT else "mem_contrast_ce_loss",
+                            contrast=c["contrast"], ce_weight=c["ce_weight"])
+    crit = ref_mem_auxce(cfg) if c["loss"] == "mem_contrast_auxce_loss" else SEG_LOSS_DICT[c["loss"]](cfg)
     target, seg, embed, extra = case_inputs(c)
     t_target = torch.from_numpy(target)
     t_seg = torch.from_numpy(seg).requires_grad_(True)
@@ -119,7 +165,7 @@ def run_loss_case(name, c):
         h, w = seg.shape[-2:]
         _, predict = torch.max(t_seg, 1)
         torch.manual_seed(c["torch_seed"])
-        if c["loss"] == "mem_contrast_ce_loss":
+        if c["loss"].startswith("mem_"):
             queue = torch.cat((preds["segment_queue"], preds["pixel_queue"]), dim=1)
             lc = crit.contrast_criterion(t_embed, t_target, predict, queue)
         else:
@@ -151,6 +197,8 @@ def run_loss_case(name, c):
         out["d_embed_rows_s%d" % GRAD_ROW_STEP] = g[img, :, pix]
         out["d_embed_abs_sum"] = float(np.abs(t_embed.grad.numpy().astype(np.float64)).sum())
         out["d_seg_abs_sum"] = float(np.abs(t_seg.grad.numpy().astype(np.float64)).sum())
+        if "seg_aux" in leaves:
+            out["d_seg_aux_s%d" % GRAD_SEG_STEP] = leaves["seg_aux"].grad.numpy()[:, :, ::GRAD_SEG_STEP, ::GRAD_SEG_STEP].copy()
     elif c["grads"]:
         out["d_seg"] = t_seg.grad.numpy()
         g = t_embed.grad.numpy().reshape(embed.shape[0], embed.shape[1], -1)

@@ -20,7 +20,7 @@ def lib():
             pytest.skip(str(e))
         _LIB = ctypes.CDLL(path)
         for name in ("cseg_conv3x3_sb_packed_bytes", "cseg_conv1x1_sb_packed_bytes", "cseg_conv3x3_sb_wrw_ws_floats",
-                     "cseg_conv1x1_sb_wrw_ws_floats"):
+                     "cseg_conv1x1_sb_wrw_ws_floats", "cseg_conv3x3_split_packed_bytes", "cseg_conv1x1_split_packed_bytes"):
             getattr(_LIB, name).restype = ctypes.c_size_t
         _LIB.cseg_last_error.restype = ctypes.c_char_p
     return _LIB
@@ -78,10 +78,33 @@ def call(name, *args):
 
 
 # ---- entry points ------------------------------------------------------------------------------------------------------
-def conv3x3_sb(x, w, bias=None, transpose_flip=False, nt=0):
+BF16X6, F16X3 = 0, 1
+
+
+def amax(a):
+    """max|a| as the library hands it around: one uint32 holding the bit pattern, accumulated by cseg_amax_f32."""
+    out = aligned((4,), np.uint32, 0)
+    d = dev(a)
+    call("cseg_amax_f32", ptr(d), ctypes.c_long(d.size), ptr(out), None)
+    assert out[0] == np.abs(a.astype(np.float32)).max().view(np.uint32), (out[0], np.abs(a).max())
+    return out
+
+
+def conv3x3_sb(x, w, bias=None, transpose_flip=False, nt=0, arith=None):
     co, ci = w.shape[:2]
     conv_in, conv_out = (co, ci) if transpose_flip else (ci, co)
     B, _, H, W = x.shape
+    if arith is not None:                      # the round-3 entry points (selectable arithmetic)
+        n = lib().cseg_conv3x3_split_packed_bytes(arith, conv_in, conv_out)
+        assert n > 0
+        wp = aligned((n,), np.uint8, 0xFF)
+        y = aligned((B, conv_out, H, W))
+        xd, wd, bd = dev(x), dev(w), (None if bias is None else dev(bias))
+        ax, aw = (amax(x), amax(w)) if arith == F16X3 else (None, None)
+        call("cseg_conv3x3_split_pack", ptr(wd), co, ci, int(transpose_flip), nt, arith, ptr(aw), ptr(wp), None)
+        call("cseg_conv3x3_split_fwd", ptr(xd), ptr(wp), ptr(bd), B, conv_in, conv_out, H, W, nt, arith, ptr(ax), ptr(aw), ptr(y),
+             None)
+        return y
     n = lib().cseg_conv3x3_sb_packed_bytes(conv_in, conv_out)
     assert n > 0
     wp = aligned((n,), np.uint8, 0xFF)
@@ -96,20 +119,34 @@ def conv3x3_sb(x, w, bias=None, transpose_flip=False, nt=0):
     return y
 
 
-def conv3x3_sb_wrw(x, dy):
+def conv3x3_sb_wrw(x, dy, arith=None):
     B, ci, H, W = x.shape
     co = dy.shape[1]
     n = lib().cseg_conv3x3_sb_wrw_ws_floats(B, ci, co, H, W)
     assert n > 0
     ws, dw = aligned((n,)), aligned((co, ci, 3, 3))
+    if arith is not None:
+        ax, ad = (amax(x), amax(dy)) if arith == F16X3 else (None, None)
+        call("cseg_conv3x3_split_wrw", ptr(dev(x)), ptr(dev(dy)), B, ci, co, H, W, arith, ptr(ax), ptr(ad), ptr(ws), ptr(dw), None)
+        return dw
     call("cseg_conv3x3_sb_wrw", ptr(dev(x)), ptr(dev(dy)), B, ci, co, H, W, ptr(ws), ptr(dw), None)
     return dw
 
 
-def conv1x1_sb(x, w, bias=None, transpose=False):
+def conv1x1_sb(x, w, bias=None, transpose=False, arith=None):
     co, ci = w.shape[:2]
     conv_in, conv_out = (co, ci) if transpose else (ci, co)
     B, _, H, W = x.shape
+    if arith is not None:
+        n = lib().cseg_conv1x1_split_packed_bytes(arith, conv_in, conv_out)
+        assert n > 0
+        wp = aligned((n,), np.uint8, 0xFF)
+        y = aligned((B, conv_out, H, W))
+        ax, aw = (amax(x), amax(w)) if arith == F16X3 else (None, None)
+        call("cseg_conv1x1_split_pack", ptr(dev(w)), co, ci, int(transpose), arith, ptr(aw), ptr(wp), None)
+        call("cseg_conv1x1_split_fwd", ptr(dev(x)), ptr(wp), ptr(None if bias is None else dev(bias)), B, conv_in, conv_out, H * W,
+             arith, ptr(ax), ptr(aw), ptr(y), None)
+        return y
     n = lib().cseg_conv1x1_sb_packed_bytes(conv_in, conv_out)
     assert n > 0
     wp = aligned((n,), np.uint8, 0xFF)
@@ -120,12 +157,16 @@ def conv1x1_sb(x, w, bias=None, transpose=False):
     return y
 
 
-def conv1x1_sb_wrw(x, dy):
+def conv1x1_sb_wrw(x, dy, arith=None):
     B, ci, H, W = x.shape
     co = dy.shape[1]
     n = lib().cseg_conv1x1_sb_wrw_ws_floats(B, ci, co, H * W)
     assert n > 0
     ws, dw = aligned((n,)), aligned((co, ci, 1, 1))
+    if arith is not None:
+        ax, ad = (amax(x), amax(dy)) if arith == F16X3 else (None, None)
+        call("cseg_conv1x1_split_wrw", ptr(dev(x)), ptr(dev(dy)), B, ci, co, H * W, arith, ptr(ax), ptr(ad), ptr(ws), ptr(dw), None)
+        return dw
     call("cseg_conv1x1_sb_wrw", ptr(dev(x)), ptr(dev(dy)), B, ci, co, H * W, ptr(ws), ptr(dw), None)
     return dw
 

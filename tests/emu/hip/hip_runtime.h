@@ -120,6 +120,25 @@ static inline emu_f32x4 emu_mfma_f32_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, e
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_f32_16x16x32_bf16
 
+// v_mfma_f32_16x16x32_f16: same operand layout; fp16 products are exact in fp32 (11 x 11 bits), fp32 accumulation in k order
+typedef _Float16 emu_f16x8 __attribute__((ext_vector_type(8)));
+static inline emu_f32x4 emu_mfma_f32_16x16x32_f16(emu_f16x8 a, emu_f16x8 b, emu_f32x4 c, int, int, int) {
+    struct Ops { emu_f16x8 a, b; } mine{a, b};
+    const unsigned char* all = emu::wave_exchange(&mine, sizeof(Ops));
+    const int lane = emu::lane_id(), j = lane & 15, g = lane >> 4;
+    emu_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k)
+            acc += (float)emu::slot<Ops>(all, i + 16 * (k >> 3)).a[k & 7] * (float)emu::slot<Ops>(all, j + 16 * (k >> 3)).b[k & 7];
+        d[r] = acc;
+    }
+    emu::wave_release();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16 emu_mfma_f32_16x16x32_f16
+
 static inline unsigned emu_alignbit(unsigned hi, unsigned lo, unsigned shift) {
     return (unsigned)((((uint64_t)hi << 32) | lo) >> (shift & 31));
 }
@@ -171,6 +190,11 @@ static inline V4 emu_mfma_f32_16x16x4f32(float a, float b, V4 c, int, int, int) 
 // atomics: blocks run concurrently on several OS threads, the threads of one block never do
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicMax(unsigned* p, unsigned v) {
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 template <class F, class I>
 static inline F emu_atomic_add_fp(F* p, F v) {

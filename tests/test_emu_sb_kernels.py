@@ -168,3 +168,83 @@ def test_head_width_weight_gradient(version, monkeypatch):
     ref = E.ref_conv3x3_wrw(x, dy)
     assert not np.isnan(dw).any()
     assert np.abs(dw - ref).max() <= _bound(ref, 3 * 64)
+
+
+# ---- round 3: the same kernels through the selectable-arithmetic entry points (cseg_*_split_*) -------------------------------
+# f16x3 = two scaled fp16 pieces, three MFMAs per product. The operands get magnitudes far from 1 (activations ~1e3, gradients
+# ~1e-7) so that a wrong or missing power-of-two scale shows: unscaled fp16 would overflow / flush them.
+ARITHS = [E.BF16X6, E.F16X3]
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+@pytest.mark.parametrize("case,var", [(FWD_CASES[0], "auto"), (FWD_CASES[1], "auto"), (FWD_CASES[2], "auto"), (FWD_CASES[0], "1")])
+def test_split_conv3x3_forward_and_backward_data(case, var, arith, wave_order, monkeypatch):
+    if var != "auto":
+        monkeypatch.setenv("CSEG_CONV3X3_SB_VAR", var)
+    B, ci, co, H, W = case
+    x, w, b = _rand((B, ci, H, W), 31, 1e3), _rand((co, ci, 3, 3), 32, 1e-4 / (3 * ci ** 0.5)), _rand((co,), 33, 0.1)
+    y = E.conv3x3_sb(x, w, b, arith=arith)
+    ref = E.ref_conv3x3(x, w, b)
+    assert not np.isnan(y).any()
+    assert np.abs(y - ref).max() <= _bound(ref, 9 * ci)
+    if ci % 48 == 0 and co % 16 == 0:
+        dy = _rand((B, co, H, W), 34, 1e-7)
+        dx = E.conv3x3_sb(dy, w, None, transpose_flip=True, arith=arith)
+        ref = E.ref_conv3x3_bwd_data(dy, w)
+        assert np.abs(dx - ref).max() <= 3e-6 * np.sqrt(9 * co) * float(np.abs(ref).max())
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+@pytest.mark.parametrize("case", WRW_CASES)
+def test_split_conv3x3_weight_gradient(case, arith, wave_order):
+    B, ci, co, H, W = case
+    x, dy = _rand((B, ci, H, W), 37, 50.0), _rand((B, co, H, W), 38, 1e-6)
+    dw = E.conv3x3_sb_wrw(x, dy, arith=arith)
+    ref = E.ref_conv3x3_wrw(x, dy)
+    assert not np.isnan(dw).any()
+    assert np.abs(dw - ref).max() <= 3e-6 * np.sqrt(B * H * W) * float(np.abs(ref).max())
+
+
+@pytest.mark.parametrize("case", [(1, 192, 192, 4, 64), (1, 96, 192, 4, 64)])
+def test_split_weight_gradient_group_order(case, wave_order):
+    """several channel blocks each way: the XCD-aware block order (groups of SC x SI channel blocks) covers every block once."""
+    B, ci, co, H, W = case
+    x, dy = _rand((B, ci, H, W), 41), _rand((B, co, H, W), 42)
+    ref = E.ref_conv3x3_wrw(x, dy)
+    for arith in ARITHS:
+        dw = E.conv3x3_sb_wrw(x, dy, arith=arith)
+        assert not np.isnan(dw).any()
+        assert np.abs(dw - ref).max() <= _bound(ref, B * H * W)
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+@pytest.mark.parametrize("case", ONE_CASES)
+def test_split_conv1x1(case, arith, wave_order):
+    B, ci, co, H, W = case
+    x, w, b = _rand((B, ci, H, W), 43, 300.0), _rand((co, ci, 1, 1), 44, 1e-3 / ci ** 0.5), _rand((co,), 45, 0.1)
+    y = E.conv1x1_sb(x, w, b, arith=arith)
+    ref = np.einsum("bchw,oc->bohw", x.astype(np.float64), w[:, :, 0, 0].astype(np.float64)) + b.astype(np.float64)[None, :, None, None]
+    assert not np.isnan(y).any()
+    assert np.abs(y - ref).max() <= _bound(ref, ci)
+    if not (ci % 48 and ci % 64):
+        dy = _rand((B, co, H, W), 46, 1e-8)
+        dx = E.conv1x1_sb(dy, w, None, transpose=True, arith=arith)
+        ref = np.einsum("bohw,oc->bchw", dy.astype(np.float64), w[:, :, 0, 0].astype(np.float64))
+        assert np.abs(dx - ref).max() <= 3e-6 * np.sqrt(co) * float(np.abs(ref).max())
+    if (H * W) % 32 == 0:
+        dy = _rand((B, co, H, W), 47, 1e-5)
+        dw = E.conv1x1_sb_wrw(x, dy, arith=arith)
+        ref = np.einsum("bohw,bchw->oc", dy.astype(np.float64), x.astype(np.float64)).reshape(co, ci, 1, 1)
+        assert np.abs(dw - ref).max() <= 3e-6 * np.sqrt(B * H * W) * float(np.abs(ref).max())
+
+
+def test_f16x3_error_is_fp32_class():
+    """Same operands through both arithmetics: the f16x3 error vs float64 stays within 2x of the bf16x6 error plus the fp32
+    accumulation floor (the two share the accumulation order; what differs is the 2^-22 vs 2^-24 operand representation)."""
+    B, ci, co, H, W = 1, 144, 48, 4, 64
+    x, w = _rand((B, ci, H, W), 51), _rand((co, ci, 3, 3), 52, 1.0 / (3 * ci ** 0.5))
+    ref = E.ref_conv3x3(x, w)
+    e6 = np.abs(E.conv3x3_sb(x, w, None, arith=E.BF16X6) - ref).max()
+    e3 = np.abs(E.conv3x3_sb(x, w, None, arith=E.F16X3) - ref).max()
+    x32 = np.abs(E.ref_conv3x3(x, w).astype(np.float32) - ref).max()         # one fp32 rounding of the exact result
+    assert e3 <= 2.0 * e6 + 4.0 * x32, (e3, e6, x32)

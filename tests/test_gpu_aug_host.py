@@ -192,3 +192,41 @@ def test_folder_loader_feeds_the_trainer_on_cpu(tmp_path, monkeypatch):
     from oracle import cpu_port
     cpu_port.install(monkeypatch)
     run_folder_trainer(tmp_path, cpu=True)
+
+
+# ---- sharding of the file list across ranks (private, epoch-seeded generator; equal shard lengths) ----------------
+def test_folder_source_shards_like_distributed_sampler(monkeypatch):
+    import torch
+    from contrastiveseg_amd.lib.datasets import data_loader as DL
+
+    def source(rank, world, n, bs, shuffle, drop_last):
+        src = DL.FolderSource.__new__(DL.FolderSource)
+        src.pairs, src.batch_size, src.shuffle, src.drop_last = [("i%d" % k, "l%d" % k) for k in range(n)], bs, shuffle, drop_last
+        src.epoch, src.seed = 0, 304
+        monkeypatch.setattr(DL, "get_rank", lambda: rank)
+        monkeypatch.setattr(DL, "get_world_size", lambda: world)
+        return src
+
+    n, world, bs = 2975, 4, 2                                  # Cityscapes train on 4 ranks: 2975 % 8 != 0
+    shards = []
+    for rank in range(world):
+        src = source(rank, world, n, bs, True, True)
+        torch.manual_seed(rank * 7919)                         # the global generator differs per rank (anchor sampling, bank)
+        torch.randperm(1000 + rank)
+        shards.append(src.shard(epoch=3))
+        assert len(src) == n // (world * bs) == len(shards[-1]) // bs
+    assert len({len(s) for s in shards}) == 1                  # every rank: the same number of batches
+    flat = [k for s in shards for k in s]
+    assert len(flat) == len(set(flat)) == (n // (world * bs)) * world * bs          # disjoint, only the tail is dropped
+    src = source(0, world, n, bs, True, True)
+    assert src.shard(epoch=3) == shards[0] and src.shard(epoch=4) != shards[0]     # function of (seed, epoch) only
+    g = torch.Generator()
+    g.manual_seed(304 + 3)
+    assert shards[1] == torch.randperm(n, generator=g).tolist()[:(n // (world * bs)) * world * bs][1::world]
+    # validation: nothing dropped, ranks padded to equal length by wrapping around (DistributedSampler's default)
+    val = [source(r, 4, 10, 2, False, False).shard() for r in range(4)]
+    assert [len(v) for v in val] == [3, 3, 3, 3] and set(k for v in val for k in v) == set(range(10))
+    assert all(len(source(r, 4, 10, 2, False, False)) == 2 for r in range(4))
+    it = source(0, 1, 5, 2, True, False)
+    it.set_epoch(9)
+    assert it.epoch == 9

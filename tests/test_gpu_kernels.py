@@ -89,6 +89,9 @@ def test_criterion_matches_reference_golden(name, golden_dir):
         ref = g["d_embed_rows_s%d" % GRAD_ROW_STEP]
         assert np.allclose(rows, ref, rtol=GRAD_RTOL, atol=GRAD_ATOL), np.abs(rows - ref).max()
         assert abs(np.abs(ge.astype(np.float64)).sum() - float(g["d_embed_abs_sum"])) <= 1e-4 * float(g["d_embed_abs_sum"])
+        if "seg_aux" in extra:
+            sub = preds["seg_aux"].grad.cpu().numpy()[:, :, ::GRAD_SEG_STEP, ::GRAD_SEG_STEP]
+            assert np.allclose(sub, g["d_seg_aux_s%d" % GRAD_SEG_STEP], rtol=GRAD_RTOL, atol=GRAD_ATOL)
         return
     # gradients
     d_seg = t_seg.grad.cpu().numpy()

@@ -25,7 +25,7 @@ def run_oracle(c):
     cfg = oracle_cfg(c)
     rng = O.TorchCpuRng(c["torch_seed"])
     queue = None
-    mem = c["loss"] == "mem_contrast_ce_loss"
+    mem = c["loss"].startswith("mem_")
     if mem:
         queue = np.concatenate([extra["segment_queue"], extra["pixel_queue"]], axis=1)
     total, segments, n_view = O.contrast_ce_loss(seg, embed, target, cfg, rng,
