@@ -81,6 +81,10 @@ SIGNATURES = {
                                         _ptr]),
     "cseg_bn_fwd": (_c_int, [_ptr] * 4 + [_c_int] * 4 + [_ptr, _c_float, _c_float] + [_ptr] * 5 + [_ptr]),
     "cseg_bn_bwd": (_c_int, [_ptr] * 6 + [_c_int] * 5 + [_ptr] * 5 + [_ptr]),
+    "cseg_bn_fwd_amax": (_c_int, [_ptr] * 4 + [_c_int] * 4 + [_ptr, _c_float, _c_float] + [_ptr] * 5 + [_ptr, _ptr]),
+    "cseg_bn_bwd_amax": (_c_int, [_ptr] * 6 + [_c_int] * 5 + [_ptr] * 5 + [_ptr, _ptr]),
+    "cseg_bn_apply_amax": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
+    "cseg_bn_bwd_apply_amax": (_c_int, [_ptr] * 6 + [ctypes.c_double, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "cseg_bn_apply": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
     "cseg_bn_bwd_reduce": (_c_int, [_ptr] * 6 + [_c_int] * 4 + [_ptr] * 5 + [_ptr]),
     "cseg_bn_bwd_apply": (_c_int, [_ptr] * 6 + [ctypes.c_double, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),

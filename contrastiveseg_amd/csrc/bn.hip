@@ -175,6 +175,22 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     finalize_channel(moments[2 * c], moments[2 * c + 1], count, eps, momentum, running_mean, running_var, c, mean_invstd);
 }
 
+// max|value written| of the block -> *amax_out (bit pattern of a non-negative float, monotone as unsigned: the word the f16x3
+// convolutions scale their operands with, csrc/cseg_split.h). One atomic per block at most, and only when the block's maximum
+// exceeds what the word already holds (a stale read only costs a redundant atomic: the word never decreases).
+__device__ __forceinline__ unsigned abs_bits(float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; }
+__device__ __forceinline__ void publish_amax(unsigned m, unsigned* __restrict__ amax_out) {
+    __shared__ unsigned amax_red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(amax_red[0], amax_red[1]), max(amax_red[2], amax_red[3]));
+        if (m > *reinterpret_cast<volatile unsigned*>(amax_out)) atomicMax(amax_out, m);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // forward apply: y = act((x - mean) * (gamma * invstd) + beta [+ residual])
 // ---------------------------------------------------------------------------------------------------------
@@ -182,7 +198,7 @@ template <bool VEC, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                        const float* __restrict__ mean_invstd,
                                                        const float* __restrict__ weight, const float* __restrict__ bias,
-                                                       BnDims d, int relu, float* __restrict__ y) {
+                                                       BnDims d, int relu, float* __restrict__ y, unsigned* __restrict__ amax_out) {
     const int plane = blockIdx.x / d.n_ck, ck = blockIdx.x - plane * d.n_ck;
     const int c = plane % d.C;
     const float mean = mean_invstd[2 * c];
@@ -191,6 +207,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const size_t base = (size_t)plane * d.HW + (size_t)ck * CHUNK;
     const int len = min(CHUNK, d.HW - ck * CHUNK);
     const bool rl = relu != 0;      // NaN-propagating ReLU like torch's clamp: (v < 0) ? 0 : v
+    unsigned am = 0;
     if (VEC) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -207,15 +224,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                 o.x = (rl && o.x < 0.f) ? 0.f : o.x; o.y = (rl && o.y < 0.f) ? 0.f : o.y;
                 o.z = (rl && o.z < 0.f) ? 0.f : o.z; o.w = (rl && o.w < 0.f) ? 0.f : o.w;
                 *reinterpret_cast<float4*>(y + base + i) = o;
+                am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
             }
         }
     } else {
         for (int i = threadIdx.x; i < len; i += 256) {
             float o = fmaf(x[base + i] - mean, a, beta);
             if (RES) o += res[base + i];
-            y[base + i] = (rl && o < 0.f) ? 0.f : o;
+            o = (rl && o < 0.f) ? 0.f : o;
+            y[base + i] = o;
+            am = max(am, abs_bits(o));
         }
     }
+    if (amax_out) publish_amax(am, amax_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -307,7 +328,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean_invstd,
                                                            const float* __restrict__ weight,
                                                            const float* __restrict__ bias, const double* __restrict__ sums,
-                                                           double inv_count, BnDims d, float* __restrict__ dx) {
+                                                           double inv_count, BnDims d, float* __restrict__ dx, unsigned* __restrict__ amax_out) {
     const int plane = blockIdx.x / d.n_ck, ck = blockIdx.x - plane * d.n_ck;
     const int c = plane % d.C;
     const float mean = mean_invstd[2 * c], invstd = mean_invstd[2 * c + 1];
@@ -321,6 +342,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float k1 = sums ? (float)(sums[2 * c + 1] * inv_count * (double)invstd * (double)invstd) : 0.f;
     const size_t base = (size_t)plane * d.HW + (size_t)ck * CHUNK;
     const int len = min(CHUNK, d.HW - ck * CHUNK);
+    unsigned am = 0;
     if (VEC) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -337,6 +359,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 o.x = a * ((g.x - k0) - k0l - x0 * k1); o.y = a * ((g.y - k0) - k0l - x1 * k1);
                 o.z = a * ((g.z - k0) - k0l - x2 * k1); o.w = a * ((g.w - k0) - k0l - x3 * k1);
                 *reinterpret_cast<float4*>(dx + base + i) = o;
+                am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
             }
         }
     } else {
@@ -344,9 +367,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             float g = dy[base + i];
             const float xm = x[base + i] - mean;
             if (MASK) g = fmaf(xm, a, beta) > 0.f ? g : 0.f;
-            dx[base + i] = a * ((g - k0) - k0l - xm * k1);
+            const float o = a * ((g - k0) - k0l - xm * k1);
+            dx[base + i] = o;
+            am = max(am, abs_bits(o));
         }
     }
+    if (amax_out) publish_amax(am, amax_out);
 }
 
 
@@ -368,7 +394,7 @@ template <bool VEC, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_fused_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                              BnFinalize f, const float* __restrict__ weight,
                                                              const float* __restrict__ bias, BnDims d, int relu,
-                                                             float* __restrict__ y) {
+                                                             float* __restrict__ y, unsigned* __restrict__ amax_out) {
     __shared__ float mi[2];
     const int plane = blockIdx.x / d.n_ck, ck = blockIdx.x - plane * d.n_ck;
     const int c = plane % d.C;
@@ -403,6 +429,7 @@ __global__ __launch_bounds__(256) void bn_apply_fused_kernel(const float* __rest
     const size_t base = (size_t)plane * d.HW + (size_t)ck * CHUNK;
     const int len = min(CHUNK, d.HW - ck * CHUNK);
     const bool rl = relu != 0;
+    unsigned am = 0;
     if (VEC) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -419,15 +446,19 @@ __global__ __launch_bounds__(256) void bn_apply_fused_kernel(const float* __rest
                 o.x = (rl && o.x < 0.f) ? 0.f : o.x; o.y = (rl && o.y < 0.f) ? 0.f : o.y;
                 o.z = (rl && o.z < 0.f) ? 0.f : o.z; o.w = (rl && o.w < 0.f) ? 0.f : o.w;
                 *reinterpret_cast<float4*>(y + base + i) = o;
+                am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
             }
         }
     } else {
         for (int i = threadIdx.x; i < len; i += 256) {
             float o = fmaf(x[base + i] - mean, a, beta);
             if (RES) o += res[base + i];
-            y[base + i] = (rl && o < 0.f) ? 0.f : o;
+            o = (rl && o < 0.f) ? 0.f : o;
+            y[base + i] = o;
+            am = max(am, abs_bits(o));
         }
     }
+    if (amax_out) publish_amax(am, amax_out);
 }
 
 // backward twin: every bwd-apply block reduces the channel's partial sums itself; the publisher block writes
@@ -439,7 +470,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const float* __
                                                                  const float* __restrict__ bias,
                                                                  const float* __restrict__ partial, int training,
                                                                  BnDims d, float* __restrict__ d_weight,
-                                                                 float* __restrict__ d_bias, float* __restrict__ dx) {
+                                                                 float* __restrict__ d_bias, float* __restrict__ dx, unsigned* __restrict__ amax_out) {
     __shared__ float kk[3];            // k0 (hi), k1, k0 (lo): see bn_bwd_apply_kernel
     const int plane = blockIdx.x / d.n_ck, ck = blockIdx.x - plane * d.n_ck;
     const int c = plane % d.C;
@@ -470,6 +501,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const float* __
     const float k0 = kk[0], k1 = kk[1], k0l = kk[2];
     const size_t base = (size_t)plane * d.HW + (size_t)ck * CHUNK;
     const int len = min(CHUNK, d.HW - ck * CHUNK);
+    unsigned am = 0;
     if (VEC) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -486,6 +518,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const float* __
                 o.x = a * ((g.x - k0) - k0l - x0 * k1); o.y = a * ((g.y - k0) - k0l - x1 * k1);
                 o.z = a * ((g.z - k0) - k0l - x2 * k1); o.w = a * ((g.w - k0) - k0l - x3 * k1);
                 *reinterpret_cast<float4*>(dx + base + i) = o;
+                am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
             }
         }
     } else {
@@ -493,9 +526,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const float* __
             float g = dy[base + i];
             const float xm = x[base + i] - mean;
             if (MASK) g = fmaf(xm, a, beta) > 0.f ? g : 0.f;
-            dx[base + i] = a * ((g - k0) - k0l - xm * k1);
+            const float o = a * ((g - k0) - k0l - xm * k1);
+            dx[base + i] = o;
+            am = max(am, abs_bits(o));
         }
     }
+    if (amax_out) publish_amax(am, amax_out);
 }
 
 bool vec_ok(int HW, const void* p0, const void* p1 = nullptr, const void* p2 = nullptr, const void* p3 = nullptr) {
@@ -558,8 +594,8 @@ extern "C" int cseg_bn_stats_finalize(const float* x, int B, int C, int HW, floa
     return 1;
 }
 
-extern "C" int cseg_bn_apply(const float* x, const float* residual, const float* mean_invstd, const float* weight,
-                             const float* bias, int relu, int B, int C, int HW, float* y, cseg_stream_t stream_) {
+static int bn_apply_impl(const float* x, const float* residual, const float* mean_invstd, const float* weight,
+                         const float* bias, int relu, int B, int C, int HW, float* y, unsigned* amax_out, cseg_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!check_dims("bn_apply", B, C, HW)) return 0;
     CSEG_REQUIRE(x && mean_invstd && y, "bn_apply: null pointer");
@@ -567,7 +603,7 @@ extern "C" int cseg_bn_apply(const float* x, const float* residual, const float*
     const dim3 grid((unsigned)((long)B * C * d.n_ck));
     const bool v = vec_ok(HW, x, residual, y);
 #define LAUNCH(V, R) hipLaunchKernelGGL((bn_apply_kernel<V, R>), grid, dim3(256), 0, stream, x, residual, mean_invstd, \
-                                        weight, bias, d, relu, y)
+                                        weight, bias, d, relu, y, amax_out)
     if (v) { if (residual) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (residual) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
@@ -597,9 +633,9 @@ extern "C" int cseg_bn_bwd_reduce(const float* dy, const float* x, const float* 
     return 1;
 }
 
-extern "C" int cseg_bn_bwd_apply(const float* dy, const float* x, const float* mean_invstd, const float* weight,
-                                 const float* bias, const double* sums, double count, int mask_from_x, int B, int C,
-                                 int HW, float* dx, cseg_stream_t stream_) {
+static int bn_bwd_apply_impl(const float* dy, const float* x, const float* mean_invstd, const float* weight,
+                             const float* bias, const double* sums, double count, int mask_from_x, int B, int C,
+                             int HW, float* dx, unsigned* amax_out, cseg_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!check_dims("bn_bwd_apply", B, C, HW)) return 0;
     CSEG_REQUIRE(dy && x && mean_invstd && dx, "bn_bwd_apply: null pointer");
@@ -609,7 +645,7 @@ extern "C" int cseg_bn_bwd_apply(const float* dy, const float* x, const float* m
     const bool v = vec_ok(HW, dy, x, dx);
     const double inv = sums ? 1.0 / count : 0.0;
 #define LAUNCH(V, M) hipLaunchKernelGGL((bn_bwd_apply_kernel<V, M>), grid, dim3(256), 0, stream, dy, x, mean_invstd, weight, \
-                                        bias, sums, inv, d, dx)
+                                        bias, sums, inv, d, dx, amax_out)
     if (v) { if (mask_from_x) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (mask_from_x) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
@@ -618,9 +654,9 @@ extern "C" int cseg_bn_bwd_apply(const float* dy, const float* x, const float* m
 }
 
 // Single-rank training forward in two launches: statistics partials, then apply with the finalisation folded in.
-extern "C" int cseg_bn_fwd(const float* x, const float* residual, const float* weight, const float* bias, int relu, int B,
-                           int C, int HW, float* ws, float eps, float momentum, float* running_mean, float* running_var,
-                           int64_t* num_batches_tracked, float* mean_invstd, float* y, cseg_stream_t stream_) {
+static int bn_fwd_impl(const float* x, const float* residual, const float* weight, const float* bias, int relu, int B,
+                       int C, int HW, float* ws, float eps, float momentum, float* running_mean, float* running_var,
+                       int64_t* num_batches_tracked, float* mean_invstd, float* y, unsigned* amax_out, cseg_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!check_dims("bn_fwd", B, C, HW)) return 0;
     CSEG_REQUIRE(x && ws && mean_invstd && y, "bn_fwd: null pointer");
@@ -634,7 +670,7 @@ extern "C" int cseg_bn_fwd(const float* x, const float* residual, const float* w
     const dim3 grid((unsigned)((long)B * C * d.n_ck));
     const bool v = vec_ok(HW, x, residual, y);
 #define LAUNCH(V, R) hipLaunchKernelGGL((bn_apply_fused_kernel<V, R>), grid, dim3(256), 0, stream, x, residual, f, weight, \
-                                        bias, d, relu, y)
+                                        bias, d, relu, y, amax_out)
     if (v) { if (residual) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (residual) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
@@ -643,9 +679,9 @@ extern "C" int cseg_bn_fwd(const float* x, const float* residual, const float* w
 }
 
 // Single-rank backward in two launches (mode as in cseg_bn_bwd_reduce; training = 0: frozen statistics).
-extern "C" int cseg_bn_bwd(const float* dy, const float* x, const float* out, const float* mean_invstd,
-                           const float* weight, const float* bias, int mode, int training, int B, int C, int HW, float* ws,
-                           float* g_masked, float* d_weight, float* d_bias, float* dx, cseg_stream_t stream_) {
+static int bn_bwd_impl(const float* dy, const float* x, const float* out, const float* mean_invstd,
+                       const float* weight, const float* bias, int mode, int training, int B, int C, int HW, float* ws,
+                       float* g_masked, float* d_weight, float* d_bias, float* dx, unsigned* amax_out, cseg_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!check_dims("bn_bwd", B, C, HW)) return 0;
     CSEG_REQUIRE(dy && x && mean_invstd && ws, "bn_bwd: null pointer");
@@ -666,7 +702,7 @@ extern "C" int cseg_bn_bwd(const float* dy, const float* x, const float* out, co
         const dim3 grid((unsigned)((long)B * C * d.n_ck));
         const bool v = vec_ok(HW, g, x, dx);
 #define LAUNCH(V, M) hipLaunchKernelGGL((bn_bwd_apply_fused_kernel<V, M>), grid, dim3(256), 0, stream, g, x, mean_invstd, \
-                                        weight, bias, ws, training, d, d_weight, d_bias, dx)
+                                        weight, bias, ws, training, d, d_weight, d_bias, dx, amax_out)
         if (v) { if (mode == 1) LAUNCH(true, true); else LAUNCH(true, false); }
         else { if (mode == 1) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
@@ -677,4 +713,52 @@ extern "C" int cseg_bn_bwd(const float* dy, const float* x, const float* out, co
     }
     CSEG_CHECK_LAUNCH("bn_bwd");
     return 1;
+}
+
+// ---- the four apply-type entry points, plain and with max|output| accumulated into *amax_out (round 3: the word the f16x3
+// convolution that consumes the tensor scales it with; the caller zeroes it, cseg_amax_f32 semantics) ----------------------
+extern "C" int cseg_bn_apply(const float* x, const float* residual, const float* mean_invstd, const float* weight,
+                             const float* bias, int relu, int B, int C, int HW, float* y, cseg_stream_t stream_) {
+    return bn_apply_impl(x, residual, mean_invstd, weight, bias, relu, B, C, HW, y, nullptr, stream_);
+}
+extern "C" int cseg_bn_apply_amax(const float* x, const float* residual, const float* mean_invstd, const float* weight,
+                                  const float* bias, int relu, int B, int C, int HW, float* y, unsigned* amax_out,
+                                  cseg_stream_t stream_) {
+    return bn_apply_impl(x, residual, mean_invstd, weight, bias, relu, B, C, HW, y, amax_out, stream_);
+}
+extern "C" int cseg_bn_bwd_apply(const float* dy, const float* x, const float* mean_invstd, const float* weight,
+                                 const float* bias, const double* sums, double count, int mask_from_x, int B, int C,
+                                 int HW, float* dx, cseg_stream_t stream_) {
+    return bn_bwd_apply_impl(dy, x, mean_invstd, weight, bias, sums, count, mask_from_x, B, C, HW, dx, nullptr, stream_);
+}
+extern "C" int cseg_bn_bwd_apply_amax(const float* dy, const float* x, const float* mean_invstd, const float* weight,
+                                      const float* bias, const double* sums, double count, int mask_from_x, int B, int C,
+                                      int HW, float* dx, unsigned* amax_out, cseg_stream_t stream_) {
+    return bn_bwd_apply_impl(dy, x, mean_invstd, weight, bias, sums, count, mask_from_x, B, C, HW, dx, amax_out, stream_);
+}
+extern "C" int cseg_bn_fwd(const float* x, const float* residual, const float* weight, const float* bias, int relu, int B,
+                           int C, int HW, float* ws, float eps, float momentum, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, float* mean_invstd, float* y, cseg_stream_t stream_) {
+    return bn_fwd_impl(x, residual, weight, bias, relu, B, C, HW, ws, eps, momentum, running_mean, running_var,
+                       num_batches_tracked, mean_invstd, y, nullptr, stream_);
+}
+extern "C" int cseg_bn_fwd_amax(const float* x, const float* residual, const float* weight, const float* bias, int relu, int B,
+                                int C, int HW, float* ws, float eps, float momentum, float* running_mean, float* running_var,
+                                int64_t* num_batches_tracked, float* mean_invstd, float* y, unsigned* amax_out,
+                                cseg_stream_t stream_) {
+    return bn_fwd_impl(x, residual, weight, bias, relu, B, C, HW, ws, eps, momentum, running_mean, running_var,
+                       num_batches_tracked, mean_invstd, y, amax_out, stream_);
+}
+extern "C" int cseg_bn_bwd(const float* dy, const float* x, const float* out, const float* mean_invstd,
+                           const float* weight, const float* bias, int mode, int training, int B, int C, int HW, float* ws,
+                           float* g_masked, float* d_weight, float* d_bias, float* dx, cseg_stream_t stream_) {
+    return bn_bwd_impl(dy, x, out, mean_invstd, weight, bias, mode, training, B, C, HW, ws, g_masked, d_weight, d_bias, dx,
+                       nullptr, stream_);
+}
+extern "C" int cseg_bn_bwd_amax(const float* dy, const float* x, const float* out, const float* mean_invstd,
+                                const float* weight, const float* bias, int mode, int training, int B, int C, int HW, float* ws,
+                                float* g_masked, float* d_weight, float* d_bias, float* dx, unsigned* amax_out,
+                                cseg_stream_t stream_) {
+    return bn_bwd_impl(dy, x, out, mean_invstd, weight, bias, mode, training, B, C, HW, ws, g_masked, d_weight, d_bias, dx,
+                       amax_out, stream_);
 }

@@ -531,12 +531,13 @@ def bn_stats_finalize(x, eps, momentum, running_mean, running_var, num_batches_t
 
 
 @torch.no_grad()
-def bn_apply(x, mean_invstd, weight, bias, residual, relu):
+def bn_apply(x, mean_invstd, weight, bias, residual, relu, amax=None):
+    """amax: zeroed word (amax_request) that receives max|y|."""
     B, C, HW = _bn_dims(x)
     y = torch.empty_like(x)
-    _hip.call("cseg_bn_apply", _p(x, F32, "x"), _opt(residual, F32, "residual"), _p(mean_invstd, F32, "mean_invstd"),
+    _hip.call("cseg_bn_apply_amax", _p(x, F32, "x"), _opt(residual, F32, "residual"), _p(mean_invstd, F32, "mean_invstd"),
               _opt(weight, F32, "weight"), _opt(bias, F32, "bias"), int(bool(relu)), B, C, HW, _p(y, F32, "y"),
-              _hip.stream_ptr())
+              _pf(amax) if amax is not None else _null(), _hip.stream_ptr())
     return y
 
 
@@ -557,13 +558,14 @@ def bn_bwd_reduce(dy, x, out, mean_invstd, weight, bias, mode):
 
 
 @torch.no_grad()
-def bn_bwd_apply(dy, x, mean_invstd, weight, bias, sums, count, mask_from_x):
-    """sums None = frozen statistics (eval mode)."""
+def bn_bwd_apply(dy, x, mean_invstd, weight, bias, sums, count, mask_from_x, amax=None):
+    """sums None = frozen statistics (eval mode). amax: zeroed word that receives max|dx|."""
     B, C, HW = _bn_dims(x)
     dx = torch.empty_like(x)
-    _hip.call("cseg_bn_bwd_apply", _p(dy, F32, "dy"), _p(x, F32, "x"), _p(mean_invstd, F32, "mean_invstd"),
+    _hip.call("cseg_bn_bwd_apply_amax", _p(dy, F32, "dy"), _p(x, F32, "x"), _p(mean_invstd, F32, "mean_invstd"),
               _opt(weight, F32, "weight"), _opt(bias, F32, "bias"), _opt(sums, F64, "sums"), float(count),
-              int(bool(mask_from_x)), B, C, HW, _p(dx, F32, "dx"), _hip.stream_ptr())
+              int(bool(mask_from_x)), B, C, HW, _p(dx, F32, "dx"), _pf(amax) if amax is not None else _null(),
+              _hip.stream_ptr())
     return dx
 
 
@@ -685,6 +687,37 @@ def tensor_amax(t, slot=None):
         slot = amax_slot(t.device)
     _hip.call("cseg_amax_f32", _p(t, F32, "tensor"), ctypes.c_long(t.numel()), _pf(slot), _hip.stream_ptr())
     return slot
+
+
+def amax_request(t):
+    """A zeroed max|.| word for a tensor a producer kernel is about to write (the fused-BN apply kernels accumulate it while
+    they store), or None when nobody will read it (bf16x6 arithmetic)."""
+    return amax_slot(t.device) if (split_arith_id() and _on_device(t)) else None
+
+
+def amax_attach(t, slot):
+    """Hands the word to whoever consumes `t` next: an attribute of the tensor object (it travels with the tensor through
+    autograd; the version counter guards against a later in-place change of the values)."""
+    if slot is not None:
+        t._cseg_amax = (slot, t._version)
+    return t
+
+
+def known_amax(t):
+    a = getattr(t, "_cseg_amax", None)
+    return a[0] if (a is not None and a[1] == t._version) else None
+
+
+def amax_of(t):
+    """max|t| word: the producer's if it left one, a pass over the tensor otherwise."""
+    a = known_amax(t)
+    if a is None:
+        a = tensor_amax(t.contiguous())
+        try:
+            amax_attach(t, a)          # a second consumer of the same tensor (the head's 3x3 and 1x1 both read `feats`) reuses it
+        except Exception:
+            pass
+    return a
 
 
 def _pack_key(weight, *what):
@@ -855,14 +888,14 @@ class Conv3x3SplitBF16(Function):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.pick = weight.shape[0] in CONV3X3_SB_PICK_NT_CHANNELS
-        ctx.ax = tensor_amax(x) if split_arith_id() else None          # reused by the weight gradient
+        ctx.ax = amax_of(x) if split_arith_id() else None              # reused by the weight gradient
         return conv3x3_sb_run(x, weight, False, bias, conv3x3_sb_pick_nt(x, weight.shape[0]) if ctx.pick else 0, ax=ctx.ax)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
+        ady = amax_of(dy) if split_arith_id() else None
         dy = dy.contiguous()
-        ady = tensor_amax(dy) if split_arith_id() else None
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv3x3_sb_run(dy, weight, True, None, conv3x3_sb_pick_nt(dy, weight.shape[1]) if ctx.pick else 0, ax=ady)
@@ -984,14 +1017,14 @@ class Conv1x1SplitBF16(Function):
         weight = weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        ctx.ax = tensor_amax(x) if split_arith_id() else None
+        ctx.ax = amax_of(x) if split_arith_id() else None
         return conv1x1_sb_run(x, weight, False, bias, ax=ctx.ax)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
+        ady = amax_of(dy) if split_arith_id() else None
         dy = dy.contiguous()
-        ady = tensor_amax(dy) if split_arith_id() else None
         dx = conv1x1_sb_run(dy, weight, True, ax=ady) if ctx.needs_input_grad[0] else None
         dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
@@ -1010,31 +1043,33 @@ def conv1x1_split_bf16(x, weight, bias=None):
 
 
 @torch.no_grad()
-def bn_fwd(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches_tracked):
-    """Single-rank training forward (2 launches): -> (y, mean_invstd [C,2])."""
+def bn_fwd(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches_tracked, amax=None):
+    """Single-rank training forward (2 launches): -> (y, mean_invstd [C,2]). amax: zeroed word that receives max|y|."""
     B, C, HW = _bn_dims(x)
     mi = torch.empty(C, 2, dtype=F32, device=x.device)
     y = torch.empty_like(x)
-    _hip.call("cseg_bn_fwd", _p(x, F32, "x"), _opt(residual, F32, "residual"), _opt(weight, F32, "weight"),
+    _hip.call("cseg_bn_fwd_amax", _p(x, F32, "x"), _opt(residual, F32, "residual"), _opt(weight, F32, "weight"),
               _opt(bias, F32, "bias"), int(bool(relu)), B, C, HW, _pf(_bn_ws(B, C, HW, x.device)), float(eps),
               float(momentum), _opt(running_mean, F32, "running_mean"), _opt(running_var, F32, "running_var"),
-              _opt(num_batches_tracked, I64, "num_batches_tracked"), _pf(mi), _pf(y), _hip.stream_ptr())
+              _opt(num_batches_tracked, I64, "num_batches_tracked"), _pf(mi), _pf(y),
+              _pf(amax) if amax is not None else _null(), _hip.stream_ptr())
     return y, mi
 
 
 @torch.no_grad()
-def bn_bwd(dy, x, out, mean_invstd, weight, bias, mode, training, want_dx):
-    """Single-rank backward (2 launches): -> (dx or None, d_weight, d_bias, g_masked or None)."""
+def bn_bwd(dy, x, out, mean_invstd, weight, bias, mode, training, want_dx, amax=None):
+    """Single-rank backward (2 launches): -> (dx or None, d_weight, d_bias, g_masked or None). amax: zeroed word for max|dx|."""
     B, C, HW = _bn_dims(x)
     dev = x.device
     d_wb = torch.empty(2, C, dtype=F32, device=dev)
     d_weight, d_bias = d_wb[0], d_wb[1]
     g = torch.empty_like(x) if mode == 2 else None
     dx = torch.empty_like(x) if want_dx else None
-    _hip.call("cseg_bn_bwd", _p(dy, F32, "dy"), _pf(x), _pf(out) if out is not None else _null(),
+    _hip.call("cseg_bn_bwd_amax", _p(dy, F32, "dy"), _pf(x), _pf(out) if out is not None else _null(),
               _pf(mean_invstd), _opt(weight, F32, "weight"), _opt(bias, F32, "bias"), int(mode),
               int(bool(training)), B, C, HW, _pf(_bn_ws(B, C, HW, dev)), _pf(g) if g is not None else _null(),
-              _pf(d_weight), _pf(d_bias), _pf(dx) if dx is not None else _null(), _hip.stream_ptr())
+              _pf(d_weight), _pf(d_bias), _pf(dx) if dx is not None else _null(),
+              _pf(amax) if (amax is not None and dx is not None) else _null(), _hip.stream_ptr())
     return dx, d_weight, d_bias, g
 
 

@@ -32,20 +32,24 @@ def bn_forward(x, weight, bias, residual, running_mean, running_var, num_batches
     sync_group: None = local statistics; otherwise the process group whose ranks share statistics."""
     n_local = x.numel() // x.shape[1]
     count = float(n_local)
+    # max|y|, accumulated by the apply kernel while it stores y: the next split-operand convolution (f16x3 arithmetic) scales
+    # its input with it and would otherwise spend a pass over y on it (kernels.amax_of)
+    amax = K.amax_request(x)
     if training:
         if sync_group is not None:
             world = torch.distributed.get_world_size(sync_group)
             moments = _all_reduce(K.bn_stats(x), sync_group)
             count = float(n_local * world)          # equal per-rank batch (data_loader.py:137 splits evenly)
             mi = K.bn_finalize(moments, count, eps, momentum, running_mean, running_var, num_batches_tracked)
-            y = K.bn_apply(x, mi, weight, bias, residual, relu)
+            y = K.bn_apply(x, mi, weight, bias, residual, relu, amax=amax)
         else:
             # single rank: statistics + (finalise, running statistics, apply) in two launches
             y, mi = K.bn_fwd(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var,
-                             num_batches_tracked)
+                             num_batches_tracked, amax=amax)
     else:
         mi = torch.stack([running_mean, torch.rsqrt(running_var + eps)], dim=1).contiguous()
-        y = K.bn_apply(x, mi, weight, bias, residual, relu)
+        y = K.bn_apply(x, mi, weight, bias, residual, relu, amax=amax)
+    K.amax_attach(y, amax)
     return y, mi, count
 
 
@@ -53,15 +57,18 @@ def bn_backward(dy, x, out, mi, weight, bias, relu, has_res, training, count, sy
     """Adjoint of bn_forward -> (dx or None, d_weight, d_bias, gradient of the residual or None). dy contiguous; `out` is
     the forward's output when a residual was added under the ReLU (the mask cannot be rebuilt from x then)."""
     mode = 0 if not relu else (2 if has_res else 1)
+    amax = K.amax_request(x) if want_dx else None      # max|dx|: dx is the output gradient of the convolution in front
     if sync_group is None or not training:
         # single rank (or frozen statistics): reduce + (sums, parameter gradients, dx) in two launches
-        dx, d_weight, d_bias, g = K.bn_bwd(dy, x, out, mi, weight, bias, mode, training, want_dx)
+        dx, d_weight, d_bias, g = K.bn_bwd(dy, x, out, mi, weight, bias, mode, training, want_dx, amax=amax)
     else:
         sums, d_weight, d_bias, g = K.bn_bwd_reduce(dy, x, out, mi, weight, bias, mode)
         dx = None
         if want_dx:
             sums = _all_reduce(sums, sync_group)
-            dx = K.bn_bwd_apply(g if mode == 2 else dy, x, mi, weight, bias, sums, count, mode == 1)
+            dx = K.bn_bwd_apply(g if mode == 2 else dy, x, mi, weight, bias, sums, count, mode == 1, amax=amax)
+    if dx is not None:
+        K.amax_attach(dx, amax)
     d_res = None
     if has_res:
         d_res = g if mode == 2 else dy          # the add passes the (masked) gradient straight through
@@ -120,7 +127,8 @@ class _BNActGroup(torch.autograd.Function):
             mi = K.bn_finalize(packed[off:off + C].contiguous(), count, eps, momentum, rm, rv, nbt)
             off += C
             r = None if r is None else r.contiguous()
-            y = K.bn_apply(x, mi, w, b, r, relu)
+            amax = K.amax_request(x)
+            y = K.amax_attach(K.bn_apply(x, mi, w, b, r, relu, amax=amax), amax)
             outs.append(y)
             counts.append(count)
             saved += [x, mi, w, b, y if (relu and r is not None) else None]
@@ -150,8 +158,9 @@ class _BNActGroup(torch.autograd.Function):
             C = x.shape[1]
             dx = None
             if ctx.needs_input_grad[2 + 4 * i]:
-                dx = K.bn_bwd_apply(g if mode == 2 else dy, x, mi, w, b, packed[off:off + C].contiguous(),
-                                    ctx.counts[i], mode == 1)
+                amax = K.amax_request(x)
+                dx = K.amax_attach(K.bn_bwd_apply(g if mode == 2 else dy, x, mi, w, b, packed[off:off + C].contiguous(),
+                                                  ctx.counts[i], mode == 1, amax=amax), amax)
             off += C
             d_res = (g if mode == 2 else dy) if (ctx.meta[i][1] and ctx.needs_input_grad[2 + 4 * i + 3]) else None
             grads += [dx, d_w if w is not None else None, d_b if b is not None else None, d_res]

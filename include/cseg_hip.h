@@ -210,6 +210,22 @@ int cseg_bn_bwd_apply(const float* dy, const float* x, const float* mean_invstd,
                       const double* sums, double count, int mask_from_x, int B, int C, int HW, float* dx,
                       cseg_stream_t stream);
 
+/* Round 3: the four apply-type calls above with max|output| accumulated into *amax_out (uint32 bit pattern of the float,
+ * atomicMax; the caller zeroes the word): the tensor they write is the operand of the next split-operand convolution
+ * (CSEG_ARITH_F16X3 scales it by a power of two derived from this word), so the maximum comes for free instead of from an
+ * extra pass over the tensor (cseg_amax_f32).  amax_out == NULL: identical to the plain call. */
+int cseg_bn_fwd_amax(const float* x, const float* residual, const float* weight, const float* bias, int relu, int B, int C,
+                     int HW, float* ws, float eps, float momentum, float* running_mean, float* running_var,
+                     int64_t* num_batches_tracked, float* mean_invstd, float* y, unsigned* amax_out, cseg_stream_t stream);
+int cseg_bn_bwd_amax(const float* dy, const float* x, const float* out, const float* mean_invstd, const float* weight,
+                     const float* bias, int mode, int training, int B, int C, int HW, float* ws, float* g_masked,
+                     float* d_weight, float* d_bias, float* dx, unsigned* amax_out, cseg_stream_t stream);
+int cseg_bn_apply_amax(const float* x, const float* residual, const float* mean_invstd, const float* weight,
+                       const float* bias, int relu, int B, int C, int HW, float* y, unsigned* amax_out, cseg_stream_t stream);
+int cseg_bn_bwd_apply_amax(const float* dy, const float* x, const float* mean_invstd, const float* weight, const float* bias,
+                           const double* sums, double count, int mask_from_x, int B, int C, int HW, float* dx,
+                           unsigned* amax_out, cseg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * 3x3 / stride 1 / pad 1 convolution, NCHW fp32, forward and backward-data, for the narrow HRNet branches
  * (lib/models/backbones/hrnet/hrnet_backbone.py:35-66 BasicBlock conv1/conv2 -> nn.Conv2d -> MIOpen in the reference;

@@ -243,7 +243,7 @@ def _bn_affine(x, mean_invstd, weight, bias):
 
 
 @torch.no_grad()
-def bn_apply(x, mean_invstd, weight, bias, residual, relu):
+def bn_apply(x, mean_invstd, weight, bias, residual, relu, amax=None):
     _, _, z = _bn_affine(x, mean_invstd, weight, bias)
     if residual is not None:
         z = z + residual
@@ -265,13 +265,13 @@ def bn_bwd_reduce(dy, x, out, mean_invstd, weight, bias, mode):
 
 
 @torch.no_grad()
-def bn_fwd(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches_tracked):
+def bn_fwd(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches_tracked, amax=None):
     mi = bn_stats_finalize(x, eps, momentum, running_mean, running_var, num_batches_tracked)
     return bn_apply(x, mi, weight, bias, residual, relu), mi
 
 
 @torch.no_grad()
-def bn_bwd(dy, x, out, mean_invstd, weight, bias, mode, training, want_dx):
+def bn_bwd(dy, x, out, mean_invstd, weight, bias, mode, training, want_dx, amax=None):
     sums, d_weight, d_bias, g = bn_bwd_reduce(dy, x, out, mean_invstd, weight, bias, mode)
     dx = None
     if want_dx:
@@ -281,7 +281,7 @@ def bn_bwd(dy, x, out, mean_invstd, weight, bias, mode, training, want_dx):
 
 
 @torch.no_grad()
-def bn_bwd_apply(dy, x, mean_invstd, weight, bias, sums, count, mask_from_x):
+def bn_bwd_apply(dy, x, mean_invstd, weight, bias, sums, count, mask_from_x, amax=None):
     xm, a, z = _bn_affine(x, mean_invstd, weight, bias)
     shape = (1, -1) + (1,) * (x.dim() - 2)
     g = dy * (z > 0) if mask_from_x else dy
@@ -308,6 +308,15 @@ def augment_batch(img_u8, lab_u8, lut, params, out_hw, div_value, mean, std):
         imgs.append(torch.from_numpy(im))
         labs.append(None if lb is None else torch.from_numpy(lb))
     return torch.stack(imgs), (None if lab_u8 is None else torch.stack(labs))
+
+
+def amax_request(t):
+    """kernels.amax_request: the CPU restatement has no split-operand convolutions, so nobody asks for max|t|."""
+    return None
+
+
+def amax_attach(t, slot):
+    return t
 
 
 def install(monkeypatch_or_none=None):

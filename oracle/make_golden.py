@@ -407,8 +407,60 @@ STEP_CASES = {
                                          "decoder.layer_aspp.b1.0.weight", "decoder.layer_aspp.b4.1.weight", "decoder.layer_aspp.project.0.weight",
                                          "decoder.layer_dsn.0.weight", "decoder.refine.2.weight",
                                          "proj_head.proj.2.weight"]),
+    # BASELINE.json configs[3] (row g): DeepLab-V3 + the per-class memory bank. The reference registers a memory model only
+    # for HRNet (lib/models/nets/hrnet.py:153-188); the golden runs the reference's OWN HRNet_W48_MEM class with its encoder
+    # symbol pointed at the reference's DeepLabV3Contrast (ref_memory_model below), the composed criterion ref_mem_auxce and
+    # the reference's _dequeue_and_enqueue.
+    "step_resnet50_deeplab_mem": dict(model="deeplab_v3_mem", backbone="deepbase_resnet50_dilated8",
+                                      loss="mem_contrast_auxce_loss", K=7, B=4, H=97, W=129, seed=45, torch_seed=5,
+                                      spread=True, network_stride=8,
+                                      contrast=dict(max_samples=128, max_views=1, proj_dim=64, with_memory=True,
+                                                    memory_size=12, pixel_update_freq=10, loss_weight=1.0),
+                                      watch=["encoder_q.backbone.resinit.conv1.weight",
+                                             "encoder_q.backbone.layer4.2.conv2.weight",
+                                             "encoder_q.decoder.layer_aspp.project.0.weight",
+                                             "encoder_q.decoder.layer_dsn.0.weight", "encoder_q.decoder.refine.2.weight",
+                                             "encoder_q.proj_head.proj.0.weight", "encoder_q.proj_head.proj.2.weight"]),
 }
 SGD = dict(lr=0.01, momentum=0.9, weight_decay=5e-4)
+
+
+def ref_memory_model(cfg, encoder_name):
+    """The reference's HRNet_W48_MEM (lib/models/nets/hrnet.py:153-188: encoder_q, then the two randn queues, L2-normalised,
+    and their pointers, in that order) with `HRNet_W48_CONTRAST` resolved to another reference encoder while the constructor
+    runs; forward keeps every head output of the encoder (the reference drops 'seg_aux', which its own memory criterion never
+    reads) and adds key / lb_key exactly as :178-188."""
+    import lib.models.nets.hrnet as ref_hrnet
+    import lib.models.nets.deeplab as ref_deeplab
+    encoder = {"deeplab_v3_contrast": ref_deeplab.DeepLabV3Contrast}[encoder_name]
+
+    class RefMem(ref_hrnet.HRNet_W48_MEM):
+        def forward(self, im_q, lb_q=None, with_embed=True, is_eval=False):
+            if is_eval is True or lb_q is None:
+                return self.encoder_q(im_q, with_embed=with_embed)
+            ret = self.encoder_q(im_q)
+            q = ret['embed']
+            ret.update({'key': q.detach(), 'lb_key': lb_q.detach()})
+            return ret
+
+    saved = ref_hrnet.HRNet_W48_CONTRAST
+    ref_hrnet.HRNet_W48_CONTRAST = encoder
+    try:
+        return RefMem(cfg, dim=cfg.get('contrast', 'proj_dim'))
+    finally:
+        ref_hrnet.HRNet_W48_CONTRAST = saved
+
+
+def ref_model(cfg, name):
+    from lib.models.model_manager import ModelManager
+    if name == "deeplab_v3_mem":
+        return ref_memory_model(cfg, "deeplab_v3_contrast")
+    return ModelManager(cfg).semantic_segmentor()
+
+
+def ref_criterion(cfg, name):
+    from lib.loss.loss_manager import SEG_LOSS_DICT
+    return ref_mem_auxce(cfg) if name == "mem_contrast_auxce_loss" else SEG_LOSS_DICT[name](cfg)
 
 
 def watch_subset(a, cap=16384):
@@ -435,12 +487,12 @@ def run_step_case(name, c):
     ref_shim.install()
     from lib.loss.loss_manager import SEG_LOSS_DICT
     from lib.models.model_manager import ModelManager
-    cfg = ref_shim.configer(num_classes=c["K"], model_name=c["model"], backbone=c["backbone"], loss_type=c["loss"],
-                            contrast=c["contrast"])
+    cfg = ref_shim.configer(num_classes=c["K"], model_name=c["model"], backbone=c["backbone"],
+                            loss_type=c["loss"] if c["loss"] in SEG_LOSS_DICT else "mem_contrast_ce_loss", contrast=c["contrast"])
     torch.manual_seed(304)
-    net = ModelManager(cfg).semantic_segmentor().train()
+    net = ref_model(cfg, c["model"]).train()
     freeze_dropout(net)
-    crit = SEG_LOSS_DICT[c["loss"]](cfg)
+    crit = ref_criterion(cfg, c["loss"])
     opt = torch.optim.SGD(net.parameters(), **SGD)
     img, target = step_inputs(c)
     img, target = torch.from_numpy(img).requires_grad_(True), torch.from_numpy(target)
@@ -460,9 +512,9 @@ def run_step_case(name, c):
     res = {}
     # the reference's OWN fp32 rounding noise on these gradients: the same model, input and anchor draws in fp64
     torch.manual_seed(304)
-    net64 = ModelManager(cfg).semantic_segmentor().train()
+    net64 = ref_model(cfg, c["model"]).train()
     freeze_dropout(net64)
-    net64, crit64 = net64.double(), SEG_LOSS_DICT[c["loss"]](cfg).double()
+    net64, crit64 = net64.double(), ref_criterion(cfg, c["loss"]).double()
     torch.manual_seed(c["torch_seed"])
     img64 = img.detach().double().requires_grad_(True)
     if with_memory:

@@ -137,7 +137,7 @@ def _compare(res, g, c, loss_rtol, grad_tol, loss1_rtol):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("name", ["step_hrnet48_contrast", "step_hrnet48_mem", "step_resnet50_deeplab"])
+@pytest.mark.parametrize("name", ["step_hrnet48_contrast", "step_hrnet48_mem", "step_resnet50_deeplab", "step_resnet50_deeplab_mem"])
 def test_sgd_step_cpu_port_matches_reference(name, golden_dir, monkeypatch):
     cpu_port.install(monkeypatch)
     c = STEP_CASES[name]

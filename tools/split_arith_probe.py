@@ -2,7 +2,10 @@
 computed once -- what a training step pays per call) and error against an fp64 convolution of the same operands, with MIOpen's
 fp32 kernel as the yardstick. One JSON line per (operator, shape). Usage: split_arith_probe.py [fwd] [wrw] [c1]"""
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 import torch
 import torch.nn.functional as F
