@@ -59,7 +59,14 @@ WORKLOADS = {
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense; a split-bf16 ("bf16x6") product costs six bf16 MFMAs
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 / fp16 MFMA; a split-operand product costs six ("bf16x6") or three ("f16x3") MFMAs
+MFMAS_PER_PRODUCT = {"bf16x6": 6.0, "f16x3": 3.0}
+
+
+def peak_split_tflops(arith):
+    return PEAK_BF16_MFMA_TFLOPS / MFMAS_PER_PRODUCT[arith]
+
+
 PEAK_SPLIT_BF16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
@@ -237,16 +244,19 @@ def kernel_rooflines(device, B, K=19, H=512, W=1024, stride=4, D=256):
                   time_kernel(lambda: torch.autograd.grad(y2, (x, r), gy, retain_graph=True)), bytes_=7 * nb)
             del y2
         del bn, x, r, y, gy
-    # split-bf16 3x3 convolution at the head's shape (forward = backward-data): fp32-equivalent flops vs 2500/6 TF/s
+    # the head's 3x3 convolution in the current split arithmetic (forward = backward-data): fp32-equivalent flops vs 2500 / k TF/s
     C = 720
     xh = torch.randn(B, C, h, w, device=device)
     wh = torch.randn(C, C, 3, 3, device=device) / (3.0 * C ** 0.5)
-    us = time_kernel(lambda: Kn.conv3x3_sb_run(xh, wh, False), iters=5, warm=2)
+    axh = Kn.tensor_amax(xh) if Kn.split_arith_id() else None
+    us = time_kernel(lambda: Kn.conv3x3_sb_run(xh, wh, False, ax=axh), iters=5, warm=2)
     fl = 2.0 * B * h * w * C * C * 9
-    out["conv3x3_split_bf16 720->720 (pack + conv)"] = {
+    pk = peak_split_tflops(Kn.SPLIT_ARITH)
+    out["conv3x3_split 720->720 (%s)" % Kn.SPLIT_ARITH] = {
         "us": round(us, 1), "bound": "mfma", "flops": int(fl), "achieved_TFLOPs": round(fl / us * 1e-6, 1),
-        "peak_TFLOPs": round(PEAK_SPLIT_BF16_TFLOPS, 1), "frac": round(fl / us * 1e-6 / PEAK_SPLIT_BF16_TFLOPS, 4),
-        "note": "fp32-equivalent flops; six v_mfma_f32_16x16x32_bf16 per product; MIOpen fp32 at this shape: 19.8 ms"}
+        "peak_TFLOPs": round(pk, 1), "frac": round(fl / us * 1e-6 / pk, 4),
+        "note": "fp32-equivalent flops; %d MFMAs per product; weights packed once per optimizer step (cached); MIOpen fp32 at "
+                "this shape: 19.8 ms" % MFMAS_PER_PRODUCT[Kn.SPLIT_ARITH]}
     del xh, wh
     return out
 
@@ -255,29 +265,105 @@ def conv_arith_note(Kn, split_on):
     """config.conv3x3_arithmetic of the JSON line: which convolutions run in which arithmetic in this process."""
     if not split_on:
         return "fp32"
+    how = {"f16x3": "split-fp16 x3 on the matrix cores (fp32 in/out; every operand = two fp16 pieces of the tensor scaled by a "
+                    "power of two taken from max|tensor|, three fp16 piece products per fp32 product, fp32 accumulate",
+           "bf16x6": "split-bf16 x6 on the matrix cores (fp32 in/out; every operand = three bf16 pieces, six bf16 piece products "
+                     "per fp32 product, fp32 accumulate"}[Kn.SPLIT_ARITH]
     wrw = ""
     if Kn.CONV3X3_SB_WRW:
         wrw = " + weight gradient (%s channels)" % "/".join(str(c) for c in Kn.CONV3X3_SB_WRW_CHANNELS)
-    return ("split-bf16 x6 on the BF16 matrix cores (fp32 in/out, six bf16 piece products per fp32 product, fp32 "
-            "accumulate; fp32-class accuracy: tools/split_bf16_probe.py, tests/test_gpu_conv3x3_sb.py) for the 720->720 "
-            "head convolution and the %s-channel branches, forward + backward-data%s; everything else fp32"
-            % ("/".join(str(c) for c in Kn.CONV3X3_SB_BRANCH_CHANNELS), wrw))
+    one = ""
+    if Kn.CONV1X1_SPLIT_BF16:
+        one = "; 1x1 convolutions with tiling channel counts (projection head, bottlenecks) forward + backward-data" + (
+            " + weight gradient (>= %d channels)" % Kn.CONV1X1_SB_WRW_MIN_CH if Kn.CONV1X1_SB_WRW else "")
+    return ("%s; fp32-class accuracy: whole-network logits vs fp64 5.1e-5 (f16x3) / 2.1e-5 (bf16x6) against fp32's own 4.3e-5, "
+            "tools/split_bf16_probe.py, tests/test_gpu_conv3x3_sb.py) for the 720->720 head convolution and the %s-channel "
+            "branches, forward + backward-data%s%s; everything else fp32 (MIOpen / rocBLAS)"
+            % (how, "/".join(str(c) for c in Kn.CONV3X3_SB_BRANCH_CHANNELS), wrw, one))
 
 
-def dominant_kernel(kernels):
-    """roofline.dominant_kernel: the single kernel with the largest share of the step (13 % in
-    profiles/r02_step_steady_kernel_stats_split_bf16.csv), timed live by kernel_rooflines() with HIP events."""
-    dom = (kernels or {}).get("conv3x3_split_bf16 720->720 (pack + conv)")
-    if not (isinstance(dom, dict) and all(k in dom for k in ("achieved_TFLOPs", "peak_TFLOPs", "frac", "us", "flops"))):
+SPLIT_OPS = ("conv3x3_sb_run", "conv3x3_sb_wrw", "conv1x1_sb_run", "conv1x1_sb_wrw")
+
+
+def tally_split_calls(tr, batch, Kn):
+    """One extra (untimed) train step with counting wrappers around the four split-operand entry points of
+    contrastiveseg_amd.kernels: {(op, operand shapes, flag): calls per step}. What the step REALLY launches -- the dominant
+    kernel is picked from this and from live timings, not from a table written by hand."""
+    counts = {}
+    saved = {n: getattr(Kn, n) for n in SPLIT_OPS}
+
+    def wrap(name, fn):
+        def inner(*a, **k):
+            flag = bool(a[2]) if (name.endswith("_run") and len(a) > 2) else False
+            key = (name, tuple(a[0].shape), tuple(a[1].shape), flag)
+            counts[key] = counts.get(key, 0) + 1
+            return fn(*a, **k)
+        return inner
+    try:
+        for n in SPLIT_OPS:
+            setattr(Kn, n, wrap(n, saved[n]))
+        tr.train_step(batch)
+        torch.cuda.synchronize()
+    finally:
+        for n in SPLIT_OPS:
+            setattr(Kn, n, saved[n])
+    return counts
+
+
+def split_kernel_rooflines(counts, device, Kn):
+    """Times every distinct (op, shape) of the tally in isolation (HIP events over a loop, weights packed and max|.| words
+    computed once, as inside a step) -> list of dicts sorted by their share of the step, plus the fp32-equivalent flops per
+    step that run on the split-operand kernels."""
+    peak = peak_split_tflops(Kn.SPLIT_ARITH)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    rows, split_flops = [], 0.0
+    for (name, sa, sb, flag), n in sorted(counts.items(), key=lambda kv: -kv[1]):
+        a = torch.randn(*sa, generator=g).to(device)
+        if name.endswith("_run"):
+            w = (torch.randn(*sb, generator=g) / (sb[1] * sb[2] * sb[3]) ** 0.5).to(device)
+            taps = sb[2] * sb[3]
+            nt = Kn.conv3x3_sb_pick_nt(a, sb[1] if flag else sb[0]) if (taps == 9 and sb[0] in Kn.CONV3X3_SB_PICK_NT_CHANNELS) else 0
+            ax = Kn.tensor_amax(a) if Kn.split_arith_id() else None
+            if taps == 9:
+                fn = lambda: Kn.conv3x3_sb_run(a, w, flag, None, nt, ax=ax)
+            else:
+                fn = lambda: Kn.conv1x1_sb_run(a, w, flag, None, ax=ax)
+            flops = 2.0 * sa[0] * sa[2] * sa[3] * sb[0] * sb[1] * taps
+            what = "%s %d->%d %s @%dx%dx%d" % ("conv3x3" if taps == 9 else "conv1x1", sb[0] if flag else sb[1],
+                                               sb[1] if flag else sb[0], "backward-data" if flag else "forward", sa[0], sa[2], sa[3])
+        else:
+            dy = (torch.randn(*sb, generator=g) * 1e-3).to(device)
+            ax, ad = (Kn.tensor_amax(a), Kn.tensor_amax(dy)) if Kn.split_arith_id() else (None, None)
+            taps = 9 if name == "conv3x3_sb_wrw" else 1
+            fn = (lambda: Kn.conv3x3_sb_wrw(a, dy, ax=ax, ady=ad)) if taps == 9 else (lambda: Kn.conv1x1_sb_wrw(a, dy, ax=ax, ady=ad))
+            flops = 2.0 * sa[0] * sa[2] * sa[3] * sa[1] * sb[1] * taps
+            what = "%s %d->%d weight gradient @%dx%dx%d" % ("conv3x3" if taps == 9 else "conv1x1", sa[1], sb[1], sa[0], sa[2], sa[3])
+        us = time_kernel(fn, iters=5 if flops > 5e11 else 20, warm=2)
+        tf = flops / us * 1e-6
+        rows.append({"kernel": what, "entry": name, "calls_per_step": n, "us_per_launch": round(us, 1),
+                     "ms_per_step": round(n * us * 1e-3, 3), "algorithmic_flops_per_launch": int(flops),
+                     "achieved_TFLOPs": round(tf, 1), "peak_TFLOPs": round(peak, 1), "frac": round(tf / peak, 4)})
+        split_flops += n * flops
+        del a
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows, split_flops
+
+
+def dominant_kernel(split_rows, arith):
+    """roofline.dominant_kernel: the split-operand kernel with the largest calls x time product of THIS run."""
+    if not split_rows:
         return None
-    return {"name": "conv3x3_sb_kernel<9> (720->720 head convolution, forward = backward-data)", "bound": "mfma",
-            "achieved": dom["achieved_TFLOPs"], "peak": dom["peak_TFLOPs"],
-            "unit": "TFLOP/s fp32-equivalent (six bf16 MFMAs per product: peak = 2500 / 6)", "frac": dom["frac"],
-            "us_per_launch": dom["us"], "algorithmic_flops_per_launch": dom["flops"]}
+    d = split_rows[0]
+    return {"name": d["kernel"], "entry": d["entry"], "bound": "mfma", "achieved": d["achieved_TFLOPs"], "peak": d["peak_TFLOPs"],
+            "unit": "TFLOP/s fp32-equivalent (%s: %d MFMAs per product, peak = 2500 / %d)"
+                    % (arith, MFMAS_PER_PRODUCT[arith], MFMAS_PER_PRODUCT[arith]),
+            "frac": d["frac"], "us_per_launch": d["us_per_launch"], "calls_per_step": d["calls_per_step"],
+            "ms_per_step": d["ms_per_step"], "algorithmic_flops_per_launch": d["algorithmic_flops_per_launch"],
+            "picked_from": "live tally of one train step x live HIP-event timings (bench.py:split_kernel_rooflines)"}
 
 
 def assemble_line(args, wl, cfg, world, global_batch, dt, ev_ms, final_loss, split_on, Kn, backend, fp32_pass, weak, cpu,
-                  kernels):
+                  kernels, split_rows=None, split_flops=0.0):
     """The ONE JSON line of the contract (pure function of the measurements: exercised on CPU by
     tests/test_host_surface.py so that a formatting slip cannot cost a GPU run its result)."""
     ips = global_batch * args.steps / dt
@@ -307,15 +393,29 @@ def assemble_line(args, wl, cfg, world, global_batch, dt, ev_ms, final_loss, spl
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "note": "whole step: images/s (HIP-event time %.1f ms/step) x %.4f TFLOP/image of fp32-equivalent "
-                             "work vs the fp32 MFMA peak (the roof of a pure fp32 implementation; the split-bf16 "
-                             "convolutions run on the bf16 pipe at 6 MFMAs per product, roof 2500/6 = 417 TF/s for "
-                             "that share of the work); per-kernel rooflines under 'kernels'"
+                             "work vs the fp32 MFMA peak (the roof of a pure fp32 implementation: a fraction above 1 means "
+                             "the step beats what fp32 MFMA arithmetic could do at 100 %% utilisation). The split-operand "
+                             "convolutions run on the fp16/bf16 pipe, so the roof of THIS implementation is lower: see "
+                             "blended_roof; per-kernel rooflines under 'split_kernels' and 'kernels'"
                              % (ev_ms / args.steps, wl["tflop"])},
         "fp32_conv_path": fp32_pass, "weak": weak, "cpu_baseline": cpu, "kernels": kernels,
     }
-    dom = dominant_kernel(kernels)
+    arith = getattr(Kn, "SPLIT_ARITH", "bf16x6")
+    dom = dominant_kernel(split_rows, arith) if split_on else None
     if dom is not None:
         line["roofline"]["dominant_kernel"] = dom
+    if split_rows:
+        line["split_kernels"] = split_rows
+    if split_on and split_flops > 0 and world == 1:
+        # the roof of this implementation: split-operand work at 2500 / (MFMAs per product) TFLOP/s, the rest at the fp32 MFMA peak
+        total = wl["tflop"] * 1e12 * global_batch
+        rest = max(total - split_flops, 0.0)
+        roof_ms = (split_flops / (peak_split_tflops(arith) * 1e12) + rest / (PEAK_FP32_MFMA_TFLOPS * 1e12)) * 1e3
+        line["roofline"]["blended_roof"] = {
+            "split_operand_TFLOP_per_step": round(split_flops * 1e-12, 3), "fp32_TFLOP_per_step": round(rest * 1e-12, 3),
+            "roof_ms_per_step": round(roof_ms, 2), "frac": round(roof_ms / (ev_ms / args.steps), 4),
+            "note": "roof = split-operand flops / (2500 / %d TFLOP/s) + remaining flops / 157.3 TFLOP/s; frac = roof time / "
+                    "measured step time" % MFMAS_PER_PRODUCT[arith]}
     return line
 
 
@@ -562,10 +662,18 @@ def main():
         torch.cuda.empty_cache()
 
     kernels = None
+    split_rows, split_flops = None, 0.0
     if rank == 0 and not args.no_kernels and args.workload == "cfg2":
+        if world == 1 and split_on:
+            try:
+                split_rows, split_flops = split_kernel_rooflines(tally_split_calls(tr, batch, Kn), device, Kn)
+            except Exception as e:        # never lose the headline number to a micro-benchmark problem
+                split_rows = [{"error": repr(e)}]
+        tr = None
+        torch.cuda.empty_cache()
         try:
             kernels = kernel_rooflines(device, 8)
-        except Exception as e:            # never lose the headline number to a micro-benchmark problem
+        except Exception as e:
             kernels = {"error": repr(e)}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":
@@ -578,7 +686,8 @@ def main():
 
     if rank == 0:
         line = assemble_line(args, wl, cfg, world, global_batch, dt, ev_ms, final_loss, split_on, Kn,
-                             torch.distributed.get_backend() if world > 1 else None, fp32_pass, weak, cpu, kernels)
+                             torch.distributed.get_backend() if world > 1 else None, fp32_pass, weak, cpu, kernels,
+                             split_rows if (split_rows and "error" not in split_rows[0]) else None, split_flops)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -17,7 +17,7 @@
 // per 256-thread block iteration, >= 1024 blocks. Reductions are fixed-order (block partials -> fp64 per-channel sum):
 // run-to-run deterministic. Statistics are accumulated as shifted sums (shift = first element of the channel) so
 // that the fp32 partials do not cancel when |mean| >> std.
-#include "cseg_common.h"
+#include "cseg_split.h"
 
 namespace {
 
@@ -175,9 +175,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     finalize_channel(moments[2 * c], moments[2 * c + 1], count, eps, momentum, running_mean, running_var, c, mean_invstd);
 }
 
-// max|value written| of the block -> *amax_out (bit pattern of a non-negative float, monotone as unsigned: the word the f16x3
-// convolutions scale their operands with, csrc/cseg_split.h). One atomic per block at most, and only when the block's maximum
-// exceeds what the word already holds (a stale read only costs a redundant atomic: the word never decreases).
+// max|value written| of the block -> the block's slot of the max|.| record amax_out (csrc/cseg_split.h: what the f16x3
+// convolutions scale their operands with).
 __device__ __forceinline__ unsigned abs_bits(float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; }
 __device__ __forceinline__ void publish_amax(unsigned m, unsigned* __restrict__ amax_out) {
     __shared__ unsigned amax_red[4];
@@ -185,10 +184,7 @@ __device__ __forceinline__ void publish_amax(unsigned m, unsigned* __restrict__ 
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
     if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        m = max(max(amax_red[0], amax_red[1]), max(amax_red[2], amax_red[3]));
-        if (m > *reinterpret_cast<volatile unsigned*>(amax_out)) atomicMax(amax_out, m);
-    }
+    if (threadIdx.x == 0) amax_publish_block(max(max(amax_red[0], amax_red[1]), max(amax_red[2], amax_red[3])), amax_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -32,6 +32,7 @@ template <class AR>
 __global__ __launch_bounds__(256) void pack_weights_1x1_kernel(const float* __restrict__ w, int Cout, int Cin, int transpose,
                                                                int NT, const unsigned* __restrict__ amax_w,
                                                                uint4* __restrict__ wp, int total) {
+    const float wscale = AR::SCALED ? split_scale_of(split_amax_exp(amax_w)) : 1.f;      // every thread (shuffles inside)
     const int e = blockIdx.x * 256 + threadIdx.x;          // one thread per (co_tile, kstep, nt, lane)
     if (e >= total) return;
     const int conv_in = transpose ? Cout : Cin;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void pack_weights_1x1_kernel(const float* __re
         v[j] = t;
     }
     uint4 cells[AR::NP];
-    split_cells8<AR>(v, AR::SCALED ? split_scale_of(split_amax_exp(amax_w)) : 1.f, cells);
+    split_cells8<AR>(v, wscale, cells);
     uint4* dst = wp + (((size_t)(co_tile * n_steps + ks) * NT + nt) * AR::NP) * 64 + lane;
 #pragma unroll
     for (int p = 0; p < AR::NP; ++p) dst[64 * p] = cells[p];

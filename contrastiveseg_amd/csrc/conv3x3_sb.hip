@@ -57,11 +57,14 @@ int sb_variant() {
     const char* e = getenv("CSEG_CONV3X3_SB_VAR");
     return e ? atoi(e) : -1;
 }
+// 64 output channels (4 channel tiles: the 3x3 convolutions of the layer-1 bottlenecks) exist only in the 16-channel-chunk kernel
 bool use_sb16(int conv_out) {
     const int v = sb_variant();
+    if (conv_out == 64) return true;
     if (v == 2) return conv_out <= 192 && conv_out % 48 == 0;
     return v < 0 && (conv_out == 48 || conv_out == 192);
 }
+int sb16_nt(int conv_out, int NT) { return conv_out == 64 ? 4 : (NT == 6 ? 6 : 3); }
 
 constexpr int TR = 4;                 // output rows per block (one per wave)
 constexpr int TC = 64;                // output columns per block
@@ -80,6 +83,7 @@ template <class AR>
 __global__ __launch_bounds__(256) void pack_weights_sb_kernel(const float* __restrict__ w, int Cout, int Cin,
                                                               int transpose_flip, int NT, const unsigned* __restrict__ amax_w,
                                                               uint4* __restrict__ wp, int total) {
+    const float wscale = AR::SCALED ? split_scale_of(split_amax_exp(amax_w)) : 1.f;      // every thread (shuffles inside)
     const int e = blockIdx.x * 256 + threadIdx.x;          // one thread per (co_tile, kstep, nt, lane)
     if (e >= total) return;
     const int conv_in = transpose_flip ? Cout : Cin;
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void pack_weights_sb_kernel(const float* __res
         v[j] = t;
     }
     uint4 cells[AR::NP];
-    split_cells8<AR>(v, AR::SCALED ? split_scale_of(split_amax_exp(amax_w)) : 1.f, cells);
+    split_cells8<AR>(v, wscale, cells);
     uint4* dst = wp + (((size_t)(co_tile * n_steps + ks) * NT + nt) * AR::NP) * 64 + lane;
 #pragma unroll
     for (int p = 0; p < AR::NP; ++p) dst[64 * p] = cells[p];
@@ -361,6 +365,7 @@ int pick_nt(int Cout) {
     if (Cout % 144 == 0) return 9;
     if (Cout % 96 == 0) return 6;
     if (Cout % 48 == 0) return 3;
+    if (Cout == 64) return 4;                              // conv3x3_sb16.hip only
     return 0;
 }
 
@@ -410,7 +415,7 @@ static int pack_impl(const float* w, int Cout, int Cin, int transpose_flip, int 
     const int conv_in = transpose_flip ? Cout : Cin, conv_out = transpose_flip ? Cin : Cout;
     CSEG_REQUIRE(w && wp, "conv3x3_sb_pack_weights: null pointer");
     CSEG_REQUIRE(arith_ok(arith) && (arith == CSEG_ARITH_BF16X6 || amax_w), "conv3x3 split pack: arithmetic %d needs max|w|", arith);
-    if (use_sb16(conv_out)) return cseg_sb16::pack(w, Cout, Cin, transpose_flip, NT == 6 ? 6 : 3, arith, amax_w, wp, stream);
+    if (use_sb16(conv_out)) return cseg_sb16::pack(w, Cout, Cin, transpose_flip, sb16_nt(conv_out, NT), arith, amax_w, wp, stream);
     if (NT == 0) NT = pick_nt(conv_out);
     CSEG_REQUIRE(conv_in % 16 == 0 && NT > 0 && nt_ok(NT, conv_out),
                  "conv3x3_sb: needs input channels %% 16 == 0 and output channels %% 48 == 0 (got %d -> %d)", conv_in, conv_out);
@@ -455,7 +460,7 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, int B, in
     if (use_sb16(Cout)) {
         CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && W % 4 == 0,
                      "conv3x3_sb: packed weights / output must be 16-byte aligned and W a multiple of 4");
-        return cseg_sb16::fwd(x, wp, bias, B, Cin, Cout, H, W, NT == 6 ? 6 : 3, arith, amax_x, amax_w, y, stream);
+        return cseg_sb16::fwd(x, wp, bias, B, Cin, Cout, H, W, sb16_nt(Cout, NT), arith, amax_x, amax_w, y, stream);
     }
     if (NT == 0) NT = pick_nt(Cout);
     CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && NT > 0 && nt_ok(NT, Cout),
@@ -505,7 +510,7 @@ extern "C" int cseg_conv3x3_split_fwd(const float* x, const void* wp, const floa
     return fwd_impl(x, wp, bias, B, Cin, Cout, H, W, nt, arith, amax_x, amax_w, y, (hipStream_t)stream_);
 }
 
-// ---- max|x| of a tensor, accumulated into *amax_bits (bit pattern of a non-negative float; the caller zeroes it) ------------
+// ---- max|x| of a tensor, accumulated into the record amax_bits[CSEG_AMAX_WORDS] (include/cseg_hip.h; the caller zeroes it) ----
 namespace {
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ amax_bits) {
     __shared__ unsigned red[4];
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(amax_bits, max(max(red[0], red[1]), max(red[2], red[3])));
+    if (threadIdx.x == 0) amax_publish_block(max(max(red[0], red[1]), max(red[2], red[3])), amax_bits);
 }
 }  // namespace
 

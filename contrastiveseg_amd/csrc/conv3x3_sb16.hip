@@ -35,6 +35,7 @@ template <class AR>
 __global__ __launch_bounds__(256) void pack_weights_sb16_kernel(const float* __restrict__ w, int Cout, int Cin,
                                                                 int transpose_flip, int NT, const unsigned* __restrict__ amax_w,
                                                                 uint4* __restrict__ wp, int total) {
+    const float wscale = AR::SCALED ? split_scale_of(split_amax_exp(amax_w)) : 1.f;      // every thread (shuffles inside)
     const int e = blockIdx.x * 256 + threadIdx.x;          // one thread per (co_tile, kstep, nt, lane)
     if (e >= total) return;
     const int conv_in = transpose_flip ? Cout : Cin;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void pack_weights_sb16_kernel(const float* __r
         v[j] = t;
     }
     uint4 cells[AR::NP];
-    split_cells8<AR>(v, AR::SCALED ? split_scale_of(split_amax_exp(amax_w)) : 1.f, cells);
+    split_cells8<AR>(v, wscale, cells);
     uint4* dst = wp + (((size_t)(co_tile * n_steps + ks) * NT + nt) * AR::NP) * 64 + lane;
 #pragma unroll
     for (int p = 0; p < AR::NP; ++p) dst[64 * p] = cells[p];
@@ -285,8 +286,8 @@ size_t packed_bytes(int arith, int Cin, int Cout) {
 int pack(const float* w, int Cout, int Cin, int transpose_flip, int NT, int arith, const unsigned* amax_w, void* wp,
          hipStream_t stream) {
     const int conv_in = transpose_flip ? Cout : Cin, conv_out = transpose_flip ? Cin : Cout;
-    CSEG_REQUIRE((NT == 3 || NT == 6) && conv_out % (NT * 16) == 0 && conv_in % 16 == 0,
-                 "conv3x3_sb16: needs 3 or 6 channel tiles per block (got %d) and input channels %% 16 == 0", NT);
+    CSEG_REQUIRE((NT == 3 || NT == 4 || NT == 6) && conv_out % (NT * 16) == 0 && conv_in % 16 == 0,
+                 "conv3x3_sb16: needs 3, 4 or 6 channel tiles per block (got %d) and input channels %% 16 == 0", NT);
     const long total = (long)(conv_out / 16) * steps16(conv_in) * 64;
     CSEG_REQUIRE(total < 2147483647L, "conv3x3_sb16 pack: too large");
     if (arith == CSEG_ARITH_F16X3)
@@ -301,14 +302,16 @@ int pack(const float* w, int Cout, int Cin, int transpose_flip, int NT, int arit
 
 int fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int NT, int arith,
         const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream) {
-    CSEG_REQUIRE((NT == 3 || NT == 6) && Cout % (NT * 16) == 0 && Cin % 16 == 0 && (long)H * W * 16 * 4 < 2147483647L,
+    CSEG_REQUIRE((NT == 3 || NT == 4 || NT == 6) && Cout % (NT * 16) == 0 && Cin % 16 == 0 && (long)H * W * 16 * 4 < 2147483647L,
                  "conv3x3_sb16: unsupported shape Cin=%d Cout=%d %dx%d with %d channel tiles per block", Cin, Cout, H, W, NT);
     const uint4* wq = (const uint4*)wp;
     if (arith == CSEG_ARITH_F16X3) {
         if (NT == 6) return launch_sb16<SplitF16x3, 6>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+        if (NT == 4) return launch_sb16<SplitF16x3, 4>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
         return launch_sb16<SplitF16x3, 3>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
     }
     if (NT == 6) return launch_sb16<SplitBF16x6, 6>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+    if (NT == 4) return launch_sb16<SplitBF16x6, 4>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
     return launch_sb16<SplitBF16x6, 3>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
 }
 

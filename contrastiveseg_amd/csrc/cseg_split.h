@@ -26,11 +26,23 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
-// max|x| of a tensor is handed around as the BIT PATTERN of that non-negative float (monotone as an unsigned integer, so a
-// plain atomicMax accumulates it). Scale of the f16x3 split: 2^k with k = 14 - floor(log2 max|x|).
-__device__ __forceinline__ unsigned split_amax_exp(const unsigned* __restrict__ amax_bits) {
-    unsigned e = (amax_bits ? *amax_bits : 0x3f800000u) >> 23 & 0xffu;          // biased exponent of max|x|
+// max|x| of a tensor is handed around as a RECORD of CSEG_AMAX_SLOTS words, CSEG_AMAX_STRIDE words apart (include/cseg_hip.h),
+// each the BIT PATTERN of a non-negative float (monotone as an unsigned integer, so a plain atomicMax accumulates it; the slots
+// spread the atomics of thousands of producer blocks over 32 cache lines). Scale of the f16x3 split: 2^k with
+// k = 14 - floor(log2 max|x|). Must be called by EVERY thread of the block (before any early exit): lane l reads slot l mod 32
+// and the 32-lane groups reduce with shuffles.
+__device__ __forceinline__ unsigned split_amax_exp(const unsigned* __restrict__ amax_rec) {
+    unsigned v = amax_rec ? amax_rec[(threadIdx.x & (CSEG_AMAX_SLOTS - 1)) * CSEG_AMAX_STRIDE] : 0x3f800000u;
+#pragma unroll
+    for (int o = CSEG_AMAX_SLOTS / 2; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+    const unsigned e = v >> 23 & 0xffu;                                          // biased exponent of max|x|
     return e < 15u ? 15u : (e > 253u ? 253u : e);                                // all-zero / tiny / non-finite tensors: any finite scale
+}
+// a block's maximum into its slot of the record: at most one atomic per block, none when the slot already holds more (a stale
+// read only costs a redundant atomic: the words never decrease)
+__device__ __forceinline__ void amax_publish_block(unsigned block_max, unsigned* __restrict__ amax_rec) {
+    unsigned* slot = amax_rec + (blockIdx.x & (CSEG_AMAX_SLOTS - 1)) * CSEG_AMAX_STRIDE;
+    if (block_max > *reinterpret_cast<volatile unsigned*>(slot)) atomicMax(slot, block_max);
 }
 __device__ __forceinline__ float split_scale_of(unsigned e) { return __builtin_bit_cast(float, (268u - e) << 23); }     // 2^(141 - e)
 __device__ __forceinline__ float split_unscale_of(unsigned e) { return __builtin_bit_cast(float, (e - 14u) << 23); }    // 2^(e - 141)

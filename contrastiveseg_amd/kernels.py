@@ -663,26 +663,28 @@ def split_arith_id():
     return ARITH_IDS[SPLIT_ARITH]
 
 
-_AMAX_ARENAS = {}        # device -> [arena int32 [4096] (zeroed once), next free slot]
+AMAX_WORDS = 1024        # CSEG_AMAX_WORDS of include/cseg_hip.h: 32 slots, 128 bytes apart
+_AMAX_ARENAS = {}        # device -> [arena int32 [2048 x AMAX_WORDS] (zeroed once), next free record]
 
 
 def amax_slot(device):
-    """A zeroed uint32 word on the device (a 1-element int32 view into an arena that is zero-filled once per 4096 slots, so
-    that a maximum costs ONE launch, not a fill + a launch). Slots are not recycled: a used arena lives as long as a view of it."""
+    """A zeroed max|.| record on the device (include/cseg_hip.h: CSEG_AMAX_WORDS uint32): a view into an arena that is zero-filled
+    once per 2048 records, so that a maximum costs ONE launch, not a fill + a launch. Records are not recycled: a used arena
+    lives as long as a view of it."""
     key = (device.type, device.index)
     st = _AMAX_ARENAS.get(key)
-    if st is None or st[1] >= st[0].numel():
-        st = [torch.zeros(4096, dtype=I32, device=device), 0]
+    if st is None or st[1] >= st[0].shape[0]:
+        st = [torch.zeros(2048, AMAX_WORDS, dtype=I32, device=device), 0]
         _AMAX_ARENAS[key] = st
     i = st[1]
     st[1] = i + 1
-    return st[0][i:i + 1]
+    return st[0][i]
 
 
 @torch.no_grad()
 def tensor_amax(t, slot=None):
-    """max|t| as the split kernels take it: a device int32 [1] holding the bit pattern of that float. `slot`: accumulate into an
-    existing word (max over several tensors)."""
+    """max|t| as the split kernels take it: a device record (amax_slot) whose maximum word is the bit pattern of that float.
+    `slot`: accumulate into an existing record (max over several tensors)."""
     if slot is None:
         slot = amax_slot(t.device)
     _hip.call("cseg_amax_f32", _p(t, F32, "tensor"), ctypes.c_long(t.numel()), _pf(slot), _hip.stream_ptr())
@@ -753,19 +755,22 @@ CONV3X3_SPLIT_BF16 = os.environ.get("CSEG_CONV3X3_SPLIT_BF16", "1") == "1"
 # benched shapes, tools/conv3x3_sb_probe.py: 96 ch 70 vs 101 us; 48 ch 99 vs 106 us on the fp32-MFMA kernel; 192 ch at
 # 8x32x64 with 3 channel tiles per block 81 / 78 us forward / backward-data vs 98-117 us on MIOpen's Winograd kernel,
 # profiles/r02_conv3x3_split_bf16_nt_probe.jsonl). 384 channels (16x32 maps) can be added but waste half of every tile.
-CONV3X3_SB_BRANCH_CHANNELS = tuple(int(c) for c in os.environ.get("CSEG_CONV3X3_SB_CHANNELS", "48,96,192").split(","))
+# 384 channels (8x16x32 maps: half of every 4x64 tile is padding) since round 3: with three MFMAs per product the kernel still beats
+# MIOpen's NHWC implicit GEMM + its layout transposes (87 vs 117 + ~30 us, gpurun r03j3 split_arith_probe).
+CONV3X3_SB_BRANCH_CHANNELS = tuple(int(c) for c in os.environ.get("CSEG_CONV3X3_SB_CHANNELS", "48,64,96,192,384").split(","))
 # channel counts that go through the explicit-tiling entry points (conv3x3_sb_pick_nt); 48 / 96 / 720 keep the library's
 # default tiling, which is what the parity suite ran on
 CONV3X3_SB_PICK_NT_CHANNELS = (192, 384)
 
 
 def conv3x3_sb_eligible(x, weight):
-    """NCHW fp32 on the GPU, 3x3, channels % 48 both ways (forward needs Cin % 16 and Cout % 48, backward-data the
-    mirror image), width % 4."""
+    """NCHW fp32 on the GPU, 3x3, channels % 48 (or exactly 64: the layer-1 bottlenecks) both ways (forward needs Cin % 16 and
+    a tiling Cout, backward-data the mirror image), width % 4."""
     if not (_on_device(x) and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4 and x.is_contiguous()):
         return False
     co, ci, kh, kw = weight.shape
-    return (kh, kw) == (3, 3) and ci % 48 == 0 and co % 48 == 0 and x.shape[1] == ci and x.shape[3] % 4 == 0
+    ok = lambda c: c % 48 == 0 or c == 64
+    return (kh, kw) == (3, 3) and ok(ci) and ok(co) and x.shape[1] == ci and x.shape[3] % 4 == 0
 
 
 def conv3x3_sb_pick_nt(x, c_out):
@@ -827,7 +832,7 @@ def conv3x3_sb_tiles(x, c_out):
     if c_out in CONV3X3_SB_PICK_NT_CHANNELS:
         nt16 = 16 * conv3x3_sb_pick_nt(x, c_out)
     else:
-        nt16 = 144 if c_out % 144 == 0 else 96 if c_out % 96 == 0 else 48
+        nt16 = 144 if c_out % 144 == 0 else 96 if c_out % 96 == 0 else 48 if c_out % 48 == 0 else 64
     return x.shape[0] * (c_out // nt16) * ((x.shape[2] + 3) // 4) * ((x.shape[3] + 63) // 64)
 
 

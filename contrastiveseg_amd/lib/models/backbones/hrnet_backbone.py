@@ -58,7 +58,7 @@ class Bottleneck(nn.Module):
         super(Bottleneck, self).__init__()
         self.conv1 = Conv1x1(inplanes, planes, bias=False)
         self.bn1 = _norm(bn_type, planes, bn_momentum)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.conv2 = Conv3x3(planes, planes, stride)        # an nn.Conv2d (same init, same state_dict); 64 ch -> split kernel
         self.bn2 = _norm(bn_type, planes, bn_momentum)
         self.conv3 = Conv1x1(planes, planes * 4, bias=False)
         self.bn3 = _norm(bn_type, planes * 4, bn_momentum)

@@ -309,13 +309,21 @@ int cseg_conv1x1_sb_wrw(const float* x, const float* dy, int B, int Cin, int Cou
  *   CSEG_ARITH_BF16X6  three bf16 pieces per operand, six MFMAs per product (roof 2500/6 = 417 TFLOP/s fp32-equivalent)
  *   CSEG_ARITH_F16X3   two fp16 pieces of the operand scaled by a power of two, three MFMAs per product (roof 833 TFLOP/s);
  *                      same fp32-class accuracy (csrc/cseg_split.h).  The scale comes from max|tensor|, which the caller
- *                      supplies as a DEVICE pointer to the bit pattern of that float (one uint32; cseg_amax_f32 accumulates
- *                      it with atomicMax into a word the caller has zeroed; several tensors may share one word).  With
+ *                      supplies as a DEVICE pointer to a max|tensor| record (CSEG_AMAX_WORDS uint32, below; cseg_amax_f32
+ *                      accumulates into a record the caller has zeroed).  With
  *                      BF16X6 the amax pointers may be NULL.
  * pack and forward / weight gradient of one operator must use the same arith (and nt).  nt = 0: the library's tiling.
  * ------------------------------------------------------------------------------------------------ */
 #define CSEG_ARITH_BF16X6 0
 #define CSEG_ARITH_F16X3 1
+/* A max|tensor| RECORD is CSEG_AMAX_WORDS uint32 (4 KB): CSEG_AMAX_SLOTS words, CSEG_AMAX_STRIDE words (128 bytes) apart, each
+ * the bit pattern of a non-negative float; the value is the maximum over the slots.  Producers (cseg_amax_f32, the
+ * cseg_bn_*_amax calls) accumulate with atomicMax into slot (block index mod CSEG_AMAX_SLOTS): thousands of blocks hitting ONE
+ * word serialise in the L2 atomic unit (measured: 15 -> 33 us for a 48-channel BN apply kernel with a single word), 32 words on
+ * 32 cache lines do not.  The caller zeroes the record; several tensors may share one. */
+#define CSEG_AMAX_SLOTS 32
+#define CSEG_AMAX_STRIDE 32
+#define CSEG_AMAX_WORDS (CSEG_AMAX_SLOTS * CSEG_AMAX_STRIDE)
 int cseg_amax_f32(const float* x, long n, unsigned* amax_bits, cseg_stream_t stream);
 size_t cseg_conv3x3_split_packed_bytes(int arith, int Cin, int Cout);
 int cseg_conv3x3_split_pack(const float* w, int Cout, int Cin, int transpose_flip, int nt, int arith, const unsigned* amax_w,

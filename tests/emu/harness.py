@@ -83,10 +83,11 @@ BF16X6, F16X3 = 0, 1
 
 def amax(a):
     """max|a| as the library hands it around: one uint32 holding the bit pattern, accumulated by cseg_amax_f32."""
-    out = aligned((4,), np.uint32, 0)
+    out = aligned((1024,), np.uint32, 0)       # CSEG_AMAX_WORDS: 32 slots, 32 words apart
     d = dev(a)
     call("cseg_amax_f32", ptr(d), ctypes.c_long(d.size), ptr(out), None)
-    assert out[0] == np.abs(a.astype(np.float32)).max().view(np.uint32), (out[0], np.abs(a).max())
+    assert out[::32].max() == np.abs(a.astype(np.float32)).max().view(np.uint32), (out[::32].max(), np.abs(a).max())
+    assert not out.reshape(32, 32)[:, 1:].any()
     return out
 
 

@@ -167,20 +167,26 @@ def test_bench_line_is_assembled_from_measurements(monkeypatch):
         for world, split_on, extras in ((1, True, True), (8, False, False)):
             args = types.SimpleNamespace(steps=10, warmup=3, scaling="strong", workload=workload, labels=None, miopen_find=0,
                                          channels_last=0)
-            kernels = {"conv3x3_split_bf16 720->720 (pack + conv)": {"us": 10970.0, "bound": "mfma", "flops": 2446118092800,
-                                                                     "achieved_TFLOPs": 223.0, "peak_TFLOPs": 416.7,
-                                                                     "frac": 0.535}} if extras else {"error": "boom"}
+            kernels = {"upcat_fwd": {"us": 190.0}} if extras else {"error": "boom"}
+            rows = [{"kernel": "conv3x3 720->720 forward @8x128x256", "entry": "conv3x3_sb_run", "calls_per_step": 1,
+                     "us_per_launch": 6500.0, "ms_per_step": 6.5, "algorithmic_flops_per_launch": 2446118092800,
+                     "achieved_TFLOPs": 376.3, "peak_TFLOPs": 833.3, "frac": 0.4516}] if extras else None
             line = bench.assemble_line(args, wl, cfg, world, wl["batch"], 1.766, 1765.0, 2.34567, split_on, Kn,
                                        "nccl" if world > 1 else None, {"value": 40.0} if extras else None, None,
-                                       {"value": 0.2, "cores": 16, "kind": "port"} if extras else None, kernels)
+                                       {"value": 0.2, "cores": 16, "kind": "port"} if extras else None, kernels,
+                                       rows, 12.7e12 if extras else 0.0)
             back = json.loads(json.dumps(line))
             for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                         "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
                 assert key in back, key
             assert back["n_gpus"] == world and abs(back["value"] - wl["batch"] * 10 / 1.766) < 1e-2
             assert abs(back["roofline"]["frac"] - back["roofline"]["achieved"] / back["roofline"]["peak"]) < 1e-3
-            assert ("dominant_kernel" in back["roofline"]) == extras
-            assert ("split-bf16" in back["config"]["conv3x3_arithmetic"]) == split_on
+            assert ("dominant_kernel" in back["roofline"]) == extras == ("blended_roof" in back["roofline"])
+            if extras:
+                assert back["roofline"]["dominant_kernel"]["name"] == rows[0]["kernel"]
+                br = back["roofline"]["blended_roof"]
+                assert abs(br["frac"] - br["roof_ms_per_step"] / 176.5) < 1e-3 and br["frac"] > 0
+            assert (("split-fp16" in back["config"]["conv3x3_arithmetic"]) or ("split-bf16" in back["config"]["conv3x3_arithmetic"])) == split_on
 
 
 def test_bench_guard_repeats_once_with_the_hardware_measured_routes(monkeypatch, capfd):

@@ -424,7 +424,7 @@ def test_host_tiling_heuristics():
     assert K.conv1x1_sb_tiles(meta(8, 720, 128, 256), 256) == 8 * 2 * 128
     assert K.conv1x1_sb_tiles(meta(8, 720, 128, 256), 720) == 8 * 5 * 128
     # defaults (round 3): every split kernel that won its hardware timing in the round-2 driver pass is on
-    assert isinstance(K.CONV3X3_SPLIT_BF16, bool) and K.CONV3X3_SB_BRANCH_CHANNELS[:2] == (48, 96)
+    assert isinstance(K.CONV3X3_SPLIT_BF16, bool) and K.CONV3X3_SB_BRANCH_CHANNELS[:3] == (48, 64, 96)
     import os
     if not any(k.startswith("CSEG_CONV") for k in os.environ):
         assert K.CONV3X3_SB_WRW and K.CONV3X3_SB_WRW_CHANNELS == (48, 96, 192, 720)
