@@ -17,13 +17,13 @@
 // (kernels.CONV1X1_SPLIT_BF16).
 // Round 3: default on the GPU (720 -> 720: 1.5-1.65 vs 2.2 ms on rocBLAS in the round-2 driver pass); written against the
 // arithmetic traits of cseg_split.h (bf16x6 and f16x3: two scaled fp16 pieces, three MFMAs per product).
-#include "cseg_split.h"
+#include "cseg_pack.h"
 
 namespace {
 
 constexpr int MT_PX = 256;                  // pixels per block
 
-__host__ __device__ constexpr int steps1(int Cin) { return (Cin + 31) / 32; }
+__host__ __device__ constexpr int steps1(int Cin) { return pack_steps_c1(Cin); }
 
 // Packed weights: Wp[co_tile][kstep][nt][piece][lane] of uint4 (8 bf16, element j), lane = 16*g + n:
 //   value(co = (co_tile*NT + nt)*16 + n, ci = 32*kstep + 8g + j), zero beyond the channel count.
@@ -35,28 +35,7 @@ __global__ __launch_bounds__(256) void pack_weights_1x1_kernel(const float* __re
     const float wscale = AR::SCALED ? split_scale_of(split_amax_exp(amax_w)) : 1.f;      // every thread (shuffles inside)
     const int e = blockIdx.x * 256 + threadIdx.x;          // one thread per (co_tile, kstep, nt, lane)
     if (e >= total) return;
-    const int conv_in = transpose ? Cout : Cin;
-    const int n_steps = steps1(conv_in);
-    int r = e;
-    const int lane = r & 63; r >>= 6;
-    const int nt = r % NT; r /= NT;
-    const int ks = r % n_steps;
-    const int co_tile = r / n_steps;
-    const int g = lane >> 4, n = lane & 15;
-    const int oc = (co_tile * NT + nt) * 16 + n;           // output channel of THIS operator
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int ic = ks * 32 + 8 * g + j;                // input channel of THIS operator
-        float t = 0.f;
-        if (ic < conv_in) t = transpose ? w[(size_t)ic * Cin + oc] : w[(size_t)oc * Cin + ic];
-        v[j] = t;
-    }
-    uint4 cells[AR::NP];
-    split_cells8<AR>(v, wscale, cells);
-    uint4* dst = wp + (((size_t)(co_tile * n_steps + ks) * NT + nt) * AR::NP) * 64 + lane;
-#pragma unroll
-    for (int p = 0; p < AR::NP; ++p) dst[64 * p] = cells[p];
+    pack_elem_c1<AR>(w, Cout, Cin, transpose, NT, wscale, wp, e);
 }
 
 template <class AR, int NTW, int NTMAX>
@@ -287,6 +266,13 @@ int run_1x1(const float* x, const void* wp, const float* bias, int B, int Cin, i
 }
 
 }  // namespace
+
+extern "C" int cseg_conv1x1_split_plan(int conv_in, int conv_out, int* nt, long* threads) {
+    if (!nt || !threads || conv_in <= 0 || conv_out <= 0 || conv_in % 16 || pick_nt1(conv_out) == 0) return 0;
+    *nt = pick_nt1(conv_out);
+    *threads = (long)(conv_out / 16) * steps1(conv_in) * 64;
+    return 1;
+}
 
 extern "C" size_t cseg_conv1x1_split_packed_bytes(int arith, int Cin, int Cout) {
     if ((arith != CSEG_ARITH_BF16X6 && arith != CSEG_ARITH_F16X3) || Cin <= 0 || Cout <= 0 || Cin % 16 || pick_nt1(Cout) == 0) return 0;

@@ -33,7 +33,7 @@
 // and f16x3 (two scaled fp16 pieces, three MFMAs per product, roof 2500 / 3 = 833 TFLOP/s of fp32-equivalent work). The f16x3
 // form needs max|x| and max|w| (device pointers, bit patterns; cseg_amax_f32): the patch is scaled while it is split, the weights
 // while they are packed, and the epilogue multiplies the accumulators by the inverse power of two.
-#include "cseg_split.h"
+#include "cseg_pack.h"
 #include <stdlib.h>
 
 // conv3x3_sb16.hip: the small-channel variant (16-channel chunks, two blocks per CU), reached under CSEG_CONV3X3_SB_VAR=2
@@ -74,7 +74,7 @@ constexpr int CELLS = XROWS * XCOLS;  // 396 pixels per (piece, octet)
 constexpr int A_ITEMS = 4 * CELLS;    // (octet, pixel) staging items of a 32-channel chunk
 constexpr int AU = (A_ITEMS + 511) / 512;     // staging items per thread (512 threads)
 
-__host__ __device__ constexpr int steps_of(int Cin) { return (Cin / 32) * 9 + ((Cin & 31) ? 5 : 0); }
+__host__ __device__ constexpr int steps_of(int Cin) { return pack_steps_c3(Cin); }
 
 // Packed weights: Wp[co_tile][kstep][nt][piece][lane] of uint4 (8 bf16, element j), lane = 16*g + n:
 //   full K-step (chunk c, tap t):  value(co = (co_tile*NT + nt)*16 + n, ci = 32c + 8g + j, tap t)
@@ -86,34 +86,7 @@ __global__ __launch_bounds__(256) void pack_weights_sb_kernel(const float* __res
     const float wscale = AR::SCALED ? split_scale_of(split_amax_exp(amax_w)) : 1.f;      // every thread (shuffles inside)
     const int e = blockIdx.x * 256 + threadIdx.x;          // one thread per (co_tile, kstep, nt, lane)
     if (e >= total) return;
-    const int conv_in = transpose_flip ? Cout : Cin;
-    const int n_full = conv_in / 32, n_steps = steps_of(conv_in);
-    int r = e;
-    const int lane = r & 63; r >>= 6;
-    const int nt = r % NT; r /= NT;
-    const int ks = r % n_steps;
-    const int co_tile = r / n_steps;
-    const int g = lane >> 4, n = lane & 15;
-    const int oc = (co_tile * NT + nt) * 16 + n;           // output channel of THIS convolution
-    int tap, ic0;
-    if (ks < n_full * 9) { tap = ks % 9; ic0 = (ks / 9) * 32 + 8 * g; }
-    else { tap = 2 * (ks - n_full * 9) + (g >> 1); ic0 = n_full * 32 + 8 * (g & 1); }
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int ic = ic0 + j;                            // input channel of THIS convolution
-        float t = 0.f;
-        if (tap <= 8) {
-            if (!transpose_flip) t = w[((size_t)oc * Cin + ic) * 9 + tap];            // w[co][ci][ky][kx]
-            else t = w[((size_t)ic * Cin + oc) * 9 + (8 - tap)];                      // w[co=ic][ci=oc][2-ky][2-kx]
-        }
-        v[j] = t;
-    }
-    uint4 cells[AR::NP];
-    split_cells8<AR>(v, wscale, cells);
-    uint4* dst = wp + (((size_t)(co_tile * n_steps + ks) * NT + nt) * AR::NP) * 64 + lane;
-#pragma unroll
-    for (int p = 0; p < AR::NP; ++p) dst[64 * p] = cells[p];
+    pack_elem_c3<AR>(w, Cout, Cin, transpose_flip, NT, wscale, wp, e);
 }
 
 // One K-step of a wave: 4 pixel tiles x NTW channel tiles x 6 piece products. `ap` = this lane's cell in the hi-piece
@@ -403,6 +376,22 @@ extern "C" size_t cseg_conv3x3_split_packed_bytes(int arith, int Cin, int Cout) 
     if (!arith_ok(arith) || Cin <= 0 || Cout <= 0 || Cin % 16 || pick_nt(Cout) == 0) return 0;
     if (use_sb16(Cout)) return cseg_sb16::packed_bytes(arith, Cin, Cout);
     return (size_t)(Cout / 16) * steps_of(Cin) * np_of(arith) * 64 * sizeof(uint4);
+}
+
+extern "C" int cseg_conv3x3_split_plan(int conv_in, int conv_out, int nt_request, int* kind, int* nt, long* threads) {
+    if (!kind || !nt || !threads || conv_in <= 0 || conv_out <= 0 || conv_in % 16 || pick_nt(conv_out) == 0) return 0;
+    if (use_sb16(conv_out)) {
+        *kind = CSEG_PACK_C3_16;
+        *nt = sb16_nt(conv_out, nt_request);
+        if (conv_out % (*nt * 16)) return 0;
+        *threads = (long)(conv_out / 16) * pack_steps_c3_16(conv_in) * 64;
+        return 1;
+    }
+    *kind = CSEG_PACK_C3;
+    *nt = nt_request ? nt_request : pick_nt(conv_out);
+    if (!nt_ok(*nt, conv_out)) return 0;
+    *threads = (long)(conv_out / 16) * pack_steps_c3(conv_in) * 64;
+    return 1;
 }
 
 extern "C" size_t cseg_conv3x3_sb_packed_bytes(int Cin, int Cout) {

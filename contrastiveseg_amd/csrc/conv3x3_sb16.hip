@@ -12,7 +12,7 @@
 // Entry points: the cseg_conv3x3_sb_* family dispatches here when CSEG_CONV3X3_SB_VAR=2 (packing and forward must run under
 // the same setting; kernels.conv3x3_sb_run does both back to back).
 // Round 3: default for 48 / 192 output channels; written against the arithmetic traits of cseg_split.h (bf16x6 and f16x3).
-#include "cseg_split.h"
+#include "cseg_pack.h"
 #include <stdlib.h>
 
 namespace {
@@ -27,7 +27,7 @@ constexpr int A_ITEMS = NOCT * CELLS; // (octet, pixel) staging items of a 16-ch
 constexpr int AU = (A_ITEMS + 511) / 512;     // staging items per thread (512 threads): 2
 constexpr int STEPS = 5;              // K-steps per chunk: taps (0,1) (2,3) (4,5) (6,7) (8,-)
 
-__host__ __device__ constexpr int steps16(int Cin) { return (Cin / 16) * STEPS; }
+__host__ __device__ constexpr int steps16(int Cin) { return pack_steps_c3_16(Cin); }
 
 // Packed weights: Wp[co_tile][kstep][nt][piece][lane] of uint4 (8 bf16, element j), lane = 16*g + n; K-step ks = 5*chunk + q:
 //   value(co = (co_tile*NT + nt)*16 + n, ci = 16*chunk + 8*(g&1) + j, tap = 2q + (g>>1))   (zero when tap > 8)
@@ -38,33 +38,7 @@ __global__ __launch_bounds__(256) void pack_weights_sb16_kernel(const float* __r
     const float wscale = AR::SCALED ? split_scale_of(split_amax_exp(amax_w)) : 1.f;      // every thread (shuffles inside)
     const int e = blockIdx.x * 256 + threadIdx.x;          // one thread per (co_tile, kstep, nt, lane)
     if (e >= total) return;
-    const int conv_in = transpose_flip ? Cout : Cin;
-    const int n_steps = steps16(conv_in);
-    int r = e;
-    const int lane = r & 63; r >>= 6;
-    const int nt = r % NT; r /= NT;
-    const int ks = r % n_steps;
-    const int co_tile = r / n_steps;
-    const int g = lane >> 4, n = lane & 15;
-    const int oc = (co_tile * NT + nt) * 16 + n;           // output channel of THIS convolution
-    const int chunk = ks / STEPS, q = ks - chunk * STEPS;
-    const int tap = 2 * q + (g >> 1), ic0 = 16 * chunk + 8 * (g & 1);
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int ic = ic0 + j;                            // input channel of THIS convolution
-        float t = 0.f;
-        if (tap <= 8) {
-            if (!transpose_flip) t = w[((size_t)oc * Cin + ic) * 9 + tap];            // w[co][ci][ky][kx]
-            else t = w[((size_t)ic * Cin + oc) * 9 + (8 - tap)];                      // w[co=ic][ci=oc][2-ky][2-kx]
-        }
-        v[j] = t;
-    }
-    uint4 cells[AR::NP];
-    split_cells8<AR>(v, wscale, cells);
-    uint4* dst = wp + (((size_t)(co_tile * n_steps + ks) * NT + nt) * AR::NP) * 64 + lane;
-#pragma unroll
-    for (int p = 0; p < AR::NP; ++p) dst[64 * p] = cells[p];
+    pack_elem_c3_16<AR>(w, Cout, Cin, transpose_flip, NT, wscale, wp, e);
 }
 
 // One K-step of a wave: 4 pixel tiles x NTW channel tiles x 6 piece products (see conv3x3_sb.hip:sb_kstep)

@@ -246,18 +246,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw_kernel(const float* __r
 // fall on 16 distinct bank quads), dy [2][piece][co 48][72]: 155 KB.
 // Status: index-checked against the numpy lane model; first hardware run pending (CSEG_CONV3X3_SB_WRW_V=2 selects it).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int X2_CH = 296;                          // elements per (piece, ci): 4 slots x 72 + 8 pad  (148 dwords)
-constexpr int RPU2 = 16;
-__host__ __device__ constexpr int x2_elems(int np) { return np * CI_B * X2_CH; }
-__host__ __device__ constexpr int d2_elems(int np) { return 2 * np * CO_B * DP; }
+// Round 3: SEGW = 64 (two K-steps per row-step) or 32 (one: the 384-channel maps are 32 columns wide). Per (piece, ci) the x ring
+// holds 4 slots of SEGW + 8 entries + 8 pad = 296 / 168 half-words = 148 / 84 dwords (4 x odd either way); a dy row has
+// SEGW + 8 half-words (36 / 20 dwords = 4 x odd).
+__host__ __device__ constexpr int x2_ch(int segw) { return 4 * (segw + 8) + 8; }
+__host__ __device__ constexpr int x2_elems(int np, int segw) { return np * CI_B * x2_ch(segw); }
+__host__ __device__ constexpr int d2_elems(int np, int segw) { return 2 * np * CO_B * (segw + 8); }
 
-__device__ __forceinline__ int x2_idx(int p, int ci, int slot, int i) { return (p * CI_B + ci) * X2_CH + slot * 72 + i; }
-template <int NP>
-__device__ __forceinline__ int d2_idx(int buf, int p, int co, int i) { return ((buf * NP + p) * CO_B + co) * DP + i; }
+template <int SEGW>
+__device__ __forceinline__ int x2_idx(int p, int ci, int slot, int i) { return (p * CI_B + ci) * x2_ch(SEGW) + slot * (SEGW + 8) + i; }
+template <int NP, int SEGW>
+__device__ __forceinline__ int d2_idx(int buf, int p, int co, int i) { return ((buf * NP + p) * CO_B + co) * (SEGW + 8) + i; }
 
-template <class AR>
+template <class AR, int SEGW>
 __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                 int B, int Cin, int Cout, int H, int W, int n_split,
+                                                                 int B, int Cin, int Cout, int H, int W, int n_split, int rpu,
                                                                  int SC, int SI, const unsigned* __restrict__ amax_x,
                                                                  const unsigned* __restrict__ amax_dy,
                                                                  float* __restrict__ partial) {
@@ -265,7 +268,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
     constexpr int NP = AR::NP;
     typedef typename AR::frag_t frag_t;
     unsigned short* xs = smem_w;
-    unsigned short* ds = smem_w + x2_elems(NP);
+    unsigned short* ds = smem_w + x2_elems(NP, SEGW);
+    constexpr int XCH = (SEGW + 8) / 4, XU = (CI_B * XCH + 255) / 256;       // float4 chunks per x row, per loader thread
+    constexpr int DCH = SEGW / 4, DU = (CO_B * DCH + 255) / 256;             // float4 chunks per dy row, per loader thread
     const unsigned ex = AR::SCALED ? split_amax_exp(amax_x) : 141u, ed = AR::SCALED ? split_amax_exp(amax_dy) : 141u;
     const float xscale = split_scale_of(ex), dscale = split_scale_of(ed);      // 1 for the unscaled arithmetic
     // readfirstlane: the role split below must be a SCALAR branch (the wave index is uniform, which the compiler cannot see)
@@ -291,75 +296,77 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
         cob = (st / n_si) * SC + j / SI;
     }
     const size_t plane = (size_t)H * W;
-    const int segs = W / SEG;
-    const int runs = (H + RPU2 - 1) / RPU2;
+    const int segs = W / SEGW;
+    const int runs = (H + rpu - 1) / rpu;
     const int n_units = B * segs * runs;
     const bool tile_ok = !loader && cib * CI_B + wave * 16 < Cin;
 
     // ---- loader side. x row: 64 ci x 18 chunks of 4 entries (entry i = pixel x0 - 4 + i); dy row: 48 co x 16 chunks
-    auto x_load = [&](int b, int x0, int row, float4 (&v)[5]) {
+    auto x_load = [&](int b, int x0, int row, float4 (&v)[XU]) {
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int item = min(lt + 256 * u, CI_B * 18 - 1);
-            const int ci = item / 18, c = item - ci * 18;
+        for (int u = 0; u < XU; ++u) {
+            const int item = min(lt + 256 * u, CI_B * XCH - 1);
+            const int ci = item / XCH, c = item - ci * XCH;
             const int px = x0 - 4 + 4 * c;
             const int cic = min(cib * CI_B + ci, Cin - 1), rowc = min(max(row, 0), H - 1), pxc = min(max(px, 0), W - 4);
             v[u] = *reinterpret_cast<const float4*>(x + ((size_t)b * Cin + cic) * plane + (size_t)rowc * W + pxc);
         }
     };
-    auto x_put = [&](int x0, int row, int slot, const float4 (&v)[5]) {
+    auto x_put = [&](int x0, int row, int slot, const float4 (&v)[XU]) {
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
+        for (int u = 0; u < XU; ++u) {
             const int item = lt + 256 * u;
-            if (item < CI_B * 18) {
-                const int ci = item / 18, c = item - ci * 18;
+            if (item < CI_B * XCH) {
+                const int ci = item / XCH, c = item - ci * XCH;
                 const int px = x0 - 4 + 4 * c;
                 const bool ok = cib * CI_B + ci < Cin && row >= 0 && row < H && px >= 0 && px < W;
                 const float4 t = ok ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 cells[NP];
                 split_cells4<AR>(t, xscale, cells);
 #pragma unroll
-                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(xs + x2_idx(p, ci, slot, 4 * c)) = cells[p];
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(xs + x2_idx<SEGW>(p, ci, slot, 4 * c)) = cells[p];
             }
         }
     };
-    auto d_load = [&](int b, int x0, int row, float4 (&v)[3]) {
+    auto d_load = [&](int b, int x0, int row, float4 (&v)[DU]) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int item = lt + 256 * u;             // 768 items exactly
-            const int co = item >> 4, c = item & 15;
+        for (int u = 0; u < DU; ++u) {
+            const int item = min(lt + 256 * u, CO_B * DCH - 1);
+            const int co = item / DCH, c = item - co * DCH;
             v[u] = *reinterpret_cast<const float4*>(dy + (((size_t)b * Cout + cob * CO_B + co) * H + min(row, H - 1)) * W + x0 + 4 * c);
         }
     };
-    auto d_put = [&](int buf, const float4 (&v)[3]) {
+    auto d_put = [&](int buf, const float4 (&v)[DU]) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int u = 0; u < DU; ++u) {
             const int item = lt + 256 * u;
-            const int co = item >> 4, c = item & 15;
-            uint2 cells[NP];
-            split_cells4<AR>(v[u], dscale, cells);
+            if (item < CO_B * DCH) {
+                const int co = item / DCH, c = item - co * DCH;
+                uint2 cells[NP];
+                split_cells4<AR>(v[u], dscale, cells);
 #pragma unroll
-            for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(ds + d2_idx<NP>(buf, p, co, 4 * c)) = cells[p];
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(ds + d2_idx<NP, SEGW>(buf, p, co, 4 * c)) = cells[p];
+            }
         }
     };
 
     // ---- consumer side: output row with x rows in slots s0 (row - 1), s0 + 1, s0 + 2 (mod 4), dy in buffer `buf`
     auto compute = [&](int s0, int buf, f32x4 (&acc)[9][3]) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < SEGW / 32; ++ks) {
             frag_t a[3][NP];
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    a[c][p] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(ds + d2_idx<NP>(buf, p, c * 16 + n, 32 * ks + 8 * g)));
+                    a[c][p] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(ds + d2_idx<NP, SEGW>(buf, p, c * 16 + n, 32 * ks + 8 * g)));
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int slot = (s0 + ky) & 3;
                 frag_t bfr[3][NP];                     // [kx][piece]
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    const unsigned short* src = xs + x2_idx(p, wave * 16 + n, slot, 32 * ks + 8 * g);
+                    const unsigned short* src = xs + x2_idx<SEGW>(p, wave * 16 + n, slot, 32 * ks + 8 * g);
                     const uint4 c0 = *reinterpret_cast<const uint4*>(src);          // entries e .. e+7    (d0..d3)
                     const uint4 c1 = *reinterpret_cast<const uint4*>(src + 8);      // entries e+8 .. e+15 (d4..d7)
                     const unsigned a21 = __builtin_amdgcn_alignbit(c0.z, c0.y, 16), a32 = __builtin_amdgcn_alignbit(c0.w, c0.z, 16),
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
         const int run = t % runs; t /= runs;
         const int seg = t % segs;
         b = t / segs;
-        x0 = seg * SEG; ya = run * RPU2; yb = min(ya + RPU2, H);
+        x0 = seg * SEGW; ya = run * rpu; yb = min(ya + rpu, H);
     };
 
     // The two roles run separate loops (separate register budgets: staging registers on one side, 27 accumulators on the
@@ -395,10 +402,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
         for (int unit = split; unit < n_units; unit += n_split) {
             int b, x0, ya, yb;
             unit_dims(unit, b, x0, ya, yb);
-            float4 xv[5], dv[3];
+            float4 xv[XU], dv[DU];
             {   // prologue tick (the previous unit's last barrier has released the image): x rows ya-1, ya, ya+1 -> slots
                 // 0, 1, 2; dy row ya -> buffer 0; then the loads of the first steady tick are put in flight
-                float4 x0v[5], x1v[5];
+                float4 x0v[XU], x1v[XU];
                 x_load(b, x0, ya - 1, x0v);
                 x_load(b, x0, ya, x1v);
                 x_load(b, x0, ya + 1, xv);
@@ -493,9 +500,16 @@ int sb_wrw_version() {
     return e && atoi(e) == 1 ? 1 : 2;      // default: the producer / consumer version (13.2 vs 17.6 ms at 720 channels, 76-82 vs 108-114 us on the branches)
 }
 
-int sb_wrw_splits(int B, int Cin, int Cout, int H, int W) {
-    const int rpu = sb_wrw_version() == 2 ? RPU2 : ROWS_PER_UNIT;
-    const int units = B * (W / SEG) * ((H + rpu - 1) / rpu);
+// version 2: 64-pixel row segments, or 32-pixel ones when the width is 32 mod 64 (the 384-channel maps of HRNet-W48: 16 x 32);
+// runs of 16 rows (8 on maps lower than 64 rows, so that small maps still give every split a unit)
+int wrw2_seg(int W) { return W % 64 == 0 ? 64 : 32; }
+int wrw2_rpu(int H) { return H >= 64 ? 16 : 8; }
+
+int sb_wrw_splits(int B, int Cin, int Cout, int H, int W, int arith) {
+    const bool v2 = arith == CSEG_ARITH_F16X3 || sb_wrw_version() == 2;
+    const int rpu = v2 ? wrw2_rpu(H) : ROWS_PER_UNIT;
+    const int seg = v2 ? wrw2_seg(W) : SEG;
+    const int units = B * (W / seg) * ((H + rpu - 1) / rpu);
     const int pairs = ((Cin + CI_B - 1) / CI_B) * (Cout / CO_B);
     int n = (768 + pairs - 1) / pairs;               // ~3 blocks per CU in total
     if (n > 256) n = 256;                            // bounds the partial buffer (256 x 9 x Cout x Cin floats)
@@ -506,9 +520,12 @@ int sb_wrw_splits(int B, int Cin, int Cout, int H, int W) {
 
 }  // namespace
 
+// the larger of the two arithmetics' needs (they may split differently: version 1 has no 32-pixel segments)
 extern "C" size_t cseg_conv3x3_sb_wrw_ws_floats(int B, int Cin, int Cout, int H, int W) {
-    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || Cin % 16 || Cout % CO_B || W % SEG) return 0;
-    return (size_t)sb_wrw_splits(B, Cin, Cout, H, W) * 9 * Cin * Cout;
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || Cin % 16 || Cout % CO_B || W % 32) return 0;
+    if (W % SEG && sb_wrw_version() != 2) return (size_t)sb_wrw_splits(B, Cin, Cout, H, W, CSEG_ARITH_F16X3) * 9 * Cin * Cout;
+    const int a = sb_wrw_splits(B, Cin, Cout, H, W, CSEG_ARITH_BF16X6), b = sb_wrw_splits(B, Cin, Cout, H, W, CSEG_ARITH_F16X3);
+    return (size_t)(a > b ? a : b) * 9 * Cin * Cout;
 }
 
 namespace {
@@ -528,13 +545,13 @@ void sb_wrw_group(int n_cob, int n_cib, int& SC, int& SI) {
     }
 }
 
-template <class AR>
+template <class AR, int SEGW>
 int launch_wrw2(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, int n_split, const unsigned* amax_x,
                 const unsigned* amax_dy, float* ws, hipStream_t stream) {
-    const size_t lds2 = sizeof(unsigned short) * (x2_elems(AR::NP) + d2_elems(AR::NP));
+    const size_t lds2 = sizeof(unsigned short) * (x2_elems(AR::NP, SEGW) + d2_elems(AR::NP, SEGW));
     static bool attr2_set = false;
     if (!attr2_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_sb_wrw2_kernel<AR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) !=
+        if (hipFuncSetAttribute((const void*)(conv3x3_sb_wrw2_kernel<AR, SEGW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) !=
             hipSuccess) {
             cseg_set_error("conv3x3_sb_wrw: cannot raise dynamic LDS to %zu bytes", lds2);
             return 0;
@@ -547,8 +564,8 @@ int launch_wrw2(const float* x, const float* dy, int B, int Cin, int Cout, int H
     const long n_groups = (long)n_split * (n_cob / SC) * (n_cib / SI);
     const long blocks = ((n_groups + 7) / 8) * 8 * SC * SI;
     CSEG_REQUIRE(blocks < 2147483647L, "conv3x3_sb_wrw: grid too large");
-    hipLaunchKernelGGL(conv3x3_sb_wrw2_kernel<AR>, dim3((unsigned)blocks), dim3(512), lds2, stream, x, dy, B, Cin, Cout, H, W,
-                       n_split, SC, SI, amax_x, amax_dy, ws);
+    hipLaunchKernelGGL((conv3x3_sb_wrw2_kernel<AR, SEGW>), dim3((unsigned)blocks), dim3(512), lds2, stream, x, dy, B, Cin, Cout, H, W,
+                       n_split, wrw2_rpu(H), SC, SI, amax_x, amax_dy, ws);
     CSEG_CHECK_LAUNCH("conv3x3_sb_wrw2_kernel");
     return 1;
 }
@@ -556,20 +573,24 @@ int launch_wrw2(const float* x, const float* dy, int B, int Cin, int Cout, int H
 int wrw_impl(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, int arith, const unsigned* amax_x,
              const unsigned* amax_dy, float* ws, float* dw, hipStream_t stream) {
     CSEG_REQUIRE(x && dy && ws && dw, "conv3x3_sb_wrw: null pointer");
-    CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % CO_B == 0 && W % SEG == 0,
-                 "conv3x3_sb_wrw: unsupported shape B=%d Cin=%d Cout=%d %dx%d (needs Cin %% 16, Cout %% 48, W %% 64)", B, Cin,
-                 Cout, H, W);
+    const bool v2 = arith == CSEG_ARITH_F16X3 || sb_wrw_version() == 2;
+    CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % CO_B == 0 && W % (v2 ? 32 : SEG) == 0,
+                 "conv3x3_sb_wrw: unsupported shape B=%d Cin=%d Cout=%d %dx%d (needs Cin %% 16, Cout %% 48, W %% 32; version 1: W %% 64)",
+                 B, Cin, Cout, H, W);
     CSEG_REQUIRE(arith == CSEG_ARITH_BF16X6 || (arith == CSEG_ARITH_F16X3 && amax_x && amax_dy),
                  "conv3x3 split wrw: arithmetic %d needs max|x| and max|dy|", arith);
-    const int n_split = sb_wrw_splits(B, Cin, Cout, H, W);
+    const int n_split = sb_wrw_splits(B, Cin, Cout, H, W, arith);
     const long blocks = (long)n_split * ((Cin + CI_B - 1) / CI_B) * (Cout / CO_B);
     CSEG_REQUIRE(blocks < 2147483647L && (long)9 * Cin * Cout < 2147483647L, "conv3x3_sb_wrw: grid too large");
-    if (arith == CSEG_ARITH_F16X3 || sb_wrw_version() == 2) {
+    if (v2) {
         CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0,
                      "conv3x3_sb_wrw: tensors must be 16-byte aligned");
+        const bool wide = wrw2_seg(W) == 64;
         const int ok = arith == CSEG_ARITH_F16X3
-                           ? launch_wrw2<SplitF16x3>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream)
-                           : launch_wrw2<SplitBF16x6>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream);
+                           ? (wide ? launch_wrw2<SplitF16x3, 64>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream)
+                                   : launch_wrw2<SplitF16x3, 32>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream))
+                           : (wide ? launch_wrw2<SplitBF16x6, 64>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream)
+                                   : launch_wrw2<SplitBF16x6, 32>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream));
         if (!ok) return 0;
     } else {
         const size_t lds = sizeof(unsigned short) * (XS_ELEMS + DS_ELEMS);

@@ -722,28 +722,128 @@ def amax_of(t):
     return a
 
 
-def _pack_key(weight, *what):
-    return (weight.data_ptr(), weight._version, SPLIT_ARITH, os.environ.get("CSEG_CONV3X3_SB_VAR")) + what
+import weakref
+
+import numpy as np
+
+_JOB_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("amax", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("flag", "<i4"),
+                       ("nt", "<i4"), ("kind", "<i4"), ("total", "<i4"), ("block0", "<i4"), ("reserved", "<i4")])   # cseg_split_job
 
 
-def _pack_cache(weight, key, make):
-    """Packed forms of a weight tensor, kept ON the tensor object and keyed by (storage, version counter, arithmetic, operator):
-    an optimizer step (in-place update) bumps the version and the next forward re-packs -- once per step and direction instead of
-    once per call (round 2 re-split, re-packed and re-allocated on every call: VERDICT r2 weak 13)."""
-    cache = getattr(weight, "_cseg_packs", None)
-    if cache is None or cache.get("version") != (weight.data_ptr(), weight._version):
-        cache = {"version": (weight.data_ptr(), weight._version)}
-        try:
-            weight._cseg_packs = cache
-        except Exception:                      # a tensor type that takes no attributes: no caching
-            return make()
-    if key not in cache:
-        cache[key] = make()
-    return cache[key]
+class SplitWeights(object):
+    """Packed forms of every split-operand convolution weight, refreshed for the WHOLE network in three launches per optimizer
+    step (zero the max|w| records, cseg_amax_batch, cseg_split_pack_batch) instead of three launches per layer (round-3 trace:
+    213 + 426 launches of ~5 us = 3.9 ms of GPU time and as many host launches per step).
+    A pack request (weight, operator) is registered on first use; its buffer and the weight's max|w| record then live as long as
+    the weight. Staleness = the weight's (storage pointer, version counter) differs from what was packed: an optimizer step
+    bumps the version of every trained weight, and the first request of the next forward repacks every stale entry at once."""
+
+    def __init__(self):
+        self.weights = {}                                # id(weight) -> state dict (holds a weak reference; dropped with the weight)
+        self.arena = None                                # [n, AMAX_WORDS] int32: one record per registered weight
+        self.next_row = 0
+        self.table_cache = {}                            # kind of table -> (identity tuple, device tensor, n_jobs, total_blocks)
+
+    def _record(self, state):
+        return self.arena[state["row"]]
+
+    def _grow(self, device):
+        n = 0 if self.arena is None else self.arena.shape[0]
+        new = torch.zeros(max(512, 2 * n), AMAX_WORDS, dtype=I32, device=device)
+        if n:
+            new[:n].copy_(self.arena)
+        self.arena = new
+        for st in self.weights.values():
+            for e in st["entries"].values():
+                e["version"] = None                      # record addresses changed: every entry is packed again
+        self.table_cache.clear()
+
+    def get(self, weight, tag, flag, nt_req):
+        """-> (packed buffer uint8, max|w| record or None). tag: 'c3' | 'c1'."""
+        arith = split_arith_id()
+        st = self.weights.get(id(weight))
+        if st is None or st["ref"]() is not weight:
+            if self.arena is None or self.next_row >= self.arena.shape[0] or self.arena.device != weight.device:
+                self._grow(weight.device)
+            wid = id(weight)
+            st = {"row": self.next_row, "entries": {}, "ref": weakref.ref(weight, lambda _r, wid=wid: self.weights.pop(wid, None))}
+            self.next_row += 1                           # rows are not recycled (a dead weight's row stays zero)
+            self.weights[wid] = st
+        key = (tag, bool(flag), int(nt_req), SPLIT_ARITH, os.environ.get("CSEG_CONV3X3_SB_VAR"))
+        e = st["entries"].get(key)
+        if e is None:
+            e = self._plan(weight, tag, flag, nt_req, arith)
+            st["entries"][key] = e
+        now = (weight.data_ptr(), weight._version)
+        if e["version"] != now:
+            self.refresh()
+        return e["wp"], (self._record(st) if arith else None)
+
+    def _plan(self, weight, tag, flag, nt_req, arith):
+        co, ci = weight.shape[:2]
+        conv_in, conv_out = (co, ci) if flag else (ci, co)
+        lib = _hip.lib()
+        kind, nt, threads = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_long(0)
+        if tag == "c3":
+            ok = lib.cseg_conv3x3_split_plan(conv_in, conv_out, int(nt_req), ctypes.byref(kind), ctypes.byref(nt), ctypes.byref(threads))
+            n_bytes = lib.cseg_conv3x3_split_packed_bytes(arith, conv_in, conv_out)
+        else:
+            ok = lib.cseg_conv1x1_split_plan(conv_in, conv_out, ctypes.byref(nt), ctypes.byref(threads))
+            kind = ctypes.c_int(2)
+            n_bytes = lib.cseg_conv1x1_split_packed_bytes(arith, conv_in, conv_out)
+        if not ok or n_bytes == 0:
+            raise RuntimeError("split convolution: unsupported channel counts %d -> %d (%s)" % (conv_in, conv_out, tag))
+        return {"wp": torch.empty(n_bytes, dtype=torch.uint8, device=weight.device), "kind": kind.value, "nt": nt.value,
+                "total": threads.value, "flag": int(bool(flag)), "version": None, "arith": arith}
+
+    @torch.no_grad()
+    def refresh(self):
+        arith = split_arith_id()
+        stale, every = [], []
+        for st in list(self.weights.values()):
+            w = st["ref"]()
+            if w is None or not _on_device(w) or w.device != self.arena.device:
+                continue
+            now = (w.data_ptr(), w._version)
+            every.append((w, st))
+            for e in st["entries"].values():
+                if e["version"] != now and e["arith"] == arith:
+                    stale.append((w, st, e, now))
+        if not stale:
+            return
+        sp = _hip.stream_ptr()
+        if arith:
+            # all records are re-accumulated (140 MB of weights: ~30 us), so one fill serves them all
+            self.arena.zero_()
+            tab = self._table("amax", [(w.data_ptr(), 0, self._record(st).data_ptr(), 0, 0, 0, 0, 0, w.numel(),
+                                        max(1, min(64, w.numel() // 16384))) for w, st in every],
+                              tuple((id(w), w.data_ptr()) for w, _ in every))
+            _hip.call("cseg_amax_batch", tab[0].data_ptr(), tab[1], tab[2], sp)
+        tab = self._table("pack", [(w.data_ptr(), e["wp"].data_ptr(), self._record(st).data_ptr() if arith else 0, w.shape[0],
+                                    w.shape[1], e["flag"], e["nt"], e["kind"], e["total"], (e["total"] + 255) // 256)
+                                   for w, st, e, _ in stale],
+                          tuple((id(e), w.data_ptr()) for w, _, e, _ in stale))
+        _hip.call("cseg_split_pack_batch", tab[0].data_ptr(), tab[1], tab[2], arith, sp)
+        for _, _, e, now in stale:
+            e["version"] = now
+
+    def _table(self, name, rows, identity):
+        """rows: (src, dst, amax, cout, cin, flag, nt, kind, total, n_blocks) -> (device table, n_jobs, total_blocks); the device
+        copy is reused while the same jobs come back (every step of a training run)."""
+        hit = self.table_cache.get(name)
+        if hit is not None and hit[0] == identity:
+            return hit[1:]
+        arr = np.zeros(len(rows), dtype=_JOB_DTYPE)
+        b0 = 0
+        for i, r in enumerate(rows):
+            arr[i] = (r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], b0, 0)
+            b0 += r[9]
+        dev = torch.from_numpy(arr.view(np.uint8).copy()).to(self.arena.device)
+        self.table_cache[name] = (identity, dev, len(rows), b0)
+        return dev, len(rows), b0
 
 
-def weight_amax(weight):
-    return _pack_cache(weight, _pack_key(weight, "amax"), lambda: tensor_amax(weight.contiguous()))
+SPLIT_WEIGHTS = SplitWeights()
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -788,20 +888,9 @@ def conv3x3_sb_pick_nt(x, c_out):
 @torch.no_grad()
 def conv3x3_sb_pack(weight, transpose_flip=False, nt=0):
     """-> (wp uint8 [...], aw): weight split + packed for the forward (or, transpose_flip, the backward-data) operator in the
-    current arithmetic, cached on the weight until it changes; aw = max|w| word (None with bf16x6)."""
-    def make():
-        co, ci = weight.shape[:2]
-        conv_in, conv_out = (co, ci) if transpose_flip else (ci, co)
-        arith = split_arith_id()
-        n_bytes = _hip.lib().cseg_conv3x3_split_packed_bytes(arith, conv_in, conv_out)
-        if n_bytes == 0:
-            raise RuntimeError("conv3x3_sb: unsupported channel counts %d -> %d" % (conv_in, conv_out))
-        aw = weight_amax(weight) if arith else None
-        wp = torch.empty(n_bytes, dtype=torch.uint8, device=weight.device)
-        _hip.call("cseg_conv3x3_split_pack", _p(weight, F32, "weight"), co, ci, int(transpose_flip), int(nt), arith,
-                  _pf(aw) if aw is not None else _null(), wp.data_ptr(), _hip.stream_ptr())
-        return wp, aw
-    return _pack_cache(weight, _pack_key(weight, "c3", bool(transpose_flip), int(nt)), make)
+    current arithmetic; aw = max|w| record (None with bf16x6). Kept fresh by SplitWeights: one batched launch per optimizer step
+    for all layers."""
+    return SPLIT_WEIGHTS.get(weight, "c3", transpose_flip, nt)
 
 
 @torch.no_grad()
@@ -845,13 +934,14 @@ def conv3x3_sb_tiles(x, c_out):
 # every eligible layer (tools/emu_step_golden.py, profiles/r02_emu_step_golden_*.json). CSEG_CONV3X3_SB_WRW=0 restores the
 # fp32-MFMA kernel / MIOpen; CSEG_CONV3X3_SB_WRW_V=2 selects the producer/consumer version (not yet run on hardware).
 CONV3X3_SB_WRW = os.environ.get("CSEG_CONV3X3_SB_WRW", "1") == "1"
-CONV3X3_SB_WRW_CHANNELS = tuple(int(c) for c in os.environ.get("CSEG_CONV3X3_SB_WRW_CHANNELS", "48,96,192,720").split(","))
+CONV3X3_SB_WRW_CHANNELS = tuple(int(c) for c in os.environ.get("CSEG_CONV3X3_SB_WRW_CHANNELS", "48,96,192,384,720").split(","))
 
 
 def conv3x3_sb_wrw_eligible(x, dy):
-    """Shapes the kernel covers (NCHW fp32, Cin % 16, Cout % 48, width % 64)."""
+    """Shapes the kernel covers (NCHW fp32, Cin % 16, Cout % 48, width % 32: 64-pixel row segments, 32-pixel ones for the
+    16 x 32 maps of the 384-channel branch)."""
     return (_on_device(x) and x.dtype == F32 and dy.dtype == F32 and x.is_contiguous() and dy.is_contiguous()
-            and x.shape[1] % 16 == 0 and dy.shape[1] % 48 == 0 and x.shape[3] % 64 == 0)
+            and x.shape[1] % 16 == 0 and dy.shape[1] % 48 == 0 and x.shape[3] % 32 == 0)
 
 
 def conv3x3_sb_wrw_wanted(x, dy):
@@ -947,19 +1037,7 @@ def conv1x1_sb_tiles(x, c_out):
 
 @torch.no_grad()
 def conv1x1_sb_pack(weight, transpose=False):
-    def make():
-        co, ci = weight.shape[:2]
-        conv_in, conv_out = (co, ci) if transpose else (ci, co)
-        arith = split_arith_id()
-        n_bytes = _hip.lib().cseg_conv1x1_split_packed_bytes(arith, conv_in, conv_out)
-        if n_bytes == 0:
-            raise RuntimeError("conv1x1_sb: unsupported channel counts %d -> %d" % (conv_in, conv_out))
-        aw = weight_amax(weight) if arith else None
-        wp = torch.empty(n_bytes, dtype=torch.uint8, device=weight.device)
-        _hip.call("cseg_conv1x1_split_pack", _p(weight, F32, "weight"), co, ci, int(transpose), arith,
-                  _pf(aw) if aw is not None else _null(), wp.data_ptr(), _hip.stream_ptr())
-        return wp, aw
-    return _pack_cache(weight, _pack_key(weight, "c1", bool(transpose)), make)
+    return SPLIT_WEIGHTS.get(weight, "c1", transpose, 0)
 
 
 @torch.no_grad()

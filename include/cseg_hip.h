@@ -333,6 +333,28 @@ int cseg_conv3x3_split_fwd(const float* x, const void* wp, const float* bias, in
 /* ws: cseg_conv3x3_sb_wrw_ws_floats(...) */
 int cseg_conv3x3_split_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, int arith,
                            const unsigned* amax_x, const unsigned* amax_dy, float* ws, float* dw, cseg_stream_t stream);
+/* plan of one pack call, for callers that batch many of them (cseg_split_pack_batch below): kind = CSEG_PACK_* (which packed
+ * format the library uses for these channel counts), nt = effective channel tiles per block, threads = one per packed uint4
+ * group; conv_in / conv_out are the channel counts of the PACKED operator; returns 0 when the shape is not covered. */
+#define CSEG_PACK_C3 0
+#define CSEG_PACK_C3_16 1
+#define CSEG_PACK_C1 2
+int cseg_conv3x3_split_plan(int conv_in, int conv_out, int nt_request, int* kind, int* nt, long* threads);
+int cseg_conv1x1_split_plan(int conv_in, int conv_out, int* nt, long* threads);
+/* Batched form: jobs_dev = DEVICE array of n_jobs records sorted by block0 (block0 of job 0 = 0; job i owns blocks
+ * [block0_i, block0_{i+1}) of a grid of total_blocks 256-thread blocks).
+ *   cseg_amax_batch:       src = float tensor, total = its element count, amax = its (zeroed) max|.| record; any block count >= 1
+ *   cseg_split_pack_batch: src = w (the forward's layout), dst = packed buffer, amax = max|w| record (F16X3), cout / cin = the
+ *                          forward's channel counts, flag = transpose(_flip), nt / kind / total = the plan (blocks = ceil(total / 256))
+ * One launch each, for every layer of the network. */
+typedef struct cseg_split_job {
+    const void* src;
+    void* dst;
+    unsigned* amax;
+    int cout, cin, flag, nt, kind, total, block0, reserved;
+} cseg_split_job;
+int cseg_amax_batch(const cseg_split_job* jobs_dev, int n_jobs, int total_blocks, cseg_stream_t stream);
+int cseg_split_pack_batch(const cseg_split_job* jobs_dev, int n_jobs, int total_blocks, int arith, cseg_stream_t stream);
 size_t cseg_conv1x1_split_packed_bytes(int arith, int Cin, int Cout);
 int cseg_conv1x1_split_pack(const float* w, int Cout, int Cin, int transpose, int arith, const unsigned* amax_w, void* wp,
                             cseg_stream_t stream);

@@ -278,15 +278,27 @@ MODEL_CASES = {
     "hrnet_w48_ocr_contrast": dict(backbone="hrnet48", K=19, B=2, H=64, W=96, seed=32, contrast={}),
     # eval-mode BN here: the ASPP image-pool BN sees only B=2 values per channel in train mode, which amplifies
     # fp32 rounding differences by up to 1/sqrt(eps) -- an ill-conditioned comparison, not a property of the model
-    "deeplab_v3_contrast": dict(backbone="deepbase_resnet101_dilated8", K=19, B=2, H=65, W=97, seed=33, contrast={},
-                                mode="eval"),
+    # (round 3: `prime` -- the running statistics are first set to the batch statistics of this input by one train-mode pass
+    # with momentum 1, prime_bn below; with the untrained statistics (mean 0, variance 1) the activations grew through 100 layers
+    # to logits of 1.5e5, where an absolute 1e-3 means nothing. Primed, the logits are O(1) and the north_star bar applies.)
+    # `head_scale`: the last layer of both classifiers is multiplied by 0.1 after the seeded initialisation (scale_heads below), on
+    # both sides of the comparison. At its random initialisation DeepLab's logits reach |11-15| and the reference's own fp32
+    # forward sits 1.6e-3 away from the fp64 evaluation of the same network whatever the batch (measured: eval / train mode,
+    # B = 6 / 12 / 16) -- 1e-4 of the logit scale, like HRNet, but HRNet's logits are O(1). With O(1) logits the reference is within
+    # 2e-4 of fp64 and the north_star bar (absolute 1e-3) is a meaningful assertion for DeepLab too.
+    "deeplab_v3_contrast": dict(backbone="deepbase_resnet101_dilated8", K=19, B=6, H=65, W=97, seed=33, contrast={},
+                                mode="eval", prime=True, spread=True, head_scale=0.1),
     # train-mode BN with B=6 so that the image-pool BN of the ASPP head sees six values per channel
     "deeplab_v3_contrast_train": dict(model="deeplab_v3_contrast", backbone="deepbase_resnet101_dilated8", K=19, B=6,
-                                      H=97, W=129, seed=35, contrast={}, spread=True),
+                                      H=97, W=129, seed=35, contrast={}, spread=True, head_scale=0.1),
     # THE BENCHED CONFIGURATION (BASELINE.json configs[1]): HRNet-W48 at 3x512x1024, features 128x256. On the GPU this
     # reaches the same MIOpen solvers as bench.py (shipped miopen_db records active). seg stored dense.
     "hrnet_w48_contrast_fullres": dict(model="hrnet_w48_contrast", backbone="hrnet48", K=19, B=2, H=512, W=1024,
                                        seed=34, contrast={}, embed_step=8),
+    # the benched BATCH (8 images: with the grid-fill thresholds of kernels.py this reaches the 96- / 192- / 384-channel branch
+    # kernels and every other default route of bench.py inside ONE reference-pinned forward); logits stored every 2nd pixel
+    "hrnet_w48_contrast_fullres_b8": dict(model="hrnet_w48_contrast", backbone="hrnet48", K=19, B=8, H=512, W=1024,
+                                          seed=37, contrast={}, embed_step=16, seg_step=2),
     # memory-bank wrapper: forward(img, labels) -> seg / embed / key / lb_key (nets/hrnet.py:178-188 of the reference)
     "hrnet_w48_mem": dict(backbone="hrnet48", K=19, B=2, H=64, W=128, seed=36, with_labels=True,
                           contrast=dict(with_memory=True, memory_size=16, pixel_update_freq=10)),
@@ -304,6 +316,47 @@ def model_input(c):
         bias = np.linspace(-0.8, 0.8, c["B"]).astype(np.float32).reshape(-1, 1, 1, 1)
         x = x * gain + bias * np.array([1.0, -0.5, 0.25], dtype=np.float32).reshape(1, 3, 1, 1)
     return x
+
+
+HEAD_LAST_LAYERS = ("decoder.refine.2.", "decoder.layer_dsn.2.")          # DeepLabHead: final 1x1 of the classifier / the DSN head
+
+
+def scale_heads(net, factor):
+    import torch
+    with torch.no_grad():
+        hit = 0
+        for n, p in net.named_parameters():
+            if n.startswith(HEAD_LAST_LAYERS):
+                p.mul_(factor)
+                hit += 1
+        assert hit >= 2, "no classifier parameters found to scale"
+
+
+def set_bn_eval(net):
+    import torch.nn as nn
+    for m in net.modules():
+        if isinstance(m, nn.modules.batchnorm._BatchNorm):
+            m.eval()
+
+
+def prime_bn(net, x):
+    """running statistics := batch statistics of x (one train-mode forward with momentum 1, no gradient); every module's
+    train / eval flag is restored afterwards (net.train() would switch the frozen dropout layers back on)."""
+    import torch
+    import torch.nn as nn
+    bns = [m for m in net.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+    saved = [m.momentum for m in bns]
+    flags = [(m, m.training) for m in net.modules()]
+    for m in bns:
+        m.momentum = 1.0
+    net.train()
+    freeze_dropout(net)
+    with torch.no_grad():
+        net(x.detach(), with_embed=True)
+    for m, mom in zip(bns, saved):
+        m.momentum = mom
+    for m, t in flags:
+        m.training = t
 
 
 def freeze_dropout(net):
@@ -330,6 +383,10 @@ def run_model_case(name, c):
     torch.manual_seed(304)
     net = ModelManager(cfg).semantic_segmentor().train()
     freeze_dropout(net)
+    if c.get("head_scale"):
+        scale_heads(net, c["head_scale"])
+    if c.get("prime"):
+        prime_bn(net, torch.from_numpy(model_input(c)))
     if c.get("mode") == "eval":
         net.eval()
     with torch.no_grad():
@@ -338,8 +395,13 @@ def run_model_case(name, c):
         else:
             out = net(torch.from_numpy(model_input(c)), with_embed=True)
     es = c.get("embed_step", 4)
-    res = {"seg": out["seg"].numpy(), "embed_s%d" % es: out["embed"][:, :, ::es, ::es].numpy().copy(),
-           "embed_shape": np.array(out["embed"].shape)}
+    ss = c.get("seg_step", 1)
+    res = {"embed_s%d" % es: out["embed"][:, :, ::es, ::es].numpy().copy(), "embed_shape": np.array(out["embed"].shape)}
+    if ss == 1:
+        res["seg"] = out["seg"].numpy()
+    else:
+        res["seg_s%d" % ss] = out["seg"][:, :, ::ss, ::ss].numpy().copy()
+        res["seg_absmax"] = np.array(float(out["seg"].abs().max()))
     if "seg_aux" in out:
         res["seg_aux"] = out["seg_aux"].numpy()
     if "key" in out:
@@ -407,6 +469,24 @@ STEP_CASES = {
                                          "decoder.layer_aspp.b1.0.weight", "decoder.layer_aspp.b4.1.weight", "decoder.layer_aspp.project.0.weight",
                                          "decoder.layer_dsn.0.weight", "decoder.refine.2.weight",
                                          "proj_head.proj.2.weight"]),
+    # Frozen-statistics backward (round 3): the same network with BatchNorm in eval mode on statistics primed from this batch
+    # (prime_bn) -- the adjoint of the eval-mode BN kernels inside a whole-network step. It was also an experiment (VERDICT r2
+    # weak 3): does removing the batch-statistics terms make fp32 backward well conditioned? It does not: the reference's own fp32
+    # gradients still sit 1e-2..2e-2 (max-norm) from the fp64 evaluation of the same function in the backbone (2e-5..4e-5 in the
+    # last head layers), so the deviation comes from the depth of the ReLU network itself (pre-activations within rounding of
+    # zero), not from the statistics. The noise-aware bounds stay; the second loss is not compared (an SGD step of lr 0.01 on
+    # frozen statistics leaves the primed operating point: loss 1e5 in the reference too).
+    "step_hrnet48_contrast_evalbn": dict(model="hrnet_w48_contrast", backbone="hrnet48", loss="contrast_ce_loss", K=7, B=2,
+                                         H=128, W=256, seed=46, torch_seed=304, bn_eval=True, skip_loss1=True,
+                                         contrast=dict(max_samples=256, max_views=16, proj_dim=64),
+                                         watch=["backbone.conv1.weight", "backbone.layer1.0.conv2.weight",
+                                                "backbone.stage2.0.branches.0.1.conv1.weight",
+                                                "backbone.stage3.1.fuse_layers.2.0.0.0.weight",
+                                                "backbone.stage3.2.branches.2.0.conv2.weight",
+                                                "backbone.stage4.2.fuse_layers.0.3.0.weight",
+                                                "backbone.stage4.0.branches.3.0.conv1.weight",
+                                                "cls_head.0.weight", "cls_head.3.weight", "proj_head.proj.0.weight",
+                                                "proj_head.proj.2.weight"]),
     # BASELINE.json configs[3] (row g): DeepLab-V3 + the per-class memory bank. The reference registers a memory model only
     # for HRNet (lib/models/nets/hrnet.py:153-188); the golden runs the reference's OWN HRNet_W48_MEM class with its encoder
     # symbol pointed at the reference's DeepLabV3Contrast (ref_memory_model below), the composed criterion ref_mem_auxce and
@@ -496,6 +576,9 @@ def run_step_case(name, c):
     opt = torch.optim.SGD(net.parameters(), **SGD)
     img, target = step_inputs(c)
     img, target = torch.from_numpy(img).requires_grad_(True), torch.from_numpy(target)
+    if c.get("bn_eval"):
+        prime_bn(net, img)
+        set_bn_eval(net)
     with_memory = "with_memory" in c["contrast"]
     if with_memory:
         for m in ("lib.vis.seg_visualizer", "lib.datasets.data_loader", "segmentor.tools.evaluator"):
@@ -514,6 +597,9 @@ def run_step_case(name, c):
     torch.manual_seed(304)
     net64 = ref_model(cfg, c["model"]).train()
     freeze_dropout(net64)
+    if c.get("bn_eval"):
+        net64.load_state_dict(net.state_dict())          # the SAME (fp32-primed) running statistics: the truth of the same function
+        set_bn_eval(net64)
     net64, crit64 = net64.double(), ref_criterion(cfg, c["loss"]).double()
     torch.manual_seed(c["torch_seed"])
     img64 = img.detach().double().requires_grad_(True)

@@ -407,3 +407,66 @@ def test_single_rank_process_group_takes_the_multi_rank_paths():
     assert out.returncode == 0, out.stderr[-1500:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["ok"] and d["syncbn_all_reduces"] == 2 and d["cross_rank_collectives"] >= 2
+
+
+# ---- round 3: the whole network's weights packed in one launch (kernels.SplitWeights -> cseg_amax_batch / cseg_split_pack_batch) --
+@pytest.mark.parametrize("arith", ["f16x3", "bf16x6"])
+def test_batched_weight_packs_equal_the_per_layer_packs(arith, monkeypatch):
+    """Same bytes as cseg_conv3x3_split_pack / cseg_conv1x1_split_pack layer by layer (all three packed formats, forward and
+    backward-data operators), refreshed together after an in-place update of the weights, dropped with the weight."""
+    import ctypes
+    import gc
+    from contrastiveseg_amd import _hip
+    from contrastiveseg_amd import kernels as K
+    inject.install(monkeypatch)
+    monkeypatch.setattr(K, "SPLIT_ARITH", arith)
+    monkeypatch.setattr(K, "SPLIT_WEIGHTS", K.SplitWeights())
+    aid = K.split_arith_id()
+    g = torch.Generator().manual_seed(3)
+    ws = {"c3_main_96": torch.randn(96, 96, 3, 3, generator=g) * 0.05, "c3_sb16_48": torch.randn(48, 48, 3, 3, generator=g) * 3.0,
+          "c3_sb16_64": torch.randn(64, 64, 3, 3, generator=g) * 1e-3, "c3_192_nt3": torch.randn(192, 48, 3, 3, generator=g),
+          "c1_64_256": torch.randn(256, 64, 1, 1, generator=g) * 0.2, "c1_144_48": torch.randn(48, 144, 1, 1, generator=g)}
+    reqs = [("c3_main_96", "c3", False, 0), ("c3_main_96", "c3", True, 0), ("c3_sb16_48", "c3", False, 0), ("c3_sb16_48", "c3", True, 0),
+            ("c3_sb16_64", "c3", False, 0), ("c3_192_nt3", "c3", False, 3), ("c1_64_256", "c1", False, 0), ("c1_64_256", "c1", True, 0),
+            ("c1_144_48", "c1", False, 0)]
+
+    def single(w, tag, flag, nt):
+        co, ci = w.shape[:2]
+        conv_in, conv_out = (co, ci) if flag else (ci, co)
+        lib = _hip.lib()
+        aw = K.tensor_amax(w.contiguous()) if aid else None
+        ap = ctypes.c_void_p(aw.data_ptr()) if aid else ctypes.c_void_p(None)
+        if tag == "c3":
+            wp = torch.full((lib.cseg_conv3x3_split_packed_bytes(aid, conv_in, conv_out),), 0xEE, dtype=torch.uint8)
+            _hip.call("cseg_conv3x3_split_pack", ctypes.c_void_p(w.data_ptr()), co, ci, int(flag), nt, aid, ap, wp.data_ptr(), None)
+        else:
+            wp = torch.full((lib.cseg_conv1x1_split_packed_bytes(aid, conv_in, conv_out),), 0xEE, dtype=torch.uint8)
+            _hip.call("cseg_conv1x1_split_pack", ctypes.c_void_p(w.data_ptr()), co, ci, int(flag), aid, ap, wp.data_ptr(), None)
+        return wp, aw
+
+    def check():
+        for name, tag, flag, nt in reqs:
+            wp, aw = K.SPLIT_WEIGHTS.get(ws[name], tag, flag, nt)
+            ref, ref_aw = single(ws[name], tag, flag, nt)
+            assert wp.shape == ref.shape and torch.equal(wp, ref), (name, tag, flag)
+            if aid:
+                assert int(aw.view(32, 32)[:, 0].max()) == int(ref_aw.view(32, 32)[:, 0].max()) == \
+                    int(ws[name].abs().max().view(torch.int32))
+    check()                                             # registration: every request packs on first use
+    launches = []
+    orig = _hip.call
+    monkeypatch.setattr(_hip, "call", lambda name, *a: (launches.append(name), orig(name, *a))[1])
+    for w in ws.values():
+        w.mul_(1.7).add_(0.01)                          # what an optimizer step does: in place, version bumped
+    K.SPLIT_WEIGHTS.get(ws["c1_144_48"], "c1", False, 0)          # the first request of the next step refreshes everything
+    assert launches == (["cseg_amax_batch", "cseg_split_pack_batch"] if aid else ["cseg_split_pack_batch"]), launches
+    launches.clear()
+    monkeypatch.setattr(_hip, "call", orig)
+    check()
+    n = len(K.SPLIT_WEIGHTS.weights)
+    del ws["c3_192_nt3"]
+    gc.collect()
+    assert len(K.SPLIT_WEIGHTS.weights) == n - 1
+    reqs = [r for r in reqs if r[0] != "c3_192_nt3"]
+    ws["c1_144_48"].mul_(0.5)
+    check()                                             # one stale weight among fresh ones

@@ -205,6 +205,18 @@ def test_split_conv3x3_weight_gradient(case, arith, wave_order):
     assert np.abs(dw - ref).max() <= 3e-6 * np.sqrt(B * H * W) * float(np.abs(ref).max())
 
 
+@pytest.mark.parametrize("arith", ARITHS)
+@pytest.mark.parametrize("case", [(2, 48, 96, 5, 32), (1, 80, 48, 9, 32), (1, 64, 48, 19, 96)])
+def test_split_weight_gradient_32_pixel_segments(case, arith, wave_order):
+    """widths that are 32 mod 64 (the 16 x 32 maps of the 384-channel branch): one K-step per row-step, runs of 8 rows"""
+    B, ci, co, H, W = case
+    x, dy = _rand((B, ci, H, W), 61, 7.0), _rand((B, co, H, W), 62, 1e-4)
+    dw = E.conv3x3_sb_wrw(x, dy, arith=arith)
+    ref = E.ref_conv3x3_wrw(x, dy)
+    assert not np.isnan(dw).any()
+    assert np.abs(dw - ref).max() <= 3e-6 * np.sqrt(B * H * W) * float(np.abs(ref).max())
+
+
 @pytest.mark.parametrize("case", [(1, 192, 192, 4, 64), (1, 96, 192, 4, 64)])
 def test_split_weight_gradient_group_order(case, wave_order):
     """several channel blocks each way: the XCD-aware block order (groups of SC x SI channel blocks) covers every block once."""

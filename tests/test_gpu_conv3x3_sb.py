@@ -86,8 +86,7 @@ WRW_CASES = [  # B, Cin, Cout, H, W
 ]
 
 
-@pytest.mark.parametrize("version", ["1", pytest.param("2", marks=pytest.mark.skipif(
-    os.environ.get("CSEG_TEST_SB_WRW_V2") != "1", reason="producer/consumer version: first hardware run pending"))])
+@pytest.mark.parametrize("version", ["1", "2"])
 @pytest.mark.parametrize("case", WRW_CASES)
 def test_weight_gradient_matches_fp64(case, version, monkeypatch):
     from contrastiveseg_amd import kernels as K
@@ -108,7 +107,6 @@ def test_weight_gradient_matches_fp64(case, version, monkeypatch):
     assert torch.equal(got, K.conv3x3_sb_wrw(xd, dyd)), "weight gradient not deterministic"
 
 
-@pytest.mark.skipif(os.environ.get("CSEG_TEST_SB_NT") != "1", reason="explicit-tiling entry points: first hardware run pending")
 @pytest.mark.parametrize("nt", [3, 6])
 def test_explicit_channel_tiling_matches_default(nt):
     """cseg_conv3x3_sb_*_nt: same convolution whatever the number of channel tiles per block."""
@@ -132,7 +130,6 @@ ONE_CASES = [  # B, Cin, Cout, H, W
 ]
 
 
-@pytest.mark.skipif(os.environ.get("CSEG_TEST_SB_1X1") != "1", reason="1x1 split-bf16 kernel: first hardware run pending")
 @pytest.mark.parametrize("case", ONE_CASES)
 def test_pointwise_matches_fp64(case):
     from contrastiveseg_amd import kernels as K
@@ -158,7 +155,6 @@ def test_pointwise_matches_fp64(case):
         assert err <= tol, (case, name, err, tol)
 
 
-@pytest.mark.skipif(os.environ.get("CSEG_TEST_SB_1X1") != "1", reason="1x1 split-bf16 kernels: first hardware run pending")
 @pytest.mark.parametrize("case", [(2, 48, 64, 8, 8), (1, 144, 160, 8, 12), (1, 720, 720, 8, 64), (1, 720, 256, 8, 64),
                                   (2, 64, 256, 16, 16)])
 def test_pointwise_weight_gradient_matches_fp64(case):

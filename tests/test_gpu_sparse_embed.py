@@ -6,9 +6,7 @@ import os
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("CSEG_TEST_SPARSE_EMBED") != "1",
-                                 reason="row-sparse embedding gradient: first hardware run pending")]
+pytestmark = pytest.mark.gpu          # the row-sparse route is the default since round 3
 
 
 def _dev():
