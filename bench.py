@@ -576,12 +576,15 @@ def self_launch(args):
 def step_traffic():
     """HBM bytes per step of the default workload at N=1, from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs; gfx950 FETCH_SIZE x2 for wide coalesced reads per MI355X_MICROARCH.md)."""
-    path = os.path.join(ROOT, "profiles", "r02_step_pmc.json")
-    if not os.path.exists(path):
+    for name in ("r03_step_pmc.json", "r02_step_pmc.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            break
+    else:
         return None, None
     try:
         d = json.load(open(path))
-        return d["hbm_bytes_per_step"], "profiles/r02_step_pmc.json (%s)" % d.get("note", "")
+        return d["hbm_bytes_per_step"], "profiles/%s (%s)" % (name, d.get("note", ""))
     except Exception:
         return None, None
 

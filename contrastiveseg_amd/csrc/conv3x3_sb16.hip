@@ -226,6 +226,211 @@ __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 3: persistent form for the small-channel convolutions. The kernel above is LATENCY-bound on the branches (48 channels at
+// 8x128x256: 52 us against 9 us of MFMA time and 20 us of HBM time): every one of its 15 K-steps ends in a barrier that waits for
+// the LDS-DMA of the next step's weights, issued only one short step (~0.25 us of MFMAs) earlier, and a block lives for one
+// 4x64 tile, so prologue (first patch from HBM) and epilogue overlap nothing when one block fits a CU.
+// Here a block keeps ONE channel tile group and walks several spatial tiles:
+//   * weights: the whole packed operator of the channel tile group stays RESIDENT in LDS when it fits (48 -> 48: 15 K-steps x
+//     6 KB = 90 KB, loaded once per block by LDS-DMA), otherwise it is streamed one 16-channel chunk (5 K-steps) ahead into a
+//     double buffer -- a whole chunk of MFMAs (~1.2 us) lies between the issue of a DMA and the barrier that waits for it;
+//   * patch: double-buffered; the fp32 loads of the NEXT (tile, chunk) item are issued before the MFMAs of the current one and
+//     split + stored into the other buffer after them -- also across tile boundaries, so a new tile starts without a prologue;
+//   * ONE barrier per 16-channel chunk (5 K-steps) instead of one per K-step.
+// Same packed-weight format (CSEG_PACK_C3_16), same fragment layout and epilogue as above. f16x3 only (with three pieces the
+// buffers do not fit). CSEG_CONV3X3_SB16_P=0 switches back to the one-tile kernel.
+// ---------------------------------------------------------------------------------------------------------
+template <class AR, int NT, bool RES>
+__global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
+                                                               const float* __restrict__ bias, int Cin, int Cout, int H, int W,
+                                                               int tiles_x, int tiles_y, int n_spatial, int groups,
+                                                               const unsigned* __restrict__ amax_x,
+                                                               const unsigned* __restrict__ amax_w, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_s16p[];
+    constexpr int NP = AR::NP;
+    constexpr int A_CELLS = NP * NOCT * CELLS;
+    constexpr int BSTEP = NT * NP * 64;            // uint4 per K-step
+    constexpr int BCHUNK = STEPS * BSTEP;          // uint4 per 16-channel chunk
+    constexpr int NT0 = (NT + 1) / 2, NT1 = NT - NT0;
+    uint4* As = smem_s16p;                         // [2][piece NP][octet 2][CELLS]
+    uint4* Bs = smem_s16p + 2 * A_CELLS;           // RES: [n_chunks][BCHUNK]; else [2][BCHUNK]
+    const unsigned ex = AR::SCALED ? split_amax_exp(amax_x) : 141u, ew = AR::SCALED ? split_amax_exp(amax_w) : 141u;
+    const float xscale = split_scale_of(ex);
+    const float unscale = split_unscale_of(ex) * split_unscale_of(ew);
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row = wave & 3, half = wave >> 2;
+    const int g = lane >> 4, n = lane & 15;
+    const int n_cot = Cout / (NT * 16);
+    const size_t plane = (size_t)H * W;
+    const int cot = blockIdx.x % n_cot, grp = blockIdx.x / n_cot;      // this block: spatial tiles grp, grp + groups, ...
+    const int n_chunks = Cin / 16;
+    const uint4* wbase = wp + (size_t)cot * n_chunks * BCHUNK;
+    const int my_tiles = grp < n_spatial ? (n_spatial - grp + groups - 1) / groups : 0;
+    const int n_items = my_tiles * n_chunks;
+    if (n_items == 0) return;
+
+    auto b_dma = [&](int chunk, uint4* dst) {      // one 16-channel chunk of packed weights: STEPS * NT * NP rows of 1 KB
+        constexpr int ROWS = STEPS * NT * NP;
+#pragma unroll
+        for (int i = 0; i < (ROWS + 7) / 8; ++i) {
+            const int r = wave + 8 * i;
+            if (r < ROWS)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(wbase + (size_t)chunk * BCHUNK + r * 64 + lane),
+                    (__attribute__((address_space(3))) void*)(dst + r * 64), 16, 0, 0);
+        }
+    };
+    auto tile_of = [&](int it, int& b, int& y0, int& x0) {
+        int t = grp + (it / n_chunks) * groups;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        b = t / tiles_y;
+        x0 = tx * TC; y0 = ty * TR;
+    };
+    float apre[AU][8];
+    auto a_item = [&](int u, int y0, int x0, int& oct, int& rc, bool& ok) {
+        const int item = tid + 512 * u;
+        oct = item / CELLS; rc = item - oct * CELLS;
+        const int r = rc / XCOLS, col = rc - r * XCOLS;
+        const int yy = y0 + r - 1, xx = x0 + col - 1;
+        ok = oct < NOCT && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    };
+    auto a_issue = [&](int it) {
+        int b, y0, x0;
+        tile_of(it, b, y0, x0);
+        const int chunk = it % n_chunks;
+        const float* xc = x + ((size_t)b * Cin + (size_t)chunk * 16) * plane;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xc, 0, (int)(16 * plane * sizeof(float)),
+                                                                            0x00020000);
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            int oct, rc;
+            bool ok;
+            a_item(u, y0, x0, oct, rc, ok);
+            const int r = rc / XCOLS, col = rc - r * XCOLS;
+            const int octc = min(oct, NOCT - 1), yc = min(max(y0 + r - 1, 0), H - 1), xcl = min(max(x0 + col - 1, 0), W - 1);
+            const int off = (octc * 8 * (int)plane + yc * W + xcl) * (int)sizeof(float);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                apre[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                           rs, off, j * (int)plane * (int)sizeof(float), 0));
+        }
+    };
+    auto a_store = [&](int it, uint4* dst) {
+        int b, y0, x0;
+        tile_of(it, b, y0, x0);
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            int oct, rc;
+            bool ok;
+            a_item(u, y0, x0, oct, rc, ok);
+            if (oct < NOCT) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = ok ? apre[u][j] : 0.f;       // zero padding / outside the tensor
+                uint4 cells[NP];
+                split_cells8<AR>(v, xscale, cells);
+                const int item = oct * CELLS + rc;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) dst[p * NOCT * CELLS + item] = cells[p];
+            }
+        }
+    };
+
+    f32x4 acc[4][NT0];
+    // ---- prologue: weights (all of them, or chunk 0), patch of item 0
+    a_issue(0);
+    if (RES) {
+        for (int c = 0; c < n_chunks; ++c) b_dma(c, Bs + (size_t)c * BCHUNK);
+    } else {
+        b_dma(0, Bs);
+    }
+    a_store(0, As);
+    __syncthreads();
+
+    const int a_lane_off = row * XCOLS + n;
+    const int b_lane_off = (half ? NT0 * NP * 64 : 0) + lane;
+#pragma unroll 1
+    for (int it = 0; it < n_items; ++it) {
+        const int chunk = it % n_chunks;
+        const bool more = it + 1 < n_items;
+        if (chunk == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT0; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (more) {
+            a_issue(it + 1);                                             // fp32 loads of the next item fly under the MFMAs below
+            if (!RES) b_dma((it + 1) % n_chunks, Bs + (size_t)((it + 1) & 1) * BCHUNK);   // that buffer was last read in item it - 1
+        }
+        const uint4* a_lane = As + (size_t)(it & 1) * A_CELLS + a_lane_off;
+        const uint4* b_base = (RES ? Bs + (size_t)chunk * BCHUNK : Bs + (size_t)(it & 1) * BCHUNK) + b_lane_off;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            // the ninth tap is paired with a tenth that does not exist: its packed weights are zero
+            const int tap = min(2 * s + (g >> 1), 8);
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int a_off = (g & 1) * CELLS + ky * XCOLS + kx;
+            if (half == 0) sb16_kstep<AR, NT0, NT0>(a_lane + a_off, b_base + s * BSTEP, acc);
+            else if (NT1 > 0) sb16_kstep<AR, NT1, NT0>(a_lane + a_off, b_base + s * BSTEP, acc);
+        }
+        if (chunk == n_chunks - 1) {
+            int b, y0, x0;
+            tile_of(it, b, y0, x0);
+            const int yy = y0 + row;
+            if (yy < H) {
+                float* ybc = y + (size_t)b * Cout * plane;
+                const int co0 = cot * NT * 16;
+                if (half == 0) sb16_store<NT0, NT0>(acc, ybc, bias, co0, plane, yy, x0, W, g, n, unscale);
+                else if (NT1 > 0) sb16_store<NT1, NT0>(acc, ybc, bias, co0 + NT0 * 16, plane, yy, x0, W, g, n, unscale);
+            }
+        }
+        if (more) a_store(it + 1, As + (size_t)((it + 1) & 1) * A_CELLS);  // the other patch buffer: last read in item it - 1
+        __syncthreads();
+    }
+}
+
+template <class AR, int NT, bool RES>
+int launch_sb16p(const float* x, const uint4* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
+                 const unsigned* amax_x, const unsigned* amax_w, float* y, size_t lds, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)(conv3x3_sb16p_kernel<AR, NT, RES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            cseg_set_error("conv3x3_sb16p: cannot raise dynamic LDS to %zu bytes", lds);
+            return 0;
+        }
+        attr_set = true;
+    }
+    const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
+    const int n_cot = Cout / (NT * 16);
+    const long n_spatial = (long)B * tiles_y * tiles_x;
+    CSEG_REQUIRE(n_spatial < 2147483647L, "conv3x3_sb16p: too many tiles");
+    long groups = 256 / n_cot;                       // one block per CU: 256 CUs shared by the channel tile groups
+    if (groups < 1) groups = 1;
+    if (groups > n_spatial) groups = n_spatial;
+    hipLaunchKernelGGL((conv3x3_sb16p_kernel<AR, NT, RES>), dim3((unsigned)(groups * n_cot)), dim3(512), lds, stream, x, wp, bias,
+                       Cin, Cout, H, W, tiles_x, tiles_y, (int)n_spatial, (int)groups, amax_x, amax_w, y);
+    CSEG_CHECK_LAUNCH("conv3x3_sb16p_kernel");
+    return 1;
+}
+
+// the persistent kernel when its buffers fit the 160 KB of LDS (f16x3); `lds` and `res` say how
+bool sb16p_plan(int arith, int Cin, int NT, size_t& lds, bool& res) {
+    const char* e = getenv("CSEG_CONV3X3_SB16_P");
+    if (arith != CSEG_ARITH_F16X3 || (e && atoi(e) == 0)) return false;
+    const size_t a = 2 * (size_t)2 * NOCT * CELLS * sizeof(uint4);               // two patch buffers, two pieces
+    const size_t chunk = (size_t)STEPS * NT * 2 * 64 * sizeof(uint4);
+    const size_t all = (size_t)(Cin / 16) * chunk;
+    const size_t cap = 160 * 1024;
+    if (a + all <= cap) { lds = a + all; res = true; return true; }
+    if (a + 2 * chunk <= cap) { lds = a + 2 * chunk; res = false; return true; }
+    return false;
+}
+
 template <class AR, int NT>
 int launch_sb16(const float* x, const uint4* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
                 const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream) {
@@ -279,6 +484,17 @@ int fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int C
     CSEG_REQUIRE((NT == 3 || NT == 4 || NT == 6) && Cout % (NT * 16) == 0 && Cin % 16 == 0 && (long)H * W * 16 * 4 < 2147483647L,
                  "conv3x3_sb16: unsupported shape Cin=%d Cout=%d %dx%d with %d channel tiles per block", Cin, Cout, H, W, NT);
     const uint4* wq = (const uint4*)wp;
+    size_t lds = 0;
+    bool res = false;
+    if (sb16p_plan(arith, Cin, NT, lds, res)) {
+#define SB16P(N)                                                                                                              \
+    return res ? launch_sb16p<SplitF16x3, N, true>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, lds, stream)          \
+               : launch_sb16p<SplitF16x3, N, false>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, lds, stream);
+        if (NT == 3) { SB16P(3) }
+        if (NT == 4) { SB16P(4) }
+        if (NT == 6) { SB16P(6) }
+#undef SB16P
+    }
     if (arith == CSEG_ARITH_F16X3) {
         if (NT == 6) return launch_sb16<SplitF16x3, 6>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
         if (NT == 4) return launch_sb16<SplitF16x3, 4>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);

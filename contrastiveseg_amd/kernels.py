@@ -817,19 +817,22 @@ class SplitWeights(object):
             self.arena.zero_()
             tab = self._table("amax", [(w.data_ptr(), 0, self._record(st).data_ptr(), 0, 0, 0, 0, 0, w.numel(),
                                         max(1, min(64, w.numel() // 16384))) for w, st in every],
-                              tuple((id(w), w.data_ptr()) for w, _ in every))
+                              tuple((w.data_ptr(), w.numel(), st["row"]) for w, st in every))
             _hip.call("cseg_amax_batch", tab[0].data_ptr(), tab[1], tab[2], sp)
         tab = self._table("pack", [(w.data_ptr(), e["wp"].data_ptr(), self._record(st).data_ptr() if arith else 0, w.shape[0],
                                     w.shape[1], e["flag"], e["nt"], e["kind"], e["total"], (e["total"] + 255) // 256)
                                    for w, st, e, _ in stale],
-                          tuple((id(e), w.data_ptr()) for w, _, e, _ in stale))
+                          tuple((w.data_ptr(), e["wp"].data_ptr(), st["row"], e["flag"], e["nt"], e["kind"], e["total"])
+                                for w, st, e, _ in stale))
         _hip.call("cseg_split_pack_batch", tab[0].data_ptr(), tab[1], tab[2], arith, sp)
         for _, _, e, now in stale:
             e["version"] = now
 
     def _table(self, name, rows, identity):
         """rows: (src, dst, amax, cout, cin, flag, nt, kind, total, n_blocks) -> (device table, n_jobs, total_blocks); the device
-        copy is reused while the same jobs come back (every step of a training run)."""
+        copy is reused while the same jobs come back (every step of a training run). `identity` must name everything the table
+        holds by VALUE -- pointers and record rows, not Python object ids (those are recycled: a new layer that landed on a dead
+        layer's id and storage would otherwise inherit its max|w| row, and a zero row means an overflowing scale)."""
         hit = self.table_cache.get(name)
         if hit is not None and hit[0] == identity:
             return hit[1:]

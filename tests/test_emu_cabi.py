@@ -470,3 +470,31 @@ def test_batched_weight_packs_equal_the_per_layer_packs(arith, monkeypatch):
     reqs = [r for r in reqs if r[0] != "c3_192_nt3"]
     ws["c1_144_48"].mul_(0.5)
     check()                                             # one stale weight among fresh ones
+
+
+def test_batched_weight_packs_survive_recycled_layers(monkeypatch):
+    """Layers that come and go (every test builds its own): a new weight that lands on a dead weight's Python id AND storage gets a
+    fresh max|w| row, so the cached job table of the dead one must not be reused (it was, in the first hardware run: NaN outputs
+    from a scale derived from a zero record)."""
+    import gc
+    from contrastiveseg_amd import kernels as K
+    inject.install(monkeypatch)
+    monkeypatch.setattr(K, "SPLIT_ARITH", "f16x3")
+    monkeypatch.setattr(K, "SPLIT_WEIGHTS", K.SplitWeights())
+    monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 48, 4, 64, generator=g)
+    seen = set()
+    for trial in range(12):
+        w = torch.randn(48, 48, 3, 3, generator=g) * (10.0 ** (trial % 6 - 3))   # very different magnitudes: a stale scale shows
+        y = K.conv3x3_sb_run(x, w, False)
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+        assert torch.isfinite(y).all()
+        assert float((y.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+        seen.add((id(w), w.data_ptr()))
+        # what the cached job tables are keyed on names pointers and record rows by value
+        ident = K.SPLIT_WEIGHTS.table_cache["amax"][0]
+        assert ident == tuple((v.data_ptr(), v.numel(), st["row"]) for st in K.SPLIT_WEIGHTS.weights.values() for v in [st["ref"]()])
+        del w, y
+        gc.collect()
+    # (whether an (id, storage) pair really recurs is up to CPython and the allocator: on the GPU box it did)

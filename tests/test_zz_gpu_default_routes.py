@@ -85,7 +85,7 @@ def test_branch_convolution_routes_at_the_benched_shapes(channels, hw, monkeypat
     assert len(runs) == 2, "forward / backward-data did not take the split-bf16 route"
     if channels in K.CONV3X3_SB_PICK_NT_CHANNELS:
         assert all((c[1][4] if len(c[1]) > 4 else c[2].get("nt", 0)) == 3 for c in runs), "expected 3 channel tiles per block"
-    assert (len([c for c in calls if c[0] == "conv3x3_sb_wrw"]) == 1) == (channels in K.CONV3X3_SB_WRW_CHANNELS and hw[1] % 64 == 0)
+    assert (len([c for c in calls if c[0] == "conv3x3_sb_wrw"]) == 1) == (channels in K.CONV3X3_SB_WRW_CHANNELS and hw[1] % 32 == 0)
     # fp64 truth on the host, MIOpen's fp32 result as the yardstick (same rule as tests/test_gpu_conv3x3_sb.py)
     x64 = x.clone().double().requires_grad_(True)
     w64 = conv.weight.detach().cpu().double().requires_grad_(True)
