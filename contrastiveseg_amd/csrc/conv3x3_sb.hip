@@ -57,10 +57,20 @@ int sb_variant() {
     const char* e = getenv("CSEG_CONV3X3_SB_VAR");
     return e ? atoi(e) : -1;
 }
-// 64 output channels (4 channel tiles: the 3x3 convolutions of the layer-1 bottlenecks) exist only in the 16-channel-chunk kernel
+// 64 output channels (4 channel tiles: the 3x3 convolutions of the layer-1 bottlenecks) exist only in the 16-channel-chunk kernel.
+// CSEG_CONV3X3_SB16_CH = comma-separated output channel counts that go to conv3x3_sb16.hip (tuning; overrides the default list).
 bool use_sb16(int conv_out) {
     const int v = sb_variant();
     if (conv_out == 64) return true;
+    const char* list = getenv("CSEG_CONV3X3_SB16_CH");
+    if (list) {
+        for (const char* p = list; *p;) {
+            if (atoi(p) == conv_out) return conv_out % 48 == 0;
+            while (*p && *p != ',') ++p;
+            if (*p == ',') ++p;
+        }
+        return false;
+    }
     if (v == 2) return conv_out <= 192 && conv_out % 48 == 0;
     return v < 0 && (conv_out == 48 || conv_out == 192);
 }

@@ -769,7 +769,7 @@ class SplitWeights(object):
             st = {"row": self.next_row, "entries": {}, "ref": weakref.ref(weight, lambda _r, wid=wid: self.weights.pop(wid, None))}
             self.next_row += 1                           # rows are not recycled (a dead weight's row stays zero)
             self.weights[wid] = st
-        key = (tag, bool(flag), int(nt_req), SPLIT_ARITH, os.environ.get("CSEG_CONV3X3_SB_VAR"))
+        key = (tag, bool(flag), int(nt_req), SPLIT_ARITH, os.environ.get("CSEG_CONV3X3_SB_VAR"), os.environ.get("CSEG_CONV3X3_SB16_CH"))
         e = st["entries"].get(key)
         if e is None:
             e = self._plan(weight, tag, flag, nt_req, arith)

@@ -260,3 +260,23 @@ def test_f16x3_error_is_fp32_class():
     e3 = np.abs(E.conv3x3_sb(x, w, None, arith=E.F16X3) - ref).max()
     x32 = np.abs(E.ref_conv3x3(x, w).astype(np.float32) - ref).max()         # one fp32 rounding of the exact result
     assert e3 <= 2.0 * e6 + 4.0 * x32, (e3, e6, x32)
+
+
+# ---- round 3: the persistent chunk-barrier form of the 16-channel-chunk kernel (conv3x3_sb16p_kernel, f16x3) ------------------
+@pytest.mark.parametrize("case,what", [
+    ((1, 96, 48, 5, 68), "weights streamed chunk by chunk (6 chunks do not fit), ragged tiles"),
+    ((1, 64, 64, 6, 68), "4 channel tiles per block (layer-1 bottleneck), streamed"),
+    ((1, 32, 48, 104, 640), "260 tiles on 256 blocks: some blocks walk two tiles with the weights resident"),
+    ((2, 64, 64, 52, 640), "260 tiles, streamed weights across the tile boundary"),
+])
+def test_persistent_small_channel_convolution(case, what, monkeypatch):
+    monkeypatch.setenv("CSEG_EMU_WAVE_ORDER", "shuffle:11")
+    B, ci, co, H, W = case
+    x, w, b = _rand((B, ci, H, W), 71, 2.0), _rand((co, ci, 3, 3), 72, 1.0 / (3 * ci ** 0.5)), _rand((co,), 73)
+    y = E.conv3x3_sb(x, w, b, arith=E.F16X3)
+    ref = E.ref_conv3x3(x, w, b)
+    assert not np.isnan(y).any()
+    assert np.abs(y - ref).max() <= _bound(ref, 9 * ci), what
+    monkeypatch.setenv("CSEG_CONV3X3_SB16_P", "0")                 # the one-tile kernel on the same operands: same arithmetic
+    y1 = E.conv3x3_sb(x, w, b, arith=E.F16X3)
+    assert np.array_equal(y, y1), "persistent and one-tile kernels accumulate in the same order: bit-identical results"
