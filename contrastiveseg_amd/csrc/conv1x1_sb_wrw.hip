@@ -20,7 +20,8 @@
 namespace {
 
 constexpr int CO_T = 144, CI_T = 128, STG = 32;      // channel block, pixels per stage
-constexpr int PITCH = 40;                            // bf16 elements per (piece, channel) row: 32 + 8 pad (20 dwords = 4 * odd)
+constexpr int PITCH = 48;                            // half-words per (piece, channel) row: 32 + 16 pad = 96 bytes (6 x 16: conflict-free
+                                                     // under the real ds_read_b128 lane groups, see conv3x3_sb_wrw.hip; 80 bytes was not)
 __host__ __device__ constexpr int dy_elems(int np) { return np * CO_T * PITCH; }      // one dy buffer
 __host__ __device__ constexpr int x_elems(int np) { return np * CI_T * PITCH; }       // one x buffer
 constexpr int CH_ALL = CO_T + CI_T;                  // 272 channel rows per stage

@@ -22,6 +22,7 @@ constexpr int TC = 64;                // output columns per block
 constexpr int XROWS = TR + 2;
 constexpr int XCOLS = TC + 2;         // cell 0 = column x0 - 1
 constexpr int CELLS = XROWS * XCOLS;  // 396 pixels per (piece, octet)
+constexpr int PLANE = (CELLS + 15) / 16 * 16;     // LDS stride of a (piece, octet) plane: 0 mod 256 bytes, see conv3x3_sb.hip
 constexpr int NOCT = 2;               // channel octets per chunk
 constexpr int A_ITEMS = NOCT * CELLS; // (octet, pixel) staging items of a 16-channel chunk
 constexpr int AU = (A_ITEMS + 511) / 512;     // staging items per thread (512 threads): 2
@@ -50,7 +51,7 @@ __device__ __forceinline__ void sb16_kstep(const uint4* __restrict__ ap, const u
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int p = 0; p < AR::NP; ++p) a[mt][p] = __builtin_bit_cast(frag_t, ap[p * NOCT * CELLS + 16 * mt]);
+        for (int p = 0; p < AR::NP; ++p) a[mt][p] = __builtin_bit_cast(frag_t, ap[p * NOCT * PLANE + 16 * mt]);
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         frag_t b[AR::NP];
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(cons
                                                               const unsigned* __restrict__ amax_w, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s16[];
     constexpr int NP = AR::NP;
-    constexpr int A_CELLS = NP * NOCT * CELLS;
+    constexpr int A_CELLS = NP * NOCT * PLANE;
     uint4* As = smem_s16;                          // [piece NP][octet 2][CELLS]
     uint4* Bs = smem_s16 + A_CELLS;                // [2][NT*NP*64]
     constexpr int BSTEP = NT * NP * 64;            // uint4 per K-step
@@ -172,9 +173,9 @@ __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(cons
                 for (int j = 0; j < 8; ++j) v[j] = ok ? apre[u][j] : 0.f;       // zero padding / outside the tensor
                 uint4 cells[NP];
                 split_cells8<AR>(v, xscale, cells);
-                const int item = oct * CELLS + rc;
+                const int item = oct * PLANE + rc;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) As[p * NOCT * CELLS + item] = cells[p];
+                for (int p = 0; p < NP; ++p) As[p * NOCT * PLANE + item] = cells[p];
             }
         }
     };
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(cons
             // patch values those lanes read contribute nothing
             const int tap = min(2 * s + (g >> 1), 8);
             const int ky = tap / 3, kx = tap - 3 * ky;
-            const int a_off = (g & 1) * CELLS + ky * XCOLS + kx;
+            const int a_off = (g & 1) * PLANE + ky * XCOLS + kx;
             if (half == 0) sb16_kstep<AR, NT0, NT0>(a_lane + a_off, b_lane + buf * BSTEP, acc);
             else if (NT1 > 0) sb16_kstep<AR, NT1, NT0>(a_lane + a_off, b_lane + buf * BSTEP, acc);
             if (s == STEPS - 1 && c + 1 < n_chunks) {
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
                                                                const unsigned* __restrict__ amax_w, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s16p[];
     constexpr int NP = AR::NP;
-    constexpr int A_CELLS = NP * NOCT * CELLS;
+    constexpr int A_CELLS = NP * NOCT * PLANE;
     constexpr int BSTEP = NT * NP * 64;            // uint4 per K-step
     constexpr int BCHUNK = STEPS * BSTEP;          // uint4 per 16-channel chunk
     constexpr int NT0 = (NT + 1) / 2, NT1 = NT - NT0;
@@ -332,9 +333,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
                 for (int j = 0; j < 8; ++j) v[j] = ok ? apre[u][j] : 0.f;       // zero padding / outside the tensor
                 uint4 cells[NP];
                 split_cells8<AR>(v, xscale, cells);
-                const int item = oct * CELLS + rc;
+                const int item = oct * PLANE + rc;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) dst[p * NOCT * CELLS + item] = cells[p];
+                for (int p = 0; p < NP; ++p) dst[p * NOCT * PLANE + item] = cells[p];
             }
         }
     };
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
             // the ninth tap is paired with a tenth that does not exist: its packed weights are zero
             const int tap = min(2 * s + (g >> 1), 8);
             const int ky = tap / 3, kx = tap - 3 * ky;
-            const int a_off = (g & 1) * CELLS + ky * XCOLS + kx;
+            const int a_off = (g & 1) * PLANE + ky * XCOLS + kx;
             if (half == 0) sb16_kstep<AR, NT0, NT0>(a_lane + a_off, b_base + s * BSTEP, acc);
             else if (NT1 > 0) sb16_kstep<AR, NT1, NT0>(a_lane + a_off, b_base + s * BSTEP, acc);
         }
@@ -422,19 +423,21 @@ int launch_sb16p(const float* x, const uint4* wp, const float* bias, int B, int 
 bool sb16p_plan(int arith, int Cin, int NT, size_t& lds, bool& res) {
     const char* e = getenv("CSEG_CONV3X3_SB16_P");
     if (arith != CSEG_ARITH_F16X3 || (e && atoi(e) == 0)) return false;
-    const size_t a = 2 * (size_t)2 * NOCT * CELLS * sizeof(uint4);               // two patch buffers, two pieces
+    const size_t a = 2 * (size_t)2 * NOCT * PLANE * sizeof(uint4);               // two patch buffers, two pieces
     const size_t chunk = (size_t)STEPS * NT * 2 * 64 * sizeof(uint4);
     const size_t all = (size_t)(Cin / 16) * chunk;
     const size_t cap = 160 * 1024;
     if (a + all <= cap) { lds = a + all; res = true; return true; }
-    if (a + 2 * chunk <= cap) { lds = a + 2 * chunk; res = false; return true; }
+    // streamed weights: measured a win at 3 channel tiles per block (192 ch 47.4 vs 52.2 us, 384 ch 79.8 vs 95.7) and a loss at
+    // 4 (64 ch: 83.2 vs 72.9 us for the one-tile kernel, which keeps two blocks per CU) -- tools/branch_conv_probe.py
+    if (NT == 3 && a + 2 * chunk <= cap) { lds = a + 2 * chunk; res = false; return true; }
     return false;
 }
 
 template <class AR, int NT>
 int launch_sb16(const float* x, const uint4* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
                 const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream) {
-    const size_t lds = sizeof(uint4) * (AR::NP * NOCT * CELLS + 2 * NT * AR::NP * 64);
+    const size_t lds = sizeof(uint4) * (AR::NP * NOCT * PLANE + 2 * NT * AR::NP * 64);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv3x3_sb16_kernel<AR, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
