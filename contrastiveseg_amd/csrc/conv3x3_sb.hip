@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void pack_weights_sb_kernel(const float* __res
 
 // One K-step of a wave: 4 pixel tiles x NTW channel tiles x 6 piece products. `ap` = this lane's cell in the hi-piece
 // image (octet, row, tap and column already applied), `bp` = this lane's slot in the staged B step.
-template <class AR, int NTW, int NTMAX>
+template <class AR, int NTW, int NTMAX, int ABL = 0>
 __device__ __forceinline__ void sb_kstep(const uint4* __restrict__ ap, const uint4* __restrict__ bp,
                                          f32x4 (&acc)[4][NTMAX]) {
     typedef typename AR::frag_t frag_t;
@@ -127,7 +127,10 @@ __device__ __forceinline__ void sb_kstep(const uint4* __restrict__ ap, const uin
 #pragma unroll
         for (int t = 0; t < AR::NTERMS; ++t)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = AR::mfma(a[mt][AR::ta(t)], b[AR::tb(t)], acc[mt][nt]);
+            for (int mt = 0; mt < 4; ++mt) {
+                if (ABL & 1) acc[mt][nt][0] += (float)a[mt][AR::ta(t)][0] + (float)b[AR::tb(t)][0];
+                else acc[mt][nt] = AR::mfma(a[mt][AR::ta(t)], b[AR::tb(t)], acc[mt][nt]);
+            }
     }
 }
 
@@ -165,7 +168,14 @@ __device__ __forceinline__ void sb_store(const f32x4 (&acc)[4][NTMAX], float* __
 //          64 VGPRs for addresses alone, the kernel sits at the 256-register limit with 26 spilled VGPRs, and every chunk
 //          starts with 13 serialized scratch reloads (hipcc -S: "Folded Reload" under .LBB1_23) while both waves of a SIMD
 //          wait. Index-identical to VAR 0 (same elements, same order); first hardware run pending -> CSEG_CONV3X3_SB_VAR=1.
-template <class AR, int NT, bool GLDS, int VAR = 0>
+// ABL != 0: ABLATION builds for timing experiments only (wrong results; CSEG_ABLATE, tools/ablate_probe.py): bit 0 = no MFMAs,
+// bit 1 = the patch is stored as truncated bits (no split arithmetic), bit 2 = no patch loads, bit 3 = no weight DMA.
+// SPS = K-steps per weight stage (round 3). With SPS = 1 every K-step (one tap x 32 channels: 54 MFMAs per wave at 9 channel
+// tiles) ends in a barrier that also waits for the next step's LDS-DMA; the ablation runs (tools/ablate_probe.py,
+// profiles/r03_ablate_probe.jsonl: with every global access removed the kernel still takes 4.1 ms against 2.9 ms of MFMA time)
+// put ~1.2 ms of the 5.6 ms on that per-step synchronisation. SPS = 3 stages a whole filter row (3 taps = 3 K-steps, 54 KB at 9
+// tiles, double-buffered: 161.8 KB of LDS with the patch) and synchronises once per row. f16x3 only (three pieces do not fit).
+template <class AR, int NT, bool GLDS, int VAR = 0, int ABL = 0, int SPS = 1>
 __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                             const float* __restrict__ bias, int Cin, int Cout, int H,
                                                             int W, int tiles_x, int tiles_y,
@@ -175,8 +185,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
     constexpr int NP = AR::NP;
     constexpr int A_CELLS = NP * 4 * PLANE;
     uint4* As = smem_sb;                           // [piece NP][octet 4][CELLS]
-    uint4* Bs = smem_sb + A_CELLS;                 // [2][NT*NP*64]
+    uint4* Bs = smem_sb + A_CELLS;                 // [2][SPS][NT*NP*64]
     constexpr int BSTEP = NT * NP * 64;            // uint4 per K-step
+    constexpr int BSTAGE = SPS * BSTEP;
     const unsigned ex = AR::SCALED ? split_amax_exp(amax_x) : 141u, ew = AR::SCALED ? split_amax_exp(amax_w) : 141u;
     const float xscale = split_scale_of(ex);       // 1 for the unscaled arithmetic
     constexpr int BU = (BSTEP + 511) / 512;
@@ -218,6 +229,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
     // A staging: item = (octet, patch pixel); 8 channel loads each (coalesced along the row), branch-free: the address
     // is clamped into the tensor and the value masked
     auto b_glds = [&](int ks, int buf) {
+        if (ABL & 8) return;
 #pragma unroll
         for (int i = 0; i < (NT * NP + 7) / 8; ++i) {
             const int r = wave + 8 * i;                  // one 1 KB row (channel tile, piece) per wave instruction
@@ -238,6 +250,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
         ok = oct < n_oct && yy >= 0 && yy < H && xx >= 0 && xx < W;
     };
     auto a_issue = [&](int chunk) {
+        if (ABL & 4) {
+#pragma unroll
+            for (int u = 0; u < AU; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) apre[u][j] = 1.f + j;
+            return;
+        }
         const int n_oct = chunk < n_full ? 4 : 2;
         const float* xc = x + ((size_t)b * Cin + (size_t)chunk * 32) * plane;
 #pragma unroll
@@ -276,7 +295,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = ok ? apre[u][j] : 0.f;       // zero padding / outside the tensor
                 uint4 cells[NP];
-                split_cells8<AR>(v, xscale, cells);
+                if (ABL & 2) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        cells[p] = make_uint4(__builtin_bit_cast(unsigned, v[0]) >> 16 | (__builtin_bit_cast(unsigned, v[1]) & 0xffff0000u),
+                                              __builtin_bit_cast(unsigned, v[2]) >> 16 | (__builtin_bit_cast(unsigned, v[3]) & 0xffff0000u),
+                                              __builtin_bit_cast(unsigned, v[4]) >> 16 | (__builtin_bit_cast(unsigned, v[5]) & 0xffff0000u),
+                                              __builtin_bit_cast(unsigned, v[6]) >> 16 | (__builtin_bit_cast(unsigned, v[7]) & 0xffff0000u));
+                } else split_cells8<AR>(v, xscale, cells);
                 const int item = oct * PLANE + rc;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) As[p * 4 * PLANE + item] = cells[p];
@@ -290,48 +316,108 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
 #pragma unroll
         for (int nt = 0; nt < NT0; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    a_issue(0);
-    if (GLDS) b_glds(0, 0);
-    else b_issue(0);
-    a_store(0);
-    if (!GLDS) b_store(0);
-    __syncthreads();
-
-    const uint4* a_lane = As + row * XCOLS + n;                        // + octet / tap offset per K-step
-    const uint4* b_lane = Bs + (half ? NT0 * NP * 64 : 0) + lane;      // + buffer offset per K-step
-    int ks = 0, buf = 0;
-    for (int c = 0; c < n_chunks; ++c) {
-        const bool full = c < n_full;
-        const int steps = full ? 9 : 5;
+    if constexpr (SPS > 1) {
+        static_assert(GLDS, "staged weights need the LDS-DMA path");
+        auto b_stage = [&](int ks0, int nsteps, int buf) {           // nsteps consecutive K-steps -> stage `buf`
+            if (ABL & 8) return;
+            const int rows = nsteps * NT * NP;
+#pragma unroll
+            for (int i = 0; i < (SPS * NT * NP + 7) / 8; ++i) {
+                const int r = wave + 8 * i;                          // one 1 KB row per wave instruction
+                if (r < rows)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(wbase + (size_t)ks0 * BSTEP + r * 64 + lane),
+                        (__attribute__((address_space(3))) void*)(Bs + buf * BSTAGE + r * 64), 16, 0, 0);
+            }
+        };
+        auto steps_of_chunk = [&](int c) { return c < n_full ? 9 : 5; };
+        a_issue(0);
+        b_stage(0, min(SPS, steps_of_chunk(0)), 0);
+        a_store(0);
+        __syncthreads();
+        const uint4* a_lane = As + row * XCOLS + n;
+        const uint4* b_lane = Bs + (half ? NT0 * NP * 64 : 0) + lane;
+        int ks = 0, buf = 0;
+        for (int c = 0; c < n_chunks; ++c) {
+            const bool full = c < n_full;
+            const int steps = steps_of_chunk(c);
 #pragma unroll 1
-        for (int s = 0; s < steps; ++s) {
-            const bool more = ks + 1 < n_steps;
-            if (more) {
-                if (GLDS) b_glds(ks + 1, buf ^ 1);      // that buffer was last read in step ks - 1 (barrier since)
-                else b_issue(ks + 1);
+            for (int s0 = 0; s0 < steps; s0 += SPS) {
+                const int nst = min(SPS, steps - s0);
+                const bool last = s0 + nst >= steps;                 // last stage of this chunk
+                if (ks + nst < n_steps)                              // next stage: the rest of this chunk or the head of the next
+                    b_stage(ks + nst, last ? min(SPS, steps_of_chunk(c + 1)) : min(SPS, steps - s0 - nst), buf ^ 1);
+                if (last && c + 1 < n_chunks) a_issue(c + 1);
+#pragma unroll
+                for (int j = 0; j < SPS; ++j) {
+                    if (j < nst) {
+                        const int st = s0 + j;
+                        int a_off;
+                        if (full) {
+                            const int ky = st / 3, kx = st - 3 * ky;
+                            a_off = g * PLANE + ky * XCOLS + kx;
+                        } else {
+                            const int tap = min(2 * st + (g >> 1), 8);   // tail chunk: two taps x 16 channels per K-step
+                            const int ky = tap / 3, kx = tap - 3 * ky;
+                            a_off = (g & 1) * PLANE + ky * XCOLS + kx;
+                        }
+                        if (half == 0) sb_kstep<AR, NT0, NT0, ABL>(a_lane + a_off, b_lane + buf * BSTAGE + j * BSTEP, acc);
+                        else if (NT1 > 0) sb_kstep<AR, NT1, NT0, ABL>(a_lane + a_off, b_lane + buf * BSTAGE + j * BSTEP, acc);
+                    }
+                }
+                if (last && c + 1 < n_chunks) {
+                    __syncthreads();                // every wave is done with this chunk's patch
+                    a_store(c + 1);
+                }
+                __syncthreads();
+                buf ^= 1;
+                ks += nst;
             }
-            if (s == steps - 3 && c + 1 < n_chunks) a_issue(c + 1);
-            int a_off;
-            if (full) {
-                const int ky = s / 3, kx = s - 3 * ky;
-                a_off = g * PLANE + ky * XCOLS + kx;
-            } else {
-                // the ninth tap is paired with a tenth that does not exist: its packed weights are zero, so whatever
-                // (finite) patch values those lanes read contribute nothing
-                const int tap = min(2 * s + (g >> 1), 8);
-                const int ky = tap / 3, kx = tap - 3 * ky;
-                a_off = (g & 1) * PLANE + ky * XCOLS + kx;
+        }
+    } else {
+        a_issue(0);
+        if (GLDS) b_glds(0, 0);
+        else b_issue(0);
+        a_store(0);
+        if (!GLDS) b_store(0);
+        __syncthreads();
+
+        const uint4* a_lane = As + row * XCOLS + n;                        // + octet / tap offset per K-step
+        const uint4* b_lane = Bs + (half ? NT0 * NP * 64 : 0) + lane;      // + buffer offset per K-step
+        int ks = 0, buf = 0;
+        for (int c = 0; c < n_chunks; ++c) {
+            const bool full = c < n_full;
+            const int steps = full ? 9 : 5;
+    #pragma unroll 1
+            for (int s = 0; s < steps; ++s) {
+                const bool more = ks + 1 < n_steps;
+                if (more) {
+                    if (GLDS) b_glds(ks + 1, buf ^ 1);      // that buffer was last read in step ks - 1 (barrier since)
+                    else b_issue(ks + 1);
+                }
+                if (s == steps - 3 && c + 1 < n_chunks) a_issue(c + 1);
+                int a_off;
+                if (full) {
+                    const int ky = s / 3, kx = s - 3 * ky;
+                    a_off = g * PLANE + ky * XCOLS + kx;
+                } else {
+                    // the ninth tap is paired with a tenth that does not exist: its packed weights are zero, so whatever
+                    // (finite) patch values those lanes read contribute nothing
+                    const int tap = min(2 * s + (g >> 1), 8);
+                    const int ky = tap / 3, kx = tap - 3 * ky;
+                    a_off = (g & 1) * PLANE + ky * XCOLS + kx;
+                }
+                if (half == 0) sb_kstep<AR, NT0, NT0, ABL>(a_lane + a_off, b_lane + buf * BSTEP, acc);
+                else if (NT1 > 0) sb_kstep<AR, NT1, NT0, ABL>(a_lane + a_off, b_lane + buf * BSTEP, acc);
+                if (more && !GLDS) b_store(buf ^ 1);
+                if (s == steps - 1 && c + 1 < n_chunks) {
+                    __syncthreads();                    // every wave is done with this chunk's patch
+                    a_store(c + 1);
+                }
+                __syncthreads();
+                buf ^= 1;
+                ++ks;
             }
-            if (half == 0) sb_kstep<AR, NT0, NT0>(a_lane + a_off, b_lane + buf * BSTEP, acc);
-            else if (NT1 > 0) sb_kstep<AR, NT1, NT0>(a_lane + a_off, b_lane + buf * BSTEP, acc);
-            if (more && !GLDS) b_store(buf ^ 1);
-            if (s == steps - 1 && c + 1 < n_chunks) {
-                __syncthreads();                    // every wave is done with this chunk's patch
-                a_store(c + 1);
-            }
-            __syncthreads();
-            buf ^= 1;
-            ++ks;
         }
     }
 
@@ -359,13 +445,13 @@ int pick_nt(int Cout) {
     return 0;
 }
 
-template <class AR, int NT, bool GLDS, int VAR = 0>
+template <class AR, int NT, bool GLDS, int VAR = 0, int ABL = 0, int SPS = 1>
 int launch_sb(const float* x, const uint4* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
               const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream) {
-    const size_t lds = sizeof(uint4) * (AR::NP * 4 * PLANE + 2 * NT * AR::NP * 64);
+    const size_t lds = sizeof(uint4) * (AR::NP * 4 * PLANE + 2 * SPS * NT * AR::NP * 64);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_sb_kernel<AR, NT, GLDS, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        if (hipFuncSetAttribute((const void*)conv3x3_sb_kernel<AR, NT, GLDS, VAR, ABL, SPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess) {
             cseg_set_error("conv3x3_sb: cannot raise dynamic LDS to %zu bytes", lds);
             return 0;
@@ -375,7 +461,7 @@ int launch_sb(const float* x, const uint4* wp, const float* bias, int B, int Cin
     const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
     const long n_tiles = (long)B * (Cout / (NT * 16)) * tiles_y * tiles_x;
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb: grid too large");
-    hipLaunchKernelGGL((conv3x3_sb_kernel<AR, NT, GLDS, VAR>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, Cin, Cout, H, W, tiles_x,
+    hipLaunchKernelGGL((conv3x3_sb_kernel<AR, NT, GLDS, VAR, ABL, SPS>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, Cin, Cout, H, W, tiles_x,
                        tiles_y, amax_x, amax_w, y);
     CSEG_CHECK_LAUNCH("conv3x3_sb_kernel");
     return 1;
@@ -487,8 +573,32 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, int B, in
         case 6: return launch_sb<AR, 6, G, V>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);             \
         default: return launch_sb<AR, 3, G, V>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);            \
     }
+    if (arith == CSEG_ARITH_F16X3 && NT == 9 && var >= 1) {
+        const char* abl_env = getenv("CSEG_ABLATE");                // timing experiments only (wrong results)
+        switch (abl_env ? atoi(abl_env) : 0) {
+            case 0: break;
+            case 1: return launch_sb<SplitF16x3, 9, true, 1, 1>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            case 2: return launch_sb<SplitF16x3, 9, true, 1, 2>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            case 4: return launch_sb<SplitF16x3, 9, true, 1, 4>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            case 6: return launch_sb<SplitF16x3, 9, true, 1, 6>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            case 8: return launch_sb<SplitF16x3, 9, true, 1, 8>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            case 14: return launch_sb<SplitF16x3, 9, true, 1, 14>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            case 7: return launch_sb<SplitF16x3, 9, true, 1, 7>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            case 9: return launch_sb<SplitF16x3, 9, true, 1, 9>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            default: return launch_sb<SplitF16x3, 9, true, 1, 15>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+        }
+    }
     if (arith == CSEG_ARITH_F16X3) {
-        // one form only: LDS-DMA for the weights, buffer-load addressing of the patch when the offsets fit 32 bits
+        // LDS-DMA for the weights, buffer-load addressing of the patch when the offsets fit 32 bits; weights staged a filter row
+        // (3 K-steps) at a time unless CSEG_CONV3X3_SB_SPS=1
+        const char* sps_env = getenv("CSEG_CONV3X3_SB_SPS");
+        if (var >= 1 && !(sps_env && atoi(sps_env) == 1)) {
+            switch (NT) {
+                case 9: return launch_sb<SplitF16x3, 9, true, 1, 0, 3>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+                case 6: return launch_sb<SplitF16x3, 6, true, 1, 0, 3>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+                default: return launch_sb<SplitF16x3, 3, true, 1, 0, 3>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            }
+        }
         if (var >= 1) { SB_LAUNCH(SplitF16x3, true, 1) }
         SB_LAUNCH(SplitF16x3, true, 0)
     }

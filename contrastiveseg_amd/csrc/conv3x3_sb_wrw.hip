@@ -263,7 +263,10 @@ __device__ __forceinline__ int x2_idx(int p, int ci, int slot, int i) { return (
 template <int NP, int SEGW>
 __device__ __forceinline__ int d2_idx(int buf, int p, int co, int i) { return ((buf * NP + p) * CO_B + co) * d2_pitch(NP, SEGW) + i; }
 
-template <class AR, int SEGW>
+// ABL != 0: ABLATION builds for timing experiments only (results are wrong): bit 0 = the consumers skip their MFMAs, bit 1 = the
+// loaders store truncated bits instead of splitting (no conversion arithmetic), bit 2 = the loaders skip the global loads.
+// Reached with CSEG_ABLATE=<bits> (tools/ablate_probe.py); never set in the product.
+template <class AR, int SEGW, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                  int B, int Cin, int Cout, int H, int W, int n_split, int rpu,
                                                                  int SC, int SI, const unsigned* __restrict__ amax_x,
@@ -314,7 +317,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
             const int ci = item / XCH, c = item - ci * XCH;
             const int px = x0 - 4 + 4 * c;
             const int cic = min(cib * CI_B + ci, Cin - 1), rowc = min(max(row, 0), H - 1), pxc = min(max(px, 0), W - 4);
-            v[u] = *reinterpret_cast<const float4*>(x + ((size_t)b * Cin + cic) * plane + (size_t)rowc * W + pxc);
+            if (ABL & 4) v[u] = make_float4(1.f, 2.f, 3.f, 4.f);
+            else v[u] = *reinterpret_cast<const float4*>(x + ((size_t)b * Cin + cic) * plane + (size_t)rowc * W + pxc);
         }
     };
     auto x_put = [&](int x0, int row, int slot, const float4 (&v)[XU]) {
@@ -327,7 +331,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
                 const bool ok = cib * CI_B + ci < Cin && row >= 0 && row < H && px >= 0 && px < W;
                 const float4 t = ok ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 cells[NP];
-                split_cells4<AR>(t, xscale, cells);
+                if (ABL & 2) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        cells[p] = make_uint2(__builtin_bit_cast(unsigned, t.x) >> 16 | (__builtin_bit_cast(unsigned, t.y) & 0xffff0000u),
+                                              __builtin_bit_cast(unsigned, t.z) >> 16 | (__builtin_bit_cast(unsigned, t.w) & 0xffff0000u));
+                } else split_cells4<AR>(t, xscale, cells);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(xs + x2_idx<NP, SEGW>(p, ci, slot, 4 * c)) = cells[p];
             }
@@ -338,7 +347,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
         for (int u = 0; u < DU; ++u) {
             const int item = min(lt + 256 * u, CO_B * DCH - 1);
             const int co = item / DCH, c = item - co * DCH;
-            v[u] = *reinterpret_cast<const float4*>(dy + (((size_t)b * Cout + cob * CO_B + co) * H + min(row, H - 1)) * W + x0 + 4 * c);
+            if (ABL & 4) v[u] = make_float4(1.f, 2.f, 3.f, 4.f);
+            else v[u] = *reinterpret_cast<const float4*>(dy + (((size_t)b * Cout + cob * CO_B + co) * H + min(row, H - 1)) * W + x0 + 4 * c);
         }
     };
     auto d_put = [&](int buf, const float4 (&v)[DU]) {
@@ -348,7 +358,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
             if (item < CO_B * DCH) {
                 const int co = item / DCH, c = item - co * DCH;
                 uint2 cells[NP];
-                split_cells4<AR>(v[u], dscale, cells);
+                if (ABL & 2) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        cells[p] = make_uint2(__builtin_bit_cast(unsigned, v[u].x) >> 16 | (__builtin_bit_cast(unsigned, v[u].y) & 0xffff0000u),
+                                              __builtin_bit_cast(unsigned, v[u].z) >> 16 | (__builtin_bit_cast(unsigned, v[u].w) & 0xffff0000u));
+                } else split_cells4<AR>(v[u], dscale, cells);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(ds + d2_idx<NP, SEGW>(buf, p, co, 4 * c)) = cells[p];
             }
@@ -388,7 +403,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
                     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                         for (int c = 0; c < 3; ++c)
-                            acc[ky * 3 + kx][c] = AR::mfma(a[c][AR::ta(t)], bfr[kx][AR::tb(t)], acc[ky * 3 + kx][c]);
+                            if (ABL & 1) acc[ky * 3 + kx][c][0] += (float)a[c][AR::ta(t)][0] + (float)bfr[kx][AR::tb(t)][0];
+                            else acc[ky * 3 + kx][c] = AR::mfma(a[c][AR::ta(t)], bfr[kx][AR::tb(t)], acc[ky * 3 + kx][c]);
             }
         }
     };
@@ -506,9 +522,9 @@ int sb_wrw_version() {
 }
 
 // version 2: 64-pixel row segments, or 32-pixel ones when the width is 32 mod 64 (the 384-channel maps of HRNet-W48: 16 x 32);
-// runs of 16 rows (8 on maps lower than 64 rows, so that small maps still give every split a unit)
+// runs of 16 rows (8 on maps lower than 32 rows, so that the 16 x 32 maps still give every split a unit)
 int wrw2_seg(int W) { return W % 64 == 0 ? 64 : 32; }
-int wrw2_rpu(int H) { return H >= 64 ? 16 : 8; }
+int wrw2_rpu(int H) { return H >= 32 ? 16 : 8; }      // 8-row runs at 32 rows cost the 192-channel maps 52 -> 62 us (more splits, more partials)
 
 int sb_wrw_splits(int B, int Cin, int Cout, int H, int W, int arith) {
     const bool v2 = arith == CSEG_ARITH_F16X3 || sb_wrw_version() == 2;
@@ -550,13 +566,13 @@ void sb_wrw_group(int n_cob, int n_cib, int& SC, int& SI) {
     }
 }
 
-template <class AR, int SEGW>
+template <class AR, int SEGW, int ABL = 0>
 int launch_wrw2(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, int n_split, const unsigned* amax_x,
                 const unsigned* amax_dy, float* ws, hipStream_t stream) {
     const size_t lds2 = sizeof(unsigned short) * (x2_elems(AR::NP, SEGW) + d2_elems(AR::NP, SEGW));
     static bool attr2_set = false;
     if (!attr2_set) {
-        if (hipFuncSetAttribute((const void*)(conv3x3_sb_wrw2_kernel<AR, SEGW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) !=
+        if (hipFuncSetAttribute((const void*)(conv3x3_sb_wrw2_kernel<AR, SEGW, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) !=
             hipSuccess) {
             cseg_set_error("conv3x3_sb_wrw: cannot raise dynamic LDS to %zu bytes", lds2);
             return 0;
@@ -569,7 +585,7 @@ int launch_wrw2(const float* x, const float* dy, int B, int Cin, int Cout, int H
     const long n_groups = (long)n_split * (n_cob / SC) * (n_cib / SI);
     const long blocks = ((n_groups + 7) / 8) * 8 * SC * SI;
     CSEG_REQUIRE(blocks < 2147483647L, "conv3x3_sb_wrw: grid too large");
-    hipLaunchKernelGGL((conv3x3_sb_wrw2_kernel<AR, SEGW>), dim3((unsigned)blocks), dim3(512), lds2, stream, x, dy, B, Cin, Cout, H, W,
+    hipLaunchKernelGGL((conv3x3_sb_wrw2_kernel<AR, SEGW, ABL>), dim3((unsigned)blocks), dim3(512), lds2, stream, x, dy, B, Cin, Cout, H, W,
                        n_split, wrw2_rpu(H), SC, SI, amax_x, amax_dy, ws);
     CSEG_CHECK_LAUNCH("conv3x3_sb_wrw2_kernel");
     return 1;
@@ -591,6 +607,25 @@ int wrw_impl(const float* x, const float* dy, int B, int Cin, int Cout, int H, i
         CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0,
                      "conv3x3_sb_wrw: tensors must be 16-byte aligned");
         const bool wide = wrw2_seg(W) == 64;
+        const char* abl_env = getenv("CSEG_ABLATE");
+        const int abl = abl_env ? atoi(abl_env) : 0;
+        if (abl && arith == CSEG_ARITH_F16X3 && wide) {                 // timing experiments only (wrong results)
+            int ok2 = 0;
+            switch (abl) {
+                case 1: ok2 = launch_wrw2<SplitF16x3, 64, 1>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
+                case 2: ok2 = launch_wrw2<SplitF16x3, 64, 2>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
+                case 4: ok2 = launch_wrw2<SplitF16x3, 64, 4>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
+                case 6: ok2 = launch_wrw2<SplitF16x3, 64, 6>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
+                case 3: ok2 = launch_wrw2<SplitF16x3, 64, 3>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
+                case 5: ok2 = launch_wrw2<SplitF16x3, 64, 5>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
+                default: ok2 = launch_wrw2<SplitF16x3, 64, 7>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
+            }
+            if (!ok2) return 0;
+            const int total_a = 9 * Cin * Cout;
+            hipLaunchKernelGGL(sb_wrw_reduce_kernel, dim3((total_a + 63) / 64), dim3(256), 0, stream, ws, n_split, Cout, Cin, dw);
+            CSEG_CHECK_LAUNCH("sb_wrw_reduce_kernel");
+            return 1;
+        }
         const int ok = arith == CSEG_ARITH_F16X3
                            ? (wide ? launch_wrw2<SplitF16x3, 64>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream)
                                    : launch_wrw2<SplitF16x3, 32>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream))
