@@ -370,42 +370,61 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
         }
     };
 
-    // ---- consumer side: output row with x rows in slots s0 (row - 1), s0 + 1, s0 + 2 (mod 4), dy in buffer `buf`
+    // ---- consumer side: output row with x rows in slots s0 (row - 1), s0 + 1, s0 + 2 (mod 4), dy in buffer `buf`.
+    // A row-step is (SEGW / 32) x 3 groups (K-step, filter row) of 27 MFMAs x AR::NTERMS. Round 3: software-pipelined by hand --
+    // the LDS reads of group i + 1 are issued before the MFMAs of group i (the compiler's own order waited on freshly issued reads
+    // ~20 times per row-step, and with ONE consumer wave per SIMD nothing else can issue MFMAs meanwhile).
+    struct XRaw { uint4 c0[NP], c1[NP]; };
+    auto load_a = [&](int ks, int buf, frag_t (&a)[3][NP]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                a[c][p] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(ds + d2_idx<NP, SEGW>(buf, p, c * 16 + n, 32 * ks + 8 * g)));
+    };
+    auto load_x = [&](int ks, int slot, XRaw& r) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const unsigned short* src = xs + x2_idx<NP, SEGW>(p, wave * 16 + n, slot, 32 * ks + 8 * g);
+            r.c0[p] = *reinterpret_cast<const uint4*>(src);          // entries e .. e+7    (d0..d3)
+            r.c1[p] = *reinterpret_cast<const uint4*>(src + 8);      // entries e+8 .. e+15 (d4..d7)
+        }
+    };
     auto compute = [&](int s0, int buf, f32x4 (&acc)[9][3]) {
+        constexpr int NG = (SEGW / 32) * 3;
+        frag_t a[2][3][NP];
+        XRaw xr[2];
+        load_a(0, buf, a[0]);
+        load_x(0, s0 & 3, xr[0]);
 #pragma unroll
-        for (int ks = 0; ks < SEGW / 32; ++ks) {
-            frag_t a[3][NP];
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int p = 0; p < NP; ++p)
-                    a[c][p] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(ds + d2_idx<NP, SEGW>(buf, p, c * 16 + n, 32 * ks + 8 * g)));
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int slot = (s0 + ky) & 3;
-                frag_t bfr[3][NP];                     // [kx][piece]
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    const unsigned short* src = xs + x2_idx<NP, SEGW>(p, wave * 16 + n, slot, 32 * ks + 8 * g);
-                    const uint4 c0 = *reinterpret_cast<const uint4*>(src);          // entries e .. e+7    (d0..d3)
-                    const uint4 c1 = *reinterpret_cast<const uint4*>(src + 8);      // entries e+8 .. e+15 (d4..d7)
-                    const unsigned a21 = __builtin_amdgcn_alignbit(c0.z, c0.y, 16), a32 = __builtin_amdgcn_alignbit(c0.w, c0.z, 16),
-                                   a43 = __builtin_amdgcn_alignbit(c1.x, c0.w, 16), a54 = __builtin_amdgcn_alignbit(c1.y, c1.x, 16),
-                                   a65 = __builtin_amdgcn_alignbit(c1.z, c1.y, 16);
-                    bfr[0][p] = __builtin_bit_cast(frag_t, make_uint4(a21, a32, a43, a54));     // entries e+3 .. e+10 (kx = 0)
-                    bfr[1][p] = __builtin_bit_cast(frag_t, make_uint4(c0.z, c0.w, c1.x, c1.y)); // entries e+4 .. e+11
-                    bfr[2][p] = __builtin_bit_cast(frag_t, make_uint4(a32, a43, a54, a65));     // entries e+5 .. e+12
-                }
-                // term-major, smallest terms first; nine independent accumulators between two MFMAs on the same one
-#pragma unroll
-                for (int t = 0; t < AR::NTERMS; ++t)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            if (ABL & 1) acc[ky * 3 + kx][c][0] += (float)a[c][AR::ta(t)][0] + (float)bfr[kx][AR::tb(t)][0];
-                            else acc[ky * 3 + kx][c] = AR::mfma(a[c][AR::ta(t)], bfr[kx][AR::tb(t)], acc[ky * 3 + kx][c]);
+        for (int grp = 0; grp < NG; ++grp) {
+            const int ks = grp / 3, ky = grp % 3;
+            if (grp + 1 < NG) {
+                const int nks = (grp + 1) / 3, nky = (grp + 1) % 3;
+                if (nky == 0) load_a(nks, buf, a[nks & 1]);
+                load_x(nks, (s0 + nky) & 3, xr[(grp + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);         // keep the prefetch in front of this group's MFMAs
             }
+            frag_t bfr[3][NP];                             // [kx][piece]
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const uint4 c0 = xr[grp & 1].c0[p], c1 = xr[grp & 1].c1[p];
+                const unsigned a21 = __builtin_amdgcn_alignbit(c0.z, c0.y, 16), a32 = __builtin_amdgcn_alignbit(c0.w, c0.z, 16),
+                               a43 = __builtin_amdgcn_alignbit(c1.x, c0.w, 16), a54 = __builtin_amdgcn_alignbit(c1.y, c1.x, 16),
+                               a65 = __builtin_amdgcn_alignbit(c1.z, c1.y, 16);
+                bfr[0][p] = __builtin_bit_cast(frag_t, make_uint4(a21, a32, a43, a54));     // entries e+3 .. e+10 (kx = 0)
+                bfr[1][p] = __builtin_bit_cast(frag_t, make_uint4(c0.z, c0.w, c1.x, c1.y)); // entries e+4 .. e+11
+                bfr[2][p] = __builtin_bit_cast(frag_t, make_uint4(a32, a43, a54, a65));     // entries e+5 .. e+12
+            }
+            // term-major, smallest terms first; nine independent accumulators between two MFMAs on the same one
+#pragma unroll
+            for (int t = 0; t < AR::NTERMS; ++t)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (ABL & 1) acc[ky * 3 + kx][c][0] += (float)a[ks & 1][c][AR::ta(t)][0] + (float)bfr[kx][AR::tb(t)][0];
+                        else acc[ky * 3 + kx][c] = AR::mfma(a[ks & 1][c][AR::ta(t)], bfr[kx][AR::tb(t)], acc[ky * 3 + kx][c]);
         }
     };
 
@@ -654,6 +673,332 @@ int wrw_impl(const float* x, const float* dy, int B, int Cin, int Cout, int H, i
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// Stride 2 (round 3): dW[co][ci][ky][kx] = sum_{b,oy,ox} dy[b][co][oy][ox] * x[b][ci][2 oy + ky - 1][2 ox + kx - 1]   (pad 1, x is
+// 2 Ho x 2 Wo). The 52 downsampling convolutions of HRNet-W48's fuse / transition layers ran on MIOpen's NHWC implicit-GEMM
+// weight gradient, which brings two layout transposes per call: ~9 ms of the 108 ms step (profiles/r03_step_steady_kernel_stats.csv).
+// Same producer / consumer structure, block shape (48 co x 64 ci x 9 taps), partial buffer, XCD-aware block order and reduction
+// as version 2 above; what changes is the x image in LDS:
+//   * an output row oy needs the EVEN input row 2 oy (ky = 1) and the ODD rows 2 oy - 1, 2 oy + 1 (ky = 0, 2); the odd row
+//     2 oy + 1 is used again by oy + 1. Rings: two slots for even rows, three for odd rows; per row-step the loaders stage one of
+//     each (twice the x traffic of stride 1 per output row, as the operator demands) and one dy row;
+//   * within a row the columns are stored DE-INTERLEAVED: plane 0 holds the even input columns 2 ox (kx = 1), plane 1 the odd
+//     ones 2 ox + 1 (kx = 2; kx = 0 is the same plane one entry to the left), entry i of a plane <-> ox = i - 8, so that the
+//     fragment of a K-group (8 consecutive ox) is ONE aligned ds_read_b128 for kx = 1 and kx = 2 and that cell shifted by one
+//     half-word (4 v_alignbit + the last dword of the cell in front) for kx = 0. The loaders fetch aligned float4 (4 consecutive
+//     input columns = 2 even + 2 odd) and write one dword per plane and piece.
+// Segments of 32 output columns = one K-step per row-step (with 64 the five-slot image does not fit: 174 KB). f16x3 only.
+// LDS: x [piece 2][ci 64][slot 5][plane 2][40] half-words, channel pitch 432 (= 54 x 16 B, 6 mod 16: conflict-free b128 reads),
+// dy [2][piece][co 48][48]: 110.6 + 18.4 = 129 KB.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int S2_SEG = 32;
+constexpr int S2_PL = S2_SEG + 8;                  // entries of one column-parity plane
+constexpr int S2_ROWIMG = 2 * S2_PL;               // half-words of one staged x row
+constexpr int S2_XCH = 432;                        // per (piece, ci) pitch: 5 slots x 80 + 32 pad
+constexpr int S2_DP = 48;                          // dy row pitch
+constexpr int S2_KCH = S2_SEG / 2 + 2;             // float4 chunks of a staged x row: input columns 2 x0 - 8 .. 2 x0 + 63
+constexpr int s2_x_elems(int np) { return np * CI_B * S2_XCH; }
+constexpr int s2_d_elems(int np) { return 2 * np * CO_B * S2_DP; }
+
+template <class AR>
+__global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw_s2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   int B, int Cin, int Cout, int Ho, int Wo, int n_split, int rpu,
+                                                                   int SC, int SI, const unsigned* __restrict__ amax_x,
+                                                                   const unsigned* __restrict__ amax_dy,
+                                                                   float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_w[];
+    constexpr int NP = AR::NP;
+    typedef typename AR::frag_t frag_t;
+    unsigned short* xs = smem_w;
+    unsigned short* ds = smem_w + s2_x_elems(NP);
+    constexpr int XU = (CI_B * S2_KCH + 255) / 256;      // 5 float4 chunks per loader thread and x row
+    constexpr int DCH = S2_SEG / 4, DU = (CO_B * DCH + 255) / 256;
+    const unsigned ex = split_amax_exp(amax_x), ed = split_amax_exp(amax_dy);
+    const float xscale = split_scale_of(ex), dscale = split_scale_of(ed);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool loader = wave >= 4;
+    const int lt = tid - 256;
+    const int g = lane >> 4, n = lane & 15;
+    const int n_cib = (Cin + CI_B - 1) / CI_B;
+    int split, cib, cob;
+    {   // XCD-aware block order, see conv3x3_sb_wrw2_kernel
+        const int n_cob = Cout / CO_B;
+        const int n_si = n_cib / SI, gsz = SC * SI, n_groups = n_split * (n_cob / SC) * n_si;
+        const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+        const int grp = (l / gsz) * 8 + xcd, j = l % gsz;
+        if (grp >= n_groups) return;
+        split = grp % n_split;
+        const int st = grp / n_split;
+        cib = (st % n_si) * SI + j % SI;
+        cob = (st / n_si) * SC + j / SI;
+    }
+    const int H = 2 * Ho, W = 2 * Wo;
+    const size_t plane = (size_t)H * W, oplane = (size_t)Ho * Wo;
+    const int segs = Wo / S2_SEG;
+    const int runs = (Ho + rpu - 1) / rpu;
+    const int n_units = B * segs * runs;
+    const bool tile_ok = !loader && cib * CI_B + wave * 16 < Cin;
+
+    auto x_at = [&](int p, int ci, int slot, int pl, int i) { return xs + (p * CI_B + ci) * S2_XCH + slot * S2_ROWIMG + pl * S2_PL + i; };
+    auto d_at = [&](int buf, int p, int co, int i) { return ds + ((buf * NP + p) * CO_B + co) * S2_DP + i; };
+
+    // ---- loader side. Chunk k (2 .. 19) of a staged x row = input columns 2 x0 - 16 + 4k .. + 3 -> entries 2k, 2k + 1 of both planes
+    auto x_load = [&](int b, int x0, int row, float4 (&v)[XU]) {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int item = min(lt + 256 * u, CI_B * S2_KCH - 1);
+            const int ci = item / S2_KCH, k = item - ci * S2_KCH + 2;
+            const int px = 2 * x0 - 16 + 4 * k;
+            const int cic = min(cib * CI_B + ci, Cin - 1), rowc = min(max(row, 0), H - 1), pxc = min(max(px, 0), W - 4);
+            v[u] = *reinterpret_cast<const float4*>(x + ((size_t)b * Cin + cic) * plane + (size_t)rowc * W + pxc);
+        }
+    };
+    auto x_put = [&](int x0, int row, int slot, const float4 (&v)[XU]) {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int item = lt + 256 * u;
+            if (item < CI_B * S2_KCH) {
+                const int ci = item / S2_KCH, k = item - ci * S2_KCH + 2;
+                const int px = 2 * x0 - 16 + 4 * k;
+                const bool ok = cib * CI_B + ci < Cin && row >= 0 && row < H && px >= 0 && px < W;
+                const float4 t = ok ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                uint2 cells[NP];
+                split_cells4<AR>(t, xscale, cells);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    // half-words (v0, v1 | v2, v3): the even columns v0, v2 and the odd columns v1, v3
+                    *reinterpret_cast<unsigned*>(x_at(p, ci, slot, 0, 2 * k)) = (cells[p].x & 0xffffu) | (cells[p].y << 16);
+                    *reinterpret_cast<unsigned*>(x_at(p, ci, slot, 1, 2 * k)) = (cells[p].x >> 16) | (cells[p].y & 0xffff0000u);
+                }
+            }
+        }
+    };
+    auto d_load = [&](int b, int x0, int row, float4 (&v)[DU]) {
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int item = min(lt + 256 * u, CO_B * DCH - 1);
+            const int co = item / DCH, c = item - co * DCH;
+            v[u] = *reinterpret_cast<const float4*>(dy + ((size_t)b * Cout + cob * CO_B + co) * oplane + (size_t)min(row, Ho - 1) * Wo + x0 + 4 * c);
+        }
+    };
+    auto d_put = [&](int buf, const float4 (&v)[DU]) {
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int item = lt + 256 * u;
+            if (item < CO_B * DCH) {
+                const int co = item / DCH, c = item - co * DCH;
+                uint2 cells[NP];
+                split_cells4<AR>(v[u], dscale, cells);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(d_at(buf, p, co, 4 * c)) = cells[p];
+            }
+        }
+    };
+
+    // ---- consumer side. Step k of a unit (output row ya + k): the even input row sits in slot k & 1, the odd rows 2 oy - 1 and
+    // 2 oy + 1 in slots 2 + k % 3 and 2 + (k + 1) % 3. Hand-pipelined like version 2: the reads of filter row ky + 1 are issued
+    // before the MFMAs of ky.
+    struct XRaw { uint4 e[NP], o1[NP]; unsigned o0[NP]; };
+    auto load_x = [&](int slot, XRaw& r) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const unsigned short* src = x_at(p, wave * 16 + n, slot, 0, 8 * g);
+            r.e[p] = *reinterpret_cast<const uint4*>(src + 8);                    // even columns, ox = 8g .. 8g + 7
+            r.o1[p] = *reinterpret_cast<const uint4*>(src + S2_PL + 8);           // odd columns 2 ox + 1
+            r.o0[p] = *reinterpret_cast<const unsigned*>(src + S2_PL + 6);        // its left neighbour 2 (8g - 1) + 1 in the high half
+        }
+    };
+    auto compute = [&](int k, int m3, f32x4 (&acc)[9][3]) {
+        frag_t a[3][NP];
+        XRaw xr[2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) a[c][p] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(d_at(k & 1, p, c * 16 + n, 8 * g)));
+        const int s_odd0 = 2 + m3, s_odd1 = 2 + (m3 == 2 ? 0 : m3 + 1), s_even = k & 1;
+        load_x(s_odd0, xr[0]);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            if (ky < 2) {
+                load_x(ky == 0 ? s_even : s_odd1, xr[(ky + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            frag_t bfr[3][NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const uint4 o1 = xr[ky & 1].o1[p];
+                bfr[0][p] = __builtin_bit_cast(frag_t, make_uint4(__builtin_amdgcn_alignbit(o1.x, xr[ky & 1].o0[p], 16),
+                                                                  __builtin_amdgcn_alignbit(o1.y, o1.x, 16),
+                                                                  __builtin_amdgcn_alignbit(o1.z, o1.y, 16),
+                                                                  __builtin_amdgcn_alignbit(o1.w, o1.z, 16)));      // 2 ox - 1
+                bfr[1][p] = __builtin_bit_cast(frag_t, xr[ky & 1].e[p]);                                           // 2 ox
+                bfr[2][p] = __builtin_bit_cast(frag_t, o1);                                                        // 2 ox + 1
+            }
+#pragma unroll
+            for (int t = 0; t < AR::NTERMS; ++t)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        acc[ky * 3 + kx][c] = AR::mfma(a[c][AR::ta(t)], bfr[kx][AR::tb(t)], acc[ky * 3 + kx][c]);
+        }
+    };
+
+    auto unit_dims = [&](int unit, int& b, int& x0, int& ya, int& yb) {
+        int t = unit;
+        const int run = t % runs; t /= runs;
+        const int seg = t % segs;
+        b = t / segs;
+        x0 = seg * S2_SEG; ya = run * rpu; yb = min(ya + rpu, Ho);
+    };
+
+    if (loader) {
+        for (int unit = split; unit < n_units; unit += n_split) {
+            int b, x0, ya, yb;
+            unit_dims(unit, b, x0, ya, yb);
+            float4 ev[XU], ov[XU], dv[DU];
+            {   // prologue tick: even row 2 ya -> slot 0, odd rows 2 ya - 1, 2 ya + 1 -> slots 2, 3, dy row ya -> buffer 0
+                float4 o0v[XU];
+                x_load(b, x0, 2 * ya - 1, o0v);
+                x_load(b, x0, 2 * ya, ev);
+                x_load(b, x0, 2 * ya + 1, ov);
+                d_load(b, x0, ya, dv);
+                x_put(x0, 2 * ya - 1, 2, o0v);
+                x_put(x0, 2 * ya, 0, ev);
+                x_put(x0, 2 * ya + 1, 3, ov);
+                d_put(0, dv);
+            }
+            if (ya + 1 < yb) {
+                x_load(b, x0, 2 * ya + 2, ev);
+                x_load(b, x0, 2 * ya + 3, ov);
+                d_load(b, x0, ya + 1, dv);
+            }
+            __syncthreads();
+            int m3 = 0;                                // k % 3
+#pragma unroll 1
+            for (int row = ya; row < yb; ++row) {
+                const int k = row - ya;
+                if (row + 1 < yb) {
+                    x_put(x0, 2 * row + 2, (k + 1) & 1, ev);                       // even row of the next step
+                    x_put(x0, 2 * row + 3, 2 + (m3 == 0 ? 2 : m3 - 1), ov);        // odd row 2 (oy + 1) + 1 -> slot 2 + (k + 2) % 3
+                    d_put((k + 1) & 1, dv);
+                    if (row + 2 < yb) {
+                        x_load(b, x0, 2 * row + 4, ev);
+                        x_load(b, x0, 2 * row + 5, ov);
+                        d_load(b, x0, row + 2, dv);
+                    }
+                }
+                __syncthreads();
+                m3 = m3 == 2 ? 0 : m3 + 1;
+            }
+        }
+    } else {
+        f32x4 acc[9][3];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int unit = split; unit < n_units; unit += n_split) {
+            int b, x0, ya, yb;
+            unit_dims(unit, b, x0, ya, yb);
+            __syncthreads();
+            int m3 = 0;
+#pragma unroll 1
+            for (int row = ya; row < yb; ++row) {
+                if (tile_ok) compute(row - ya, m3, acc);
+                __syncthreads();
+                m3 = m3 == 2 ? 0 : m3 + 1;
+            }
+        }
+        if (tile_ok) {
+            const int ci = cib * CI_B + wave * 16 + n;
+            const float unscale = split_unscale_of(ex) * split_unscale_of(ed);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float* dst = partial + (((size_t)split * 9 + t) * Cout + cob * CO_B + c * 16 + 4 * g) * Cin + ci;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[(size_t)r * Cin] = acc[t][c][r] * unscale;
+                }
+        }
+    }
+}
+
+// rows per unit: the largest of 16 / 8 / 4 that still gives >= 256 blocks; number of pixel splits like sb_wrw_splits
+void s2_plan(int B, int Cin, int Cout, int Ho, int Wo, int& rpu, int& n_split) {
+    const int pairs = ((Cin + CI_B - 1) / CI_B) * (Cout / CO_B);
+    int want = (768 + pairs - 1) / pairs;
+    if (want > 256) want = 256;
+    rpu = 4;
+    const char* force = getenv("CSEG_S2_WRW_RPU");            // tests: run lengths the small emulated shapes would not reach
+    const int forced = force ? atoi(force) : 0;
+    for (int r = 16; r >= 4; r >>= 1) {
+        if (forced > 0) { rpu = forced; break; }
+        const long units = (long)B * (Wo / S2_SEG) * ((Ho + r - 1) / r);
+        if (units * pairs >= 256 || r == 4) { rpu = r; break; }
+    }
+    const long units = (long)B * (Wo / S2_SEG) * ((Ho + rpu - 1) / rpu);
+    n_split = (int)(want < units ? want : units);
+    if (n_split < 1) n_split = 1;
+}
+
+bool s2_shape_ok(int B, int Cin, int Cout, int Ho, int Wo) {
+    return B > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0 && Cin % 16 == 0 && Cout % CO_B == 0 && Wo % S2_SEG == 0;
+}
+
+}  // namespace
+
+// workspace (floats) of cseg_conv3x3_s2_split_wrw; 0 = unsupported shape (needs Cin % 16, Cout % 48, output width % 32)
+extern "C" size_t cseg_conv3x3_s2_wrw_ws_floats(int B, int Cin, int Cout, int Ho, int Wo) {
+    if (!s2_shape_ok(B, Cin, Cout, Ho, Wo)) return 0;
+    int rpu, n_split;
+    s2_plan(B, Cin, Cout, Ho, Wo, rpu, n_split);
+    return (size_t)n_split * 9 * Cin * Cout;
+}
+
+// Weight gradient of conv2d(x, w, stride 2, padding 1), 3x3: x [B, Cin, 2 Ho, 2 Wo], dy [B, Cout, Ho, Wo] -> dw [Cout, Cin, 3, 3].
+// arith must be CSEG_ARITH_F16X3 (amax_x / amax_dy: max|x| / max|dy| records). Deterministic (fixed-order reduction of the partials).
+extern "C" int cseg_conv3x3_s2_split_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int Ho, int Wo, int arith,
+                                         const unsigned* amax_x, const unsigned* amax_dy, float* ws, float* dw,
+                                         cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CSEG_REQUIRE(x && dy && ws && dw, "conv3x3_s2_wrw: null pointer");
+    CSEG_REQUIRE(s2_shape_ok(B, Cin, Cout, Ho, Wo), "conv3x3_s2_wrw: unsupported shape B=%d Cin=%d Cout=%d out %dx%d (needs Cin %% 16, Cout %% 48, Wo %% 32)",
+                 B, Cin, Cout, Ho, Wo);
+    CSEG_REQUIRE(arith == CSEG_ARITH_F16X3 && amax_x && amax_dy, "conv3x3_s2_wrw: f16x3 only (needs max|x| and max|dy|)");
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0,
+                 "conv3x3_s2_wrw: tensors must be 16-byte aligned");
+    CSEG_REQUIRE((long)9 * Cin * Cout < 2147483647L, "conv3x3_s2_wrw: too large");
+    int rpu, n_split;
+    s2_plan(B, Cin, Cout, Ho, Wo, rpu, n_split);
+    const size_t lds = sizeof(unsigned short) * (s2_x_elems(2) + s2_d_elems(2));
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)(conv3x3_sb_wrw_s2_kernel<SplitF16x3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            cseg_set_error("conv3x3_s2_wrw: cannot raise dynamic LDS to %zu bytes", lds);
+            return 0;
+        }
+        attr_set = true;
+    }
+    const int n_cob = Cout / CO_B, n_cib = (Cin + CI_B - 1) / CI_B;
+    int SC, SI;
+    sb_wrw_group(n_cob, n_cib, SC, SI);
+    const long n_groups = (long)n_split * (n_cob / SC) * (n_cib / SI);
+    const long blocks = ((n_groups + 7) / 8) * 8 * SC * SI;
+    CSEG_REQUIRE(blocks < 2147483647L, "conv3x3_s2_wrw: grid too large");
+    hipLaunchKernelGGL((conv3x3_sb_wrw_s2_kernel<SplitF16x3>), dim3((unsigned)blocks), dim3(512), lds, stream, x, dy, B, Cin, Cout, Ho, Wo,
+                       n_split, rpu, SC, SI, amax_x, amax_dy, ws);
+    CSEG_CHECK_LAUNCH("conv3x3_sb_wrw_s2_kernel");
+    const int total = 9 * Cin * Cout;
+    hipLaunchKernelGGL(sb_wrw_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, ws, n_split, Cout, Cin, dw);
+    CSEG_CHECK_LAUNCH("sb_wrw_reduce_kernel");
+    return 1;
+}
 
 extern "C" int cseg_conv3x3_sb_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, float* ws,
                                    float* dw, cseg_stream_t stream_) {

@@ -9,6 +9,7 @@
 #define CSEG_PACK_C3 0        // conv3x3_sb.hip: 32-channel chunks x 9 taps, 16-channel tail pairs two taps per K-step
 #define CSEG_PACK_C3_16 1     // conv3x3_sb16.hip: 16-channel chunks, every K-step pairs two taps
 #define CSEG_PACK_C1 2        // conv1x1_sb.hip: 32 input channels per K-step
+#define CSEG_PACK_C3_S2T 3    // conv3x3_s2.hip: backward-data operator of the stride-2 convolution (taps grouped by output parity)
 
 __host__ __device__ constexpr int pack_steps_c3(int Cin) { return (Cin / 32) * 9 + ((Cin & 31) ? 5 : 0); }
 __host__ __device__ constexpr int pack_steps_c3_16(int Cin) { return (Cin / 16) * 5; }
@@ -103,5 +104,37 @@ __device__ __forceinline__ void pack_elem_c1(const float* __restrict__ w, int Co
         if (ic < conv_in) t = transpose ? w[(size_t)ic * Cin + oc] : w[(size_t)oc * Cin + ic];
         v[j] = t;
     }
+    pack_store<AR>(v, wscale, wp, (size_t)(co_tile * n_steps + ks) * NT + nt, lane);
+}
+
+// Backward-data operator of the 3x3 / stride 2 / pad 1 convolution (conv3x3_s2.hip): dx[ci][2 qy + py][2 qx + px] sums, over the
+// output channels co and over the taps whose parity matches -- ky = 1 for py = 0, ky in {0, 2} for py = 1, same in x --
+// dy[co][qy + dyy][qx + dxx] * w[co][ci][ky][kx] with dyy = 1 for ky = 0 and 0 otherwise (likewise dxx). 16-channel chunks of co
+// like CSEG_PACK_C3_16, five K-steps per chunk, K-step q pairs two taps (lane groups g >> 1 = 0 / 1) of ONE parity class:
+//   q = 0: class (py, px) = (0, 0): tap (1, 1) | nothing (zeros)
+//   q = 1: class (0, 1): taps (1, 0) | (1, 2)
+//   q = 2: class (1, 0): taps (0, 1) | (2, 1)
+//   q = 3: class (1, 1): taps (0, 0) | (0, 2)
+//   q = 4: class (1, 1): taps (2, 0) | (2, 2)
+// value(oc = ci of the convolution, ic = co = 16*chunk + 8*(g&1) + j). w = the forward's [Cout, Cin, 3, 3].
+__host__ __device__ constexpr int pack_s2t_tap(int q, int second) {       // tap index ky*3 + kx, -1 = none
+    return q == 0 ? (second ? -1 : 4) : q == 1 ? (second ? 5 : 3) : q == 2 ? (second ? 7 : 1) : q == 3 ? (second ? 2 : 0) : (second ? 8 : 6);
+}
+template <class AR>
+__device__ __forceinline__ void pack_elem_c3_s2t(const float* __restrict__ w, int Cout, int Cin, int NT, float wscale,
+                                                 uint4* __restrict__ wp, int e) {
+    const int n_steps = pack_steps_c3_16(Cout);            // the operator's input channels are the convolution's output channels
+    int r = e;
+    const int lane = r & 63; r >>= 6;
+    const int nt = r % NT; r /= NT;
+    const int ks = r % n_steps;
+    const int co_tile = r / n_steps;
+    const int g = lane >> 4, n = lane & 15;
+    const int oc = (co_tile * NT + nt) * 16 + n;           // = ci of the convolution
+    const int chunk = ks / 5, q = ks - chunk * 5;
+    const int tap = pack_s2t_tap(q, g >> 1), ic0 = 16 * chunk + 8 * (g & 1);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tap >= 0 ? w[((size_t)(ic0 + j) * Cin + oc) * 9 + tap] : 0.f;
     pack_store<AR>(v, wscale, wp, (size_t)(co_tile * n_steps + ks) * NT + nt, lane);
 }

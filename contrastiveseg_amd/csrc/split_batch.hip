@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const cseg_split_job* _
     uint4* wp = static_cast<uint4*>(jb.dst);
     if (jb.kind == CSEG_PACK_C3) pack_elem_c3<AR>(w, jb.cout, jb.cin, jb.flag, jb.nt, wscale, wp, e);
     else if (jb.kind == CSEG_PACK_C3_16) pack_elem_c3_16<AR>(w, jb.cout, jb.cin, jb.flag, jb.nt, wscale, wp, e);
+    else if (jb.kind == CSEG_PACK_C3_S2T) pack_elem_c3_s2t<AR>(w, jb.cout, jb.cin, jb.nt, wscale, wp, e);
     else pack_elem_c1<AR>(w, jb.cout, jb.cin, jb.flag, jb.nt, wscale, wp, e);
 }
 

@@ -787,6 +787,11 @@ class SplitWeights(object):
         if tag == "c3":
             ok = lib.cseg_conv3x3_split_plan(conv_in, conv_out, int(nt_req), ctypes.byref(kind), ctypes.byref(nt), ctypes.byref(threads))
             n_bytes = lib.cseg_conv3x3_split_packed_bytes(arith, conv_in, conv_out)
+        elif tag == "c3s2":                              # stride 2: flag = backward-data operator, nt as requested
+            ok = arith == ARITH_IDS["f16x3"] and lib.cseg_conv3x3_s2_split_plan(conv_in, conv_out, int(bool(flag)), int(nt_req),
+                                                                                 ctypes.byref(kind), ctypes.byref(threads))
+            nt = ctypes.c_int(int(nt_req))
+            n_bytes = lib.cseg_conv3x3_s2_split_packed_bytes(conv_in, conv_out)
         else:
             ok = lib.cseg_conv1x1_split_plan(conv_in, conv_out, ctypes.byref(nt), ctypes.byref(threads))
             kind = ctypes.c_int(2)
@@ -1015,6 +1020,125 @@ class Conv3x3SplitBF16(Function):
 
 def conv3x3_split_bf16(x, weight, bias=None):
     return Conv3x3SplitBF16.apply(x, weight, bias)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# 3x3 / stride 2 / pad 1 on the split kernels (csrc/conv3x3_s2.hip, csrc/conv3x3_sb_wrw.hip): f16x3 only
+# ----------------------------------------------------------------------------------------------------------
+# HRNet's 52 downsampling convolutions (fuse + transition layers): on MIOpen 32 + 33 Winograd launches and ~50 NHWC implicit-GEMM
+# weight gradients with their layout transposes per step, ~15 ms of the 108 ms step (profiles/r03_step_steady_kernel_stats.csv).
+# Each direction is routed on its own (256 -> 96 has no 48-multiple on the input side: its backward-data stays on MIOpen).
+CONV3X3_S2_SPLIT = os.environ.get("CSEG_CONV3X3_S2_SPLIT", "1") == "1"
+
+
+def _s2_base_ok(x, weight):
+    return (CONV3X3_S2_SPLIT and SPLIT_ARITH == "f16x3" and _on_device(x) and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4
+            and tuple(weight.shape[2:]) == (3, 3) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
+
+
+def conv3x3_s2_fwd_eligible(x, weight):
+    co, ci = weight.shape[:2]
+    return _s2_base_ok(x, weight) and x.shape[1] == ci and ci % 16 == 0 and co % 48 == 0 and x.shape[3] % 8 == 0
+
+
+def conv3x3_s2_bwd_eligible(x, weight):
+    co, ci = weight.shape[:2]
+    return _s2_base_ok(x, weight) and co % 16 == 0 and ci % 48 == 0 and x.shape[3] % 4 == 0
+
+
+def conv3x3_s2_wrw_eligible(x, weight):
+    co, ci = weight.shape[:2]
+    return _s2_base_ok(x, weight) and ci % 16 == 0 and co % 48 == 0 and x.shape[3] % 64 == 0
+
+
+def conv3x3_s2_pick_nt(B, Ho, Wo, c_out):
+    """16-channel tiles per block: 6 when the grid still has >= 256 blocks of 4 x 64 outputs, else 3."""
+    spatial = B * ((Ho + 3) // 4) * ((Wo + 63) // 64)
+    return 6 if c_out % 96 == 0 and spatial * (c_out // 96) >= 256 else 3
+
+
+@torch.no_grad()
+def conv3x3_s2_run(x, weight, ax=None):
+    """y = conv2d(x, weight, None, stride 2, padding 1)."""
+    co, ci = weight.shape[:2]
+    B, _, H, W = x.shape
+    Ho, Wo = H // 2, W // 2
+    nt = conv3x3_s2_pick_nt(B, Ho, Wo, co)
+    wp, aw = SPLIT_WEIGHTS.get(weight, "c3s2", False, nt)
+    ax = tensor_amax(x) if ax is None else ax
+    y = torch.empty(B, co, Ho, Wo, dtype=F32, device=x.device)
+    _hip.call("cseg_conv3x3_s2_split_fwd", _p(x, F32, "x"), wp.data_ptr(), B, ci, co, Ho, Wo, nt, _pf(ax), _pf(aw), _pf(y),
+              _hip.stream_ptr())
+    return y
+
+
+@torch.no_grad()
+def conv3x3_s2_bwd_run(dy, weight, ady=None):
+    """dx of that convolution for the output gradient dy [B, Cout, Ho, Wo] -> [B, Cin, 2 Ho, 2 Wo]."""
+    co, ci = weight.shape[:2]
+    B, _, Ho, Wo = dy.shape
+    nt = conv3x3_s2_pick_nt(B, Ho, Wo, ci)
+    wp, aw = SPLIT_WEIGHTS.get(weight, "c3s2", True, nt)
+    ady = tensor_amax(dy) if ady is None else ady
+    dx = torch.empty(B, ci, 2 * Ho, 2 * Wo, dtype=F32, device=dy.device)
+    _hip.call("cseg_conv3x3_s2_split_bwd", _p(dy, F32, "dy"), wp.data_ptr(), B, ci, co, Ho, Wo, nt, _pf(ady), _pf(aw), _pf(dx),
+              _hip.stream_ptr())
+    return dx
+
+
+@torch.no_grad()
+def conv3x3_s2_wrw(x, dy, ax=None, ady=None):
+    """dw [Cout, Cin, 3, 3] of that convolution."""
+    B, ci, H, W = x.shape
+    co, Ho, Wo = dy.shape[1:]
+    n = _hip.lib().cseg_conv3x3_s2_wrw_ws_floats(B, ci, co, Ho, Wo)
+    if n == 0 or (H, W) != (2 * Ho, 2 * Wo):
+        raise RuntimeError("conv3x3_s2_wrw: unsupported shape %s x %s" % (tuple(x.shape), tuple(dy.shape)))
+    ax = tensor_amax(x) if ax is None else ax
+    ady = tensor_amax(dy) if ady is None else ady
+    ws = torch.empty(n, dtype=F32, device=x.device)
+    dw = torch.empty(co, ci, 3, 3, dtype=F32, device=x.device)
+    _hip.call("cseg_conv3x3_s2_split_wrw", _p(x, F32, "x"), _p(dy, F32, "dy"), B, ci, co, Ho, Wo, split_arith_id(), _pf(ax), _pf(ady),
+              _pf(ws), _pf(dw), _hip.stream_ptr())
+    return dw
+
+
+class Conv3x3S2Split(Function):
+    """y = conv2d(x, weight, None, stride 2, padding 1) with every direction the split kernels cover on them and the others on
+    MIOpen (aten)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        weight = weight.contiguous()
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.ax = amax_of(x)                              # reused by the weight gradient
+        if conv3x3_s2_fwd_eligible(x, weight):
+            return conv3x3_s2_run(x, weight, ax=ctx.ax)
+        return torch.nn.functional.conv2d(x, weight, None, 2, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        co, ci = weight.shape[:2]
+        ady = amax_of(dy)
+        dy = dy.contiguous()
+        need_dx, need_dw = bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1])
+        dx = dw = None
+        if need_dx and conv3x3_s2_bwd_eligible(x, weight):
+            dx = conv3x3_s2_bwd_run(dy, weight, ady=ady)
+        if need_dw and conv3x3_s2_wrw_eligible(x, weight):
+            dw = conv3x3_s2_wrw(x, dy, ax=ctx.ax, ady=ady)
+        rest = [need_dx and dx is None, need_dw and dw is None, False]
+        if rest[0] or rest[1]:
+            gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, rest)
+            dx = gx if rest[0] else dx
+            dw = gw if rest[1] else dw
+        return dx, dw
+
+
+def conv3x3_s2_split(x, weight):
+    return Conv3x3S2Split.apply(x, weight)
 
 
 # ----------------------------------------------------------------------------------------------------------

@@ -36,6 +36,10 @@ class Conv3x3(nn.Conv2d):
                 return K.conv3x3_split_bf16(x, self.weight)
             if self.in_channels in self.MFMA_CHANNELS and K.conv3x3_eligible(x, self.weight):
                 return K.conv3x3(x, self.weight)
+        if (K._on_device(x) and self.stride == (2, 2) and self.dilation == (1, 1)
+                and (K.conv3x3_s2_fwd_eligible(x, self.weight) or K.conv3x3_s2_wrw_eligible(x, self.weight))):
+            # downsampling convolutions of the fuse / transition layers: csrc/conv3x3_s2.hip + the stride-2 weight gradient
+            return K.conv3x3_s2_split(x, self.weight)
         return super(Conv3x3, self).forward(x)
 
 

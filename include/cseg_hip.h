@@ -333,12 +333,33 @@ int cseg_conv3x3_split_fwd(const float* x, const void* wp, const float* bias, in
 /* ws: cseg_conv3x3_sb_wrw_ws_floats(...) */
 int cseg_conv3x3_split_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, int arith,
                            const unsigned* amax_x, const unsigned* amax_dy, float* ws, float* dw, cseg_stream_t stream);
+/* ---- stride 2 (round 3): the 3x3 / stride 2 / pad 1 convolutions of HRNet's fuse and transition layers (reference:
+ * lib/models/backbones/hrnet/hrnet_backbone.py:230-250 fuse layers, :652-660 transition layers -- nn.Conv2d(.., 3, 2, 1, bias=False)),
+ * f16x3 arithmetic only. x is [B, Cin, 2 Ho, 2 Wo], y / dy are [B, Cout, Ho, Wo].
+ *   forward:        cseg_conv3x3_s2_split_fwd, weights packed by cseg_conv3x3_s2_split_pack(transposed = 0) (format CSEG_PACK_C3_16);
+ *   backward-data:  cseg_conv3x3_s2_split_bwd, weights packed with transposed = 1 (format CSEG_PACK_C3_S2T): dx [B, Cin, 2 Ho, 2 Wo];
+ *   weight gradient: cseg_conv3x3_s2_split_wrw (ws: cseg_conv3x3_s2_wrw_ws_floats floats), deterministic.
+ * nt = 16-channel tiles of the OUTPUT of the packed operator per block (3 or 6; must divide its channel count / 16; the same value for
+ * pack and run). Shapes: input channels of the operator % 16, output channels % 48, Wo % 32 for the weight gradient; 0 / error
+ * otherwise. Replaces miopenSp3AsmConv_*_stride2 / _dilation2 and the NHWC implicit-GEMM weight gradient with its layout transposes. */
+size_t cseg_conv3x3_s2_split_packed_bytes(int conv_in, int conv_out);
+int cseg_conv3x3_s2_split_plan(int conv_in, int conv_out, int transposed, int nt, int* kind, long* threads);
+int cseg_conv3x3_s2_split_pack(const float* w, int Cout, int Cin, int transposed, int nt, const unsigned* amax_w, void* wp,
+                               cseg_stream_t stream);
+int cseg_conv3x3_s2_split_fwd(const float* x, const void* wp, int B, int Cin, int Cout, int Ho, int Wo, int nt,
+                              const unsigned* amax_x, const unsigned* amax_w, float* y, cseg_stream_t stream);
+int cseg_conv3x3_s2_split_bwd(const float* dy, const void* wp, int B, int Cin, int Cout, int Ho, int Wo, int nt,
+                              const unsigned* amax_dy, const unsigned* amax_w, float* dx, cseg_stream_t stream);
+size_t cseg_conv3x3_s2_wrw_ws_floats(int B, int Cin, int Cout, int Ho, int Wo);
+int cseg_conv3x3_s2_split_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int Ho, int Wo, int arith,
+                              const unsigned* amax_x, const unsigned* amax_dy, float* ws, float* dw, cseg_stream_t stream);
 /* plan of one pack call, for callers that batch many of them (cseg_split_pack_batch below): kind = CSEG_PACK_* (which packed
  * format the library uses for these channel counts), nt = effective channel tiles per block, threads = one per packed uint4
  * group; conv_in / conv_out are the channel counts of the PACKED operator; returns 0 when the shape is not covered. */
 #define CSEG_PACK_C3 0
 #define CSEG_PACK_C3_16 1
 #define CSEG_PACK_C1 2
+#define CSEG_PACK_C3_S2T 3   /* backward-data operator of the stride-2 convolution, see cseg_pack.h */
 int cseg_conv3x3_split_plan(int conv_in, int conv_out, int nt_request, int* kind, int* nt, long* threads);
 int cseg_conv1x1_split_plan(int conv_in, int conv_out, int* nt, long* threads);
 /* Batched form: jobs_dev = DEVICE array of n_jobs records sorted by block0 (block0 of job 0 = 0; job i owns blocks

@@ -20,7 +20,8 @@ def lib():
             pytest.skip(str(e))
         _LIB = ctypes.CDLL(path)
         for name in ("cseg_conv3x3_sb_packed_bytes", "cseg_conv1x1_sb_packed_bytes", "cseg_conv3x3_sb_wrw_ws_floats",
-                     "cseg_conv1x1_sb_wrw_ws_floats", "cseg_conv3x3_split_packed_bytes", "cseg_conv1x1_split_packed_bytes"):
+                     "cseg_conv1x1_sb_wrw_ws_floats", "cseg_conv3x3_split_packed_bytes", "cseg_conv1x1_split_packed_bytes",
+                     "cseg_conv3x3_s2_split_packed_bytes", "cseg_conv3x3_s2_wrw_ws_floats"):
             getattr(_LIB, name).restype = ctypes.c_size_t
         _LIB.cseg_last_error.restype = ctypes.c_char_p
     return _LIB
@@ -170,6 +171,67 @@ def conv1x1_sb_wrw(x, dy, arith=None):
         return dw
     call("cseg_conv1x1_sb_wrw", ptr(dev(x)), ptr(dev(dy)), B, ci, co, H * W, ptr(ws), ptr(dw), None)
     return dw
+
+
+# ---- 3x3 / stride 2 / pad 1 (f16x3 only): x [B, ci, 2 Ho, 2 Wo], y / dy [B, co, Ho, Wo]
+def _s2_pack(w, transposed, nt):
+    co, ci = w.shape[:2]
+    conv_in, conv_out = (co, ci) if transposed else (ci, co)
+    n = lib().cseg_conv3x3_s2_split_packed_bytes(conv_in, conv_out)
+    assert n > 0
+    wp = aligned((n,), np.uint8, 0xFF)
+    aw = amax(w)
+    call("cseg_conv3x3_s2_split_pack", ptr(dev(w)), co, ci, int(transposed), nt, ptr(aw), ptr(wp), None)
+    return wp, aw
+
+
+def conv3x3_s2(x, w, nt=3):
+    co, ci = w.shape[:2]
+    B, _, H, W = x.shape
+    Ho, Wo = H // 2, W // 2
+    wp, aw = _s2_pack(w, False, nt)
+    y = aligned((B, co, Ho, Wo))
+    call("cseg_conv3x3_s2_split_fwd", ptr(dev(x)), ptr(wp), B, ci, co, Ho, Wo, nt, ptr(amax(x)), ptr(aw), ptr(y), None)
+    return y
+
+
+def conv3x3_s2_bwd(dy, w, nt=3):
+    co, ci = w.shape[:2]
+    B, _, Ho, Wo = dy.shape
+    wp, aw = _s2_pack(w, True, nt)
+    dx = aligned((B, ci, 2 * Ho, 2 * Wo))
+    call("cseg_conv3x3_s2_split_bwd", ptr(dev(dy)), ptr(wp), B, ci, co, Ho, Wo, nt, ptr(amax(dy)), ptr(aw), ptr(dx), None)
+    return dx
+
+
+def conv3x3_s2_wrw(x, dy):
+    B, ci, H, W = x.shape
+    co, Ho, Wo = dy.shape[1:]
+    assert (H, W) == (2 * Ho, 2 * Wo)
+    n = lib().cseg_conv3x3_s2_wrw_ws_floats(B, ci, co, Ho, Wo)
+    assert n > 0
+    ws, dw = aligned((n,)), aligned((co, ci, 3, 3))
+    call("cseg_conv3x3_s2_split_wrw", ptr(dev(x)), ptr(dev(dy)), B, ci, co, Ho, Wo, F16X3, ptr(amax(x)), ptr(amax(dy)), ptr(ws), ptr(dw),
+         None)
+    return dw
+
+
+def ref_conv3x3_s2(x, w):
+    return ref_conv3x3(x, w)[:, :, ::2, ::2]
+
+
+def ref_conv3x3_s2_bwd_data(dy, w):
+    B, co, Ho, Wo = dy.shape
+    up = np.zeros((B, co, 2 * Ho, 2 * Wo))
+    up[:, :, ::2, ::2] = dy
+    return ref_conv3x3_bwd_data(up, w)
+
+
+def ref_conv3x3_s2_wrw(x, dy):
+    B, co, Ho, Wo = dy.shape
+    up = np.zeros((B, co, 2 * Ho, 2 * Wo))
+    up[:, :, ::2, ::2] = dy
+    return ref_conv3x3_wrw(x, up)
 
 
 # ---- float64 references ------------------------------------------------------------------------------------------------

@@ -186,6 +186,20 @@ def test_sb_pointwise_autograd_matches_fp64(kw, wrw, monkeypatch):
     _replay_sb(monkeypatch, "test_pointwise_matches_fp64", kw)
 
 
+# ---- stride-2 convolutions: the module-level GPU test of tests/test_gpu_conv3x3_s2.py on the emulated device -----------------------
+S2_MOD = _cases("test_gpu_conv3x3_s2", "test_stride2_module_matches_fp64", lambda kw: kw["case"][1] * kw["case"][2] <= 96 * 192)
+
+
+@pytest.mark.parametrize("kw", S2_MOD, ids=_ids(S2_MOD))
+def test_stride2_module_matches_fp64(kw, monkeypatch):
+    """Conv3x3(cin, cout, 2) end to end: SplitWeights' batched packs in both stride-2 formats, the three kernels, the routing."""
+    inject.install(monkeypatch)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)
+    mod = importlib.import_module("test_gpu_conv3x3_s2")
+    mod.test_stride2_module_matches_fp64(monkeypatch=monkeypatch, **kw)
+
+
 # ---- row-sparse projection-head backward with the PRODUCT's deposit path (kernels.PixelContrast / GatherAnchors) ---------
 @pytest.mark.parametrize("loss_type", ["contrast_ce_loss", "mem_contrast_ce_loss"])
 def test_sparse_embed_route_equals_dense_route(loss_type, monkeypatch):

@@ -280,3 +280,47 @@ def test_persistent_small_channel_convolution(case, what, monkeypatch):
     monkeypatch.setenv("CSEG_CONV3X3_SB16_P", "0")                 # the one-tile kernel on the same operands: same arithmetic
     y1 = E.conv3x3_sb(x, w, b, arith=E.F16X3)
     assert np.array_equal(y, y1), "persistent and one-tile kernels accumulate in the same order: bit-identical results"
+
+
+# ---- 3x3 / stride 2 / pad 1 (csrc/conv3x3_s2.hip and the stride-2 weight gradient of conv3x3_sb_wrw.hip), f16x3 -----------------
+S2_FWD_CASES = [  # B, Cin, Cout, Ho, Wo, nt
+    (1, 48, 48, 5, 32, 3),       # ragged row tile, half a column tile
+    (2, 32, 96, 3, 68, 6),       # two column tiles, the second ragged; six channel tiles per block
+    (1, 16, 96, 9, 132, 3),      # one chunk, three row tiles, two channel tile groups
+]
+
+
+@pytest.mark.parametrize("case", S2_FWD_CASES)
+def test_stride2_forward(case, wave_order):
+    B, ci, co, Ho, Wo, nt = case
+    x, w = _rand((B, ci, 2 * Ho, 2 * Wo), 71, 3.0), _rand((co, ci, 3, 3), 72, 0.1)
+    y = E.conv3x3_s2(x, w, nt)
+    ref = E.ref_conv3x3_s2(x, w)
+    assert not np.isnan(y).any()
+    assert np.abs(y - ref).max() <= _bound(ref, 9 * ci)
+
+
+@pytest.mark.parametrize("case", [(1, 48, 48, 5, 32, 3), (2, 96, 32, 3, 66, 6), (1, 96, 16, 9, 130, 3)])
+def test_stride2_backward_data(case, wave_order):
+    """every pixel of dx is written exactly once (NaN-filled output buffer), all four parity classes, ragged quad tiles"""
+    B, ci, co, Ho, Wo, nt = case
+    dy, w = _rand((B, co, Ho, Wo), 73, 1e-3), _rand((co, ci, 3, 3), 74, 0.1)
+    dx = E.conv3x3_s2_bwd(dy, w, nt)
+    ref = E.ref_conv3x3_s2_bwd_data(dy, w)
+    assert not np.isnan(dx).any()
+    assert np.abs(dx - ref).max() <= 3e-6 * np.sqrt(4 * co) * float(np.abs(ref).max())
+
+
+@pytest.mark.parametrize("case", [(1, 48, 48, 5, 32), (2, 80, 96, 3, 64), (1, 16, 48, 18, 32), (1, 192, 96, 2, 32)])
+@pytest.mark.parametrize("rpu", ["4", "16"])
+def test_stride2_weight_gradient(case, rpu, wave_order, monkeypatch):
+    """runs of 4 / 16 rows (the benched shapes use 16 / 8), ragged channel block (80 = 64 + 16), several channel blocks each
+    way, wrap-around of the odd-row ring"""
+    monkeypatch.setenv("CSEG_S2_WRW_RPU", rpu)
+    B, ci, co, Ho, Wo = case
+    x, dy = _rand((B, ci, 2 * Ho, 2 * Wo), 75, 7.0), _rand((B, co, Ho, Wo), 76, 1e-4)
+    dw = E.conv3x3_s2_wrw(x, dy)
+    ref = E.ref_conv3x3_s2_wrw(x, dy)
+    assert not np.isnan(dw).any()
+    assert np.abs(dw - ref).max() <= 3e-6 * np.sqrt(B * Ho * Wo) * float(np.abs(ref).max())
+    assert np.array_equal(dw, E.conv3x3_s2_wrw(x, dy))          # fixed-order reduction: bit-identical on a second run
