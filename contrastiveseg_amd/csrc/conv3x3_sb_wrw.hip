@@ -409,6 +409,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const uint4 c0 = xr[grp & 1].c0[p], c1 = xr[grp & 1].c1[p];
+                CSEG_KEEP_DWORD(c0.x);                     // whole cells: two ds_read_b128
+                CSEG_KEEP_DWORD(c1.w);
                 const unsigned a21 = __builtin_amdgcn_alignbit(c0.z, c0.y, 16), a32 = __builtin_amdgcn_alignbit(c0.w, c0.z, 16),
                                a43 = __builtin_amdgcn_alignbit(c1.x, c0.w, 16), a54 = __builtin_amdgcn_alignbit(c1.y, c1.x, 16),
                                a65 = __builtin_amdgcn_alignbit(c1.z, c1.y, 16);

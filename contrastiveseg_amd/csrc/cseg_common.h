@@ -21,6 +21,14 @@
     } while (0)
 #endif
 
+// "This 32-bit value is used here": keeps the compiler from narrowing a 16-byte LDS read whose outer dwords the arithmetic does
+// not need into ds_read2_b64 / ds_read2_b32 pairs -- those have a different bank pattern than the ds_read_b128 the LDS pitches
+// were chosen for (weight gradient: half the banks idle, SQ_LDS_BANK_CONFLICT = 55 % of SQ_LDS_IDX_ACTIVE). No instruction is
+// emitted. (tests/emu defines it as a no-op.)
+#ifndef CSEG_KEEP_DWORD
+#define CSEG_KEEP_DWORD(v) asm volatile("" ::"v"(v))
+#endif
+
 void cseg_set_error(const char* fmt, ...);
 
 // reference convention: 1 = ok, 0 = error (lib/extensions/cc_attention/src/ca.cu:199-204)

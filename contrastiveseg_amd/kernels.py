@@ -1032,7 +1032,8 @@ CONV3X3_S2_SPLIT = os.environ.get("CSEG_CONV3X3_S2_SPLIT", "1") == "1"
 
 
 def _s2_base_ok(x, weight):
-    return (CONV3X3_S2_SPLIT and SPLIT_ARITH == "f16x3" and _on_device(x) and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4
+    # CONV3X3_SPLIT_BF16 off = the strict fp32 configuration (bench.py --conv-arith fp32): nothing on the 16-bit matrix pipes
+    return (CONV3X3_S2_SPLIT and CONV3X3_SPLIT_BF16 and SPLIT_ARITH == "f16x3" and _on_device(x) and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4
             and tuple(weight.shape[2:]) == (3, 3) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
 
 

@@ -143,6 +143,7 @@ static inline unsigned emu_alignbit(unsigned hi, unsigned lo, unsigned shift) {
     return (unsigned)((((uint64_t)hi << 32) | lo) >> (shift & 31));
 }
 #define __builtin_amdgcn_alignbit emu_alignbit
+#define CSEG_KEEP_DWORD(v) ((void)(v))
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)      // instruction-scheduling fence: nothing to emulate
 
 // global_load_lds: the LDS operand is the wave-uniform base, every lane lands at base + lane * size

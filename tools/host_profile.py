@@ -1,0 +1,41 @@
+"""Host-side cost of one train step of the benched configuration: cProfile over 3 steady steps (the GPU runs asynchronously; what
+is measured is Python + launch time on the enqueueing threads), top functions by own time and by cumulative time. Optional arg:
+global batch (default 8; 1 = the per-GPU batch of the 8-GPU strong-scaling point)."""
+import cProfile
+import io
+import os
+import pstats
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+import torch
+
+import bench
+
+gb = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+sys.argv = [sys.argv[0]]
+args = bench.parse()
+dev = torch.device("cuda:0")
+tr, cfg, batch = bench.build_trainer(args, 1, dev, gb)
+for _ in range(4):
+    tr.train_step(batch)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3):
+    tr.train_step(batch)
+t_enq = (time.perf_counter() - t0) / 3
+torch.cuda.synchronize()
+t_all = (time.perf_counter() - t0) / 3
+print("global batch %d: host enqueue %.1f ms/step, with final sync %.1f ms/step" % (gb, 1e3 * t_enq, 1e3 * t_all))
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(3):
+    tr.train_step(batch)
+pr.disable()
+torch.cuda.synchronize()
+for key in ("tottime", "cumtime"):
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(45)
+    print("\n".join(l[:190] for l in s.getvalue().splitlines()[:70]))
