@@ -125,17 +125,28 @@ def _check(ok, what):
         raise RuntimeError("%s failed: %s" % (what, lib().cseg_last_error().decode()))
 
 
+_raw_device = torch._C._cuda_getDevice
+_raw_stream = torch._C._cuda_getCurrentRawStream
+
+
+def raw_stream():
+    """Current HIP stream of the current device as an integer (key of per-stream scratch buffers)."""
+    return _raw_stream(_raw_device())
+
+
 def stream_ptr():
     """The current HIP stream of the CURRENT device: `dev()` below insists that every tensor lives on that device, so
     kernel, stream and pointers always agree."""
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw accessors: torch.cuda.current_stream() builds a Stream object and goes through three Python layers (7.7 us per call,
+    # ~1000 calls per step: 7 ms of the host's 79 ms per step at batch 8, tools/host_profile.py)
+    return ctypes.c_void_p(_raw_stream(_raw_device()))
 
 
 def dev(t, dtype, what):
     """Validates a tensor that is about to be handed to the kernels as a raw pointer."""
     if not t.is_cuda:
         raise RuntimeError("%s must live on the GPU (got %s): libcseg_hip has no CPU path" % (what, t.device))
-    if t.device.index != torch.cuda.current_device():
+    if t.device.index != _raw_device():
         raise RuntimeError("%s lives on %s but the current device is cuda:%d: call torch.cuda.set_device(local_rank) "
                            "(one process per GPU) or wrap the call in torch.cuda.device(tensor.device)"
                            % (what, t.device, torch.cuda.current_device()))

@@ -547,17 +547,43 @@ int sb_wrw_version() {
 int wrw2_seg(int W) { return W % 64 == 0 ? 64 : 32; }
 int wrw2_rpu(int H) { return H >= 32 ? 16 : 8; }      // 8-row runs at 32 rows cost the 192-channel maps 52 -> 62 us (more splits, more partials)
 
+void sb_wrw_group(int n_cob, int n_cib, int& SC, int& SI);
+
+// Number of pixel splits. Version 1: ~3 blocks per CU in total. Version 2 (round 3): the blocks of a split run group by group on the
+// XCDs (conv3x3_sb_wrw2_kernel), block b on XCD b % 8, so what counts is how many ROUNDS of 32 CUs the busiest XCD needs times the
+// units a block walks per round, plus the cost of writing and re-reading one more set of partials. At 720 channels (30-block
+// groups, 6 per split, 256 units): 5 splits = 30 groups = 4 rounds x 52 units, 4 splits = 24 groups = 3 rounds x 64 units (-8 %).
 int sb_wrw_splits(int B, int Cin, int Cout, int H, int W, int arith) {
     const bool v2 = arith == CSEG_ARITH_F16X3 || sb_wrw_version() == 2;
     const int rpu = v2 ? wrw2_rpu(H) : ROWS_PER_UNIT;
     const int seg = v2 ? wrw2_seg(W) : SEG;
     const int units = B * (W / seg) * ((H + rpu - 1) / rpu);
-    const int pairs = ((Cin + CI_B - 1) / CI_B) * (Cout / CO_B);
-    int n = (768 + pairs - 1) / pairs;               // ~3 blocks per CU in total
-    if (n > 256) n = 256;                            // bounds the partial buffer (256 x 9 x Cout x Cin floats)
-    if (n > units) n = units;
-    if (n < 1) n = 1;
-    return n;
+    const int n_cib = (Cin + CI_B - 1) / CI_B, n_cob = Cout / CO_B;
+    const int pairs = n_cib * n_cob;
+    if (!v2) {
+        int n = (768 + pairs - 1) / pairs;
+        if (n > 256) n = 256;                        // bounds the partial buffer (256 x 9 x Cout x Cin floats)
+        if (n > units) n = units;
+        return n < 1 ? 1 : n;
+    }
+    int SC, SI;
+    sb_wrw_group(n_cob, n_cib, SC, SI);
+    const int gsz = SC * SI, groups_per_split = (n_cob / SC) * (n_cib / SI);
+    const double unit_us = rpu * (seg / 32) * 1.15;                                  // ~1.15 us per K-step row (measured: 2.3 us per 64-pixel row-step)
+    const double split_us = 2.0 * 9.0 * Cin * Cout * sizeof(float) / 4.0e6;          // partials written + read back at ~4 TB/s
+    const char* force = getenv("CSEG_SB_WRW_SPLITS");                                // tuning runs (tools/wrw_split_probe.py)
+    if (force && atoi(force) > 0) return atoi(force) < units ? atoi(force) : units;
+    auto cost_of = [&](int n) {
+        const long per_xcd = ((long)n * groups_per_split + 7) / 8 * gsz;             // blocks of the busiest XCD
+        const long rounds = (per_xcd + 31) / 32;
+        return rounds * ((double)((units + n - 1) / n) * unit_us + 5.0) + n * split_us;   // 5 us per block: prologue + partial write
+    };
+    const int n_max = units < 256 ? units : 256;
+    double best_cost = 1e30;
+    for (int n = 1; n <= n_max; ++n) best_cost = cost_of(n) < best_cost ? cost_of(n) : best_cost;
+    for (int n = 1; n <= n_max; ++n)
+        if (cost_of(n) <= 1.03 * best_cost) return n;                                // near-ties: the fewest partials
+    return n_max;
 }
 
 }  // namespace

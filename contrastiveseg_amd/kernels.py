@@ -489,7 +489,7 @@ def _bn_ws(B, C, HW, device):
     reads it, so one buffer per (device, stream) serves all layers (saves two allocator round trips per BN call: the
     step issues ~600 of them and is host-bound at small per-GPU batches)."""
     need = max(1, _hip.lib().cseg_bn_ws_floats(B, C, HW))
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else (-1, 0)
+    key = (device.index, _hip.raw_stream()) if device.type == "cuda" else (-1, 0)     # callers run on the current device (_hip.dev)
     buf = _BN_WS.get(key)
     if buf is None or buf.numel() < need:
         buf = torch.empty(max(need, 1 << 16), dtype=F32, device=device)
