@@ -264,7 +264,8 @@ template <int NP, int SEGW>
 __device__ __forceinline__ int d2_idx(int buf, int p, int co, int i) { return ((buf * NP + p) * CO_B + co) * d2_pitch(NP, SEGW) + i; }
 
 // ABL != 0: ABLATION builds for timing experiments only (results are wrong): bit 0 = the consumers skip their MFMAs, bit 1 = the
-// loaders store truncated bits instead of splitting (no conversion arithmetic), bit 2 = the loaders skip the global loads.
+// loaders store truncated bits instead of splitting (no conversion arithmetic), bit 2 = the loaders skip the global loads, bit 3 =
+// the loaders do not stage anything after a unit's prologue (consumer-only time).
 // Reached with CSEG_ABLATE=<bits> (tools/ablate_probe.py); never set in the product.
 template <class AR, int SEGW, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -309,27 +310,63 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
     const int n_units = B * segs * runs;
     const bool tile_ok = !loader && cib * CI_B + wave * 16 < Cin;
 
-    // ---- loader side. x row: 64 ci x 18 chunks of 4 entries (entry i = pixel x0 - 4 + i); dy row: 48 co x 16 chunks
-    auto x_load = [&](int b, int x0, int row, float4 (&v)[XU]) {
+    // ---- loader side. x row: 64 ci x 18 chunks of 4 entries (entry i = pixel x0 - 4 + i); dy row: 48 co x 16 chunks.
+    // Round 3: everything about a staging item that does not change from row to row is computed ONCE (per kernel: which channel
+    // and chunk, its LDS offset; per unit: its byte offset inside the image and whether its columns exist), and the fetch is a
+    // buffer load with the row as SCALAR offset -- the per-row cost of an item is the load, a select and the split. (The first
+    // version recomputed item / 18, three clamps and a 64-bit address per item and row: ~400 VALU instructions per row-step on
+    // the SIMDs that issue the consumers' MFMAs; with all loads removed the kernel ran 22 % faster, tools/ablate_probe.py.)
+    int xi_lds[XU], xi_px[XU], xi_ch[XU];          // LDS half-word offset (piece 0, slot 0); pixel offset from x0; channel (clamped)
+    bool xi_ok[XU];
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+        const int item = lt + 256 * u, itc = min(max(item, 0), CI_B * XCH - 1);
+        const int ci = itc / XCH, c = itc - ci * XCH;
+        xi_lds[u] = x2_idx<NP, SEGW>(0, ci, 0, 4 * c);
+        xi_px[u] = 4 * c - 4;
+        xi_ch[u] = min(cib * CI_B + ci, Cin - 1);
+        xi_ok[u] = loader && item < CI_B * XCH && cib * CI_B + ci < Cin;
+    }
+    int di_lds[DU], di_off[DU];                    // LDS offset (buffer 0, piece 0); element offset of (co, chunk) inside the image
+    bool di_ok[DU];
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+        const int item = lt + 256 * u, itc = min(max(item, 0), CO_B * DCH - 1);
+        const int co = itc / DCH, c = itc - co * DCH;
+        di_lds[u] = d2_idx<NP, SEGW>(0, 0, co, 4 * c);
+        di_off[u] = (cob * CO_B + co) * (int)plane + 4 * c;
+        di_ok[u] = loader && item < CO_B * DCH;
+    }
+    // per unit (set by unit_setup): buffer resources of the image, byte offsets of the items, column validity
+    __amdgpu_buffer_rsrc_t x_rs, d_rs;
+    int xu_off[XU], du_off[DU];
+    bool xu_ok[XU];
+    auto unit_setup = [&](int b, int x0) {
+        x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * Cin * plane), 0, (int)(Cin * plane * sizeof(float)), 0x00020000);
+        d_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (size_t)b * Cout * plane), 0, (int)(Cout * plane * sizeof(float)), 0x00020000);
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const int item = min(lt + 256 * u, CI_B * XCH - 1);
-            const int ci = item / XCH, c = item - ci * XCH;
-            const int px = x0 - 4 + 4 * c;
-            const int cic = min(cib * CI_B + ci, Cin - 1), rowc = min(max(row, 0), H - 1), pxc = min(max(px, 0), W - 4);
+            const int px = x0 + xi_px[u];
+            xu_off[u] = (xi_ch[u] * (int)plane + min(max(px, 0), W - 4)) * (int)sizeof(float);
+            xu_ok[u] = xi_ok[u] && px >= 0 && px < W;
+        }
+#pragma unroll
+        for (int u = 0; u < DU; ++u) du_off[u] = (di_off[u] + x0) * (int)sizeof(float);
+    };
+    auto x_load = [&](int row, float4 (&v)[XU]) __attribute__((always_inline)) {
+        const int soff = min(max(row, 0), H - 1) * W * (int)sizeof(float);       // uniform
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
             if (ABL & 4) v[u] = make_float4(1.f, 2.f, 3.f, 4.f);
-            else v[u] = *reinterpret_cast<const float4*>(x + ((size_t)b * Cin + cic) * plane + (size_t)rowc * W + pxc);
+            else v[u] = cseg_buffer_load_f4(x_rs, xu_off[u], soff);
         }
     };
-    auto x_put = [&](int x0, int row, int slot, const float4 (&v)[XU]) {
+    auto x_put = [&](int row, int slot, const float4 (&v)[XU]) __attribute__((always_inline)) {
+        const bool row_ok = row >= 0 && row < H;
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const int item = lt + 256 * u;
-            if (item < CI_B * XCH) {
-                const int ci = item / XCH, c = item - ci * XCH;
-                const int px = x0 - 4 + 4 * c;
-                const bool ok = cib * CI_B + ci < Cin && row >= 0 && row < H && px >= 0 && px < W;
-                const float4 t = ok ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xi_ok[u]) {
+                const float4 t = (xu_ok[u] && row_ok) ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 cells[NP];
                 if (ABL & 2) {
 #pragma unroll
@@ -338,25 +375,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
                                               __builtin_bit_cast(unsigned, t.z) >> 16 | (__builtin_bit_cast(unsigned, t.w) & 0xffff0000u));
                 } else split_cells4<AR>(t, xscale, cells);
 #pragma unroll
-                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(xs + x2_idx<NP, SEGW>(p, ci, slot, 4 * c)) = cells[p];
+                for (int p = 0; p < NP; ++p)
+                    *reinterpret_cast<uint2*>(xs + xi_lds[u] + p * CI_B * x2_ch(NP, SEGW) + slot * (SEGW + 8)) = cells[p];
             }
         }
     };
-    auto d_load = [&](int b, int x0, int row, float4 (&v)[DU]) {
+    auto d_load = [&](int row, float4 (&v)[DU]) __attribute__((always_inline)) {
+        const int soff = min(row, H - 1) * W * (int)sizeof(float);
 #pragma unroll
         for (int u = 0; u < DU; ++u) {
-            const int item = min(lt + 256 * u, CO_B * DCH - 1);
-            const int co = item / DCH, c = item - co * DCH;
             if (ABL & 4) v[u] = make_float4(1.f, 2.f, 3.f, 4.f);
-            else v[u] = *reinterpret_cast<const float4*>(dy + (((size_t)b * Cout + cob * CO_B + co) * H + min(row, H - 1)) * W + x0 + 4 * c);
+            else v[u] = cseg_buffer_load_f4(d_rs, du_off[u], soff);
         }
     };
-    auto d_put = [&](int buf, const float4 (&v)[DU]) {
+    auto d_put = [&](int buf, const float4 (&v)[DU]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < DU; ++u) {
-            const int item = lt + 256 * u;
-            if (item < CO_B * DCH) {
-                const int co = item / DCH, c = item - co * DCH;
+            if (di_ok[u]) {
                 uint2 cells[NP];
                 if (ABL & 2) {
 #pragma unroll
@@ -365,7 +400,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
                                               __builtin_bit_cast(unsigned, v[u].z) >> 16 | (__builtin_bit_cast(unsigned, v[u].w) & 0xffff0000u));
                 } else split_cells4<AR>(v[u], dscale, cells);
 #pragma unroll
-                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(ds + d2_idx<NP, SEGW>(buf, p, co, 4 * c)) = cells[p];
+                for (int p = 0; p < NP; ++p)
+                    *reinterpret_cast<uint2*>(ds + di_lds[u] + (buf * NP + p) * CO_B * d2_pitch(NP, SEGW)) = cells[p];
             }
         }
     };
@@ -390,7 +426,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
             r.c1[p] = *reinterpret_cast<const uint4*>(src + 8);      // entries e+8 .. e+15 (d4..d7)
         }
     };
-    auto compute = [&](int s0, int buf, f32x4 (&acc)[9][3]) {
+    auto compute = [&](int s0, int buf, f32x4 (&acc)[9][3]) __attribute__((always_inline)) {
         constexpr int NG = (SEGW / 32) * 3;
         frag_t a[2][3][NP];
         XRaw xr[2];
@@ -439,41 +475,50 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
     };
 
     // The two roles run separate loops (separate register budgets: staging registers on one side, 27 accumulators on the
-    // other) that execute the SAME sequence of barriers: one after the prologue of a unit, one per row.
+    // other) that execute the SAME sequence of barriers: one after the prologue of a unit, one per row. Both walk the rows of a
+    // unit four at a time, so that ring slots and dy buffers are compile-time constants (LDS offsets become instruction immediates).
     if (loader) {
         for (int unit = split; unit < n_units; unit += n_split) {
             int b, x0, ya, yb;
             unit_dims(unit, b, x0, ya, yb);
+            unit_setup(b, x0);
             float4 xv[XU], dv[DU];
             {   // prologue tick (the previous unit's last barrier has released the image): x rows ya-1, ya, ya+1 -> slots
                 // 0, 1, 2; dy row ya -> buffer 0; then the loads of the first steady tick are put in flight
                 float4 x0v[XU], x1v[XU];
-                x_load(b, x0, ya - 1, x0v);
-                x_load(b, x0, ya, x1v);
-                x_load(b, x0, ya + 1, xv);
-                d_load(b, x0, ya, dv);
-                x_put(x0, ya - 1, 0, x0v);
-                x_put(x0, ya, 1, x1v);
-                x_put(x0, ya + 1, 2, xv);
+                x_load(ya - 1, x0v);
+                x_load(ya, x1v);
+                x_load(ya + 1, xv);
+                d_load(ya, dv);
+                x_put(ya - 1, 0, x0v);
+                x_put(ya, 1, x1v);
+                x_put(ya + 1, 2, xv);
                 d_put(0, dv);
             }
             if (ya + 1 < yb) {
-                x_load(b, x0, ya + 2, xv);
-                d_load(b, x0, ya + 1, dv);
+                x_load(ya + 2, xv);
+                d_load(ya + 1, dv);
             }
             __syncthreads();
 #pragma unroll 1
-            for (int row = ya; row < yb; ++row) {
-                const int k = row - ya;                // x row r of the unit lives in slot (r - ya + 1) & 3
-                if (row + 1 < yb) {
-                    x_put(x0, row + 2, (k + 3) & 3, xv);           // the slot that held row - 2
-                    d_put((k + 1) & 1, dv);
-                    if (row + 2 < yb) {
-                        x_load(b, x0, row + 3, xv);
-                        d_load(b, x0, row + 2, dv);
+            for (int r0 = ya; r0 < yb; r0 += 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {          // row r0 + j = step k of the unit with k & 3 == j
+                    const int row = r0 + j;
+                    if (row < yb) {
+                        if (row + 1 < yb) {
+                            if (!(ABL & 8)) {
+                                x_put(row + 2, (j + 3) & 3, xv);       // the slot that held row - 2
+                                d_put((j + 1) & 1, dv);
+                            }
+                            if (row + 2 < yb) {
+                                x_load(row + 3, xv);
+                                d_load(row + 2, dv);
+                            }
+                        }
+                        __syncthreads();
                     }
                 }
-                __syncthreads();
             }
         }
     } else {
@@ -487,10 +532,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
             unit_dims(unit, b, x0, ya, yb);
             __syncthreads();
 #pragma unroll 1
-            for (int row = ya; row < yb; ++row) {
-                const int k = row - ya;
-                if (tile_ok) compute(k & 3, k & 1, acc);
-                __syncthreads();
+            for (int r0 = ya; r0 < yb; r0 += 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (r0 + j < yb) {
+                        if (tile_ok) compute(j, j & 1, acc);
+                        __syncthreads();
+                    }
+                }
             }
         }
         if (tile_ok) {
@@ -653,6 +702,8 @@ int wrw_impl(const float* x, const float* dy, int B, int Cin, int Cout, int H, i
     if (v2) {
         CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0,
                      "conv3x3_sb_wrw: tensors must be 16-byte aligned");
+        CSEG_REQUIRE((long)Cin * H * W * 4 < 2147483647L && (long)Cout * H * W * 4 < 2147483647L,
+                     "conv3x3_sb_wrw: one image of x / dy must stay below 2 GiB (32-bit buffer offsets)");
         const bool wide = wrw2_seg(W) == 64;
         const char* abl_env = getenv("CSEG_ABLATE");
         const int abl = abl_env ? atoi(abl_env) : 0;
@@ -665,6 +716,7 @@ int wrw_impl(const float* x, const float* dy, int B, int Cin, int Cout, int H, i
                 case 6: ok2 = launch_wrw2<SplitF16x3, 64, 6>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
                 case 3: ok2 = launch_wrw2<SplitF16x3, 64, 3>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
                 case 5: ok2 = launch_wrw2<SplitF16x3, 64, 5>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
+                case 14: ok2 = launch_wrw2<SplitF16x3, 64, 14>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
                 default: ok2 = launch_wrw2<SplitF16x3, 64, 7>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
             }
             if (!ok2) return 0;

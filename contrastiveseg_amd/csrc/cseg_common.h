@@ -29,6 +29,15 @@
 #define CSEG_KEEP_DWORD(v) asm volatile("" ::"v"(v))
 #endif
 
+// 16-byte buffer load: per-lane byte offset + scalar byte offset into a buffer resource (range-checked by the hardware: 0 beyond it)
+#ifndef CSEG_EMU_BUFFER_LOAD_F4
+__device__ __forceinline__ float4 cseg_buffer_load_f4(__amdgpu_buffer_rsrc_t rs, int voffset, int soffset) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voffset, soffset, 0);
+    return make_float4(__builtin_bit_cast(float, v[0]), __builtin_bit_cast(float, v[1]), __builtin_bit_cast(float, v[2]),
+                       __builtin_bit_cast(float, v[3]));
+}
+#endif
+
 void cseg_set_error(const char* fmt, ...);
 
 // reference convention: 1 = ok, 0 = error (lib/extensions/cc_attention/src/ca.cu:199-204)

@@ -39,12 +39,12 @@ dy = (torch.randn(B, C, H, W, generator=g) * 1e-3).to(dev)
 w = (torch.randn(C, C, 3, 3, generator=g) / (3.0 * C ** 0.5)).to(dev)
 ax, ad = K.tensor_amax(x), K.tensor_amax(dy)
 row = {"kernel": "conv3x3 720->720 forward, f16x3"}
-for abl in (0, 1, 2, 4, 8, 6, 14, 7, 9, 15):
+for abl in (0, 14):
     os.environ["CSEG_ABLATE"] = str(abl)
     row[str(abl)] = timeit(lambda: K.conv3x3_sb_run(x, w, False, None, 0, ax=ax))
 print(json.dumps(row), flush=True)
 row = {"kernel": "conv3x3 720->720 weight gradient, f16x3"}
-for abl in (0, 1, 2, 4, 6, 3, 5, 7):
+for abl in (0, 2, 4, 6, 14):
     os.environ["CSEG_ABLATE"] = str(abl)
     row[str(abl)] = timeit(lambda: K.conv3x3_sb_wrw(x, dy, ax=ax, ady=ad))
 print(json.dumps(row), flush=True)
