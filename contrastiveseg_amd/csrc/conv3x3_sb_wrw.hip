@@ -313,7 +313,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
     // ---- loader side. x row: 64 ci x 18 chunks of 4 entries (entry i = pixel x0 - 4 + i); dy row: 48 co x 16 chunks.
     // Round 3: everything about a staging item that does not change from row to row is computed ONCE (per kernel: which channel
     // and chunk, its LDS offset; per unit: its byte offset inside the image and whether its columns exist), and the fetch is a
-    // buffer load with the row as SCALAR offset -- the per-row cost of an item is the load, a select and the split. (The first
+    // global load with a SCALAR base (image + row) and that 32-bit offset -- the per-row cost of an item is the load, a select and
+    // the split. (The first
     // version recomputed item / 18, three clamps and a 64-bit address per item and row: ~400 VALU instructions per row-step on
     // the SIMDs that issue the consumers' MFMAs; with all loads removed the kernel ran 22 % faster, tools/ablate_probe.py.)
     int xi_lds[XU], xi_px[XU], xi_ch[XU];          // LDS half-word offset (piece 0, slot 0); pixel offset from x0; channel (clamped)
@@ -337,28 +338,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
         di_off[u] = (cob * CO_B + co) * (int)plane + 4 * c;
         di_ok[u] = loader && item < CO_B * DCH;
     }
-    // per unit (set by unit_setup): buffer resources of the image, byte offsets of the items, column validity
-    __amdgpu_buffer_rsrc_t x_rs, d_rs;
-    int xu_off[XU], du_off[DU];
+    // per unit (set by unit_setup): base pointers of the image, byte offsets of the items inside it, column validity
+    const float* x_img = x;
+    const float* d_img = dy;
+    unsigned xu_off[XU], du_off[DU];
     bool xu_ok[XU];
     auto unit_setup = [&](int b, int x0) {
-        x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * Cin * plane), 0, (int)(Cin * plane * sizeof(float)), 0x00020000);
-        d_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (size_t)b * Cout * plane), 0, (int)(Cout * plane * sizeof(float)), 0x00020000);
+        x_img = x + (size_t)b * Cin * plane;
+        d_img = dy + (size_t)b * Cout * plane;
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             const int px = x0 + xi_px[u];
-            xu_off[u] = (xi_ch[u] * (int)plane + min(max(px, 0), W - 4)) * (int)sizeof(float);
+            xu_off[u] = (unsigned)(xi_ch[u] * (int)plane + min(max(px, 0), W - 4)) * (unsigned)sizeof(float);
             xu_ok[u] = xi_ok[u] && px >= 0 && px < W;
         }
 #pragma unroll
-        for (int u = 0; u < DU; ++u) du_off[u] = (di_off[u] + x0) * (int)sizeof(float);
+        for (int u = 0; u < DU; ++u) du_off[u] = (unsigned)(di_off[u] + x0) * (unsigned)sizeof(float);
     };
     auto x_load = [&](int row, float4 (&v)[XU]) __attribute__((always_inline)) {
-        const int soff = min(max(row, 0), H - 1) * W * (int)sizeof(float);       // uniform
+        const float* rowp = x_img + (size_t)min(max(row, 0), H - 1) * W;          // uniform
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             if (ABL & 4) v[u] = make_float4(1.f, 2.f, 3.f, 4.f);
-            else v[u] = cseg_buffer_load_f4(x_rs, xu_off[u], soff);
+            else v[u] = cseg_load_f4(rowp, xu_off[u]);
         }
     };
     auto x_put = [&](int row, int slot, const float4 (&v)[XU]) __attribute__((always_inline)) {
@@ -381,11 +383,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
         }
     };
     auto d_load = [&](int row, float4 (&v)[DU]) __attribute__((always_inline)) {
-        const int soff = min(row, H - 1) * W * (int)sizeof(float);
+        const float* rowp = d_img + (size_t)min(row, H - 1) * W;
 #pragma unroll
         for (int u = 0; u < DU; ++u) {
             if (ABL & 4) v[u] = make_float4(1.f, 2.f, 3.f, 4.f);
-            else v[u] = cseg_buffer_load_f4(d_rs, du_off[u], soff);
+            else v[u] = cseg_load_f4(rowp, du_off[u]);
         }
     };
     auto d_put = [&](int buf, const float4 (&v)[DU]) __attribute__((always_inline)) {
@@ -703,7 +705,7 @@ int wrw_impl(const float* x, const float* dy, int B, int Cin, int Cout, int H, i
         CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0,
                      "conv3x3_sb_wrw: tensors must be 16-byte aligned");
         CSEG_REQUIRE((long)Cin * H * W * 4 < 2147483647L && (long)Cout * H * W * 4 < 2147483647L,
-                     "conv3x3_sb_wrw: one image of x / dy must stay below 2 GiB (32-bit buffer offsets)");
+                     "conv3x3_sb_wrw: one image of x / dy must stay below 2 GiB (32-bit offsets)");
         const bool wide = wrw2_seg(W) == 64;
         const char* abl_env = getenv("CSEG_ABLATE");
         const int abl = abl_env ? atoi(abl_env) : 0;

@@ -29,14 +29,13 @@
 #define CSEG_KEEP_DWORD(v) asm volatile("" ::"v"(v))
 #endif
 
-// 16-byte buffer load: per-lane byte offset + scalar byte offset into a buffer resource (range-checked by the hardware: 0 beyond it)
-#ifndef CSEG_EMU_BUFFER_LOAD_F4
-__device__ __forceinline__ float4 cseg_buffer_load_f4(__amdgpu_buffer_rsrc_t rs, int voffset, int soffset) {
-    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voffset, soffset, 0);
-    return make_float4(__builtin_bit_cast(float, v[0]), __builtin_bit_cast(float, v[1]), __builtin_bit_cast(float, v[2]),
-                       __builtin_bit_cast(float, v[3]));
+// 16-byte load from a UNIFORM base pointer plus a per-lane 32-bit byte offset: the form the compiler turns into
+// `global_load_dwordx4 v, v_off, s[base]` (scalar base, no 64-bit vector address arithmetic). Not a buffer load: ROCm 7.2's
+// __builtin_amdgcn_raw_buffer_load_b128 lowers to buffer_load_dword (ONE dword; found by the fp64 parity test on the MI355X,
+// /tmp-size reproducer in DESIGN.md section 4), so 16-byte buffer loads are not available from HIP source in this toolchain.
+__device__ __forceinline__ float4 cseg_load_f4(const void* uniform_base, unsigned byte_offset) {
+    return *reinterpret_cast<const float4*>(static_cast<const char*>(uniform_base) + byte_offset);
 }
-#endif
 
 void cseg_set_error(const char* fmt, ...);
 

@@ -234,13 +234,6 @@ static inline int emu_raw_buffer_load_b32(emu_buffer_rsrc r, int voffset, int so
     if ((uint64_t)o + 4 <= r.num_records) memcpy(&v, r.base + o, 4);
     return v;
 }
-#define CSEG_EMU_BUFFER_LOAD_F4 1
-static inline float4 cseg_buffer_load_f4(emu_buffer_rsrc r, int voffset, int soffset) {
-    const unsigned o = (unsigned)voffset + (unsigned)soffset;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((uint64_t)o + 16 <= r.num_records) memcpy(&v, r.base + o, 16);
-    return v;
-}
 #define __builtin_amdgcn_make_buffer_rsrc emu_make_buffer_rsrc
 #define __builtin_amdgcn_raw_buffer_load_b32 emu_raw_buffer_load_b32
 
