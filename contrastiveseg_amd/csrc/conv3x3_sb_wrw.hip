@@ -827,55 +827,81 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw_s2_kernel(const float* 
     auto x_at = [&](int p, int ci, int slot, int pl, int i) { return xs + (p * CI_B + ci) * S2_XCH + slot * S2_ROWIMG + pl * S2_PL + i; };
     auto d_at = [&](int buf, int p, int co, int i) { return ds + ((buf * NP + p) * CO_B + co) * S2_DP + i; };
 
-    // ---- loader side. Chunk k (2 .. 19) of a staged x row = input columns 2 x0 - 16 + 4k .. + 3 -> entries 2k, 2k + 1 of both planes
-    auto x_load = [&](int b, int x0, int row, float4 (&v)[XU]) {
+    // ---- loader side. Chunk k (2 .. 19) of a staged x row = input columns 2 x0 - 16 + 4k .. + 3 -> entries 2k, 2k + 1 of both planes.
+    // Item descriptors are computed once, offsets once per unit, loads use a scalar base (see conv3x3_sb_wrw2_kernel).
+    int xi_lds[XU], xi_px[XU], xi_ch[XU];
+    bool xi_ok[XU];
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+        const int item = lt + 256 * u, itc = min(max(item, 0), CI_B * S2_KCH - 1);
+        const int ci = itc / S2_KCH, k = itc - ci * S2_KCH + 2;
+        xi_lds[u] = (int)(x_at(0, ci, 0, 0, 2 * k) - xs);
+        xi_px[u] = 4 * k - 16;
+        xi_ch[u] = min(cib * CI_B + ci, Cin - 1);
+        xi_ok[u] = loader && item < CI_B * S2_KCH && cib * CI_B + ci < Cin;
+    }
+    int di_lds[DU], di_off[DU];
+    bool di_ok[DU];
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+        const int item = lt + 256 * u, itc = min(max(item, 0), CO_B * DCH - 1);
+        const int co = itc / DCH, c = itc - co * DCH;
+        di_lds[u] = (int)(d_at(0, 0, co, 4 * c) - ds);
+        di_off[u] = (cob * CO_B + co) * (int)oplane + 4 * c;
+        di_ok[u] = loader && item < CO_B * DCH;
+    }
+    const float* x_img = x;
+    const float* d_img = dy;
+    unsigned xu_off[XU], du_off[DU];
+    bool xu_ok[XU];
+    auto unit_setup = [&](int b, int x0) {
+        x_img = x + (size_t)b * Cin * plane;
+        d_img = dy + (size_t)b * Cout * oplane;
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const int item = min(lt + 256 * u, CI_B * S2_KCH - 1);
-            const int ci = item / S2_KCH, k = item - ci * S2_KCH + 2;
-            const int px = 2 * x0 - 16 + 4 * k;
-            const int cic = min(cib * CI_B + ci, Cin - 1), rowc = min(max(row, 0), H - 1), pxc = min(max(px, 0), W - 4);
-            v[u] = *reinterpret_cast<const float4*>(x + ((size_t)b * Cin + cic) * plane + (size_t)rowc * W + pxc);
+            const int px = 2 * x0 + xi_px[u];
+            xu_off[u] = (unsigned)(xi_ch[u] * (int)plane + min(max(px, 0), W - 4)) * (unsigned)sizeof(float);
+            xu_ok[u] = xi_ok[u] && px >= 0 && px < W;
         }
+#pragma unroll
+        for (int u = 0; u < DU; ++u) du_off[u] = (unsigned)(di_off[u] + x0) * (unsigned)sizeof(float);
     };
-    auto x_put = [&](int x0, int row, int slot, const float4 (&v)[XU]) {
+    auto x_load = [&](int row, float4 (&v)[XU]) __attribute__((always_inline)) {
+        const float* rowp = x_img + (size_t)min(max(row, 0), H - 1) * W;
+#pragma unroll
+        for (int u = 0; u < XU; ++u) v[u] = cseg_load_f4(rowp, xu_off[u]);
+    };
+    auto x_put = [&](int row, int slot, const float4 (&v)[XU]) __attribute__((always_inline)) {
+        const bool row_ok = row >= 0 && row < H;
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const int item = lt + 256 * u;
-            if (item < CI_B * S2_KCH) {
-                const int ci = item / S2_KCH, k = item - ci * S2_KCH + 2;
-                const int px = 2 * x0 - 16 + 4 * k;
-                const bool ok = cib * CI_B + ci < Cin && row >= 0 && row < H && px >= 0 && px < W;
-                const float4 t = ok ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xi_ok[u]) {
+                const float4 t = (xu_ok[u] && row_ok) ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 cells[NP];
                 split_cells4<AR>(t, xscale, cells);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     // half-words (v0, v1 | v2, v3): the even columns v0, v2 and the odd columns v1, v3
-                    *reinterpret_cast<unsigned*>(x_at(p, ci, slot, 0, 2 * k)) = (cells[p].x & 0xffffu) | (cells[p].y << 16);
-                    *reinterpret_cast<unsigned*>(x_at(p, ci, slot, 1, 2 * k)) = (cells[p].x >> 16) | (cells[p].y & 0xffff0000u);
+                    unsigned short* dst = xs + xi_lds[u] + p * CI_B * S2_XCH + slot * S2_ROWIMG;
+                    *reinterpret_cast<unsigned*>(dst) = (cells[p].x & 0xffffu) | (cells[p].y << 16);
+                    *reinterpret_cast<unsigned*>(dst + S2_PL) = (cells[p].x >> 16) | (cells[p].y & 0xffff0000u);
                 }
             }
         }
     };
-    auto d_load = [&](int b, int x0, int row, float4 (&v)[DU]) {
+    auto d_load = [&](int row, float4 (&v)[DU]) __attribute__((always_inline)) {
+        const float* rowp = d_img + (size_t)min(row, Ho - 1) * Wo;
 #pragma unroll
-        for (int u = 0; u < DU; ++u) {
-            const int item = min(lt + 256 * u, CO_B * DCH - 1);
-            const int co = item / DCH, c = item - co * DCH;
-            v[u] = *reinterpret_cast<const float4*>(dy + ((size_t)b * Cout + cob * CO_B + co) * oplane + (size_t)min(row, Ho - 1) * Wo + x0 + 4 * c);
-        }
+        for (int u = 0; u < DU; ++u) v[u] = cseg_load_f4(rowp, du_off[u]);
     };
-    auto d_put = [&](int buf, const float4 (&v)[DU]) {
+    auto d_put = [&](int buf, const float4 (&v)[DU]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < DU; ++u) {
-            const int item = lt + 256 * u;
-            if (item < CO_B * DCH) {
-                const int co = item / DCH, c = item - co * DCH;
+            if (di_ok[u]) {
                 uint2 cells[NP];
                 split_cells4<AR>(v[u], dscale, cells);
 #pragma unroll
-                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(d_at(buf, p, co, 4 * c)) = cells[p];
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(ds + di_lds[u] + (buf * NP + p) * CO_B * S2_DP) = cells[p];
             }
         }
     };
@@ -941,22 +967,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw_s2_kernel(const float* 
         for (int unit = split; unit < n_units; unit += n_split) {
             int b, x0, ya, yb;
             unit_dims(unit, b, x0, ya, yb);
+            unit_setup(b, x0);
             float4 ev[XU], ov[XU], dv[DU];
             {   // prologue tick: even row 2 ya -> slot 0, odd rows 2 ya - 1, 2 ya + 1 -> slots 2, 3, dy row ya -> buffer 0
                 float4 o0v[XU];
-                x_load(b, x0, 2 * ya - 1, o0v);
-                x_load(b, x0, 2 * ya, ev);
-                x_load(b, x0, 2 * ya + 1, ov);
-                d_load(b, x0, ya, dv);
-                x_put(x0, 2 * ya - 1, 2, o0v);
-                x_put(x0, 2 * ya, 0, ev);
-                x_put(x0, 2 * ya + 1, 3, ov);
+                x_load(2 * ya - 1, o0v);
+                x_load(2 * ya, ev);
+                x_load(2 * ya + 1, ov);
+                d_load(ya, dv);
+                x_put(2 * ya - 1, 2, o0v);
+                x_put(2 * ya, 0, ev);
+                x_put(2 * ya + 1, 3, ov);
                 d_put(0, dv);
             }
             if (ya + 1 < yb) {
-                x_load(b, x0, 2 * ya + 2, ev);
-                x_load(b, x0, 2 * ya + 3, ov);
-                d_load(b, x0, ya + 1, dv);
+                x_load(2 * ya + 2, ev);
+                x_load(2 * ya + 3, ov);
+                d_load(ya + 1, dv);
             }
             __syncthreads();
             int m3 = 0;                                // k % 3
@@ -964,13 +991,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw_s2_kernel(const float* 
             for (int row = ya; row < yb; ++row) {
                 const int k = row - ya;
                 if (row + 1 < yb) {
-                    x_put(x0, 2 * row + 2, (k + 1) & 1, ev);                       // even row of the next step
-                    x_put(x0, 2 * row + 3, 2 + (m3 == 0 ? 2 : m3 - 1), ov);        // odd row 2 (oy + 1) + 1 -> slot 2 + (k + 2) % 3
+                    x_put(2 * row + 2, (k + 1) & 1, ev);                       // even row of the next step
+                    x_put(2 * row + 3, 2 + (m3 == 0 ? 2 : m3 - 1), ov);        // odd row 2 (oy + 1) + 1 -> slot 2 + (k + 2) % 3
                     d_put((k + 1) & 1, dv);
                     if (row + 2 < yb) {
-                        x_load(b, x0, 2 * row + 4, ev);
-                        x_load(b, x0, 2 * row + 5, ov);
-                        d_load(b, x0, row + 2, dv);
+                        x_load(2 * row + 4, ev);
+                        x_load(2 * row + 5, ov);
+                        d_load(row + 2, dv);
                     }
                 }
                 __syncthreads();

@@ -33,7 +33,9 @@ def timeit(fn, iters=5, warm=2):
 g = torch.Generator().manual_seed(1)
 CASES = [((8, 720, 128, 256), (0, 3, 4, 5, 8, 16)), ((8, 384, 16, 32), (0, 2, 4, 8, 16)), ((8, 192, 32, 64), (0, 4, 8, 16)),
          ((8, 96, 64, 128), (0, 16, 32, 64)), ((8, 48, 128, 256), (0, 64, 128, 256))]
+MODEL_ONLY = os.environ.get("CSEG_PROBE_MODEL_ONLY") == "1"
 for (B, C, H, W), ns in CASES:
+    ns = (0,) if MODEL_ONLY else ns
     x = torch.randn(B, C, H, W, generator=g).relu_().to(dev)
     dy = (torch.randn(B, C, H, W, generator=g) * 1e-3).to(dev)
     ax, ad = K.tensor_amax(x), K.tensor_amax(dy)
