@@ -276,13 +276,17 @@ def conv_arith_note(Kn, split_on):
     if Kn.CONV1X1_SPLIT_BF16:
         one = "; 1x1 convolutions with tiling channel counts (projection head, bottlenecks) forward + backward-data" + (
             " + weight gradient (>= %d channels)" % Kn.CONV1X1_SB_WRW_MIN_CH if Kn.CONV1X1_SB_WRW else "")
+    s2 = ""
+    if getattr(Kn, "CONV3X3_S2_SPLIT", False) and Kn.SPLIT_ARITH == "f16x3":
+        s2 = "; the 3x3 stride-2 convolutions of the fuse / transition layers in all three directions"
     return ("%s; fp32-class accuracy: whole-network logits vs fp64 5.1e-5 (f16x3) / 2.1e-5 (bf16x6) against fp32's own 4.3e-5, "
             "tools/split_bf16_probe.py, tests/test_gpu_conv3x3_sb.py) for the 720->720 head convolution and the %s-channel "
-            "branches, forward + backward-data%s%s; everything else fp32 (MIOpen / rocBLAS)"
-            % (how, "/".join(str(c) for c in Kn.CONV3X3_SB_BRANCH_CHANNELS), wrw, one))
+            "branches, forward + backward-data%s%s%s; everything else fp32 (MIOpen / rocBLAS)"
+            % (how, "/".join(str(c) for c in Kn.CONV3X3_SB_BRANCH_CHANNELS), wrw, one, s2))
 
 
-SPLIT_OPS = ("conv3x3_sb_run", "conv3x3_sb_wrw", "conv1x1_sb_run", "conv1x1_sb_wrw")
+SPLIT_OPS = ("conv3x3_sb_run", "conv1x1_sb_run", "conv3x3_sb_wrw", "conv1x1_sb_wrw",
+             "conv3x3_s2_run", "conv3x3_s2_bwd_run", "conv3x3_s2_wrw")     # the last three: stride 2 (round 3)
 
 
 def tally_split_calls(tr, batch, Kn):
@@ -319,7 +323,22 @@ def split_kernel_rooflines(counts, device, Kn):
     rows, split_flops = [], 0.0
     for (name, sa, sb, flag), n in sorted(counts.items(), key=lambda kv: -kv[1]):
         a = torch.randn(*sa, generator=g).to(device)
-        if name.endswith("_run"):
+        if name.startswith("conv3x3_s2_"):
+            if name == "conv3x3_s2_wrw":
+                dy = (torch.randn(*sb, generator=g) * 1e-3).to(device)
+                ax, ad = Kn.tensor_amax(a), Kn.tensor_amax(dy)
+                fn = lambda: Kn.conv3x3_s2_wrw(a, dy, ax=ax, ady=ad)
+                ci, co, ho, wo, kind = sa[1], sb[1], sb[2], sb[3], "weight gradient"
+            else:
+                w = (torch.randn(*sb, generator=g) / (9 * sb[1]) ** 0.5).to(device)
+                ax = Kn.tensor_amax(a)
+                bwd = name == "conv3x3_s2_bwd_run"
+                fn = (lambda: Kn.conv3x3_s2_bwd_run(a, w, ady=ax)) if bwd else (lambda: Kn.conv3x3_s2_run(a, w, ax=ax))
+                ci, co, kind = sb[1], sb[0], "backward-data" if bwd else "forward"
+                ho, wo = (sa[2], sa[3]) if bwd else (sa[2] // 2, sa[3] // 2)
+            flops = 2.0 * sa[0] * ho * wo * ci * co * 9
+            what = "conv3x3 stride 2 %d->%d %s @%dx%dx%d (output)" % (ci, co, kind, sa[0], ho, wo)
+        elif name.endswith("_run"):
             w = (torch.randn(*sb, generator=g) / (sb[1] * sb[2] * sb[3]) ** 0.5).to(device)
             taps = sb[2] * sb[3]
             nt = Kn.conv3x3_sb_pick_nt(a, sb[1] if flag else sb[0]) if (taps == 9 and sb[0] in Kn.CONV3X3_SB_PICK_NT_CHANNELS) else 0

@@ -59,34 +59,42 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
     const long u_lo = n_units * split / n_split, u_hi = n_units * (split + 1) / n_split;     // this split's stages
 
     if (loader) {
-        // item = (channel row r of the 272, chunk c of 8): rows 0..143 = dy channels cob*144 + r, rows 144..271 = x channels
-        auto load = [&](long unit, float4 (&v)[LD_U]) {
-            const int b = (int)(unit / stages_per_img);
-            const size_t p0 = (size_t)(unit % stages_per_img) * STG;
+        // item = (channel row r of the 272, chunk c of 8): rows 0..143 = dy channels cob*144 + r, rows 144..271 = x channels.
+        // Round 3: what an item is (which tensor, channel, chunk, LDS offset) is fixed for the whole kernel, so it is computed once;
+        // a stage then costs, per item, one load with a SCALAR base (tensor + image + pixel offset of the stage) and a constant
+        // 32-bit lane offset, a select and the split. Whether an item belongs to dy or x is uniform per wave (1 152 dy items =
+        // 4.5 x 256), which the compiler cannot see: it is derived from the scalar wave index. (Before: a 64-bit division and a
+        // 64-bit address per item and stage, ~360 VALU instructions per stage against the consumers' 60 MFMAs.)
+        unsigned off[LD_U];
+        int lds_off[LD_U];
+        bool ok[LD_U], is_dy[LD_U];
 #pragma unroll
-            for (int u = 0; u < LD_U; ++u) {
-                const int item = min(lt + 256 * u, LD_ITEMS - 1);
-                const int r = item >> 3, c = item & 7;
-                const float* src;
-                if (r < CO_T) src = dy + ((size_t)b * Cout + min(cob * CO_T + r, Cout - 1)) * plane;
-                else src = x + ((size_t)b * Cin + min(cib * CI_T + r - CO_T, Cin - 1)) * plane;
-                v[u] = *reinterpret_cast<const float4*>(src + p0 + 4 * c);
-            }
+        for (int u = 0; u < LD_U; ++u) {
+            const int item = lt + 256 * u, itc = min(item, LD_ITEMS - 1);
+            const int r = itc >> 3, c = itc & 7;
+            is_dy[u] = 256 * u + 64 * (wave - 4) < CO_T * 8;                     // scalar
+            const int ch = is_dy[u] ? min(cob * CO_T + r, Cout - 1) : min(cib * CI_T + r - CO_T, Cin - 1);
+            off[u] = (unsigned)(ch * plane_i + 4 * c) * (unsigned)sizeof(float);
+            ok[u] = item < LD_ITEMS && (is_dy[u] ? cob * CO_T + r < Cout : cib * CI_T + r - CO_T < Cin);
+            lds_off[u] = is_dy[u] ? r * PITCH + 4 * c : (r - CO_T) * PITCH + 4 * c;
+        }
+        int img = (int)(u_lo / stages_per_img), stage = (int)(u_lo % stages_per_img);       // of the next stage to LOAD
+        auto load = [&](float4 (&v)[LD_U]) __attribute__((always_inline)) {
+            const float* dyp = dy + ((size_t)img * Cout * plane + (size_t)stage * STG);     // uniform
+            const float* xp = x + ((size_t)img * Cin * plane + (size_t)stage * STG);
+#pragma unroll
+            for (int u = 0; u < LD_U; ++u) v[u] = cseg_load_f4(is_dy[u] ? dyp : xp, off[u]);
+            if (++stage == stages_per_img) { stage = 0; ++img; }
         };
-        auto put = [&](int buf, const float4 (&v)[LD_U]) {
+        auto put = [&](int buf, const float4 (&v)[LD_U]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < LD_U; ++u) {
-                const int item = lt + 256 * u;
-                if (item < LD_ITEMS) {
-                    const int r = item >> 3, c = item & 7;
-                    const bool is_dy = r < CO_T;
-                    const bool ok = is_dy ? cob * CO_T + r < Cout : cib * CI_T + r - CO_T < Cin;
-                    const float4 t = ok ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok[u] || lt + 256 * u < LD_ITEMS) {                          // rows beyond the channel count are zero-filled
+                    const float4 t = ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
                     uint2 cells[NP];
-                    split_cells4<AR>(t, is_dy ? dscale : xscale, cells);
-                    unsigned short* base = is_dy ? ds + buf * DY_ELEMS + r * PITCH + 4 * c
-                                                 : xs + buf * X_ELEMS + (r - CO_T) * PITCH + 4 * c;
-                    const int pstride = is_dy ? CO_T * PITCH : CI_T * PITCH;
+                    split_cells4<AR>(t, is_dy[u] ? dscale : xscale, cells);
+                    unsigned short* base = is_dy[u] ? ds + buf * DY_ELEMS + lds_off[u] : xs + buf * X_ELEMS + lds_off[u];
+                    const int pstride = is_dy[u] ? CO_T * PITCH : CI_T * PITCH;
 #pragma unroll
                     for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(base + q * pstride) = cells[q];
                 }
@@ -94,19 +102,23 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
         };
         float4 v[LD_U];
         if (u_lo < u_hi) {
-            load(u_lo, v);
+            load(v);
             put(0, v);
-            if (u_lo + 1 < u_hi) load(u_lo + 1, v);
+            if (u_lo + 1 < u_hi) load(v);
         }
         __syncthreads();
 #pragma unroll 1
-        for (long unit = u_lo; unit < u_hi; ++unit) {
-            const int k = (int)(unit - u_lo);
-            if (unit + 1 < u_hi) {
-                put((k + 1) & 1, v);                   // that buffer was last read in stage k - 1 (barrier since)
-                if (unit + 2 < u_hi) load(unit + 2, v);
+        for (long unit = u_lo; unit < u_hi; unit += 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {              // stage k = unit - u_lo + j: buffer k & 1 = j
+                if (unit + j < u_hi) {
+                    if (unit + j + 1 < u_hi) {
+                        put((j + 1) & 1, v);           // that buffer was last read in stage k - 1 (barrier since)
+                        if (unit + j + 2 < u_hi) load(v);
+                    }
+                    __syncthreads();
+                }
             }
-            __syncthreads();
         }
     } else {
         const int mh = wave & 1, nh = wave >> 1;       // co half (tiles 0-4 / 5-8), ci half (tiles 0-3 / 4-7)
@@ -117,9 +129,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();
-#pragma unroll 1
-        for (long unit = u_lo; unit < u_hi; ++unit) {
-            const int buf = (int)(unit - u_lo) & 1;
+        auto stage_mfmas = [&](int buf) __attribute__((always_inline)) {
             frag_t bf[4][NP];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -140,7 +150,16 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
 #pragma unroll
                     for (int c = 0; c < 4; ++c) acc[a][c] = AR::mfma(af[AR::ta(t)], bf[c][AR::tb(t)], acc[a][c]);
             }
-            __syncthreads();
+        };
+#pragma unroll 1
+        for (long unit = u_lo; unit < u_hi; unit += 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {              // buffer index = stage parity = j: LDS offsets are immediates
+                if (unit + j < u_hi) {
+                    stage_mfmas(j);
+                    __syncthreads();
+                }
+            }
         }
         // D[m = 4g + r][n]: co = cob*144 + (cot0 + a)*16 + 4g + r, ci = cib*128 + (cit0 + c)*16 + n
         const float unscale = split_unscale_of(ex) * split_unscale_of(ed);
@@ -176,14 +195,23 @@ __global__ __launch_bounds__(256) void sb_wrw1_reduce_kernel(const float* __rest
     dw[e] = s0 + s1;
 }
 
+// Pixel splits: one block per CU at a time (104 KB of LDS), so the launch runs in ROUNDS of 256 blocks; the count that minimises
+// rounds x stages per block (+ the partials written and re-read per split) is taken. 720 x 720 at 8 x 128 x 256: 30 channel blocks;
+// the old rule (768 / 30 = 26 splits = 780 blocks) paid a fourth round for 12 blocks.
 int wrw1_splits(int B, int Cin, int Cout, int plane) {
     const long units = (long)B * (plane / STG);
     const int pairs = ((Cin + CI_T - 1) / CI_T) * ((Cout + CO_T - 1) / CO_T);
-    long n = (768 + pairs - 1) / pairs;              // ~3 blocks per CU in total
-    if (n > 64) n = 64;
-    if (n > units) n = units;
-    if (n < 1) n = 1;
-    return (int)n;
+    const double stage_us = 0.75, split_us = 2.0 * Cin * Cout * sizeof(float) / 4.0e6;
+    const long n_max = units < 64 ? units : 64;
+    auto cost_of = [&](long n) {
+        const long rounds = (n * pairs + 255) / 256;
+        return rounds * ((double)((units + n - 1) / n) * stage_us + 5.0) + n * split_us;
+    };
+    double best = 1e30;
+    for (long n = 1; n <= n_max; ++n) best = cost_of(n) < best ? cost_of(n) : best;
+    for (long n = 1; n <= n_max; ++n)
+        if (cost_of(n) <= 1.03 * best) return (int)n;
+    return (int)n_max;
 }
 
 }  // namespace
@@ -222,6 +250,8 @@ int wrw1_impl(const float* x, const float* dy, int B, int Cin, int Cout, int HW,
                  "conv1x1_sb_wrw: tensors must be 16-byte aligned");
     CSEG_REQUIRE(arith == CSEG_ARITH_BF16X6 || (arith == CSEG_ARITH_F16X3 && amax_x && amax_dy),
                  "conv1x1 split wrw: arithmetic %d needs max|x| and max|dy|", arith);
+    CSEG_REQUIRE((long)Cin * HW * 4 < 2147483647L && (long)Cout * HW * 4 < 2147483647L,
+                 "conv1x1_sb_wrw: one image of x / dy must stay below 2 GiB (32-bit offsets)");
     const int n_split = wrw1_splits(B, Cin, Cout, HW);
     const long blocks = (long)n_split * ((Cin + CI_T - 1) / CI_T) * ((Cout + CO_T - 1) / CO_T);
     CSEG_REQUIRE(blocks < 2147483647L && (long)Cin * Cout < 2147483647L, "conv1x1_sb_wrw: grid too large");
