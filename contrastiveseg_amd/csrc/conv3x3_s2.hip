@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void pack_s2_kernel(const float* __restrict__ 
     else pack_elem_c3_16<SplitF16x3>(w, Cout, Cin, 0, NT, wscale, wp, e);
 }
 
-bool s2_nt_ok(int nt, int conv_out) { return (nt == 3 || nt == 6) && conv_out % (nt * 16) == 0; }
+bool s2_nt_ok(int nt, int conv_out) { return (nt == 3 || nt == 4 || nt == 6) && conv_out % (nt * 16) == 0; }      // 4: 256 channels
 
 template <class K>
 bool s2_set_lds(K kernel, size_t lds, bool& done) {
@@ -416,7 +416,7 @@ bool s2_set_lds(K kernel, size_t lds, bool& done) {
 
 // bytes of the packed operator (either direction): conv_in = its input channels (% 16), conv_out = its output channels
 extern "C" size_t cseg_conv3x3_s2_split_packed_bytes(int conv_in, int conv_out) {
-    if (conv_in <= 0 || conv_out <= 0 || conv_in % 16 || conv_out % 48) return 0;
+    if (conv_in <= 0 || conv_out <= 0 || conv_in % 16 || (conv_out % 48 && conv_out % 64)) return 0;
     return (size_t)(conv_out / 16) * pack_steps_c3_16(conv_in) * 2 * 64 * sizeof(uint4);
 }
 
@@ -442,6 +442,9 @@ extern "C" int cseg_conv3x3_s2_split_pack(const float* w, int Cout, int Cin, int
     if (nt == 3)
         hipLaunchKernelGGL(pack_s2_kernel<3>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, Cout, Cin, transposed, amax_w,
                            (uint4*)wp, (int)total);
+    else if (nt == 4)
+        hipLaunchKernelGGL(pack_s2_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, Cout, Cin, transposed, amax_w,
+                           (uint4*)wp, (int)total);
     else
         hipLaunchKernelGGL(pack_s2_kernel<6>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, Cout, Cin, transposed, amax_w,
                            (uint4*)wp, (int)total);
@@ -462,10 +465,14 @@ extern "C" int cseg_conv3x3_s2_split_fwd(const float* x, const void* wp, int B, 
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_s2_fwd: grid too large");
     hipStream_t stream = (hipStream_t)stream_;
     const size_t lds = sizeof(uint4) * (2 * NOCT * F_PLANE + 2 * nt * 2 * 64);
-    static bool set3 = false, set6 = false;
+    static bool set3 = false, set4 = false, set6 = false;
     if (nt == 3) {
         if (!s2_set_lds(conv3x3_s2_fwd_kernel<SplitF16x3, 3>, lds, set3)) return 0;
         hipLaunchKernelGGL((conv3x3_s2_fwd_kernel<SplitF16x3, 3>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, (const uint4*)wp, Cin,
+                           Cout, Ho, Wo, tiles_x, tiles_y, amax_x, amax_w, y);
+    } else if (nt == 4) {
+        if (!s2_set_lds(conv3x3_s2_fwd_kernel<SplitF16x3, 4>, lds, set4)) return 0;
+        hipLaunchKernelGGL((conv3x3_s2_fwd_kernel<SplitF16x3, 4>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, (const uint4*)wp, Cin,
                            Cout, Ho, Wo, tiles_x, tiles_y, amax_x, amax_w, y);
     } else {
         if (!s2_set_lds(conv3x3_s2_fwd_kernel<SplitF16x3, 6>, lds, set6)) return 0;
@@ -490,10 +497,14 @@ extern "C" int cseg_conv3x3_s2_split_bwd(const float* dy, const void* wp, int B,
     CSEG_REQUIRE(n_blocks < 2147483647L, "conv3x3_s2_bwd: grid too large");
     hipStream_t stream = (hipStream_t)stream_;
     const size_t lds = sizeof(uint4) * (2 * NOCT * D_PLANE + 2 * nt * 2 * 64);
-    static bool set3 = false, set6 = false;
+    static bool set3 = false, set4 = false, set6 = false;
     if (nt == 3) {
         if (!s2_set_lds(conv3x3_s2_bwd_kernel<SplitF16x3, 3>, lds, set3)) return 0;
         hipLaunchKernelGGL((conv3x3_s2_bwd_kernel<SplitF16x3, 3>), dim3((unsigned)n_blocks), dim3(512), lds, stream, dy, (const uint4*)wp,
+                           Cin, Cout, Ho, Wo, tiles_x, tiles_y, amax_dy, amax_w, dx);
+    } else if (nt == 4) {
+        if (!s2_set_lds(conv3x3_s2_bwd_kernel<SplitF16x3, 4>, lds, set4)) return 0;
+        hipLaunchKernelGGL((conv3x3_s2_bwd_kernel<SplitF16x3, 4>), dim3((unsigned)n_blocks), dim3(512), lds, stream, dy, (const uint4*)wp,
                            Cin, Cout, Ho, Wo, tiles_x, tiles_y, amax_dy, amax_w, dx);
     } else {
         if (!s2_set_lds(conv3x3_s2_bwd_kernel<SplitF16x3, 6>, lds, set6)) return 0;

@@ -57,11 +57,12 @@ int sb_variant() {
     const char* e = getenv("CSEG_CONV3X3_SB_VAR");
     return e ? atoi(e) : -1;
 }
-// 64 output channels (4 channel tiles: the 3x3 convolutions of the layer-1 bottlenecks) exist only in the 16-channel-chunk kernel.
+// Output channel counts that are multiples of 64 but not of 48 (4 channel tiles per block: the 3x3 convolutions of the layer-1
+// bottlenecks, the backward-data operator of the 256 -> 48 transition) exist only in the 16-channel-chunk kernel.
 // CSEG_CONV3X3_SB16_CH = comma-separated output channel counts that go to conv3x3_sb16.hip (tuning; overrides the default list).
 bool use_sb16(int conv_out) {
     const int v = sb_variant();
-    if (conv_out == 64) return true;
+    if (conv_out % 48 != 0) return conv_out % 64 == 0;     // 64, 128, 256, ...: four channel tiles per block, 16-channel-chunk kernel only
     const char* list = getenv("CSEG_CONV3X3_SB16_CH");
     if (list) {
         for (const char* p = list; *p;) {
@@ -76,7 +77,7 @@ bool use_sb16(int conv_out) {
     // 72.4 us on the 32-channel-chunk kernel, 192 ch 47.4 vs 48.1, 384 ch 79.8 vs 87.1; 96 ch stays (41-45 vs 48)
     return v < 0 && (conv_out == 48 || conv_out == 192 || conv_out == 384);
 }
-int sb16_nt(int conv_out, int NT) { return conv_out == 64 ? 4 : (NT == 6 ? 6 : 3); }
+int sb16_nt(int conv_out, int NT) { return conv_out % 48 != 0 ? 4 : (NT == 6 ? 6 : 3); }
 
 constexpr int TR = 4;                 // output rows per block (one per wave)
 constexpr int TC = 64;                // output columns per block
@@ -441,7 +442,7 @@ int pick_nt(int Cout) {
     if (Cout % 144 == 0) return 9;
     if (Cout % 96 == 0) return 6;
     if (Cout % 48 == 0) return 3;
-    if (Cout == 64) return 4;                              // conv3x3_sb16.hip only
+    if (Cout % 64 == 0) return 4;                          // conv3x3_sb16.hip only (64: layer-1 bottlenecks; 256: input side of transition 1)
     return 0;
 }
 

@@ -877,7 +877,7 @@ def conv3x3_sb_eligible(x, weight):
     if not (_on_device(x) and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4 and x.is_contiguous()):
         return False
     co, ci, kh, kw = weight.shape
-    ok = lambda c: c % 48 == 0 or c == 64
+    ok = lambda c: c % 48 == 0 or c % 64 == 0
     return (kh, kw) == (3, 3) and ok(ci) and ok(co) and x.shape[1] == ci and x.shape[3] % 4 == 0
 
 
@@ -929,7 +929,7 @@ def conv3x3_sb_tiles(x, c_out):
     if c_out in CONV3X3_SB_PICK_NT_CHANNELS:
         nt16 = 16 * conv3x3_sb_pick_nt(x, c_out)
     else:
-        nt16 = 144 if c_out % 144 == 0 else 96 if c_out % 96 == 0 else 48 if c_out % 48 == 0 else 64
+        nt16 = 144 if c_out % 144 == 0 else 96 if c_out % 96 == 0 else 48 if c_out % 48 == 0 else 64      # % 64: four tiles per block
     return x.shape[0] * (c_out // nt16) * ((x.shape[2] + 3) // 4) * ((x.shape[3] + 63) // 64)
 
 
@@ -945,6 +945,10 @@ CONV3X3_SB_WRW = os.environ.get("CSEG_CONV3X3_SB_WRW", "1") == "1"
 CONV3X3_SB_WRW_CHANNELS = tuple(int(c) for c in os.environ.get("CSEG_CONV3X3_SB_WRW_CHANNELS", "48,96,192,384,720").split(","))
 
 
+# (Cin, Cout) pairs with different channel counts that take the split weight gradient too: transition 1 of HRNet (256 -> 48)
+CONV3X3_SB_WRW_PAIRS = ((256, 48),)
+
+
 def conv3x3_sb_wrw_eligible(x, dy):
     """Shapes the kernel covers (NCHW fp32, Cin % 16, Cout % 48, width % 32: 64-pixel row segments, 32-pixel ones for the
     16 x 32 maps of the 384-channel branch)."""
@@ -954,8 +958,8 @@ def conv3x3_sb_wrw_eligible(x, dy):
 
 def conv3x3_sb_wrw_wanted(x, dy):
     """The autograd path takes the split-bf16 weight gradient: switched on, covered, and a channel count it was timed on."""
-    return (CONV3X3_SB_WRW and x.shape[1] == dy.shape[1] and x.shape[1] in CONV3X3_SB_WRW_CHANNELS
-            and conv3x3_sb_wrw_eligible(x, dy))
+    same = x.shape[1] == dy.shape[1] and x.shape[1] in CONV3X3_SB_WRW_CHANNELS
+    return CONV3X3_SB_WRW and (same or (x.shape[1], dy.shape[1]) in CONV3X3_SB_WRW_PAIRS) and conv3x3_sb_wrw_eligible(x, dy)
 
 
 @torch.no_grad()
@@ -1044,7 +1048,7 @@ def conv3x3_s2_fwd_eligible(x, weight):
 
 def conv3x3_s2_bwd_eligible(x, weight):
     co, ci = weight.shape[:2]
-    return _s2_base_ok(x, weight) and co % 16 == 0 and ci % 48 == 0 and x.shape[3] % 4 == 0
+    return _s2_base_ok(x, weight) and co % 16 == 0 and (ci % 48 == 0 or ci % 64 == 0) and x.shape[3] % 4 == 0
 
 
 def conv3x3_s2_wrw_eligible(x, weight):
@@ -1055,6 +1059,8 @@ def conv3x3_s2_wrw_eligible(x, weight):
 def conv3x3_s2_pick_nt(B, Ho, Wo, c_out):
     """16-channel tiles per block: 6 when the grid still has >= 256 blocks of 4 x 64 outputs, else 3."""
     spatial = B * ((Ho + 3) // 4) * ((Wo + 63) // 64)
+    if c_out % 48:
+        return 4                                         # 256 channels (input side of transition 1)
     return 6 if c_out % 96 == 0 and spatial * (c_out // 96) >= 256 else 3
 
 

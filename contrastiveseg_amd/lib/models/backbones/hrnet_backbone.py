@@ -27,8 +27,8 @@ def _conv_bn(cin, cout, k, stride, bn_type, momentum, relu):
     """conv -> BN [-> ReLU]; the ReLU (stateless third child in the reference) is fused into the norm kernel."""
     if k == 1 and stride == 1:
         conv = Conv1x1(cin, cout, bias=False)
-    elif k == 3 and stride == 2:
-        conv = Conv3x3(cin, cout, 2)                     # an nn.Conv2d(cin, cout, 3, 2, 1, bias=False); split kernels where covered
+    elif k == 3 and stride in (1, 2):
+        conv = Conv3x3(cin, cout, stride)                # an nn.Conv2d(cin, cout, 3, stride, 1, bias=False); split kernels where covered
     else:
         conv = nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=False)
     return nn.Sequential(conv,

@@ -29,12 +29,13 @@ class Conv3x3(nn.Conv2d):
 
     def forward(self, x):
         from contrastiveseg_amd import kernels as K
-        if K._on_device(x) and self.stride == (1, 1) and self.dilation == (1, 1) and self.in_channels == self.out_channels:
-            if (K.CONV3X3_SPLIT_BF16 and self.in_channels in K.CONV3X3_SB_BRANCH_CHANNELS
+        pair = (self.in_channels, self.out_channels) in K.CONV3X3_SB_WRW_PAIRS        # transition 1: 256 -> 48
+        if K._on_device(x) and self.stride == (1, 1) and self.dilation == (1, 1) and (self.in_channels == self.out_channels or pair):
+            if (K.CONV3X3_SPLIT_BF16 and (pair or self.in_channels in K.CONV3X3_SB_BRANCH_CHANNELS)
                     and K.conv3x3_sb_eligible(x, self.weight)
                     and K.conv3x3_sb_tiles(x, self.out_channels) >= K.CONV3X3_SB_MIN_TILES):
                 return K.conv3x3_split_bf16(x, self.weight)
-            if self.in_channels in self.MFMA_CHANNELS and K.conv3x3_eligible(x, self.weight):
+            if not pair and self.in_channels in self.MFMA_CHANNELS and K.conv3x3_eligible(x, self.weight):
                 return K.conv3x3(x, self.weight)
         if (K._on_device(x) and self.stride == (2, 2) and self.dilation == (1, 1)
                 and (K.conv3x3_s2_fwd_eligible(x, self.weight) or K.conv3x3_s2_wrw_eligible(x, self.weight))):

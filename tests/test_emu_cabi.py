@@ -200,6 +200,13 @@ def test_stride2_module_matches_fp64(kw, monkeypatch):
     mod.test_stride2_module_matches_fp64(monkeypatch=monkeypatch, **kw)
 
 
+def test_transition_256_to_48_module_matches_fp64(monkeypatch):
+    inject.install(monkeypatch)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)
+    importlib.import_module("test_gpu_conv3x3_s2").test_transition_256_to_48_module_matches_fp64(monkeypatch=monkeypatch)
+
+
 # ---- row-sparse projection-head backward with the PRODUCT's deposit path (kernels.PixelContrast / GatherAnchors) ---------
 @pytest.mark.parametrize("loss_type", ["contrast_ce_loss", "mem_contrast_ce_loss"])
 def test_sparse_embed_route_equals_dense_route(loss_type, monkeypatch):

@@ -324,3 +324,31 @@ def test_stride2_weight_gradient(case, rpu, wave_order, monkeypatch):
     assert not np.isnan(dw).any()
     assert np.abs(dw - ref).max() <= 3e-6 * np.sqrt(B * Ho * Wo) * float(np.abs(ref).max())
     assert np.array_equal(dw, E.conv3x3_s2_wrw(x, dy))          # fixed-order reduction: bit-identical on a second run
+
+
+# ---- transition 1 of HRNet (256 -> 48 at stride 1, 256 -> 96 at stride 2): channel counts that are multiples of 64, not of 48 ------
+def test_transition_layer_256_to_48(wave_order):
+    """forward (conv_out 48, 16 chunks streamed), backward-data (conv_out 256: four channel tiles per block, 16-channel-chunk
+    kernel), weight gradient with different channel counts (four 64-wide input blocks)"""
+    B, ci, co, H, W = 1, 256, 48, 5, 64
+    x, w, dy = _rand((B, ci, H, W), 81, 2.0), _rand((co, ci, 3, 3), 82, 0.05), _rand((B, co, H, W), 83, 1e-3)
+    y = E.conv3x3_sb(x, w, arith=E.F16X3)
+    ref = E.ref_conv3x3(x, w)
+    assert not np.isnan(y).any() and np.abs(y - ref).max() <= _bound(ref, 9 * ci)
+    dx = E.conv3x3_sb(dy, w, transpose_flip=True, arith=E.F16X3)
+    ref = E.ref_conv3x3_bwd_data(dy, w)
+    assert dx.shape == (B, ci, H, W) and not np.isnan(dx).any()
+    assert np.abs(dx - ref).max() <= 3e-6 * np.sqrt(9 * co) * float(np.abs(ref).max())
+    dw = E.conv3x3_sb_wrw(x, dy, arith=E.F16X3)
+    ref = E.ref_conv3x3_wrw(x, dy)
+    assert not np.isnan(dw).any() and np.abs(dw - ref).max() <= 3e-6 * np.sqrt(B * H * W) * float(np.abs(ref).max())
+
+
+def test_stride2_backward_data_256_input_channels(wave_order):
+    """256 -> 96 at stride 2: dx has 256 channels = four tiles per block"""
+    B, ci, co, Ho, Wo = 1, 256, 96, 3, 34
+    dy, w = _rand((B, co, Ho, Wo), 84, 1e-3), _rand((co, ci, 3, 3), 85, 0.05)
+    dx = E.conv3x3_s2_bwd(dy, w, 4)
+    ref = E.ref_conv3x3_s2_bwd_data(dy, w)
+    assert not np.isnan(dx).any()
+    assert np.abs(dx - ref).max() <= 3e-6 * np.sqrt(4 * co) * float(np.abs(ref).max())

@@ -12,7 +12,7 @@ S2_CASES = [  # B, Cin, Cout, Ho, Wo
     (2, 48, 96, 8, 64),          # the shape class of the fuse layers (48 -> 96)
     (1, 96, 192, 6, 96),         # two column tiles, the second ragged; two input-channel blocks in the weight gradient
     (2, 192, 384, 4, 32),        # the widest pair of HRNet-W48
-    (1, 256, 96, 8, 64),         # transition 1: no 48-multiple on the input side -> its backward-data stays on MIOpen
+    (1, 256, 96, 8, 64),         # transition 1: 256 input channels = four channel tiles per block in the backward-data kernel
 ]
 
 
@@ -54,7 +54,7 @@ def test_stride2_module_matches_fp64(case, monkeypatch):
     xr, wr = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
     yr = F.conv2d(xr, wr, None, 2, 1)
     yr.backward(dy.cuda())
-    want = ["conv3x3_s2_run"] + (["conv3x3_s2_bwd_run"] if ci % 48 == 0 else []) + (["conv3x3_s2_wrw"] if Wo % 32 == 0 else [])
+    want = ["conv3x3_s2_run", "conv3x3_s2_bwd_run"] + (["conv3x3_s2_wrw"] if Wo % 32 == 0 else [])
     assert calls == want, (calls, want)
     for name, ref, got, fp32 in (("y", y64.detach(), y.detach(), yr.detach()), ("dx", x64.grad, xd.grad, xr.grad),
                                  ("dw", w64.grad, conv.weight.grad, wr.grad)):
@@ -85,3 +85,37 @@ def test_stride2_at_the_benched_shapes():
         for name, got, ref in (("y", K.conv3x3_s2_run(xd, wd), yr.detach()), ("dx", K.conv3x3_s2_bwd_run(dyd, wd), xr.grad),
                                ("dw", K.conv3x3_s2_wrw(xd, dyd), wr.grad)):
             assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (ci, co, name)
+
+
+def test_transition_256_to_48_module_matches_fp64(monkeypatch):
+    """module_helper.Conv3x3(256, 48): the stride-1 transition of HRNet (reference hrnet_backbone.py:635-645) -- forward on the
+    16-channel-chunk kernel with streamed weights, backward-data with four channel tiles per block (256 output channels of the
+    operator), weight gradient with four 64-wide input-channel blocks; all three checked against fp64."""
+    from contrastiveseg_amd import kernels as K
+    from contrastiveseg_amd.lib.models.tools.module_helper import Conv3x3
+    monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
+    B, ci, co, H, W = 2, 256, 48, 12, 64
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, ci, H, W, generator=g).relu_()
+    w = torch.randn(co, ci, 3, 3, generator=g) / (3.0 * ci ** 0.5)
+    dy = torch.randn(B, co, H, W, generator=g) * 1e-3
+    calls = []
+    for name in ("conv3x3_sb_run", "conv3x3_sb_wrw"):
+        monkeypatch.setattr(K, name, (lambda fn, name: lambda *a, **k: (calls.append(name), fn(*a, **k))[1])(getattr(K, name), name))
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, None, 1, 1)
+    y64.backward(dy.double())
+    conv = Conv3x3(ci, co).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(w.cuda())
+    xd = x.cuda().requires_grad_(True)
+    y = conv(xd)
+    y.backward(dy.cuda())
+    xr, wr = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, 1)
+    yr.backward(dy.cuda())
+    assert calls == ["conv3x3_sb_run", "conv3x3_sb_run", "conv3x3_sb_wrw"], calls
+    for name, ref, got, fp32 in (("y", y64.detach(), y.detach(), yr.detach()), ("dx", x64.grad, xd.grad, xr.grad),
+                                 ("dw", w64.grad, conv.weight.grad, wr.grad)):
+        err, tol = _bound(ref, got.cpu(), fp32.cpu())
+        assert err <= tol, (name, err, tol)
