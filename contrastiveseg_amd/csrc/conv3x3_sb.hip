@@ -41,6 +41,8 @@ namespace cseg_sb16 {
 size_t packed_bytes(int arith, int Cin, int Cout);
 int pack(const float* w, int Cout, int Cin, int transpose_flip, int NT, int arith, const unsigned* amax_w, void* wp,
          hipStream_t stream);
+int fwd8(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int arith, const unsigned* amax_x,
+         const unsigned* amax_w, float* y, hipStream_t stream);
 int fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int NT, int arith,
         const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream);
 }  // namespace cseg_sb16
@@ -479,11 +481,23 @@ int np_of(int arith) { return arith == CSEG_ARITH_F16X3 ? 2 : 3; }
 extern "C" size_t cseg_conv3x3_split_packed_bytes(int arith, int Cin, int Cout) {
     if (!arith_ok(arith) || Cin <= 0 || Cout <= 0 || Cin % 16 || pick_nt(Cout) == 0) return 0;
     if (use_sb16(Cout)) return cseg_sb16::packed_bytes(arith, Cin, Cout);
-    return (size_t)(Cout / 16) * steps_of(Cin) * np_of(arith) * 64 * sizeof(uint4);
+    const size_t own = (size_t)(Cout / 16) * steps_of(Cin) * np_of(arith) * 64 * sizeof(uint4);
+    if (arith == CSEG_ARITH_F16X3 && Cout % 144 == 0) {          // nt = CSEG_NT_SB8 packs the 16-channel-chunk format: room for either
+        const size_t alt = cseg_sb16::packed_bytes(arith, Cin, Cout);
+        return alt > own ? alt : own;
+    }
+    return own;
 }
 
 extern "C" int cseg_conv3x3_split_plan(int conv_in, int conv_out, int nt_request, int* kind, int* nt, long* threads) {
     if (!kind || !nt || !threads || conv_in <= 0 || conv_out <= 0 || conv_in % 16 || pick_nt(conv_out) == 0) return 0;
+    if (nt_request == CSEG_NT_SB8) {                             // the 8-row head kernel: 16-channel-chunk format, nine tiles
+        if (conv_out % 144) return 0;
+        *kind = CSEG_PACK_C3_16;
+        *nt = 9;
+        *threads = (long)(conv_out / 16) * pack_steps_c3_16(conv_in) * 64;
+        return 1;
+    }
     if (use_sb16(conv_out)) {
         *kind = CSEG_PACK_C3_16;
         *nt = sb16_nt(conv_out, nt_request);
@@ -508,6 +522,10 @@ static int pack_impl(const float* w, int Cout, int Cin, int transpose_flip, int 
     const int conv_in = transpose_flip ? Cout : Cin, conv_out = transpose_flip ? Cin : Cout;
     CSEG_REQUIRE(w && wp, "conv3x3_sb_pack_weights: null pointer");
     CSEG_REQUIRE(arith_ok(arith) && (arith == CSEG_ARITH_BF16X6 || amax_w), "conv3x3 split pack: arithmetic %d needs max|w|", arith);
+    if (NT == CSEG_NT_SB8) {
+        CSEG_REQUIRE(arith == CSEG_ARITH_F16X3 && conv_out % 144 == 0, "conv3x3 split pack: nt = CSEG_NT_SB8 needs f16x3 and output channels %% 144");
+        return cseg_sb16::pack(w, Cout, Cin, transpose_flip, 9, arith, amax_w, wp, stream);
+    }
     if (use_sb16(conv_out)) return cseg_sb16::pack(w, Cout, Cin, transpose_flip, sb16_nt(conv_out, NT), arith, amax_w, wp, stream);
     if (NT == 0) NT = pick_nt(conv_out);
     CSEG_REQUIRE(conv_in % 16 == 0 && NT > 0 && nt_ok(NT, conv_out),
@@ -541,7 +559,7 @@ extern "C" int cseg_conv3x3_sb_pack_weights_nt(const float* w, int Cout, int Cin
 // nt = 0: the library's channel tiling. arith: CSEG_ARITH_BF16X6 (amax_w may be null) | CSEG_ARITH_F16X3 (amax_w = max|w| bits)
 extern "C" int cseg_conv3x3_split_pack(const float* w, int Cout, int Cin, int transpose_flip, int nt, int arith,
                                        const unsigned* amax_w, void* wp, cseg_stream_t stream_) {
-    CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9, "conv3x3_split_pack: nt must be 0, 3, 6 or 9 (got %d)", nt);
+    CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9 || nt == CSEG_NT_SB8, "conv3x3_split_pack: nt must be 0, 3, 6, 9 or CSEG_NT_SB8 (got %d)", nt);
     return pack_impl(w, Cout, Cin, transpose_flip, nt, arith, amax_w, wp, (hipStream_t)stream_);
 }
 
@@ -550,6 +568,11 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, int B, in
     CSEG_REQUIRE(x && wp && y, "conv3x3_sb: null pointer");
     CSEG_REQUIRE(arith_ok(arith) && (arith == CSEG_ARITH_BF16X6 || (amax_x && amax_w)),
                  "conv3x3 split: arithmetic %d needs max|x| and max|w|", arith);
+    if (NT == CSEG_NT_SB8) {
+        CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && W % 4 == 0,
+                     "conv3x3_sb: packed weights / output must be 16-byte aligned and W a multiple of 4");
+        return cseg_sb16::fwd8(x, wp, bias, B, Cin, Cout, H, W, arith, amax_x, amax_w, y, stream);
+    }
     if (use_sb16(Cout)) {
         CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && W % 4 == 0,
                      "conv3x3_sb: packed weights / output must be 16-byte aligned and W a multiple of 4");
@@ -623,7 +646,7 @@ extern "C" int cseg_conv3x3_sb_fwd_nt(const float* x, const void* wp, const floa
 extern "C" int cseg_conv3x3_split_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
                                       int nt, int arith, const unsigned* amax_x, const unsigned* amax_w, float* y,
                                       cseg_stream_t stream_) {
-    CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9, "conv3x3_split_fwd: nt must be 0, 3, 6 or 9 (got %d)", nt);
+    CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9 || nt == CSEG_NT_SB8, "conv3x3_split_fwd: nt must be 0, 3, 6, 9 or CSEG_NT_SB8 (got %d)", nt);
     return fwd_impl(x, wp, bias, B, Cin, Cout, H, W, nt, arith, amax_x, amax_w, y, (hipStream_t)stream_);
 }
 

@@ -458,7 +458,235 @@ int launch_sb16(const float* x, const uint4* wp, const float* bias, int B, int C
 
 }  // namespace
 
-// Reached from the cseg_conv3x3_sb_* / cseg_conv3x3_split_* entry points of conv3x3_sb.hip (NT = 3 or 6).
+// ---------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 split f16x3 convolution, variant for the HEAD (720 -> 720 at 8 x 128 x 256; 44 % of the forward FLOPs of
+// HRNet-W48-contrast, lib/models/nets/hrnet.py:72-77 of the reference): a block owns 8 rows x 64 columns x 144 output channels.
+// Why: conv3x3_sb_kernel<9> moves 24 KB per K-step from L2 for a 4 x 64-pixel tile -- 18.4 KB of
+// packed weights and 5.6 KB of patch for 1 824 MFMA cycles per SIMD = 13 B per cycle and CU, above the ~10 B/cycle/CU a CU
+// sustains; with every global access removed it runs in 4.1 instead of 5.5 ms. Twice the pixels per block halve the weight bytes
+// per MFMA (7 B/cycle/CU). What that costs and how it is paid:
+//   * 144 accumulator registers per wave (one row = 4 pixel tiles x 9 channel tiles): little else may live in registers across
+//     the MFMAs, so the fp32 patch does NOT travel through registers. It is brought in by LDS-DMA (global_load_lds, one dword per
+//     lane, one patch row per instruction with a scalar base, the image border clamped) into a raw staging area while the MFMAs of
+//     the previous chunk run,
+//     and a short split phase between two chunks turns it into the [piece][octet][cell] image of 16-byte cells the fragments are
+//     read from (8 strided ds_read_b32 -> packed split -> 2 ds_write_b128 per item; ~130 VALU instructions per wave and chunk
+//     against 600 MFMAs);
+//   * LDS: 16-channel chunks (pieces 43 KB + raw 42.2 KB + 2 weight stages 36.9 KB = 122 KB); the K-step pairs two taps x 16
+//     channels like conv3x3_sb16.hip (same packed weights, CSEG_PACK_C3_16 with 9 channel tiles; the tenth tap slot is zero: 11 %
+//     more MFMA slots than taps).
+// Wave = one output row of the tile; per K-step a wave keeps its 4 pixel tiles' fragments x 2 pieces in registers and streams the
+// nine channel tiles' weight fragments: 26 ds_read_b128 for 108 MFMAs. Weights: LDS-DMA, double-buffered, one K-step ahead,
+// one barrier per K-step (1 920 MFMA cycles). f16x3 only.
+// Selected with nt = CSEG_NT_SB8 through the cseg_conv3x3_split_* entry points (pack and forward must use the same nt).
+namespace sb8 {
+
+constexpr int R8 = 8, C8 = 64;                  // output rows / columns per block
+constexpr int XR = R8 + 2, XC = C8 + 2;         // patch: 10 x 66 pixels, cell (0, 0) = pixel (y0 - 1, x0 - 1)
+constexpr int CELLS8 = XR * XC;                 // 660
+constexpr int PLANE8 = 672;                     // LDS stride of a (piece, octet) plane: 0 mod 256 bytes
+constexpr int RAW_LINES = 16 * XR;              // 160 (channel, patch row) lines per chunk
+constexpr int RAW_MAIN = RAW_LINES * 64;        // floats: patch columns 0 .. 63 of every line, one DMA instruction per line
+constexpr int RAW_EXTRA = RAW_LINES * 2;        // patch columns 64, 65 of every line: 5 more instructions
+constexpr int RAW_FLOATS = RAW_MAIN + RAW_EXTRA;
+constexpr int S_ITEMS = 2 * CELLS8;             // (octet, cell) items of the split phase: 1 320
+constexpr int S_U = (S_ITEMS + 511) / 512;      // 3 per thread
+constexpr int NT = 9;
+constexpr int STEPS = 5;
+
+// One K-step of a wave: its row's four pixel tiles (fragments resident: 8 registers x 4) x all nine channel tiles (weight
+// fragments streamed, two at a time) x three piece products; term-major, four independent accumulators between dependent MFMAs.
+template <class AR>
+__device__ __forceinline__ void kstep8(const uint4* __restrict__ ap, const uint4* __restrict__ bp, f32x4 (&acc)[4][NT]) {
+    typedef typename AR::frag_t frag_t;
+    frag_t a[4][AR::NP];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int p = 0; p < AR::NP; ++p) a[mt][p] = __builtin_bit_cast(frag_t, ap[p * 2 * PLANE8 + 16 * mt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        frag_t b[AR::NP];
+#pragma unroll
+        for (int p = 0; p < AR::NP; ++p) b[p] = __builtin_bit_cast(frag_t, bp[(nt * AR::NP + p) * 64]);
+#pragma unroll
+        for (int t = 0; t < AR::NTERMS; ++t)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = AR::mfma(a[mt][AR::ta(t)], b[AR::tb(t)], acc[mt][nt]);
+    }
+}
+
+__device__ __forceinline__ void store8(const f32x4 (&acc)[4][NT], float* __restrict__ ybc, const float* __restrict__ bias, int co0,
+                                       size_t plane, int yy, int x0, int W, int g, int n, float unscale) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float bv = bias ? bias[co0 + nt * 16 + n] : 0.f;
+        float* orow = ybc + (size_t)(co0 + nt * 16 + n) * plane + (size_t)yy * W;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int xx = x0 + 16 * mt + 4 * g;
+            f32x4 v = acc[mt][nt] * unscale;
+            v += bv;
+            if (xx + 3 < W) *reinterpret_cast<float4*>(orow + xx) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+                if (xx < W) orow[xx] = v[0];
+                if (xx + 1 < W) orow[xx + 1] = v[1];
+                if (xx + 2 < W) orow[xx + 2] = v[2];
+            }
+        }
+    }
+}
+
+template <class AR>
+__global__ __launch_bounds__(512, 1) void conv3x3_sb8_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
+                                                             const float* __restrict__ bias, int Cin, int Cout, int H, int W,
+                                                             int tiles_x, int tiles_y, const unsigned* __restrict__ amax_x,
+                                                             const unsigned* __restrict__ amax_w, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_s8[];
+    constexpr int NP = AR::NP;
+    constexpr int A_CELLS = NP * 2 * PLANE8;
+    constexpr int BSTEP = NT * NP * 64;
+    uint4* As = smem_s8;                                       // [piece][octet 2][PLANE8]
+    uint4* Bs = smem_s8 + A_CELLS;                             // [2][BSTEP]
+    float* Raw = reinterpret_cast<float*>(Bs + 2 * BSTEP);     // [16 ch x 10 rows][64] + [16 ch x 10 rows][2]
+    const unsigned ex = split_amax_exp(amax_x), ew = split_amax_exp(amax_w);
+    const float xscale = split_scale_of(ex);
+
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int row = wave;                          // one output row of the tile per wave
+    const int g = lane >> 4, n = lane & 15;
+    const int n_cot = Cout / (NT * 16);
+    const size_t plane = (size_t)H * W;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    const int cot = t % n_cot;
+    const int b = t / n_cot;
+    const int x0 = tx * C8, y0 = ty * R8;
+    const int n_chunks = Cin / 16;
+    const int n_steps = n_chunks * STEPS;
+    const uint4* wbase = wp + (size_t)cot * n_steps * BSTEP;
+
+    auto b_glds = [&](int ks, int buf) {
+#pragma unroll
+        for (int i = 0; i < (NT * NP + 7) / 8; ++i) {
+            const int r = wave + 8 * i;
+            if (r < NT * NP)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(wbase + (size_t)ks * BSTEP + r * 64 + lane),
+                    (__attribute__((address_space(3))) void*)(Bs + buf * BSTEP + r * 64), 16, 0, 0);
+        }
+    };
+
+    // raw patch of one 16-channel chunk by LDS-DMA. Main part: instruction `line` (= channel * 10 + patch row, 160 per chunk)
+    // fetches patch columns 0 .. 63 of that line, lane = column: scalar base (chunk, channel, row) + one per-lane column offset
+    // that never changes -> no vector address arithmetic. Columns 64, 65 of all lines: five more instructions with a fixed
+    // per-lane offset. Wave w issues lines w, w + 8, ... and extra instruction w (w < 5); the issue is spread over the five
+    // K-steps of the previous chunk (`part` = 0 .. 4; part < 0: everything) so that no barrier waits for a whole chunk at once.
+    // Border pixels are fetched from the nearest pixel inside the image (any finite value: the split phase writes zeros there).
+    const int col_off = min(max(x0 - 1 + lane, 0), W - 1);
+    int extra_off;                                 // element offset inside a chunk of this lane's extra pixel
+    {
+        const int line = min(32 * wave + (lane >> 1), RAW_LINES - 1), e = lane & 1;
+        const int ch = line / XR, r = line - ch * XR;
+        extra_off = ch * (int)plane + min(max(y0 - 1 + r, 0), H - 1) * W + min(max(x0 - 1 + 64 + e, 0), W - 1);
+    }
+    auto raw_dma = [&](int chunk, int part) {
+        const float* xc = x + ((size_t)b * Cin + (size_t)chunk * 16) * plane;
+#pragma unroll 1
+        for (int i = (part < 0 ? 0 : part); i < RAW_LINES / 8; i += (part < 0 ? 1 : STEPS)) {
+            const int line = wave + 8 * i;                              // uniform
+            const int ch = line / XR, r = line - ch * XR;
+            const float* rowp = xc + (size_t)ch * plane + (size_t)min(max(y0 - 1 + r, 0), H - 1) * W;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp + col_off),
+                                             (__attribute__((address_space(3))) void*)(Raw + 64 * line), 4, 0, 0);
+        }
+        if (wave < RAW_EXTRA / 64 && part <= 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xc + extra_off),
+                                             (__attribute__((address_space(3))) void*)(Raw + RAW_MAIN + 64 * wave), 4, 0, 0);
+    };
+
+    // split phase: item = (octet, cell); everything about an item is fixed for the block
+    int s_raw[S_U], s_dst[S_U], s_chs[S_U];
+    bool s_do[S_U], s_in[S_U];
+#pragma unroll
+    for (int u = 0; u < S_U; ++u) {
+        const int item = tid + 512 * u, itc = min(item, S_ITEMS - 1);
+        const int oct = itc / CELLS8, cell = itc - oct * CELLS8;
+        const int r = cell / XC, c = cell - r * XC;
+        // raw position of channel 0 of the octet and the stride to the next channel (main part / extra columns)
+        s_raw[u] = c < 64 ? (oct * 8 * XR + r) * 64 + c : RAW_MAIN + (oct * 8 * XR + r) * 2 + (c - 64);
+        s_chs[u] = c < 64 ? XR * 64 : XR * 2;
+        s_dst[u] = oct * PLANE8 + cell;
+        s_do[u] = item < S_ITEMS;
+        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+        s_in[u] = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    }
+    auto split_phase = [&]() {
+#pragma unroll
+        for (int u = 0; u < S_U; ++u) {
+            if (s_do[u]) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float rv = Raw[s_raw[u] + j * s_chs[u]];
+                    v[j] = s_in[u] ? rv : 0.f;
+                }
+                uint4 cells[NP];
+                split_cells8<AR>(v, xscale, cells);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) As[p * 2 * PLANE8 + s_dst[u]] = cells[p];
+            }
+        }
+    };
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    raw_dma(0, -1);
+    b_glds(0, 0);
+    __syncthreads();                               // (the fence of the barrier waits for this wave's DMA; the barrier for everyone's)
+    split_phase();
+    __syncthreads();
+
+    const uint4* a_lane = As + row * XC + n;
+    const uint4* b_lane = Bs + lane;
+    int ks = 0, buf = 0;
+#pragma unroll 1
+    for (int c = 0; c < n_chunks; ++c) {
+#pragma unroll 1
+        for (int s = 0; s < STEPS; ++s) {
+            if (ks + 1 < n_steps) b_glds(ks + 1, buf ^ 1);              // that stage was last read in step ks - 1 (barrier since)
+            if (c + 1 < n_chunks) raw_dma(c + 1, s);                    // a fifth of the next chunk's raw patch (Raw is free: split
+                                                                        // phase of this chunk + barrier are behind us)
+            const int tap = min(2 * s + (g >> 1), 8);                   // the tenth tap slot multiplies zero weights
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int a_off = (g & 1) * PLANE8 + ky * XC + kx;
+            kstep8<AR>(a_lane + a_off, b_lane + buf * BSTEP, acc);
+            __syncthreads();
+            buf ^= 1;
+            ++ks;
+        }
+        if (c + 1 < n_chunks) {
+            split_phase();                         // raw chunk c + 1 landed before the last barrier (its fence waited for the DMA)
+            __syncthreads();
+        }
+    }
+
+    float* ybc = y + (size_t)b * Cout * plane;
+    const int co0 = cot * NT * 16;
+    const float unscale = split_unscale_of(ex) * split_unscale_of(ew);
+    if (y0 + row < H) store8(acc, ybc, bias, co0, plane, y0 + row, x0, W, g, n, unscale);
+}
+
+constexpr size_t lds_bytes() { return sizeof(uint4) * (2 * 2 * PLANE8 + 2 * NT * 2 * 64) + sizeof(float) * RAW_FLOATS; }      // 122 112
+
+}  // namespace sb8
+
+// Reached from the cseg_conv3x3_sb_* / cseg_conv3x3_split_* entry points of conv3x3_sb.hip (NT = 3, 4, 6; 9 = the 8-row head kernel).
 namespace cseg_sb16 {
 
 size_t packed_bytes(int arith, int Cin, int Cout) {
@@ -468,8 +696,8 @@ size_t packed_bytes(int arith, int Cin, int Cout) {
 int pack(const float* w, int Cout, int Cin, int transpose_flip, int NT, int arith, const unsigned* amax_w, void* wp,
          hipStream_t stream) {
     const int conv_in = transpose_flip ? Cout : Cin, conv_out = transpose_flip ? Cin : Cout;
-    CSEG_REQUIRE((NT == 3 || NT == 4 || NT == 6) && conv_out % (NT * 16) == 0 && conv_in % 16 == 0,
-                 "conv3x3_sb16: needs 3, 4 or 6 channel tiles per block (got %d) and input channels %% 16 == 0", NT);
+    CSEG_REQUIRE((NT == 3 || NT == 4 || NT == 6 || NT == 9) && conv_out % (NT * 16) == 0 && conv_in % 16 == 0,
+                 "conv3x3_sb16: needs 3, 4, 6 or 9 channel tiles per block (got %d) and input channels %% 16 == 0", NT);
     const long total = (long)(conv_out / 16) * steps16(conv_in) * 64;
     CSEG_REQUIRE(total < 2147483647L, "conv3x3_sb16 pack: too large");
     if (arith == CSEG_ARITH_F16X3)
@@ -506,6 +734,31 @@ int fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int C
     if (NT == 6) return launch_sb16<SplitBF16x6, 6>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
     if (NT == 4) return launch_sb16<SplitBF16x6, 4>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
     return launch_sb16<SplitBF16x6, 3>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+}
+
+// the 8-row head kernel (namespace sb8 above): f16x3, 9 channel tiles per block, weights packed by pack(..., NT = 9, ...)
+int fwd8(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int arith, const unsigned* amax_x,
+         const unsigned* amax_w, float* y, hipStream_t stream) {
+    CSEG_REQUIRE(arith == CSEG_ARITH_F16X3 && amax_x && amax_w, "conv3x3_sb8: f16x3 only (needs max|x| and max|w|)");
+    CSEG_REQUIRE(Cout % 144 == 0 && Cin % 16 == 0 && W % 4 == 0 && (long)H * W * 16 * 4 < 2147483647L,
+                 "conv3x3_sb8: unsupported shape Cin=%d Cout=%d %dx%d (needs Cout %% 144, Cin %% 16, W %% 4)", Cin, Cout, H, W);
+    const size_t lds = sb8::lds_bytes();
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)sb8::conv3x3_sb8_kernel<SplitF16x3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            cseg_set_error("conv3x3_sb8: cannot raise dynamic LDS to %zu bytes", lds);
+            return 0;
+        }
+        attr_set = true;
+    }
+    const int tiles_x = (W + sb8::C8 - 1) / sb8::C8, tiles_y = (H + sb8::R8 - 1) / sb8::R8;
+    const long n_tiles = (long)B * (Cout / 144) * tiles_y * tiles_x;
+    CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb8: grid too large");
+    hipLaunchKernelGGL(sb8::conv3x3_sb8_kernel<SplitF16x3>, dim3((unsigned)n_tiles), dim3(512), lds, stream, x, (const uint4*)wp, bias, Cin,
+                       Cout, H, W, tiles_x, tiles_y, amax_x, amax_w, y);
+    CSEG_CHECK_LAUNCH("conv3x3_sb8_kernel");
+    return 1;
 }
 
 }  // namespace cseg_sb16

@@ -881,6 +881,16 @@ def conv3x3_sb_eligible(x, weight):
     return (kh, kw) == (3, 3) and ok(ci) and ok(co) and x.shape[1] == ci and x.shape[3] % 4 == 0
 
 
+# nt value that selects the 8 x 64-pixel kernel (include/cseg_hip.h: CSEG_NT_SB8) for wide layers: f16x3, output channels % 144
+NT_SB8 = 0x109
+CONV3X3_SB8 = os.environ.get("CSEG_CONV3X3_SB8", "1") == "1"
+
+
+def conv3x3_sb_head_nt(c_out):
+    """nt for the layers whose operator has `c_out` output channels: NT_SB8 where the 8-row kernel applies, else 0 (library default)."""
+    return NT_SB8 if (CONV3X3_SB8 and SPLIT_ARITH == "f16x3" and c_out % 144 == 0) else 0
+
+
 def conv3x3_sb_pick_nt(x, c_out):
     """16-channel tiles per block: the largest of 9 / 6 / 3 that still gives the grid >= 256 blocks (one per CU), else
     the smallest that divides the channel count. Measured at 192 channels, 8x32x64: nt 3 (256 blocks) 81 us, nt 6 (128
@@ -996,7 +1006,8 @@ class Conv3x3SplitBF16(Function):
         ctx.has_bias = bias is not None
         ctx.pick = weight.shape[0] in CONV3X3_SB_PICK_NT_CHANNELS
         ctx.ax = amax_of(x) if split_arith_id() else None              # reused by the weight gradient
-        return conv3x3_sb_run(x, weight, False, bias, conv3x3_sb_pick_nt(x, weight.shape[0]) if ctx.pick else 0, ax=ctx.ax)
+        nt = conv3x3_sb_pick_nt(x, weight.shape[0]) if ctx.pick else conv3x3_sb_head_nt(weight.shape[0])
+        return conv3x3_sb_run(x, weight, False, bias, nt, ax=ctx.ax)
 
     @staticmethod
     def backward(ctx, dy):
@@ -1005,7 +1016,8 @@ class Conv3x3SplitBF16(Function):
         dy = dy.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = conv3x3_sb_run(dy, weight, True, None, conv3x3_sb_pick_nt(dy, weight.shape[1]) if ctx.pick else 0, ax=ady)
+            nt = conv3x3_sb_pick_nt(dy, weight.shape[1]) if ctx.pick else conv3x3_sb_head_nt(weight.shape[1])
+            dx = conv3x3_sb_run(dy, weight, True, None, nt, ax=ady)
         dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_db:

@@ -325,6 +325,11 @@ int cseg_conv1x1_sb_wrw(const float* x, const float* dy, int B, int Cin, int Cou
 #define CSEG_AMAX_STRIDE 32
 #define CSEG_AMAX_WORDS (CSEG_AMAX_SLOTS * CSEG_AMAX_STRIDE)
 int cseg_amax_f32(const float* x, long n, unsigned* amax_bits, cseg_stream_t stream);
+/* nt of the split 3x3 entry points: 0 = the library's channel tiling, 3 / 6 / 9 = explicit 16-channel tiles per block, or
+ * CSEG_NT_SB8 = the 8 x 64-pixel kernel for wide layers (f16x3 only, output channels % 144: the 720 -> 720 classifier-head convolution,
+ * lib/models/nets/hrnet.py:72-77): half the packed-weight bytes per MFMA of the 4 x 64 kernel. Pack and forward must use the same nt;
+ * cseg_conv3x3_split_packed_bytes already covers either format. */
+#define CSEG_NT_SB8 0x109
 size_t cseg_conv3x3_split_packed_bytes(int arith, int Cin, int Cout);
 int cseg_conv3x3_split_pack(const float* w, int Cout, int Cin, int transpose_flip, int nt, int arith, const unsigned* amax_w,
                             void* wp, cseg_stream_t stream);

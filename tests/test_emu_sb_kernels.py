@@ -352,3 +352,27 @@ def test_stride2_backward_data_256_input_channels(wave_order):
     ref = E.ref_conv3x3_s2_bwd_data(dy, w)
     assert not np.isnan(dx).any()
     assert np.abs(dx - ref).max() <= 3e-6 * np.sqrt(4 * co) * float(np.abs(ref).max())
+
+
+# ---- the 8 x 64-pixel head kernel (conv3x3_sb16.hip, namespace sb8; nt = CSEG_NT_SB8) ----------------------------------------------
+NT_SB8 = 0x109
+
+
+@pytest.mark.parametrize("case", [(1, 48, 144, 9, 68), (2, 16, 144, 8, 64), (1, 32, 288, 3, 20)])
+def test_head_kernel_8_rows(case, wave_order):
+    """ragged tiles both ways (9 rows = one full + one single-row tile, 68 columns), one / two / three 16-channel chunks (raw patch of
+    chunk c + 1 brought in by LDS-DMA in five parts during the K-steps of chunk c), two channel tile groups, bias, and the
+    backward-data operator (mirrored packing) of the same weights"""
+    B, ci, co, H, W = case
+    x, w, b = _rand((B, ci, H, W), 91, 3.0), _rand((co, ci, 3, 3), 92, 0.1), _rand((co,), 93)
+    y = E.conv3x3_sb(x, w, bias=b, nt=NT_SB8, arith=E.F16X3)
+    ref = E.ref_conv3x3(x, w, b)
+    assert not np.isnan(y).any()
+    assert np.abs(y - ref).max() <= _bound(ref, 9 * ci)
+    # backward-data: the operator maps co -> ci channels, so it needs ci % 144 == 0: use square weights
+    w2 = _rand((144, 144, 3, 3), 94, 0.05)
+    dy = _rand((1, 144, 5, 36), 95, 1e-3)
+    dx = E.conv3x3_sb(dy, w2, transpose_flip=True, nt=NT_SB8, arith=E.F16X3)
+    ref = E.ref_conv3x3_bwd_data(dy, w2)
+    assert not np.isnan(dx).any()
+    assert np.abs(dx - ref).max() <= 3e-6 * np.sqrt(9 * 144) * float(np.abs(ref).max())
