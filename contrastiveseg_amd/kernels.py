@@ -886,9 +886,16 @@ NT_SB8 = 0x109
 CONV3X3_SB8 = os.environ.get("CSEG_CONV3X3_SB8", "1") == "1"
 
 
-def conv3x3_sb_head_nt(c_out):
-    """nt for the layers whose operator has `c_out` output channels: NT_SB8 where the 8-row kernel applies, else 0 (library default)."""
-    return NT_SB8 if (CONV3X3_SB8 and SPLIT_ARITH == "f16x3" and c_out % 144 == 0) else 0
+def conv3x3_sb_head_nt(c_out, x=None):
+    """nt for the layers whose operator has `c_out` output channels: NT_SB8 where the 8-row kernel applies AND pays, else 0 (library
+    default). Measured on the MI355X (tools/sb8_probe.py, profiles/r03_sb8_probe.jsonl): 720 -> 720 at 8 x 128 x 256 (2 560 blocks)
+    5.28 vs 5.41 ms forward, 5.59 vs 5.74 backward-data; at batch 1 (320 blocks: 1.25 rounds of 256 CUs) 0.99 vs 0.88 ms and at
+    144 channels on 64 x 128 maps 124 vs 76 us -- so only launches of at least four rounds take it."""
+    if not (CONV3X3_SB8 and SPLIT_ARITH == "f16x3" and c_out % 144 == 0):
+        return 0
+    if x is not None and x.shape[0] * ((x.shape[2] + 7) // 8) * ((x.shape[3] + 63) // 64) * (c_out // 144) < 1024:
+        return 0
+    return NT_SB8
 
 
 def conv3x3_sb_pick_nt(x, c_out):
@@ -1006,7 +1013,7 @@ class Conv3x3SplitBF16(Function):
         ctx.has_bias = bias is not None
         ctx.pick = weight.shape[0] in CONV3X3_SB_PICK_NT_CHANNELS
         ctx.ax = amax_of(x) if split_arith_id() else None              # reused by the weight gradient
-        nt = conv3x3_sb_pick_nt(x, weight.shape[0]) if ctx.pick else conv3x3_sb_head_nt(weight.shape[0])
+        nt = conv3x3_sb_pick_nt(x, weight.shape[0]) if ctx.pick else conv3x3_sb_head_nt(weight.shape[0], x)
         return conv3x3_sb_run(x, weight, False, bias, nt, ax=ctx.ax)
 
     @staticmethod
@@ -1016,7 +1023,7 @@ class Conv3x3SplitBF16(Function):
         dy = dy.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            nt = conv3x3_sb_pick_nt(dy, weight.shape[1]) if ctx.pick else conv3x3_sb_head_nt(weight.shape[1])
+            nt = conv3x3_sb_pick_nt(dy, weight.shape[1]) if ctx.pick else conv3x3_sb_head_nt(weight.shape[1], dy)
             dx = conv3x3_sb_run(dy, weight, True, None, nt, ax=ady)
         dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]

@@ -175,6 +175,14 @@ def test_sb_autograd_matches_fp64(kw, wrw, monkeypatch):
     _replay_sb(monkeypatch, "test_autograd_matches_fp64", kw, [("CSEG_CONV3X3_SB_WRW_V", wrw)] if wrw != "0" else [])
 
 
+SB_HEAD8 = _cases("test_gpu_conv3x3_sb", "test_head_kernel_8_rows_matches_fp64", _SMALL)
+
+
+@pytest.mark.parametrize("kw", SB_HEAD8, ids=_ids(SB_HEAD8))
+def test_head_kernel_8_rows_matches_fp64(kw, monkeypatch):
+    _replay_sb(monkeypatch, "test_head_kernel_8_rows_matches_fp64", kw)
+
+
 SB_ONE = _cases("test_gpu_conv3x3_sb", "test_pointwise_matches_fp64", _SMALL)
 
 

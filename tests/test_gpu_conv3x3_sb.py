@@ -171,3 +171,26 @@ def test_pointwise_weight_gradient_matches_fp64(case):
     err, tol = _bound(ref, got.cpu(), fp32.cpu())
     assert err <= tol, (case, err, tol)
     assert torch.equal(got, K.conv1x1_sb_wrw(xd, dyd)), "weight gradient not deterministic"
+
+
+@pytest.mark.parametrize("case", [(1, 48, 144, 9, 68), (2, 720, 720, 8, 64)])
+def test_head_kernel_8_rows_matches_fp64(case):
+    """nt = CSEG_NT_SB8: the 8 x 64-pixel kernel the 720 -> 720 head takes at the benched batch (csrc/conv3x3_sb16.hip, namespace
+    sb8), forward with bias and the backward-data operator, against fp64 with MIOpen's fp32 result as the yardstick."""
+    from contrastiveseg_amd import kernels as K
+    B, ci, co, H, W = case
+    x, w, b = _inputs(*case, seed=11)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    got = K.conv3x3_sb_run(xd, wd, False, bd, K.NT_SB8).cpu()
+    err, tol = _bound(ref, got, F.conv2d(xd, wd, bd, 1, 1).cpu())
+    assert err <= tol, (case, err, tol)
+    if ci % 144 == 0:
+        dy = torch.randn(B, co, H, W, generator=torch.Generator().manual_seed(12))
+        x64 = x.double().requires_grad_(True)
+        F.conv2d(x64, w.double(), None, 1, 1).backward(dy.double())
+        xr = xd.clone().requires_grad_(True)
+        F.conv2d(xr, wd, None, 1, 1).backward(dy.cuda())
+        got = K.conv3x3_sb_run(dy.cuda(), wd, True, None, K.NT_SB8).cpu()
+        err, tol = _bound(x64.grad, got, xr.grad.cpu())
+        assert err <= tol, (case, "dx", err, tol)
