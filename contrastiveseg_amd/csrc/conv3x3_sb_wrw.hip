@@ -253,13 +253,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw_kernel(const float* __r
 // share a group, MI355X_MICROARCH.md): with address = n * pitch + 16 g bytes a pitch of 6 or 10 (mod 16) x 16 bytes is
 // conflict-free; round 2's 592 / 144 bytes (5 / 9 mod 16) cost 12 / 28 extra cycles per 64 lanes (round-3 counters:
 // SQ_LDS_BANK_CONFLICT = 55 % of SQ_LDS_IDX_ACTIVE). Three pieces (bf16x6) keep the old pitches: the new ones would not fit 160 KB.
-__host__ __device__ constexpr int x2_ch(int np, int segw) { return np == 2 ? (segw == 64 ? 304 : 176) : 4 * (segw + 8) + 8; }
+// Two pieces (f16x3), since the end of round 3: the row image starts 8 pixels left of the segment (entry i = pixel x0 - 8 + i, SEGW + 16
+// entries per slot), so that the CENTRE tap's fragment (pixels x0 + 8g ..) is one aligned cell with no register work, and the left /
+// right taps are that cell shifted by one half-word against the last dword of the cell in front / the first dword of the cell behind
+// (4 + 4 v_perm, two ds_read_b32). Before, all three taps were cut out of two cells (5 v_perm + 7 v_mov per piece and filter row:
+// the assembled centre fragment had to be copied into a contiguous register tuple) -- 144 -> ~100 VALU instructions per row-step on
+// the SIMD that issues the row-step's 162 MFMAs. Three pieces (bf16x6) keep the 4-pixel lead: the wider image would not fit.
+__host__ __device__ constexpr int x2_lead(int np) { return np == 2 ? 8 : 4; }
+__host__ __device__ constexpr int x2_slot(int np, int segw) { return segw + 2 * x2_lead(np); }        // entries per ring slot
+__host__ __device__ constexpr int x2_ch(int np, int segw) { return np == 2 ? (segw == 64 ? 336 : 208) : 4 * (segw + 8) + 8; }
 __host__ __device__ constexpr int d2_pitch(int np, int segw) { return np == 2 ? (segw == 64 ? 80 : 48) : segw + 8; }
 __host__ __device__ constexpr int x2_elems(int np, int segw) { return np * CI_B * x2_ch(np, segw); }
 __host__ __device__ constexpr int d2_elems(int np, int segw) { return 2 * np * CO_B * d2_pitch(np, segw); }
 
 template <int NP, int SEGW>
-__device__ __forceinline__ int x2_idx(int p, int ci, int slot, int i) { return (p * CI_B + ci) * x2_ch(NP, SEGW) + slot * (SEGW + 8) + i; }
+__device__ __forceinline__ int x2_idx(int p, int ci, int slot, int i) { return (p * CI_B + ci) * x2_ch(NP, SEGW) + slot * x2_slot(NP, SEGW) + i; }
 template <int NP, int SEGW>
 __device__ __forceinline__ int d2_idx(int buf, int p, int co, int i) { return ((buf * NP + p) * CO_B + co) * d2_pitch(NP, SEGW) + i; }
 
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
     typedef typename AR::frag_t frag_t;
     unsigned short* xs = smem_w;
     unsigned short* ds = smem_w + x2_elems(NP, SEGW);
-    constexpr int XCH = (SEGW + 8) / 4, XU = (CI_B * XCH + 255) / 256;       // float4 chunks per x row, per loader thread
+    constexpr int XCH = x2_slot(NP, SEGW) / 4, XU = (CI_B * XCH + 255) / 256;  // float4 chunks per x row, per loader thread
     constexpr int DCH = SEGW / 4, DU = (CO_B * DCH + 255) / 256;             // float4 chunks per dy row, per loader thread
     const unsigned ex = AR::SCALED ? split_amax_exp(amax_x) : 141u, ed = AR::SCALED ? split_amax_exp(amax_dy) : 141u;
     const float xscale = split_scale_of(ex), dscale = split_scale_of(ed);      // 1 for the unscaled arithmetic
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
         const int item = lt + 256 * u, itc = min(max(item, 0), CI_B * XCH - 1);
         const int ci = itc / XCH, c = itc - ci * XCH;
         xi_lds[u] = x2_idx<NP, SEGW>(0, ci, 0, 4 * c);
-        xi_px[u] = 4 * c - 4;
+        xi_px[u] = 4 * c - x2_lead(NP);
         xi_ch[u] = min(cib * CI_B + ci, Cin - 1);
         xi_ok[u] = loader && item < CI_B * XCH && cib * CI_B + ci < Cin;
     }
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
                 } else split_cells4<AR>(t, xscale, cells);
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    *reinterpret_cast<uint2*>(xs + xi_lds[u] + p * CI_B * x2_ch(NP, SEGW) + slot * (SEGW + 8)) = cells[p];
+                    *reinterpret_cast<uint2*>(xs + xi_lds[u] + p * CI_B * x2_ch(NP, SEGW) + slot * x2_slot(NP, SEGW)) = cells[p];
             }
         }
     };
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
     // A row-step is (SEGW / 32) x 3 groups (K-step, filter row) of 27 MFMAs x AR::NTERMS. Round 3: software-pipelined by hand --
     // the LDS reads of group i + 1 are issued before the MFMAs of group i (the compiler's own order waited on freshly issued reads
     // ~20 times per row-step, and with ONE consumer wave per SIMD nothing else can issue MFMAs meanwhile).
-    struct XRaw { uint4 c0[NP], c1[NP]; };
+    struct XRaw { uint4 c0[NP], c1[NP]; unsigned left[NP], right[NP]; };
     auto load_a = [&](int ks, int buf, frag_t (&a)[3][NP]) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -424,8 +432,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const unsigned short* src = xs + x2_idx<NP, SEGW>(p, wave * 16 + n, slot, 32 * ks + 8 * g);
-            r.c0[p] = *reinterpret_cast<const uint4*>(src);          // entries e .. e+7    (d0..d3)
-            r.c1[p] = *reinterpret_cast<const uint4*>(src + 8);      // entries e+8 .. e+15 (d4..d7)
+            if constexpr (NP == 2) {
+                r.c1[p] = *reinterpret_cast<const uint4*>(src + 8);           // entries e+8 .. e+15 = pixels x0 + 32 ks + 8 g .. + 7
+                r.left[p] = *reinterpret_cast<const unsigned*>(src + 6);      // entries e+6, e+7: the pixel in front in the high half
+                r.right[p] = *reinterpret_cast<const unsigned*>(src + 16);    // entries e+16, e+17: the pixel behind in the low half
+            } else {
+                r.c0[p] = *reinterpret_cast<const uint4*>(src);               // entries e .. e+7    (d0..d3)
+                r.c1[p] = *reinterpret_cast<const uint4*>(src + 8);           // entries e+8 .. e+15 (d4..d7)
+            }
         }
     };
     auto compute = [&](int s0, int buf, f32x4 (&acc)[9][3]) __attribute__((always_inline)) {
@@ -446,15 +460,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
             frag_t bfr[3][NP];                             // [kx][piece]
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                const uint4 c0 = xr[grp & 1].c0[p], c1 = xr[grp & 1].c1[p];
-                CSEG_KEEP_DWORD(c0.x);                     // whole cells: two ds_read_b128
-                CSEG_KEEP_DWORD(c1.w);
-                const unsigned a21 = __builtin_amdgcn_alignbit(c0.z, c0.y, 16), a32 = __builtin_amdgcn_alignbit(c0.w, c0.z, 16),
-                               a43 = __builtin_amdgcn_alignbit(c1.x, c0.w, 16), a54 = __builtin_amdgcn_alignbit(c1.y, c1.x, 16),
-                               a65 = __builtin_amdgcn_alignbit(c1.z, c1.y, 16);
-                bfr[0][p] = __builtin_bit_cast(frag_t, make_uint4(a21, a32, a43, a54));     // entries e+3 .. e+10 (kx = 0)
-                bfr[1][p] = __builtin_bit_cast(frag_t, make_uint4(c0.z, c0.w, c1.x, c1.y)); // entries e+4 .. e+11
-                bfr[2][p] = __builtin_bit_cast(frag_t, make_uint4(a32, a43, a54, a65));     // entries e+5 .. e+12
+                if constexpr (NP == 2) {
+                    const uint4 c = xr[grp & 1].c1[p];
+                    const unsigned lf = xr[grp & 1].left[p], rt = xr[grp & 1].right[p];
+                    bfr[0][p] = __builtin_bit_cast(frag_t, make_uint4(__builtin_amdgcn_alignbit(c.x, lf, 16), __builtin_amdgcn_alignbit(c.y, c.x, 16),
+                                                                      __builtin_amdgcn_alignbit(c.z, c.y, 16), __builtin_amdgcn_alignbit(c.w, c.z, 16)));
+                    bfr[1][p] = __builtin_bit_cast(frag_t, c);
+                    bfr[2][p] = __builtin_bit_cast(frag_t, make_uint4(__builtin_amdgcn_alignbit(c.y, c.x, 16), __builtin_amdgcn_alignbit(c.z, c.y, 16),
+                                                                      __builtin_amdgcn_alignbit(c.w, c.z, 16), __builtin_amdgcn_alignbit(rt, c.w, 16)));
+                } else {
+                    const uint4 c0 = xr[grp & 1].c0[p], c1 = xr[grp & 1].c1[p];
+                    const unsigned a21 = __builtin_amdgcn_alignbit(c0.z, c0.y, 16), a32 = __builtin_amdgcn_alignbit(c0.w, c0.z, 16),
+                                   a43 = __builtin_amdgcn_alignbit(c1.x, c0.w, 16), a54 = __builtin_amdgcn_alignbit(c1.y, c1.x, 16),
+                                   a65 = __builtin_amdgcn_alignbit(c1.z, c1.y, 16);
+                    bfr[0][p] = __builtin_bit_cast(frag_t, make_uint4(a21, a32, a43, a54));     // entries e+3 .. e+10 (kx = 0)
+                    bfr[1][p] = __builtin_bit_cast(frag_t, make_uint4(c0.z, c0.w, c1.x, c1.y)); // entries e+4 .. e+11
+                    bfr[2][p] = __builtin_bit_cast(frag_t, make_uint4(a32, a43, a54, a65));     // entries e+5 .. e+12
+                }
             }
             // term-major, smallest terms first; nine independent accumulators between two MFMAs on the same one
 #pragma unroll

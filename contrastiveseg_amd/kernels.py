@@ -1212,7 +1212,7 @@ def conv1x1_sb_run(x, weight, transpose=False, bias=None, ax=None):
 # weight gradient on the split kernel where it won in the round-2 driver pass (720x720: 2.98 vs 5.75 ms, 720x256: 0.96 vs 1.31 ms
 # on MIOpen; the 64 <-> 256 bottleneck convolutions lost: 0.30 vs 0.22 ms) -> both channel counts >= CONV1X1_SB_WRW_MIN_CH
 CONV1X1_SB_WRW = os.environ.get("CSEG_CONV1X1_SB_WRW", "1") == "1"
-CONV1X1_SB_WRW_MIN_CH = int(os.environ.get("CSEG_CONV1X1_SB_WRW_MIN_CH", "256"))
+CONV1X1_SB_WRW_MIN_CH = int(os.environ.get("CSEG_CONV1X1_SB_WRW_MIN_CH", "16"))      # round 3, lean loader: 98.2 ms/step at 256, 97.6 at 48, 96.8 at 16 (same box)
 
 
 def conv1x1_sb_wrw_eligible(x, dy):
