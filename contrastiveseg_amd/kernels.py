@@ -798,49 +798,55 @@ class SplitWeights(object):
             n_bytes = lib.cseg_conv1x1_split_packed_bytes(arith, conv_in, conv_out)
         if not ok or n_bytes == 0:
             raise RuntimeError("split convolution: unsupported channel counts %d -> %d (%s)" % (conv_in, conv_out, tag))
-        return {"wp": torch.empty(n_bytes, dtype=torch.uint8, device=weight.device), "kind": kind.value, "nt": nt.value,
-                "total": threads.value, "flag": int(bool(flag)), "version": None, "arith": arith}
+        wp = torch.empty(n_bytes, dtype=torch.uint8, device=weight.device)
+        return {"wp": wp, "wp_ptr": wp.data_ptr(), "kind": kind.value, "nt": nt.value, "total": threads.value, "flag": int(bool(flag)),
+                "version": None, "arith": arith}
 
     @torch.no_grad()
     def refresh(self):
+        """Host cost matters here: this runs at the top of every step, when the GPU has nothing queued behind the optimizer kernels
+        (tools/host_profile.py: 2.7 ms per step for the first version, which rebuilt ~1 000 Python tuples and ~1 300 tensor views per
+        step only to find the cached device tables unchanged). Now one pass over the entries collects what identifies the tables BY
+        VALUE (pointers, record rows, formats); the row tuples are only built on a cache miss."""
         arith = split_arith_id()
+        base = self.arena.data_ptr()
         stale, every = [], []
-        for st in list(self.weights.values()):
+        for st in list(self.weights.values()):               # (a copy: weak-reference callbacks may drop entries meanwhile)
             w = st["ref"]()
             if w is None or not _on_device(w) or w.device != self.arena.device:
                 continue
-            now = (w.data_ptr(), w._version)
-            every.append((w, st))
+            ptr = w.data_ptr()
+            now = (ptr, w._version)
+            every.append((ptr, w.numel(), st["row"]))
             for e in st["entries"].values():
                 if e["version"] != now and e["arith"] == arith:
                     stale.append((w, st, e, now))
         if not stale:
             return
         sp = _hip.stream_ptr()
+        rec = lambda row: base + row * AMAX_WORDS * 4                    # device address of a max|w| record (int32 words)
         if arith:
             # all records are re-accumulated (140 MB of weights: ~30 us), so one fill serves them all
             self.arena.zero_()
-            tab = self._table("amax", [(w.data_ptr(), 0, self._record(st).data_ptr(), 0, 0, 0, 0, 0, w.numel(),
-                                        max(1, min(64, w.numel() // 16384))) for w, st in every],
-                              tuple((w.data_ptr(), w.numel(), st["row"]) for w, st in every))
+            tab = self._table("amax", tuple(every),
+                              lambda: [(ptr, 0, rec(row), 0, 0, 0, 0, 0, n, max(1, min(64, n // 16384))) for ptr, n, row in every])
             _hip.call("cseg_amax_batch", tab[0].data_ptr(), tab[1], tab[2], sp)
-        tab = self._table("pack", [(w.data_ptr(), e["wp"].data_ptr(), self._record(st).data_ptr() if arith else 0, w.shape[0],
-                                    w.shape[1], e["flag"], e["nt"], e["kind"], e["total"], (e["total"] + 255) // 256)
-                                   for w, st, e, _ in stale],
-                          tuple((w.data_ptr(), e["wp"].data_ptr(), st["row"], e["flag"], e["nt"], e["kind"], e["total"])
-                                for w, st, e, _ in stale))
+        tab = self._table("pack", tuple((now[0], e["wp_ptr"], st["row"], e["flag"], e["nt"], e["kind"], e["total"]) for _, st, e, now in stale),
+                          lambda: [(now[0], e["wp_ptr"], rec(st["row"]) if arith else 0, w.shape[0], w.shape[1], e["flag"], e["nt"],
+                                    e["kind"], e["total"], (e["total"] + 255) // 256) for w, st, e, now in stale])
         _hip.call("cseg_split_pack_batch", tab[0].data_ptr(), tab[1], tab[2], arith, sp)
         for _, _, e, now in stale:
             e["version"] = now
 
-    def _table(self, name, rows, identity):
-        """rows: (src, dst, amax, cout, cin, flag, nt, kind, total, n_blocks) -> (device table, n_jobs, total_blocks); the device
-        copy is reused while the same jobs come back (every step of a training run). `identity` must name everything the table
-        holds by VALUE -- pointers and record rows, not Python object ids (those are recycled: a new layer that landed on a dead
-        layer's id and storage would otherwise inherit its max|w| row, and a zero row means an overflowing scale)."""
+    def _table(self, name, identity, make_rows):
+        """make_rows() -> rows (src, dst, amax, cout, cin, flag, nt, kind, total, n_blocks); returns (device table, n_jobs,
+        total_blocks). The device copy is reused while the same jobs come back (every step of a training run). `identity` must name
+        everything the table holds by VALUE -- pointers and record rows, not Python object ids (those are recycled: a new layer that
+        landed on a dead layer's id and storage would otherwise inherit its max|w| row, and a zero row means an overflowing scale)."""
         hit = self.table_cache.get(name)
         if hit is not None and hit[0] == identity:
             return hit[1:]
+        rows = make_rows()
         arr = np.zeros(len(rows), dtype=_JOB_DTYPE)
         b0 = 0
         for i, r in enumerate(rows):
