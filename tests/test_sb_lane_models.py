@@ -428,6 +428,7 @@ def test_host_tiling_heuristics():
     import os
     if not any(k.startswith("CSEG_CONV") for k in os.environ):
         assert K.CONV3X3_SB_WRW and K.CONV3X3_SB_WRW_CHANNELS == (48, 96, 192, 384, 720)
-        assert K.CONV1X1_SPLIT_BF16 and K.CONV1X1_SB_WRW and K.CONV1X1_SB_WRW_MIN_CH == 256
+        assert K.CONV1X1_SPLIT_BF16 and K.CONV1X1_SB_WRW and K.CONV1X1_SB_WRW_MIN_CH == 16     # 256 until the lean loader (round 3)
+        assert K.CONV3X3_S2_SPLIT and K.CONV3X3_SB8 and K.CONV3X3_SB_WRW_PAIRS == ((256, 48),)
         if "CSEG_SPARSE_EMBED_GRAD" not in os.environ:
             assert K.SPARSE_EMBED_GRAD
