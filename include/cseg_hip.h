@@ -344,9 +344,9 @@ int cseg_conv3x3_split_wrw(const float* x, const float* dy, int B, int Cin, int 
  *   forward:        cseg_conv3x3_s2_split_fwd, weights packed by cseg_conv3x3_s2_split_pack(transposed = 0) (format CSEG_PACK_C3_16);
  *   backward-data:  cseg_conv3x3_s2_split_bwd, weights packed with transposed = 1 (format CSEG_PACK_C3_S2T): dx [B, Cin, 2 Ho, 2 Wo];
  *   weight gradient: cseg_conv3x3_s2_split_wrw (ws: cseg_conv3x3_s2_wrw_ws_floats floats), deterministic.
- * nt = 16-channel tiles of the OUTPUT of the packed operator per block (3 or 6; must divide its channel count / 16; the same value for
- * pack and run). Shapes: input channels of the operator % 16, output channels % 48, Wo % 32 for the weight gradient; 0 / error
- * otherwise. Replaces miopenSp3AsmConv_*_stride2 / _dilation2 and the NHWC implicit-GEMM weight gradient with its layout transposes. */
+ * nt = 16-channel tiles of the OUTPUT of the packed operator per block (3, 4 or 6; must divide its channel count / 16; the same value
+ * for pack and run). Shapes: input channels of the operator % 16, output channels % 48 (or % 64 with nt = 4: the 256 input channels of
+ * transition 1 in the backward-data direction), Wo % 32 for the weight gradient; 0 / error otherwise. Replaces miopenSp3AsmConv_*_stride2 / _dilation2 and the NHWC implicit-GEMM weight gradient with its layout transposes. */
 size_t cseg_conv3x3_s2_split_packed_bytes(int conv_in, int conv_out);
 int cseg_conv3x3_s2_split_plan(int conv_in, int conv_out, int transposed, int nt, int* kind, long* threads);
 int cseg_conv3x3_s2_split_pack(const float* w, int Cout, int Cin, int transposed, int nt, const unsigned* amax_w, void* wp,
