@@ -43,7 +43,7 @@ int pack(const float* w, int Cout, int Cin, int transpose_flip, int NT, int arit
          hipStream_t stream);
 int fwd8(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int arith, const unsigned* amax_x,
          const unsigned* amax_w, float* y, hipStream_t stream);
-int fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int NT, int arith,
+int fwd(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W, int NT, int arith,
         const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream);
 }  // namespace cseg_sb16
 
@@ -138,49 +138,40 @@ __device__ __forceinline__ void sb_kstep(const uint4* __restrict__ ap, const uin
 }
 
 // accumulator layout: D[m = 4*g + r][n]: pixel column x0 + 16*mt + 4*g + r, channel co0 + 16*nt + n
+// addend (nullable): a tensor of the output's shape added in the epilogue -- the residual gradient that meets the backward-data result of
+// a BasicBlock's first convolution (hrnet_backbone.py: BasicBlock.forward); saves the separate elementwise add autograd would launch
 template <int NTW, int NTMAX>
 __device__ __forceinline__ void sb_store(const f32x4 (&acc)[4][NTMAX], float* __restrict__ ybc,
-                                         const float* __restrict__ bias, int co0, size_t plane, int yy, int x0, int W,
-                                         int g, int n, float unscale) {
+                                         const float* __restrict__ bias, const float* __restrict__ abc, int co0, size_t plane, int yy,
+                                         int x0, int W, int g, int n, float unscale) {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-        float* orow = ybc + (size_t)(co0 + nt * 16 + n) * plane + (size_t)yy * W;
+        const size_t roff = (size_t)(co0 + nt * 16 + n) * plane + (size_t)yy * W;
+        float* orow = ybc + roff;
         const float bv = bias ? bias[co0 + nt * 16 + n] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int xx = x0 + 16 * mt + 4 * g;
             f32x4 v = acc[mt][nt] * unscale;
             v += bv;
-            if (xx + 3 < W) *reinterpret_cast<float4*>(orow + xx) = make_float4(v[0], v[1], v[2], v[3]);
-            else {
-                if (xx < W) orow[xx] = v[0];
-                if (xx + 1 < W) orow[xx + 1] = v[1];
-                if (xx + 2 < W) orow[xx + 2] = v[2];
+            if (xx + 3 < W) {
+                if (abc) {
+                    const float4 ad = *reinterpret_cast<const float4*>(abc + roff + xx);
+                    v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
+                }
+                *reinterpret_cast<float4*>(orow + xx) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                if (xx < W) orow[xx] = v[0] + (abc ? abc[roff + xx] : 0.f);
+                if (xx + 1 < W) orow[xx + 1] = v[1] + (abc ? abc[roff + xx + 1] : 0.f);
+                if (xx + 2 < W) orow[xx + 2] = v[2] + (abc ? abc[roff + xx + 2] : 0.f);
             }
         }
     }
 }
 
-// 8 waves: wave = (row = wave & 3, half = wave >> 2); the two halves split the NT channel tiles (NT0 + NT1), so each
-// SIMD hosts one wave of either half (2 waves per SIMD: one issues MFMAs while the other waits on LDS).
-// GLDS: the B stage is filled by LDS-DMA (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16, which is exactly
-// the packed lane order) instead of a register round trip -- no VGPRs held across the MFMAs of the step.
-// VAR (tuning variants, 0 = the kernel as it was verified and timed on the MI355X):
-//   bit 0: the patch loads are buffer loads -- (the chunk's channel planes as a buffer resource in SGPRs) + (channel plane as
-//          scalar offset) + (one 32-bit per-lane offset per staging item) -- instead of 8 full 64-bit per-lane pointers per item. At NT = 9 the 64-bit form needs
-//          64 VGPRs for addresses alone, the kernel sits at the 256-register limit with 26 spilled VGPRs, and every chunk
-//          starts with 13 serialized scratch reloads (hipcc -S: "Folded Reload" under .LBB1_23) while both waves of a SIMD
-//          wait. Index-identical to VAR 0 (same elements, same order); first hardware run pending -> CSEG_CONV3X3_SB_VAR=1.
-// ABL != 0: ABLATION builds for timing experiments only (wrong results; CSEG_ABLATE, tools/ablate_probe.py): bit 0 = no MFMAs,
-// bit 1 = the patch is stored as truncated bits (no split arithmetic), bit 2 = no patch loads, bit 3 = no weight DMA.
-// SPS = K-steps per weight stage (round 3). With SPS = 1 every K-step (one tap x 32 channels: 54 MFMAs per wave at 9 channel
-// tiles) ends in a barrier that also waits for the next step's LDS-DMA; the ablation runs (tools/ablate_probe.py,
-// profiles/r03_ablate_probe.jsonl: with every global access removed the kernel still takes 4.1 ms against 2.9 ms of MFMA time)
-// put ~1.2 ms of the 5.6 ms on that per-step synchronisation. SPS = 3 stages a whole filter row (3 taps = 3 K-steps, 54 KB at 9
-// tiles, double-buffered: 161.8 KB of LDS with the patch) and synchronises once per row. f16x3 only (three pieces do not fit).
 template <class AR, int NT, bool GLDS, int VAR = 0, int ABL = 0, int SPS = 1>
 __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
-                                                            const float* __restrict__ bias, int Cin, int Cout, int H,
+                                                            const float* __restrict__ bias, const float* __restrict__ addend, int Cin, int Cout, int H,
                                                             int W, int tiles_x, int tiles_y,
                                                             const unsigned* __restrict__ amax_x,
                                                             const unsigned* __restrict__ amax_w, float* __restrict__ y) {
@@ -429,8 +420,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
         float* ybc = y + (size_t)b * Cout * plane;
         const int co0 = cot * NT * 16;
         const float unscale = split_unscale_of(ex) * split_unscale_of(ew);
-        if (half == 0) sb_store<NT0, NT0>(acc, ybc, bias, co0, plane, yy, x0, W, g, n, unscale);
-        else if (NT1 > 0) sb_store<NT1, NT0>(acc, ybc, bias, co0 + NT0 * 16, plane, yy, x0, W, g, n, unscale);
+        const float* abc = addend ? addend + (size_t)b * Cout * plane : nullptr;
+        if (half == 0) sb_store<NT0, NT0>(acc, ybc, bias, abc, co0, plane, yy, x0, W, g, n, unscale);
+        else if (NT1 > 0) sb_store<NT1, NT0>(acc, ybc, bias, abc, co0 + NT0 * 16, plane, yy, x0, W, g, n, unscale);
     }
 }
 
@@ -449,7 +441,7 @@ int pick_nt(int Cout) {
 }
 
 template <class AR, int NT, bool GLDS, int VAR = 0, int ABL = 0, int SPS = 1>
-int launch_sb(const float* x, const uint4* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
+int launch_sb(const float* x, const uint4* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W,
               const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream) {
     const size_t lds = sizeof(uint4) * (AR::NP * 4 * PLANE + 2 * SPS * NT * AR::NP * 64);
     static bool attr_set = false;
@@ -464,7 +456,7 @@ int launch_sb(const float* x, const uint4* wp, const float* bias, int B, int Cin
     const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
     const long n_tiles = (long)B * (Cout / (NT * 16)) * tiles_y * tiles_x;
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb: grid too large");
-    hipLaunchKernelGGL((conv3x3_sb_kernel<AR, NT, GLDS, VAR, ABL, SPS>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, Cin, Cout, H, W, tiles_x,
+    hipLaunchKernelGGL((conv3x3_sb_kernel<AR, NT, GLDS, VAR, ABL, SPS>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, addend, Cin, Cout, H, W, tiles_x,
                        tiles_y, amax_x, amax_w, y);
     CSEG_CHECK_LAUNCH("conv3x3_sb_kernel");
     return 1;
@@ -563,7 +555,7 @@ extern "C" int cseg_conv3x3_split_pack(const float* w, int Cout, int Cin, int tr
     return pack_impl(w, Cout, Cin, transpose_flip, nt, arith, amax_w, wp, (hipStream_t)stream_);
 }
 
-static int fwd_impl(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int NT, int arith,
+static int fwd_impl(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W, int NT, int arith,
                     const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream) {
     CSEG_REQUIRE(x && wp && y, "conv3x3_sb: null pointer");
     CSEG_REQUIRE(arith_ok(arith) && (arith == CSEG_ARITH_BF16X6 || (amax_x && amax_w)),
@@ -571,12 +563,13 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, int B, in
     if (NT == CSEG_NT_SB8) {
         CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && W % 4 == 0,
                      "conv3x3_sb: packed weights / output must be 16-byte aligned and W a multiple of 4");
+        CSEG_REQUIRE(!addend, "conv3x3_sb: the 8-row kernel takes no addend");
         return cseg_sb16::fwd8(x, wp, bias, B, Cin, Cout, H, W, arith, amax_x, amax_w, y, stream);
     }
     if (use_sb16(Cout)) {
         CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && W % 4 == 0,
                      "conv3x3_sb: packed weights / output must be 16-byte aligned and W a multiple of 4");
-        return cseg_sb16::fwd(x, wp, bias, B, Cin, Cout, H, W, sb16_nt(Cout, NT), arith, amax_x, amax_w, y, stream);
+        return cseg_sb16::fwd(x, wp, bias, addend, B, Cin, Cout, H, W, sb16_nt(Cout, NT), arith, amax_x, amax_w, y, stream);
     }
     if (NT == 0) NT = pick_nt(Cout);
     CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && NT > 0 && nt_ok(NT, Cout),
@@ -593,23 +586,23 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, int B, in
                  "conv3x3_sb: unsupported CSEG_CONV3X3_SB_VAR=%d", var);
 #define SB_LAUNCH(AR, G, V)                                                                                            \
     switch (NT) {                                                                                                      \
-        case 9: return launch_sb<AR, 9, G, V>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);             \
-        case 6: return launch_sb<AR, 6, G, V>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);             \
-        default: return launch_sb<AR, 3, G, V>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);            \
+        case 9: return launch_sb<AR, 9, G, V>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);             \
+        case 6: return launch_sb<AR, 6, G, V>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);             \
+        default: return launch_sb<AR, 3, G, V>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);            \
     }
     if (arith == CSEG_ARITH_F16X3 && NT == 9 && var >= 1) {
         const char* abl_env = getenv("CSEG_ABLATE");                // timing experiments only (wrong results)
         switch (abl_env ? atoi(abl_env) : 0) {
             case 0: break;
-            case 1: return launch_sb<SplitF16x3, 9, true, 1, 1>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-            case 2: return launch_sb<SplitF16x3, 9, true, 1, 2>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-            case 4: return launch_sb<SplitF16x3, 9, true, 1, 4>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-            case 6: return launch_sb<SplitF16x3, 9, true, 1, 6>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-            case 8: return launch_sb<SplitF16x3, 9, true, 1, 8>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-            case 14: return launch_sb<SplitF16x3, 9, true, 1, 14>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-            case 7: return launch_sb<SplitF16x3, 9, true, 1, 7>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-            case 9: return launch_sb<SplitF16x3, 9, true, 1, 9>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-            default: return launch_sb<SplitF16x3, 9, true, 1, 15>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            case 1: return launch_sb<SplitF16x3, 9, true, 1, 1>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            case 2: return launch_sb<SplitF16x3, 9, true, 1, 2>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            case 4: return launch_sb<SplitF16x3, 9, true, 1, 4>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            case 6: return launch_sb<SplitF16x3, 9, true, 1, 6>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            case 8: return launch_sb<SplitF16x3, 9, true, 1, 8>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            case 14: return launch_sb<SplitF16x3, 9, true, 1, 14>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            case 7: return launch_sb<SplitF16x3, 9, true, 1, 7>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            case 9: return launch_sb<SplitF16x3, 9, true, 1, 9>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            default: return launch_sb<SplitF16x3, 9, true, 1, 15>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
         }
     }
     if (arith == CSEG_ARITH_F16X3) {
@@ -618,9 +611,9 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, int B, in
         const char* sps_env = getenv("CSEG_CONV3X3_SB_SPS");
         if (var >= 1 && !(sps_env && atoi(sps_env) == 1)) {
             switch (NT) {
-                case 9: return launch_sb<SplitF16x3, 9, true, 1, 0, 3>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-                case 6: return launch_sb<SplitF16x3, 6, true, 1, 0, 3>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-                default: return launch_sb<SplitF16x3, 3, true, 1, 0, 3>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+                case 9: return launch_sb<SplitF16x3, 9, true, 1, 0, 3>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+                case 6: return launch_sb<SplitF16x3, 6, true, 1, 0, 3>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+                default: return launch_sb<SplitF16x3, 3, true, 1, 0, 3>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
             }
         }
         if (var >= 1) { SB_LAUNCH(SplitF16x3, true, 1) }
@@ -634,20 +627,20 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, int B, in
 
 extern "C" int cseg_conv3x3_sb_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H,
                                    int W, float* y, cseg_stream_t stream_) {
-    return fwd_impl(x, wp, bias, B, Cin, Cout, H, W, 0, CSEG_ARITH_BF16X6, nullptr, nullptr, y, (hipStream_t)stream_);
+    return fwd_impl(x, wp, bias, nullptr, B, Cin, Cout, H, W, 0, CSEG_ARITH_BF16X6, nullptr, nullptr, y, (hipStream_t)stream_);
 }
 
 extern "C" int cseg_conv3x3_sb_fwd_nt(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H,
                                       int W, int nt, float* y, cseg_stream_t stream_) {
     CSEG_REQUIRE(nt == 3 || nt == 6 || nt == 9, "conv3x3_sb_fwd_nt: nt must be 3, 6 or 9 (got %d)", nt);
-    return fwd_impl(x, wp, bias, B, Cin, Cout, H, W, nt, CSEG_ARITH_BF16X6, nullptr, nullptr, y, (hipStream_t)stream_);
+    return fwd_impl(x, wp, bias, nullptr, B, Cin, Cout, H, W, nt, CSEG_ARITH_BF16X6, nullptr, nullptr, y, (hipStream_t)stream_);
 }
 
 extern "C" int cseg_conv3x3_split_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
                                       int nt, int arith, const unsigned* amax_x, const unsigned* amax_w, float* y,
                                       cseg_stream_t stream_) {
     CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9 || nt == CSEG_NT_SB8, "conv3x3_split_fwd: nt must be 0, 3, 6, 9 or CSEG_NT_SB8 (got %d)", nt);
-    return fwd_impl(x, wp, bias, B, Cin, Cout, H, W, nt, arith, amax_x, amax_w, y, (hipStream_t)stream_);
+    return fwd_impl(x, wp, bias, nullptr, B, Cin, Cout, H, W, nt, arith, amax_x, amax_w, y, (hipStream_t)stream_);
 }
 
 // ---- max|x| of a tensor, accumulated into the record amax_bits[CSEG_AMAX_WORDS] (include/cseg_hip.h; the caller zeroes it) ----
@@ -678,4 +671,14 @@ extern "C" int cseg_amax_f32(const float* x, long n, unsigned* amax_bits, cseg_s
     hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, x, n, amax_bits);
     CSEG_CHECK_LAUNCH("amax_kernel");
     return 1;
+}
+
+// The same convolution with a tensor of the output's shape added in the epilogue (y = conv(x) + bias + addend; addend may be null):
+// one pass less than a separate elementwise add. 16-byte aligned like y. Not with nt = CSEG_NT_SB8.
+extern "C" int cseg_conv3x3_split_fwd_add(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin,
+                                          int Cout, int H, int W, int nt, int arith, const unsigned* amax_x, const unsigned* amax_w,
+                                          float* y, cseg_stream_t stream_) {
+    CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9, "conv3x3_split_fwd_add: nt must be 0, 3, 6 or 9 (got %d)", nt);
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(addend) & 15) == 0, "conv3x3_split_fwd_add: addend must be 16-byte aligned");
+    return fwd_impl(x, wp, bias, addend, B, Cin, Cout, H, W, nt, arith, amax_x, amax_w, y, (hipStream_t)stream_);
 }

@@ -67,22 +67,28 @@ __device__ __forceinline__ void sb16_kstep(const uint4* __restrict__ ap, const u
 // accumulator layout: D[m = 4*g + r][n]: pixel column x0 + 16*mt + 4*g + r, channel co0 + 16*nt + n
 template <int NTW, int NTMAX>
 __device__ __forceinline__ void sb16_store(const f32x4 (&acc)[4][NTMAX], float* __restrict__ ybc,
-                                           const float* __restrict__ bias, int co0, size_t plane, int yy, int x0, int W,
-                                           int g, int n, float unscale) {
+                                           const float* __restrict__ bias, const float* __restrict__ abc, int co0, size_t plane, int yy,
+                                           int x0, int W, int g, int n, float unscale) {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-        float* orow = ybc + (size_t)(co0 + nt * 16 + n) * plane + (size_t)yy * W;
+        const size_t roff = (size_t)(co0 + nt * 16 + n) * plane + (size_t)yy * W;
+        float* orow = ybc + roff;
         const float bv = bias ? bias[co0 + nt * 16 + n] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int xx = x0 + 16 * mt + 4 * g;
             f32x4 v = acc[mt][nt] * unscale;
             v += bv;
-            if (xx + 3 < W) *reinterpret_cast<float4*>(orow + xx) = make_float4(v[0], v[1], v[2], v[3]);
-            else {
-                if (xx < W) orow[xx] = v[0];
-                if (xx + 1 < W) orow[xx + 1] = v[1];
-                if (xx + 2 < W) orow[xx + 2] = v[2];
+            if (xx + 3 < W) {
+                if (abc) {                          // epilogue addend (see conv3x3_sb.hip:sb_store)
+                    const float4 ad = *reinterpret_cast<const float4*>(abc + roff + xx);
+                    v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
+                }
+                *reinterpret_cast<float4*>(orow + xx) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                if (xx < W) orow[xx] = v[0] + (abc ? abc[roff + xx] : 0.f);
+                if (xx + 1 < W) orow[xx + 1] = v[1] + (abc ? abc[roff + xx + 1] : 0.f);
+                if (xx + 2 < W) orow[xx + 2] = v[2] + (abc ? abc[roff + xx + 2] : 0.f);
             }
         }
     }
@@ -92,7 +98,7 @@ __device__ __forceinline__ void sb16_store(const f32x4 (&acc)[4][NTMAX], float* 
 // SIMD (the second launch-bounds argument of HIP is waves per execution unit): 128 VGPRs.
 template <class AR, int NT>
 __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
-                                                              const float* __restrict__ bias, int Cin, int Cout, int H,
+                                                              const float* __restrict__ bias, const float* __restrict__ addend, int Cin, int Cout, int H,
                                                               int W, int tiles_x, int tiles_y,
                                                               const unsigned* __restrict__ amax_x,
                                                               const unsigned* __restrict__ amax_w, float* __restrict__ y) {
@@ -222,8 +228,9 @@ __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(cons
         float* ybc = y + (size_t)b * Cout * plane;
         const int co0 = cot * NT * 16;
         const float unscale = split_unscale_of(ex) * split_unscale_of(ew);
-        if (half == 0) sb16_store<NT0, NT0>(acc, ybc, bias, co0, plane, yy, x0, W, g, n, unscale);
-        else if (NT1 > 0) sb16_store<NT1, NT0>(acc, ybc, bias, co0 + NT0 * 16, plane, yy, x0, W, g, n, unscale);
+        const float* abc = addend ? addend + (size_t)b * Cout * plane : nullptr;
+        if (half == 0) sb16_store<NT0, NT0>(acc, ybc, bias, abc, co0, plane, yy, x0, W, g, n, unscale);
+        else if (NT1 > 0) sb16_store<NT1, NT0>(acc, ybc, bias, abc, co0 + NT0 * 16, plane, yy, x0, W, g, n, unscale);
     }
 }
 
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(cons
 // ---------------------------------------------------------------------------------------------------------
 template <class AR, int NT, bool RES>
 __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
-                                                               const float* __restrict__ bias, int Cin, int Cout, int H, int W,
+                                                               const float* __restrict__ bias, const float* __restrict__ addend, int Cin, int Cout, int H, int W,
                                                                int tiles_x, int tiles_y, int n_spatial, int groups,
                                                                const unsigned* __restrict__ amax_x,
                                                                const unsigned* __restrict__ amax_w, float* __restrict__ y) {
@@ -384,9 +391,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
             const int yy = y0 + row;
             if (yy < H) {
                 float* ybc = y + (size_t)b * Cout * plane;
+                const float* abc = addend ? addend + (size_t)b * Cout * plane : nullptr;
                 const int co0 = cot * NT * 16;
-                if (half == 0) sb16_store<NT0, NT0>(acc, ybc, bias, co0, plane, yy, x0, W, g, n, unscale);
-                else if (NT1 > 0) sb16_store<NT1, NT0>(acc, ybc, bias, co0 + NT0 * 16, plane, yy, x0, W, g, n, unscale);
+                if (half == 0) sb16_store<NT0, NT0>(acc, ybc, bias, abc, co0, plane, yy, x0, W, g, n, unscale);
+                else if (NT1 > 0) sb16_store<NT1, NT0>(acc, ybc, bias, abc, co0 + NT0 * 16, plane, yy, x0, W, g, n, unscale);
             }
         }
         if (more) a_store(it + 1, As + (size_t)((it + 1) & 1) * A_CELLS);  // the other patch buffer: last read in item it - 1
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
 }
 
 template <class AR, int NT, bool RES>
-int launch_sb16p(const float* x, const uint4* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
+int launch_sb16p(const float* x, const uint4* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W,
                  const unsigned* amax_x, const unsigned* amax_w, float* y, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -414,7 +422,7 @@ int launch_sb16p(const float* x, const uint4* wp, const float* bias, int B, int 
     if (groups < 1) groups = 1;
     if (groups > n_spatial) groups = n_spatial;
     hipLaunchKernelGGL((conv3x3_sb16p_kernel<AR, NT, RES>), dim3((unsigned)(groups * n_cot)), dim3(512), lds, stream, x, wp, bias,
-                       Cin, Cout, H, W, tiles_x, tiles_y, (int)n_spatial, (int)groups, amax_x, amax_w, y);
+                       addend, Cin, Cout, H, W, tiles_x, tiles_y, (int)n_spatial, (int)groups, amax_x, amax_w, y);
     CSEG_CHECK_LAUNCH("conv3x3_sb16p_kernel");
     return 1;
 }
@@ -435,7 +443,7 @@ bool sb16p_plan(int arith, int Cin, int NT, size_t& lds, bool& res) {
 }
 
 template <class AR, int NT>
-int launch_sb16(const float* x, const uint4* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
+int launch_sb16(const float* x, const uint4* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W,
                 const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream) {
     const size_t lds = sizeof(uint4) * (AR::NP * NOCT * PLANE + 2 * NT * AR::NP * 64);
     static bool attr_set = false;
@@ -450,7 +458,7 @@ int launch_sb16(const float* x, const uint4* wp, const float* bias, int B, int C
     const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
     const long n_tiles = (long)B * (Cout / (NT * 16)) * tiles_y * tiles_x;
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb16: grid too large");
-    hipLaunchKernelGGL((conv3x3_sb16_kernel<AR, NT>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, Cin, Cout, H, W,
+    hipLaunchKernelGGL((conv3x3_sb16_kernel<AR, NT>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, addend, Cin, Cout, H, W,
                        tiles_x, tiles_y, amax_x, amax_w, y);
     CSEG_CHECK_LAUNCH("conv3x3_sb16_kernel");
     return 1;
@@ -710,7 +718,7 @@ int pack(const float* w, int Cout, int Cin, int transpose_flip, int NT, int arit
     return 1;
 }
 
-int fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int NT, int arith,
+int fwd(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W, int NT, int arith,
         const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream) {
     CSEG_REQUIRE((NT == 3 || NT == 4 || NT == 6) && Cout % (NT * 16) == 0 && Cin % 16 == 0 && (long)H * W * 16 * 4 < 2147483647L,
                  "conv3x3_sb16: unsupported shape Cin=%d Cout=%d %dx%d with %d channel tiles per block", Cin, Cout, H, W, NT);
@@ -719,21 +727,21 @@ int fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int C
     bool res = false;
     if (sb16p_plan(arith, Cin, NT, lds, res)) {
 #define SB16P(N)                                                                                                              \
-    return res ? launch_sb16p<SplitF16x3, N, true>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, lds, stream)          \
-               : launch_sb16p<SplitF16x3, N, false>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, lds, stream);
+    return res ? launch_sb16p<SplitF16x3, N, true>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, lds, stream)          \
+               : launch_sb16p<SplitF16x3, N, false>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, lds, stream);
         if (NT == 3) { SB16P(3) }
         if (NT == 4) { SB16P(4) }
         if (NT == 6) { SB16P(6) }
 #undef SB16P
     }
     if (arith == CSEG_ARITH_F16X3) {
-        if (NT == 6) return launch_sb16<SplitF16x3, 6>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-        if (NT == 4) return launch_sb16<SplitF16x3, 4>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-        return launch_sb16<SplitF16x3, 3>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+        if (NT == 6) return launch_sb16<SplitF16x3, 6>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+        if (NT == 4) return launch_sb16<SplitF16x3, 4>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+        return launch_sb16<SplitF16x3, 3>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
     }
-    if (NT == 6) return launch_sb16<SplitBF16x6, 6>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-    if (NT == 4) return launch_sb16<SplitBF16x6, 4>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-    return launch_sb16<SplitBF16x6, 3>(x, wq, bias, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+    if (NT == 6) return launch_sb16<SplitBF16x6, 6>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+    if (NT == 4) return launch_sb16<SplitBF16x6, 4>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+    return launch_sb16<SplitBF16x6, 3>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
 }
 
 // the 8-row head kernel (namespace sb8 above): f16x3, 9 channel tiles per block, weights packed by pack(..., NT = 9, ...)

@@ -48,8 +48,11 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x), relu=True)                      # BN + ReLU: one statistics pass + one apply pass
-        res = x if self.downsample is None else self.downsample(x)
+        if self.downsample is None:
+            out, res = self.conv1.forward_fork(x)                     # conv1(x) and the identity path from one autograd node
+        else:
+            out, res = self.conv1(x), self.downsample(x)
+        out = self.bn1(out, relu=True)                                # BN + ReLU: one statistics pass + one apply pass
         return self.bn2(self.conv2(out), residual=res, relu=True)     # BN + residual add + ReLU in the same apply pass
 
 

@@ -43,6 +43,18 @@ class Conv3x3(nn.Conv2d):
             return K.conv3x3_s2_split(x, self.weight)
         return super(Conv3x3, self).forward(x)
 
+    def forward_fork(self, x):
+        """(self(x), x) for the first convolution of a residual block whose identity path is `x` itself: where the split kernels take
+        this layer, both come out of ONE autograd node whose backward adds the identity path's gradient in the epilogue of the
+        backward-data kernel (kernels.Conv3x3SplitFork); otherwise plainly (self(x), x)."""
+        from contrastiveseg_amd import kernels as K
+        if (K.CONV3X3_FORK and K._on_device(x) and x.requires_grad and self.stride == (1, 1) and self.dilation == (1, 1)
+                and self.in_channels == self.out_channels and K.CONV3X3_SPLIT_BF16
+                and self.in_channels in K.CONV3X3_SB_BRANCH_CHANNELS and K.conv3x3_sb_eligible(x, self.weight)
+                and K.conv3x3_sb_tiles(x, self.out_channels) >= K.CONV3X3_SB_MIN_TILES):
+            return K.conv3x3_split_fork(x, self.weight)
+        return self.forward(x), x
+
 
 class HeadConv3x3(nn.Conv2d):
     """nn.Conv2d(C, C, 3, 1, 1) with bias (same parameters / state_dict) for the 720 -> 720 convolution in front of the

@@ -335,6 +335,12 @@ int cseg_conv3x3_split_pack(const float* w, int Cout, int Cin, int transpose_fli
                             void* wp, cseg_stream_t stream);
 int cseg_conv3x3_split_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int nt,
                            int arith, const unsigned* amax_x, const unsigned* amax_w, float* y, cseg_stream_t stream);
+/* y = conv(x) + bias + addend: `addend` (nullable) has the output's shape and is added in the epilogue -- the residual gradient that
+ * meets the backward-data result of the first convolution of a BasicBlock (reference hrnet_backbone.py:49-65: `out += residual`
+ * forward means two gradients arrive at the block input backward), saving the elementwise add autograd would launch. nt: 0 / 3 / 6 / 9. */
+int cseg_conv3x3_split_fwd_add(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin, int Cout,
+                               int H, int W, int nt, int arith, const unsigned* amax_x, const unsigned* amax_w, float* y,
+                               cseg_stream_t stream);
 /* ws: cseg_conv3x3_sb_wrw_ws_floats(...) */
 int cseg_conv3x3_split_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, int arith,
                            const unsigned* amax_x, const unsigned* amax_dy, float* ws, float* dw, cseg_stream_t stream);

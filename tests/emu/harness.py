@@ -92,7 +92,7 @@ def amax(a):
     return out
 
 
-def conv3x3_sb(x, w, bias=None, transpose_flip=False, nt=0, arith=None):
+def conv3x3_sb(x, w, bias=None, transpose_flip=False, nt=0, arith=None, addend=None):
     co, ci = w.shape[:2]
     conv_in, conv_out = (co, ci) if transpose_flip else (ci, co)
     B, _, H, W = x.shape
@@ -104,6 +104,10 @@ def conv3x3_sb(x, w, bias=None, transpose_flip=False, nt=0, arith=None):
         xd, wd, bd = dev(x), dev(w), (None if bias is None else dev(bias))
         ax, aw = (amax(x), amax(w)) if arith == F16X3 else (None, None)
         call("cseg_conv3x3_split_pack", ptr(wd), co, ci, int(transpose_flip), nt, arith, ptr(aw), ptr(wp), None)
+        if addend is not None:
+            call("cseg_conv3x3_split_fwd_add", ptr(xd), ptr(wp), ptr(bd), ptr(dev(addend)), B, conv_in, conv_out, H, W, nt, arith, ptr(ax),
+                 ptr(aw), ptr(y), None)
+            return y
         call("cseg_conv3x3_split_fwd", ptr(xd), ptr(wp), ptr(bd), B, conv_in, conv_out, H, W, nt, arith, ptr(ax), ptr(aw), ptr(y),
              None)
         return y

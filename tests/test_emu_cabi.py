@@ -183,6 +183,15 @@ def test_head_kernel_8_rows_matches_fp64(kw, monkeypatch):
     _replay_sb(monkeypatch, "test_head_kernel_8_rows_matches_fp64", kw)
 
 
+SB_FORK = _cases("test_gpu_conv3x3_sb", "test_basic_block_with_fused_identity_gradient", lambda kw: True)
+
+
+@pytest.mark.parametrize("kw", SB_FORK, ids=_ids(SB_FORK))
+def test_basic_block_with_fused_identity_gradient(kw, monkeypatch):
+    monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)
+    _replay_sb(monkeypatch, "test_basic_block_with_fused_identity_gradient", kw)
+
+
 SB_ONE = _cases("test_gpu_conv3x3_sb", "test_pointwise_matches_fp64", _SMALL)
 
 

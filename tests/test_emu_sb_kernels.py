@@ -376,3 +376,16 @@ def test_head_kernel_8_rows(case, wave_order):
     ref = E.ref_conv3x3_bwd_data(dy, w2)
     assert not np.isnan(dx).any()
     assert np.abs(dx - ref).max() <= 3e-6 * np.sqrt(9 * 144) * float(np.abs(ref).max())
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+@pytest.mark.parametrize("case", [(1, 48, 48, 6, 68), (2, 16, 96, 4, 64), (1, 64, 64, 5, 20), (1, 32, 192, 3, 36)])
+def test_epilogue_addend(case, arith, wave_order):
+    """y = conv(x) + bias + addend in the three forward kernels that take branch layers (persistent 16-channel-chunk kernel at 48 / 192
+    channels, its one-tile form at 64, the 32-channel-chunk kernel at 96), ragged tiles: full float4 and scalar edge stores"""
+    B, ci, co, H, W = case
+    x, w, b, ad = _rand((B, ci, H, W), 101, 2.0), _rand((co, ci, 3, 3), 102, 0.1), _rand((co,), 103), _rand((B, co, H, W), 104, 5.0)
+    y = E.conv3x3_sb(x, w, bias=b, arith=arith, addend=ad)
+    ref = E.ref_conv3x3(x, w, b) + ad
+    assert not np.isnan(y).any()
+    assert np.abs(y - ref).max() <= _bound(ref, 9 * ci)

@@ -194,3 +194,47 @@ def test_head_kernel_8_rows_matches_fp64(case):
         got = K.conv3x3_sb_run(dy.cuda(), wd, True, None, K.NT_SB8).cpu()
         err, tol = _bound(x64.grad, got, xr.grad.cpu())
         assert err <= tol, (case, "dx", err, tol)
+
+
+@pytest.mark.parametrize("case", [(2, 48, 8, 64), (1, 96, 6, 36)])
+def test_basic_block_with_fused_identity_gradient(case, monkeypatch):
+    """hrnet_backbone.BasicBlock: the first convolution and the identity path leave ONE autograd node (kernels.Conv3x3SplitFork) whose
+    backward adds the identity path's gradient in the epilogue of the backward-data kernel. Output, input gradient and both weight
+    gradients against the same block in fp64 (torch), and against the un-fused route of this package."""
+    from contrastiveseg_amd import kernels as K
+    from contrastiveseg_amd.lib.models.backbones.hrnet_backbone import BasicBlock
+    monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
+    B, C, H, W = case
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, C, H, W, generator=g)
+    dy = torch.randn(B, C, H, W, generator=g)
+    torch.manual_seed(5)
+    blk = BasicBlock(C, C, bn_type="torchbn").cuda().train()
+    calls = []
+    monkeypatch.setattr(K, "conv3x3_split_fork", (lambda fn: lambda *a, **k: (calls.append("fork"), fn(*a, **k))[1])(K.conv3x3_split_fork))
+
+    def run(fork):
+        monkeypatch.setattr(K, "CONV3X3_FORK", fork)
+        blk.zero_grad(set_to_none=True)
+        xd = x.clone().cuda().requires_grad_(True)
+        y = blk(xd * 1.0)                 # (a non-leaf input, as inside the network)
+        y.backward(dy.cuda())
+        return y.detach().cpu(), xd.grad.cpu(), blk.conv1.weight.grad.cpu().clone(), blk.conv2.weight.grad.cpu().clone()
+
+    got = run(True)
+    assert calls == ["fork"], calls
+    plain = run(False)
+    assert calls == ["fork"]
+    # fp64 reference of the same block
+    w1, w2 = blk.conv1.weight.detach().cpu().double().requires_grad_(True), blk.conv2.weight.detach().cpu().double().requires_grad_(True)
+    g1, b1 = blk.bn1.weight.detach().cpu().double(), blk.bn1.bias.detach().cpu().double()
+    g2, b2 = blk.bn2.weight.detach().cpu().double(), blk.bn2.bias.detach().cpu().double()
+    x64 = x.detach().double().requires_grad_(True)
+    o = F.relu(F.batch_norm(F.conv2d(x64, w1, None, 1, 1), None, None, g1, b1, True, 0.1, 1e-5))
+    o = F.relu(F.batch_norm(F.conv2d(o, w2, None, 1, 1), None, None, g2, b2, True, 0.1, 1e-5) + x64)
+    o.backward(dy.double())
+    for name, ref, a, p in (("y", o.detach(), got[0], plain[0]), ("dx", x64.grad, got[1], plain[1]), ("dw1", w1.grad, got[2], plain[2]),
+                            ("dw2", w2.grad, got[3], plain[3])):
+        scale = float(ref.abs().max())
+        assert float((a.double() - ref).abs().max()) <= 2e-4 * scale, (case, name)
+        assert float((a - p).abs().max()) <= 2e-5 * scale, (case, name, "fused vs plain")
