@@ -26,6 +26,32 @@ def _all_reduce(t, group):
     return t
 
 
+_EQUAL_COUNT_CHECKED = set()       # (shape, id of the process group) already verified in this process
+
+
+def check_equal_counts(x, sync_group):
+    """The SyncBN exchange takes the global element count as n_local * world (one fp64 all-reduce of the moments, no second
+    collective and no host round trip per layer). That is only right when every rank contributes the same number of elements, which
+    the shipped loaders guarantee (data_loader.py: equal shards, drop_last) -- a custom loader or a last partial batch would
+    silently skew mean / var / dx (torch's SyncBatchNorm gathers the per-rank counts instead). So the assumption is VERIFIED once
+    per input shape and process group: one tiny all-reduce and one host read the first time a shape is seen, nothing afterwards.
+    Every rank of the group reaches this through the same code path (a rank with a different shape raises here instead of hanging
+    later)."""
+    key = (tuple(x.shape[1:]), id(sync_group))           # per-image shape: the batch dimension is what may differ
+    mark = (x.shape[0],) + key
+    if mark in _EQUAL_COUNT_CHECKED:
+        return
+    n = float(x.numel() // x.shape[1])
+    t = torch.tensor([n, -n], dtype=torch.float64, device=x.device)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=sync_group)
+    hi, lo = float(t[0]), -float(t[1])
+    if hi != lo:
+        raise RuntimeError("FusedSyncBatchNorm: ranks contribute different element counts per channel (min %d, max %d, this rank %d): "
+                           "the fused exchange assumes equal per-rank batches (use drop_last / equal shards, or nn.SyncBatchNorm)"
+                           % (int(lo), int(hi), int(n)))
+    _EQUAL_COUNT_CHECKED.add(mark)
+
+
 def bn_forward(x, weight, bias, residual, running_mean, running_var, num_batches_tracked, training, relu, momentum, eps,
                sync_group):
     """Device half of one BN(+residual)(+ReLU) site -> (y, mean_invstd [C,2], count). x / residual contiguous.
@@ -38,8 +64,9 @@ def bn_forward(x, weight, bias, residual, running_mean, running_var, num_batches
     if training:
         if sync_group is not None:
             world = torch.distributed.get_world_size(sync_group)
+            check_equal_counts(x, sync_group)
             moments = _all_reduce(K.bn_stats(x), sync_group)
-            count = float(n_local * world)          # equal per-rank batch (data_loader.py:137 splits evenly)
+            count = float(n_local * world)          # equal per-rank batch: verified once per shape above
             mi = K.bn_finalize(moments, count, eps, momentum, running_mean, running_var, num_batches_tracked)
             y = K.bn_apply(x, mi, weight, bias, residual, relu, amax=amax)
         else:
@@ -114,6 +141,7 @@ class _BNActGroup(torch.autograd.Function):
         xs, moments = [], []
         for i in range(n):
             x = tensors[4 * i].contiguous()
+            check_equal_counts(x, sync_group)
             xs.append(x)
             moments.append(K.bn_stats(x))
         packed = _all_reduce(torch.cat(moments, dim=0), sync_group)

@@ -322,6 +322,42 @@ def test_fused_syncbn_host_logic_two_ranks_equal_single_process():
     assert np.abs(res[0][4] - bn.running_var.numpy()).max() <= 1e-6
 
 
+def _unequal_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import cpu_port
+    cpu_port.install(None)
+    from contrastiveseg_amd.lib.models.tools.fused_bn import FusedSyncBatchNorm
+    m = FusedSyncBatchNorm(6).train()
+    x = torch.randn(2 + rank, 6, 5, 7)                   # rank 1 brings one image more
+    try:
+        m(x, relu=True)
+        q.put((rank, "no error"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fused_syncbn_rejects_unequal_per_rank_batches():
+    """The fused exchange uses n_local * world as the global count; unequal per-rank batches must be an error on EVERY rank (not a
+    silently wrong mean / var), checked once per shape."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_unequal_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, msg in res:
+        assert "different element counts" in msg and "min 70, max 105" in msg, (rank, msg)
+
+
 def _install_device_half():
     """CSEG_TEST_DEVICE_HALF=emu: the HIP sources on the CPU emulation of the execution model (tests/emu); default: the
     torch restatement oracle/cpu_port.py. -> a function that undoes the installation."""
@@ -356,7 +392,8 @@ def _hrnet_sync_worker(rank, world, port, q):
     real = dist.all_reduce
 
     def counting(t, *a, **k):
-        calls["n"] += 1
+        if k.get("op", dist.ReduceOp.SUM) == dist.ReduceOp.SUM:      # (not the once-per-shape MAX of fused_bn.check_equal_counts)
+            calls["n"] += 1
         return real(t, *a, **k)
     dist.all_reduce = counting
     torch.manual_seed(304)
