@@ -432,3 +432,36 @@ def test_host_tiling_heuristics():
         assert K.CONV3X3_S2_SPLIT and K.CONV3X3_SB8 and K.CONV3X3_SB_WRW_PAIRS == ((256, 48),)
         if "CSEG_SPARSE_EMBED_GRAD" not in os.environ:
             assert K.SPARSE_EMBED_GRAD
+
+
+def test_round_aware_split_counts_and_head_kernel_rule():
+    """The launch-shape decisions of round 3 that were fitted to hardware timings: pixel splits of the weight
+    gradients from the rounds-of-blocks cost models (host functions of libcseg_hip.so, no GPU needed), the 8-row head kernel only for
+    launches of at least four rounds."""
+    import ctypes
+    import os
+    import torch
+    from contrastiveseg_amd import _hip, kernels as K
+    if not os.path.exists(_hip.LIB_PATH):
+        pytest.skip("libcseg_hip.so not built")
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    lib.cseg_conv3x3_sb_wrw_ws_floats.restype = ctypes.c_size_t
+    lib.cseg_conv1x1_sb_wrw_ws_floats.restype = ctypes.c_size_t
+    lib.cseg_conv3x3_s2_wrw_ws_floats.restype = ctypes.c_size_t
+    if "CSEG_SB_WRW_SPLITS" not in os.environ and "CSEG_CONV3X3_SB_WRW_V" not in os.environ:
+        splits3 = lambda B, C, H, W: lib.cseg_conv3x3_sb_wrw_ws_floats(B, C, C, H, W) // (9 * C * C)
+        assert splits3(8, 720, 128, 256) == 4        # 30-block groups over 8 XCDs: 3 rounds x 64 units (6.86 ms; 5 splits: 7.70, 3: 9.74)
+        assert splits3(8, 48, 128, 256) == 256       # one unit per block (50 us; 128 splits: 70)
+        assert splits3(8, 96, 64, 128) == 64
+        assert splits3(8, 192, 32, 64) == 16
+        assert splits3(8, 384, 16, 32) == 4
+    assert lib.cseg_conv1x1_sb_wrw_ws_floats(8, 720, 720, 128 * 256) // (720 * 720) == 17       # 510 blocks = 2 rounds (26: a 4th round for 12 blocks)
+    assert lib.cseg_conv3x3_s2_wrw_ws_floats(8, 48, 96, 64, 128) // (9 * 48 * 96) == 128        # 256 blocks of one 16-row unit
+    assert lib.cseg_conv3x3_s2_wrw_ws_floats(8, 48, 96, 64, 100) == 0                           # output width % 32
+    meta = lambda *s: torch.empty(*s, device="meta")
+    if K.CONV3X3_SB8 and K.SPLIT_ARITH == "f16x3":
+        assert K.conv3x3_sb_head_nt(720, meta(8, 720, 128, 256)) == K.NT_SB8          # 2 560 blocks: 5.28 vs 5.41 ms
+        assert K.conv3x3_sb_head_nt(720, meta(1, 720, 128, 256)) == 0                 # 320 blocks: 0.99 vs 0.88 ms
+        assert K.conv3x3_sb_head_nt(144, meta(8, 144, 64, 128)) == 0                  # 128 blocks
+    assert K.conv3x3_sb_head_nt(96, meta(8, 96, 64, 128)) == 0
+    assert K.conv3x3_s2_pick_nt(8, 64, 128, 96) == 6 and K.conv3x3_s2_pick_nt(8, 32, 64, 192) == 3 and K.conv3x3_s2_pick_nt(8, 64, 128, 256) == 4
