@@ -1104,6 +1104,8 @@ extern "C" int cseg_conv3x3_s2_split_wrw(const float* x, const float* dy, int B,
     CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0,
                  "conv3x3_s2_wrw: tensors must be 16-byte aligned");
     CSEG_REQUIRE((long)9 * Cin * Cout < 2147483647L, "conv3x3_s2_wrw: too large");
+    CSEG_REQUIRE((long)Cin * Ho * Wo * 16 < 2147483647L && (long)Cout * Ho * Wo * 4 < 2147483647L,
+                 "conv3x3_s2_wrw: one image of x / dy must stay below 2 GiB (32-bit offsets)");
     int rpu, n_split;
     s2_plan(B, Cin, Cout, Ho, Wo, rpu, n_split);
     const size_t lds = sizeof(unsigned short) * (s2_x_elems(2) + s2_d_elems(2));
