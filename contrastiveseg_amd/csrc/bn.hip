@@ -129,6 +129,10 @@ __device__ __forceinline__ void channel_moments(const float* __restrict__ x, con
 __global__ __launch_bounds__(256) void bn_moments_kernel(const float* __restrict__ x, const float* __restrict__ partial,
                                                          BnDims d, double* __restrict__ moments) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {           // row C: this rank's element count per channel (summed by the exchange)
+        moments[2 * d.C] = (double)d.B * (double)d.HW;
+        moments[2 * d.C + 1] = 0.0;
+    }
     if (c >= d.C) return;
     double m0, m1;
     channel_moments(x, partial, d, c, lane, m0, m1);
@@ -172,6 +176,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
     if (c >= C) return;
+    if (count <= 0.0) count = moments[2 * C];            // the exchanged element count (row C), no host round trip
     finalize_channel(moments[2 * c], moments[2 * c + 1], count, eps, momentum, running_mean, running_var, c, mean_invstd);
 }
 
@@ -302,6 +307,10 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restric
                                                           const float* __restrict__ mean_invstd, double* __restrict__ sums,
                                                           float* __restrict__ d_weight, float* __restrict__ d_bias) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {           // row C: this rank's element count per channel
+        sums[2 * d.C] = (double)d.B * (double)d.HW;
+        sums[2 * d.C + 1] = 0.0;
+    }
     if (c >= d.C) return;
     double s0 = 0.0, s1 = 0.0;
     for (int s = lane; s < d.S; s += 64) {
@@ -333,6 +342,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     // k0 = mean(dy') is subtracted from EVERY element: a float-rounded k0 would shift all of them by the same ~6e-8*|k0|,
     // an error that adds up coherently in the weight gradient of the convolution in front (sum_p dx_p * input_p, where
     // sum_p dx_p = 0 in exact arithmetic). Carry it as hi + lo.
+    if (sums && inv_count <= 0.0) inv_count = 1.0 / sums[2 * d.C];      // the exchanged element count (row C)
     const double k0d = sums ? sums[2 * c] * inv_count : 0.0;
     const float k0 = (float)k0d, k0l = (float)(k0d - (double)k0);
     const float k1 = sums ? (float)(sums[2 * c + 1] * inv_count * (double)invstd * (double)invstd) : 0.f;
@@ -546,7 +556,7 @@ int check_dims(const char* who, int B, int C, int HW) {
 extern "C" size_t cseg_bn_ws_floats(int B, int C, int HW) {
     if (B <= 0 || C <= 0 || HW <= 0) return 0;
     const BnDims d = bn_dims(B, C, HW);
-    return (size_t)d.S * C * 2 + (size_t)C * 4 + 4;      // partials + room for [C,2] fp64 sums (cseg_bn_bwd without dx)
+    return (size_t)d.S * C * 2 + (size_t)C * 4 + 8;      // partials + room for [C+1,2] fp64 sums (cseg_bn_bwd without dx)
 }
 
 extern "C" int cseg_bn_stats(const float* x, int B, int C, int HW, float* ws, double* moments, cseg_stream_t stream_) {
@@ -565,7 +575,7 @@ extern "C" int cseg_bn_finalize(const double* moments, int C, double count, floa
                                 float* running_var, int64_t* num_batches_tracked, float* mean_invstd,
                                 cseg_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    CSEG_REQUIRE(moments && mean_invstd && C > 0 && count > 0.0, "bn_finalize: bad arguments");
+    CSEG_REQUIRE(moments && mean_invstd && C > 0 && count >= 0.0, "bn_finalize: bad arguments");
     CSEG_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean/var must come together");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, moments, C, count, eps, momentum,
                        running_mean, running_var, num_batches_tracked, mean_invstd);
@@ -635,11 +645,11 @@ static int bn_bwd_apply_impl(const float* dy, const float* x, const float* mean_
     hipStream_t stream = (hipStream_t)stream_;
     if (!check_dims("bn_bwd_apply", B, C, HW)) return 0;
     CSEG_REQUIRE(dy && x && mean_invstd && dx, "bn_bwd_apply: null pointer");
-    CSEG_REQUIRE(sums == nullptr || count > 0.0, "bn_bwd_apply: count must be positive");
+    CSEG_REQUIRE(sums == nullptr || count >= 0.0, "bn_bwd_apply: count must not be negative");
     const BnDims d = bn_dims(B, C, HW);
     const dim3 grid((unsigned)((long)B * C * d.n_ck));
     const bool v = vec_ok(HW, dy, x, dx);
-    const double inv = sums ? 1.0 / count : 0.0;
+    const double inv = (sums && count > 0.0) ? 1.0 / count : 0.0;      // 0 = the kernel reads the count from row C of `sums`
 #define LAUNCH(V, M) hipLaunchKernelGGL((bn_bwd_apply_kernel<V, M>), grid, dim3(256), 0, stream, dy, x, mean_invstd, weight, \
                                         bias, sums, inv, d, dx, amax_out)
     if (v) { if (mask_from_x) LAUNCH(true, true); else LAUNCH(true, false); }

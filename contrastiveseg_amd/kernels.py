@@ -499,9 +499,10 @@ def _bn_ws(B, C, HW, device):
 
 @torch.no_grad()
 def bn_stats(x):
-    """-> moments [C,2] f64 = (sum x, sum x^2) over this rank's values (the tensor a SyncBN exchange all-reduces)."""
+    """-> moments [C+1,2] f64: rows 0..C-1 = (sum x, sum x^2) over this rank's values, row C = (this rank's element count per
+    channel, 0) -- the tensor a SyncBN exchange all-reduces; the summed row C is the global count (bn_finalize with count 0)."""
     B, C, HW = _bn_dims(x)
-    moments = torch.empty(C, 2, dtype=F64, device=x.device)
+    moments = torch.empty(C + 1, 2, dtype=F64, device=x.device)
     _hip.call("cseg_bn_stats", _p(x, F32, "x"), B, C, HW, _p(_bn_ws(B, C, HW, x.device), F32, "ws"),
               _p(moments, F64, "moments"), _hip.stream_ptr())
     return moments
@@ -509,8 +510,9 @@ def bn_stats(x):
 
 @torch.no_grad()
 def bn_finalize(moments, count, eps, momentum, running_mean, running_var, num_batches_tracked):
-    """(global) moments -> mean_invstd [C,2] f32; running statistics / batch counter updated in place."""
-    C = moments.shape[0]
+    """(global) moments [C+1,2] -> mean_invstd [C,2] f32; running statistics / batch counter updated in place. count 0 = read the
+    exchanged count from row C on the device (no host round trip, unequal per-rank batches allowed)."""
+    C = moments.shape[0] - 1
     mi = torch.empty(C, 2, dtype=F32, device=moments.device)
     _hip.call("cseg_bn_finalize", _p(moments, F64, "moments"), C, float(count), float(eps), float(momentum),
               _opt(running_mean, F32, "running_mean"), _opt(running_var, F32, "running_var"),
@@ -543,10 +545,11 @@ def bn_apply(x, mean_invstd, weight, bias, residual, relu, amax=None):
 
 @torch.no_grad()
 def bn_bwd_reduce(dy, x, out, mean_invstd, weight, bias, mode):
-    """-> (sums [C,2] f64, d_weight [C], d_bias [C], g_masked or None). mode: 0 none | 1 ReLU mask from x | 2 from out."""
+    """-> (sums [C+1,2] f64 (row C = this rank's element count, 0), d_weight [C], d_bias [C], g_masked or None).
+    mode: 0 none | 1 ReLU mask from x | 2 from out."""
     B, C, HW = _bn_dims(x)
     dev = x.device
-    sums = torch.empty(C, 2, dtype=F64, device=dev)
+    sums = torch.empty(C + 1, 2, dtype=F64, device=dev)
     d_weight = torch.empty(C, dtype=F32, device=dev)
     d_bias = torch.empty(C, dtype=F32, device=dev)
     g = torch.empty_like(x) if mode == 2 else None
@@ -559,7 +562,8 @@ def bn_bwd_reduce(dy, x, out, mean_invstd, weight, bias, mode):
 
 @torch.no_grad()
 def bn_bwd_apply(dy, x, mean_invstd, weight, bias, sums, count, mask_from_x, amax=None):
-    """sums None = frozen statistics (eval mode). amax: zeroed word that receives max|dx|."""
+    """sums None = frozen statistics (eval mode); count 0 = the exchanged count in row C of `sums`. amax: zeroed word that
+    receives max|dx|."""
     B, C, HW = _bn_dims(x)
     dx = torch.empty_like(x)
     _hip.call("cseg_bn_bwd_apply_amax", _p(dy, F32, "dy"), _p(x, F32, "x"), _p(mean_invstd, F32, "mean_invstd"),
@@ -735,48 +739,75 @@ class SplitWeights(object):
     step (zero the max|w| records, cseg_amax_batch, cseg_split_pack_batch) instead of three launches per layer (round-3 trace:
     213 + 426 launches of ~5 us = 3.9 ms of GPU time and as many host launches per step).
     A pack request (weight, operator) is registered on first use; its buffer and the weight's max|w| record then live as long as
-    the weight. Staleness = the weight's (storage pointer, version counter) differs from what was packed: an optimizer step
-    bumps the version of every trained weight, and the first request of the next forward repacks every stale entry at once."""
+    the weight. Staleness = the weight's (storage pointer, version counter, epoch) differs from what was packed. The version
+    counter alone is NOT enough: torch's fused optimizers (torch._fused_sgd_ & co.) and every write through `param.data` or a raw
+    pointer change the values without bumping `Tensor._version` (with fused SGD the step-0 packs stayed in use for the
+    whole run). So there is an explicit `epoch`, advanced by `invalidate()`:
+      * after EVERY optimizer step of ANY torch optimizer (a global step post-hook registered below),
+      * by ModuleRunner.load_state_dict (nn.Module.load_state_dict itself copies with `copy_`, which does bump the version),
+      * by the caller after any other out-of-band write (EMA / SWA copies through `.data`, manual re-initialisation).
+    The first request after that repacks every entry at once (three launches for the whole network)."""
 
     def __init__(self):
         self.weights = {}                                # id(weight) -> state dict (holds a weak reference; dropped with the weight)
-        self.arena = None                                # [n, AMAX_WORDS] int32: one record per registered weight
-        self.next_row = 0
-        self.table_cache = {}                            # kind of table -> (identity tuple, device tensor, n_jobs, total_blocks)
+        self.arenas = {}                                 # device -> [arena [n, AMAX_WORDS] int32 (one record per weight), next free row]
+        self.table_cache = {}                            # (device, kind of table) -> (identity tuple, device tensor, n_jobs, total_blocks)
+        self.epoch = 0
+
+    def invalidate(self):
+        """Marks every packed weight (and its max|w| record) stale: call after any change of weight VALUES that does not go through
+        an autograd-visible in-place op. Costs nothing until the next request."""
+        self.epoch += 1
+
+    @staticmethod
+    def _dkey(device):
+        return (device.type, device.index)
 
     def _record(self, state):
-        return self.arena[state["row"]]
+        return self.arenas[state["dev"]][0][state["row"]]
 
     def _grow(self, device):
-        n = 0 if self.arena is None else self.arena.shape[0]
+        """A larger record arena for `device` (one arena per device: two GPUs in one process keep separate tables)."""
+        key = self._dkey(device)
+        old = self.arenas.get(key)
+        n = 0 if old is None else old[0].shape[0]
         new = torch.zeros(max(512, 2 * n), AMAX_WORDS, dtype=I32, device=device)
         if n:
-            new[:n].copy_(self.arena)
-        self.arena = new
+            new[:n].copy_(old[0])
+        self.arenas[key] = [new, 0 if old is None else old[1]]
         for st in self.weights.values():
-            for e in st["entries"].values():
-                e["version"] = None                      # record addresses changed: every entry is packed again
-        self.table_cache.clear()
+            if st["dev"] == key:
+                for e in st["entries"].values():
+                    e["version"] = None                  # record addresses changed: every entry of this device is packed again
+        for k in [k for k in self.table_cache if k[0] == key]:
+            del self.table_cache[k]
 
     def get(self, weight, tag, flag, nt_req):
         """-> (packed buffer uint8, max|w| record or None). tag: 'c3' | 'c1'."""
         arith = split_arith_id()
         st = self.weights.get(id(weight))
-        if st is None or st["ref"]() is not weight:
-            if self.arena is None or self.next_row >= self.arena.shape[0] or self.arena.device != weight.device:
+        dkey = self._dkey(weight.device)
+        if st is None or st["ref"]() is not weight or st["dev"] != dkey:
+            ar = self.arenas.get(dkey)
+            if ar is None or ar[1] >= ar[0].shape[0]:
                 self._grow(weight.device)
+                ar = self.arenas[dkey]
             wid = id(weight)
-            st = {"row": self.next_row, "entries": {}, "ref": weakref.ref(weight, lambda _r, wid=wid: self.weights.pop(wid, None))}
-            self.next_row += 1                           # rows are not recycled (a dead weight's row stays zero)
+            st = {"row": ar[1], "dev": dkey, "entries": {},
+                  "ref": weakref.ref(weight, lambda _r, wid=wid: self.weights.pop(wid, None))}
+            ar[1] += 1                                   # rows are not recycled (a dead weight's row stays zero)
             self.weights[wid] = st
         key = (tag, bool(flag), int(nt_req), SPLIT_ARITH, os.environ.get("CSEG_CONV3X3_SB_VAR"), os.environ.get("CSEG_CONV3X3_SB16_CH"))
         e = st["entries"].get(key)
         if e is None:
             e = self._plan(weight, tag, flag, nt_req, arith)
             st["entries"][key] = e
-        now = (weight.data_ptr(), weight._version)
+        now = (weight.data_ptr(), weight._version, self.epoch)
         if e["version"] != now:
-            self.refresh()
+            self.refresh(weight.device)
+            if e["version"] != now:
+                raise RuntimeError("SplitWeights: the packed form of a %s weight on %s is still stale after a refresh"
+                                   % (tuple(weight.shape), weight.device))
         return e["wp"], (self._record(st) if arith else None)
 
     def _plan(self, weight, tag, flag, nt_req, arith):
@@ -803,20 +834,23 @@ class SplitWeights(object):
                 "version": None, "arith": arith}
 
     @torch.no_grad()
-    def refresh(self):
+    def refresh(self, device):
         """Host cost matters here: this runs at the top of every step, when the GPU has nothing queued behind the optimizer kernels
         (tools/host_profile.py: 2.7 ms per step for the first version, which rebuilt ~1 000 Python tuples and ~1 300 tensor views per
         step only to find the cached device tables unchanged). Now one pass over the entries collects what identifies the tables BY
         VALUE (pointers, record rows, formats); the row tuples are only built on a cache miss."""
         arith = split_arith_id()
-        base = self.arena.data_ptr()
+        dkey = self._dkey(device)
+        arena = self.arenas[dkey][0]
+        base = arena.data_ptr()
+        epoch = self.epoch
         stale, every = [], []
         for st in list(self.weights.values()):               # (a copy: weak-reference callbacks may drop entries meanwhile)
             w = st["ref"]()
-            if w is None or not _on_device(w) or w.device != self.arena.device:
+            if w is None or st["dev"] != dkey or not _on_device(w):
                 continue
             ptr = w.data_ptr()
-            now = (ptr, w._version)
+            now = (ptr, w._version, epoch)
             every.append((ptr, w.numel(), st["row"]))
             for e in st["entries"].values():
                 if e["version"] != now and e["arith"] == arith:
@@ -827,22 +861,23 @@ class SplitWeights(object):
         rec = lambda row: base + row * AMAX_WORDS * 4                    # device address of a max|w| record (int32 words)
         if arith:
             # all records are re-accumulated (140 MB of weights: ~30 us), so one fill serves them all
-            self.arena.zero_()
-            tab = self._table("amax", tuple(every),
+            arena.zero_()
+            tab = self._table(dkey, "amax", tuple(every),
                               lambda: [(ptr, 0, rec(row), 0, 0, 0, 0, 0, n, max(1, min(64, n // 16384))) for ptr, n, row in every])
             _hip.call("cseg_amax_batch", tab[0].data_ptr(), tab[1], tab[2], sp)
-        tab = self._table("pack", tuple((now[0], e["wp_ptr"], st["row"], e["flag"], e["nt"], e["kind"], e["total"]) for _, st, e, now in stale),
+        tab = self._table(dkey, "pack", tuple((now[0], e["wp_ptr"], st["row"], e["flag"], e["nt"], e["kind"], e["total"]) for _, st, e, now in stale),
                           lambda: [(now[0], e["wp_ptr"], rec(st["row"]) if arith else 0, w.shape[0], w.shape[1], e["flag"], e["nt"],
                                     e["kind"], e["total"], (e["total"] + 255) // 256) for w, st, e, now in stale])
         _hip.call("cseg_split_pack_batch", tab[0].data_ptr(), tab[1], tab[2], arith, sp)
         for _, _, e, now in stale:
             e["version"] = now
 
-    def _table(self, name, identity, make_rows):
+    def _table(self, dkey, name, identity, make_rows):
         """make_rows() -> rows (src, dst, amax, cout, cin, flag, nt, kind, total, n_blocks); returns (device table, n_jobs,
         total_blocks). The device copy is reused while the same jobs come back (every step of a training run). `identity` must name
         everything the table holds by VALUE -- pointers and record rows, not Python object ids (those are recycled: a new layer that
         landed on a dead layer's id and storage would otherwise inherit its max|w| row, and a zero row means an overflowing scale)."""
+        name = (dkey, name)
         hit = self.table_cache.get(name)
         if hit is not None and hit[0] == identity:
             return hit[1:]
@@ -852,12 +887,23 @@ class SplitWeights(object):
         for i, r in enumerate(rows):
             arr[i] = (r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], b0, 0)
             b0 += r[9]
-        dev = torch.from_numpy(arr.view(np.uint8).copy()).to(self.arena.device)
+        dev = torch.from_numpy(arr.view(np.uint8).copy()).to(self.arenas[dkey][0].device)
         self.table_cache[name] = (identity, dev, len(rows), b0)
         return dev, len(rows), b0
 
 
 SPLIT_WEIGHTS = SplitWeights()
+
+
+def invalidate_packed_weights(*_args, **_kwargs):
+    """Hook form of SPLIT_WEIGHTS.invalidate() (looked up at call time: tests replace the instance)."""
+    SPLIT_WEIGHTS.invalidate()
+
+
+# Every optimizer step marks the packs stale -- whatever the optimizer implementation does to Tensor._version (torch's fused
+# kernels do not touch it).
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook
+_register_step_hook(invalidate_packed_weights)
 
 
 # ----------------------------------------------------------------------------------------------------------

@@ -26,36 +26,21 @@ def _all_reduce(t, group):
     return t
 
 
-_EQUAL_COUNT_CHECKED = set()       # (shape, id of the process group) already verified in this process
-
-
-def check_equal_counts(x, sync_group):
-    """The SyncBN exchange takes the global element count as n_local * world (one fp64 all-reduce of the moments, no second
-    collective and no host round trip per layer). That is only right when every rank contributes the same number of elements, which
-    the shipped loaders guarantee (data_loader.py: equal shards, drop_last) -- a custom loader or a last partial batch would
-    silently skew mean / var / dx (torch's SyncBatchNorm gathers the per-rank counts instead). So the assumption is VERIFIED once
-    per input shape and process group: one tiny all-reduce and one host read the first time a shape is seen, nothing afterwards.
-    Every rank of the group reaches this through the same code path (a rank with a different shape raises here instead of hanging
-    later)."""
-    key = (tuple(x.shape[1:]), id(sync_group))           # per-image shape: the batch dimension is what may differ
-    mark = (x.shape[0],) + key
-    if mark in _EQUAL_COUNT_CHECKED:
-        return
-    n = float(x.numel() // x.shape[1])
-    t = torch.tensor([n, -n], dtype=torch.float64, device=x.device)
-    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=sync_group)
-    hi, lo = float(t[0]), -float(t[1])
-    if hi != lo:
-        raise RuntimeError("FusedSyncBatchNorm: ranks contribute different element counts per channel (min %d, max %d, this rank %d): "
-                           "the fused exchange assumes equal per-rank batches (use drop_last / equal shards, or nn.SyncBatchNorm)"
-                           % (int(lo), int(hi), int(n)))
-    _EQUAL_COUNT_CHECKED.add(mark)
+# Element counts under SyncBN. The exchange sums, with the moments, each rank's element count per channel (row C of the
+# [C+1,2] fp64 tensor cseg_bn_stats / cseg_bn_bwd_reduce write, ABI 4), and cseg_bn_finalize / cseg_bn_bwd_apply read the
+# summed count ON THE DEVICE (count argument 0). Ranks may therefore contribute different batch sizes -- a last partial
+# batch, a custom loader -- exactly like torch.nn.SyncBatchNorm (which all_gathers the counts), with no second collective,
+# no host round trip and nothing cached per shape. (Round 3 assumed equal batches and verified the assumption with an
+# extra MAX all-reduce that was skipped for shapes a rank had seen before: a rank with a new shape issued it while its
+# peers did not, and the collectives fell out of step -- ADVICE r3.)
+SYNC_COUNT = 0.0          # "take the count from the exchanged tensor"
 
 
 def bn_forward(x, weight, bias, residual, running_mean, running_var, num_batches_tracked, training, relu, momentum, eps,
                sync_group):
     """Device half of one BN(+residual)(+ReLU) site -> (y, mean_invstd [C,2], count). x / residual contiguous.
-    sync_group: None = local statistics; otherwise the process group whose ranks share statistics."""
+    sync_group: None = local statistics; otherwise the process group whose ranks share statistics. count: a float
+    (local statistics) or a 0-dim fp64 DEVICE tensor (synchronised: the summed per-rank counts, never read by the host)."""
     n_local = x.numel() // x.shape[1]
     count = float(n_local)
     # max|y|, accumulated by the apply kernel while it stores y: the next split-operand convolution (f16x3 arithmetic) scales
@@ -63,11 +48,9 @@ def bn_forward(x, weight, bias, residual, running_mean, running_var, num_batches
     amax = K.amax_request(x)
     if training:
         if sync_group is not None:
-            world = torch.distributed.get_world_size(sync_group)
-            check_equal_counts(x, sync_group)
-            moments = _all_reduce(K.bn_stats(x), sync_group)
-            count = float(n_local * world)          # equal per-rank batch: verified once per shape above
-            mi = K.bn_finalize(moments, count, eps, momentum, running_mean, running_var, num_batches_tracked)
+            moments = _all_reduce(K.bn_stats(x), sync_group)          # [C+1,2]: row C = summed element counts
+            count = moments[-1, 0]
+            mi = K.bn_finalize(moments, SYNC_COUNT, eps, momentum, running_mean, running_var, num_batches_tracked)
             y = K.bn_apply(x, mi, weight, bias, residual, relu, amax=amax)
         else:
             # single rank: statistics + (finalise, running statistics, apply) in two launches
@@ -92,8 +75,8 @@ def bn_backward(dy, x, out, mi, weight, bias, relu, has_res, training, count, sy
         sums, d_weight, d_bias, g = K.bn_bwd_reduce(dy, x, out, mi, weight, bias, mode)
         dx = None
         if want_dx:
-            sums = _all_reduce(sums, sync_group)
-            dx = K.bn_bwd_apply(g if mode == 2 else dy, x, mi, weight, bias, sums, count, mode == 1, amax=amax)
+            sums = _all_reduce(sums, sync_group)                      # [C+1,2]: row C = summed element counts again
+            dx = K.bn_bwd_apply(g if mode == 2 else dy, x, mi, weight, bias, sums, SYNC_COUNT, mode == 1, amax=amax)
     if dx is not None:
         K.amax_attach(dx, amax)
     d_res = None
@@ -137,31 +120,27 @@ class _BNActGroup(torch.autograd.Function):
         # meta: per site (running_mean, running_var, num_batches_tracked, relu, momentum, eps)
         # tensors: per site x, weight, bias, residual (None allowed for weight / bias / residual)
         n = len(meta)
-        world = torch.distributed.get_world_size(sync_group)
         xs, moments = [], []
         for i in range(n):
             x = tensors[4 * i].contiguous()
-            check_equal_counts(x, sync_group)
             xs.append(x)
-            moments.append(K.bn_stats(x))
+            moments.append(K.bn_stats(x))                 # [C_i + 1, 2]: the last row carries this rank's element count
         packed = _all_reduce(torch.cat(moments, dim=0), sync_group)
-        outs, saved, counts = [], [], []
+        outs, saved = [], []
         off = 0
         for i in range(n):
             rm, rv, nbt, relu, momentum, eps = meta[i]
             x, w, b, r = xs[i], tensors[4 * i + 1], tensors[4 * i + 2], tensors[4 * i + 3]
             C = x.shape[1]
-            count = float((x.numel() // C) * world)
-            mi = K.bn_finalize(packed[off:off + C].contiguous(), count, eps, momentum, rm, rv, nbt)
-            off += C
+            mi = K.bn_finalize(packed[off:off + C + 1], SYNC_COUNT, eps, momentum, rm, rv, nbt)     # a row slice: contiguous
+            off += C + 1
             r = None if r is None else r.contiguous()
             amax = K.amax_request(x)
             y = K.amax_attach(K.bn_apply(x, mi, w, b, r, relu, amax=amax), amax)
             outs.append(y)
-            counts.append(count)
             saved += [x, mi, w, b, y if (relu and r is not None) else None]
         ctx.meta = [(m[3], tensors[4 * i + 3] is not None) for i, m in enumerate(meta)]
-        ctx.counts, ctx.sync_group = counts, sync_group
+        ctx.sync_group = sync_group
         ctx.save_for_backward(*saved)
         return tuple(outs)
 
@@ -187,9 +166,9 @@ class _BNActGroup(torch.autograd.Function):
             dx = None
             if ctx.needs_input_grad[2 + 4 * i]:
                 amax = K.amax_request(x)
-                dx = K.amax_attach(K.bn_bwd_apply(g if mode == 2 else dy, x, mi, w, b, packed[off:off + C].contiguous(),
-                                                  ctx.counts[i], mode == 1, amax=amax), amax)
-            off += C
+                dx = K.amax_attach(K.bn_bwd_apply(g if mode == 2 else dy, x, mi, w, b, packed[off:off + C + 1],
+                                                  SYNC_COUNT, mode == 1, amax=amax), amax)
+            off += C + 1
             d_res = (g if mode == 2 else dy) if (ctx.meta[i][1] and ctx.needs_input_grad[2 + 4 * i + 3]) else None
             grads += [dx, d_w if w is not None else None, d_b if b is not None else None, d_res]
         return tuple(grads)

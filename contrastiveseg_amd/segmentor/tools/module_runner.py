@@ -107,6 +107,8 @@ class ModuleRunner(object):
                 mismatched.append('{}: {} vs {}'.format(name, tuple(own[name].shape), tuple(param.shape)))
                 continue
             own[name].copy_(param)
+        from contrastiveseg_amd import kernels as K
+        K.SPLIT_WEIGHTS.invalidate()          # packed convolution weights follow the new values (copy_ bumps the version too)
         missing = sorted(set(own.keys()) - set(state_dict.keys()))
         msg = []
         if unexpected:

@@ -171,14 +171,17 @@ int cseg_queue_write_pixels(const float* keys, int B, int D, int Pk, const int32
  *   relu(bn(conv(x)) [+ residual]) chains of lib/models/backbones/hrnet/hrnet_backbone.py:49-105 and
  *   lib/models/backbones/resnet/resnet_models.py run as separate BN / add / clamp / threshold kernels.
  * x, y, dy, dx, residual, out: [B,C,HW] f32.  mean_invstd [C,2] f32 = (mean, 1/sqrt(var+eps)).
- * moments / sums [C,2] f64: the ONLY data a SyncBN exchange needs -- the host all-reduces them (RCCL) between
- * cseg_bn_stats and cseg_bn_finalize, and between cseg_bn_bwd_reduce and cseg_bn_bwd_apply.
+ * moments / sums [C+1,2] f64: the ONLY data a SyncBN exchange needs -- the host all-reduces them (RCCL) between
+ * cseg_bn_stats and cseg_bn_finalize, and between cseg_bn_bwd_reduce and cseg_bn_bwd_apply. Row C (ABI 4) carries this
+ * rank's element count per channel (B*HW, 0): summed by the same all-reduce it becomes the GLOBAL count, which
+ * cseg_bn_finalize / cseg_bn_bwd_apply read on the device when their `count` argument is 0 -- ranks may then contribute
+ * different batch sizes (torch.nn.SyncBatchNorm semantics) without a second collective or a host round trip.
  * ws: cseg_bn_ws_floats(B,C,HW) floats of scratch.  weight / bias may be NULL (affine=False).
  * ------------------------------------------------------------------------------------------------ */
 size_t cseg_bn_ws_floats(int B, int C, int HW);
-/* moments[c] = (sum x, sum x^2) over this rank's B*HW values of channel c */
+/* moments[c] = (sum x, sum x^2) over this rank's B*HW values of channel c; moments[C] = (B*HW, 0) */
 int cseg_bn_stats(const float* x, int B, int C, int HW, float* ws, double* moments, cseg_stream_t stream);
-/* (globally summed) moments + total count -> mean_invstd; running_mean/var (nullable pair) updated in place with
+/* (globally summed) moments + total count (0 = moments[C][0]) -> mean_invstd; running_mean/var (nullable pair) updated in place with
  * `momentum` and the unbiased variance, *num_batches_tracked (nullable, i64) incremented: nn.BatchNorm2d semantics */
 int cseg_bn_finalize(const double* moments, int C, double count, float eps, float momentum, float* running_mean,
                      float* running_var, int64_t* num_batches_tracked, float* mean_invstd, cseg_stream_t stream);
@@ -198,13 +201,13 @@ int cseg_bn_bwd(const float* dy, const float* x, const float* out, const float* 
 /* y = relu?((x - mean) * invstd * weight + bias [+ residual]) */
 int cseg_bn_apply(const float* x, const float* residual, const float* mean_invstd, const float* weight,
                   const float* bias, int relu, int B, int C, int HW, float* y, cseg_stream_t stream);
-/* sums[c] = (sum dy', sum dy' * (x - mean)); d_weight[c] = sums[c][1] * invstd, d_bias[c] = sums[c][0] (nullable,
+/* sums[c] = (sum dy', sum dy' * (x - mean)), sums[C] = (B*HW, 0); d_weight[c] = sums[c][1] * invstd, d_bias[c] = sums[c][0] (nullable,
  * rank-local like torch's SyncBatchNorm).  dy' = dy (mode 0) | dy * [(x-mean)*invstd*w+b > 0] (mode 1: ReLU mask
  * recomputed from x) | dy * [out > 0] (mode 2: residual case; dy' is written to g_masked = gradient of the residual) */
 int cseg_bn_bwd_reduce(const float* dy, const float* x, const float* out, const float* mean_invstd, const float* weight,
                        const float* bias, int mode, int B, int C, int HW, float* ws, float* g_masked, double* sums,
                        float* d_weight, float* d_bias, cseg_stream_t stream);
-/* dx = w*invstd * (dy' - sums0/count - (x-mean) * invstd^2 * sums1/count); sums == NULL: frozen statistics (eval),
+/* dx = w*invstd * (dy' - sums0/count - (x-mean) * invstd^2 * sums1/count), count 0 = sums[C][0]; sums == NULL: frozen statistics (eval),
  * dx = w*invstd*dy'.  mask_from_x: apply the mode-1 mask to dy here too (pass the already masked g for mode 2). */
 int cseg_bn_bwd_apply(const float* dy, const float* x, const float* mean_invstd, const float* weight, const float* bias,
                       const double* sums, double count, int mask_from_x, int B, int C, int HW, float* dx,

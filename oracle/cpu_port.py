@@ -209,12 +209,18 @@ def _bn_flat(x):
 
 @torch.no_grad()
 def bn_stats(x):
+    """[C+1,2]: row C = (this rank's element count per channel, 0), as cseg_bn_stats (ABI 4)."""
     f = _bn_flat(x).double()
-    return torch.stack([f.sum((0, 2)), (f * f).sum((0, 2))], dim=1)
+    m = torch.stack([f.sum((0, 2)), (f * f).sum((0, 2))], dim=1)
+    n = torch.tensor([[float(f.shape[0] * f.shape[2]), 0.0]], dtype=torch.float64, device=x.device)
+    return torch.cat([m, n], dim=0)
 
 
 @torch.no_grad()
 def bn_finalize(moments, count, eps, momentum, running_mean, running_var, num_batches_tracked):
+    if count == 0:
+        count = float(moments[-1, 0])              # the exchanged count (the kernel reads it on the device)
+    moments = moments[:-1]
     mean = moments[:, 0] / count
     var = (moments[:, 1] / count - mean * mean).clamp_(min=0.0)
     if running_mean is not None:
@@ -260,7 +266,8 @@ def bn_bwd_reduce(dy, x, out, mean_invstd, weight, bias, mode):
         g = dy * (out > 0)
     s0 = _bn_flat(g).double().sum((0, 2))
     s1 = (_bn_flat(g).double() * _bn_flat(xm).double()).sum((0, 2))
-    sums = torch.stack([s0, s1], dim=1)
+    n = torch.tensor([[float(x.numel() // x.shape[1]), 0.0]], dtype=torch.float64, device=x.device)
+    sums = torch.cat([torch.stack([s0, s1], dim=1), n], dim=0)
     return sums, (s1 * mean_invstd[:, 1].double()).float(), s0.float(), (g if mode == 2 else None)
 
 
@@ -287,6 +294,9 @@ def bn_bwd_apply(dy, x, mean_invstd, weight, bias, sums, count, mask_from_x, ama
     g = dy * (z > 0) if mask_from_x else dy
     if sums is None:
         return g * a.reshape(shape)
+    if count == 0:
+        count = float(sums[-1, 0])
+    sums = sums[:-1]
     k0d = sums[:, 0] / count
     k0 = k0d.float()
     k0l = (k0d - k0.double()).float().reshape(shape)      # mean(dy') carried as hi + lo, like the kernel

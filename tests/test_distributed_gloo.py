@@ -326,23 +326,41 @@ def _unequal_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from oracle import cpu_port
-    cpu_port.install(None)
-    from contrastiveseg_amd.lib.models.tools.fused_bn import FusedSyncBatchNorm
+    _install_device_half()
+    from contrastiveseg_amd.lib.models.tools.fused_bn import FusedSyncBatchNorm, bn_act_group
+    torch.manual_seed(3)
     m = FusedSyncBatchNorm(6).train()
-    x = torch.randn(2 + rank, 6, 5, 7)                   # rank 1 brings one image more
-    try:
-        m(x, relu=True)
-        q.put((rank, "no error"))
-    except RuntimeError as e:
-        q.put((rank, str(e)))
+    m2 = FusedSyncBatchNorm(6).train()
+    gen = torch.Generator().manual_seed(11)
+    out = []
+    # step 0: equal batches (2 + 2); step 1: rank 1 alone gets a LAST PARTIAL batch (2 + 1) -- the case in which round 3's
+    # once-per-shape check let the ranks' collectives fall out of step; step 2: the grouped exchange with unequal batches
+    for step, sizes in enumerate(((2, 2), (2, 1), (3, 1))):
+        x = torch.randn(sum(sizes), 6, 5, 8, generator=gen) * 1.5 + 0.5
+        g = torch.randn(sum(sizes), 6, 5, 8, generator=gen)
+        lo = sum(sizes[:rank])
+        xr = x[lo:lo + sizes[rank]].clone().requires_grad_(True)
+        if step < 2:
+            y = m(xr, relu=True)
+        else:
+            y, y2 = bn_act_group([(m, xr, None, True), (m2, xr * 2.0, None, False)])
+            y = y + y2
+        y.backward(g[lo:lo + sizes[rank]])
+        out.append((y.detach().numpy(), xr.grad.numpy(), m.weight.grad.numpy().copy(), m.running_var.numpy().copy()))
+        m.weight.grad = None
+        m2.weight.grad = None
+    q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_fused_syncbn_rejects_unequal_per_rank_batches():
-    """The fused exchange uses n_local * world as the global count; unequal per-rank batches must be an error on EVERY rank (not a
-    silently wrong mean / var), checked once per shape."""
+@pytest.mark.parametrize("device_half", ["cpu_port", "emu"])
+def test_fused_syncbn_takes_unequal_per_rank_batches(device_half, monkeypatch):
+    """The SyncBN exchange carries every rank's element count in the same all-reduce as the moments (row C, ABI 4) and the kernels
+    read the summed count on the device: per-rank batches of different sizes -- in particular a last partial batch on ONE rank
+    after warm-up -- give exactly what torch.nn.BatchNorm2d computes on the concatenated batch (= nn.SyncBatchNorm of the
+    reference), per site and through the grouped exchange, with no extra collective."""
+    monkeypatch.setenv("CSEG_TEST_DEVICE_HALF", device_half)
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -350,12 +368,28 @@ def test_fused_syncbn_rejects_unequal_per_rank_batches():
     procs = [ctx.Process(target=_unequal_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    res = dict(q.get(timeout=600) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, msg in res:
-        assert "different element counts" in msg and "min 70, max 105" in msg, (rank, msg)
+    torch.manual_seed(3)
+    bn, bn2 = torch.nn.BatchNorm2d(6).train(), torch.nn.BatchNorm2d(6).train()
+    gen = torch.Generator().manual_seed(11)
+    for step, sizes in enumerate(((2, 2), (2, 1), (3, 1))):
+        x = torch.randn(sum(sizes), 6, 5, 8, generator=gen) * 1.5 + 0.5
+        g = torch.randn(sum(sizes), 6, 5, 8, generator=gen)
+        xd = x.clone().requires_grad_(True)
+        y = torch.relu(bn(xd)) if step < 2 else torch.relu(bn(xd)) + bn2(xd * 2.0)
+        y.backward(g)
+        got_y = np.concatenate([res[0][step][0], res[1][step][0]])
+        got_dx = np.concatenate([res[0][step][1], res[1][step][1]])
+        assert np.abs(got_y - y.detach().numpy()).max() <= 5e-6, step
+        assert np.abs(got_dx - xd.grad.numpy()).max() <= 5e-6, step
+        assert np.abs(res[0][step][2] + res[1][step][2] - bn.weight.grad.numpy()).max() <= 2e-4, step
+        assert np.abs(res[0][step][3] - bn.running_var.numpy()).max() <= 1e-6, step
+        assert np.abs(res[1][step][3] - bn.running_var.numpy()).max() <= 1e-6, step
+        bn.weight.grad = None
+        bn2.weight.grad = None
 
 
 def _install_device_half():
@@ -392,7 +426,7 @@ def _hrnet_sync_worker(rank, world, port, q):
     real = dist.all_reduce
 
     def counting(t, *a, **k):
-        if k.get("op", dist.ReduceOp.SUM) == dist.ReduceOp.SUM:      # (not the once-per-shape MAX of fused_bn.check_equal_counts)
+        if k.get("op", dist.ReduceOp.SUM) == dist.ReduceOp.SUM:      # (SUM collectives only)
             calls["n"] += 1
         return real(t, *a, **k)
     dist.all_reduce = counting

@@ -510,6 +510,53 @@ def test_batched_weight_packs_equal_the_per_layer_packs(arith, monkeypatch):
     check()                                             # one stale weight among fresh ones
 
 
+@pytest.mark.parametrize("how", ["fused_sgd", "foreach_sgd", "param_data", "raw_pointer"])
+def test_packed_weights_follow_updates_that_skip_the_version_counter(how, monkeypatch):
+    """torch._fused_sgd_ updates parameters WITHOUT bumping Tensor._version, and so does every write through
+    `param.data` or a raw pointer; SplitWeights used to key staleness on (data_ptr, _version) alone, so the step-0 packs stayed in
+    use for the whole run. Now every optimizer step (global post-hook) and an explicit invalidate() advance an epoch. Three steps;
+    after each the split kernel's output must equal the convolution with the CURRENT weights."""
+    from contrastiveseg_amd import kernels as K
+    from contrastiveseg_amd.lib.models.tools.module_helper import Conv3x3
+    inject.install(monkeypatch)
+    monkeypatch.setattr(K, "SPLIT_ARITH", "f16x3")
+    monkeypatch.setattr(K, "SPLIT_WEIGHTS", K.SplitWeights())
+    monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
+    torch.manual_seed(11)
+    conv = Conv3x3(48, 48)
+    x = torch.randn(1, 48, 4, 64)
+    opt = None
+    if how.endswith("_sgd"):
+        try:
+            opt = torch.optim.SGD(conv.parameters(), lr=0.5, momentum=0.9, **({"fused": True} if how == "fused_sgd" else {"foreach": True}))
+        except (RuntimeError, TypeError) as e:
+            pytest.skip("this torch build has no fused SGD on the CPU: %s" % e)
+    for step in range(3):
+        y = conv(x)
+        ref = torch.nn.functional.conv2d(x.double(), conv.weight.detach().double(), None, 1, 1)
+        err = float((y.detach().double() - ref).abs().max()) / float(ref.abs().max())
+        assert err <= 3e-5, (how, step, err)          # a stale pack is off by the size of the update: O(1)
+        v0 = conv.weight._version
+        if opt is not None:
+            opt.zero_grad()
+            y.square().mean().backward()
+            conv.weight.grad.add_(0.3)                # a visible update whatever the loss gradient is
+            opt.step()
+            if how == "fused_sgd" and conv.weight._version != v0:
+                pass                                   # (a torch that bumps the version: the epoch is then redundant, not wrong)
+        elif how == "param_data":
+            conv.weight.data.mul_(1.5).add_(0.02)
+            K.SPLIT_WEIGHTS.invalidate()
+        else:
+            import ctypes
+            n = conv.weight.numel()
+            buf = (ctypes.c_float * n).from_address(conv.weight.data_ptr())
+            for i in range(0, n, 7):
+                buf[i] = buf[i] * -2.0 + 0.05
+            assert conv.weight._version == v0
+            K.SPLIT_WEIGHTS.invalidate()
+
+
 def test_batched_weight_packs_survive_recycled_layers(monkeypatch):
     """Layers that come and go (every test builds its own): a new weight that lands on a dead weight's Python id AND storage gets a
     fresh max|w| row, so the cached job table of the dead one must not be reused (it was, in the first hardware run: NaN outputs
@@ -531,7 +578,7 @@ def test_batched_weight_packs_survive_recycled_layers(monkeypatch):
         assert float((y.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
         seen.add((id(w), w.data_ptr()))
         # what the cached job tables are keyed on names pointers and record rows by value
-        ident = K.SPLIT_WEIGHTS.table_cache["amax"][0]
+        ident = K.SPLIT_WEIGHTS.table_cache[(("cpu", None), "amax")][0]
         assert ident == tuple((v.data_ptr(), v.numel(), st["row"]) for st in K.SPLIT_WEIGHTS.weights.values() for v in [st["ref"]()])
         del w, y
         gc.collect()

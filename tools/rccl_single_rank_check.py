@@ -53,7 +53,7 @@ def main():
     for name in ("all_reduce", "all_gather_into_tensor", "all_gather"):
         def wrap(fn, name=name):
             def f(*args, **kw):
-                if kw.get("op", dist.ReduceOp.SUM) == dist.ReduceOp.SUM:     # (not the once-per-shape MAX of fused_bn.check_equal_counts)
+                if kw.get("op", dist.ReduceOp.SUM) == dist.ReduceOp.SUM:     # (SUM collectives only)
                     n_coll["n"] += 1
                 return fn(*args, **kw)
             return f
