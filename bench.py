@@ -21,15 +21,18 @@ Scaling (--scaling): `strong` (default) = the BASELINE configuration: GLOBAL bat
 ranks; `weak` = per-GPU batch fixed at the global batch of the config. With N > 1 and strong scaling the weak-scaling
 throughput is measured as well (fewer steps, after the timed region) and reported under "weak".
 
-Besides the contract fields the line carries
-  roofline      whole-step view of the dominant work (dense conv contraction on MIOpen, MFMA-bound in fp32):
-                achieved = images/s x TFLOP/image (counted on the reference) against the fp32
-                MFMA peak of the N GPUs; step time from HIP events on the compute stream; traffic = HBM bytes per step
-                from the committed rocprofv3 PMC passes (profiles/r02_step_pmc.json), null if that file is absent.
-  kernels       per hand-written HIP kernel at this workload's shapes: HIP-event time, algorithmic bytes / flops
-                 and fraction of its own roofline.
+The contract line is the LAST line of stdout and at most 2 KB (the driver keeps a bounded tail of stdout; BENCH_r03 lost its
+head to a 12 KB line). It carries
+  roofline      whole step against the roof of THIS implementation: achieved = images/s x TFLOP/image (BASELINE.md section 2,
+                counted on the reference; HIP-event step time) / peak = the same flops with every pipe at its dense peak (split-
+                operand convolutions at 2500 / 3 TFLOP/s for f16x3, the rest at the 157.3 TFLOP/s fp32 MFMA peak); frac = A / P;
+                traffic = HBM bytes per step from the committed rocprofv3 PMC passes (profiles/*_step_pmc.json) or null;
+                dominant_kernel = the split-operand kernel with the largest calls x time product of this run {name, frac, us}.
   cpu_baseline  N=1, rank 0 only: CPU port of the same train step (same model classes, oracle/cpu_port.py device
                 half) timed on this box's usable host cores on a bounded sample, in a subprocess with a timeout.
+Everything else -- per-kernel rooflines of every hand-written kernel (`kernels`), of every split-operand launch shape of the
+step (`split_kernels`), the strict-fp32 comparison pass, notes -- goes to bench_detail.json (next to bench.py and under
+gpurun_out/ when that exists).
 """
 import argparse
 import json
@@ -314,6 +317,25 @@ def tally_split_calls(tr, batch, Kn):
     return counts
 
 
+def split_flops_of(counts):
+    """fp32-equivalent flops per step on the split-operand kernels, from the tally alone (no timing)."""
+    total = 0.0
+    for (name, sa, sb, flag), n in counts.items():
+        if name.startswith("conv3x3_s2_"):
+            if name == "conv3x3_s2_wrw":
+                ci, co, ho, wo = sa[1], sb[1], sb[2], sb[3]
+            else:
+                ci, co = sb[1], sb[0]
+                ho, wo = (sa[2], sa[3]) if name == "conv3x3_s2_bwd_run" else (sa[2] // 2, sa[3] // 2)
+            flops = 2.0 * sa[0] * ho * wo * ci * co * 9
+        elif name.endswith("_run"):
+            flops = 2.0 * sa[0] * sa[2] * sa[3] * sb[0] * sb[1] * sb[2] * sb[3]
+        else:
+            flops = 2.0 * sa[0] * sa[2] * sa[3] * sa[1] * sb[1] * (9 if name == "conv3x3_sb_wrw" else 1)
+        total += n * flops
+    return total
+
+
 def split_kernel_rooflines(counts, device, Kn):
     """Times every distinct (op, shape) of the tally in isolation (HIP events over a loop, weights packed and max|.| words
     computed once, as inside a step) -> list of dicts sorted by their share of the step, plus the fp32-equivalent flops per
@@ -381,61 +403,112 @@ def dominant_kernel(split_rows, arith):
             "picked_from": "live tally of one train step x live HIP-event timings (bench.py:split_kernel_rooflines)"}
 
 
+LINE_LIMIT = 2048          # bytes of the contract line: the driver keeps a bounded tail of stdout (BENCH_r03: parsed null at ~12 KB)
+DETAIL_NAME = "bench_detail.json"
+
+
+def arithmetic_name(Kn, split_on):
+    """`dtype` of the contract line: the arithmetic type the dominant path computes in."""
+    if not split_on:
+        return "fp32"
+    arith = getattr(Kn, "SPLIT_ARITH", "bf16x6")
+    return {"f16x3": "fp32 in/out, f16x3 split MFMA (fp32 accumulate)",
+            "bf16x6": "fp32 in/out, bf16x6 split MFMA (fp32 accumulate)"}[arith]
+
+
 def assemble_line(args, wl, cfg, world, global_batch, dt, ev_ms, final_loss, split_on, Kn, backend, fp32_pass, weak, cpu,
                   kernels, split_rows=None, split_flops=0.0):
-    """The ONE JSON line of the contract (pure function of the measurements: exercised on CPU by
-    tests/test_host_surface.py so that a formatting slip cannot cost a GPU run its result)."""
+    """-> (line, detail). `line` = the ONE JSON line of the contract, at most LINE_LIMIT bytes, printed LAST; `detail` = everything
+    else (per-kernel tables, notes, the comparison passes), written to bench_detail.json. Pure function of the measurements:
+    exercised on CPU by tests/test_host_surface.py so that a formatting slip cannot cost a GPU run its result.
+
+    roofline (top level) = the whole step against the roof of THIS implementation: achieved = images/s x TFLOP/image of
+    fp32-equivalent work (HIP-event step time); peak = the rate at which the same flops would run with every pipe at its dense
+    peak -- split-operand flops at 2500 / (MFMAs per product) TFLOP/s, the rest at the 157.3 TFLOP/s fp32 MFMA peak -- so
+    frac = achieved / peak = roof time / measured time. The figure against the fp32 MFMA peak alone (what a pure fp32
+    implementation is bounded by; can exceed 1) is kept as roofline.vs_fp32_mfma_peak."""
     ips = global_batch * args.steps / dt
+    step_ms = ev_ms / args.steps
     ips_ev = global_batch * args.steps / (ev_ms * 1e-3)
     achieved = ips_ev * wl["tflop"]
-    peak = PEAK_FP32_MFMA_TFLOPS * world
+    arith = getattr(Kn, "SPLIT_ARITH", "bf16x6")
+    total = wl["tflop"] * 1e12 * global_batch                      # flops per step, all ranks
+    split = min(split_flops * world, total) if split_on else 0.0   # the tally is per rank
+    rest = total - split
+    roof_s = (split / (peak_split_tflops(arith) * 1e12) + rest / (PEAK_FP32_MFMA_TFLOPS * 1e12)) / world
+    peak = total / roof_s * 1e-12                                   # TFLOP/s, whole job
     traffic, traffic_src = step_traffic() if (world == 1 and args.workload == "cfg2") else (None, None)
     W, H = cfg.get("train", "data_transformer")["input_size"]
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "split_TFLOP_per_step": round(split * 1e-12, 3), "fp32_TFLOP_per_step": round(rest * 1e-12, 3),
+                "vs_fp32_mfma_peak": round(achieved / (PEAK_FP32_MFMA_TFLOPS * world), 4)}
+    dom = dominant_kernel(split_rows, arith) if (split_on and split_rows) else None
+    if dom is not None:
+        roofline["dominant_kernel"] = {"name": dom["name"], "frac": dom["frac"], "us": dom["us_per_launch"],
+                                       "achieved": dom["achieved"], "peak": dom["peak"], "calls_per_step": dom["calls_per_step"]}
+    cpu_short = None
+    if cpu is not None:
+        cpu_short = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "error") if k in cpu}
+        if "sample" in cpu:
+            cpu_short["sample"] = cpu["sample"][:160]
     line = {
         "metric": "images/sec contrastive train step, HRNet-W48 1024x512 bs8" if args.workload == "cfg2" else
                   "images/sec contrastive train step, " + args.workload,
         "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
-        "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
-        "config": {"workload": wl["name"], "model": cfg.get("network", "model_name"),
+        "vs_baseline": None, "dtype": arithmetic_name(Kn, split_on), "data": "synthetic",
+        "config": {"workload": args.workload + ": " + wl["name"][:150], "model": cfg.get("network", "model_name"),
                    "loss": cfg.get("loss", "loss_type"), "global_batch": global_batch,
                    "per_gpu_batch": global_batch // world, "input": [3, H, W],
-                   "num_classes": cfg.get("data", "num_classes"), "labels": args.labels or wl["labels"],
-                   "parallelism": "dp%d" % world,
+                   "arithmetic": ("%s on the matrix cores for the 3x3 / 1x1 convolutions, rest fp32" % arith) if split_on else "fp32",
+                   "parallelism": "dp%d" % world, "backend": backend,
+                   "step_graph": os.environ.get("CSEG_STEP_GRAPH_STATE"),
+                   "final_loss": round(final_loss, 5)},
+        "roofline": roofline, "cpu_baseline": cpu_short, "detail": DETAIL_NAME,
+    }
+    if fp32_pass is not None and "ms_per_step" in fp32_pass:
+        line["fp32_conv_path_ms_per_step"] = fp32_pass["ms_per_step"]
+    if weak is not None:
+        line["weak"] = {k: weak[k] for k in ("value", "global_batch", "ms_per_step") if k in weak}
+    if os.environ.get("CSEG_BENCH_ROUTE_FALLBACK"):
+        line["config"]["route_fallback"] = os.environ["CSEG_BENCH_ROUTE_FALLBACK"][:200]
+    detail = {
+        "line": dict(line),
+        "config": {"workload": wl["name"], "num_classes": cfg.get("data", "num_classes"), "labels": args.labels or wl["labels"],
                    "cross_rank_contrast_set": bool(world > 1 and cfg.exists("contrast", "cross_rank")
                                                    and cfg.get("contrast", "cross_rank")),
-                   "backend": backend,
-                   "conv3x3_arithmetic": conv_arith_note(Kn, split_on),
-                   "miopen_find": bool(args.miopen_find), "channels_last": bool(args.channels_last),
-                   "final_loss": round(final_loss, 5),
-                   "route_fallback": os.environ.get("CSEG_BENCH_ROUTE_FALLBACK")},
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "note": "whole step: images/s (HIP-event time %.1f ms/step) x %.4f TFLOP/image of fp32-equivalent "
-                             "work vs the fp32 MFMA peak (the roof of a pure fp32 implementation: a fraction above 1 means "
-                             "the step beats what fp32 MFMA arithmetic could do at 100 %% utilisation). The split-operand "
-                             "convolutions run on the fp16/bf16 pipe, so the roof of THIS implementation is lower: see "
-                             "blended_roof; per-kernel rooflines under 'split_kernels' and 'kernels'"
-                             % (ev_ms / args.steps, wl["tflop"])},
-        "fp32_conv_path": fp32_pass, "weak": weak, "cpu_baseline": cpu, "kernels": kernels,
+                   "conv3x3_arithmetic": conv_arith_note(Kn, split_on), "miopen_find": bool(args.miopen_find),
+                   "channels_last": bool(args.channels_last)},
+        "roofline": {"traffic_source": traffic_src, "hip_event_ms_per_step": round(step_ms, 3),
+                     "roof_ms_per_step": round(roof_s * 1e3, 2), "dominant_kernel": dom,
+                     "note": "whole step: images/s (HIP-event time) x %.4f TFLOP/image of fp32-equivalent work; peak = split-operand flops "
+                             "at 2500 / %d TFLOP/s + remaining flops at 157.3 TFLOP/s (dense peaks, MI355X_MICROARCH.md)"
+                             % (wl["tflop"], MFMAS_PER_PRODUCT[arith])},
+        "fp32_conv_path": fp32_pass, "weak": weak, "cpu_baseline": cpu, "kernels": kernels, "split_kernels": split_rows,
     }
-    arith = getattr(Kn, "SPLIT_ARITH", "bf16x6")
-    dom = dominant_kernel(split_rows, arith) if split_on else None
-    if dom is not None:
-        line["roofline"]["dominant_kernel"] = dom
-    if split_rows:
-        line["split_kernels"] = split_rows
-    if split_on and split_flops > 0 and world == 1:
-        # the roof of this implementation: split-operand work at 2500 / (MFMAs per product) TFLOP/s, the rest at the fp32 MFMA peak
-        total = wl["tflop"] * 1e12 * global_batch
-        rest = max(total - split_flops, 0.0)
-        roof_ms = (split_flops / (peak_split_tflops(arith) * 1e12) + rest / (PEAK_FP32_MFMA_TFLOPS * 1e12)) * 1e3
-        line["roofline"]["blended_roof"] = {
-            "split_operand_TFLOP_per_step": round(split_flops * 1e-12, 3), "fp32_TFLOP_per_step": round(rest * 1e-12, 3),
-            "roof_ms_per_step": round(roof_ms, 2), "frac": round(roof_ms / (ev_ms / args.steps), 4),
-            "note": "roof = split-operand flops / (2500 / %d TFLOP/s) + remaining flops / 157.3 TFLOP/s; frac = roof time / "
-                    "measured step time" % MFMAS_PER_PRODUCT[arith]}
-    return line
+    # the contract line must fit whatever a configuration puts into it: shed the optional fields before a parser loses the head
+    for victim in ("weak", "fp32_conv_path_ms_per_step", "detail"):
+        if len(json.dumps(line)) <= LINE_LIMIT:
+            break
+        line.pop(victim, None)
+    if len(json.dumps(line)) > LINE_LIMIT:
+        line["config"] = {k: line["config"][k] for k in ("model", "global_batch", "arithmetic", "parallelism")}
+        line["config"]["workload"] = args.workload
+    return line, detail
+
+
+def write_detail(detail):
+    """bench_detail.json next to bench.py and, when it exists (GPU box: merged back by gpurun), under gpurun_out/."""
+    paths = [os.path.join(ROOT, DETAIL_NAME)]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", DETAIL_NAME))
+    for path in paths:
+        try:
+            with open(path, "w") as f:
+                json.dump(detail, f, indent=1)
+        except OSError as e:
+            sys.stderr.write("bench.py: could not write %s: %s\n" % (path, e))
 
 
 def usable_cores():
@@ -665,6 +738,16 @@ def main():
         finally:
             Kn.CONV3X3_SPLIT_BF16 = True
 
+    split_flops = 0.0
+    tally = None
+    if split_on:
+        # one extra untimed step with counting wrappers, on EVERY rank (it contains the step's collectives): which flops run on the
+        # split-operand kernels -> the roof of this implementation
+        try:
+            tally = tally_split_calls(tr, batch, Kn)
+            split_flops = split_flops_of(tally)
+        except Exception as e:
+            sys.stderr.write("bench.py: tally of the split-operand launches failed: %r\n" % (e,))
     weak = None
     # extra weak-scaling pass: RCCL runs only (the gloo dry run shares one GPU between the ranks and says nothing about
     # scaling), and only when the headline measurement itself was quick, so the whole invocation stays within minutes
@@ -684,11 +767,11 @@ def main():
         torch.cuda.empty_cache()
 
     kernels = None
-    split_rows, split_flops = None, 0.0
+    split_rows = None
     if rank == 0 and not args.no_kernels and args.workload == "cfg2":
-        if world == 1 and split_on:
+        if world == 1 and split_on and tally is not None:
             try:
-                split_rows, split_flops = split_kernel_rooflines(tally_split_calls(tr, batch, Kn), device, Kn)
+                split_rows, split_flops = split_kernel_rooflines(tally, device, Kn)
             except Exception as e:        # never lose the headline number to a micro-benchmark problem
                 split_rows = [{"error": repr(e)}]
         tr = None
@@ -707,10 +790,12 @@ def main():
         torch.distributed.barrier()
 
     if rank == 0:
-        line = assemble_line(args, wl, cfg, world, global_batch, dt, ev_ms, final_loss, split_on, Kn,
-                             torch.distributed.get_backend() if world > 1 else None, fp32_pass, weak, cpu, kernels,
-                             split_rows if (split_rows and "error" not in split_rows[0]) else None, split_flops)
-        print(json.dumps(line), flush=True)
+        line, detail = assemble_line(args, wl, cfg, world, global_batch, dt, ev_ms, final_loss, split_on, Kn,
+                                     torch.distributed.get_backend() if world > 1 else None, fp32_pass, weak, cpu, kernels,
+                                     split_rows if (split_rows and "error" not in split_rows[0]) else None, split_flops)
+        write_detail(detail)
+        sys.stderr.flush()
+        print(json.dumps(line), flush=True)           # the LAST line of stdout, <= LINE_LIMIT bytes
     if world > 1:
         torch.distributed.destroy_process_group()
 

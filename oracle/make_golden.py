@@ -469,6 +469,16 @@ STEP_CASES = {
                                          "decoder.layer_aspp.b1.0.weight", "decoder.layer_aspp.b4.1.weight", "decoder.layer_aspp.project.0.weight",
                                          "decoder.layer_dsn.0.weight", "decoder.refine.2.weight",
                                          "proj_head.proj.2.weight"]),
+    # BASELINE.json configs[3] names ResNet-101 (resnet_models.py:107-178 of the reference): the same step on the real depth
+    # (23 dilated blocks in layer3), round 4 -- the R-50 case above stays as the quick one.
+    "step_resnet101_deeplab": dict(model="deeplab_v3_contrast", backbone="deepbase_resnet101_dilated8",
+                                   loss="contrast_auxce_loss", K=7, B=4, H=97, W=129, seed=47, torch_seed=5, spread=True,
+                                   contrast=dict(max_samples=128, max_views=8, proj_dim=64),
+                                   watch=["backbone.resinit.conv1.weight", "backbone.layer2.0.downsample.0.weight",
+                                          "backbone.layer3.11.conv2.weight", "backbone.layer3.22.conv3.weight",
+                                          "backbone.layer4.2.conv2.weight", "decoder.layer_aspp.b1.0.weight",
+                                          "decoder.layer_aspp.project.0.weight", "decoder.layer_dsn.0.weight",
+                                          "decoder.refine.2.weight", "proj_head.proj.2.weight"]),
     # Frozen-statistics backward (round 3): the same network with BatchNorm in eval mode on statistics primed from this batch
     # (prime_bn) -- the adjoint of the eval-mode BN kernels inside a whole-network step. It was also an experiment (VERDICT r2
     # weak 3): does removing the batch-statistics terms make fp32 backward well conditioned? It does not: the reference's own fp32
