@@ -725,6 +725,10 @@ def main():
     # the same step with the 3x3 convolutions on the pure fp32 path (MIOpen + fp32-MFMA kernel), same trainer, same
     # batch: what the split-bf16 kernels buy, measured under the same clock
     fp32_pass = None
+    from contrastiveseg_amd.segmentor.tools import step_graph
+    graph_state = os.environ.get("CSEG_STEP_GRAPH_STATE")          # of the TIMED steps (the passes below run eagerly)
+    graph_was = step_graph.ENABLED
+    step_graph.ENABLED = False            # the comparison pass and the launch tally need the Python path (a replay ignores the switches)
     if split_on and not args.no_fp32_pass:
         Kn.CONV3X3_SPLIT_BF16 = False
         try:                              # never lose the headline number to the comparison pass
@@ -748,6 +752,9 @@ def main():
             split_flops = split_flops_of(tally)
         except Exception as e:
             sys.stderr.write("bench.py: tally of the split-operand launches failed: %r\n" % (e,))
+    step_graph.ENABLED = graph_was
+    if graph_state is not None:
+        os.environ["CSEG_STEP_GRAPH_STATE"] = graph_state
     weak = None
     # extra weak-scaling pass: RCCL runs only (the gloo dry run shares one GPU between the ranks and says nothing about
     # scaling), and only when the headline measurement itself was quick, so the whole invocation stays within minutes

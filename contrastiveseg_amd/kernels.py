@@ -833,6 +833,12 @@ class SplitWeights(object):
         return {"wp": wp, "wp_ptr": wp.data_ptr(), "kind": kind.value, "nt": nt.value, "total": threads.value, "flag": int(bool(flag)),
                 "version": None, "arith": arith}
 
+    def refresh_all(self):
+        """refresh() for every device that holds registered weights: what a hipGraph replay calls before its forward graph (the
+        replay runs none of the Python that would otherwise notice stale packs on first use)."""
+        for (kind, index), st in list(self.arenas.items()):
+            self.refresh(st[0].device)
+
     @torch.no_grad()
     def refresh(self, device):
         """Host cost matters here: this runs at the top of every step, when the GPU has nothing queued behind the optimizer kernels

@@ -88,6 +88,22 @@ def _block_chain(block, inplanes, planes, n, bn_type, momentum):
     return nn.Sequential(*blocks)
 
 
+_FORK_STREAMS = {}
+
+
+def _fork_streams(device, n):
+    import torch
+    have = _FORK_STREAMS.setdefault((device.type, device.index), [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
+
+
+def _capture_forks():
+    from contrastiveseg_amd.segmentor.tools import step_graph
+    return step_graph.capturing() and step_graph.BRANCH_STREAMS
+
+
 class HighResolutionModule(nn.Module):
     """One multi-resolution exchange unit: per-branch residual chains, then every output resolution sums all
     branches (strided 3x3 chains going down, 1x1 + bilinear going up). Reference :108-288."""
@@ -153,10 +169,33 @@ class HighResolutionModule(nn.Module):
             outs.append(K.fuse_sum_relu(same, low))
         return outs
 
+    def _branches_forked(self, x):
+        """Inside a hipGraph capture (segmentor/tools/step_graph.py): every branch after the first on a side stream of its own, forked
+        from and joined to the capturing stream -- the captured graph then has one independent path per branch (four residual chains of
+        equal flops whose kernels fill 4 / 1 / 1 / 0.5 rounds of the 256 CUs when they run one after the other), and autograd replays the
+        same fork in backward (a node's backward runs on the stream of its forward). Eager runs keep one stream: the host could not feed
+        four anyway."""
+        import torch
+        cur = torch.cuda.current_stream(x[0].device)
+        streams = _fork_streams(x[0].device, len(self.branches) - 1)
+        outs = [None] * len(self.branches)
+        for i in range(1, len(self.branches)):
+            streams[i - 1].wait_stream(cur)
+            with torch.cuda.stream(streams[i - 1]):
+                outs[i] = self.branches[i](x[i])
+        outs[0] = self.branches[0](x[0])
+        for s in streams:
+            cur.wait_stream(s)
+        return outs
+
     def forward(self, x):
         sync = self._sync_active()
-        x = self._branches_lockstep(x) if (sync and self.num_branches > 1) else \
-            [branch(xi) for branch, xi in zip(self.branches, x)]
+        if sync and self.num_branches > 1:
+            x = self._branches_lockstep(x)
+        elif self.num_branches > 1 and _capture_forks():
+            x = self._branches_forked(x)
+        else:
+            x = [branch(xi) for branch, xi in zip(self.branches, x)]
         if self.num_branches == 1:
             return x
         if sync:

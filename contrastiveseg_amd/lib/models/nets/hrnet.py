@@ -31,7 +31,7 @@ class HRNet_W48_CONTRAST(nn.Module):
     def forward(self, x_, with_embed=False, is_eval=False):
         feats = K.upsample_concat(self.backbone(x_))
         out = {'seg': self.cls_head(feats)}
-        if out['seg'].is_cuda and self.training:
+        if out['seg'].is_cuda and self.training and not torch.cuda.is_current_stream_capturing():
             # lets the criterion start anchor mining (and its one host round trip) on a side HIP stream while the
             # projection head below is still running on the compute stream (lib/loss/loss_contrast.py)
             out['seg_ready'] = torch.cuda.Event()

@@ -99,6 +99,10 @@ class Trainer(object):
         if self.configer.exists('network', 'channels_last') and self.configer.get('network', 'channels_last'):
             self.seg_net = self.seg_net.to(memory_format=torch.channels_last)
         self.seg_net = self.module_runner.load_net(self.seg_net)
+        # single-rank GPU runs: the segmentor's forward and backward are replayed as two hipGraphs (segmentor/tools/step_graph.py);
+        # everything the graphs do not cover (eval, other shapes, multi-rank) stays on the eager path
+        from contrastiveseg_amd.segmentor.tools import step_graph
+        self.step_graph = step_graph.install(_unwrap(self.seg_net), self.configer)
 
         Log.info('Params Group Method: {}'.format(self.configer.get('optim', 'group_method')))
         if self.configer.get('optim', 'group_method') == 'decay':

@@ -1,0 +1,118 @@
+"""hipGraph replay of the segmentor inside Trainer.train_step (segmentor/tools/step_graph.py) against the eager path: the same
+kernels on the same values, so losses, updated weights, BN buffers and the memory bank must agree to rounding after several steps
+-- for every model family of the hot path, with the split-operand kernels engaged (tile thresholds lifted) and dropout off (the
+graph-safe RNG of a captured dropout draws a different, equally valid mask sequence)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = [
+    ("hrnet_w48_contrast", "hrnet18", "contrast_ce_loss", "cityscapes/H_48_D_4.json", {}),
+    ("hrnet_w48_ocr_contrast", "hrnet18", "contrast_auxce_loss", "coco_stuff/H_48_D_4.json", {}),
+    ("hrnet_w48_mem", "hrnet18", "mem_contrast_ce_loss", "cityscapes/H_48_D_4_MEM.json", {"memory_size": 64}),
+    ("deeplab_v3_contrast", "deepbase_resnet18_dilated8", "contrast_auxce_loss", "cityscapes/R_101_D_8.json", {}),
+    ("deeplab_v3_contrast", "deepbase_resnet18_dilated8", "contrast_ce_loss", "cityscapes/R_101_D_8.json", {}),   # seg_aux unused
+]
+
+
+def _trainer(model, backbone, loss, cfg_file, contrast, batch=2):
+    from contrastiveseg_amd.lib.utils.tools.configer import Configer
+    from contrastiveseg_amd.segmentor.tools.data_helper import SyntheticLoader
+    from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
+    cfg = Configer(configs=os.path.join(ROOT, "configs", cfg_file))
+    cfg.update(["network", "backbone"], backbone)
+    cfg.update(["network", "model_name"], model)
+    cfg.update(["loss", "loss_type"], loss)
+    cfg.update(["data", "num_classes"], 7)
+    cfg.get("loss", "params").pop("ce_weight", None)
+    cfg.update(["train", "batch_size"], batch)
+    cfg.get("train", "data_transformer")["input_size"] = [256, 128]
+    cfg.update(["contrast", "warmup_iters"], 0)
+    cfg.update(["contrast", "max_views"], 1 if "mem" in loss else 12)
+    for k, v in contrast.items():
+        cfg.update(["contrast", k], v)
+    cfg.update(["solver", "max_iters"], 1000)
+    cfg.add(["network", "pretrained"], None)
+    cfg.add(["network", "resume"], None)
+    torch.manual_seed(304)
+    tr = Trainer(cfg, train_loader=[])
+    for m in tr.seg_net.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
+            m.p = 0.0
+    data = list(SyntheticLoader(cfg, tr.module_runner.device(), length=1, mode="blocky", fixed=True))[0]
+    tr.seg_net.train()
+    tr.pixel_loss.train()
+    return tr, data
+
+
+@pytest.mark.parametrize("model,backbone,loss,cfg_file,contrast", CASES)
+def test_graph_replay_equals_eager_steps(model, backbone, loss, cfg_file, contrast, monkeypatch):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from contrastiveseg_amd import kernels as K
+    from contrastiveseg_amd.segmentor.tools import step_graph
+    monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
+    monkeypatch.setattr(K, "CONV1X1_SB_MIN_TILES", 1)
+    steps = 5
+    runs = {}
+    for name, on in (("eager", False), ("graph", True)):
+        monkeypatch.setattr(step_graph, "ENABLED", on)
+        tr, data = _trainer(model, backbone, loss, cfg_file, contrast)
+        torch.manual_seed(17)                                    # the anchor draws (CPU generator)
+        losses = [float(tr.train_step(data)) for _ in range(steps)]
+        torch.cuda.synchronize()
+        sd = {k: v.detach().float().cpu().numpy().copy() for k, v in tr.seg_net.state_dict().items()}
+        runs[name] = (losses, sd)
+        if on:
+            g = tr.step_graph
+            assert g is not None and g.failed is None and len(g.captured) == 1, (g and g.failed)
+            assert os.environ.get("CSEG_STEP_GRAPH_STATE", "").startswith("replay"), os.environ.get("CSEG_STEP_GRAPH_STATE")
+        else:
+            assert tr.step_graph is None or not tr.step_graph.captured
+        del tr, data
+        torch.cuda.empty_cache()
+    le, lg = np.array(runs["eager"][0]), np.array(runs["graph"][0])
+    assert np.isfinite(le).all() and np.isfinite(lg).all()
+    assert np.abs(le - lg).max() <= 2e-5 * np.abs(le).max(), (le.tolist(), lg.tolist())
+    worst = ("", 0.0)
+    for k, a in runs["eager"][1].items():
+        b = runs["graph"][1][k]
+        scale = max(float(np.abs(a).max()), 1e-12)
+        dev = float(np.abs(a - b).max()) / scale
+        if dev > worst[1]:
+            worst = (k, dev)
+        # five SGD steps of lr 0.01 on gradients that agree to rounding; BN buffers and queue pointers exactly
+        assert dev <= (0.0 if k.endswith(("num_batches_tracked", "_ptr")) else 5e-4), (k, dev)
+    print(model, loss, "worst state_dict deviation after %d steps: %s %.2e" % (steps, worst[0], worst[1]))
+
+
+def test_graph_falls_back_for_what_it_does_not_cover(monkeypatch):
+    """eval mode, no_grad, an input that wants its own gradient and a third input shape run the original forward."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from contrastiveseg_amd.segmentor.tools import step_graph
+    monkeypatch.setattr(step_graph, "ENABLED", True)
+    tr, data = _trainer(*CASES[0])
+    g = tr.step_graph
+    net = tr.seg_net
+    x = data["img"]
+    float(tr.train_step(data))
+    assert len(g.captured) == 1
+    with torch.no_grad():
+        net(x, with_embed=True)
+    net.eval()
+    net(x, with_embed=True, is_eval=True)
+    net.train()
+    xg = x.clone().requires_grad_(True)
+    out = net(xg, with_embed=True)
+    (out["seg"].square().mean() + out["embed"].square().mean()).backward()
+    assert xg.grad is not None and len(g.captured) == 1
+    for w in (192, 320, 384):                                   # two shapes get graphs, the next ones stay eager
+        out = net(torch.randn(2, 3, 128, w, device=x.device), with_embed=True)
+        assert torch.isfinite(out["seg"]).all()
+    assert len(g.captured) == step_graph.MAX_SHAPES

@@ -5,7 +5,8 @@ a timeout and progress markers (a crash must not take the caller down, and the l
 
   python tools/graph_probe.py [variant ...]     variants: one (forward+backward in ONE capture), two (forward graph + backward graph
                                                 through torch.autograd.grad, the make_graphed_callables scheme), relaxed (as `two`, capture
-                                                error mode 'relaxed'), fwd (forward only, no_grad)
+                                                error mode 'relaxed'), fwd (forward only, no_grad); suffix _st = autograd's
+                                                multithreading off (backward on the calling thread)
 Prints one JSON line per variant: {"variant", "ok", "eager_ms", "replay_ms", "max_abs_dev_vs_eager", "last_marker", ...}."""
 import json
 import os
@@ -70,11 +71,21 @@ def child(variant, batch):
             for k, v in net.state_dict().items():
                 v.copy_(state[k])
 
+    # EVERYTHING eager runs on the side stream the captures will use, and no autograd graph of an eager iteration survives into
+    # the capture: a live graph keeps the parameters' AccumulateGrad nodes -- and the stream they were created on -- alive, and
+    # the engine then synchronises the capture stream with that stream (GPU call 1: rc -11 in every backward variant, with
+    # exactly that warning from torch/autograd/graph.py)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(side)
+    if variant.endswith("st"):
+        torch.autograd.set_multithreading_enabled(False)          # backward on the calling thread
     for _ in range(2):
         eager_step()
     restore()
     seg_e, emb_e, grads_e = eager_step()
-    ref = [seg_e.clone(), emb_e.clone()] + [t.clone() for t in (grads_e[0], grads_e[len(grads_e) // 2], grads_e[-1])]
+    ref = [seg_e.detach().clone(), emb_e.detach().clone()] + [t.clone() for t in (grads_e[0], grads_e[len(grads_e) // 2], grads_e[-1])]
+    del seg_e, emb_e, grads_e
     eager_ms = timed(eager_step)
     mark("eager done %.1f ms" % eager_ms)
 
@@ -85,34 +96,30 @@ def child(variant, batch):
         K._BN_WS.clear()
     K.SPLIT_WEIGHTS.get  # (weights are fresh: no optimizer step since the last forward -> no pack launches inside the capture)
 
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(3):
-            eager_step()
-    torch.cuda.current_stream().wait_stream(side)
+    import gc
+    gc.collect()
     torch.cuda.synchronize()
     restore()
     mark("side-stream warm-up done")
     res = {"variant": variant, "batch": batch, "eager_ms": round(eager_ms, 2)}
-    mode = "relaxed" if variant == "relaxed" else "global"
+    mode = "relaxed" if variant.startswith("relaxed") else "global"
     if variant == "fwd":
         g1 = torch.cuda.CUDAGraph()
         fresh_arenas()
         with torch.no_grad():
             mark("capture begin (fwd)")
-            with torch.cuda.graph(g1, capture_error_mode=mode):
+            with torch.cuda.graph(g1, stream=side, capture_error_mode=mode):
                 seg_s, emb_s = fwd()
             mark("capture end (fwd)")
         outs = [seg_s, emb_s]
 
         def replay():
             g1.replay()
-    elif variant == "one":
+    elif variant.startswith("one"):
         g1 = torch.cuda.CUDAGraph()
         fresh_arenas()
         mark("capture begin (one)")
-        with torch.cuda.graph(g1, capture_error_mode=mode):
+        with torch.cuda.graph(g1, stream=side, capture_error_mode=mode):
             seg_s, emb_s = fwd()
             grads_s = torch.autograd.grad((seg_s, emb_s), params, (g_seg, g_emb))
         mark("capture end (one)")
@@ -125,10 +132,10 @@ def child(variant, batch):
         pool = torch.cuda.graph_pool_handle()
         fresh_arenas()
         mark("capture begin (two: forward)")
-        with torch.cuda.graph(g1, pool=pool, capture_error_mode=mode):
+        with torch.cuda.graph(g1, pool=pool, stream=side, capture_error_mode=mode):
             seg_s, emb_s = fwd()
         mark("capture end (two: forward)")
-        with torch.cuda.graph(g2, pool=pool, capture_error_mode=mode):
+        with torch.cuda.graph(g2, pool=pool, stream=side, capture_error_mode=mode):
             grads_s = torch.autograd.grad((seg_s, emb_s), params, (g_seg, g_emb))
         mark("capture end (two: backward)")
         outs = [seg_s, emb_s, grads_s[0], grads_s[len(grads_s) // 2], grads_s[-1]]
@@ -154,7 +161,7 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
         child(sys.argv[2], int(sys.argv[3]))
         return
-    variants = [a for a in sys.argv[1:] if not a.startswith("-")] or ["fwd", "two", "one", "relaxed"]
+    variants = [a for a in sys.argv[1:] if not a.startswith("-")] or ["two", "one", "two_st", "relaxed_st"]
     batch = int(os.environ.get("PROBE_BATCH", "1"))
     for v in variants:
         t0 = time.time()
