@@ -181,11 +181,13 @@ class HighResolutionModule(nn.Module):
         outs = [None] * len(self.branches)
         for i in range(1, len(self.branches)):
             streams[i - 1].wait_stream(cur)
+            x[i].record_stream(streams[i - 1])        # allocated on `cur`, read (now and again in backward) on the side stream
             with torch.cuda.stream(streams[i - 1]):
                 outs[i] = self.branches[i](x[i])
         outs[0] = self.branches[0](x[0])
-        for s in streams:
+        for i, s in enumerate(streams):
             cur.wait_stream(s)
+            outs[i + 1].record_stream(cur)            # allocated on the side stream, read by the exchange unit on `cur`
         return outs
 
     def forward(self, x):

@@ -39,7 +39,13 @@ from contrastiveseg_amd import kernels as K
 from contrastiveseg_amd.lib.utils.distributed import is_distributed
 from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
 
-ENABLED = os.environ.get("CSEG_STEP_GRAPH", "1") == "1"
+# "auto" (default): replay where the eager step is host-bound -- per-GPU batches of at most AUTO_MAX_BATCH images (the 8-GPU
+# strong-scaling point of BASELINE.json's bs-8 metric is ONE image per GPU) -- and stay eager where the GPU is the limit anyway:
+# measured on the MI355X (profiles/r04_step_graph_ab.txt), batch 8: eager 95.1 ms/step, replay 102.3 (110.2 without the forked
+# branches: hipGraph launches on ROCm 7.2 keep a per-node cost and lose the back-to-back dispatch of an in-order queue).
+MODE = os.environ.get("CSEG_STEP_GRAPH", "auto")
+ENABLED = MODE != "0"
+AUTO_MAX_BATCH = int(os.environ.get("CSEG_STEP_GRAPH_MAX_BATCH", "2"))
 BRANCH_STREAMS = os.environ.get("CSEG_STEP_GRAPH_STREAMS", "1") == "1"
 MAX_SHAPES = 2                       # distinct input shapes that get their own pair of graphs
 
@@ -121,6 +127,7 @@ class GraphedEncoder(object):
     # -- routing ---------------------------------------------------------------------------------------
     def _usable(self, x, is_eval):
         return (ENABLED and self.failed is None and not is_eval and self.module.training and torch.is_grad_enabled()
+                and (MODE != "auto" or x.shape[0] <= AUTO_MAX_BATCH)
                 and x.is_cuda and not x.requires_grad and not is_distributed() and x.dtype == torch.float32
                 and not torch.cuda.is_current_stream_capturing())
 
@@ -163,7 +170,7 @@ class GraphedEncoder(object):
             torch.cuda.set_rng_state(rng, dev)
 
         cap = _Captured()
-        cap.x = x.detach().clone()
+        cap.x = x.detach().clone()              # (a fresh tensor object: no max|.| record of an earlier forward hangs on it)
         cap.cap = self.max_rows
         main = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
@@ -184,6 +191,8 @@ class GraphedEncoder(object):
                 torch.cuda.synchronize(dev)
                 restore()
                 gc.collect()
+                if hasattr(cap.x, "_cseg_amax"):
+                    del cap.x._cseg_amax   # a record computed by the warm-up must not be baked into the graph: the replay recomputes it
                 K._AMAX_ARENAS.clear()     # the capture allocates (and zero-fills, as a graph node) its own max|.| arenas
                 pool = torch.cuda.graph_pool_handle()
                 cap.g_fwd, cap.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -235,6 +244,8 @@ def install(seg_net, configer):
     if not ENABLED:
         _set_state("eager (CSEG_STEP_GRAPH=0)")
         return None
+    if MODE == "auto":
+        _set_state("eager (auto: per-GPU batch above %d, the GPU is the limit)" % AUTO_MAX_BATCH)
     if not torch.cuda.is_available() or not next(seg_net.parameters()).is_cuda:
         return None
     if is_distributed():
@@ -244,5 +255,6 @@ def install(seg_net, configer):
     if hasattr(encoder, "_cseg_step_graph"):
         return encoder._cseg_step_graph
     max_rows = configer.get("contrast", "max_samples") if configer.exists("contrast", "max_samples") else 1024
-    _set_state("eager (not captured yet)")
+    if MODE != "auto":
+        _set_state("eager (not captured yet)")
     return GraphedEncoder(encoder, max_rows)

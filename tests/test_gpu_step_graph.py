@@ -50,14 +50,17 @@ def _trainer(model, backbone, loss, cfg_file, contrast, batch=2):
     return tr, data
 
 
+@pytest.mark.parametrize("streams", [False, True])
 @pytest.mark.parametrize("model,backbone,loss,cfg_file,contrast", CASES)
-def test_graph_replay_equals_eager_steps(model, backbone, loss, cfg_file, contrast, monkeypatch):
+def test_graph_replay_equals_eager_steps(model, backbone, loss, cfg_file, contrast, streams, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from contrastiveseg_amd import kernels as K
     from contrastiveseg_amd.segmentor.tools import step_graph
     monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
     monkeypatch.setattr(K, "CONV1X1_SB_MIN_TILES", 1)
+    monkeypatch.setattr(step_graph, "MODE", "1")
+    monkeypatch.setattr(step_graph, "BRANCH_STREAMS", streams)
     steps = 5
     runs = {}
     for name, on in (("eager", False), ("graph", True)):
@@ -97,6 +100,7 @@ def test_graph_falls_back_for_what_it_does_not_cover(monkeypatch):
         pytest.skip("needs a GPU")
     from contrastiveseg_amd.segmentor.tools import step_graph
     monkeypatch.setattr(step_graph, "ENABLED", True)
+    monkeypatch.setattr(step_graph, "MODE", "1")
     tr, data = _trainer(*CASES[0])
     g = tr.step_graph
     net = tr.seg_net

@@ -221,3 +221,15 @@ def test_trainer_steps_identically_with_the_sparse_route(cfg_file, model_over, m
     # a freshly initialised network whose backward amplifies perturbations -> sanity bound only
     assert gworst[0] <= 1e-5, gworst
     assert worst[0] <= 5e-3, worst
+
+
+def test_standin_is_recognised_at_a_batch_of_one_image():
+    """The per-GPU batch of the 8-GPU strong-scaling point: expanding [1,1,1,1] to [1,D,h,w] keeps a non-zero stride on the batch
+    dimension, which round 3's test (`not any(stride)`) read as "a real dense gradient" -- the dense route, 268 MB / image."""
+    slot = Kn.SparseGradSlot()
+    s = slot.deposit(torch.ones(3, 4), torch.tensor([0, 5, 9], dtype=torch.int32), (1, 4, 2, 3))
+    assert s.shape == (1, 4, 2, 3) and slot.is_standin(s)
+    assert not slot.is_standin(torch.zeros(1, 4, 2, 3))
+    slot1 = Kn.SparseGradSlot()
+    s1 = slot1.deposit(torch.ones(2, 4), torch.tensor([1, 2], dtype=torch.int32), (1, 4, 1, 1))      # every dimension of size one
+    assert slot1.is_standin(s1) and not slot1.is_standin(torch.zeros(1, 4, 1, 1))
