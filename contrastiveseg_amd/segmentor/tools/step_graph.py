@@ -41,11 +41,12 @@ from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
 
 # "auto" (default): replay where the eager step is host-bound -- per-GPU batches of at most AUTO_MAX_BATCH images (the 8-GPU
 # strong-scaling point of BASELINE.json's bs-8 metric is ONE image per GPU) -- and stay eager where the GPU is the limit anyway:
-# measured on the MI355X (profiles/r04_step_graph_ab.txt), batch 8: eager 95.1 ms/step, replay 102.3 (110.2 without the forked
-# branches: hipGraph launches on ROCm 7.2 keep a per-node cost and lose the back-to-back dispatch of an in-order queue).
+# measured on the MI355X (profiles/r04_step_graph_ab.txt), ms/step eager vs replay: batch 8 95.1 vs 102.3 (110.2 without the forked
+# branches), batch 2 57.1 vs 56.6, batch 1 62.0 vs 48.6 -- a hipGraph launch on ROCm 7.2 keeps a per-node cost of ~13 us and loses
+# the back-to-back dispatch of an in-order queue, so it pays only where the host is the limit.
 MODE = os.environ.get("CSEG_STEP_GRAPH", "auto")
 ENABLED = MODE != "0"
-AUTO_MAX_BATCH = int(os.environ.get("CSEG_STEP_GRAPH_MAX_BATCH", "2"))
+AUTO_MAX_BATCH = int(os.environ.get("CSEG_STEP_GRAPH_MAX_BATCH", "1"))
 BRANCH_STREAMS = os.environ.get("CSEG_STEP_GRAPH_STREAMS", "1") == "1"
 MAX_SHAPES = 2                       # distinct input shapes that get their own pair of graphs
 

@@ -1,7 +1,14 @@
 """hipGraph replay of the segmentor inside Trainer.train_step (segmentor/tools/step_graph.py) against the eager path: the same
-kernels on the same values, so losses, updated weights, BN buffers and the memory bank must agree to rounding after several steps
--- for every model family of the hot path, with the split-operand kernels engaged (tile thresholds lifted) and dropout off (the
-graph-safe RNG of a captured dropout draws a different, equally valid mask sequence)."""
+kernels on the same values, so losses, updated weights, BN buffers and the memory bank must agree after several steps -- for every
+model family of the hot path, with the split-operand kernels engaged (tile thresholds lifted) and dropout off (the graph-safe RNG of
+a captured dropout draws a different, equally valid mask sequence).
+
+How close is "agree": fp32 backward through these networks at random initialisation amplifies rounding-level differences by ~1e5
+(the reference's own fp32 gradients sit 1e-2 from its fp64 ones), so two runs whose weight gradients differ
+in the ORDER of a few atomic additions (MIOpen's split-K weight-gradient solvers) are 1e-4..4e-3 apart in loss after one SGD step
+(first hardware run of this file, GPU call r04j4). The test therefore (a) asks MIOpen for its deterministic solvers and (b)
+measures the eager path against ITSELF first: the replay must be as close to an eager run as a second eager run is (x4), with
+2e-5 as the floor for runs that reproduce exactly."""
 import os
 
 import numpy as np
@@ -63,7 +70,8 @@ def test_graph_replay_equals_eager_steps(model, backbone, loss, cfg_file, contra
     monkeypatch.setattr(step_graph, "BRANCH_STREAMS", streams)
     steps = 5
     runs = {}
-    for name, on in (("eager", False), ("graph", True)):
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
+    for name, on in (("eager", False), ("eager2", False), ("graph", True)):
         monkeypatch.setattr(step_graph, "ENABLED", on)
         tr, data = _trainer(model, backbone, loss, cfg_file, contrast)
         torch.manual_seed(17)                                    # the anchor draws (CPU generator)
@@ -71,7 +79,7 @@ def test_graph_replay_equals_eager_steps(model, backbone, loss, cfg_file, contra
         torch.cuda.synchronize()
         sd = {k: v.detach().float().cpu().numpy().copy() for k, v in tr.seg_net.state_dict().items()}
         runs[name] = (losses, sd)
-        if on:
+        if name == "graph":
             g = tr.step_graph
             assert g is not None and g.failed is None and len(g.captured) == 1, (g and g.failed)
             assert os.environ.get("CSEG_STEP_GRAPH_STATE", "").startswith("replay"), os.environ.get("CSEG_STEP_GRAPH_STATE")
@@ -79,19 +87,22 @@ def test_graph_replay_equals_eager_steps(model, backbone, loss, cfg_file, contra
             assert tr.step_graph is None or not tr.step_graph.captured
         del tr, data
         torch.cuda.empty_cache()
-    le, lg = np.array(runs["eager"][0]), np.array(runs["graph"][0])
+    le, le2, lg = (np.array(runs[k][0]) for k in ("eager", "eager2", "graph"))
     assert np.isfinite(le).all() and np.isfinite(lg).all()
-    assert np.abs(le - lg).max() <= 2e-5 * np.abs(le).max(), (le.tolist(), lg.tolist())
-    worst = ("", 0.0)
+    assert abs(le[0] - lg[0]) <= 2e-6 * abs(le[0]), (le[0], lg[0])          # the first forward: same weights, same kernels
+    self_dev = np.abs(le - le2)                                             # eager vs eager: what the arithmetic itself reproduces
+    assert (np.abs(le - lg) <= np.maximum(4.0 * self_dev, 2e-5 * np.abs(le))).all(), (le.tolist(), le2.tolist(), lg.tolist())
+    worst = ("", 0.0, 0.0)
     for k, a in runs["eager"][1].items():
-        b = runs["graph"][1][k]
+        b, a2 = runs["graph"][1][k], runs["eager2"][1][k]
         scale = max(float(np.abs(a).max()), 1e-12)
-        dev = float(np.abs(a - b).max()) / scale
+        dev, own = float(np.abs(a - b).max()) / scale, float(np.abs(a - a2).max()) / scale
         if dev > worst[1]:
-            worst = (k, dev)
-        # five SGD steps of lr 0.01 on gradients that agree to rounding; BN buffers and queue pointers exactly
-        assert dev <= (0.0 if k.endswith(("num_batches_tracked", "_ptr")) else 5e-4), (k, dev)
-    print(model, loss, "worst state_dict deviation after %d steps: %s %.2e" % (steps, worst[0], worst[1]))
+            worst = (k, dev, own)
+        # BN counters and queue pointers exactly; everything else as close as a second eager run
+        assert dev <= (0.0 if k.endswith(("num_batches_tracked", "_ptr")) else max(4.0 * own, 2e-5)), (k, dev, own)
+    print(model, loss, "streams" if streams else "one stream", "loss dev graph %.1e eager-vs-eager %.1e; worst state_dict deviation "
+          "after %d steps: %s %.2e (eager-vs-eager %.2e)" % (np.abs(le - lg).max(), self_dev.max(), steps, worst[0], worst[1], worst[2]))
 
 
 def test_graph_falls_back_for_what_it_does_not_cover(monkeypatch):
