@@ -100,7 +100,7 @@ class PixelContrastLoss(nn.Module, ABC):
         self.last_selection = None   # {'sel_pix': i32 [N] (b*P+pixel, view-major), 'plan': SelectionPlan}
 
     # -- mining ------------------------------------------------------------------------------------------
-    def _mine(self, feats, labels, predict, seg, seg_ready=None):
+    def _mine(self, feats, labels, predict, seg, seg_ready=None, gather=False):
         """Runs cseg_classify_partition. With `seg_ready` (a HIP event recorded right after the logits were produced,
         see nets/hrnet.py) the kernels and the counts D2H copy go to a side stream, so they -- and the host-side
         selection plan that follows -- overlap the projection head still running on the compute stream."""
@@ -120,6 +120,11 @@ class PixelContrastLoss(nn.Module, ABC):
             self._side.wait_event(seg_ready)
             cp = run()
             flat = torch.cat([cp["counts"].reshape(-1), cp["status"]])
+            if gather:
+                # cross-rank contrast set: the all-gather of the per-rank counts is issued HERE, on the side stream, so that it -- like
+                # the mining itself and the D2H copy -- runs under the CE kernels / projection head on the compute stream and the host
+                # only waits on the event below (round 3: a blocking all-gather + .cpu() in the middle of the loss forward)
+                flat = D.all_gather_cat(flat.unsqueeze(0))
             host = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
             host.copy_(flat, non_blocking=True)
             done = torch.cuda.Event()
@@ -129,7 +134,7 @@ class PixelContrastLoss(nn.Module, ABC):
         seg.record_stream(self._side)
         labels.record_stream(self._side)
         main.wait_event(done)
-        cp["host_counts"] = (host, done)
+        cp["host_counts_global" if gather else "host_counts"] = (host, done)
         return cp
 
     def _plan(self, counts, budget_mult=1, draw_images=None):
@@ -148,9 +153,10 @@ class PixelContrastLoss(nn.Module, ABC):
         assert labels is not None and (predict is not None or seg is not None)
         B, Dm, h, w = feats.shape
         P = h * w
-        cp = self._mine(feats, labels, predict, seg, seg_ready)
         world = D.get_world_size()
-        if (world > 1 or D.exercise_single_rank()) and self.cross_rank:
+        cross = (world > 1 or D.exercise_single_rank()) and self.cross_rank
+        cp = self._mine(feats, labels, predict, seg, seg_ready, gather=cross)
+        if cross:
             return self._forward_cross_rank(feats, cp, P, world)
         plan = self._plan(_counts_to_host(cp))
         dev = feats.device
@@ -165,8 +171,12 @@ class PixelContrastLoss(nn.Module, ABC):
         rank = D.get_rank()
         B = feats.shape[0]
         dev = feats.device
-        local = torch.cat([cp["counts"].reshape(-1), cp["status"]])      # compute stream (waits on the side stream)
-        host = D.all_gather_cat(local.unsqueeze(0)).cpu()      # RCCL all-gather, B*K*2+4 ints per rank
+        if "host_counts_global" in cp:
+            host, done = cp["host_counts_global"]               # gathered and copied on the side stream (_mine)
+            done.synchronize()
+        else:
+            local = torch.cat([cp["counts"].reshape(-1), cp["status"]])
+            host = D.all_gather_cat(local.unsqueeze(0)).cpu()  # RCCL all-gather, B*K*2+4 ints per rank
         if int(host[:, -4].sum()) != 0:
             raise RuntimeError("PixelContrastLoss: labels outside [0, num_classes) on some rank")
         counts = host[:, :-4].reshape((world * B,) + tuple(cp["counts"].shape[1:])).numpy()

@@ -45,7 +45,6 @@ class ModuleRunner(object):
     def _make_parallel(self, net):
         if not is_distributed():
             return net
-        has_queues = any(name.endswith('_queue') for name, _ in net.named_buffers())
         bucket_mb = 64
         if self.configer.exists('network', 'ddp_bucket_mb'):
             bucket_mb = self.configer.get('network', 'ddp_bucket_mb')
@@ -53,8 +52,11 @@ class ModuleRunner(object):
         if self.configer.exists('network', 'ddp_find_unused'):
             find_unused = bool(self.configer.get('network', 'ddp_find_unused'))
         kwargs = dict(find_unused_parameters=find_unused, gradient_as_bucket_view=True, bucket_cap_mb=bucket_mb,
-                      # SyncBN keeps BN buffers identical on all ranks; only the memory queues need rank 0's copy
-                      broadcast_buffers=has_queues)
+                      # no per-forward buffer broadcast (the reference's default, module_runner.py:62-76): SyncBN keeps the BN
+                      # buffers identical on all ranks, and the memory queues are updated identically on every rank from the
+                      # all-gathered keys (Trainer._enqueue_global) instead of being overwritten by rank 0's copy each step
+                      # (2 x 97 MB per step at memory_size 5000). DDP's constructor still syncs the initial state from rank 0.
+                      broadcast_buffers=False)
         if next(net.parameters()).is_cuda:
             kwargs.update(device_ids=[device_index()], output_device=device_index())
         return torch.nn.parallel.DistributedDataParallel(net, **kwargs)

@@ -24,7 +24,8 @@ from contrastiveseg_amd import kernels as K
 from contrastiveseg_amd.lib.loss.loss_manager import LossManager
 from contrastiveseg_amd.lib.metrics.running_score import RunningScore
 from contrastiveseg_amd.lib.models.model_manager import ModelManager
-from contrastiveseg_amd.lib.utils.distributed import get_rank, get_world_size, is_distributed
+from contrastiveseg_amd.lib.utils.distributed import (all_gather_cat, exercise_single_rank, get_rank, get_world_size,
+                                                      is_distributed)
 from contrastiveseg_amd.lib.utils.tools.average_meter import AverageMeter
 from contrastiveseg_amd.lib.utils.tools.logger import Logger as Log
 from contrastiveseg_amd.segmentor.tools.data_helper import DataHelper, SyntheticLoader
@@ -143,7 +144,10 @@ class Trainer(object):
 
     # ------------------------------------------------------------------------------------------------------
     def _dequeue_and_enqueue(self, keys, labels, segment_queue, segment_queue_ptr, pixel_queue, pixel_queue_ptr):
-        """reference :102-138; all four queue tensors are updated in place."""
+        """reference :102-138; all four queue tensors are updated in place. Multi-rank runs: _enqueue_global (the same update from
+        the GLOBAL batch on every rank)."""
+        if get_world_size() > 1 or exercise_single_rank():
+            return self._enqueue_global(keys, labels, segment_queue, segment_queue_ptr, pixel_queue, pixel_queue_ptr)
         Kc = segment_queue.shape[0]
         keys = keys.contiguous()
         counts_d = K.queue_count(labels, self.network_stride, Kc)
@@ -163,6 +167,55 @@ class Trainer(object):
             r = torch.from_numpy(pix_rows).to(dev)
             K.queue_write_pixels(keys, r[:, 0].contiguous(), r[:, 1].contiguous(), r[:, 2].contiguous(),
                                  r[:, 3].contiguous(), pixel_queue)
+        segment_queue_ptr.copy_(torch.from_numpy(seg_ptr.astype(np.int64)))
+        pixel_queue_ptr.copy_(torch.from_numpy(pix_ptr.astype(np.int64)))
+
+    def _enqueue_global(self, keys, labels, segment_queue, segment_queue_ptr, pixel_queue, pixel_queue_ptr):
+        """The memory bank under data parallelism (exchange 4). The reference lets every rank enqueue its own
+        images and then has DDP broadcast rank 0's queues over everybody else's before each forward (module_runner.py:62-76
+        `broadcast_buffers`; at memory_size 5000 that is 2 x 97 MB per step, and the other ranks' keys are lost). Here every rank
+        applies the update of the GLOBAL batch -- images in rank order = the batch a single process would see -- so the banks stay
+        identical without any buffer broadcast:
+          1. all-gather of the per-(image, class) strided-label counts and class sums ([B, K, D + 1] floats per rank);
+          2. every rank walks the global (image, class) pairs with plan_enqueue (pointer arithmetic is a function of the counts;
+             the torch.randperm draws are rank 0's -- one broadcast of the drawn positions -- so ranks whose CPU generators have
+             diverged still agree, and rank 0 draws exactly what a single process on the concatenated batch draws);
+          3. each rank reads the selected pixels of ITS images; one all-reduce assembles the [rows, D] selection (each row has
+             one owner, the others contribute zeros);
+          4. identical writes on every rank."""
+        import torch.distributed as dist
+        world, rank = get_world_size(), get_rank()
+        Kc, ms, Dq = segment_queue.shape
+        keys = keys.contiguous()
+        B, D = keys.shape[:2]
+        dev = keys.device
+        counts_l = K.queue_count(labels, self.network_stride, Kc)
+        sums_l = K.queue_class_sums(keys, labels, self.network_stride, Kc)
+        packed = all_gather_cat(torch.cat([sums_l, counts_l.to(sums_l.dtype).unsqueeze(2)], dim=2))        # [world * B, K, D + 1]
+        counts_d = packed[:, :, D].round().to(torch.int32).contiguous()
+        sums = packed[:, :, :D].contiguous()
+        host = torch.cat([counts_d.reshape(-1).long(), segment_queue_ptr, pixel_queue_ptr]).cpu().numpy()
+        Bg = world * B
+        counts = host[:Bg * Kc].reshape(Bg, Kc)
+        seg_ptr, pix_ptr = host[Bg * Kc:Bg * Kc + Kc], host[Bg * Kc + Kc:]
+        seg_jobs, pix_rows, seg_ptr, pix_ptr = plan_enqueue(counts, seg_ptr, pix_ptr, self.memory_size, self.pixel_update_freq)
+        if len(seg_jobs):
+            j = torch.from_numpy(seg_jobs).to(dev)
+            K.queue_write_segments(sums, counts_d, j[:, 0].contiguous(), j[:, 1].contiguous(), j[:, 2].contiguous(), segment_queue)
+        if len(pix_rows):
+            on_dev = dist.get_backend() == "nccl"
+            pos = torch.from_numpy(np.ascontiguousarray(pix_rows[:, 1]).astype(np.int64))
+            pos = pos.to(dev) if on_dev else pos
+            dist.broadcast(pos, src=0)                       # rank 0's draws decide
+            pos = pos.to(dev)
+            r = torch.from_numpy(pix_rows).to(dev).long()
+            owner = torch.div(r[:, 0], B, rounding_mode='floor')
+            mine = torch.nonzero(owner == rank).reshape(-1)
+            rows = torch.zeros(len(pix_rows), D, dtype=keys.dtype, device=dev)
+            if mine.numel():
+                rows[mine] = keys.view(B, D, -1)[r[mine, 0] - rank * B, :, pos[mine]]
+            dist.all_reduce(rows)                            # every row has exactly one owner: x + 0 + ... + 0 is exact
+            pixel_queue[r[:, 2], r[:, 3]] = nn.functional.normalize(rows, p=2, dim=1)      # targets are unique (last writer wins on the host)
         segment_queue_ptr.copy_(torch.from_numpy(seg_ptr.astype(np.int64)))
         pixel_queue_ptr.copy_(torch.from_numpy(pix_ptr.astype(np.int64)))
 

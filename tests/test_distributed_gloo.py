@@ -510,3 +510,90 @@ def test_hrnet_grouped_syncbn_equals_single_process_and_batches_the_exchanges(de
             ref = named[k].grad.numpy()
             assert np.abs(tot - ref).max() <= 5e-3 * np.abs(ref).max() + 1e-7, (k, np.abs(tot - ref).max(), np.abs(ref).max())
     assert np.abs(res[0][7] - net.stage4[2].branches[3][3].bn2.running_var.detach().numpy()).max() <= 1e-5
+
+
+# ---- round 4: the memory bank under data parallelism (exchange 4) ---------------------
+def _enqueue_inputs(rounds=3, Bg=4, Kc=6, D=16, hw=(12, 20), stride=2):
+    g = torch.Generator().manual_seed(23)
+    data = []
+    for _ in range(rounds):
+        keys = torch.randn(Bg, D, hw[0], hw[1], generator=g)
+        labels = torch.randint(-1, Kc, (Bg, hw[0] * stride, hw[1] * stride), generator=g)
+        data.append((keys, labels))
+    sq = torch.nn.functional.normalize(torch.randn(Kc, 7, D, generator=g), dim=2)
+    pq = torch.nn.functional.normalize(torch.randn(Kc, 7, D, generator=g), dim=2)
+    return data, sq, pq, stride
+
+
+def _enqueue_stub(stride):
+    from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
+    me = Trainer.__new__(Trainer)
+    me.network_stride, me.memory_size, me.pixel_update_freq = stride, 7, 3
+    return me
+
+
+def _enqueue_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_device_half()
+    data, sq, pq, stride = _enqueue_inputs()
+    me = _enqueue_stub(stride)
+    sp, pp = torch.zeros(sq.shape[0], dtype=torch.long), torch.zeros(sq.shape[0], dtype=torch.long)
+    torch.manual_seed(99 if rank == 0 else 12345)          # the ranks' CPU generators have diverged: rank 0's draws must decide
+    calls = []
+    for name in ("all_reduce", "broadcast", "all_gather", "all_gather_into_tensor"):
+        real = getattr(dist, name)
+        setattr(dist, name, lambda *a, _n=name, _r=real, **k: (calls.append(_n), _r(*a, **k))[1])
+    for keys, labels in data:
+        B = keys.shape[0] // world
+        me._dequeue_and_enqueue(keys[rank * B:(rank + 1) * B].clone(), labels[rank * B:(rank + 1) * B].clone(), segment_queue=sq,
+                                segment_queue_ptr=sp, pixel_queue=pq, pixel_queue_ptr=pp)
+    q.put((rank, sq.numpy(), pq.numpy(), sp.numpy(), pp.numpy(), len(calls) / len(data)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("device_half", ["cpu_port", "emu"])
+def test_memory_bank_update_is_global_and_identical_on_every_rank(device_half, monkeypatch):
+    """Two ranks with half of the batch each apply the enqueue of the GLOBAL batch: both banks and pointer sets end up identical --
+    with no buffer broadcast -- and equal to what ONE process computes on the concatenated batch with rank 0's generator (the
+    reference's own update, trainer_contrastive.py:102-138, which the single-rank path is pinned to by tests/golden/enq_*.npz)."""
+    monkeypatch.setenv("CSEG_TEST_DEVICE_HALF", device_half)
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_enqueue_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for a, b in zip(res[0][1:5], res[1][1:5]):
+        assert np.array_equal(a, b), "the ranks' banks diverged"
+    assert res[0][5] <= 3.0 + 1e-9, "more than three collectives per update: %s" % (res[0][5],)
+    # one process on the concatenated batch
+    undo = _install_device_half()
+    try:
+        data, sq, pq, stride = _enqueue_inputs()
+        me = _enqueue_stub(stride)
+        sp, pp = torch.zeros(sq.shape[0], dtype=torch.long), torch.zeros(sq.shape[0], dtype=torch.long)
+        torch.manual_seed(99)
+        for keys, labels in data:
+            me._dequeue_and_enqueue(keys.clone(), labels.clone(), segment_queue=sq, segment_queue_ptr=sp, pixel_queue=pq,
+                                    pixel_queue_ptr=pp)
+    finally:
+        undo()
+    assert np.array_equal(res[0][3], sp.numpy()) and np.array_equal(res[0][4], pp.numpy())
+    assert np.abs(res[0][1] - sq.numpy()).max() <= 2e-6 and np.abs(res[0][2] - pq.numpy()).max() <= 2e-6
+    assert np.abs(res[0][2] - _enqueue_inputs()[2].numpy()).max() > 0.1, "the update wrote nothing"
+
+
+def test_ddp_wrap_does_not_broadcast_buffers():
+    """module_runner.py: no per-forward buffer broadcast any more (the banks are kept identical by the global update)."""
+    import inspect
+    from contrastiveseg_amd.segmentor.tools import module_runner
+    src = inspect.getsource(module_runner.ModuleRunner._make_parallel)
+    assert "broadcast_buffers=False" in src and "has_queues" not in src

@@ -3,12 +3,13 @@ kernels on the same values, so losses, updated weights, BN buffers and the memor
 model family of the hot path, with the split-operand kernels engaged (tile thresholds lifted) and dropout off (the graph-safe RNG of
 a captured dropout draws a different, equally valid mask sequence).
 
-How close is "agree": fp32 backward through these networks at random initialisation amplifies rounding-level differences by ~1e5
-(the reference's own fp32 gradients sit 1e-2 from its fp64 ones), so two runs whose weight gradients differ
-in the ORDER of a few atomic additions (MIOpen's split-K weight-gradient solvers) are 1e-4..4e-3 apart in loss after one SGD step
-(first hardware run of this file, GPU call r04j4). The test therefore (a) asks MIOpen for its deterministic solvers and (b)
-measures the eager path against ITSELF first: the replay must be as close to an eager run as a second eager run is (x4), with
-2e-5 as the floor for runs that reproduce exactly."""
+How close is "agree": training these freshly initialised networks is chaotic -- in the first hardware runs of this file (GPU calls
+r04j4 / r04j5, deterministic MIOpen solvers, eager vs eager bit-identical) the replay had the SAME first loss, a second loss 3e-7
+away, and then 4e-3 / 3e-2 / 9e-2: a rounding-level difference in one gradient (a different but equally valid summation order
+somewhere under the capture) grows ~1000x per SGD step of lr 0.01 (the reference's own fp32 gradients sit 1e-2
+from its fp64 ones). Loss curves of many steps therefore cannot tell a correct replay from a wrong one; what can: the first forward
+(exact), the GRADIENTS of the first backward against the eager ones (same weights, same input: 2e-4 relative L2 per tensor, or 4x the
+eager path's own run-to-run deviation), the state after the first update, and the second loss."""
 import os
 
 import numpy as np
@@ -68,17 +69,20 @@ def test_graph_replay_equals_eager_steps(model, backbone, loss, cfg_file, contra
     monkeypatch.setattr(K, "CONV1X1_SB_MIN_TILES", 1)
     monkeypatch.setattr(step_graph, "MODE", "1")
     monkeypatch.setattr(step_graph, "BRANCH_STREAMS", streams)
-    steps = 5
     runs = {}
     monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
     for name, on in (("eager", False), ("eager2", False), ("graph", True)):
         monkeypatch.setattr(step_graph, "ENABLED", on)
         tr, data = _trainer(model, backbone, loss, cfg_file, contrast)
         torch.manual_seed(17)                                    # the anchor draws (CPU generator)
-        losses = [float(tr.train_step(data)) for _ in range(steps)]
+        l0 = float(tr.train_step(data))
         torch.cuda.synchronize()
+        # gradients of the first backward (same weights, same input in every run) and the state after the first update
+        grads = {k: p.grad.detach().float().cpu().numpy().copy() for k, p in tr.seg_net.named_parameters() if p.grad is not None}
         sd = {k: v.detach().float().cpu().numpy().copy() for k, v in tr.seg_net.state_dict().items()}
-        runs[name] = (losses, sd)
+        losses = [l0] + [float(tr.train_step(data)) for _ in range(2)]
+        torch.cuda.synchronize()
+        runs[name] = (losses, grads, sd)
         if name == "graph":
             g = tr.step_graph
             assert g is not None and g.failed is None and len(g.captured) == 1, (g and g.failed)
@@ -90,19 +94,27 @@ def test_graph_replay_equals_eager_steps(model, backbone, loss, cfg_file, contra
     le, le2, lg = (np.array(runs[k][0]) for k in ("eager", "eager2", "graph"))
     assert np.isfinite(le).all() and np.isfinite(lg).all()
     assert abs(le[0] - lg[0]) <= 2e-6 * abs(le[0]), (le[0], lg[0])          # the first forward: same weights, same kernels
-    self_dev = np.abs(le - le2)                                             # eager vs eager: what the arithmetic itself reproduces
-    assert (np.abs(le - lg) <= np.maximum(4.0 * self_dev, 2e-5 * np.abs(le))).all(), (le.tolist(), le2.tolist(), lg.tolist())
+    assert abs(le[1] - lg[1]) <= 2e-5 * abs(le[1]), (le[1], lg[1])          # after ONE update from (nearly) the same gradients
+    # every parameter the eager step gives a gradient gets one from the replay, equal to rounding (one backward: no amplification yet)
+    ge, ge2, gg = runs["eager"][1], runs["eager2"][1], runs["graph"][1]
+    assert set(ge) == set(gg), sorted(set(ge) ^ set(gg))[:5]
+    gnorm = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in ge.values()))
     worst = ("", 0.0, 0.0)
-    for k, a in runs["eager"][1].items():
-        b, a2 = runs["graph"][1][k], runs["eager2"][1][k]
-        scale = max(float(np.abs(a).max()), 1e-12)
-        dev, own = float(np.abs(a - b).max()) / scale, float(np.abs(a - a2).max()) / scale
+    for k, a in ge.items():
+        den = max(float(np.linalg.norm(a)), 1e-6 * gnorm)
+        dev, own = float(np.linalg.norm(a - gg[k])) / den, float(np.linalg.norm(a - ge2[k])) / den
         if dev > worst[1]:
             worst = (k, dev, own)
-        # BN counters and queue pointers exactly; everything else as close as a second eager run
-        assert dev <= (0.0 if k.endswith(("num_batches_tracked", "_ptr")) else max(4.0 * own, 2e-5)), (k, dev, own)
-    print(model, loss, "streams" if streams else "one stream", "loss dev graph %.1e eager-vs-eager %.1e; worst state_dict deviation "
-          "after %d steps: %s %.2e (eager-vs-eager %.2e)" % (np.abs(le - lg).max(), self_dev.max(), steps, worst[0], worst[1], worst[2]))
+        assert dev <= max(4.0 * own, 2e-4), ("grad " + k, dev, own)
+    for k, a in runs["eager"][2].items():
+        b = runs["graph"][2][k]
+        scale = max(float(np.abs(a).max()), 1e-12)
+        dev = float(np.abs(a - b).max()) / scale
+        # BN counters and queue pointers exactly; weights after one SGD step of lr 0.01, BN buffers and the bank to rounding
+        assert dev <= (0.0 if k.endswith(("num_batches_tracked", "_ptr")) else 2e-5), ("state " + k, dev)
+    print(model, loss, "streams" if streams else "one stream", "losses eager %s | graph %s (eager-vs-eager %.1e); worst gradient "
+          "deviation %s %.2e (eager-vs-eager %.2e)" % (le.round(6).tolist(), lg.round(6).tolist(), np.abs(le - le2).max(),
+                                                       worst[0], worst[1], worst[2]))
 
 
 def test_graph_falls_back_for_what_it_does_not_cover(monkeypatch):
