@@ -63,7 +63,7 @@ def _set_state(text):
 
 class _Captured(object):
     """One input shape: static input, outputs, gradient buffers and the two graphs."""
-    __slots__ = ("x", "out", "keys", "grad_keys", "g_out", "rows", "sel", "g_fwd", "g_bwd", "grads", "embed_shape", "cap")
+    __slots__ = ("x", "out", "keys", "grad_keys", "g_out", "rows", "sel", "g_fwd", "g_bwd", "grads", "reach", "cap")
 
 
 class _Replay(torch.autograd.Function):
@@ -109,7 +109,14 @@ class _Replay(torch.autograd.Function):
             else:
                 cap.g_out[k].copy_(g)
         cap.g_bwd.replay()
-        return (None, None, None) + tuple(None if g is None else g.detach() for g in cap.grads)
+        live = [k for k in cap.grad_keys if by_key[k] is not None]
+        if len(live) == len(cap.grad_keys) or cap.reach is None:
+            return (None, None, None) + tuple(None if g is None else g.detach() for g in cap.grads)
+        # an output the criterion does not use (DeepLab's `seg_aux` under contrast_ce_loss): the eager step leaves the parameters
+        # that feed only that output WITHOUT a gradient (the optimizer skips them: no weight decay, no momentum); a zero-filled
+        # gradient from the replay would not be the same update
+        keep = [any(cap.reach[k][i] for k in live) for i in range(len(cap.grads))]
+        return (None, None, None) + tuple(g.detach() if (g is not None and keep[i]) else None for i, g in enumerate(cap.grads))
 
 
 class GraphedEncoder(object):
@@ -182,12 +189,21 @@ class GraphedEncoder(object):
         try:
             with torch.cuda.stream(side):
                 # warm-up on the capture stream: per-stream scratch, MIOpen solver selection, registration of the weight packs
-                for _ in range(2):
+                cap.reach = None
+                for it in range(2):
                     out = self.eager_forward(cap.x, with_embed=True)
                     keys = [k for k, v in out.items() if torch.is_tensor(v)]
                     gk = [k for k in keys if out[k].requires_grad]
                     gout = [self._standin_grad(out, k) for k in gk]
-                    torch.autograd.grad([out[k] for k in gk], self.params, gout, allow_unused=True)
+                    if it == 0 and len(gk) > 1:
+                        # which parameters each output reaches (one backward per output; together they run every backward kernel)
+                        cap.reach = {}
+                        for k, g in zip(gk, gout):
+                            got = torch.autograd.grad([out[k]], self.params, [g], allow_unused=True, retain_graph=True)
+                            cap.reach[k] = [t is not None for t in got]
+                            del got
+                    else:
+                        torch.autograd.grad([out[k] for k in gk], self.params, gout, allow_unused=True)
                     del out, gout
                 torch.cuda.synchronize(dev)
                 restore()

@@ -108,7 +108,7 @@ def test_graph_replay_equals_eager_steps(model, backbone, loss, cfg_file, contra
         assert dev <= max(4.0 * own, 2e-4), ("grad " + k, dev, own)
     for k, a in runs["eager"][2].items():
         b = runs["graph"][2][k]
-        scale = max(float(np.abs(a).max()), 1e-12)
+        scale = max(float(np.abs(a).max()), 1e-3)          # (a conv bias in front of a BN moves by lr x rounding noise only)
         dev = float(np.abs(a - b).max()) / scale
         # BN counters and queue pointers exactly; weights after one SGD step of lr 0.01, BN buffers and the bank to rounding
         assert dev <= (0.0 if k.endswith(("num_batches_tracked", "_ptr")) else 2e-5), ("state " + k, dev)
