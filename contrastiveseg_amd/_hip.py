@@ -86,6 +86,12 @@ SIGNATURES = {
     "cseg_amax_batch": (_c_int, [_ptr, _c_int, _c_int, _ptr]),
     "cseg_split_pack_batch": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr]),
     "cseg_augment_batch": (_c_int, [_ptr, _ptr, _ptr, _ptr] + [_c_int] * 5 + [_c_float, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "cseg_conv_stat_segments": (ctypes.c_size_t, [_c_int] * 4),
+    "cseg_conv3x3_split_fwd_st": (_c_int, [_ptr, _ptr, _ptr] + [_c_int] * 7 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
+    "cseg_conv1x1_split_fwd_st": (_c_int, [_ptr, _ptr, _ptr] + [_c_int] * 5 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
+    "cseg_conv3x3_s2_split_fwd_st": (_c_int, [_ptr, _ptr] + [_c_int] * 6 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
+    "cseg_bn_tiles_finalize": (_c_int, [_ptr, _c_int, ctypes.c_long, _c_float, _c_float, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "cseg_bn_tiles_moments": (_c_int, [_ptr, _c_int, ctypes.c_long, _ptr, _ptr]),
     "cseg_bn_ws_floats": (ctypes.c_size_t, [_c_int, _c_int, _c_int]),
     "cseg_bn_stats": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "cseg_bn_finalize": (_c_int, [_ptr, _c_int, ctypes.c_double, _c_float, _c_float, _ptr, _ptr, _ptr, _ptr, _ptr]),

@@ -540,6 +540,68 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const float* __
     if (amax_out) publish_amax(am, amax_out);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Statistics that came out of the producing convolution's epilogue (cseg_stats.h): per channel T float4 = (count, mean, M2) of
+// 64-pixel segments. One wave per channel combines them in fp64 (two plain sums: the global mean first, then
+// M2 = sum M2_t + n_t (mean_t - mean)^2 -- Chan et al. with the exact mean), fixed order.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tiles_combine(const float4* __restrict__ st, long T, int c, int lane, double& count, double& mean,
+                                              double& m2) {
+    const float4* p = st + (size_t)c * T;
+    double n = 0.0, s = 0.0;
+    for (long t = lane; t < T; t += 64) {
+        const float4 v = p[t];
+        n += (double)v.x;
+        s += (double)v.x * (double)v.y;
+    }
+    n = wave_sum_d(n);
+    s = wave_sum_d(s);
+    mean = n > 0.0 ? s / n : 0.0;
+    double q = 0.0;
+    for (long t = lane; t < T; t += 64) {
+        const float4 v = p[t];
+        const double d = (double)v.y - mean;
+        q += (double)v.z + (double)v.x * d * d;
+    }
+    m2 = wave_sum_d(q);
+    count = n;
+}
+
+__global__ __launch_bounds__(256) void bn_tiles_finalize_kernel(const float4* __restrict__ st, long T, int C, float eps, float momentum,
+                                                                float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                                                float* __restrict__ mean_invstd) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (c >= C) return;
+    double count, mean, m2;
+    tiles_combine(st, T, c, lane, count, mean, m2);
+    if (lane == 0) {
+        // finalize_channel() takes raw moments; feed it (sum x, sum x^2) rebuilt in fp64: var = m1/n - mean^2 = M2/n exactly enough
+        // at 1e-16 (the cancellation the shifted sums avoid in fp32 does not exist here: M2 was accumulated mean-centred)
+        const double var = count > 0.0 ? m2 / count : 0.0;
+        mean_invstd[2 * c] = (float)mean;
+        mean_invstd[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+            running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+        }
+    }
+}
+
+// SyncBN form: the raw fp64 moments [C+1, 2] the exchange all-reduces (row C = this rank's element count)
+__global__ __launch_bounds__(256) void bn_tiles_moments_kernel(const float4* __restrict__ st, long T, int C, double* __restrict__ moments) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double count, mean, m2;
+    tiles_combine(st, T, c, lane, count, mean, m2);
+    if (lane == 0) {
+        moments[2 * c] = count * mean;
+        moments[2 * c + 1] = m2 + count * mean * mean;
+        if (c == 0) { moments[2 * C] = count; moments[2 * C + 1] = 0.0; }
+    }
+}
+
 bool vec_ok(int HW, const void* p0, const void* p1 = nullptr, const void* p2 = nullptr, const void* p3 = nullptr) {
     auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return HW % 4 == 0 && al(p0) && al(p1) && al(p2) && al(p3);
@@ -580,6 +642,27 @@ extern "C" int cseg_bn_finalize(const double* moments, int C, double count, floa
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, moments, C, count, eps, momentum,
                        running_mean, running_var, num_batches_tracked, mean_invstd);
     CSEG_CHECK_LAUNCH("bn_finalize");
+    return 1;
+}
+
+extern "C" int cseg_bn_tiles_finalize(const float* stats, int C, long T, float eps, float momentum, float* running_mean,
+                                      float* running_var, int64_t* num_batches_tracked, float* mean_invstd, cseg_stream_t stream_) {
+    CSEG_REQUIRE(stats && mean_invstd && C > 0 && T > 0, "bn_tiles_finalize: bad arguments");
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 15) == 0, "bn_tiles_finalize: the statistics buffer must be 16-byte aligned");
+    CSEG_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_tiles_finalize: running_mean/var must come together");
+    hipLaunchKernelGGL(bn_tiles_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream_,
+                       reinterpret_cast<const float4*>(stats), T, C, eps, momentum, running_mean, running_var, num_batches_tracked,
+                       mean_invstd);
+    CSEG_CHECK_LAUNCH("bn_tiles_finalize");
+    return 1;
+}
+
+extern "C" int cseg_bn_tiles_moments(const float* stats, int C, long T, double* moments, cseg_stream_t stream_) {
+    CSEG_REQUIRE(stats && moments && C > 0 && T > 0, "bn_tiles_moments: bad arguments");
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 15) == 0, "bn_tiles_moments: the statistics buffer must be 16-byte aligned");
+    hipLaunchKernelGGL(bn_tiles_moments_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream_,
+                       reinterpret_cast<const float4*>(stats), T, C, moments);
+    CSEG_CHECK_LAUNCH("bn_tiles_moments");
     return 1;
 }
 

@@ -18,6 +18,7 @@
 // Round 3: default on the GPU (720 -> 720: 1.5-1.65 vs 2.2 ms on rocBLAS in the round-2 driver pass); written against the
 // arithmetic traits of cseg_split.h (bf16x6 and f16x3: two scaled fp16 pieces, three MFMAs per product).
 #include "cseg_pack.h"
+#include "cseg_stats.h"
 
 namespace {
 
@@ -85,7 +86,8 @@ template <class AR, int NT>
 __global__ __launch_bounds__(512, 1) void conv1x1_sb_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                             const float* __restrict__ bias, int Cin, int Cout, int plane_i,
                                                             int tiles_p, const unsigned* __restrict__ amax_x,
-                                                            const unsigned* __restrict__ amax_w, float* __restrict__ y) {
+                                                            const unsigned* __restrict__ amax_w, float* __restrict__ y,
+                                                            float4* __restrict__ stats, int n_seg) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_o[];
     constexpr int NP = AR::NP;
     constexpr int A1_CELLS = NP * 4 * MT_PX;       // one A buffer: [piece][octet][pixel]
@@ -184,6 +186,14 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_kernel(const float* __restr
     const float unscale = split_unscale_of(ex) * split_unscale_of(ew);
     if (half == 0) o_store<NT0, NT0>(acc, ybc, bias, co0, plane, px0 + quarter * 64, g, n, unscale);
     else if (NT1 > 0) o_store<NT1, NT0>(acc, ybc, bias, co0 + NT0 * 16, plane, px0 + quarter * 64, g, n, unscale);
+    if (stats && (size_t)(px0 + quarter * 64) < plane) {      // BatchNorm statistics of what was just stored (cseg_stats.h)
+        const size_t seg = (size_t)b * ((plane + 63) / 64) + (size_t)(px0 + quarter * 64) / 64;
+        if (half == 0)
+            cseg_stats_emit<NT0, NT0>(acc, bias, co0, unscale, px0 + quarter * 64, (long)plane, g, n, stats + (size_t)co0 * n_seg + seg, n_seg);
+        else if (NT1 > 0)
+            cseg_stats_emit<NT1, NT0>(acc, bias, co0 + NT0 * 16, unscale, px0 + quarter * 64, (long)plane, g, n,
+                                      stats + (size_t)(co0 + NT0 * 16) * n_seg + seg, n_seg);
+    }
 }
 
 // channel tiles per block: the largest of {9, 8, 6, 4, 3} x 16 that divides Cout
@@ -196,7 +206,7 @@ int pick_nt1(int Cout) {
 
 template <class AR, int NT>
 int launch_1x1(const float* x, const uint4* wp, const float* bias, int B, int Cin, int Cout, int plane, const unsigned* amax_x,
-               const unsigned* amax_w, float* y, hipStream_t stream) {
+               const unsigned* amax_w, float* y, float4* stats, hipStream_t stream) {
     const size_t lds = sizeof(uint4) * (2 * AR::NP * 4 * MT_PX + 2 * NT * AR::NP * 64);
     static bool attr_set = false;
     if (!attr_set) {
@@ -211,20 +221,20 @@ int launch_1x1(const float* x, const uint4* wp, const float* bias, int B, int Ci
     const long n_tiles = (long)B * (Cout / (NT * 16)) * tiles_p;
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv1x1_sb: grid too large");
     hipLaunchKernelGGL((conv1x1_sb_kernel<AR, NT>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, Cin, Cout, plane,
-                       tiles_p, amax_x, amax_w, y);
+                       tiles_p, amax_x, amax_w, y, stats, B * ((plane + 63) / 64));
     CSEG_CHECK_LAUNCH("conv1x1_sb_kernel");
     return 1;
 }
 
 template <class AR>
 int fwd_1x1(const float* x, const uint4* wq, const float* bias, int B, int Cin, int Cout, int HW, int NT, const unsigned* amax_x,
-            const unsigned* amax_w, float* y, hipStream_t stream) {
+            const unsigned* amax_w, float* y, float4* stats, hipStream_t stream) {
     switch (NT) {
-        case 9: return launch_1x1<AR, 9>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stream);
-        case 8: return launch_1x1<AR, 8>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stream);
-        case 6: return launch_1x1<AR, 6>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stream);
-        case 4: return launch_1x1<AR, 4>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stream);
-        default: return launch_1x1<AR, 3>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stream);
+        case 9: return launch_1x1<AR, 9>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
+        case 8: return launch_1x1<AR, 8>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
+        case 6: return launch_1x1<AR, 6>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
+        case 4: return launch_1x1<AR, 4>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
+        default: return launch_1x1<AR, 3>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
     }
 }
 
@@ -251,7 +261,8 @@ int pack_1x1(const float* w, int Cout, int Cin, int transpose, int arith, const 
 }
 
 int run_1x1(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int HW, int arith, const unsigned* amax_x,
-            const unsigned* amax_w, float* y, hipStream_t stream) {
+            const unsigned* amax_w, float* y, hipStream_t stream, float4* stats = nullptr) {
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 15) == 0, "conv1x1 split: the statistics buffer must be 16-byte aligned");
     CSEG_REQUIRE(x && wp && y, "conv1x1_sb: null pointer");
     CSEG_REQUIRE(arith == CSEG_ARITH_BF16X6 || (arith == CSEG_ARITH_F16X3 && amax_x && amax_w),
                  "conv1x1 split: arithmetic %d needs max|x| and max|w|", arith);
@@ -261,8 +272,8 @@ int run_1x1(const float* x, const void* wp, const float* bias, int B, int Cin, i
     CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && HW % 4 == 0,
                  "conv1x1_sb: packed weights / output must be 16-byte aligned and H*W a multiple of 4");
     const uint4* wq = (const uint4*)wp;
-    if (arith == CSEG_ARITH_F16X3) return fwd_1x1<SplitF16x3>(x, wq, bias, B, Cin, Cout, HW, NT, amax_x, amax_w, y, stream);
-    return fwd_1x1<SplitBF16x6>(x, wq, bias, B, Cin, Cout, HW, NT, amax_x, amax_w, y, stream);
+    if (arith == CSEG_ARITH_F16X3) return fwd_1x1<SplitF16x3>(x, wq, bias, B, Cin, Cout, HW, NT, amax_x, amax_w, y, stats, stream);
+    return fwd_1x1<SplitBF16x6>(x, wq, bias, B, Cin, Cout, HW, NT, amax_x, amax_w, y, stats, stream);
 }
 
 }  // namespace
@@ -298,4 +309,12 @@ extern "C" int cseg_conv1x1_sb_fwd(const float* x, const void* wp, const float* 
 extern "C" int cseg_conv1x1_split_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int HW, int arith,
                                       const unsigned* amax_x, const unsigned* amax_w, float* y, cseg_stream_t stream_) {
     return run_1x1(x, wp, bias, B, Cin, Cout, HW, arith, amax_x, amax_w, y, (hipStream_t)stream_);
+}
+
+// The same convolution with the BatchNorm statistics of its output from the epilogue: stats [Cout][cseg_conv_stat_segments(1, B, HW, 1)]
+// float4 = (count, mean, M2) per run of 64 flat pixels (cseg_stats.h; see cseg_conv3x3_split_fwd_st).
+extern "C" int cseg_conv1x1_split_fwd_st(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int HW, int arith,
+                                         const unsigned* amax_x, const unsigned* amax_w, float* y, float* stats, cseg_stream_t stream_) {
+    CSEG_REQUIRE(stats, "conv1x1_split_fwd_st: null statistics buffer");
+    return run_1x1(x, wp, bias, B, Cin, Cout, HW, arith, amax_x, amax_w, y, (hipStream_t)stream_, reinterpret_cast<float4*>(stats));
 }

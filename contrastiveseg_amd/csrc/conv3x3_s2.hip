@@ -17,6 +17,7 @@
 //     accumulator sets (px = 0, 1), 2 (py = 0) or 3 (py = 1) K-steps per 16-channel chunk, a dy patch of 5 x 65 pixels, and writes
 //     whole rows of dx (the two column parities interleaved in registers: 32 contiguous bytes per lane).
 #include "cseg_pack.h"
+#include "cseg_stats.h"
 #include <stdlib.h>
 
 namespace {
@@ -87,7 +88,8 @@ template <class AR, int NT>
 __global__ __launch_bounds__(512, 2) void conv3x3_s2_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, int Cin,
                                                                 int Cout, int Ho, int Wo, int tiles_x, int tiles_y,
                                                                 const unsigned* __restrict__ amax_x,
-                                                                const unsigned* __restrict__ amax_w, float* __restrict__ y) {
+                                                                const unsigned* __restrict__ amax_w, float* __restrict__ y,
+                                                                float4* __restrict__ stats, int n_seg) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s2[];
     constexpr int NP = AR::NP;
     constexpr int A_CELLS = NP * NOCT * F_PLANE;
@@ -214,6 +216,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_fwd_kernel(const float* __r
         const float unscale = split_unscale_of(ex) * split_unscale_of(ew);
         if (half == 0) s2_store_fwd<NT0, NT0>(acc, ybc, co0, oplane, yy, x0, Wo, g, n, unscale);
         else if (NT1 > 0) s2_store_fwd<NT1, NT0>(acc, ybc, co0 + NT0 * 16, oplane, yy, x0, Wo, g, n, unscale);
+        if (stats) {                                // BatchNorm statistics of what was just stored (cseg_stats.h)
+            const size_t seg = ((size_t)b * Ho + yy) * tiles_x + tx;
+            if (half == 0) cseg_stats_emit<NT0, NT0>(acc, nullptr, co0, unscale, x0, Wo, g, n, stats + (size_t)co0 * n_seg + seg, n_seg);
+            else if (NT1 > 0)
+                cseg_stats_emit<NT1, NT0>(acc, nullptr, co0 + NT0 * 16, unscale, x0, Wo, g, n, stats + (size_t)(co0 + NT0 * 16) * n_seg + seg,
+                                          n_seg);
+        }
     }
 }
 
@@ -452,9 +461,10 @@ extern "C" int cseg_conv3x3_s2_split_pack(const float* w, int Cout, int Cin, int
     return 1;
 }
 
-extern "C" int cseg_conv3x3_s2_split_fwd(const float* x, const void* wp, int B, int Cin, int Cout, int Ho, int Wo, int nt,
-                                         const unsigned* amax_x, const unsigned* amax_w, float* y, cseg_stream_t stream_) {
+static int s2_fwd_impl(const float* x, const void* wp, int B, int Cin, int Cout, int Ho, int Wo, int nt, const unsigned* amax_x,
+                       const unsigned* amax_w, float* y, float4* stats, cseg_stream_t stream_) {
     CSEG_REQUIRE(x && wp && y && amax_x && amax_w, "conv3x3_s2_fwd: null pointer");
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 15) == 0, "conv3x3_s2_fwd: the statistics buffer must be 16-byte aligned");
     CSEG_REQUIRE(B > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cin % 16 == 0 && s2_nt_ok(nt, Cout) && Wo % 4 == 0 &&
                      (long)Ho * Wo * 4 * 16 * 4 < 2147483647L,
                  "conv3x3_s2_fwd: unsupported shape Cin=%d Cout=%d out %dx%d with %d channel tiles per block", Cin, Cout, Ho, Wo, nt);
@@ -469,18 +479,31 @@ extern "C" int cseg_conv3x3_s2_split_fwd(const float* x, const void* wp, int B, 
     if (nt == 3) {
         if (!s2_set_lds(conv3x3_s2_fwd_kernel<SplitF16x3, 3>, lds, set3)) return 0;
         hipLaunchKernelGGL((conv3x3_s2_fwd_kernel<SplitF16x3, 3>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, (const uint4*)wp, Cin,
-                           Cout, Ho, Wo, tiles_x, tiles_y, amax_x, amax_w, y);
+                           Cout, Ho, Wo, tiles_x, tiles_y, amax_x, amax_w, y, stats, B * Ho * tiles_x);
     } else if (nt == 4) {
         if (!s2_set_lds(conv3x3_s2_fwd_kernel<SplitF16x3, 4>, lds, set4)) return 0;
         hipLaunchKernelGGL((conv3x3_s2_fwd_kernel<SplitF16x3, 4>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, (const uint4*)wp, Cin,
-                           Cout, Ho, Wo, tiles_x, tiles_y, amax_x, amax_w, y);
+                           Cout, Ho, Wo, tiles_x, tiles_y, amax_x, amax_w, y, stats, B * Ho * tiles_x);
     } else {
         if (!s2_set_lds(conv3x3_s2_fwd_kernel<SplitF16x3, 6>, lds, set6)) return 0;
         hipLaunchKernelGGL((conv3x3_s2_fwd_kernel<SplitF16x3, 6>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, (const uint4*)wp, Cin,
-                           Cout, Ho, Wo, tiles_x, tiles_y, amax_x, amax_w, y);
+                           Cout, Ho, Wo, tiles_x, tiles_y, amax_x, amax_w, y, stats, B * Ho * tiles_x);
     }
     CSEG_CHECK_LAUNCH("conv3x3_s2_fwd_kernel");
     return 1;
+}
+
+extern "C" int cseg_conv3x3_s2_split_fwd(const float* x, const void* wp, int B, int Cin, int Cout, int Ho, int Wo, int nt,
+                                         const unsigned* amax_x, const unsigned* amax_w, float* y, cseg_stream_t stream_) {
+    return s2_fwd_impl(x, wp, B, Cin, Cout, Ho, Wo, nt, amax_x, amax_w, y, nullptr, stream_);
+}
+
+// with the BatchNorm statistics of the output from the epilogue: stats [Cout][cseg_conv_stat_segments(0, B, Ho, Wo)] float4
+extern "C" int cseg_conv3x3_s2_split_fwd_st(const float* x, const void* wp, int B, int Cin, int Cout, int Ho, int Wo, int nt,
+                                            const unsigned* amax_x, const unsigned* amax_w, float* y, float* stats,
+                                            cseg_stream_t stream_) {
+    CSEG_REQUIRE(stats, "conv3x3_s2_split_fwd_st: null statistics buffer");
+    return s2_fwd_impl(x, wp, B, Cin, Cout, Ho, Wo, nt, amax_x, amax_w, y, reinterpret_cast<float4*>(stats), stream_);
 }
 
 // nt tiles the channels of dx (= Cin of the convolution)

@@ -34,6 +34,7 @@
 // form needs max|x| and max|w| (device pointers, bit patterns; cseg_amax_f32): the patch is scaled while it is split, the weights
 // while they are packed, and the epilogue multiplies the accumulators by the inverse power of two.
 #include "cseg_pack.h"
+#include "cseg_stats.h"
 #include <stdlib.h>
 
 // conv3x3_sb16.hip: the small-channel variant (16-channel chunks, two blocks per CU), reached under CSEG_CONV3X3_SB_VAR=2
@@ -42,9 +43,9 @@ size_t packed_bytes(int arith, int Cin, int Cout);
 int pack(const float* w, int Cout, int Cin, int transpose_flip, int NT, int arith, const unsigned* amax_w, void* wp,
          hipStream_t stream);
 int fwd8(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int arith, const unsigned* amax_x,
-         const unsigned* amax_w, float* y, hipStream_t stream);
+         const unsigned* amax_w, float* y, float4* stats, hipStream_t stream);
 int fwd(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W, int NT, int arith,
-        const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream);
+        const unsigned* amax_x, const unsigned* amax_w, float* y, float4* stats, hipStream_t stream);
 }  // namespace cseg_sb16
 
 namespace {
@@ -174,7 +175,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
                                                             const float* __restrict__ bias, const float* __restrict__ addend, int Cin, int Cout, int H,
                                                             int W, int tiles_x, int tiles_y,
                                                             const unsigned* __restrict__ amax_x,
-                                                            const unsigned* __restrict__ amax_w, float* __restrict__ y) {
+                                                            const unsigned* __restrict__ amax_w, float* __restrict__ y,
+                                                            float4* __restrict__ stats, int n_seg) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_sb[];
     constexpr int NP = AR::NP;
     constexpr int A_CELLS = NP * 4 * PLANE;
@@ -423,6 +425,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
         const float* abc = addend ? addend + (size_t)b * Cout * plane : nullptr;
         if (half == 0) sb_store<NT0, NT0>(acc, ybc, bias, abc, co0, plane, yy, x0, W, g, n, unscale);
         else if (NT1 > 0) sb_store<NT1, NT0>(acc, ybc, bias, abc, co0 + NT0 * 16, plane, yy, x0, W, g, n, unscale);
+        if (stats) {                                // BatchNorm statistics of what was just stored (cseg_stats.h)
+            const size_t seg = ((size_t)b * H + yy) * tiles_x + tx;
+            if (half == 0) cseg_stats_emit<NT0, NT0>(acc, bias, co0, unscale, x0, W, g, n, stats + (size_t)co0 * n_seg + seg, n_seg);
+            else if (NT1 > 0)
+                cseg_stats_emit<NT1, NT0>(acc, bias, co0 + NT0 * 16, unscale, x0, W, g, n, stats + (size_t)(co0 + NT0 * 16) * n_seg + seg, n_seg);
+        }
     }
 }
 
@@ -442,7 +450,7 @@ int pick_nt(int Cout) {
 
 template <class AR, int NT, bool GLDS, int VAR = 0, int ABL = 0, int SPS = 1>
 int launch_sb(const float* x, const uint4* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W,
-              const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream) {
+              const unsigned* amax_x, const unsigned* amax_w, float* y, float4* stats, hipStream_t stream) {
     const size_t lds = sizeof(uint4) * (AR::NP * 4 * PLANE + 2 * SPS * NT * AR::NP * 64);
     static bool attr_set = false;
     if (!attr_set) {
@@ -457,7 +465,7 @@ int launch_sb(const float* x, const uint4* wp, const float* bias, const float* a
     const long n_tiles = (long)B * (Cout / (NT * 16)) * tiles_y * tiles_x;
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb: grid too large");
     hipLaunchKernelGGL((conv3x3_sb_kernel<AR, NT, GLDS, VAR, ABL, SPS>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, addend, Cin, Cout, H, W, tiles_x,
-                       tiles_y, amax_x, amax_w, y);
+                       tiles_y, amax_x, amax_w, y, stats, B * H * tiles_x);
     CSEG_CHECK_LAUNCH("conv3x3_sb_kernel");
     return 1;
 }
@@ -556,7 +564,9 @@ extern "C" int cseg_conv3x3_split_pack(const float* w, int Cout, int Cin, int tr
 }
 
 static int fwd_impl(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W, int NT, int arith,
-                    const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream) {
+                    const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream, float4* stats = nullptr) {
+    CSEG_REQUIRE(!stats || (!addend && (reinterpret_cast<uintptr_t>(stats) & 15) == 0),
+                 "conv3x3 split: the statistics epilogue takes no addend and needs a 16-byte aligned buffer");
     CSEG_REQUIRE(x && wp && y, "conv3x3_sb: null pointer");
     CSEG_REQUIRE(arith_ok(arith) && (arith == CSEG_ARITH_BF16X6 || (amax_x && amax_w)),
                  "conv3x3 split: arithmetic %d needs max|x| and max|w|", arith);
@@ -564,12 +574,12 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, const flo
         CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && W % 4 == 0,
                      "conv3x3_sb: packed weights / output must be 16-byte aligned and W a multiple of 4");
         CSEG_REQUIRE(!addend, "conv3x3_sb: the 8-row kernel takes no addend");
-        return cseg_sb16::fwd8(x, wp, bias, B, Cin, Cout, H, W, arith, amax_x, amax_w, y, stream);
+        return cseg_sb16::fwd8(x, wp, bias, B, Cin, Cout, H, W, arith, amax_x, amax_w, y, stats, stream);
     }
     if (use_sb16(Cout)) {
         CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && W % 4 == 0,
                      "conv3x3_sb: packed weights / output must be 16-byte aligned and W a multiple of 4");
-        return cseg_sb16::fwd(x, wp, bias, addend, B, Cin, Cout, H, W, sb16_nt(Cout, NT), arith, amax_x, amax_w, y, stream);
+        return cseg_sb16::fwd(x, wp, bias, addend, B, Cin, Cout, H, W, sb16_nt(Cout, NT), arith, amax_x, amax_w, y, stats, stream);
     }
     if (NT == 0) NT = pick_nt(Cout);
     CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && NT > 0 && nt_ok(NT, Cout),
@@ -586,23 +596,23 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, const flo
                  "conv3x3_sb: unsupported CSEG_CONV3X3_SB_VAR=%d", var);
 #define SB_LAUNCH(AR, G, V)                                                                                            \
     switch (NT) {                                                                                                      \
-        case 9: return launch_sb<AR, 9, G, V>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);             \
-        case 6: return launch_sb<AR, 6, G, V>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);             \
-        default: return launch_sb<AR, 3, G, V>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);            \
+        case 9: return launch_sb<AR, 9, G, V>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);             \
+        case 6: return launch_sb<AR, 6, G, V>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);             \
+        default: return launch_sb<AR, 3, G, V>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);            \
     }
     if (arith == CSEG_ARITH_F16X3 && NT == 9 && var >= 1) {
         const char* abl_env = getenv("CSEG_ABLATE");                // timing experiments only (wrong results)
         switch (abl_env ? atoi(abl_env) : 0) {
             case 0: break;
-            case 1: return launch_sb<SplitF16x3, 9, true, 1, 1>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-            case 2: return launch_sb<SplitF16x3, 9, true, 1, 2>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-            case 4: return launch_sb<SplitF16x3, 9, true, 1, 4>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-            case 6: return launch_sb<SplitF16x3, 9, true, 1, 6>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-            case 8: return launch_sb<SplitF16x3, 9, true, 1, 8>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-            case 14: return launch_sb<SplitF16x3, 9, true, 1, 14>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-            case 7: return launch_sb<SplitF16x3, 9, true, 1, 7>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-            case 9: return launch_sb<SplitF16x3, 9, true, 1, 9>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-            default: return launch_sb<SplitF16x3, 9, true, 1, 15>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+            case 1: return launch_sb<SplitF16x3, 9, true, 1, 1>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
+            case 2: return launch_sb<SplitF16x3, 9, true, 1, 2>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
+            case 4: return launch_sb<SplitF16x3, 9, true, 1, 4>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
+            case 6: return launch_sb<SplitF16x3, 9, true, 1, 6>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
+            case 8: return launch_sb<SplitF16x3, 9, true, 1, 8>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
+            case 14: return launch_sb<SplitF16x3, 9, true, 1, 14>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
+            case 7: return launch_sb<SplitF16x3, 9, true, 1, 7>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
+            case 9: return launch_sb<SplitF16x3, 9, true, 1, 9>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
+            default: return launch_sb<SplitF16x3, 9, true, 1, 15>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
         }
     }
     if (arith == CSEG_ARITH_F16X3) {
@@ -611,9 +621,9 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, const flo
         const char* sps_env = getenv("CSEG_CONV3X3_SB_SPS");
         if (var >= 1 && !(sps_env && atoi(sps_env) == 1)) {
             switch (NT) {
-                case 9: return launch_sb<SplitF16x3, 9, true, 1, 0, 3>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-                case 6: return launch_sb<SplitF16x3, 6, true, 1, 0, 3>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-                default: return launch_sb<SplitF16x3, 3, true, 1, 0, 3>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+                case 9: return launch_sb<SplitF16x3, 9, true, 1, 0, 3>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
+                case 6: return launch_sb<SplitF16x3, 6, true, 1, 0, 3>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
+                default: return launch_sb<SplitF16x3, 3, true, 1, 0, 3>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
             }
         }
         if (var >= 1) { SB_LAUNCH(SplitF16x3, true, 1) }
@@ -641,6 +651,27 @@ extern "C" int cseg_conv3x3_split_fwd(const float* x, const void* wp, const floa
                                       cseg_stream_t stream_) {
     CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9 || nt == CSEG_NT_SB8, "conv3x3_split_fwd: nt must be 0, 3, 6, 9 or CSEG_NT_SB8 (got %d)", nt);
     return fwd_impl(x, wp, bias, nullptr, B, Cin, Cout, H, W, nt, arith, amax_x, amax_w, y, (hipStream_t)stream_);
+}
+
+// The same convolution with the BatchNorm statistics of its OUTPUT produced by the epilogue (cseg_stats.h): stats receives
+// [Cout][cseg_conv_stat_segments(0, B, H, W)] float4 = (count, mean, M2) per 64-pixel row segment; cseg_bn_tiles_finalize /
+// cseg_bn_tiles_moments turn them into what the BatchNorm that follows needs, so that nobody re-reads y to sum it.
+extern "C" int cseg_conv3x3_split_fwd_st(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
+                                         int nt, int arith, const unsigned* amax_x, const unsigned* amax_w, float* y, float* stats,
+                                         cseg_stream_t stream_) {
+    CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9 || nt == CSEG_NT_SB8, "conv3x3_split_fwd_st: nt must be 0, 3, 6, 9 or CSEG_NT_SB8 (got %d)", nt);
+    CSEG_REQUIRE(stats, "conv3x3_split_fwd_st: null statistics buffer");
+    return fwd_impl(x, wp, bias, nullptr, B, Cin, Cout, H, W, nt, arith, amax_x, amax_w, y, (hipStream_t)stream_,
+                    reinterpret_cast<float4*>(stats));
+}
+
+// segments per channel of a statistics buffer: kind 0 = 3x3 kernels (stride 1: H, W of the tensor; stride 2: of the OUTPUT),
+// kind 1 = 1x1 kernels (H * W flat)
+extern "C" size_t cseg_conv_stat_segments(int kind, int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    if (kind == 0) return (size_t)B * H * ((W + 63) / 64);
+    if (kind == 1) return (size_t)B * (((size_t)H * W + 63) / 64);
+    return 0;
 }
 
 // ---- max|x| of a tensor, accumulated into the record amax_bits[CSEG_AMAX_WORDS] (include/cseg_hip.h; the caller zeroes it) ----

@@ -13,6 +13,7 @@
 // the same setting; kernels.conv3x3_sb_run does both back to back).
 // Round 3: default for 48 / 192 output channels; written against the arithmetic traits of cseg_split.h (bf16x6 and f16x3).
 #include "cseg_pack.h"
+#include "cseg_stats.h"
 #include <stdlib.h>
 
 namespace {
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(cons
                                                               const float* __restrict__ bias, const float* __restrict__ addend, int Cin, int Cout, int H,
                                                               int W, int tiles_x, int tiles_y,
                                                               const unsigned* __restrict__ amax_x,
-                                                              const unsigned* __restrict__ amax_w, float* __restrict__ y) {
+                                                              const unsigned* __restrict__ amax_w, float* __restrict__ y,
+                                                              float4* __restrict__ stats, int n_seg) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s16[];
     constexpr int NP = AR::NP;
     constexpr int A_CELLS = NP * NOCT * PLANE;
@@ -231,6 +233,12 @@ __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(cons
         const float* abc = addend ? addend + (size_t)b * Cout * plane : nullptr;
         if (half == 0) sb16_store<NT0, NT0>(acc, ybc, bias, abc, co0, plane, yy, x0, W, g, n, unscale);
         else if (NT1 > 0) sb16_store<NT1, NT0>(acc, ybc, bias, abc, co0 + NT0 * 16, plane, yy, x0, W, g, n, unscale);
+        if (stats) {                                // BatchNorm statistics of what was just stored (cseg_stats.h)
+            const size_t seg = ((size_t)b * H + yy) * tiles_x + tx;
+            if (half == 0) cseg_stats_emit<NT0, NT0>(acc, bias, co0, unscale, x0, W, g, n, stats + (size_t)co0 * n_seg + seg, n_seg);
+            else if (NT1 > 0)
+                cseg_stats_emit<NT1, NT0>(acc, bias, co0 + NT0 * 16, unscale, x0, W, g, n, stats + (size_t)(co0 + NT0 * 16) * n_seg + seg, n_seg);
+        }
     }
 }
 
@@ -254,7 +262,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
                                                                const float* __restrict__ bias, const float* __restrict__ addend, int Cin, int Cout, int H, int W,
                                                                int tiles_x, int tiles_y, int n_spatial, int groups,
                                                                const unsigned* __restrict__ amax_x,
-                                                               const unsigned* __restrict__ amax_w, float* __restrict__ y) {
+                                                               const unsigned* __restrict__ amax_w, float* __restrict__ y,
+                                                               float4* __restrict__ stats, int n_seg) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s16p[];
     constexpr int NP = AR::NP;
     constexpr int A_CELLS = NP * NOCT * PLANE;
@@ -395,6 +404,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
                 const int co0 = cot * NT * 16;
                 if (half == 0) sb16_store<NT0, NT0>(acc, ybc, bias, abc, co0, plane, yy, x0, W, g, n, unscale);
                 else if (NT1 > 0) sb16_store<NT1, NT0>(acc, ybc, bias, abc, co0 + NT0 * 16, plane, yy, x0, W, g, n, unscale);
+                if (stats) {
+                    const size_t seg = ((size_t)b * H + yy) * tiles_x + x0 / TC;
+                    if (half == 0) cseg_stats_emit<NT0, NT0>(acc, bias, co0, unscale, x0, W, g, n, stats + (size_t)co0 * n_seg + seg, n_seg);
+                    else if (NT1 > 0)
+                        cseg_stats_emit<NT1, NT0>(acc, bias, co0 + NT0 * 16, unscale, x0, W, g, n, stats + (size_t)(co0 + NT0 * 16) * n_seg + seg,
+                                                  n_seg);
+                }
             }
         }
         if (more) a_store(it + 1, As + (size_t)((it + 1) & 1) * A_CELLS);  // the other patch buffer: last read in item it - 1
@@ -404,7 +420,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
 
 template <class AR, int NT, bool RES>
 int launch_sb16p(const float* x, const uint4* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W,
-                 const unsigned* amax_x, const unsigned* amax_w, float* y, size_t lds, hipStream_t stream) {
+                 const unsigned* amax_x, const unsigned* amax_w, float* y, float4* stats, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)(conv3x3_sb16p_kernel<AR, NT, RES>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -422,7 +438,7 @@ int launch_sb16p(const float* x, const uint4* wp, const float* bias, const float
     if (groups < 1) groups = 1;
     if (groups > n_spatial) groups = n_spatial;
     hipLaunchKernelGGL((conv3x3_sb16p_kernel<AR, NT, RES>), dim3((unsigned)(groups * n_cot)), dim3(512), lds, stream, x, wp, bias,
-                       addend, Cin, Cout, H, W, tiles_x, tiles_y, (int)n_spatial, (int)groups, amax_x, amax_w, y);
+                       addend, Cin, Cout, H, W, tiles_x, tiles_y, (int)n_spatial, (int)groups, amax_x, amax_w, y, stats, B * H * tiles_x);
     CSEG_CHECK_LAUNCH("conv3x3_sb16p_kernel");
     return 1;
 }
@@ -444,7 +460,7 @@ bool sb16p_plan(int arith, int Cin, int NT, size_t& lds, bool& res) {
 
 template <class AR, int NT>
 int launch_sb16(const float* x, const uint4* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W,
-                const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream) {
+                const unsigned* amax_x, const unsigned* amax_w, float* y, float4* stats, hipStream_t stream) {
     const size_t lds = sizeof(uint4) * (AR::NP * NOCT * PLANE + 2 * NT * AR::NP * 64);
     static bool attr_set = false;
     if (!attr_set) {
@@ -459,7 +475,7 @@ int launch_sb16(const float* x, const uint4* wp, const float* bias, const float*
     const long n_tiles = (long)B * (Cout / (NT * 16)) * tiles_y * tiles_x;
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb16: grid too large");
     hipLaunchKernelGGL((conv3x3_sb16_kernel<AR, NT>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, addend, Cin, Cout, H, W,
-                       tiles_x, tiles_y, amax_x, amax_w, y);
+                       tiles_x, tiles_y, amax_x, amax_w, y, stats, B * H * tiles_x);
     CSEG_CHECK_LAUNCH("conv3x3_sb16_kernel");
     return 1;
 }
@@ -549,7 +565,8 @@ template <class AR>
 __global__ __launch_bounds__(512, 1) void conv3x3_sb8_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                              const float* __restrict__ bias, int Cin, int Cout, int H, int W,
                                                              int tiles_x, int tiles_y, const unsigned* __restrict__ amax_x,
-                                                             const unsigned* __restrict__ amax_w, float* __restrict__ y) {
+                                                             const unsigned* __restrict__ amax_w, float* __restrict__ y,
+                                                             float4* __restrict__ stats, int n_seg) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s8[];
     constexpr int NP = AR::NP;
     constexpr int A_CELLS = NP * 2 * PLANE8;
@@ -687,7 +704,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb8_kernel(const float* __rest
     float* ybc = y + (size_t)b * Cout * plane;
     const int co0 = cot * NT * 16;
     const float unscale = split_unscale_of(ex) * split_unscale_of(ew);
-    if (y0 + row < H) store8(acc, ybc, bias, co0, plane, y0 + row, x0, W, g, n, unscale);
+    if (y0 + row < H) {
+        store8(acc, ybc, bias, co0, plane, y0 + row, x0, W, g, n, unscale);
+        if (stats)
+            cseg_stats_emit<NT, NT>(acc, bias, co0, unscale, x0, W, g, n,
+                                    stats + (size_t)co0 * n_seg + ((size_t)b * H + y0 + row) * tiles_x + tx, n_seg);
+    }
 }
 
 constexpr size_t lds_bytes() { return sizeof(uint4) * (2 * 2 * PLANE8 + 2 * NT * 2 * 64) + sizeof(float) * RAW_FLOATS; }      // 122 112
@@ -719,7 +741,7 @@ int pack(const float* w, int Cout, int Cin, int transpose_flip, int NT, int arit
 }
 
 int fwd(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W, int NT, int arith,
-        const unsigned* amax_x, const unsigned* amax_w, float* y, hipStream_t stream) {
+        const unsigned* amax_x, const unsigned* amax_w, float* y, float4* stats, hipStream_t stream) {
     CSEG_REQUIRE((NT == 3 || NT == 4 || NT == 6) && Cout % (NT * 16) == 0 && Cin % 16 == 0 && (long)H * W * 16 * 4 < 2147483647L,
                  "conv3x3_sb16: unsupported shape Cin=%d Cout=%d %dx%d with %d channel tiles per block", Cin, Cout, H, W, NT);
     const uint4* wq = (const uint4*)wp;
@@ -727,26 +749,26 @@ int fwd(const float* x, const void* wp, const float* bias, const float* addend, 
     bool res = false;
     if (sb16p_plan(arith, Cin, NT, lds, res)) {
 #define SB16P(N)                                                                                                              \
-    return res ? launch_sb16p<SplitF16x3, N, true>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, lds, stream)          \
-               : launch_sb16p<SplitF16x3, N, false>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, lds, stream);
+    return res ? launch_sb16p<SplitF16x3, N, true>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream)          \
+               : launch_sb16p<SplitF16x3, N, false>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream);
         if (NT == 3) { SB16P(3) }
         if (NT == 4) { SB16P(4) }
         if (NT == 6) { SB16P(6) }
 #undef SB16P
     }
     if (arith == CSEG_ARITH_F16X3) {
-        if (NT == 6) return launch_sb16<SplitF16x3, 6>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-        if (NT == 4) return launch_sb16<SplitF16x3, 4>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-        return launch_sb16<SplitF16x3, 3>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+        if (NT == 6) return launch_sb16<SplitF16x3, 6>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
+        if (NT == 4) return launch_sb16<SplitF16x3, 4>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
+        return launch_sb16<SplitF16x3, 3>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
     }
-    if (NT == 6) return launch_sb16<SplitBF16x6, 6>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-    if (NT == 4) return launch_sb16<SplitBF16x6, 4>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
-    return launch_sb16<SplitBF16x6, 3>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stream);
+    if (NT == 6) return launch_sb16<SplitBF16x6, 6>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
+    if (NT == 4) return launch_sb16<SplitBF16x6, 4>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
+    return launch_sb16<SplitBF16x6, 3>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
 }
 
 // the 8-row head kernel (namespace sb8 above): f16x3, 9 channel tiles per block, weights packed by pack(..., NT = 9, ...)
 int fwd8(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int arith, const unsigned* amax_x,
-         const unsigned* amax_w, float* y, hipStream_t stream) {
+         const unsigned* amax_w, float* y, float4* stats, hipStream_t stream) {
     CSEG_REQUIRE(arith == CSEG_ARITH_F16X3 && amax_x && amax_w, "conv3x3_sb8: f16x3 only (needs max|x| and max|w|)");
     CSEG_REQUIRE(Cout % 144 == 0 && Cin % 16 == 0 && W % 4 == 0 && (long)H * W * 16 * 4 < 2147483647L,
                  "conv3x3_sb8: unsupported shape Cin=%d Cout=%d %dx%d (needs Cout %% 144, Cin %% 16, W %% 4)", Cin, Cout, H, W);
@@ -764,7 +786,7 @@ int fwd8(const float* x, const void* wp, const float* bias, int B, int Cin, int 
     const long n_tiles = (long)B * (Cout / 144) * tiles_y * tiles_x;
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb8: grid too large");
     hipLaunchKernelGGL(sb8::conv3x3_sb8_kernel<SplitF16x3>, dim3((unsigned)n_tiles), dim3(512), lds, stream, x, (const uint4*)wp, bias, Cin,
-                       Cout, H, W, tiles_x, tiles_y, amax_x, amax_w, y);
+                       Cout, H, W, tiles_x, tiles_y, amax_x, amax_w, y, stats, B * H * tiles_x);
     CSEG_CHECK_LAUNCH("conv3x3_sb8_kernel");
     return 1;
 }

@@ -730,6 +730,53 @@ def amax_of(t):
     return a
 
 
+# ----------------------------------------------------------------------------------------------------------
+# BatchNorm statistics from the producing convolution's epilogue (csrc/cseg_stats.h, round 4): the `_st` forward entry points write
+# per-(channel, 64-pixel segment) (count, mean, M2) records while the output is still in registers; the record buffer travels with
+# the output tensor exactly like the max|.| word above, and fused_bn.bn_forward finalises it (cseg_bn_tiles_finalize /
+# cseg_bn_tiles_moments) instead of reading the whole tensor once more (cseg_bn_stats*: 306 launches, 2.6 ms per step in round 3).
+# ----------------------------------------------------------------------------------------------------------
+CONV_EPILOGUE_STATS = os.environ.get("CSEG_CONV_STATS", "1") == "1"
+
+
+def tile_stats_buffer(kind, c_out, B, H, W, device):
+    """[Cout, T, 4] f32 for the statistics epilogue of a forward convolution whose OUTPUT is [B, Cout, H, W] (kind 0: 3x3 kernels,
+    1: 1x1 kernels)."""
+    T = _hip.lib().cseg_conv_stat_segments(int(kind), int(B), int(H), int(W))
+    return torch.empty(c_out, T, 4, dtype=F32, device=device)
+
+
+def tile_stats_attach(t, stats):
+    if stats is not None:
+        t._cseg_tile_stats = (stats, t._version)
+    return t
+
+
+def known_tile_stats(t):
+    a = getattr(t, "_cseg_tile_stats", None)
+    return a[0] if (a is not None and a[1] == t._version) else None
+
+
+@torch.no_grad()
+def bn_tiles_finalize(stats, eps, momentum, running_mean, running_var, num_batches_tracked):
+    """Epilogue statistics [C, T, 4] -> mean_invstd [C,2]; running statistics / batch counter updated like bn_stats_finalize."""
+    C, T = stats.shape[0], stats.shape[1]
+    mi = torch.empty(C, 2, dtype=F32, device=stats.device)
+    _hip.call("cseg_bn_tiles_finalize", _pf(stats), C, ctypes.c_long(T), float(eps), float(momentum),
+              _opt(running_mean, F32, "running_mean"), _opt(running_var, F32, "running_var"),
+              _opt(num_batches_tracked, I64, "num_batches_tracked"), _pf(mi), _hip.stream_ptr())
+    return mi
+
+
+@torch.no_grad()
+def bn_tiles_moments(stats):
+    """Epilogue statistics [C, T, 4] -> moments [C+1,2] f64 (what bn_stats returns: the tensor a SyncBN exchange all-reduces)."""
+    C, T = stats.shape[0], stats.shape[1]
+    moments = torch.empty(C + 1, 2, dtype=torch.float64, device=stats.device)
+    _hip.call("cseg_bn_tiles_moments", _pf(stats), C, ctypes.c_long(T), _pf(moments), _hip.stream_ptr())
+    return moments
+
+
 import weakref
 
 import numpy as np
@@ -981,7 +1028,7 @@ def conv3x3_sb_pack(weight, transpose_flip=False, nt=0):
 
 
 @torch.no_grad()
-def conv3x3_sb_run(x, weight, transpose_flip=False, bias=None, nt=0, ax=None, addend=None):
+def conv3x3_sb_run(x, weight, transpose_flip=False, bias=None, nt=0, ax=None, addend=None, want_stats=False):
     """y = conv2d(x, weight, bias, 1, 1) (transpose_flip: the backward-data operator of that convolution applied to x)
     through the split-operand MFMA kernel. nt = 0: the library's default channel tiling; 3 / 6 / 9: explicit. ax: max|x| word
     (tensor_amax) when the caller already has it; computed here otherwise (f16x3 only). addend: tensor of the output's shape added
@@ -1001,6 +1048,11 @@ def conv3x3_sb_run(x, weight, transpose_flip=False, bias=None, nt=0, ax=None, ad
                   conv_in, conv_out, H, W, int(nt), arith, _pf(ax) if arith else _null(), _pf(aw) if arith else _null(), _pf(y),
                   _hip.stream_ptr())
         return y
+    if want_stats and CONV_EPILOGUE_STATS:
+        st = tile_stats_buffer(0, conv_out, B, H, W, x.device)
+        _hip.call("cseg_conv3x3_split_fwd_st", _p(x, F32, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H, W,
+                  int(nt), arith, _pf(ax) if arith else _null(), _pf(aw) if arith else _null(), _pf(y), _pf(st), _hip.stream_ptr())
+        return tile_stats_attach(y, st)
     _hip.call("cseg_conv3x3_split_fwd", _p(x, F32, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H, W,
               int(nt), arith, _pf(ax) if arith else _null(), _pf(aw) if arith else _null(), _pf(y), _hip.stream_ptr())
     return y
@@ -1077,14 +1129,14 @@ class Conv3x3SplitBF16(Function):
     the bias gradient."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, want_stats=False):
         weight = weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.pick = weight.shape[0] in CONV3X3_SB_PICK_NT_CHANNELS
         ctx.ax = amax_of(x) if split_arith_id() else None              # reused by the weight gradient
         nt = conv3x3_sb_pick_nt(x, weight.shape[0]) if ctx.pick else conv3x3_sb_head_nt(weight.shape[0], x)
-        return conv3x3_sb_run(x, weight, False, bias, nt, ax=ctx.ax)
+        return conv3x3_sb_run(x, weight, False, bias, nt, ax=ctx.ax, want_stats=want_stats)
 
     @staticmethod
     def backward(ctx, dy):
@@ -1108,11 +1160,12 @@ class Conv3x3SplitBF16(Function):
                 _, dw, db = torch.ops.aten.convolution_backward(
                     dy, x, weight, [co] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                     [False, bool(ctx.needs_input_grad[1]), bool(want_db)])
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def conv3x3_split_bf16(x, weight, bias=None):
-    return Conv3x3SplitBF16.apply(x, weight, bias)
+def conv3x3_split_bf16(x, weight, bias=None, want_stats=False):
+    """want_stats: a BatchNorm follows -- let the epilogue produce its statistics (tile_stats_attach on the result)."""
+    return Conv3x3SplitBF16.apply(x, weight, bias, want_stats)
 
 
 class Conv3x3SplitFork(Function):
@@ -1122,13 +1175,13 @@ class Conv3x3SplitFork(Function):
     leaving a separate elementwise add to autograd (104 adds of 6-50 MB tensors per step of HRNet-W48: 1.7 ms)."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, want_stats=False):
         weight = weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.pick = weight.shape[0] in CONV3X3_SB_PICK_NT_CHANNELS
         ctx.ax = amax_of(x) if split_arith_id() else None
         nt = conv3x3_sb_pick_nt(x, weight.shape[0]) if ctx.pick else 0
-        return conv3x3_sb_run(x, weight, False, None, nt, ax=ctx.ax), x.view_as(x)
+        return conv3x3_sb_run(x, weight, False, None, nt, ax=ctx.ax, want_stats=want_stats), x.view_as(x)
 
     @staticmethod
     def backward(ctx, dy, g):
@@ -1149,14 +1202,14 @@ class Conv3x3SplitFork(Function):
             else:
                 dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [False, True, False])[1]
-        return dx, dw
+        return dx, dw, None
 
 
 CONV3X3_FORK = os.environ.get("CSEG_CONV3X3_FORK", "1") == "1"
 
 
-def conv3x3_split_fork(x, weight):
-    return Conv3x3SplitFork.apply(x, weight)
+def conv3x3_split_fork(x, weight, want_stats=False):
+    return Conv3x3SplitFork.apply(x, weight, want_stats)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -1198,7 +1251,7 @@ def conv3x3_s2_pick_nt(B, Ho, Wo, c_out):
 
 
 @torch.no_grad()
-def conv3x3_s2_run(x, weight, ax=None):
+def conv3x3_s2_run(x, weight, ax=None, want_stats=False):
     """y = conv2d(x, weight, None, stride 2, padding 1)."""
     co, ci = weight.shape[:2]
     B, _, H, W = x.shape
@@ -1207,6 +1260,11 @@ def conv3x3_s2_run(x, weight, ax=None):
     wp, aw = SPLIT_WEIGHTS.get(weight, "c3s2", False, nt)
     ax = tensor_amax(x) if ax is None else ax
     y = torch.empty(B, co, Ho, Wo, dtype=F32, device=x.device)
+    if want_stats and CONV_EPILOGUE_STATS:
+        st = tile_stats_buffer(0, co, B, Ho, Wo, x.device)
+        _hip.call("cseg_conv3x3_s2_split_fwd_st", _p(x, F32, "x"), wp.data_ptr(), B, ci, co, Ho, Wo, nt, _pf(ax), _pf(aw), _pf(y),
+                  _pf(st), _hip.stream_ptr())
+        return tile_stats_attach(y, st)
     _hip.call("cseg_conv3x3_s2_split_fwd", _p(x, F32, "x"), wp.data_ptr(), B, ci, co, Ho, Wo, nt, _pf(ax), _pf(aw), _pf(y),
               _hip.stream_ptr())
     return y
@@ -1248,13 +1306,13 @@ class Conv3x3S2Split(Function):
     MIOpen (aten)."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, want_stats=False):
         weight = weight.contiguous()
         x = x.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.ax = amax_of(x)                              # reused by the weight gradient
         if conv3x3_s2_fwd_eligible(x, weight):
-            return conv3x3_s2_run(x, weight, ax=ctx.ax)
+            return conv3x3_s2_run(x, weight, ax=ctx.ax, want_stats=want_stats)
         return torch.nn.functional.conv2d(x, weight, None, 2, 1)
 
     @staticmethod
@@ -1274,11 +1332,11 @@ class Conv3x3S2Split(Function):
             gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, rest)
             dx = gx if rest[0] else dx
             dw = gw if rest[1] else dw
-        return dx, dw
+        return dx, dw, None
 
 
-def conv3x3_s2_split(x, weight):
-    return Conv3x3S2Split.apply(x, weight)
+def conv3x3_s2_split(x, weight, want_stats=False):
+    return Conv3x3S2Split.apply(x, weight, want_stats)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -1308,7 +1366,7 @@ def conv1x1_sb_pack(weight, transpose=False):
 
 
 @torch.no_grad()
-def conv1x1_sb_run(x, weight, transpose=False, bias=None, ax=None):
+def conv1x1_sb_run(x, weight, transpose=False, bias=None, ax=None, want_stats=False):
     """y = conv2d(x, weight[Cout,Cin,1,1], bias) (transpose: the backward-data operator applied to x)."""
     co, ci = weight.shape[:2]
     conv_in, conv_out = (co, ci) if transpose else (ci, co)
@@ -1318,6 +1376,11 @@ def conv1x1_sb_run(x, weight, transpose=False, bias=None, ax=None):
     if arith and ax is None:
         ax = tensor_amax(x)
     y = torch.empty(B, conv_out, H, W, dtype=F32, device=x.device)
+    if want_stats and CONV_EPILOGUE_STATS:
+        st = tile_stats_buffer(1, conv_out, B, H * W, 1, x.device)
+        _hip.call("cseg_conv1x1_split_fwd_st", _p(x, F32, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H * W,
+                  arith, _pf(ax) if arith else _null(), _pf(aw) if arith else _null(), _pf(y), _pf(st), _hip.stream_ptr())
+        return tile_stats_attach(y, st)
     _hip.call("cseg_conv1x1_split_fwd", _p(x, F32, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H * W,
               arith, _pf(ax) if arith else _null(), _pf(aw) if arith else _null(), _pf(y), _hip.stream_ptr())
     return y
@@ -1363,12 +1426,12 @@ class Conv1x1SplitBF16(Function):
     gradients on MIOpen / rocBLAS (fp32)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, want_stats=False):
         weight = weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.ax = amax_of(x) if split_arith_id() else None
-        return conv1x1_sb_run(x, weight, False, bias, ax=ctx.ax)
+        return conv1x1_sb_run(x, weight, False, bias, ax=ctx.ax, want_stats=want_stats)
 
     @staticmethod
     def backward(ctx, dy):
@@ -1385,11 +1448,11 @@ class Conv1x1SplitBF16(Function):
             _, dw, db = torch.ops.aten.convolution_backward(
                 dy, x, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                 [False, bool(ctx.needs_input_grad[1]), bool(want_db)])
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def conv1x1_split_bf16(x, weight, bias=None):
-    return Conv1x1SplitBF16.apply(x, weight, bias)
+def conv1x1_split_bf16(x, weight, bias=None, want_stats=False):
+    return Conv1x1SplitBF16.apply(x, weight, bias, want_stats)
 
 
 @torch.no_grad()

@@ -46,11 +46,17 @@ def bn_forward(x, weight, bias, residual, running_mean, running_var, num_batches
     # max|y|, accumulated by the apply kernel while it stores y: the next split-operand convolution (f16x3 arithmetic) scales
     # its input with it and would otherwise spend a pass over y on it (kernels.amax_of)
     amax = K.amax_request(x)
+    # statistics the producing convolution's epilogue already wrote (csrc/cseg_stats.h), or None = one pass over x
+    tiles = K.known_tile_stats(x) if training else None
     if training:
         if sync_group is not None:
-            moments = _all_reduce(K.bn_stats(x), sync_group)          # [C+1,2]: row C = summed element counts
+            moments = _all_reduce(K.bn_tiles_moments(tiles) if tiles is not None else K.bn_stats(x), sync_group)   # [C+1,2]: row C = summed counts
             count = moments[-1, 0]
             mi = K.bn_finalize(moments, SYNC_COUNT, eps, momentum, running_mean, running_var, num_batches_tracked)
+            y = K.bn_apply(x, mi, weight, bias, residual, relu, amax=amax)
+        elif tiles is not None:
+            # single rank, statistics from the convolution's epilogue: a per-channel combine of the segment records + the apply pass
+            mi = K.bn_tiles_finalize(tiles, eps, momentum, running_mean, running_var, num_batches_tracked)
             y = K.bn_apply(x, mi, weight, bias, residual, relu, amax=amax)
         else:
             # single rank: statistics + (finalise, running statistics, apply) in two launches
@@ -124,7 +130,8 @@ class _BNActGroup(torch.autograd.Function):
         for i in range(n):
             x = tensors[4 * i].contiguous()
             xs.append(x)
-            moments.append(K.bn_stats(x))                 # [C_i + 1, 2]: the last row carries this rank's element count
+            tiles = K.known_tile_stats(x)                 # the producing convolution's epilogue statistics, if it wrote them
+            moments.append(K.bn_tiles_moments(tiles) if tiles is not None else K.bn_stats(x))     # [C_i + 1, 2]: last row = element count
         packed = _all_reduce(torch.cat(moments, dim=0), sync_group)
         outs, saved = [], []
         off = 0

@@ -23,6 +23,9 @@ class Conv3x3(nn.Conv2d):
         against MIOpen at the benched shapes, tools/conv3x3_probe.py);
       * everything else: the reference's nn.Conv2d on MIOpen."""
     MFMA_CHANNELS = (48, 96)
+    # set by the owner when a BatchNorm consumes the output directly (conv -> bn chains, hrnet_backbone.py:49-65 of the reference): the
+    # split kernels then produce the BN statistics in their epilogue (csrc/cseg_stats.h) and fused_bn skips its statistics pass
+    bn_follows = False
 
     def __init__(self, inplanes, planes, stride=1):
         super(Conv3x3, self).__init__(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
@@ -34,13 +37,13 @@ class Conv3x3(nn.Conv2d):
             if (K.CONV3X3_SPLIT_BF16 and (pair or self.in_channels in K.CONV3X3_SB_BRANCH_CHANNELS)
                     and K.conv3x3_sb_eligible(x, self.weight)
                     and K.conv3x3_sb_tiles(x, self.out_channels) >= K.CONV3X3_SB_MIN_TILES):
-                return K.conv3x3_split_bf16(x, self.weight)
+                return K.conv3x3_split_bf16(x, self.weight, None, self.bn_follows)
             if not pair and self.in_channels in self.MFMA_CHANNELS and K.conv3x3_eligible(x, self.weight):
                 return K.conv3x3(x, self.weight)
         if (K._on_device(x) and self.stride == (2, 2) and self.dilation == (1, 1)
                 and (K.conv3x3_s2_fwd_eligible(x, self.weight) or K.conv3x3_s2_wrw_eligible(x, self.weight))):
             # downsampling convolutions of the fuse / transition layers: csrc/conv3x3_s2.hip + the stride-2 weight gradient
-            return K.conv3x3_s2_split(x, self.weight)
+            return K.conv3x3_s2_split(x, self.weight, self.bn_follows)
         return super(Conv3x3, self).forward(x)
 
     def forward_fork(self, x):
@@ -52,7 +55,7 @@ class Conv3x3(nn.Conv2d):
                 and self.in_channels == self.out_channels and K.CONV3X3_SPLIT_BF16
                 and self.in_channels in K.CONV3X3_SB_BRANCH_CHANNELS and K.conv3x3_sb_eligible(x, self.weight)
                 and K.conv3x3_sb_tiles(x, self.out_channels) >= K.CONV3X3_SB_MIN_TILES):
-            return K.conv3x3_split_fork(x, self.weight)
+            return K.conv3x3_split_fork(x, self.weight, self.bn_follows)
         return self.forward(x), x
 
 
@@ -62,6 +65,8 @@ class HeadConv3x3(nn.Conv2d):
     backward-data run on the split-bf16 MFMA kernel (csrc/conv3x3_sb.hip: 11.0 vs 19.8 ms per direction at bs 8,
     128x256); otherwise, and for shapes it does not cover, this is the reference's nn.Conv2d on MIOpen."""
 
+    bn_follows = False        # see Conv3x3
+
     def __init__(self, channels):
         super(HeadConv3x3, self).__init__(channels, channels, kernel_size=3, stride=1, padding=1)
 
@@ -69,7 +74,7 @@ class HeadConv3x3(nn.Conv2d):
         from contrastiveseg_amd import kernels as K
         if (K._on_device(x) and K.CONV3X3_SPLIT_BF16 and K.conv3x3_sb_eligible(x, self.weight)
                 and K.conv3x3_sb_tiles(x, self.out_channels) >= K.CONV3X3_SB_MIN_TILES):
-            return K.conv3x3_split_bf16(x, self.weight, self.bias)
+            return K.conv3x3_split_bf16(x, self.weight, self.bias, self.bn_follows)
         return super(HeadConv3x3, self).forward(x)
 
 
@@ -78,6 +83,8 @@ class Conv1x1(nn.Conv2d):
     backward-data of the shapes the split-bf16 kernel covers (csrc/conv1x1_sb.hip) run there -- and the weight gradient
     with kernels.CONV1X1_SB_WRW -- otherwise this is the reference's pointwise convolution on rocBLAS / MIOpen."""
 
+    bn_follows = False        # see Conv3x3
+
     def __init__(self, cin, cout, bias=True):
         super(Conv1x1, self).__init__(cin, cout, kernel_size=1, bias=bias)
 
@@ -85,8 +92,34 @@ class Conv1x1(nn.Conv2d):
         from contrastiveseg_amd import kernels as K
         if (K._on_device(x) and K.CONV1X1_SPLIT_BF16 and K.conv1x1_sb_eligible(x, self.weight)
                 and K.conv1x1_sb_tiles(x, self.out_channels) >= K.CONV1X1_SB_MIN_TILES):
-            return K.conv1x1_split_bf16(x, self.weight, self.bias)
+            return K.conv1x1_split_bf16(x, self.weight, self.bias, self.bn_follows)
         return super(Conv1x1, self).forward(x)
+
+
+def mark_conv_bn_pairs(module):
+    """Sets `bn_follows` on every split-kernel convolution of `module` whose output goes straight into a BatchNorm: the (conv, norm)
+    neighbours of every nn.Sequential (the `_conv_bn` chains, classifier / projection heads, `BNReLU` wrappers included) and the
+    conv_k / bn_k attribute pairs of the residual blocks. Called once by the model constructors; purely a performance hint -- a
+    convolution marked by mistake only writes a small statistics buffer nobody reads."""
+    from contrastiveseg_amd.lib.models.tools.fused_bn import _FusedMixin
+
+    def first_norm(m):
+        if isinstance(m, _FusedMixin):
+            return True
+        return isinstance(m, nn.Sequential) and len(m) > 0 and first_norm(m[0])
+
+    kinds = (Conv3x3, HeadConv3x3, Conv1x1)
+    for m in module.modules():
+        if isinstance(m, nn.Sequential):
+            kids = list(m)
+            for a, b in zip(kids, kids[1:]):
+                if isinstance(a, kinds) and first_norm(b):
+                    a.bn_follows = True
+        for k in (1, 2, 3):
+            conv, bn = getattr(m, 'conv%d' % k, None), getattr(m, 'bn%d' % k, None)
+            if isinstance(conv, kinds) and isinstance(bn, _FusedMixin):
+                conv.bn_follows = True
+    return module
 
 
 class ModuleHelper(object):

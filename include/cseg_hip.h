@@ -229,6 +229,23 @@ int cseg_bn_bwd_apply_amax(const float* dy, const float* x, const float* mean_in
                            const double* sums, double count, int mask_from_x, int B, int C, int HW, float* dx,
                            unsigned* amax_out, cseg_stream_t stream);
 
+/* Round 4 (ABI 4): BatchNorm statistics from the epilogue of the convolution that produces the tensor (SURVEY.md section 8 f2;
+ * the conv -> bn chains of lib/models/backbones/hrnet/hrnet_backbone.py:49-65, lib/models/tools/module_helper.py:35-39).
+ * The `_st` forms of the split-operand forward convolutions are the plain calls plus `stats`: [Cout][T] float4 = (count, mean,
+ * M2 = sum (y - mean)^2) of every 64-pixel segment of the output, T = cseg_conv_stat_segments(kind, B, H, W) (kind 0: 3x3
+ * kernels, H x W of the OUTPUT; kind 1: 1x1 kernels).  cseg_bn_tiles_finalize replaces cseg_bn_stats_finalize (no pass over
+ * y), cseg_bn_tiles_moments replaces cseg_bn_stats (moments [C+1,2] f64 for the SyncBN exchange). */
+size_t cseg_conv_stat_segments(int kind, int B, int H, int W);
+int cseg_conv3x3_split_fwd_st(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int nt,
+                              int arith, const unsigned* amax_x, const unsigned* amax_w, float* y, float* stats, cseg_stream_t stream);
+int cseg_conv1x1_split_fwd_st(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int HW, int arith,
+                              const unsigned* amax_x, const unsigned* amax_w, float* y, float* stats, cseg_stream_t stream);
+int cseg_conv3x3_s2_split_fwd_st(const float* x, const void* wp, int B, int Cin, int Cout, int Ho, int Wo, int nt,
+                                 const unsigned* amax_x, const unsigned* amax_w, float* y, float* stats, cseg_stream_t stream);
+int cseg_bn_tiles_finalize(const float* stats, int C, long T, float eps, float momentum, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, float* mean_invstd, cseg_stream_t stream);
+int cseg_bn_tiles_moments(const float* stats, int C, long T, double* moments, cseg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * 3x3 / stride 1 / pad 1 convolution, NCHW fp32, forward and backward-data, for the narrow HRNet branches
  * (lib/models/backbones/hrnet/hrnet_backbone.py:35-66 BasicBlock conv1/conv2 -> nn.Conv2d -> MIOpen in the reference;

@@ -200,6 +200,11 @@ def queue_write_pixels(keys, src_img, src_pos, dst_cls, dst_row, pixel_queue):
         pixel_queue[c, r] = F.normalize(feat[b, :, p], p=2, dim=0)
 
 
+def known_tile_stats(t):
+    """The torch restatement has no convolution epilogue: BatchNorm always takes its own statistics pass."""
+    return None
+
+
 # ---- fused (Sync)BatchNorm + residual + ReLU primitives (csrc/bn.hip), torch restatement ------------------------
 # What they restate: nn.BatchNorm2d / nn.SyncBatchNorm training forward+backward (module_helper.py:29-68 of the
 # reference -> torch's batch_norm) followed by the add / ReLU of the residual blocks. Statistics in fp64 like the kernel.

@@ -1,0 +1,106 @@
+"""BatchNorm statistics from the convolution epilogue (csrc/cseg_stats.h) on the CPU emulation of the
+execution model: for every split-operand forward kernel family, the (count, mean, M2) segment records the `_st` entry points write
+must finalise (cseg_bn_tiles_finalize / cseg_bn_tiles_moments) to the same mean / invstd / running statistics / fp64 moments as the
+statistics pass over the stored output (cseg_bn_stats_finalize / cseg_bn_stats) and as torch in fp64 -- ragged shapes included
+(rows % 4 != 0, a last 64-pixel segment that is partly outside the tensor, H*W % 64 != 0) -- and a residual block built on them
+must equal the block with the switch off, forward and backward."""
+import pytest
+import torch
+
+from tests.emu import inject
+
+CASES = [
+    # kind, B, Cin, Cout, H, W, nt, bias
+    ("c3", 2, 48, 48, 6, 96, 0, False),        # conv3x3_sb16p resident, second column tile half empty, rows % 4 = 2
+    ("c3", 1, 96, 96, 5, 64, 0, False),        # conv3x3_sb_kernel<6>
+    ("c3", 1, 64, 64, 4, 68, 0, False),        # conv3x3_sb16 (four channel tiles), 4 valid columns in the last segment
+    ("c3", 1, 192, 192, 3, 32, 3, False),      # streamed weights, explicit tiling, half-empty tiles
+    ("c3", 1, 144, 144, 9, 64, 0x109, True),   # the 8-row head kernel, with bias
+    ("c1", 2, 64, 256, 5, 20, 0, False),       # 1x1: 100 flat pixels per image (one full segment + 36 pixels)
+    ("c1", 1, 48, 144, 8, 64, 0, True),
+    ("s2", 2, 48, 96, 5, 40, 0, False),        # stride 2: output 5 x 40
+]
+
+
+@pytest.mark.parametrize("kind,B,Cin,Cout,H,W,nt,bias", CASES)
+def test_epilogue_statistics_equal_a_pass_over_the_output(kind, B, Cin, Cout, H, W, nt, bias, monkeypatch):
+    from contrastiveseg_amd import kernels as K
+    inject.install(monkeypatch)
+    monkeypatch.setattr(K, "SPLIT_ARITH", "f16x3")
+    monkeypatch.setattr(K, "SPLIT_WEIGHTS", K.SplitWeights())
+    monkeypatch.setattr(K, "CONV_EPILOGUE_STATS", True)
+    g = torch.Generator().manual_seed(11 + Cin + H)
+    k = 1 if kind == "c1" else 3
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (k * k * Cin) ** 0.5
+    bvec = (torch.randn(Cout, generator=g) * 0.5) if bias else None
+    if kind == "s2":
+        x = torch.randn(B, Cin, 2 * H, 2 * W, generator=g) + 0.3
+        y = K.conv3x3_s2_run(x, w, want_stats=True)
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), None, 2, 1)
+    elif kind == "c1":
+        x = torch.randn(B, Cin, H, W, generator=g) + 0.3
+        y = K.conv1x1_sb_run(x, w, False, bvec, want_stats=True)
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), None if bvec is None else bvec.double())
+    else:
+        x = torch.randn(B, Cin, H, W, generator=g) + 0.3
+        y = K.conv3x3_sb_run(x, w, False, bvec, nt, want_stats=True)
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), None if bvec is None else bvec.double(), 1, 1)
+    assert float((y.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+    st = K.known_tile_stats(y)
+    assert st is not None and st.shape[0] == Cout and st.shape[2] == 4
+    n = y.numel() // Cout
+    assert abs(float(st[:, :, 0].sum()) - Cout * n) < 0.5, "segment counts do not add up to the tensor"
+    # finalised statistics vs the statistics pass over y and vs torch fp64 on the stored values
+    rm0, rv0 = torch.randn(Cout, generator=g), torch.rand(Cout, generator=g) + 0.5
+    rm_a, rv_a, nb_a = rm0.clone(), rv0.clone(), torch.tensor(3)
+    rm_b, rv_b, nb_b = rm0.clone(), rv0.clone(), torch.tensor(3)
+    mi_t = K.bn_tiles_finalize(st, 1e-5, 0.1, rm_a, rv_a, nb_a)
+    mi_p = K.bn_stats_finalize(y, 1e-5, 0.1, rm_b, rv_b, nb_b)
+    yd = y.double().transpose(0, 1).reshape(Cout, -1)
+    mean64, var64 = yd.mean(1), yd.var(1, unbiased=False)
+    inv64 = 1.0 / torch.sqrt(var64 + 1e-5)
+    for mi in (mi_t, mi_p):
+        assert float((mi[:, 0].double() - mean64).abs().max()) <= 2e-6 * max(1.0, float(mean64.abs().max()))
+        assert float((mi[:, 1].double() / inv64 - 1).abs().max()) <= 2e-6
+    assert int(nb_a) == int(nb_b) == 4
+    assert float((rm_a - rm_b).abs().max()) <= 1e-6 and float((rv_a - rv_b).abs().max()) <= 1e-6 * float(rv_b.abs().max())
+    mo_t, mo_p = K.bn_tiles_moments(st), K.bn_stats(y)
+    assert mo_t.shape == mo_p.shape == (Cout + 1, 2) and float(mo_t[-1, 0]) == float(mo_p[-1, 0]) == n
+    scale = float(mo_p[:-1].abs().max())
+    assert float((mo_t[:-1] - mo_p[:-1]).abs().max()) <= 2e-6 * scale
+
+
+def test_residual_block_with_epilogue_statistics_equals_the_plain_block(monkeypatch):
+    """BasicBlock (conv -> bn -> relu -> conv -> bn -> + x -> relu, hrnet_backbone.py:49-65 of the reference) with the statistics taken
+    from the convolution epilogues against the same block with CSEG_CONV_STATS off: outputs, running statistics and gradients."""
+    from contrastiveseg_amd import kernels as K
+    from contrastiveseg_amd.lib.models.backbones.hrnet_backbone import BasicBlock
+    from contrastiveseg_amd.lib.models.tools.module_helper import mark_conv_bn_pairs
+    inject.install(monkeypatch)
+    monkeypatch.setattr(K, "SPLIT_ARITH", "f16x3")
+    monkeypatch.setattr(K, "SPLIT_WEIGHTS", K.SplitWeights())
+    monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
+    torch.manual_seed(5)
+    blk = mark_conv_bn_pairs(BasicBlock(48, 48, bn_type="torchbn").train())
+    assert blk.conv1.bn_follows and blk.conv2.bn_follows
+    x0 = torch.randn(2, 48, 6, 64) + 0.2
+    gy = torch.randn(2, 48, 6, 64)
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(K, "CONV_EPILOGUE_STATS", on)
+        for bn in (blk.bn1, blk.bn2):
+            bn.reset_running_stats()
+        calls = []
+        orig = K._hip.call
+        monkeypatch.setattr(K._hip, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+        x = x0.clone().requires_grad_(True)
+        y = blk(x)
+        y.backward(gy)
+        monkeypatch.setattr(K._hip, "call", orig)
+        res[on] = (y.detach(), x.grad.clone(), blk.conv1.weight.grad.clone(), blk.bn2.running_var.clone(), calls)
+        blk.zero_grad()
+    assert "cseg_bn_fwd_amax" in res[False][4] and "cseg_bn_tiles_finalize" not in res[False][4]
+    assert res[True][4].count("cseg_bn_tiles_finalize") == 2 and res[True][4].count("cseg_conv3x3_split_fwd_st") == 2
+    assert "cseg_bn_fwd_amax" not in res[True][4], "a statistics pass ran although the epilogue had the statistics"
+    for a, b in zip(res[False][:4], res[True][:4]):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
