@@ -14,9 +14,11 @@
 // border, rounded and clipped to uint8 like cv2's result) or the raw label with cv2's nearest rule, applies brightness,
 // normalisation and the label look-up, and writes fp32 NCHW / int64 labels: one read of the source, one write of the
 // batch, no intermediate image. HBM-bound (50 MB + 33 MB out at bs8, 1024x512 crops from 2048x1024 sources).
-// Not reproduced bit for bit: cv2 evaluates INTER_CUBIC on uint8 in 11-bit fixed point; here the same weights are
-// applied in fp32 (differences of 1 grey level at most where the two round differently). cv2 is not installed in the
-// build image, so that leg of the parity is unpinned (oracle/aug_oracle.py states it).
+// INTER_CUBIC on uint8 is OpenCV's 11-bit fixed-point rule, restated bit for bit (round 4; oracle/aug_oracle.py has the derivation
+// and what "bit for bit" means without the binary): float coefficients of interpolateCubic (A = -0.75f, the source's operation
+// order, no fused multiply-adds), each rounded half-even to a short at scale 2^11; horizontal and vertical passes in int32;
+// (v + 2^21) >> 22, saturated to [0, 255]. Integer arithmetic after the coefficients: the result does not depend on the
+// evaluation order, so walking the chain backwards per output pixel gives the pixel cv2's two separable passes give.
 #include "cseg_common.h"
 
 namespace {
@@ -26,12 +28,39 @@ struct AugDims {
     float div, mean[3], std[3];
 };
 
-__device__ __forceinline__ void cubic_weights(float t, float (&w)[4]) {
-    const float A = -0.75f;      // OpenCV interpolateCubic
-    w[0] = ((A * (t + 1.f) - 5.f * A) * (t + 1.f) + 8.f * A) * (t + 1.f) - 4.f * A;
-    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
-    w[2] = ((A + 2.f) * (1.f - t) - (A + 3.f)) * (1.f - t) * (1.f - t) + 1.f;
-    w[3] = 1.f - w[0] - w[1] - w[2];
+// Individually rounded float operations. hipcc's default is -ffp-contract=fast, which fuses a product and a sum into one FMA even
+// across statements and inlined calls -- ROCm 7.2's own __fmul_rn / __fadd_rn are plain `x * y` / `x + y` and fuse as well
+// (checked in the gfx950 assembly) -- so the operations are spelled here under `contract(off)`: they carry no `contract` flag and the
+// backend has nothing it may fuse.
+__device__ __forceinline__ float f_mul(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float f_add(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float f_sub(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+
+// OpenCV interpolateCubic (modules/imgproc/src/resize.cpp) in float with the source's operation order, every product and sum rounded
+// on its own, then saturate_cast<short>(c * INTER_RESIZE_COEF_SCALE) with INTER_RESIZE_COEF_BITS = 11 (cvRound: half to even).
+__device__ __forceinline__ void cubic_coeffs_q11(float t, int (&q)[4]) {
+    const float A = -0.75f;
+    const float x1 = f_add(t, 1.f);
+    float c[4];
+    c[0] = f_sub(f_mul(f_add(f_mul(f_sub(f_mul(A, x1), 5.f * A), x1), 8.f * A), x1), 4.f * A);
+    c[1] = f_add(f_mul(f_mul(f_sub(f_mul(A + 2.f, t), A + 3.f), t), t), 1.f);
+    const float u = f_sub(1.f, t);
+    c[2] = f_add(f_mul(f_mul(f_sub(f_mul(A + 2.f, u), A + 3.f), u), u), 1.f);
+    c[3] = f_sub(f_sub(f_sub(1.f, c[0]), c[1]), c[2]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float r = rintf(f_mul(c[k], 2048.f));
+        q[k] = (int)fminf(fmaxf(r, -32768.f), 32767.f);
+    }
 }
 
 __global__ __launch_bounds__(256) void augment_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ lab,
@@ -66,25 +95,26 @@ __global__ __launch_bounds__(256) void augment_kernel(const uint8_t* __restrict_
         const double scx = 1.0 / ((double)Wr / (double)d.Ws), scy = 1.0 / ((double)Hr / (double)d.Hs);
         const float fx = (float)(((double)xr + 0.5) * scx - 0.5), fy = (float)(((double)yr + 0.5) * scy - 0.5);
         const int sx = (int)floorf(fx), sy = (int)floorf(fy);
-        float wx[4], wy[4];
-        cubic_weights(fx - (float)sx, wx);
-        cubic_weights(fy - (float)sy, wy);
-        float acc[3] = {0.f, 0.f, 0.f};
+        int ax[4], ay[4];
+        cubic_coeffs_q11(f_sub(fx, (float)sx), ax);
+        cubic_coeffs_q11(f_sub(fy, (float)sy), ay);
+        int acc[3] = {0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int yy = min(max(sy - 1 + j, 0), d.Hs - 1);
             const uint8_t* row = src + (size_t)yy * d.Ws * 3;
-            float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+            int r0 = 0, r1 = 0, r2 = 0;                      // HResizeCubic<uchar, int, short>: one row of the horizontal pass
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int xx = min(max(sx - 1 + i, 0), d.Ws - 1);
                 const uint8_t* s = row + (size_t)xx * 3;
-                r0 += wx[i] * (float)s[0]; r1 += wx[i] * (float)s[1]; r2 += wx[i] * (float)s[2];
+                r0 += ax[i] * (int)s[0]; r1 += ax[i] * (int)s[1]; r2 += ax[i] * (int)s[2];
             }
-            acc[0] += wy[j] * r0; acc[1] += wy[j] * r1; acc[2] += wy[j] * r2;
+            acc[0] += ay[j] * r0; acc[1] += ay[j] * r1; acc[2] += ay[j] * r2;      // VResizeCubic
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) v[c] = fminf(fmaxf(floorf(acc[c] + 0.5f), 0.f), 255.f);   // uint8 result of cv2
+        for (int c = 0; c < 3; ++c)                          // FixedPtCast<int, uchar, 22>: (v + 2^21) >> 22, saturated
+            v[c] = (float)min(max((acc[c] + (1 << 21)) >> 22, 0), 255);
         // INTER_NEAREST: min(floor(dst * scale), src - 1)
         const int nx = min((int)floor((double)xr * scx), d.Ws - 1), ny = min((int)floor((double)yr * scy), d.Hs - 1);
         ls = lab ? lab[(size_t)b * d.Hs * d.Ws + (size_t)ny * d.Ws + nx] : 255;

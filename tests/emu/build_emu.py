@@ -26,7 +26,7 @@ def _rewrite(text):
 
 
 def _deps():
-    return ([os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "cseg_common.h"),
+    return ([os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + [
             os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "emu_runtime.cpp"), os.path.abspath(__file__),
             os.path.join(ROOT, "include", "cseg_hip.h")])
 

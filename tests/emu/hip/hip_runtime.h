@@ -217,6 +217,10 @@ static inline F emu_atomic_add_fp(F* p, F v) {
 static inline float atomicAdd(float* p, float v) { return emu_atomic_add_fp<float, uint32_t>(p, v); }
 static inline double atomicAdd(double* p, double v) { return emu_atomic_add_fp<double, uint64_t>(p, v); }
 static inline hipError_t hipMemsetAsync(void* p, int value, size_t bytes, hipStream_t) { memset(p, value, bytes); return hipSuccess; }
+// individually rounded float operations (the device intrinsics of the same names forbid FMA contraction)
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 static inline float emu_fast_expf(float x) { return expf(x); }
 static inline float emu_fast_logf(float x) { return logf(x); }
 #define __expf emu_fast_expf          // (glibc's math.h declares functions with these names)

@@ -102,3 +102,35 @@ def test_dequeue_and_enqueue(name, golden_dir):
         assert np.array_equal(pp, g["pixel_ptr_%d" % r])
         assert np.allclose(sq, g["segment_queue_%d" % r], rtol=1e-5, atol=1e-6)
         assert np.allclose(pq, g["pixel_queue_%d" % r], rtol=1e-5, atol=1e-6)
+
+
+# ---- round 4: OpenCV's 11-bit fixed-point INTER_CUBIC on uint8 (oracle/aug_oracle.py; cv2 itself is not installable here) --------
+def test_cubic_fixed_point_known_answers():
+    """Known-answer vectors of the published rule (modules/imgproc/src/resize.cpp): the Q11 coefficient tables at exact fractions
+    (OpenCV's well-known A = -0.75 values), pixels of a 2x upsampling worked out in integers below, a constant image, and the
+    vectorised restatement against the independent scalar one on random images (up- and down-scaling, odd sizes)."""
+    from oracle import aug_oracle as A
+    q = np.rint(A.cubic_coeffs_f32(np.float32([0.0, 0.25, 0.5, 0.75])) * np.float32(2048)).astype(int)
+    assert q.tolist() == [[0, 2048, 0, 0], [-216, 1800, 536, -72], [-192, 1216, 1216, -192], [-72, 536, 1800, -216]]
+    assert (q.sum(1) == 2048).all()
+    # 4 x 4 -> 8 x 4 (width doubled): fx = (d + 0.5) / 2 - 0.5 = -0.25, 0.25, 0.75, 1.25, ...  => (s, t) = (-1, .75), (0, .25), (0, .75), (1, .25) ...
+    row = np.array([0, 10, 20, 30], np.uint8)
+    img = np.repeat(row[None, :, None], 4, axis=0)                       # every row the ramp; the vertical pass is the identity (t = 0)
+    out = A.resize_cubic_u8(img, (8, 4))[:, :, 0]
+    # d = 1: taps S[-1->0], S[0], S[1], S[2] = 0, 0, 10, 20 with (-216, 1800, 536, -72): h = 5360 - 1440 = 3920; v = 3920 * 2048;
+    #        (v + 2^21) >> 22 = (8028160 + 2097152) >> 22 = 2
+    # d = 2: same taps with (-72, 536, 1800, -216): h = 18000 - 4320 = 13680; (13680 * 2048 + 2^21) >> 22 = 7
+    # d = 0: taps S[-2->0], S[-1->0], S[0], S[1] = 0, 0, 0, 10 with (-72, 536, 1800, -216): h = -2160 -> (-4423680 + 2097152) >> 22 = -1 -> 0
+    # d = 7: s = 3, t = .25: taps S[2], S[3], S[4->3], S[5->3] = 20, 30, 30, 30 with (-216, 1800, 536, -72): h = -4320 + 67920 = 63600 -> 31
+    assert out[0].tolist()[:3] == [0, 2, 7] and out[0, 7] == 31 and (out == out[0]).all()
+    assert (3920 * 2048 + (1 << 21)) >> 22 == 2 and (13680 * 2048 + (1 << 21)) >> 22 == 7 and (63600 * 2048 + (1 << 21)) >> 22 == 31
+    assert np.unique(A.resize_cubic_u8(np.full((8, 8, 1), 200, np.uint8), (16, 12))).tolist() == [200]
+    rs = np.random.RandomState(7)
+    img = rs.randint(0, 256, size=(13, 17, 3)).astype(np.uint8)
+    for size in ((34, 26), (9, 7), (20, 13), (17, 29), (5, 40)):
+        assert np.array_equal(A.resize_cubic_u8(img, size), A.resize_cubic_u8_scalar(img, size)), size
+    # overshoot saturates (cubic lobes are negative): a step edge stays inside [0, 255]
+    step = np.zeros((4, 16, 1), np.uint8)
+    step[:, 8:] = 255
+    up = A.resize_cubic_u8(step, (48, 4))
+    assert up.min() == 0 and up.max() == 255
