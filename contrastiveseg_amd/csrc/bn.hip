@@ -542,62 +542,61 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const float* __
 
 // ---------------------------------------------------------------------------------------------------------
 // Statistics that came out of the producing convolution's epilogue (cseg_stats.h): per channel T float4 = (count, mean, M2) of
-// 64-pixel segments. One wave per channel combines them in fp64 (two plain sums: the global mean first, then
-// M2 = sum M2_t + n_t (mean_t - mean)^2 -- Chan et al. with the exact mean), fixed order.
+// 64-pixel segments. One BLOCK per channel turns them into raw fp64 moments in a single pass -- n, sum n_t mean_t,
+// sum (M2_t + n_t mean_t^2) -- and var = m1 / n - mean^2 is then taken in fp64, where the cancellation is harmless (1e-16; the
+// fp32 segment records themselves are mean-centred, so nothing was lost before). Fixed order: deterministic.
+// (First version, GPU call r04j6: one WAVE per channel, two passes of T / 64 dependent 16-byte loads -- 100 us per layer at
+// T = 4096, ten times the statistics pass it replaces; the step got 3 ms slower. Hence a block per channel, loads four deep.)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void tiles_combine(const float4* __restrict__ st, long T, int c, int lane, double& count, double& mean,
-                                              double& m2) {
+__device__ __forceinline__ void tiles_combine(const float4* __restrict__ st, long T, int c, double& count, double& m0, double& m1) {
+    __shared__ double red[3][4];
     const float4* p = st + (size_t)c * T;
-    double n = 0.0, s = 0.0;
-    for (long t = lane; t < T; t += 64) {
+    double n = 0.0, s = 0.0, q = 0.0;
+    long t = threadIdx.x;
+    for (; t + 768 < T; t += 1024) {
+        const float4 v0 = p[t], v1 = p[t + 256], v2 = p[t + 512], v3 = p[t + 768];
+        const double a0 = (double)v0.x * (double)v0.y, a1 = (double)v1.x * (double)v1.y, a2 = (double)v2.x * (double)v2.y,
+                     a3 = (double)v3.x * (double)v3.y;
+        n += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+        s += (a0 + a1) + (a2 + a3);
+        q += (((double)v0.z + a0 * (double)v0.y) + ((double)v1.z + a1 * (double)v1.y)) +
+             (((double)v2.z + a2 * (double)v2.y) + ((double)v3.z + a3 * (double)v3.y));
+    }
+    for (; t < T; t += 256) {
         const float4 v = p[t];
+        const double a = (double)v.x * (double)v.y;
         n += (double)v.x;
-        s += (double)v.x * (double)v.y;
+        s += a;
+        q += (double)v.z + a * (double)v.y;
     }
     n = wave_sum_d(n);
     s = wave_sum_d(s);
-    mean = n > 0.0 ? s / n : 0.0;
-    double q = 0.0;
-    for (long t = lane; t < T; t += 64) {
-        const float4 v = p[t];
-        const double d = (double)v.y - mean;
-        q += (double)v.z + (double)v.x * d * d;
-    }
-    m2 = wave_sum_d(q);
-    count = n;
+    q = wave_sum_d(q);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = n; red[1][threadIdx.x >> 6] = s; red[2][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    count = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    m0 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    m1 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
 }
 
 __global__ __launch_bounds__(256) void bn_tiles_finalize_kernel(const float4* __restrict__ st, long T, int C, float eps, float momentum,
                                                                 float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                                                 float* __restrict__ mean_invstd) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
-    if (c >= C) return;
-    double count, mean, m2;
-    tiles_combine(st, T, c, lane, count, mean, m2);
-    if (lane == 0) {
-        // finalize_channel() takes raw moments; feed it (sum x, sum x^2) rebuilt in fp64: var = m1/n - mean^2 = M2/n exactly enough
-        // at 1e-16 (the cancellation the shifted sums avoid in fp32 does not exist here: M2 was accumulated mean-centred)
-        const double var = count > 0.0 ? m2 / count : 0.0;
-        mean_invstd[2 * c] = (float)mean;
-        mean_invstd[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
-        if (running_mean) {
-            const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
-            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
-            running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
-        }
-    }
+    const int c = blockIdx.x;
+    if (c == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    double count, m0, m1;
+    tiles_combine(st, T, c, count, m0, m1);
+    if (threadIdx.x == 0) finalize_channel(m0, m1, count > 0.0 ? count : 1.0, eps, momentum, running_mean, running_var, c, mean_invstd);
 }
 
 // SyncBN form: the raw fp64 moments [C+1, 2] the exchange all-reduces (row C = this rank's element count)
 __global__ __launch_bounds__(256) void bn_tiles_moments_kernel(const float4* __restrict__ st, long T, int C, double* __restrict__ moments) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= C) return;
-    double count, mean, m2;
-    tiles_combine(st, T, c, lane, count, mean, m2);
-    if (lane == 0) {
-        moments[2 * c] = count * mean;
-        moments[2 * c + 1] = m2 + count * mean * mean;
+    const int c = blockIdx.x;
+    double count, m0, m1;
+    tiles_combine(st, T, c, count, m0, m1);
+    if (threadIdx.x == 0) {
+        moments[2 * c] = m0;
+        moments[2 * c + 1] = m1;
         if (c == 0) { moments[2 * C] = count; moments[2 * C + 1] = 0.0; }
     }
 }
@@ -650,7 +649,7 @@ extern "C" int cseg_bn_tiles_finalize(const float* stats, int C, long T, float e
     CSEG_REQUIRE(stats && mean_invstd && C > 0 && T > 0, "bn_tiles_finalize: bad arguments");
     CSEG_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 15) == 0, "bn_tiles_finalize: the statistics buffer must be 16-byte aligned");
     CSEG_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_tiles_finalize: running_mean/var must come together");
-    hipLaunchKernelGGL(bn_tiles_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream_,
+    hipLaunchKernelGGL(bn_tiles_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream_,
                        reinterpret_cast<const float4*>(stats), T, C, eps, momentum, running_mean, running_var, num_batches_tracked,
                        mean_invstd);
     CSEG_CHECK_LAUNCH("bn_tiles_finalize");
@@ -660,7 +659,7 @@ extern "C" int cseg_bn_tiles_finalize(const float* stats, int C, long T, float e
 extern "C" int cseg_bn_tiles_moments(const float* stats, int C, long T, double* moments, cseg_stream_t stream_) {
     CSEG_REQUIRE(stats && moments && C > 0 && T > 0, "bn_tiles_moments: bad arguments");
     CSEG_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 15) == 0, "bn_tiles_moments: the statistics buffer must be 16-byte aligned");
-    hipLaunchKernelGGL(bn_tiles_moments_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream_,
+    hipLaunchKernelGGL(bn_tiles_moments_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream_,
                        reinterpret_cast<const float4*>(stats), T, C, moments);
     CSEG_CHECK_LAUNCH("bn_tiles_moments");
     return 1;
