@@ -99,9 +99,16 @@ def _fork_streams(device, n):
     return have[:n]
 
 
+import os as _os
+
+# CSEG_BRANCH_STREAMS=1: fork the branches onto side streams in EAGER steps too (experiment: it pays only if the host can feed four
+# queues; default off -- see profiles/r04_branch_streams_ab.txt)
+EAGER_FORKS = _os.environ.get("CSEG_BRANCH_STREAMS", "0") == "1"
+
+
 def _capture_forks():
     from contrastiveseg_amd.segmentor.tools import step_graph
-    return step_graph.capturing() and step_graph.BRANCH_STREAMS
+    return EAGER_FORKS or (step_graph.capturing() and step_graph.BRANCH_STREAMS)
 
 
 class HighResolutionModule(nn.Module):
