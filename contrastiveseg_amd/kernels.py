@@ -672,18 +672,34 @@ def split_arith_id():
 
 
 AMAX_WORDS = 1024        # CSEG_AMAX_WORDS of include/cseg_hip.h: 32 slots, 128 bytes apart
-_AMAX_ARENAS = {}        # device -> [arena int32 [2048 x AMAX_WORDS] (zeroed once), next free record]
+AMAX_ARENA_RECORDS = 2048
+_AMAX_ARENAS = {}        # device -> [arena int32 [AMAX_ARENA_RECORDS x AMAX_WORDS] (zeroed once), next free record, zero-fill event, streams that waited for it]
 
 
 def amax_slot(device):
     """A zeroed max|.| record on the device (include/cseg_hip.h: CSEG_AMAX_WORDS uint32): a view into an arena that is zero-filled
     once per 2048 records, so that a maximum costs ONE launch, not a fill + a launch. Records are not recycled: a used arena
-    lives as long as a view of it."""
+    lives as long as a view of it.
+    Streams: the zero fill runs on whatever stream is current when an arena is started, and the records are handed to kernels on
+    ANY stream (the forked HRNet branches, the mining side stream, the autograd engine's replay of those forks). Every stream
+    therefore waits ONCE per arena for the fill's event before it takes its first record from it (round 4: with the branches on
+    four streams an arena switch in the middle of a fork let three of them accumulate into records that were zeroed afterwards --
+    the step's loss moved in the second digit, run to run)."""
     key = (device.type, device.index)
     st = _AMAX_ARENAS.get(key)
     if st is None or st[1] >= st[0].shape[0]:
-        st = [torch.zeros(2048, AMAX_WORDS, dtype=I32, device=device), 0]
+        arena = torch.zeros(AMAX_ARENA_RECORDS, AMAX_WORDS, dtype=I32, device=device)
+        ev = None
+        if device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+        st = [arena, 0, ev, {_hip.raw_stream()} if ev is not None else None]
         _AMAX_ARENAS[key] = st
+    if st[2] is not None:
+        sid = _hip.raw_stream()
+        if sid not in st[3]:
+            torch.cuda.current_stream(device).wait_event(st[2])
+            st[3].add(sid)
     i = st[1]
     st[1] = i + 1
     return st[0][i]

@@ -65,7 +65,14 @@ class _SparseTail(torch.autograd.Function):
             u, gamma, beta, None, bn.running_mean if track else None, bn.running_var if track else None,
             bn.num_batches_tracked if (track and bn.training) else None, training, True, float(bn.momentum),
             float(bn.eps), group)
-        e = F.normalize(F.conv2d(a, w2, b2), p=2, dim=1, eps=_EPS)
+        # proj.2 (720 -> 256 at 1/4 resolution: 97 GFLOP at batch 8) on the split-operand 1x1 kernel where it applies (rocBLAS fp32:
+        # 0.59 ms in the round-4 trace), else MIOpen / rocBLAS
+        if (_switches.CONV1X1_SPLIT_BF16 and _switches._on_device(a) and _switches.conv1x1_sb_eligible(a, w2)
+                and _switches.conv1x1_sb_tiles(a, w2.shape[0]) >= _switches.CONV1X1_SB_MIN_TILES):
+            z = K.conv1x1_sb_run(a, w2, False, b2, ax=_switches.known_amax(a))
+        else:
+            z = F.conv2d(a, w2, b2)
+        e = F.normalize(z, p=2, dim=1, eps=_EPS)
         ctx.save_for_backward(u, mi, gamma, beta, w2, b2)
         ctx.meta = (training, count, group)
         ctx.slot = slot

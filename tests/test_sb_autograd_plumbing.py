@@ -12,7 +12,7 @@ from contrastiveseg_amd import kernels as K
 def cpu_entry_points(monkeypatch):
     calls = []
 
-    def sb3(x, w, transpose_flip=False, bias=None, nt=0, ax=None):
+    def sb3(x, w, transpose_flip=False, bias=None, nt=0, ax=None, addend=None, want_stats=False):
         calls.append(("sb3", bool(transpose_flip), bias is not None, nt))
         return F.conv_transpose2d(x, w, None, 1, 1) if transpose_flip else F.conv2d(x, w, bias, 1, 1)
 
@@ -20,7 +20,7 @@ def cpu_entry_points(monkeypatch):
         calls.append(("wrw3",))
         return torch.nn.grad.conv2d_weight(x, (dy.shape[1], x.shape[1], 3, 3), dy, padding=1)
 
-    def sb1(x, w, transpose=False, bias=None, ax=None):
+    def sb1(x, w, transpose=False, bias=None, ax=None, want_stats=False):
         calls.append(("sb1", bool(transpose), bias is not None))
         return F.conv_transpose2d(x, w) if transpose else F.conv2d(x, w, bias)
 
