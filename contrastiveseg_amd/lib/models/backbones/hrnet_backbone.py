@@ -101,14 +101,19 @@ def _fork_streams(device, n):
 
 import os as _os
 
-# CSEG_BRANCH_STREAMS=1: fork the branches onto side streams in EAGER steps too (experiment: it pays only if the host can feed four
-# queues; default off -- see profiles/r04_branch_streams_ab.txt)
-EAGER_FORKS = _os.environ.get("CSEG_BRANCH_STREAMS", "0") == "1"
+# Forked branches / exchange paths in EAGER steps too (default on; CSEG_BRANCH_STREAMS=0 = one stream). One host thread can feed the
+# four queues because the kernels of a batch-8 step are long: measured on the MI355X (profiles/r04_branch_streams_ab.txt) 96.7-100.7 ms
+# per step on one stream against 89.7-95.7 with the branches forked, same losses. Only on the GPU (there are no streams elsewhere).
+EAGER_FORKS = _os.environ.get("CSEG_BRANCH_STREAMS", "1") == "1"
 
 
-def _capture_forks():
+def _capture_forks(x=None):
     from contrastiveseg_amd.segmentor.tools import step_graph
-    return EAGER_FORKS or (step_graph.capturing() and step_graph.BRANCH_STREAMS)
+    if x is not None and not x.is_cuda:
+        return False
+    if step_graph.capturing():
+        return step_graph.BRANCH_STREAMS
+    return EAGER_FORKS
 
 
 class HighResolutionModule(nn.Module):
@@ -197,11 +202,39 @@ class HighResolutionModule(nn.Module):
             outs[i + 1].record_stream(cur)            # allocated on the side stream, read by the exchange unit on `cur`
         return outs
 
+    def _exchange_forked(self, x):
+        """The exchange unit with one stream per OUTPUT resolution (see _branches_forked): output i's incoming paths -- 1x1 conv + BN
+        from the coarser branches, chains of stride-2 convolutions from the finer ones -- and its fused sum run on stream i; the paths
+        of different outputs share nothing but their inputs. These are the small launches of the step (<= 256 blocks each)."""
+        import torch
+        cur = torch.cuda.current_stream(x[0].device)
+        streams = _fork_streams(x[0].device, len(self.fuse_layers) - 1)
+
+        def row_out(i):
+            row = self.fuse_layers[i]
+            same = [x[j] if j == i else row[j](x[j]) for j in range(i + 1)]
+            low = [row[j](x[j]) for j in range(i + 1, self.num_branches)]
+            return K.fuse_sum_relu(same, low)
+
+        outs = [None] * len(self.fuse_layers)
+        for i in range(1, len(self.fuse_layers)):
+            s = streams[i - 1]
+            s.wait_stream(cur)
+            for xj in x:
+                xj.record_stream(s)                   # every output reads every branch
+            with torch.cuda.stream(s):
+                outs[i] = row_out(i)
+        outs[0] = row_out(0)
+        for i, s in enumerate(streams):
+            cur.wait_stream(s)
+            outs[i + 1].record_stream(cur)
+        return outs
+
     def forward(self, x):
         sync = self._sync_active()
         if sync and self.num_branches > 1:
             x = self._branches_lockstep(x)
-        elif self.num_branches > 1 and _capture_forks():
+        elif self.num_branches > 1 and _capture_forks(x[0]):
             x = self._branches_forked(x)
         else:
             x = [branch(xi) for branch, xi in zip(self.branches, x)]
@@ -209,6 +242,8 @@ class HighResolutionModule(nn.Module):
             return x
         if sync:
             return self._exchange_lockstep(x)
+        if _capture_forks(x[0]) and len(self.fuse_layers) > 1:
+            return self._exchange_forked(x)
         outs = []
         for i, row in enumerate(self.fuse_layers):
             same = [x[j] if j == i else row[j](x[j]) for j in range(i + 1)]     # finer branches arrive strided

@@ -110,8 +110,10 @@ def test_oracle_resampling_rules():
     lab = np.arange(6 * 4).reshape(6, 4).astype(np.uint8)
     up = A.resize_nearest(lab, (8, 12))
     assert up.shape == (12, 8) and np.array_equal(up[::2, ::2], lab)
-    w = A.cubic_weights(np.linspace(0, 1, 11))
-    assert np.allclose(w.sum(-1), 1.0)
+    w = A.cubic_coeffs_f32(np.linspace(0, 1, 11).astype(np.float32))
+    assert np.allclose(w.sum(-1), 1.0, atol=1e-6)
+    q = np.rint(w * np.float32(A.COEF_SCALE)).astype(int)           # the Q11 tables OpenCV's 8-bit path works with
+    assert (np.abs(q.sum(-1) - A.COEF_SCALE) <= 1).all()
 
 
 def make_folder_dataset(tmp_path, ids, rs):
