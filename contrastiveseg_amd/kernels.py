@@ -793,6 +793,60 @@ def bn_tiles_moments(stats):
     return moments
 
 
+# ----------------------------------------------------------------------------------------------------------
+# Weight gradients off the critical path (round 4). In backward, dx of a convolution feeds the next node of the chain; dw feeds
+# nothing until the optimizer runs. With `wgrad_scope` active (Trainer.train_step opens it around loss.backward() on single-rank
+# GPU runs) the split-operand weight-gradient kernels go to ONE side stream: it waits for the stream of the backward node (dy and
+# the max|.| words are ready there), and the trainer joins it before the optimizer step. MFMA-bound weight gradients then share the
+# chip with the HBM-bound BatchNorm passes and small backward-data launches of the chain instead of queueing between them.
+# Off outside the scope (a caller that reads .grad right after backward() would not know about the side stream), while a hipGraph
+# is being captured, and under DDP (its reducer copies gradients on the backward stream as they appear).
+# ----------------------------------------------------------------------------------------------------------
+WGRAD_STREAM = os.environ.get("CSEG_WGRAD_STREAM", "1") == "1"
+_WGRAD = {"on": False, "stream": None, "main": None, "used": False}
+
+
+class wgrad_scope(object):
+    """with kernels.wgrad_scope(device): loss.backward()   -- joins the weight-gradient stream on exit."""
+
+    def __init__(self, device):
+        self.active = bool(WGRAD_STREAM and device is not None and device.type == "cuda"
+                           and not (torch.distributed.is_available() and torch.distributed.is_initialized()))
+        self.device = device
+
+    def __enter__(self):
+        if self.active:
+            if _WGRAD["stream"] is None or _WGRAD["stream"].device != self.device:
+                _WGRAD["stream"] = torch.cuda.Stream(device=self.device)
+            _WGRAD.update(on=True, main=torch.cuda.current_stream(self.device), used=False)
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            _WGRAD["on"] = False
+            if _WGRAD["used"]:
+                _WGRAD["main"].wait_stream(_WGRAD["stream"])
+        return False
+
+
+def _on_wgrad_stream(fn, *inputs):
+    """fn() -> one tensor (a weight gradient). Runs it on the weight-gradient stream when the scope is open; `inputs` are the
+    tensors it reads (kept from being recycled until that stream is done with them)."""
+    if not _WGRAD["on"] or not inputs[0].is_cuda or torch.cuda.is_current_stream_capturing():
+        return fn()
+    cur = torch.cuda.current_stream(inputs[0].device)
+    side = _WGRAD["stream"]
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        out = fn()
+    for t in inputs:
+        if t is not None:
+            t.record_stream(side)
+    out.record_stream(_WGRAD["main"])        # read by the optimizer on the trainer's stream, after wgrad_scope joined the side stream
+    _WGRAD["used"] = True
+    return out
+
+
 import weakref
 
 import numpy as np
@@ -1168,7 +1222,8 @@ class Conv3x3SplitBF16(Function):
         if ctx.needs_input_grad[1] or want_db:
             co, ci = weight.shape[:2]
             if conv3x3_sb_wrw_wanted(x, dy):
-                dw = conv3x3_sb_wrw(x, dy, ax=ctx.ax, ady=ady) if ctx.needs_input_grad[1] else None
+                dw = _on_wgrad_stream(lambda: conv3x3_sb_wrw(x, dy, ax=ctx.ax, ady=ady), x, dy, ctx.ax, ady) \
+                    if ctx.needs_input_grad[1] else None
                 db = dy.sum((0, 2, 3)) if want_db else None
             elif not ctx.has_bias and co == ci and co in CONV3X3_WRW_CHANNELS:
                 dw = _conv3x3_wrw(x, dy, co, ci)
@@ -1212,7 +1267,7 @@ class Conv3x3SplitFork(Function):
         if ctx.needs_input_grad[1]:
             co, ci = weight.shape[:2]
             if conv3x3_sb_wrw_wanted(x, dy):
-                dw = conv3x3_sb_wrw(x, dy, ax=ctx.ax, ady=ady)
+                dw = _on_wgrad_stream(lambda: conv3x3_sb_wrw(x, dy, ax=ctx.ax, ady=ady), x, dy, ctx.ax, ady)
             elif co == ci and co in CONV3X3_WRW_CHANNELS:
                 dw = _conv3x3_wrw(x, dy, co, ci)
             else:
@@ -1342,7 +1397,7 @@ class Conv3x3S2Split(Function):
         if need_dx and conv3x3_s2_bwd_eligible(x, weight):
             dx = conv3x3_s2_bwd_run(dy, weight, ady=ady)
         if need_dw and conv3x3_s2_wrw_eligible(x, weight):
-            dw = conv3x3_s2_wrw(x, dy, ax=ctx.ax, ady=ady)
+            dw = _on_wgrad_stream(lambda: conv3x3_s2_wrw(x, dy, ax=ctx.ax, ady=ady), x, dy, ctx.ax, ady)
         rest = [need_dx and dx is None, need_dw and dw is None, False]
         if rest[0] or rest[1]:
             gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, rest)
@@ -1458,7 +1513,8 @@ class Conv1x1SplitBF16(Function):
         dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if conv1x1_sb_wrw_wanted(x, dy):
-            dw = conv1x1_sb_wrw(x, dy, ax=ctx.ax, ady=ady) if ctx.needs_input_grad[1] else None
+            dw = _on_wgrad_stream(lambda: conv1x1_sb_wrw(x, dy, ax=ctx.ax, ady=ady), x, dy, ctx.ax, ady) \
+                if ctx.needs_input_grad[1] else None
             db = dy.sum((0, 2, 3)) if want_db else None
         elif ctx.needs_input_grad[1] or want_db:
             _, dw, db = torch.ops.aten.convolution_backward(

@@ -280,7 +280,8 @@ class Trainer(object):
 
         t0 = time.time()
         self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        with K.wgrad_scope(loss.device):          # weight gradients on a side stream, joined before the optimizer (kernels.py)
+            loss.backward()
         if self.with_memory and 'key' in outputs and 'lb_key' in outputs:
             # The reference enqueues between the loss and backward (:246-251); its loss holds a torch.cat COPY of the
             # bank, so its gradient is that of the bank as it was during the forward. Here cseg_contrast_bwd re-reads

@@ -200,6 +200,19 @@ def queue_write_pixels(keys, src_img, src_pos, dst_cls, dst_row, pixel_queue):
         pixel_queue[c, r] = F.normalize(feat[b, :, p], p=2, dim=0)
 
 
+class wgrad_scope(object):
+    """kernels.wgrad_scope on the CPU: nothing to fork."""
+
+    def __init__(self, device):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 def known_tile_stats(t):
     """The torch restatement has no convolution epilogue: BatchNorm always takes its own statistics pass."""
     return None
