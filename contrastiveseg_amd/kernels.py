@@ -690,7 +690,9 @@ def amax_slot(device):
     if st is None or st[1] >= st[0].shape[0]:
         arena = torch.zeros(AMAX_ARENA_RECORDS, AMAX_WORDS, dtype=I32, device=device)
         ev = None
-        if device.type == "cuda":
+        # (not while a hipGraph is being captured: the capture starts its arena on the capturing stream before any fork, and every
+        # forked stream joins the capture by waiting for that stream -- the fill is ordered before them by the graph's own edges)
+        if device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(device))
         st = [arena, 0, ev, {_hip.raw_stream()} if ev is not None else None]
