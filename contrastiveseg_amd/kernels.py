@@ -803,8 +803,11 @@ def bn_tiles_moments(stats):
 # chip with the HBM-bound BatchNorm passes and small backward-data launches of the chain instead of queueing between them.
 # Off outside the scope (a caller that reads .grad right after backward() would not know about the side stream), while a hipGraph
 # is being captured, and under DDP (its reducer copies gradients on the backward stream as they appear).
+# MEASURED (GPU call r04j11, profiles/r04_branch_streams_ab.txt): with the branches already forked this stream makes the step SLOWER
+# (91.1 / 89.6 ms with it, 88.7 / 86.6 without: the weight gradients then compete with the chain for the same CUs instead of
+# filling holes) -- so it is an opt-in experiment (CSEG_WGRAD_STREAM=1), gradients verified equal by tests/test_gpu_streams.py.
 # ----------------------------------------------------------------------------------------------------------
-WGRAD_STREAM = os.environ.get("CSEG_WGRAD_STREAM", "1") == "1"
+WGRAD_STREAM = os.environ.get("CSEG_WGRAD_STREAM", "0") == "1"
 _WGRAD = {"on": False, "stream": None, "main": None, "used": False}
 
 

@@ -94,18 +94,19 @@ def test_graph_replay_equals_eager_steps(model, backbone, loss, cfg_file, contra
     le, le2, lg = (np.array(runs[k][0]) for k in ("eager", "eager2", "graph"))
     assert np.isfinite(le).all() and np.isfinite(lg).all()
     assert abs(le[0] - lg[0]) <= 2e-6 * abs(le[0]), (le[0], lg[0])          # the first forward: same weights, same kernels
-    assert abs(le[1] - lg[1]) <= 2e-5 * abs(le[1]), (le[1], lg[1])          # after ONE update from (nearly) the same gradients
     # every parameter the eager step gives a gradient gets one from the replay, equal to rounding (one backward: no amplification yet)
     ge, ge2, gg = runs["eager"][1], runs["eager2"][1], runs["graph"][1]
     assert set(ge) == set(gg), sorted(set(ge) ^ set(gg))[:5]
     gnorm = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in ge.values()))
-    worst = ("", 0.0, 0.0)
+    devs = []
     for k, a in ge.items():
         den = max(float(np.linalg.norm(a)), 1e-6 * gnorm)
-        dev, own = float(np.linalg.norm(a - gg[k])) / den, float(np.linalg.norm(a - ge2[k])) / den
-        if dev > worst[1]:
-            worst = (k, dev, own)
-        assert dev <= max(4.0 * own, 2e-4), ("grad " + k, dev, own)
+        devs.append((float(np.linalg.norm(a - gg[k])) / den, float(np.linalg.norm(a - ge2[k])) / den, k))
+    devs.sort(reverse=True)
+    worst = (devs[0][2], devs[0][0], devs[0][1])
+    bad = [(k, "%.2e" % d, "%.2e" % o) for d, o, k in devs if d > max(4.0 * o, 2e-4)]
+    assert not bad, ("gradients of the replay differ from the eager ones", len(bad), bad[:8], le.tolist(), le2.tolist(), lg.tolist())
+    assert abs(le[1] - lg[1]) <= 2e-5 * abs(le[1]), (le.tolist(), le2.tolist(), lg.tolist())   # after ONE update from the same gradients
     for k, a in runs["eager"][2].items():
         b = runs["graph"][2][k]
         scale = max(float(np.abs(a).max()), 1e-3)          # (a conv bias in front of a BN moves by lr x rounding noise only)
