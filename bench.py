@@ -533,7 +533,7 @@ def cpu_baseline_worker():
     """CPU port of the train step (model classes of this repo on CPU, device half = oracle/cpu_port.py).
     Runs in its own process (bench.py --cpu-baseline-worker) so that a slow host can be cut off by a timeout.
     Sample: the BASELINE batch of 8 images per step when the host has the memory for it (the reference needs ~34 GB RSS
-    at bs8), otherwise 2 images per step; 1 warm-up + 2 (bs8: 1) timed steps."""
+    at bs8), otherwise 2 images per step; 1 warm-up + 2 timed steps."""
     from oracle import cpu_port
     from contrastiveseg_amd.lib.utils.tools.configer import Configer
     from contrastiveseg_amd.segmentor.tools.data_helper import SyntheticLoader
@@ -561,18 +561,19 @@ def cpu_baseline_worker():
     tr.pixel_loss.cpu()
     batch = next(iter(SyntheticLoader(cfg, torch.device("cpu"), length=1, seed=304, mode="uniform")))
     tr.train_step(batch)                       # warm-up
-    n = 1 if batch_size == 8 else 2
+    n = 2                                      # >= 2 timed steps, also at the BASELINE batch of 8 (~42 s each)
     t0 = time.time()
     for _ in range(n):
         tr.train_step(batch)
     dt = (time.time() - t0) / n
     print("CPU_BASELINE " + json.dumps({
         "value": round(batch_size / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-        "sample": "%d images 3x512x1024 per step (BASELINE batch is 8), fwd+criterion+bwd+SGD, 1 warm-up + %d timed "
-                  "step(s), fp32, %.2f s/step, host RAM available %.0f GB" % (batch_size, n, dt, avail_gb)}))
+        "sample": "%d images/step (BASELINE bs 8), 1 warm-up + %d timed steps, fp32, %.1f s/step; port pinned to the reference by "
+                  "tests/test_step_golden.py::test_sgd_step_cpu_port_matches_reference" % (batch_size, n, dt),
+        "host_ram_gb": round(avail_gb)}))
 
 
-def cpu_baseline(timeout_s=300):
+def cpu_baseline(timeout_s=420):
     import subprocess
     env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
     try:
