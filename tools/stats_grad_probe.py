@@ -20,7 +20,11 @@ def run(stats, case):
     hooks = []
     for name, m in tr.seg_net.named_modules():
         if name.endswith(("bn1", "bn2", "bn3")) or name.split(".")[-1].isdigit():
-            hooks.append(m.register_forward_hook(lambda mod, inp, out, name=name: acts.setdefault(name, out.detach().float().cpu().numpy().copy()) if torch.is_tensor(out) else None))
+            def hook(mod, inp, out, name=name):
+                if torch.is_tensor(out) and name not in acts:
+                    acts[name] = out.detach().float().cpu().numpy().copy()
+                return None
+            hooks.append(m.register_forward_hook(hook))
     l0 = float(tr.train_step(data))
     torch.cuda.synchronize()
     for h in hooks:
