@@ -27,6 +27,14 @@ def _on_device(t):
     return t.is_cuda
 
 
+def _pq(t, what):
+    """Raw pointer of an fp32 operand of a hot entry point: one combined test on the fast path (device, dtype, layout), the full
+    _hip.dev() diagnosis only when it fails. (1.2 -> 0.5 us per operand, ~3 000 operands per batch-8 step.)"""
+    if t.dtype == F32 and t.is_contiguous() and _on_device(t) and (not t.is_cuda or t.device.index == _hip._raw_device()):
+        return ctypes.c_void_p(t.data_ptr())
+    return _hip.dev(t, F32, what)
+
+
 def _pf(t):
     """Raw pointer of a tensor this module has just allocated itself (device, dtype and layout known by construction):
     skips the four checks of _hip.dev(). The step issues ~1000 calls into the BN / convolution entry points and is
@@ -34,6 +42,9 @@ def _pf(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+# Host cost: the functions of this module that only allocate outputs and call the library (the BN and convolution entry points) carry
+# no @torch.no_grad(): they are reached from inside autograd Functions, where recording is off already, they use no differentiable torch
+# op, and the decorator's context object was 4 ms of host time per batch-8 step (3 400 entries, tools/host_profile.py, round 4).
 # ----------------------------------------------------------------------------------------------------------
 # anchor mining
 # ----------------------------------------------------------------------------------------------------------
@@ -501,7 +512,6 @@ def _bn_ws(B, C, HW, device):
     return buf
 
 
-@torch.no_grad()
 def bn_stats(x):
     """-> moments [C+1,2] f64: rows 0..C-1 = (sum x, sum x^2) over this rank's values, row C = (this rank's element count per
     channel, 0) -- the tensor a SyncBN exchange all-reduces; the summed row C is the global count (bn_finalize with count 0)."""
@@ -512,7 +522,6 @@ def bn_stats(x):
     return moments
 
 
-@torch.no_grad()
 def bn_finalize(moments, count, eps, momentum, running_mean, running_var, num_batches_tracked):
     """(global) moments [C+1,2] -> mean_invstd [C,2] f32; running statistics / batch counter updated in place. count 0 = read the
     exchanged count from row C on the device (no host round trip, unequal per-rank batches allowed)."""
@@ -524,7 +533,6 @@ def bn_finalize(moments, count, eps, momentum, running_mean, running_var, num_ba
     return mi
 
 
-@torch.no_grad()
 def bn_stats_finalize(x, eps, momentum, running_mean, running_var, num_batches_tracked):
     """Single-rank bn_stats + bn_finalize in two launches."""
     B, C, HW = _bn_dims(x)
@@ -536,18 +544,16 @@ def bn_stats_finalize(x, eps, momentum, running_mean, running_var, num_batches_t
     return mi
 
 
-@torch.no_grad()
 def bn_apply(x, mean_invstd, weight, bias, residual, relu, amax=None):
     """amax: zeroed word (amax_request) that receives max|y|."""
     B, C, HW = _bn_dims(x)
     y = torch.empty_like(x)
-    _hip.call("cseg_bn_apply_amax", _p(x, F32, "x"), _opt(residual, F32, "residual"), _p(mean_invstd, F32, "mean_invstd"),
+    _hip.call("cseg_bn_apply_amax", _pq(x, "x"), _pq(residual, "residual") if residual is not None else _null(), _pf(mean_invstd),
               _opt(weight, F32, "weight"), _opt(bias, F32, "bias"), int(bool(relu)), B, C, HW, _p(y, F32, "y"),
               _pf(amax) if amax is not None else _null(), _hip.stream_ptr())
     return y
 
 
-@torch.no_grad()
 def bn_bwd_reduce(dy, x, out, mean_invstd, weight, bias, mode):
     """-> (sums [C+1,2] f64 (row C = this rank's element count, 0), d_weight [C], d_bias [C], g_masked or None).
     mode: 0 none | 1 ReLU mask from x | 2 from out."""
@@ -564,7 +570,6 @@ def bn_bwd_reduce(dy, x, out, mean_invstd, weight, bias, mode):
     return sums, d_weight, d_bias, g
 
 
-@torch.no_grad()
 def bn_bwd_apply(dy, x, mean_invstd, weight, bias, sums, count, mask_from_x, amax=None):
     """sums None = frozen statistics (eval mode); count 0 = the exchanged count in row C of `sums`. amax: zeroed word that
     receives max|dx|."""
@@ -707,7 +712,6 @@ def amax_slot(device):
     return st[0][i]
 
 
-@torch.no_grad()
 def tensor_amax(t, slot=None):
     """max|t| as the split kernels take it: a device record (amax_slot) whose maximum word is the bit pattern of that float.
     `slot`: accumulate into an existing record (max over several tensors)."""
@@ -775,7 +779,6 @@ def known_tile_stats(t):
     return a[0] if (a is not None and a[1] == t._version) else None
 
 
-@torch.no_grad()
 def bn_tiles_finalize(stats, eps, momentum, running_mean, running_var, num_batches_tracked):
     """Epilogue statistics [C, T, 4] -> mean_invstd [C,2]; running statistics / batch counter updated like bn_stats_finalize."""
     C, T = stats.shape[0], stats.shape[1]
@@ -786,7 +789,6 @@ def bn_tiles_finalize(stats, eps, momentum, running_mean, running_var, num_batch
     return mi
 
 
-@torch.no_grad()
 def bn_tiles_moments(stats):
     """Epilogue statistics [C, T, 4] -> moments [C+1,2] f64 (what bn_stats returns: the tensor a SyncBN exchange all-reduces)."""
     C, T = stats.shape[0], stats.shape[1]
@@ -1094,7 +1096,6 @@ def conv3x3_sb_pick_nt(x, c_out):
     return cands[-1]
 
 
-@torch.no_grad()
 def conv3x3_sb_pack(weight, transpose_flip=False, nt=0):
     """-> (wp uint8 [...], aw): weight split + packed for the forward (or, transpose_flip, the backward-data) operator in the
     current arithmetic; aw = max|w| record (None with bf16x6). Kept fresh by SplitWeights: one batched launch per optimizer step
@@ -1102,7 +1103,6 @@ def conv3x3_sb_pack(weight, transpose_flip=False, nt=0):
     return SPLIT_WEIGHTS.get(weight, "c3", transpose_flip, nt)
 
 
-@torch.no_grad()
 def conv3x3_sb_run(x, weight, transpose_flip=False, bias=None, nt=0, ax=None, addend=None, want_stats=False):
     """y = conv2d(x, weight, bias, 1, 1) (transpose_flip: the backward-data operator of that convolution applied to x)
     through the split-operand MFMA kernel. nt = 0: the library's default channel tiling; 3 / 6 / 9: explicit. ax: max|x| word
@@ -1119,16 +1119,16 @@ def conv3x3_sb_run(x, weight, transpose_flip=False, bias=None, nt=0, ax=None, ad
     if addend is not None:
         if tuple(addend.shape) != tuple(y.shape):
             raise RuntimeError("conv3x3_sb_run: addend %s does not have the output's shape %s" % (tuple(addend.shape), tuple(y.shape)))
-        _hip.call("cseg_conv3x3_split_fwd_add", _p(x, F32, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), _p(addend, F32, "addend"), B,
+        _hip.call("cseg_conv3x3_split_fwd_add", _pq(x, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), _p(addend, F32, "addend"), B,
                   conv_in, conv_out, H, W, int(nt), arith, _pf(ax) if arith else _null(), _pf(aw) if arith else _null(), _pf(y),
                   _hip.stream_ptr())
         return y
     if want_stats and CONV_EPILOGUE_STATS:
         st = tile_stats_buffer(0, conv_out, B, H, W, x.device)
-        _hip.call("cseg_conv3x3_split_fwd_st", _p(x, F32, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H, W,
+        _hip.call("cseg_conv3x3_split_fwd_st", _pq(x, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H, W,
                   int(nt), arith, _pf(ax) if arith else _null(), _pf(aw) if arith else _null(), _pf(y), _pf(st), _hip.stream_ptr())
         return tile_stats_attach(y, st)
-    _hip.call("cseg_conv3x3_split_fwd", _p(x, F32, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H, W,
+    _hip.call("cseg_conv3x3_split_fwd", _pq(x, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H, W,
               int(nt), arith, _pf(ax) if arith else _null(), _pf(aw) if arith else _null(), _pf(y), _hip.stream_ptr())
     return y
 
@@ -1176,7 +1176,6 @@ def conv3x3_sb_wrw_wanted(x, dy):
     return CONV3X3_SB_WRW and (same or (x.shape[1], dy.shape[1]) in CONV3X3_SB_WRW_PAIRS) and conv3x3_sb_wrw_eligible(x, dy)
 
 
-@torch.no_grad()
 def conv3x3_sb_wrw(x, dy, ax=None, ady=None):
     """dw [Cout,Cin,3,3] of conv2d(x, w, stride 1, padding 1) for the output gradient dy, split-operand MFMA kernel. ax / ady:
     max|x| / max|dy| words when the caller has them (the forward / backward-data calls of the same layer computed both)."""
@@ -1192,7 +1191,7 @@ def conv3x3_sb_wrw(x, dy, ax=None, ady=None):
         ady = tensor_amax(dy) if ady is None else ady
     ws = torch.empty(n, dtype=F32, device=x.device)
     dw = torch.empty(co, ci, 3, 3, dtype=F32, device=x.device)
-    _hip.call("cseg_conv3x3_split_wrw", _p(x, F32, "x"), _p(dy, F32, "dy"), B, ci, co, H, W, arith,
+    _hip.call("cseg_conv3x3_split_wrw", _pq(x, "x"), _pq(dy, "dy"), B, ci, co, H, W, arith,
               _pf(ax) if arith else _null(), _pf(ady) if arith else _null(), _pf(ws), _pf(dw), _hip.stream_ptr())
     return dw
 
@@ -1284,6 +1283,83 @@ class Conv3x3SplitFork(Function):
 CONV3X3_FORK = os.environ.get("CSEG_CONV3X3_FORK", "1") == "1"
 
 
+# ----------------------------------------------------------------------------------------------------------
+# A whole residual block as ONE autograd node (round 4). Reference shape of the work: BasicBlock.forward of
+# lib/models/backbones/hrnet/hrnet_backbone.py:49-65 (conv3x3 -> bn -> relu -> conv3x3 -> bn -> + x -> relu), 104 of them per
+# HRNet-W48 step. The kernels are exactly those of the four nodes it replaces (Conv3x3SplitFork, _BNAct, Conv3x3SplitBF16, _BNAct:
+# same calls, same order, same max|.| and statistics hand-overs); what goes away is host work: three of four Function.apply round
+# trips and their module __call__ layers per direction -- the batch-8 step had become HOST-bound once the branches ran on forked
+# streams (tools/host_profile.py: 91 ms of enqueue time for a ~88 ms step).
+# ----------------------------------------------------------------------------------------------------------
+BLOCK_FUSED = os.environ.get("CSEG_BLOCK_FUSED", "1") == "1"
+
+
+def basic_block_split_ok(x, w1, w2):
+    """Both convolutions on the split kernels in all three directions (forward / backward-data / weight gradient), as the unfused
+    path would route them at this shape."""
+    c = w1.shape[0]
+    return (BLOCK_FUSED and CONV3X3_FORK and CONV3X3_SPLIT_BF16 and CONV3X3_SB_WRW and _on_device(x) and x.requires_grad
+            and tuple(w1.shape) == tuple(w2.shape) == (c, c, 3, 3) and c in CONV3X3_SB_BRANCH_CHANNELS and c in CONV3X3_SB_WRW_CHANNELS
+            and conv3x3_sb_eligible(x, w1) and conv3x3_sb_tiles(x, c) >= CONV3X3_SB_MIN_TILES and conv3x3_sb_wrw_eligible(x, x)
+            and conv3x3_sb_head_nt(c, x) == 0)
+
+
+class BasicBlockSplit(Function):
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, bn1, bn2):
+        arith = split_arith_id()
+        c = w1.shape[0]
+        nt = conv3x3_sb_pick_nt(x, c) if c in CONV3X3_SB_PICK_NT_CHANNELS else 0
+        ax = amax_of(x) if arith else None
+        c1 = conv3x3_sb_run(x, w1, False, None, nt, ax=ax, want_stats=True)
+        a1, mi1, am1 = _bn_train_fwd(c1, g1, b1, None, bn1)
+        c2 = conv3x3_sb_run(a1, w2, False, None, nt, ax=am1, want_stats=True)
+        out, mi2, am2 = _bn_train_fwd(c2, g2, b2, x, bn2)
+        amax_attach(out, am2)
+        ctx.save_for_backward(x, w1, g1, b1, w2, g2, b2, c1, a1, c2, out, mi1, mi2)
+        ctx.misc = (nt, ax, am1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, g1, b1, w2, g2, b2, c1, a1, c2, out, mi1, mi2 = ctx.saved_tensors
+        nt, ax, am1 = ctx.misc
+        dy = dy.contiguous()
+        # bn2 + add + ReLU (mask from `out`; the masked gradient g is also the identity path's gradient)
+        am = amax_request(c2)
+        dc2, dg2, db2, g = bn_bwd(dy, c2, out, mi2, g2, b2, 2, True, True, amax=am)
+        da1 = conv3x3_sb_run(dc2, w2, True, None, nt, ax=am)
+        dw2 = _on_wgrad_stream(lambda: conv3x3_sb_wrw(a1, dc2, ax=am1, ady=am), a1, dc2, am1, am) if ctx.needs_input_grad[4] else None
+        # bn1 + ReLU (mask recomputed from c1)
+        amb = amax_request(c1)
+        dc1, dg1, db1, _ = bn_bwd(da1, c1, None, mi1, g1, b1, 1, True, True, amax=amb)
+        # conv1: backward-data with the identity path's gradient added in the epilogue
+        dx = conv3x3_sb_run(dc1, w1, True, None, nt, ax=amb, addend=g) if ctx.needs_input_grad[0] else None
+        dw1 = _on_wgrad_stream(lambda: conv3x3_sb_wrw(x, dc1, ax=ax, ady=amb), x, dc1, ax, amb) if ctx.needs_input_grad[1] else None
+        return (dx, dw1, dg1 if g1 is not None else None, db1 if b1 is not None else None, dw2,
+                dg2 if g2 is not None else None, db2 if b2 is not None else None, None, None)
+
+
+def _bn_train_fwd(x, weight, bias, residual, bn):
+    """Single-rank training-mode BN(+residual)+ReLU of lib/models/tools/fused_bn.bn_forward, without its dispatch: statistics from
+    the convolution epilogue when it left them, one pass otherwise. -> (y, mean_invstd, max|y| record)."""
+    amax = amax_request(x)
+    tiles = known_tile_stats(x)
+    if tiles is not None:
+        mi = bn_tiles_finalize(tiles, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked)
+        y = bn_apply(x, mi, weight, bias, residual, True, amax=amax)
+    else:
+        y, mi = bn_fwd(x, weight, bias, residual, True, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                       amax=amax)
+    return y, mi, amax
+
+
+def basic_block_split(x, blk):
+    """blk: a residual block with conv1 / bn1 / conv2 / bn2 (no downsample, stride 1), BatchNorms in single-rank training mode."""
+    return BasicBlockSplit.apply(x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias,
+                                 blk.bn1, blk.bn2)
+
+
 def conv3x3_split_fork(x, weight, want_stats=False):
     return Conv3x3SplitFork.apply(x, weight, want_stats)
 
@@ -1326,7 +1402,6 @@ def conv3x3_s2_pick_nt(B, Ho, Wo, c_out):
     return 6 if c_out % 96 == 0 and spatial * (c_out // 96) >= 256 else 3
 
 
-@torch.no_grad()
 def conv3x3_s2_run(x, weight, ax=None, want_stats=False):
     """y = conv2d(x, weight, None, stride 2, padding 1)."""
     co, ci = weight.shape[:2]
@@ -1346,7 +1421,6 @@ def conv3x3_s2_run(x, weight, ax=None, want_stats=False):
     return y
 
 
-@torch.no_grad()
 def conv3x3_s2_bwd_run(dy, weight, ady=None):
     """dx of that convolution for the output gradient dy [B, Cout, Ho, Wo] -> [B, Cin, 2 Ho, 2 Wo]."""
     co, ci = weight.shape[:2]
@@ -1360,7 +1434,6 @@ def conv3x3_s2_bwd_run(dy, weight, ady=None):
     return dx
 
 
-@torch.no_grad()
 def conv3x3_s2_wrw(x, dy, ax=None, ady=None):
     """dw [Cout, Cin, 3, 3] of that convolution."""
     B, ci, H, W = x.shape
@@ -1436,12 +1509,10 @@ def conv1x1_sb_tiles(x, c_out):
     return x.shape[0] * (c_out // nt16) * ((x.shape[2] * x.shape[3] + 255) // 256)
 
 
-@torch.no_grad()
 def conv1x1_sb_pack(weight, transpose=False):
     return SPLIT_WEIGHTS.get(weight, "c1", transpose, 0)
 
 
-@torch.no_grad()
 def conv1x1_sb_run(x, weight, transpose=False, bias=None, ax=None, want_stats=False):
     """y = conv2d(x, weight[Cout,Cin,1,1], bias) (transpose: the backward-data operator applied to x)."""
     co, ci = weight.shape[:2]
@@ -1454,10 +1525,10 @@ def conv1x1_sb_run(x, weight, transpose=False, bias=None, ax=None, want_stats=Fa
     y = torch.empty(B, conv_out, H, W, dtype=F32, device=x.device)
     if want_stats and CONV_EPILOGUE_STATS:
         st = tile_stats_buffer(1, conv_out, B, H * W, 1, x.device)
-        _hip.call("cseg_conv1x1_split_fwd_st", _p(x, F32, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H * W,
+        _hip.call("cseg_conv1x1_split_fwd_st", _pq(x, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H * W,
                   arith, _pf(ax) if arith else _null(), _pf(aw) if arith else _null(), _pf(y), _pf(st), _hip.stream_ptr())
         return tile_stats_attach(y, st)
-    _hip.call("cseg_conv1x1_split_fwd", _p(x, F32, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H * W,
+    _hip.call("cseg_conv1x1_split_fwd", _pq(x, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H * W,
               arith, _pf(ax) if arith else _null(), _pf(aw) if arith else _null(), _pf(y), _hip.stream_ptr())
     return y
 
@@ -1477,7 +1548,6 @@ def conv1x1_sb_wrw_wanted(x, dy):
     return (CONV1X1_SB_WRW and min(x.shape[1], dy.shape[1]) >= CONV1X1_SB_WRW_MIN_CH and conv1x1_sb_wrw_eligible(x, dy))
 
 
-@torch.no_grad()
 def conv1x1_sb_wrw(x, dy, ax=None, ady=None):
     """dw [Cout,Cin,1,1] of a 1x1 convolution for the output gradient dy, split-operand MFMA kernel."""
     B, ci, H, W = x.shape
@@ -1492,7 +1562,7 @@ def conv1x1_sb_wrw(x, dy, ax=None, ady=None):
         ady = tensor_amax(dy) if ady is None else ady
     ws = torch.empty(n, dtype=F32, device=x.device)
     dw = torch.empty(co, ci, 1, 1, dtype=F32, device=x.device)
-    _hip.call("cseg_conv1x1_split_wrw", _p(x, F32, "x"), _p(dy, F32, "dy"), B, ci, co, H * W, arith,
+    _hip.call("cseg_conv1x1_split_wrw", _pq(x, "x"), _pq(dy, "dy"), B, ci, co, H * W, arith,
               _pf(ax) if arith else _null(), _pf(ady) if arith else _null(), _pf(ws), _pf(dw), _hip.stream_ptr())
     return dw
 
@@ -1532,13 +1602,12 @@ def conv1x1_split_bf16(x, weight, bias=None, want_stats=False):
     return Conv1x1SplitBF16.apply(x, weight, bias, want_stats)
 
 
-@torch.no_grad()
 def bn_fwd(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches_tracked, amax=None):
     """Single-rank training forward (2 launches): -> (y, mean_invstd [C,2]). amax: zeroed word that receives max|y|."""
     B, C, HW = _bn_dims(x)
     mi = torch.empty(C, 2, dtype=F32, device=x.device)
     y = torch.empty_like(x)
-    _hip.call("cseg_bn_fwd_amax", _p(x, F32, "x"), _opt(residual, F32, "residual"), _opt(weight, F32, "weight"),
+    _hip.call("cseg_bn_fwd_amax", _pq(x, "x"), _pq(residual, "residual") if residual is not None else _null(), _opt(weight, F32, "weight"),
               _opt(bias, F32, "bias"), int(bool(relu)), B, C, HW, _pf(_bn_ws(B, C, HW, x.device)), float(eps),
               float(momentum), _opt(running_mean, F32, "running_mean"), _opt(running_var, F32, "running_var"),
               _opt(num_batches_tracked, I64, "num_batches_tracked"), _pf(mi), _pf(y),
@@ -1546,7 +1615,6 @@ def bn_fwd(x, weight, bias, residual, relu, eps, momentum, running_mean, running
     return y, mi
 
 
-@torch.no_grad()
 def bn_bwd(dy, x, out, mean_invstd, weight, bias, mode, training, want_dx, amax=None):
     """Single-rank backward (2 launches): -> (dx or None, d_weight, d_bias, g_masked or None). amax: zeroed word for max|dx|."""
     B, C, HW = _bn_dims(x)
@@ -1555,7 +1623,7 @@ def bn_bwd(dy, x, out, mean_invstd, weight, bias, mode, training, want_dx, amax=
     d_weight, d_bias = d_wb[0], d_wb[1]
     g = torch.empty_like(x) if mode == 2 else None
     dx = torch.empty_like(x) if want_dx else None
-    _hip.call("cseg_bn_bwd_amax", _p(dy, F32, "dy"), _pf(x), _pf(out) if out is not None else _null(),
+    _hip.call("cseg_bn_bwd_amax", _pq(dy, "dy"), _pf(x), _pf(out) if out is not None else _null(),
               _pf(mean_invstd), _opt(weight, F32, "weight"), _opt(bias, F32, "bias"), int(mode),
               int(bool(training)), B, C, HW, _pf(_bn_ws(B, C, HW, dev)), _pf(g) if g is not None else _null(),
               _pf(d_weight), _pf(d_bias), _pf(dx) if dx is not None else _null(),

@@ -47,7 +47,25 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
+    def _fused_route(self, x):
+        """The whole block as one autograd node (kernels.BasicBlockSplit) where every convolution direction runs on the split kernels
+        and the BatchNorms take plain single-rank batch statistics; decided once per input shape and switch setting."""
+        fn = getattr(K, "basic_block_split_ok", None)
+        if fn is None or self.downsample is not None or not self.training:
+            return False
+        key = (x.shape, x.requires_grad, x.is_contiguous(), K.BLOCK_FUSED, K.CONV3X3_SPLIT_BF16, K.CONV3X3_SB_WRW, K.CONV3X3_FORK, K.SPLIT_ARITH,
+               K.CONV3X3_SB_MIN_TILES)
+        hit = self.__dict__.get("_route")
+        if hit is None or hit[0] != key:
+            bn_ok = all(b.track_running_stats and b.momentum is not None and getattr(b, "_sync_group", lambda: None)() is None
+                        and b.weight is not None for b in (self.bn1, self.bn2))
+            hit = (key, bool(bn_ok and fn(x, self.conv1.weight, self.conv2.weight)))
+            self.__dict__["_route"] = hit
+        return hit[1]
+
     def forward(self, x):
+        if self._fused_route(x):
+            return K.basic_block_split(x, self)
         if self.downsample is None:
             out, res = self.conv1.forward_fork(x)                     # conv1(x) and the identity path from one autograd node
         else:

@@ -104,3 +104,54 @@ def test_residual_block_with_epilogue_statistics_equals_the_plain_block(monkeypa
     assert "cseg_bn_fwd_amax" not in res[True][4], "a statistics pass ran although the epilogue had the statistics"
     for a, b in zip(res[False][:4], res[True][:4]):
         assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+
+
+@pytest.mark.parametrize("channels,hw", [(48, (6, 64)), (96, (4, 64)), (192, (4, 32))])
+def test_fused_block_node_equals_the_four_nodes_it_replaces(channels, hw, monkeypatch):
+    """kernels.BasicBlockSplit (one autograd node per residual block) against the unfused chain Conv3x3SplitFork -> _BNAct ->
+    Conv3x3SplitBF16 -> _BNAct: the same kernel calls in the same order, so outputs, every gradient and the BN buffers are
+    bit-identical; what changes is the number of autograd nodes."""
+    from contrastiveseg_amd import kernels as K
+    from contrastiveseg_amd.lib.models.backbones.hrnet_backbone import BasicBlock
+    from contrastiveseg_amd.lib.models.tools.module_helper import mark_conv_bn_pairs
+    inject.install(monkeypatch)
+    monkeypatch.setattr(K, "SPLIT_ARITH", "f16x3")
+    monkeypatch.setattr(K, "SPLIT_WEIGHTS", K.SplitWeights())
+    monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
+    monkeypatch.setattr(K, "CONV_EPILOGUE_STATS", True)
+    torch.manual_seed(channels)
+    blk = mark_conv_bn_pairs(BasicBlock(channels, channels, bn_type="torchbn").train())
+    x0 = torch.randn(2, channels, *hw) * 0.7 + 0.1
+    gy = torch.randn(2, channels, *hw)
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(K, "BLOCK_FUSED", fused)
+        for bn in (blk.bn1, blk.bn2):
+            bn.reset_running_stats()
+        calls = []
+        orig = K._hip.call
+        monkeypatch.setattr(K._hip, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+        x = (x0.clone() * 1.0).requires_grad_(True)
+        y = blk(x * 1.0)                        # a non-leaf input, as inside the network
+        n_nodes = 0
+        seen, stack = set(), [y.grad_fn]
+        while stack:
+            f = stack.pop()
+            if f is None or f in seen:
+                continue
+            seen.add(f)
+            n_nodes += 1
+            stack += [g for g, _ in f.next_functions]
+        y.backward(gy)
+        monkeypatch.setattr(K._hip, "call", orig)
+        res[fused] = ([y.detach(), x.grad.clone(), blk.conv1.weight.grad.clone(), blk.conv2.weight.grad.clone(), blk.bn1.weight.grad.clone(),
+                       blk.bn2.bias.grad.clone(), blk.bn1.running_var.clone(), blk.bn2.running_mean.clone()], calls, n_nodes,
+                      K.known_amax(y) is not None)
+        blk.zero_grad()
+    packs = ("cseg_amax_batch", "cseg_split_pack_batch")          # (the first use of a weight registers and packs it)
+    assert [c for c in res[True][1] if c not in packs] == [c for c in res[False][1] if c not in packs], \
+        "the fused node issues a different kernel sequence"
+    assert res[True][2] < res[False][2], (res[True][2], res[False][2])
+    assert res[True][3] and res[False][3], "the block output must carry its max|.| record for the next convolution"
+    for a, b in zip(res[False][0], res[True][0]):
+        assert torch.equal(a, b)
