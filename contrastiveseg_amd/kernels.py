@@ -1306,14 +1306,14 @@ def basic_block_split_ok(x, w1, w2):
 
 class BasicBlockSplit(Function):
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, w2, g2, b2, bn1, bn2):
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, bn1, bn2, stats1=True, stats2=True):
         arith = split_arith_id()
         c = w1.shape[0]
         nt = conv3x3_sb_pick_nt(x, c) if c in CONV3X3_SB_PICK_NT_CHANNELS else 0
         ax = amax_of(x) if arith else None
-        c1 = conv3x3_sb_run(x, w1, False, None, nt, ax=ax, want_stats=True)
+        c1 = conv3x3_sb_run(x, w1, False, None, nt, ax=ax, want_stats=stats1)
         a1, mi1, am1 = _bn_train_fwd(c1, g1, b1, None, bn1)
-        c2 = conv3x3_sb_run(a1, w2, False, None, nt, ax=am1, want_stats=True)
+        c2 = conv3x3_sb_run(a1, w2, False, None, nt, ax=am1, want_stats=stats2)
         out, mi2, am2 = _bn_train_fwd(c2, g2, b2, x, bn2)
         amax_attach(out, am2)
         ctx.save_for_backward(x, w1, g1, b1, w2, g2, b2, c1, a1, c2, out, mi1, mi2)
@@ -1337,7 +1337,7 @@ class BasicBlockSplit(Function):
         dx = conv3x3_sb_run(dc1, w1, True, None, nt, ax=amb, addend=g) if ctx.needs_input_grad[0] else None
         dw1 = _on_wgrad_stream(lambda: conv3x3_sb_wrw(x, dc1, ax=ax, ady=amb), x, dc1, ax, amb) if ctx.needs_input_grad[1] else None
         return (dx, dw1, dg1 if g1 is not None else None, db1 if b1 is not None else None, dw2,
-                dg2 if g2 is not None else None, db2 if b2 is not None else None, None, None)
+                dg2 if g2 is not None else None, db2 if b2 is not None else None, None, None, None, None)
 
 
 def _bn_train_fwd(x, weight, bias, residual, bn):
@@ -1357,7 +1357,7 @@ def _bn_train_fwd(x, weight, bias, residual, bn):
 def basic_block_split(x, blk):
     """blk: a residual block with conv1 / bn1 / conv2 / bn2 (no downsample, stride 1), BatchNorms in single-rank training mode."""
     return BasicBlockSplit.apply(x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias,
-                                 blk.bn1, blk.bn2)
+                                 blk.bn1, blk.bn2, blk.conv1.bn_follows, blk.conv2.bn_follows)
 
 
 def conv3x3_split_fork(x, weight, want_stats=False):

@@ -204,6 +204,7 @@ def test_basic_block_with_fused_identity_gradient(case, monkeypatch):
     from contrastiveseg_amd import kernels as K
     from contrastiveseg_amd.lib.models.backbones.hrnet_backbone import BasicBlock
     monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
+    monkeypatch.setattr(K, "BLOCK_FUSED", False)        # this test is about the two-node route; the one-node block is compared below
     B, C, H, W = case
     g = torch.Generator().manual_seed(21)
     x = torch.randn(B, C, H, W, generator=g)
@@ -225,6 +226,14 @@ def test_basic_block_with_fused_identity_gradient(case, monkeypatch):
     assert calls == ["fork"], calls
     plain = run(False)
     assert calls == ["fork"]
+    # the whole block as ONE autograd node (kernels.BasicBlockSplit, round 4): the same kernels in the same order
+    monkeypatch.setattr(K, "BLOCK_FUSED", True)
+    one = run(True)
+    monkeypatch.setattr(K, "BLOCK_FUSED", False)
+    if W % 32 == 0:                                     # (narrower maps keep the two-node route: no split weight gradient there)
+        assert calls == ["fork"], "the fused block must not go through the fork node"
+        for a, b in zip(got, one):
+            assert torch.equal(a, b)
     # fp64 reference of the same block
     w1, w2 = blk.conv1.weight.detach().cpu().double().requires_grad_(True), blk.conv2.weight.detach().cpu().double().requires_grad_(True)
     g1, b1 = blk.bn1.weight.detach().cpu().double(), blk.bn1.bias.detach().cpu().double()
