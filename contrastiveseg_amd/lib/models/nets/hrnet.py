@@ -13,14 +13,17 @@ from contrastiveseg_amd.lib.models.modules.spatial_ocr_block import SpatialGathe
 from contrastiveseg_amd.lib.models.tools.module_helper import HeadConv3x3, ModuleHelper
 
 
+import os as _os
+
 _HEAD_STREAMS = {}
+HEAD_FORK = _os.environ.get("CSEG_HEAD_FORK", "1") == "1"
 
 
 def _fork_heads(feats):
     """(current stream, side stream) when the heads may run concurrently: eager GPU steps with the stream forks on
     (hrnet_backbone.EAGER_FORKS); None otherwise (CPU, hipGraph capture, CSEG_BRANCH_STREAMS=0)."""
     from contrastiveseg_amd.lib.models.backbones import hrnet_backbone as HB
-    if not (feats.is_cuda and HB.EAGER_FORKS and torch.is_grad_enabled()) or torch.cuda.is_current_stream_capturing():
+    if not (HEAD_FORK and feats.is_cuda and HB.EAGER_FORKS and torch.is_grad_enabled()) or torch.cuda.is_current_stream_capturing():
         return None
     key = feats.device.index
     if key not in _HEAD_STREAMS:
