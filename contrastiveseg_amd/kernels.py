@@ -736,8 +736,16 @@ def amax_attach(t, slot):
 
 
 def known_amax(t):
+    """The max|t| record that travels with `t`, or None. A record that a CONSUMER computed (amax_of below) was produced on that
+    consumer's stream, after `t` itself: another stream that picks it up first waits for the pass (round 4: with the two heads of
+    the segmentor on different streams the classifier head read the record of their common input before the projection head's
+    pass over it had run -- a scale from an empty record, NaN losses)."""
     a = getattr(t, "_cseg_amax", None)
-    return a[0] if (a is not None and a[1] == t._version) else None
+    if a is None or a[1] != t._version:
+        return None
+    if len(a) > 2 and a[3] is not None and a[2] != _hip.raw_stream():
+        torch.cuda.current_stream(t.device).wait_event(a[3])
+    return a[0]
 
 
 def amax_of(t):
@@ -746,7 +754,14 @@ def amax_of(t):
     if a is None:
         a = tensor_amax(t.contiguous())
         try:
-            amax_attach(t, a)          # a second consumer of the same tensor (the head's 3x3 and 1x1 both read `feats`) reuses it
+            # a second consumer of the same tensor (the head's 3x3 and 1x1 both read `feats`) reuses it -- after waiting for this pass
+            # when it runs on another stream
+            if t.is_cuda and not torch.cuda.is_current_stream_capturing():
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(t.device))
+                t._cseg_amax = (a, t._version, _hip.raw_stream(), ev)
+            else:
+                amax_attach(t, a)
         except Exception:
             pass
     return a
