@@ -299,59 +299,61 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
                     (__attribute__((address_space(3))) void*)(dst + r * 64), 16, 0, 0);
         }
     };
-    auto tile_of = [&](int it, int& b, int& y0, int& x0) {
-        int t = grp + (it / n_chunks) * groups;
+    auto tile_of = [&](int tile, int& b, int& y0, int& x0) {      // tile = index of one of this block's spatial tiles
+        int t = grp + tile * groups;
         const int tx = t % tiles_x; t /= tiles_x;
         const int ty = t % tiles_y;
         b = t / tiles_y;
         x0 = tx * TC; y0 = ty * TR;
     };
+    // Staging items. What does not depend on the tile -- which (octet, patch row, patch column) a thread stages, the LDS cell it
+    // writes -- is computed ONCE per block (round 4: the per-item divisions by CELLS / XCOLS and the three tile_of() calls per item
+    // were a quarter of the kernel's VALU instructions, 2.9 per MFMA in the round-3 counters; VALU issue of any wave of a SIMD comes
+    // on top of its MFMA time). Tile coordinates are tracked for the tile being computed (cb, cy0, cx0) and the one being staged
+    // (sb, sy0, sx0), and recomputed only when an item starts a new tile.
     float apre[AU][8];
-    auto a_item = [&](int u, int y0, int x0, int& oct, int& rc, bool& ok) {
+    int it_r[AU], it_col[AU], it_cell[AU], it_plane[AU];
+    bool it_in[AU];
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
         const int item = tid + 512 * u;
-        oct = item / CELLS; rc = item - oct * CELLS;
-        const int r = rc / XCOLS, col = rc - r * XCOLS;
-        const int yy = y0 + r - 1, xx = x0 + col - 1;
-        ok = oct < NOCT && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    };
+        const int oct = item / CELLS, rc = item - oct * CELLS;
+        it_r[u] = rc / XCOLS;
+        it_col[u] = rc - it_r[u] * XCOLS;
+        it_in[u] = oct < NOCT;
+        it_cell[u] = oct * PLANE + rc;
+        it_plane[u] = min(oct, NOCT - 1) * 8 * (int)plane;
+    }
+    int sb, sy0, sx0;                              // tile of the item being staged
     auto a_issue = [&](int it) {
-        int b, y0, x0;
-        tile_of(it, b, y0, x0);
         const int chunk = it % n_chunks;
-        const float* xc = x + ((size_t)b * Cin + (size_t)chunk * 16) * plane;
+        if (chunk == 0) tile_of(it / n_chunks, sb, sy0, sx0);
+        const float* xc = x + ((size_t)sb * Cin + (size_t)chunk * 16) * plane;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xc, 0, (int)(16 * plane * sizeof(float)),
                                                                             0x00020000);
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
-            int oct, rc;
-            bool ok;
-            a_item(u, y0, x0, oct, rc, ok);
-            const int r = rc / XCOLS, col = rc - r * XCOLS;
-            const int octc = min(oct, NOCT - 1), yc = min(max(y0 + r - 1, 0), H - 1), xcl = min(max(x0 + col - 1, 0), W - 1);
-            const int off = (octc * 8 * (int)plane + yc * W + xcl) * (int)sizeof(float);
+            const int yc = min(max(sy0 + it_r[u] - 1, 0), H - 1), xcl = min(max(sx0 + it_col[u] - 1, 0), W - 1);
+            const int off = (it_plane[u] + yc * W + xcl) * (int)sizeof(float);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 apre[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                            rs, off, j * (int)plane * (int)sizeof(float), 0));
         }
     };
-    auto a_store = [&](int it, uint4* dst) {
-        int b, y0, x0;
-        tile_of(it, b, y0, x0);
+    auto a_store = [&](uint4* dst) {               // the item a_issue() fetched last (same tile coordinates)
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
-            int oct, rc;
-            bool ok;
-            a_item(u, y0, x0, oct, rc, ok);
-            if (oct < NOCT) {
+            if (it_in[u]) {
+                const int yy = sy0 + it_r[u] - 1, xx = sx0 + it_col[u] - 1;
+                const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = ok ? apre[u][j] : 0.f;       // zero padding / outside the tensor
                 uint4 cells[NP];
                 split_cells8<AR>(v, xscale, cells);
-                const int item = oct * PLANE + rc;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) dst[p * NOCT * PLANE + item] = cells[p];
+                for (int p = 0; p < NP; ++p) dst[p * NOCT * PLANE + it_cell[u]] = cells[p];
             }
         }
     };
@@ -364,8 +366,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
     } else {
         b_dma(0, Bs);
     }
-    a_store(0, As);
+    a_store(As);
     __syncthreads();
+    int cb = sb, cy0 = sy0, cx0 = sx0;             // tile of the item being computed
 
     const int a_lane_off = row * XCOLS + n;
     const int b_lane_off = (half ? NT0 * NP * 64 : 0) + lane;
@@ -374,6 +377,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
         const int chunk = it % n_chunks;
         const bool more = it + 1 < n_items;
         if (chunk == 0) {
+            cb = sb; cy0 = sy0; cx0 = sx0;         // (the staged tile is still this item's: a_issue(it + 1) comes below)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -395,8 +399,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
             else if (NT1 > 0) sb16_kstep<AR, NT1, NT0>(a_lane + a_off, b_base + s * BSTEP, acc);
         }
         if (chunk == n_chunks - 1) {
-            int b, y0, x0;
-            tile_of(it, b, y0, x0);
+            const int b = cb, y0 = cy0, x0 = cx0;
             const int yy = y0 + row;
             if (yy < H) {
                 float* ybc = y + (size_t)b * Cout * plane;
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
                 }
             }
         }
-        if (more) a_store(it + 1, As + (size_t)((it + 1) & 1) * A_CELLS);  // the other patch buffer: last read in item it - 1
+        if (more) a_store(As + (size_t)((it + 1) & 1) * A_CELLS);          // the other patch buffer: last read in item it - 1
         __syncthreads();
     }
 }

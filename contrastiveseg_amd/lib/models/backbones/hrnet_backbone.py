@@ -130,13 +130,19 @@ def _capturing():
     return step_graph.capturing()
 
 
+# Eager forks only where the kernels are long enough for one host thread to keep four queues busy: the finest branch at least
+# 4 x 128 x 256 pixels (measured, profiles/r04_bench_b2_eager.json vs profiles/r04_step_graph_ab.txt: at 2 images per GPU the forks cost
+# 65.4 vs 57.1 ms per step -- their wait / record calls land on a host that is the limit there anyway).
+EAGER_FORK_MIN_PIXELS = int(_os.environ.get("CSEG_BRANCH_STREAMS_MIN_PIXELS", str(4 * 128 * 256)))
+
+
 def _capture_forks(x=None):
     from contrastiveseg_amd.segmentor.tools import step_graph
     if x is not None and not x.is_cuda:
         return False
     if step_graph.capturing():
         return step_graph.BRANCH_STREAMS
-    return EAGER_FORKS
+    return EAGER_FORKS and (x is None or x.shape[0] * x.shape[2] * x.shape[3] >= EAGER_FORK_MIN_PIXELS)
 
 
 class HighResolutionModule(nn.Module):

@@ -22,6 +22,7 @@ def _run(forks, wgrad, monkeypatch, model="hrnet_w48_contrast", backbone="hrnet4
     from contrastiveseg_amd.segmentor.tools.data_helper import SyntheticLoader
     from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
     monkeypatch.setattr(HB, "EAGER_FORKS", forks)
+    monkeypatch.setattr(HB, "EAGER_FORK_MIN_PIXELS", 0)          # (the default keeps small maps like this test's on one stream)
     monkeypatch.setattr(K, "WGRAD_STREAM", wgrad)
     monkeypatch.setattr(step_graph, "ENABLED", False)
     monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
