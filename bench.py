@@ -669,7 +669,7 @@ def self_launch(args):
 def step_traffic():
     """HBM bytes per step of the default workload at N=1, from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs; gfx950 FETCH_SIZE x2 for wide coalesced reads per MI355X_MICROARCH.md)."""
-    for name in ("r03_step_pmc.json", "r02_step_pmc.json"):
+    for name in ("r04_step_pmc.json", "r03_step_pmc.json", "r02_step_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
