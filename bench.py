@@ -617,11 +617,11 @@ def timed_steps(tr, batch, steps, warmup, world, device):
     return dt, ev_ms, float(loss)
 
 
-# Routes that became defaults after the last GPU run of round 2 (split-bf16 weight gradient, 192-channel branch): if a run
-# with them dies or ends with a non-finite loss, the measurement is repeated ONCE with exactly the configuration that was
-# measured on hardware (176.6 ms/step), and the line says so in config.route_fallback. Off with CSEG_BENCH_GUARD=0 (e.g.
-# under rocprofv3), and never applied when the caller chose the routes explicitly.
-SAFE_ROUTES = {"CSEG_CONV3X3_SB_WRW": "0", "CSEG_CONV3X3_SB_CHANNELS": "48,96"}
+# Routes that became defaults in round 4 (forked streams, convolution-epilogue BN statistics, the one-node residual block, hipGraph replay
+# at one image per GPU): if a run with them dies or ends with a non-finite loss, the measurement is repeated ONCE with the configuration
+# of the round-3 closing tree (one stream, statistics pass, four nodes per block, eager), and the line says so in config.route_fallback.
+# Off with CSEG_BENCH_GUARD=0 (e.g. under rocprofv3), and never applied when the caller chose one of these routes explicitly.
+SAFE_ROUTES = {"CSEG_BRANCH_STREAMS": "0", "CSEG_CONV_STATS": "0", "CSEG_BLOCK_FUSED": "0", "CSEG_STEP_GRAPH": "0"}
 
 
 def guard_enabled():

@@ -249,8 +249,8 @@ def test_bench_guard_repeats_once_with_the_hardware_measured_routes(monkeypatch,
     for k in list(bench.SAFE_ROUTES) + ["CSEG_BENCH_GUARD", "CSEG_BENCH_ROUTE_FALLBACK", "CSEG_BENCH_GUARDED"]:
         monkeypatch.delenv(k, raising=False)
     assert bench.guard_enabled()
-    show = "import os; print(os.environ.get('CSEG_BENCH_GUARDED'), os.environ.get('CSEG_CONV3X3_SB_WRW'), " \
-           "os.environ.get('CSEG_CONV3X3_SB_CHANNELS'), os.environ.get('CSEG_BENCH_ROUTE_FALLBACK'))"
+    show = "import os; print(os.environ.get('CSEG_BENCH_GUARDED'), os.environ.get('CSEG_BRANCH_STREAMS'), " \
+           "os.environ.get('CSEG_CONV_STATS'), os.environ.get('CSEG_BENCH_ROUTE_FALLBACK'))"
     attempts = []
 
     def cmd(attempt, first_rc):
@@ -258,7 +258,7 @@ def test_bench_guard_repeats_once_with_the_hardware_measured_routes(monkeypatch,
         return [sys.executable, "-c", ("import sys; sys.exit(%d)" % first_rc) if (attempt == 0 and first_rc) else show]
     assert bench.run_guarded(lambda a: cmd(a, 3)) == 0
     out = capfd.readouterr()
-    assert attempts == [0, 1] and "1 0 48,96 the first attempt" in out.out and "exit code 3" in out.err
+    assert attempts == [0, 1] and "1 0 0 the first attempt" in out.out and "exit code 3" in out.err
     attempts.clear()
     assert bench.run_guarded(lambda a: cmd(a, 0)) == 0
     assert attempts == [0] and "1 None None None" in capfd.readouterr().out
@@ -268,8 +268,8 @@ def test_bench_guard_repeats_once_with_the_hardware_measured_routes(monkeypatch,
     assert bench.run_guarded(lambda a: (attempts.append(a), [sys.executable, "-c", late])[1]) == 0
     got = capfd.readouterr()
     assert attempts == [0] and got.out.count('"metric"') == 1 and "teardown" in got.err
-    monkeypatch.setenv("CSEG_CONV3X3_SB_WRW", "1")
+    monkeypatch.setenv("CSEG_BRANCH_STREAMS", "1")
     assert not bench.guard_enabled()
-    monkeypatch.delenv("CSEG_CONV3X3_SB_WRW")
+    monkeypatch.delenv("CSEG_BRANCH_STREAMS")
     monkeypatch.setenv("CSEG_BENCH_GUARD", "0")
     assert not bench.guard_enabled()
