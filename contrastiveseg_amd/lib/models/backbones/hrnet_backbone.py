@@ -109,11 +109,17 @@ def _block_chain(block, inplanes, planes, n, bn_type, momentum):
 _FORK_STREAMS = {}
 
 
+FORK_PRIORITY = None        # set from CSEG_FORK_PRIORITY on first use: HIP stream priority of the side streams (0 = default)
+
+
 def _fork_streams(device, n):
     import torch
+    global FORK_PRIORITY
+    if FORK_PRIORITY is None:
+        FORK_PRIORITY = int(_os.environ.get("CSEG_FORK_PRIORITY", "0"))
     have = _FORK_STREAMS.setdefault((device.type, device.index), [])
     while len(have) < n:
-        have.append(torch.cuda.Stream(device=device))
+        have.append(torch.cuda.Stream(device=device, priority=FORK_PRIORITY))
     return have[:n]
 
 
