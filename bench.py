@@ -713,9 +713,6 @@ def main():
     base_batch = args.global_batch or wl["batch"]
     global_batch = base_batch * world if args.scaling == "weak" else base_batch
     t_start = time.perf_counter()
-    if os.environ.get("CSEG_MAIN_PRIORITY"):          # experiment: the whole step on a stream of this HIP priority (-1 = high)
-        torch.cuda.synchronize()
-        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=int(os.environ["CSEG_MAIN_PRIORITY"])))
     tr, cfg, batch = build_trainer(args, world, device, global_batch)
     dt, ev_ms, final_loss = timed_steps(tr, batch, args.steps, args.warmup, world, device)
     if (final_loss != final_loss or abs(final_loss) == float("inf")) and os.environ.get("CSEG_BENCH_GUARDED") == "1" \
