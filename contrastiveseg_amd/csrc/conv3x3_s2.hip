@@ -163,11 +163,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_fwd_kernel(const float* __r
             bool ok;
             a_item(u, oct, rc, yy, xx, ok);
             if (oct < NOCT) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = ok ? apre[u][j] : 0.f;       // zero padding / outside the tensor
                 uint4 cells[NP];
-                split_cells8<AR>(v, xscale, cells);
+                split_cells8_masked<AR>(apre[u], ok, xscale, cells);            // zero padding / outside the tensor
                 const int item = oct * F_PLANE + rc;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) As[p * NOCT * F_PLANE + item] = cells[p];
@@ -330,11 +327,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_bwd_kernel(const float* __r
             bool ok;
             a_item(u, oct, rc, yy, xx, ok);
             if (oct < NOCT) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = ok ? apre[u][j] : 0.f;
                 uint4 cells[NP];
-                split_cells8<AR>(v, dscale, cells);
+                split_cells8_masked<AR>(apre[u], ok, dscale, cells);
                 const int item = oct * D_PLANE + rc;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) As[p * NOCT * D_PLANE + item] = cells[p];

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
             if (oct < n_oct) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = ok ? apre[u][j] : 0.f;       // zero padding / outside the tensor
+                for (int j = 0; j < 8; ++j) v[j] = (ABL & 2) ? (ok ? apre[u][j] : 0.f) : apre[u][j];
                 uint4 cells[NP];
                 if (ABL & 2) {
 #pragma unroll
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
                                               __builtin_bit_cast(unsigned, v[2]) >> 16 | (__builtin_bit_cast(unsigned, v[3]) & 0xffff0000u),
                                               __builtin_bit_cast(unsigned, v[4]) >> 16 | (__builtin_bit_cast(unsigned, v[5]) & 0xffff0000u),
                                               __builtin_bit_cast(unsigned, v[6]) >> 16 | (__builtin_bit_cast(unsigned, v[7]) & 0xffff0000u));
-                } else split_cells8<AR>(v, xscale, cells);
+                } else split_cells8_masked<AR>(v, ok, xscale, cells);           // zero padding / outside the tensor
                 const int item = oct * PLANE + rc;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) As[p * 4 * PLANE + item] = cells[p];

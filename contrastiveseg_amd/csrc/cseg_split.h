@@ -108,9 +108,16 @@ struct SplitF16x3 {
     }
 };
 
+__device__ __forceinline__ void split_cells8_f16_lean(const float (&v)[8], float scale, uint4 (&out)[2]);
+__device__ __forceinline__ void split_cells4_f16_lean(const float4& v, float scale, uint2 (&out)[2]);
+
 // eight values -> AR::NP cells of 16 bytes (element j of piece p in half-word j of out[p])
 template <class AR>
 __device__ __forceinline__ void split_cells8(const float (&v)[8], float scale, uint4 (&out)[AR::NP]) {
+    if constexpr (AR::ID == CSEG_ARITH_F16X3) {            // round 4: the 16-instruction form below, the same pieces bit for bit
+        split_cells8_f16_lean(v, scale, out);
+        return;
+    }
     unsigned d[4][AR::NP];
 #pragma unroll
     for (int j = 0; j < 4; ++j) AR::split2(v[2 * j], v[2 * j + 1], scale, d[j]);
@@ -118,9 +125,70 @@ __device__ __forceinline__ void split_cells8(const float (&v)[8], float scale, u
     for (int p = 0; p < AR::NP; ++p) out[p] = make_uint4(d[0][p], d[1][p], d[2][p], d[3][p]);
 }
 
+// Round 4: the f16x3 split of eight values in 16 VALU instructions instead of the
+// 24 - 36 the compiler makes of split_cells8 (it converts the hi piece back to fp32 and re-packs, or computes it twice). Per pair:
+// v_pk_mul_f32 (t = v * s), v_cvt_pk_f16_f32 (hi), and the lo piece straight from the operands with the mixed-precision FMA --
+// lo = rn16(v * s - hi), where v * s - hi is exact in fp32, so nothing is rounded twice: bit-identical to SplitF16x3::split2.
+// VALU instructions of ANY wave are paid on top of the MFMA time of its SIMD, so the count matters.
+__device__ __forceinline__ unsigned split_lo_pair_f16(float a, float b, float s, unsigned hi_pk) {
+#if defined(__AMDGCN__)
+    unsigned lo;
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(a), "v"(s), "v"(hi_pk));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(b), "v"(s), "v"(hi_pk));
+    return lo;
+#else   // host pass / CPU emulation of the execution model (tests/emu): the same arithmetic in plain C++
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t h = __builtin_bit_cast(h2_t, hi_pk);
+    const float ra = __builtin_fmaf(a, s, -(float)h[0]), rb = __builtin_fmaf(b, s, -(float)h[1]);
+    return __builtin_bit_cast(unsigned, h2_t{(_Float16)ra, (_Float16)rb});
+#endif
+}
+// eight values -> the hi and lo cells of 16 bytes; `scale` may be 0 (a pixel outside the image: every piece is +-0, finite inputs)
+__device__ __forceinline__ void split_cells8_f16_lean(const float (&v)[8], float scale, uint4 (&out)[2]) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f2_t t = (f2_t){v[2 * j], v[2 * j + 1]} * scale;                 // exact (power of two, or zero)
+        hi[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, h2_t));
+        lo[j] = split_lo_pair_f16(v[2 * j], v[2 * j + 1], scale, hi[j]);
+    }
+    out[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    out[1] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+__device__ __forceinline__ void split_cells4_f16_lean(const float4& v, float scale, uint2 (&out)[2]) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t t0 = (f2_t){v.x, v.y} * scale, t1 = (f2_t){v.z, v.w} * scale;
+    const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(t0, h2_t));
+    const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(t1, h2_t));
+    out[0] = make_uint2(h0, h1);
+    out[1] = make_uint2(split_lo_pair_f16(v.x, v.y, scale, h0), split_lo_pair_f16(v.z, v.w, scale, h1));
+}
+
+// eight values of ONE pixel that may lie outside the image (`ok` false: all pieces zero). f16x3 folds the mask into the scale
+// (v * 0 = +-0 for the finite values a clamped address fetched -- one select instead of eight); the unscaled bf16x6 masks the values.
+template <class AR>
+__device__ __forceinline__ void split_cells8_masked(const float (&v)[8], bool ok, float scale, uint4 (&out)[AR::NP]) {
+    if constexpr (AR::ID == CSEG_ARITH_F16X3) {
+        split_cells8_f16_lean(v, ok ? scale : 0.f, out);
+    } else {
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = ok ? v[j] : 0.f;
+        split_cells8<AR>(m, scale, out);
+    }
+}
+
 // four values -> AR::NP cells of 8 bytes
 template <class AR>
 __device__ __forceinline__ void split_cells4(const float4& v, float scale, uint2 (&out)[AR::NP]) {
+    if constexpr (AR::ID == CSEG_ARITH_F16X3) {
+        split_cells4_f16_lean(v, scale, out);
+        return;
+    }
     unsigned d[2][AR::NP];
     AR::split2(v.x, v.y, scale, d[0]);
     AR::split2(v.z, v.w, scale, d[1]);

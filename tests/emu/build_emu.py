@@ -31,12 +31,27 @@ def _deps():
             os.path.join(ROOT, "include", "cseg_hip.h")])
 
 
+def _fresh():
+    return os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in _deps())
+
+
 def build(force=False):
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in _deps()):
+    """Builds libcseg_emu.so when a source is newer than it. Serialised across processes with a file lock: the ranks of a
+    world-size-2 test are spawned together and would otherwise both rebuild a stale library into the same files."""
+    if not force and _fresh():
         return OUT
     if not os.path.exists(CLANG):
         raise EmuBuildError("host clang++ of the ROCm toolchain not found at %s" % CLANG)
     os.makedirs(OUT_DIR, exist_ok=True)
+    import fcntl
+    with open(os.path.join(OUT_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and _fresh():                   # another process built it while this one waited
+            return OUT
+        return _build_locked()
+
+
+def _build_locked():
     for h in os.listdir(CSRC):                       # headers that declare dynamic LDS get the same rewrite
         if h.endswith(".h"):
             with open(os.path.join(OUT_DIR, h), "w") as f:

@@ -22,10 +22,18 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("kind,B,Cin,Cout,H,W,nt,bias", CASES)
-def test_epilogue_statistics_equal_a_pass_over_the_output(kind, B, Cin, Cout, H, W, nt, bias, monkeypatch):
+# opt-in variants of the persistent small-channel kernel (conv3x3_sb16q_kernel: CSEG_SB16_PF / CSEG_SB16_FEAT, round 4) on the cases it takes
+OPT_IN = [({}, c) for c in CASES] + [({"CSEG_SB16_PF": "1", "CSEG_SB16_FEAT": "3"}, CASES[0]), ({"CSEG_SB16_PF": "2", "CSEG_SB16_FEAT": "3"}, CASES[3]),
+                                     ({"CSEG_SB16_PF": "1", "CSEG_SB16_FEAT": "2"}, CASES[3])]
+
+
+@pytest.mark.parametrize("env,case", OPT_IN)
+def test_epilogue_statistics_equal_a_pass_over_the_output(env, case, monkeypatch):
+    kind, B, Cin, Cout, H, W, nt, bias = case
     from contrastiveseg_amd import kernels as K
     inject.install(monkeypatch)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     monkeypatch.setattr(K, "SPLIT_ARITH", "f16x3")
     monkeypatch.setattr(K, "SPLIT_WEIGHTS", K.SplitWeights())
     monkeypatch.setattr(K, "CONV_EPILOGUE_STATS", True)
