@@ -707,6 +707,240 @@ int sb16q_distance() {
     return pf < 0 ? 0 : (pf > 3 ? 3 : pf);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 4, opt-in (CSEG_SB16_ROWS8=1; first hardware timing pending): the persistent kernel on 8 x 64-pixel tiles, ONE WAVE PER
+// OUTPUT ROW x all three channel tiles. Why: on 4 x 64 tiles the two halves of a block split the CHANNEL
+// tiles and both read the row's pixel fragments -- 22 ds_read_b128 per 36 MFMAs, 704 LDS cycles per K-step against 576 of MFMA
+// issue; the K-steps of the 48-channel layers take 17-19 us where the MFMAs need 13. Here a wave reads its row's four pixel tiles
+// and the three channel tiles once per K-step: 14 reads per 36 MFMAs (448 cycles), and the halo of a tile is 1.29 x instead of
+// 1.55 x its pixels (fewer loads, fewer cells to split). LDS: the patch image of a 16-channel chunk is 43 KB, so
+//   * weights RESIDENT (input channels <= 48: 3 x 30 KB) leave room for ONE patch buffer: two barriers per chunk, the split of the
+//     next chunk is not hidden behind MFMAs -- it was not hidden before either (section 11.8: the phases add up);
+//   * weights STREAMED (more input channels): two patch buffers + two weight chunks = 146 KB, one barrier per chunk as before.
+// Same packed weights (CSEG_PACK_C3_16, three channel tiles per block), same accumulation order per output element as the 4-row
+// kernels: bit-identical results. Statistics segments are rows x 64 columns as everywhere (cseg_stats.h).
+// ---------------------------------------------------------------------------------------------------------
+namespace r8 {
+constexpr int TR8 = 8;
+constexpr int XROWS8 = TR8 + 2;
+constexpr int CELLS8 = XROWS8 * XCOLS;             // 660 pixels per (piece, octet)
+constexpr int PLANE8 = 672;                        // LDS stride of a (piece, octet) plane: 0 mod 256 bytes
+constexpr int A_ITEMS8 = NOCT * CELLS8;            // 1320 staging items per chunk
+constexpr int AU8 = (A_ITEMS8 + 511) / 512;        // 3 per thread
+constexpr int NT8 = 3;
+}  // namespace r8
+
+template <class AR, bool RES>
+__global__ __launch_bounds__(512, 1) void conv3x3_sb16r_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
+                                                               const float* __restrict__ bias, const float* __restrict__ addend, int Cin, int Cout, int H, int W,
+                                                               int tiles_x, int tiles_y, int n_spatial, int groups,
+                                                               const unsigned* __restrict__ amax_x,
+                                                               const unsigned* __restrict__ amax_w, float* __restrict__ y,
+                                                               float4* __restrict__ stats, int n_seg) {
+    using namespace r8;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_s16r[];
+    constexpr int NP = AR::NP;
+    constexpr int A_CELLS = NP * NOCT * PLANE8;
+    constexpr int BSTEP = NT8 * NP * 64;
+    constexpr int BCHUNK = STEPS * BSTEP;
+    constexpr int NBUF = RES ? 1 : 2;              // patch buffers
+    uint4* As = smem_s16r;                         // [NBUF][piece NP][octet 2][PLANE8]
+    uint4* Bs = smem_s16r + NBUF * A_CELLS;        // RES: [n_chunks][BCHUNK]; else [2][BCHUNK]
+    const unsigned ex = AR::SCALED ? split_amax_exp(amax_x) : 141u, ew = AR::SCALED ? split_amax_exp(amax_w) : 141u;
+    const float xscale = split_scale_of(ex);
+    const float unscale = split_unscale_of(ex) * split_unscale_of(ew);
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row = wave;                          // one output row of the tile per wave
+    const int g = lane >> 4, n = lane & 15;
+    const int n_cot = Cout / (NT8 * 16);
+    const size_t plane = (size_t)H * W;
+    const int cot = blockIdx.x % n_cot, grp = blockIdx.x / n_cot;
+    const int n_chunks = Cin / 16;
+    const uint4* wbase = wp + (size_t)cot * n_chunks * BCHUNK;
+    const int my_tiles = grp < n_spatial ? (n_spatial - grp + groups - 1) / groups : 0;
+    const int n_items = my_tiles * n_chunks;
+    if (n_items == 0) return;
+
+    auto b_dma = [&](int chunk, uint4* dst) {
+        constexpr int ROWS = STEPS * NT8 * NP;
+#pragma unroll
+        for (int i = 0; i < (ROWS + 7) / 8; ++i) {
+            const int r = wave + 8 * i;
+            if (r < ROWS)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(wbase + (size_t)chunk * BCHUNK + r * 64 + lane),
+                    (__attribute__((address_space(3))) void*)(dst + r * 64), 16, 0, 0);
+        }
+    };
+    auto tile_of = [&](int tile, int& b, int& y0, int& x0) {
+        int t = grp + tile * groups;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        b = t / tiles_y;
+        x0 = tx * TC; y0 = ty * TR8;
+    };
+    float apre[AU8][8];
+    int it_r[AU8], it_col[AU8], it_cell[AU8], it_plane[AU8];
+    bool it_in[AU8];
+#pragma unroll
+    for (int u = 0; u < AU8; ++u) {
+        const int item = min(tid + 512 * u, A_ITEMS8 - 1);
+        const int oct = item / CELLS8, rc = item - oct * CELLS8;
+        it_r[u] = rc / XCOLS;
+        it_col[u] = rc - it_r[u] * XCOLS;
+        it_in[u] = tid + 512 * u < A_ITEMS8;
+        it_cell[u] = oct * PLANE8 + rc;
+        it_plane[u] = oct * 8 * (int)plane;
+    }
+    int sb, sy0, sx0;                              // tile of the item being staged
+    auto a_issue = [&](int it) {
+        const int chunk = it % n_chunks;
+        if (chunk == 0) tile_of(it / n_chunks, sb, sy0, sx0);
+        const float* xc = x + ((size_t)sb * Cin + (size_t)chunk * 16) * plane;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xc, 0, (int)(16 * plane * sizeof(float)),
+                                                                            0x00020000);
+#pragma unroll
+        for (int u = 0; u < AU8; ++u) {
+            const int yc = min(max(sy0 + it_r[u] - 1, 0), H - 1), xcl = min(max(sx0 + it_col[u] - 1, 0), W - 1);
+            const int off = (it_plane[u] + yc * W + xcl) * (int)sizeof(float);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                apre[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                           rs, off, j * (int)plane * (int)sizeof(float), 0));
+        }
+    };
+    auto a_store = [&](uint4* dst) {               // the item a_issue() fetched last (same tile coordinates)
+#pragma unroll
+        for (int u = 0; u < AU8; ++u) {
+            if (it_in[u]) {
+                const int yy = sy0 + it_r[u] - 1, xx = sx0 + it_col[u] - 1;
+                const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                uint4 cells[NP];
+                split_cells8_masked<AR>(apre[u], ok, xscale, cells);            // zero padding / outside the tensor
+#pragma unroll
+                for (int p = 0; p < NP; ++p) dst[p * NOCT * PLANE8 + it_cell[u]] = cells[p];
+            }
+        }
+    };
+    // one K-step of a wave: its row's four pixel tiles x three channel tiles x the piece products (sb16_kstep on the 8-row image)
+    auto kstep = [&](const uint4* ap, const uint4* bp, f32x4 (&acc)[4][NT8]) {
+        typedef typename AR::frag_t frag_t;
+        frag_t a[4][NP];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) a[mt][p] = __builtin_bit_cast(frag_t, ap[p * NOCT * PLANE8 + 16 * mt]);
+#pragma unroll
+        for (int nt = 0; nt < NT8; ++nt) {
+            frag_t b[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(frag_t, bp[(nt * NP + p) * 64]);
+#pragma unroll
+            for (int t = 0; t < AR::NTERMS; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = AR::mfma(a[mt][AR::ta(t)], b[AR::tb(t)], acc[mt][nt]);
+        }
+    };
+
+    f32x4 acc[4][NT8];
+    a_issue(0);
+    if (RES) {
+        for (int c = 0; c < n_chunks; ++c) b_dma(c, Bs + (size_t)c * BCHUNK);
+    } else {
+        b_dma(0, Bs);
+    }
+    a_store(As);
+    __syncthreads();
+    int cb = sb, cy0 = sy0, cx0 = sx0;             // tile of the item being computed
+
+    const int a_lane_off = row * XCOLS + n;
+#pragma unroll 1
+    for (int it = 0; it < n_items; ++it) {
+        const int chunk = it % n_chunks;
+        const bool more = it + 1 < n_items;
+        if (chunk == 0) {
+            cb = sb; cy0 = sy0; cx0 = sx0;         // (the staged tile is still this item's: a_issue(it + 1) comes below)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT8; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (more) {
+            a_issue(it + 1);                                             // fp32 loads of the next item fly under the MFMAs below
+            if (!RES) b_dma((it + 1) % n_chunks, Bs + (size_t)((it + 1) & 1) * BCHUNK);   // that buffer was last read in item it - 1
+        }
+        const uint4* a_lane = As + (RES ? 0 : (size_t)(it & 1) * A_CELLS) + a_lane_off;
+        const uint4* b_base = (RES ? Bs + (size_t)chunk * BCHUNK : Bs + (size_t)(it & 1) * BCHUNK) + lane;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int tap = min(2 * s + (g >> 1), 8);                    // the tenth tap slot multiplies zero weights
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            kstep(a_lane + (g & 1) * PLANE8 + ky * XCOLS + kx, b_base + s * BSTEP, acc);
+        }
+        if (chunk == n_chunks - 1) {
+            const int yy = cy0 + row;
+            if (yy < H) {
+                float* ybc = y + (size_t)cb * Cout * plane;
+                const float* abc = addend ? addend + (size_t)cb * Cout * plane : nullptr;
+                const int co0 = cot * NT8 * 16;
+                sb16_store<NT8, NT8>(acc, ybc, bias, abc, co0, plane, yy, cx0, W, g, n, unscale);
+                if (stats) {
+                    const size_t seg = ((size_t)cb * H + yy) * tiles_x + cx0 / TC;
+                    cseg_stats_emit<NT8, NT8>(acc, bias, co0, unscale, cx0, W, g, n, stats + (size_t)co0 * n_seg + seg, n_seg);
+                }
+            }
+        }
+        if (RES) {
+            __syncthreads();                       // every wave is done with the one patch image
+            if (more) a_store(As);
+        } else if (more) {
+            a_store(As + (size_t)((it + 1) & 1) * A_CELLS);              // the other patch buffer: last read in item it - 1
+        }
+        __syncthreads();
+    }
+}
+
+template <class AR, bool RES>
+int launch_sb16r(const float* x, const uint4* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W,
+                 const unsigned* amax_x, const unsigned* amax_w, float* y, float4* stats, size_t lds, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)(conv3x3_sb16r_kernel<AR, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            cseg_set_error("conv3x3_sb16r: cannot raise dynamic LDS to %zu bytes", lds);
+            return 0;
+        }
+        attr_set = true;
+    }
+    const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + r8::TR8 - 1) / r8::TR8;
+    const int n_cot = Cout / (r8::NT8 * 16);
+    const long n_spatial = (long)B * tiles_y * tiles_x;
+    CSEG_REQUIRE(n_spatial < 2147483647L, "conv3x3_sb16r: too many tiles");
+    long groups = 256 / n_cot;
+    if (groups < 1) groups = 1;
+    if (groups > n_spatial) groups = n_spatial;
+    hipLaunchKernelGGL((conv3x3_sb16r_kernel<AR, RES>), dim3((unsigned)(groups * n_cot)), dim3(512), lds, stream, x, wp, bias, addend,
+                       Cin, Cout, H, W, tiles_x, tiles_y, (int)n_spatial, (int)groups, amax_x, amax_w, y, stats, B * H * tiles_x);
+    CSEG_CHECK_LAUNCH("conv3x3_sb16r_kernel");
+    return 1;
+}
+
+// the 8-row form: opt-in, f16x3, three channel tiles per block, and only where it still gives every CU a block
+bool sb16r_plan(int arith, int B, int Cin, int Cout, int H, int W, int NT, size_t& lds, bool& res) {
+    const char* e = getenv("CSEG_SB16_ROWS8");
+    if (!e || atoi(e) == 0 || arith != CSEG_ARITH_F16X3 || NT != 3) return false;
+    const long blocks = (long)B * ((H + 7) / 8) * ((W + TC - 1) / TC) * (Cout / 48);
+    if (blocks < 256 && atoi(e) < 2) return false;                       // (2: take it regardless, for experiments)
+    const size_t a = (size_t)2 * NOCT * r8::PLANE8 * sizeof(uint4);             // one patch image, two pieces
+    const size_t chunk = (size_t)STEPS * 3 * 2 * 64 * sizeof(uint4);
+    const size_t all = (size_t)(Cin / 16) * chunk;
+    const size_t cap = 160 * 1024;
+    if (a + all <= cap) { lds = a + all; res = true; return true; }
+    if (2 * a + 2 * chunk <= cap) { lds = 2 * a + 2 * chunk; res = false; return true; }
+    return false;
+}
+
 template <class AR, int NT>
 int launch_sb16(const float* x, const uint4* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W,
                 const unsigned* amax_x, const unsigned* amax_w, float* y, float4* stats, hipStream_t stream) {
@@ -993,6 +1227,9 @@ int fwd(const float* x, const void* wp, const float* bias, const float* addend, 
     const uint4* wq = (const uint4*)wp;
     size_t lds = 0;
     bool res = false;
+    if (sb16r_plan(arith, B, Cin, Cout, H, W, NT, lds, res))
+        return res ? launch_sb16r<SplitF16x3, true>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream)
+                   : launch_sb16r<SplitF16x3, false>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream);
     if (sb16p_plan(arith, Cin, NT, lds, res)) {
         const int pf = NT == 3 ? sb16q_distance() : 0;
         const char* fe = getenv("CSEG_SB16_FEAT");

@@ -96,8 +96,18 @@ static inline hipError_t hipGetLastError() { return emu::last_error(); }
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "emulated launch failure"; }
 template <class F>
 static inline hipError_t hipFuncSetAttribute(F, int, int bytes) { return bytes <= emu::LDS_BYTES ? hipSuccess : hipErrorLaunchFailure; }
+// CSEG_EMU_TRACE=<file>: one line per launch with the kernel expression as written at the launch site (which kernel a routing
+// switch really took -- tests assert on it)
+static inline void emu_trace_launch(const char* what) {
+    if (const char* path = getenv("CSEG_EMU_TRACE")) {
+        if (FILE* f = fopen(path, "a")) {
+            fprintf(f, "%s\n", what);
+            fclose(f);
+        }
+    }
+}
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
-    emu::launch((grid), (block), (lds), [=]() { kernel(__VA_ARGS__); })
+    (emu_trace_launch(#kernel), emu::launch((grid), (block), (lds), [=]() { kernel(__VA_ARGS__); }))
 
 // ---- device operations ---------------------------------------------------------------------------------------------------
 typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));

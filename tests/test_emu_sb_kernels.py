@@ -400,7 +400,7 @@ def test_epilogue_addend(case, arith, wave_order):
     ((1, 96, 48, 5, 68), "weights streamed through registers (6 chunks do not fit), ragged tiles"),
     ((2, 96, 48, 52, 640), "260 tiles, streamed weights across the tile boundary"),
 ])
-def test_deeper_prefetch_is_bit_identical_to_the_persistent_kernel(case, what, pf, feat, monkeypatch):
+def test_deeper_prefetch_is_bit_identical_to_the_persistent_kernel(case, what, pf, feat, monkeypatch, tmp_path):
     monkeypatch.setenv("CSEG_EMU_WAVE_ORDER", "shuffle:%s" % pf)
     B, ci, co, H, W = case
     x, w, b = _rand((B, ci, H, W), 81, 2.0), _rand((co, ci, 3, 3), 82, 1.0 / (3 * ci ** 0.5)), _rand((co,), 83)
@@ -409,6 +409,34 @@ def test_deeper_prefetch_is_bit_identical_to_the_persistent_kernel(case, what, p
     assert np.abs(y0 - ref).max() <= _bound(ref, 9 * ci), what
     monkeypatch.setenv("CSEG_SB16_PF", pf)
     monkeypatch.setenv("CSEG_SB16_FEAT", feat)      # 1: the 16-instruction split (same pieces, bit for bit)
+    trace = tmp_path / "launches.txt"
+    monkeypatch.setenv("CSEG_EMU_TRACE", str(trace))
     y1 = E.conv3x3_sb(x, w, b, arith=E.F16X3)
+    assert "conv3x3_sb16q_kernel" in trace.read_text(), "the switch did not route to the opt-in kernel"
     assert not np.isnan(y1).any()
     assert np.array_equal(y0, y1), "same LDS images, same K-steps, same accumulation order: bit-identical (%s)" % what
+
+
+# ---- round 4 (opt-in, CSEG_SB16_ROWS8): 8 x 64-pixel tiles, one wave per output row x three channel tiles (conv3x3_sb16r_kernel) ----
+@pytest.mark.parametrize("case,what", [
+    ((1, 48, 48, 11, 68), "weights resident + ONE patch buffer (two barriers per chunk), ragged tiles both ways (11 rows, 68 columns)"),
+    ((2, 16, 48, 8, 64), "one chunk per tile, exact tiles"),
+    ((1, 32, 48, 208, 640), "260 tiles on 256 blocks: some blocks walk two tiles with the weights resident"),
+    ((1, 96, 48, 9, 68), "weights streamed (6 chunks do not fit), two patch buffers, ragged tiles"),
+    ((2, 96, 96, 104, 640), "two channel tile groups, 260 tiles each on 128 blocks: streamed weights across tile boundaries"),
+])
+def test_eight_row_tiles_are_bit_identical_to_the_four_row_kernels(case, what, monkeypatch, tmp_path):
+    monkeypatch.setenv("CSEG_EMU_WAVE_ORDER", "shuffle:5")
+    monkeypatch.setenv("CSEG_CONV3X3_SB16_CH", "48,96")            # 96 output channels on the 16-channel-chunk kernels too (3 tiles per block)
+    B, ci, co, H, W = case
+    x, w, b = _rand((B, ci, H, W), 91, 2.0), _rand((co, ci, 3, 3), 92, 1.0 / (3 * ci ** 0.5)), _rand((co,), 93)
+    y0 = E.conv3x3_sb(x, w, b, arith=E.F16X3)
+    ref = E.ref_conv3x3(x, w, b)
+    assert np.abs(y0 - ref).max() <= _bound(ref, 9 * ci), what
+    monkeypatch.setenv("CSEG_SB16_ROWS8", "2")                     # 2: also where the 8-row tiles do not fill 256 blocks
+    trace = tmp_path / "launches.txt"
+    monkeypatch.setenv("CSEG_EMU_TRACE", str(trace))
+    y1 = E.conv3x3_sb(x, w, b, arith=E.F16X3)
+    assert "conv3x3_sb16r_kernel" in trace.read_text(), "the switch did not route to the 8-row kernel"
+    assert not np.isnan(y1).any()
+    assert np.array_equal(y0, y1), "same packed weights, same K-steps, same accumulation order per output element (%s)" % what
