@@ -708,8 +708,10 @@ int sb16q_distance() {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Round 4, opt-in (CSEG_SB16_ROWS8=1; first hardware timing pending): the persistent kernel on 8 x 64-pixel tiles, ONE WAVE PER
-// OUTPUT ROW x all three channel tiles. Why: on 4 x 64 tiles the two halves of a block split the CHANNEL
+// Round 4, default where 8-row tiles still give every CU a block (CSEG_SB16_ROWS8=0 switches it off): the persistent kernel on
+// 8 x 64-pixel tiles, ONE WAVE PER OUTPUT ROW x all three channel tiles. Measured (tools/probes/conv_probe, profiles/
+// r04_rows8_probe.jsonl): 8 x 48 x 128 x 256 forward with statistics 52.0 -> 46.9 us, plain 48.8 -> 43.8, output bit-identical on
+// the MI355X; at 192 / 384 channels (128 blocks of 8-row tiles) it would lose (60 vs 45, 106 vs 78 us) and is not taken. Why: on 4 x 64 tiles the two halves of a block split the CHANNEL
 // tiles and both read the row's pixel fragments -- 22 ds_read_b128 per 36 MFMAs, 704 LDS cycles per K-step against 576 of MFMA
 // issue; the K-steps of the 48-channel layers take 17-19 us where the MFMAs need 13. Here a wave reads its row's four pixel tiles
 // and the three channel tiles once per K-step: 14 reads per 36 MFMAs (448 cycles), and the halo of a tile is 1.29 x instead of
@@ -926,12 +928,13 @@ int launch_sb16r(const float* x, const uint4* wp, const float* bias, const float
     return 1;
 }
 
-// the 8-row form: opt-in, f16x3, three channel tiles per block, and only where it still gives every CU a block
+// the 8-row form: f16x3, three channel tiles per block, and only where it still gives every CU a block
 bool sb16r_plan(int arith, int B, int Cin, int Cout, int H, int W, int NT, size_t& lds, bool& res) {
     const char* e = getenv("CSEG_SB16_ROWS8");
-    if (!e || atoi(e) == 0 || arith != CSEG_ARITH_F16X3 || NT != 3) return false;
+    const int mode = e ? atoi(e) : 1;                                    // 0: off, 1 (default): where it fills the chip, 2: wherever it fits
+    if (mode == 0 || arith != CSEG_ARITH_F16X3 || NT != 3) return false;
     const long blocks = (long)B * ((H + 7) / 8) * ((W + TC - 1) / TC) * (Cout / 48);
-    if (blocks < 256 && atoi(e) < 2) return false;                       // (2: take it regardless, for experiments)
+    if (blocks < 256 && mode < 2) return false;
     const size_t a = (size_t)2 * NOCT * r8::PLANE8 * sizeof(uint4);             // one patch image, two pieces
     const size_t chunk = (size_t)STEPS * 3 * 2 * 64 * sizeof(uint4);
     const size_t all = (size_t)(Cin / 16) * chunk;
@@ -1227,7 +1230,7 @@ int fwd(const float* x, const void* wp, const float* bias, const float* addend, 
     const uint4* wq = (const uint4*)wp;
     size_t lds = 0;
     bool res = false;
-    if (sb16r_plan(arith, B, Cin, Cout, H, W, NT, lds, res))
+    if (sb16q_distance() == 0 && sb16r_plan(arith, B, Cin, Cout, H, W, NT, lds, res))      // (the experimental kernel, when asked for, goes first)
         return res ? launch_sb16r<SplitF16x3, true>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream)
                    : launch_sb16r<SplitF16x3, false>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream);
     if (sb16p_plan(arith, Cin, NT, lds, res)) {

@@ -376,18 +376,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             if (xi_ok[u]) {
-                // f16x3: the zero padding is folded into the scale (v * 0 = +-0 for the finite values the clamped address fetched)
-                const bool in_img = xu_ok[u] && row_ok;
-                const bool fold = AR::ID == CSEG_ARITH_F16X3 && !(ABL & 2);
-                const float4 t = (fold || in_img) ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float xs_u = (fold && !in_img) ? 0.f : xscale;
+                const float4 t = (xu_ok[u] && row_ok) ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 cells[NP];
                 if (ABL & 2) {
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
                         cells[p] = make_uint2(__builtin_bit_cast(unsigned, t.x) >> 16 | (__builtin_bit_cast(unsigned, t.y) & 0xffff0000u),
                                               __builtin_bit_cast(unsigned, t.z) >> 16 | (__builtin_bit_cast(unsigned, t.w) & 0xffff0000u));
-                } else split_cells4<AR>(t, xs_u, cells);
+                } else split_cells4<AR>(t, xscale, cells);
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
                     *reinterpret_cast<uint2*>(xs + xi_lds[u] + p * CI_B * x2_ch(NP, SEGW) + slot * x2_slot(NP, SEGW)) = cells[p];

@@ -109,15 +109,16 @@ struct SplitF16x3 {
 };
 
 __device__ __forceinline__ void split_cells8_f16_lean(const float (&v)[8], float scale, uint4 (&out)[2]);
-__device__ __forceinline__ void split_cells4_f16_lean(const float4& v, float scale, uint2 (&out)[2]);
 
 // eight values -> AR::NP cells of 16 bytes (element j of piece p in half-word j of out[p])
 template <class AR>
 __device__ __forceinline__ void split_cells8(const float (&v)[8], float scale, uint4 (&out)[AR::NP]) {
+#ifndef CSEG_SPLIT_CLASSIC                                  // (A/B builds of the library only: the compiler's own instruction choice)
     if constexpr (AR::ID == CSEG_ARITH_F16X3) {            // round 4: the 16-instruction form below, the same pieces bit for bit
         split_cells8_f16_lean(v, scale, out);
         return;
     }
+#endif
     unsigned d[4][AR::NP];
 #pragma unroll
     for (int j = 0; j < 4; ++j) AR::split2(v[2 * j], v[2 * j + 1], scale, d[j]);
@@ -158,23 +159,16 @@ __device__ __forceinline__ void split_cells8_f16_lean(const float (&v)[8], float
     out[1] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
-__device__ __forceinline__ void split_cells4_f16_lean(const float4& v, float scale, uint2 (&out)[2]) {
-    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-    typedef float f2_t __attribute__((ext_vector_type(2)));
-    const f2_t t0 = (f2_t){v.x, v.y} * scale, t1 = (f2_t){v.z, v.w} * scale;
-    const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(t0, h2_t));
-    const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(t1, h2_t));
-    out[0] = make_uint2(h0, h1);
-    out[1] = make_uint2(split_lo_pair_f16(v.x, v.y, scale, h0), split_lo_pair_f16(v.z, v.w, scale, h1));
-}
-
 // eight values of ONE pixel that may lie outside the image (`ok` false: all pieces zero). f16x3 folds the mask into the scale
 // (v * 0 = +-0 for the finite values a clamped address fetched -- one select instead of eight); the unscaled bf16x6 masks the values.
 template <class AR>
 __device__ __forceinline__ void split_cells8_masked(const float (&v)[8], bool ok, float scale, uint4 (&out)[AR::NP]) {
+#ifndef CSEG_SPLIT_CLASSIC
     if constexpr (AR::ID == CSEG_ARITH_F16X3) {
         split_cells8_f16_lean(v, ok ? scale : 0.f, out);
-    } else {
+    } else
+#endif
+    {
         float m[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) m[j] = ok ? v[j] : 0.f;
@@ -185,10 +179,9 @@ __device__ __forceinline__ void split_cells8_masked(const float (&v)[8], bool ok
 // four values -> AR::NP cells of 8 bytes
 template <class AR>
 __device__ __forceinline__ void split_cells4(const float4& v, float scale, uint2 (&out)[AR::NP]) {
-    if constexpr (AR::ID == CSEG_ARITH_F16X3) {
-        split_cells4_f16_lean(v, scale, out);
-        return;
-    }
+    // (the fma_mix form of split_cells8 was tried here too and made the weight gradients 6-7 % SLOWER -- their loader waves stage
+    // underneath the consumers' MFMAs, and there the mixed-precision FMAs cost more than the packed sequence the compiler picks:
+    // 50.3 vs 46.9 us at 48 channels, 6.49 vs 6.13 ms at 720, A/B/A/B on one box, profiles/r04_split_ab.jsonl)
     unsigned d[2][AR::NP];
     AR::split2(v.x, v.y, scale, d[0]);
     AR::split2(v.z, v.w, scale, d[1]);

@@ -417,7 +417,7 @@ def test_deeper_prefetch_is_bit_identical_to_the_persistent_kernel(case, what, p
     assert np.array_equal(y0, y1), "same LDS images, same K-steps, same accumulation order: bit-identical (%s)" % what
 
 
-# ---- round 4 (opt-in, CSEG_SB16_ROWS8): 8 x 64-pixel tiles, one wave per output row x three channel tiles (conv3x3_sb16r_kernel) ----
+# ---- round 4 (CSEG_SB16_ROWS8; default where the tiles fill 256 blocks): 8 x 64-pixel tiles, one wave per output row x three channel tiles (conv3x3_sb16r_kernel) ----
 @pytest.mark.parametrize("case,what", [
     ((1, 48, 48, 11, 68), "weights resident + ONE patch buffer (two barriers per chunk), ragged tiles both ways (11 rows, 68 columns)"),
     ((2, 16, 48, 8, 64), "one chunk per tile, exact tiles"),
@@ -430,6 +430,7 @@ def test_eight_row_tiles_are_bit_identical_to_the_four_row_kernels(case, what, m
     monkeypatch.setenv("CSEG_CONV3X3_SB16_CH", "48,96")            # 96 output channels on the 16-channel-chunk kernels too (3 tiles per block)
     B, ci, co, H, W = case
     x, w, b = _rand((B, ci, H, W), 91, 2.0), _rand((co, ci, 3, 3), 92, 1.0 / (3 * ci ** 0.5)), _rand((co,), 93)
+    monkeypatch.setenv("CSEG_SB16_ROWS8", "0")                     # the 4-row kernels
     y0 = E.conv3x3_sb(x, w, b, arith=E.F16X3)
     ref = E.ref_conv3x3(x, w, b)
     assert np.abs(y0 - ref).max() <= _bound(ref, 9 * ci), what

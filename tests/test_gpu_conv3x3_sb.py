@@ -247,3 +247,37 @@ def test_basic_block_with_fused_identity_gradient(case, monkeypatch):
         scale = float(ref.abs().max())
         assert float((a.double() - ref).abs().max()) <= 2e-4 * scale, (case, name)
         assert float((a - p).abs().max()) <= 2e-5 * scale, (case, name, "fused vs plain")
+
+
+def test_eight_row_tiles_on_hardware(monkeypatch):
+    """conv3x3_sb16r_kernel (8 x 64-pixel tiles, one wave per output row, default where the tiles fill 256 blocks -- the 48-channel
+    branches at the benched batch): forward with bias, the BatchNorm statistics of its epilogue, and backward-data with the residual
+    addend, against the 4-row kernels on the same operands (bit-identical: same packed weights, same accumulation order) and against
+    fp64. 6 x 48 x 68 x 264: 270 tiles of 8 rows, ragged in both directions."""
+    from contrastiveseg_amd import kernels as K
+    B, C, H, W = 6, 48, 68, 264
+    x, w, b = _inputs(B, C, C, H, W, seed=7)
+    x = x.relu()
+    addend = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(8))
+    xd, wd, bd, ad = x.cuda(), w.cuda(), b.cuda(), addend.cuda()
+
+    def run(rows8):
+        monkeypatch.setenv("CSEG_SB16_ROWS8", rows8)
+        y = K.conv3x3_sb_run(xd, wd, False, bd, want_stats=True)
+        st = K.known_tile_stats(y)
+        dx = K.conv3x3_sb_run(xd, wd, True, None, addend=ad)           # backward-data operator (transposed, flipped) + epilogue addend
+        return y, (None if st is None else st.clone()), dx
+
+    y8, st8, dx8 = run("1")
+    y4, st4, dx4 = run("0")
+    assert torch.equal(y8, y4) and torch.equal(dx8, dx4), "8-row and 4-row kernels must agree bit for bit"
+    if st8 is not None and st4 is not None:
+        assert st8.shape == st4.shape and float((st8 - st4).abs().max()) <= 1e-5 * float(st4.abs().max())
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    fp32 = F.conv2d(xd, wd, bd, 1, 1).cpu()
+    err, tol = _bound(ref, y8.cpu(), fp32)
+    assert err <= tol, (err, tol)
+    ref_dx = F.conv_transpose2d(x.double(), w.double(), None, 1, 1) + addend.double()
+    fp32_dx = (F.conv_transpose2d(xd, wd, None, 1, 1) + ad).cpu()
+    err, tol = _bound(ref_dx, dx8.cpu(), fp32_dx)
+    assert err <= tol, ("backward-data", err, tol)

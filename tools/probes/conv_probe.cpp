@@ -2,7 +2,7 @@
 // instead of the minutes a Python process needs to import torch, so that kernel variants can be compared within a small budget.
 //   g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tools/probes/conv_probe.cpp -o tools/probes/conv_probe \
 //       -L/opt/rocm/lib -lamdhip64 -ldl
-//   tools/probes/conv_probe [--shape B,C,H,W]... [--variant 'name:KEY=VAL;KEY=VAL']... [--wrw] [--iters N]
+//   tools/probes/conv_probe [--shape B,C,H,W]... [--variant 'name:KEY=VAL;KEY=VAL']... [--wrw] [--iters N] [--nt N]
 // For every shape: x (non-negative, like an activation) and w are generated on the host, max|.| records and packed weights are
 // made by the library, then every variant (a set of environment switches the library reads per call) is timed with HIP events:
 // forward with the BatchNorm statistics epilogue (`fwd_st`), plain forward (`fwd`), optionally the weight gradient. The output of
@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
     std::vector<Shape> shapes;
     std::vector<Variant> variants;
     bool wrw = false;
-    int iters = 20;
+    int iters = 20, nt = 0;
     std::vector<std::string> keys;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -96,6 +96,7 @@ int main(int argc, char** argv) {
             variants.push_back(var);
         } else if (a == "--wrw") wrw = true;
         else if (a == "--iters" && i + 1 < argc) iters = atoi(argv[++i]);
+        else if (a == "--nt" && i + 1 < argc) nt = atoi(argv[++i]);          // channel tiling of pack + forward (265 = CSEG_NT_SB8: the head kernel)
     }
     if (shapes.empty()) shapes = {{8, 48, 128, 256}, {8, 96, 64, 128}, {8, 192, 32, 64}, {8, 384, 16, 32}};
     if (variants.empty()) variants.push_back({"default", {}});
@@ -166,10 +167,10 @@ int main(int argc, char** argv) {
             for (const auto& k : keys) unsetenv(k.c_str());
             for (const auto& kv : v.env) setenv(kv.first.c_str(), kv.second.c_str(), 1);
             // pack under the variant's switches too (pack and forward of one operator must agree on the tiling)
-            if (!p_pack(w, s.C, s.C, 0, 0, CSEG_ARITH_F16X3, aw, wp, st)) { fprintf(stderr, "pack: %s\n", p_err()); return 2; }
+            if (!p_pack(w, s.C, s.C, 0, nt, CSEG_ARITH_F16X3, aw, wp, st)) { fprintf(stderr, "pack: %s\n", p_err()); return 2; }
             bool ok = true;
-            auto f_st = [&]() { ok = ok && p_fwd_st(x, wp, nullptr, s.B, s.C, s.C, s.H, s.W, 0, CSEG_ARITH_F16X3, ax, aw, y, stats, st); };
-            auto f_pl = [&]() { ok = ok && p_fwd(x, wp, nullptr, s.B, s.C, s.C, s.H, s.W, 0, CSEG_ARITH_F16X3, ax, aw, y, st); };
+            auto f_st = [&]() { ok = ok && p_fwd_st(x, wp, nullptr, s.B, s.C, s.C, s.H, s.W, nt, CSEG_ARITH_F16X3, ax, aw, y, stats, st); };
+            auto f_pl = [&]() { ok = ok && p_fwd(x, wp, nullptr, s.B, s.C, s.C, s.H, s.W, nt, CSEG_ARITH_F16X3, ax, aw, y, st); };
             HIPCHECK(hipMemsetAsync(y, 0, n * 4, st));
             const double us_st = time_us(f_st, iters, st);
             const double us_pl = time_us(f_pl, iters, st);
