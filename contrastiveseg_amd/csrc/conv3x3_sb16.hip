@@ -260,7 +260,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
                                                                int tiles_x, int tiles_y, int n_spatial, int groups,
                                                                const unsigned* __restrict__ amax_x,
                                                                const unsigned* __restrict__ amax_w, float* __restrict__ y,
-                                                               float4* __restrict__ stats, int n_seg) {
+                                                               float4* __restrict__ stats, int n_seg, int xmap) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s16p[];
     constexpr int NP = AR::NP;
     constexpr int A_CELLS = NP * NOCT * PLANE;
@@ -278,10 +278,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
     const int g = lane >> 4, n = lane & 15;
     const int n_cot = Cout / (NT * 16);
     const size_t plane = (size_t)H * W;
-    const int cot = blockIdx.x % n_cot, grp = blockIdx.x / n_cot;      // this block: spatial tiles grp, grp + groups, ...
+    // this block: channel tile group `cot`, spatial tiles t_first, t_first + t_step, ... < t_end. Plain order: tiles grp, grp + groups,
+    // ... XCD-aware order (xmap, round 4; needs groups % 8 == 0): block b runs on XCD b % 8 (observed on gfx950; only speed depends
+    // on it) -- the tile list is cut into 8 contiguous ranges, one per XCD, and the n_cot blocks of a tile sit on the SAME XCD: the
+    // patch of a tile is fetched through the fabric once instead of n_cot times, halos of neighbouring tiles and the streamed
+    // weights of a channel tile group meet in that XCD's L2.
+    int cot = blockIdx.x % n_cot, grp = blockIdx.x / n_cot;
+    int t_first = grp, t_step = groups, t_end = n_spatial;
+    if (xmap) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = (n_spatial + 7) / 8;
+        cot = idx % n_cot;
+        t_first = xcd * per + idx / n_cot;
+        t_step = groups >> 3;
+        t_end = min((xcd + 1) * per, n_spatial);
+    }
     const int n_chunks = Cin / 16;
     const uint4* wbase = wp + (size_t)cot * n_chunks * BCHUNK;
-    const int my_tiles = grp < n_spatial ? (n_spatial - grp + groups - 1) / groups : 0;
+    const int my_tiles = t_first < t_end ? (t_end - t_first + t_step - 1) / t_step : 0;
     const int n_items = my_tiles * n_chunks;
     if (n_items == 0) return;
 
@@ -297,7 +310,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
         }
     };
     auto tile_of = [&](int tile, int& b, int& y0, int& x0) {      // tile = index of one of this block's spatial tiles
-        int t = grp + tile * groups;
+        int t = t_first + tile * t_step;
         const int tx = t % tiles_x; t /= tiles_x;
         const int ty = t % tiles_y;
         b = t / tiles_y;
@@ -415,6 +428,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
     }
 }
 
+// CUs a persistent launch spreads its blocks over (one block per CU). CSEG_PERSIST_CUS < 256 leaves the rest of the chip to a
+// kernel of another stream (experiments with side-by-side branch kernels, tools/probes/conv_probe --pair).
+long persist_cus() {
+    const char* e = getenv("CSEG_PERSIST_CUS");
+    const long c = e ? atol(e) : 256;
+    return c < 8 ? 8 : (c > 256 ? 256 : c);
+}
+
+// XCD-aware tile order of the persistent kernels: CSEG_SB16_XCD (default 1), possible when the tile groups divide over the 8 XCDs
+int xcd_order(long groups) {
+    const char* e = getenv("CSEG_SB16_XCD");
+    return (!e || atoi(e) != 0) && groups % 8 == 0 ? 1 : 0;
+}
+
 template <class AR, int NT, bool RES>
 int launch_sb16p(const float* x, const uint4* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W,
                  const unsigned* amax_x, const unsigned* amax_w, float* y, float4* stats, size_t lds, hipStream_t stream) {
@@ -431,11 +458,12 @@ int launch_sb16p(const float* x, const uint4* wp, const float* bias, const float
     const int n_cot = Cout / (NT * 16);
     const long n_spatial = (long)B * tiles_y * tiles_x;
     CSEG_REQUIRE(n_spatial < 2147483647L, "conv3x3_sb16p: too many tiles");
-    long groups = 256 / n_cot;                       // one block per CU: 256 CUs shared by the channel tile groups
+    long groups = persist_cus() / n_cot;                       // one block per CU: 256 CUs shared by the channel tile groups
     if (groups < 1) groups = 1;
     if (groups > n_spatial) groups = n_spatial;
     hipLaunchKernelGGL((conv3x3_sb16p_kernel<AR, NT, RES>), dim3((unsigned)(groups * n_cot)), dim3(512), lds, stream, x, wp, bias,
-                       addend, Cin, Cout, H, W, tiles_x, tiles_y, (int)n_spatial, (int)groups, amax_x, amax_w, y, stats, B * H * tiles_x);
+                       addend, Cin, Cout, H, W, tiles_x, tiles_y, (int)n_spatial, (int)groups, amax_x, amax_w, y, stats, B * H * tiles_x,
+                       xcd_order(groups));
     CSEG_CHECK_LAUNCH("conv3x3_sb16p_kernel");
     return 1;
 }
@@ -689,7 +717,7 @@ int launch_sb16q(const float* x, const uint4* wp, const float* bias, const float
     const int n_cot = Cout / (NT * 16);
     const long n_spatial = (long)B * tiles_y * tiles_x;
     CSEG_REQUIRE(n_spatial < 2147483647L, "conv3x3_sb16q: too many tiles");
-    long groups = 256 / n_cot;
+    long groups = persist_cus() / n_cot;
     if (groups < 1) groups = 1;
     if (groups > n_spatial) groups = n_spatial;
     const char* abl = getenv("CSEG_ABLATE");
@@ -738,7 +766,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16r_kernel(const float* __re
                                                                int tiles_x, int tiles_y, int n_spatial, int groups,
                                                                const unsigned* __restrict__ amax_x,
                                                                const unsigned* __restrict__ amax_w, float* __restrict__ y,
-                                                               float4* __restrict__ stats, int n_seg) {
+                                                               float4* __restrict__ stats, int n_seg, int xmap) {
     using namespace r8;
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s16r[];
     constexpr int NP = AR::NP;
@@ -760,7 +788,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16r_kernel(const float* __re
     const int cot = blockIdx.x % n_cot, grp = blockIdx.x / n_cot;
     const int n_chunks = Cin / 16;
     const uint4* wbase = wp + (size_t)cot * n_chunks * BCHUNK;
-    const int my_tiles = grp < n_spatial ? (n_spatial - grp + groups - 1) / groups : 0;
+    // Which tiles a block walks. Plain order: tiles grp, grp + groups, ... -- the blocks running at any moment cover consecutive
+    // tiles, but block b runs on XCD b % 8 (observed on gfx950; only speed depends on it), so neither the horizontal nor the
+    // vertical neighbour of a tile (4 tiles further at 256 columns) shares its XCD's L2, and every halo row is fetched through the
+    // fabric again. xmap (default; one channel tile group, groups % 8 == 0): the tile list is cut into 8 contiguous ranges, one per XCD, and
+    // the 32 blocks of an XCD walk their range side by side -- halos of neighbouring tiles meet in that XCD's L2.
+    int t_first = grp, t_step = groups, t_end = n_spatial;
+    if (xmap) {                                    // (as in conv3x3_sb16p_kernel; this kernel runs with one channel tile group)
+        const int xcd = grp & 7, idx = grp >> 3, per = (n_spatial + 7) / 8;
+        t_first = xcd * per + idx;
+        t_step = groups >> 3;
+        t_end = min((xcd + 1) * per, n_spatial);
+    }
+    const int my_tiles = t_first < t_end ? (t_end - t_first + t_step - 1) / t_step : 0;
     const int n_items = my_tiles * n_chunks;
     if (n_items == 0) return;
 
@@ -776,7 +816,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16r_kernel(const float* __re
         }
     };
     auto tile_of = [&](int tile, int& b, int& y0, int& x0) {
-        int t = grp + tile * groups;
+        int t = t_first + tile * t_step;
         const int tx = t % tiles_x; t /= tiles_x;
         const int ty = t % tiles_y;
         b = t / tiles_y;
@@ -919,11 +959,12 @@ int launch_sb16r(const float* x, const uint4* wp, const float* bias, const float
     const int n_cot = Cout / (r8::NT8 * 16);
     const long n_spatial = (long)B * tiles_y * tiles_x;
     CSEG_REQUIRE(n_spatial < 2147483647L, "conv3x3_sb16r: too many tiles");
-    long groups = 256 / n_cot;
+    long groups = persist_cus() / n_cot;
     if (groups < 1) groups = 1;
     if (groups > n_spatial) groups = n_spatial;
+    const int xmap = n_cot == 1 ? xcd_order(groups) : 0;
     hipLaunchKernelGGL((conv3x3_sb16r_kernel<AR, RES>), dim3((unsigned)(groups * n_cot)), dim3(512), lds, stream, x, wp, bias, addend,
-                       Cin, Cout, H, W, tiles_x, tiles_y, (int)n_spatial, (int)groups, amax_x, amax_w, y, stats, B * H * tiles_x);
+                       Cin, Cout, H, W, tiles_x, tiles_y, (int)n_spatial, (int)groups, amax_x, amax_w, y, stats, B * H * tiles_x, xmap);
     CSEG_CHECK_LAUNCH("conv3x3_sb16r_kernel");
     return 1;
 }

@@ -422,6 +422,7 @@ def test_deeper_prefetch_is_bit_identical_to_the_persistent_kernel(case, what, p
     ((1, 48, 48, 11, 68), "weights resident + ONE patch buffer (two barriers per chunk), ragged tiles both ways (11 rows, 68 columns)"),
     ((2, 16, 48, 8, 64), "one chunk per tile, exact tiles"),
     ((1, 32, 48, 208, 640), "260 tiles on 256 blocks: some blocks walk two tiles with the weights resident"),
+    ((3, 16, 48, 100, 640), "390 tiles: XCD ranges of 49 tiles, the last one short (47), blocks with one and with two tiles"),
     ((1, 96, 48, 9, 68), "weights streamed (6 chunks do not fit), two patch buffers, ragged tiles"),
     ((2, 96, 96, 104, 640), "two channel tile groups, 260 tiles each on 128 blocks: streamed weights across tile boundaries"),
 ])
@@ -441,3 +442,6 @@ def test_eight_row_tiles_are_bit_identical_to_the_four_row_kernels(case, what, m
     assert "conv3x3_sb16r_kernel" in trace.read_text(), "the switch did not route to the 8-row kernel"
     assert not np.isnan(y1).any()
     assert np.array_equal(y0, y1), "same packed weights, same K-steps, same accumulation order per output element (%s)" % what
+    monkeypatch.setenv("CSEG_SB16_XCD", "1")                       # XCD-contiguous tile order (one channel tile group only): every tile once
+    y2 = E.conv3x3_sb(x, w, b, arith=E.F16X3)
+    assert np.array_equal(y0, y2), "the XCD-aware tile order must compute every tile exactly once (%s)" % what

@@ -69,7 +69,7 @@ static double time_us(Fn&& fn, int iters, hipStream_t st) {
 int main(int argc, char** argv) {
     std::vector<Shape> shapes;
     std::vector<Variant> variants;
-    bool wrw = false;
+    bool wrw = false, pair = false;
     int iters = 20, nt = 0;
     std::vector<std::string> keys;
     for (int i = 1; i < argc; ++i) {
@@ -96,6 +96,7 @@ int main(int argc, char** argv) {
             variants.push_back(var);
         } else if (a == "--wrw") wrw = true;
         else if (a == "--iters" && i + 1 < argc) iters = atoi(argv[++i]);
+        else if (a == "--pair") pair = true;          // also: two launches side by side on two streams (own outputs), wall clock per pair
         else if (a == "--nt" && i + 1 < argc) nt = atoi(argv[++i]);          // channel tiling of pack + forward (265 = CSEG_NT_SB8: the head kernel)
     }
     if (shapes.empty()) shapes = {{8, 48, 128, 256}, {8, 96, 64, 128}, {8, 192, 32, 64}, {8, 384, 16, 32}};
@@ -182,6 +183,37 @@ int main(int argc, char** argv) {
                 maxdiff = std::max(maxdiff, (double)std::fabs(hy[i] - hy0[i]));
                 maxabs = std::max(maxabs, (double)std::fabs(hy0[i]));
             }
+            double us_pair = -1.0;
+            if (pair) {
+                static hipStream_t st2 = nullptr;
+                static float* y2 = nullptr;
+                static size_t y2n = 0;
+                if (!st2) HIPCHECK(hipStreamCreate(&st2));
+                if (y2n < n) { if (y2) HIPCHECK(hipFree(y2)); HIPCHECK(hipMalloc(&y2, n * 4)); y2n = n; }
+                auto both = [&]() {
+                    ok = ok && p_fwd(x, wp, nullptr, s.B, s.C, s.C, s.H, s.W, nt, CSEG_ARITH_F16X3, ax, aw, y, st);
+                    ok = ok && p_fwd(x, wp, nullptr, s.B, s.C, s.C, s.H, s.W, nt, CSEG_ARITH_F16X3, ax, aw, y2, st2);
+                };
+                for (int i = 0; i < 3; ++i) both();
+                HIPCHECK(hipDeviceSynchronize());
+                us_pair = 1e30;
+                for (int r = 0; r < 3; ++r) {
+                    hipEvent_t e0, e1, e2;
+                    HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1)); HIPCHECK(hipEventCreate(&e2));
+                    HIPCHECK(hipEventRecord(e0, st));
+                    HIPCHECK(hipStreamWaitEvent(st2, e0, 0));            // both streams start together
+                    for (int i = 0; i < iters; ++i) both();
+                    HIPCHECK(hipEventRecord(e2, st2));
+                    HIPCHECK(hipStreamWaitEvent(st, e2, 0));             // ... and the clock stops when both are done
+                    HIPCHECK(hipEventRecord(e1, st));
+                    HIPCHECK(hipEventSynchronize(e1));
+                    float ms = 0.f;
+                    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+                    us_pair = std::min(us_pair, (double)ms * 1e3 / iters);
+                    HIPCHECK(hipEventDestroy(e0)); HIPCHECK(hipEventDestroy(e1)); HIPCHECK(hipEventDestroy(e2));
+                }
+                if (!ok) { fprintf(stderr, "pair (%s): %s\n", v.name.c_str(), p_err()); return 2; }
+            }
             double us_wrw = -1.0, wdiff = 0.0;
             if (wrw) {
                 auto f_w = [&]() { ok = ok && p_wrw(x, dy, s.B, s.C, s.C, s.H, s.W, CSEG_ARITH_F16X3, ax, ady, wsb, dw, st); };
@@ -196,6 +228,7 @@ int main(int argc, char** argv) {
                    "\"max_abs_diff_vs_first\": %.3g, \"max_abs_out\": %.3g",
                    s.B, s.C, s.H, s.W, v.name.c_str(), us_st, us_pl, gf / us_st * 1e-3, maxdiff, maxabs);
             if (wrw) printf(", \"wrw_us\": %.1f, \"wrw_max_abs_diff_vs_first\": %.3g", us_wrw, wdiff);
+            if (pair) printf(", \"pair_us\": %.1f", us_pair);
             printf("}\n");
             fflush(stdout);
             first = false;
