@@ -621,7 +621,8 @@ def timed_steps(tr, batch, steps, warmup, world, device):
 # at one image per GPU): if a run with them dies or ends with a non-finite loss, the measurement is repeated ONCE with the configuration
 # of the round-3 closing tree (one stream, statistics pass, four nodes per block, eager), and the line says so in config.route_fallback.
 # Off with CSEG_BENCH_GUARD=0 (e.g. under rocprofv3), and never applied when the caller chose one of these routes explicitly.
-SAFE_ROUTES = {"CSEG_BRANCH_STREAMS": "0", "CSEG_CONV_STATS": "0", "CSEG_BLOCK_FUSED": "0", "CSEG_STEP_GRAPH": "0"}
+SAFE_ROUTES = {"CSEG_BRANCH_STREAMS": "0", "CSEG_CONV_STATS": "0", "CSEG_BLOCK_FUSED": "0", "CSEG_STEP_GRAPH": "0",
+               "CSEG_SB16_ROWS8": "0", "CSEG_SB16_XCD": "0"}      # (+ the 4-row tiles and plain tile order of the persistent 3x3 kernels)
 
 
 def guard_enabled():

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
                                                             int W, int tiles_x, int tiles_y,
                                                             const unsigned* __restrict__ amax_x,
                                                             const unsigned* __restrict__ amax_w, float* __restrict__ y,
-                                                            float4* __restrict__ stats, int n_seg) {
+                                                            float4* __restrict__ stats, int n_seg, int xmap) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_sb[];
     constexpr int NP = AR::NP;
     constexpr int A_CELLS = NP * 4 * PLANE;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
     const int g = lane >> 4, n = lane & 15;
     const int n_cot = Cout / (NT * 16);
     const size_t plane = (size_t)H * W;
-    int t = blockIdx.x;
+    int t = cseg_xcd_block(blockIdx.x, gridDim.x, xmap);
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y; t /= tiles_y;
     const int cot = t % n_cot;
@@ -465,7 +465,7 @@ int launch_sb(const float* x, const uint4* wp, const float* bias, const float* a
     const long n_tiles = (long)B * (Cout / (NT * 16)) * tiles_y * tiles_x;
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb: grid too large");
     hipLaunchKernelGGL((conv3x3_sb_kernel<AR, NT, GLDS, VAR, ABL, SPS>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, addend, Cin, Cout, H, W, tiles_x,
-                       tiles_y, amax_x, amax_w, y, stats, B * H * tiles_x);
+                       tiles_y, amax_x, amax_w, y, stats, B * H * tiles_x, cseg_xcd_remap());
     CSEG_CHECK_LAUNCH("conv3x3_sb_kernel");
     return 1;
 }

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(cons
                                                               int W, int tiles_x, int tiles_y,
                                                               const unsigned* __restrict__ amax_x,
                                                               const unsigned* __restrict__ amax_w, float* __restrict__ y,
-                                                              float4* __restrict__ stats, int n_seg) {
+                                                              float4* __restrict__ stats, int n_seg, int xmap) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s16[];
     constexpr int NP = AR::NP;
     constexpr int A_CELLS = NP * NOCT * PLANE;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(cons
     const int g = lane >> 4, n = lane & 15;
     const int n_cot = Cout / (NT * 16);
     const size_t plane = (size_t)H * W;
-    int t = blockIdx.x;
+    int t = cseg_xcd_block(blockIdx.x, gridDim.x, xmap);
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y; t /= tiles_y;
     const int cot = t % n_cot;
@@ -1002,7 +1002,7 @@ int launch_sb16(const float* x, const uint4* wp, const float* bias, const float*
     const long n_tiles = (long)B * (Cout / (NT * 16)) * tiles_y * tiles_x;
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb16: grid too large");
     hipLaunchKernelGGL((conv3x3_sb16_kernel<AR, NT>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, addend, Cin, Cout, H, W,
-                       tiles_x, tiles_y, amax_x, amax_w, y, stats, B * H * tiles_x);
+                       tiles_x, tiles_y, amax_x, amax_w, y, stats, B * H * tiles_x, cseg_xcd_remap());
     CSEG_CHECK_LAUNCH("conv3x3_sb16_kernel");
     return 1;
 }
@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb8_kernel(const float* __rest
                                                              const float* __restrict__ bias, int Cin, int Cout, int H, int W,
                                                              int tiles_x, int tiles_y, const unsigned* __restrict__ amax_x,
                                                              const unsigned* __restrict__ amax_w, float* __restrict__ y,
-                                                             float4* __restrict__ stats, int n_seg) {
+                                                             float4* __restrict__ stats, int n_seg, int xmap) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s8[];
     constexpr int NP = AR::NP;
     constexpr int A_CELLS = NP * 2 * PLANE8;
@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb8_kernel(const float* __rest
     const int g = lane >> 4, n = lane & 15;
     const int n_cot = Cout / (NT * 16);
     const size_t plane = (size_t)H * W;
-    int t = blockIdx.x;
+    int t = cseg_xcd_block(blockIdx.x, gridDim.x, xmap);
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y; t /= tiles_y;
     const int cot = t % n_cot;
@@ -1323,7 +1323,7 @@ int fwd8(const float* x, const void* wp, const float* bias, int B, int Cin, int 
     const long n_tiles = (long)B * (Cout / 144) * tiles_y * tiles_x;
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb8: grid too large");
     hipLaunchKernelGGL(sb8::conv3x3_sb8_kernel<SplitF16x3>, dim3((unsigned)n_tiles), dim3(512), lds, stream, x, (const uint4*)wp, bias, Cin,
-                       Cout, H, W, tiles_x, tiles_y, amax_x, amax_w, y, stats, B * H * tiles_x);
+                       Cout, H, W, tiles_x, tiles_y, amax_x, amax_w, y, stats, B * H * tiles_x, cseg_xcd_remap());
     CSEG_CHECK_LAUNCH("conv3x3_sb8_kernel");
     return 1;
 }

@@ -65,3 +65,17 @@ def test_product_does_not_import_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_the_torch_free_probe_compiles_against_the_header():
+    """tools/probes/conv_probe.cpp drives the C-ABI directly (dlopen + HIP runtime, no Python): it must keep compiling against
+    include/cseg_hip.h -- the calls are bound by decltype of the declarations, so a changed signature is a compile error here."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("g++") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("needs g++ and the HIP runtime headers")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                        "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "probes", "conv_probe.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]

@@ -445,3 +445,27 @@ def test_eight_row_tiles_are_bit_identical_to_the_four_row_kernels(case, what, m
     monkeypatch.setenv("CSEG_SB16_XCD", "1")                       # XCD-contiguous tile order (one channel tile group only): every tile once
     y2 = E.conv3x3_sb(x, w, b, arith=E.F16X3)
     assert np.array_equal(y0, y2), "the XCD-aware tile order must compute every tile exactly once (%s)" % what
+
+
+# ---- round 4 (opt-in, CSEG_XCD_REMAP): XCD-aware block order of the one-tile kernels -- a permutation of the grid, same results ----
+@pytest.mark.parametrize("case,nt,kernel,what", [
+    ((2, 32, 96, 8, 128), 0, "conv3x3_sb_kernel", "6 channel tiles: 2 images x 2 row tiles x 2 column tiles = 8 blocks"),
+    ((1, 32, 64, 30, 72), 0, "conv3x3_sb16_kernel", "4 channel tiles: 8 row tiles x 2 column tiles = 16 blocks, ragged"),
+    ((2, 16, 288, 9, 68), NT_SB8, "conv3x3_sb8_kernel", "head kernel: 2 images x 2 channel tile groups x 2 x 2 tiles = 16 blocks, ragged"),
+    ((1, 32, 96, 12, 64), 0, "conv3x3_sb_kernel", "3 blocks: not a multiple of 8, the remap must be the identity"),
+])
+def test_xcd_block_order_is_a_permutation(case, nt, kernel, what, monkeypatch, tmp_path):
+    monkeypatch.setenv("CSEG_EMU_WAVE_ORDER", "shuffle:3")
+    monkeypatch.setenv("CSEG_CONV3X3_SB16_P", "0")                 # the one-tile form of the 16-channel-chunk kernel
+    B, ci, co, H, W = case
+    x, w, b = _rand((B, ci, H, W), 101, 2.0), _rand((co, ci, 3, 3), 102, 1.0 / (3 * ci ** 0.5)), _rand((co,), 103)
+    y0 = E.conv3x3_sb(x, w, bias=b, nt=nt, arith=E.F16X3)
+    ref = E.ref_conv3x3(x, w, b)
+    assert np.abs(y0 - ref).max() <= _bound(ref, 9 * ci), what
+    monkeypatch.setenv("CSEG_XCD_REMAP", "1")
+    trace = tmp_path / "launches.txt"
+    monkeypatch.setenv("CSEG_EMU_TRACE", str(trace))
+    y1 = E.conv3x3_sb(x, w, bias=b, nt=nt, arith=E.F16X3)
+    launched = trace.read_text()
+    assert kernel + "<" in launched, "expected %s, got %s" % (kernel, launched)
+    assert np.array_equal(y0, y1), what
