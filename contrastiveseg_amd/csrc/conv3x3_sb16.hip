@@ -495,9 +495,9 @@ bool sb16p_plan(int arith, int Cin, int NT, size_t& lds, bool& res) {
 // LDS store, 4 no K-steps, 8 no statistics, 16 no output store, 32 no weight stores inside the loop,
 // 64 statistics computed but not stored.
 // ---------------------------------------------------------------------------------------------------------
-// FEAT (CSEG_SB16_FEAT, bits): 1 = the 16-instruction split (split_cells8_f16_lean) with the image border folded into the scale,
-// 2 = the unmasked statistics pass for full segments (cseg_stats.h).
-template <class AR, int NT, bool RES, int PF, int FEAT>
+// (The 16-instruction split and the unmasked statistics pass were first switched on in this copy -- CSEG_SB16_FEAT of GPU calls
+// r04j26 / r04j27 -- and are the library's defaults since.)
+template <class AR, int NT, bool RES, int PF>
 __global__ __launch_bounds__(512, 1) void conv3x3_sb16q_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                                const float* __restrict__ bias, const float* __restrict__ addend, int Cin, int Cout, int H, int W,
                                                                int tiles_x, int tiles_y, int n_spatial, int groups,
@@ -679,14 +679,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16q_kernel(const float* __re
                         }
                         if (stats && !(ablate & 8)) {
                             const size_t seg = ((size_t)cb * H + yy) * tiles_x + cx0 / TC;
-                            constexpr bool FS = (FEAT & 2) != 0;
                             const bool st_store = !(ablate & 64);
                             if (half == 0)
-                                cseg_stats_emit<NT0, NT0, FS>(acc, bias, co0, unscale, cx0, W, g, n, stats + (size_t)co0 * n_seg + seg, n_seg,
-                                                              st_store);
+                                cseg_stats_emit<NT0, NT0>(acc, bias, co0, unscale, cx0, W, g, n, stats + (size_t)co0 * n_seg + seg, n_seg,
+                                                          st_store);
                             else if (NT1 > 0)
-                                cseg_stats_emit<NT1, NT0, FS>(acc, bias, co0 + NT0 * 16, unscale, cx0, W, g, n,
-                                                              stats + (size_t)(co0 + NT0 * 16) * n_seg + seg, n_seg, st_store);
+                                cseg_stats_emit<NT1, NT0>(acc, bias, co0 + NT0 * 16, unscale, cx0, W, g, n,
+                                                          stats + (size_t)(co0 + NT0 * 16) * n_seg + seg, n_seg, st_store);
                         }
                     }
                 }
@@ -701,12 +700,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16q_kernel(const float* __re
     }
 }
 
-template <class AR, int NT, bool RES, int PF, int FEAT>
+template <class AR, int NT, bool RES, int PF>
 int launch_sb16q(const float* x, const uint4* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W,
                  const unsigned* amax_x, const unsigned* amax_w, float* y, float4* stats, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)(conv3x3_sb16q_kernel<AR, NT, RES, PF, FEAT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)(conv3x3_sb16q_kernel<AR, NT, RES, PF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
             cseg_set_error("conv3x3_sb16q: cannot raise dynamic LDS to %zu bytes", lds);
             return 0;
@@ -721,7 +720,7 @@ int launch_sb16q(const float* x, const uint4* wp, const float* bias, const float
     if (groups < 1) groups = 1;
     if (groups > n_spatial) groups = n_spatial;
     const char* abl = getenv("CSEG_ABLATE");
-    hipLaunchKernelGGL((conv3x3_sb16q_kernel<AR, NT, RES, PF, FEAT>), dim3((unsigned)(groups * n_cot)), dim3(512), lds, stream, x, wp, bias,
+    hipLaunchKernelGGL((conv3x3_sb16q_kernel<AR, NT, RES, PF>), dim3((unsigned)(groups * n_cot)), dim3(512), lds, stream, x, wp, bias,
                        addend, Cin, Cout, H, W, tiles_x, tiles_y, (int)n_spatial, (int)groups, amax_x, amax_w, y, stats, B * H * tiles_x,
                        abl ? atoi(abl) : 0);
     CSEG_CHECK_LAUNCH("conv3x3_sb16q_kernel");
@@ -732,7 +731,7 @@ int launch_sb16q(const float* x, const uint4* wp, const float* bias, const float
 int sb16q_distance() {
     const char* e = getenv("CSEG_SB16_PF");
     const int pf = e ? atoi(e) : 0;
-    return pf < 0 ? 0 : (pf > 3 ? 3 : pf);
+    return pf < 0 ? 0 : (pf > 2 ? 2 : pf);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1276,14 +1275,11 @@ int fwd(const float* x, const void* wp, const float* bias, const float* addend, 
                    : launch_sb16r<SplitF16x3, false>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream);
     if (sb16p_plan(arith, Cin, NT, lds, res)) {
         const int pf = NT == 3 ? sb16q_distance() : 0;
-        const char* fe = getenv("CSEG_SB16_FEAT");
-        const int feat = fe ? atoi(fe) & 3 : 0;
-#define SB16Q(P, F)                                                                                                               \
-    if (pf == P && feat == F)                                                                                                     \
-        return res ? launch_sb16q<SplitF16x3, 3, true, P, F>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream) \
-                   : launch_sb16q<SplitF16x3, 3, false, P, F>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream);
-        SB16Q(1, 0) SB16Q(1, 1) SB16Q(1, 2) SB16Q(1, 3) SB16Q(2, 0) SB16Q(2, 3)
-        CSEG_REQUIRE(pf == 0, "conv3x3_sb16q: CSEG_SB16_PF=%d with CSEG_SB16_FEAT=%d is not built", pf, feat);
+#define SB16Q(P)                                                                                                                  \
+    if (pf == P)                                                                                                                  \
+        return res ? launch_sb16q<SplitF16x3, 3, true, P>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream) \
+                   : launch_sb16q<SplitF16x3, 3, false, P>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream);
+        SB16Q(1) SB16Q(2)
 #undef SB16Q
 #define SB16P(N)                                                                                                              \
     return res ? launch_sb16p<SplitF16x3, N, true>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream)          \

@@ -22,9 +22,8 @@ CASES = [
 ]
 
 
-# opt-in variants of the persistent small-channel kernel (conv3x3_sb16q_kernel: CSEG_SB16_PF / CSEG_SB16_FEAT, round 4) on the cases it takes
-OPT_IN = [({}, c) for c in CASES] + [({"CSEG_SB16_PF": "1", "CSEG_SB16_FEAT": "3"}, CASES[0]), ({"CSEG_SB16_PF": "2", "CSEG_SB16_FEAT": "3"}, CASES[3]),
-                                     ({"CSEG_SB16_PF": "1", "CSEG_SB16_FEAT": "2"}, CASES[3]),
+# opt-in variants of the persistent small-channel kernel (conv3x3_sb16q_kernel: CSEG_SB16_PF, round 4) on the cases it takes
+OPT_IN = [({}, c) for c in CASES] + [({"CSEG_SB16_PF": "1"}, CASES[0]), ({"CSEG_SB16_PF": "2"}, CASES[3]),
                                      ({"CSEG_SB16_ROWS8": "2"}, CASES[0]), ({"CSEG_SB16_ROWS8": "2"}, CASES[3])]    # the 8-row tiles
 
 

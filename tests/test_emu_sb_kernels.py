@@ -392,7 +392,7 @@ def test_epilogue_addend(case, arith, wave_order):
 
 
 # ---- round 4 (opt-in, CSEG_SB16_PF): the persistent kernel with the patch prefetch 1 - 3 items deep (conv3x3_sb16q_kernel) --------
-@pytest.mark.parametrize("pf,feat", [("1", "0"), ("2", "0"), ("1", "1"), ("2", "3")])
+@pytest.mark.parametrize("pf", ["1", "2"])
 @pytest.mark.parametrize("case,what", [
     ((1, 48, 48, 6, 68), "weights resident, ragged tiles, one tile per block"),
     ((1, 16, 48, 5, 68), "ONE chunk per tile: fewer items than ring slots at pf 2 / 3"),
@@ -400,7 +400,7 @@ def test_epilogue_addend(case, arith, wave_order):
     ((1, 96, 48, 5, 68), "weights streamed through registers (6 chunks do not fit), ragged tiles"),
     ((2, 96, 48, 52, 640), "260 tiles, streamed weights across the tile boundary"),
 ])
-def test_deeper_prefetch_is_bit_identical_to_the_persistent_kernel(case, what, pf, feat, monkeypatch, tmp_path):
+def test_deeper_prefetch_is_bit_identical_to_the_persistent_kernel(case, what, pf, monkeypatch, tmp_path):
     monkeypatch.setenv("CSEG_EMU_WAVE_ORDER", "shuffle:%s" % pf)
     B, ci, co, H, W = case
     x, w, b = _rand((B, ci, H, W), 81, 2.0), _rand((co, ci, 3, 3), 82, 1.0 / (3 * ci ** 0.5)), _rand((co,), 83)
@@ -408,7 +408,6 @@ def test_deeper_prefetch_is_bit_identical_to_the_persistent_kernel(case, what, p
     ref = E.ref_conv3x3(x, w, b)
     assert np.abs(y0 - ref).max() <= _bound(ref, 9 * ci), what
     monkeypatch.setenv("CSEG_SB16_PF", pf)
-    monkeypatch.setenv("CSEG_SB16_FEAT", feat)      # 1: the 16-instruction split (same pieces, bit for bit)
     trace = tmp_path / "launches.txt"
     monkeypatch.setenv("CSEG_EMU_TRACE", str(trace))
     y1 = E.conv3x3_sb(x, w, b, arith=E.F16X3)

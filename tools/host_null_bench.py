@@ -2,7 +2,7 @@
 at once (size queries go to the real library), tensors live on the CPU and are never touched. What is timed is what the enqueueing
 thread pays per launch -- Python, autograd nodes, allocations, argument conversion -- i.e. the part of tools/host_profile.py's
 "host enqueue" that is not the HIP runtime. Absolute numbers are this container's CPU; the ratios guide the work.
-  python tools/host_null_bench.py [--native] [--profile]"""
+  python tools/host_null_bench.py [block|module] [--native] [--profile]"""
 import cProfile
 import ctypes
 import io
@@ -88,8 +88,53 @@ def bench_block(profile):
         print(s.getvalue())
 
 
+def bench_module(profile):
+    """One stage-4 exchange unit of HRNet-W48 (4 branches x 4 residual blocks + the 12 fuse paths) at the benched relative sizes,
+    scaled down 4 x (the stub kernels do not care; the aten fallbacks of shapes the routing refuses stay small)."""
+    from contrastiveseg_amd.lib.models.backbones.hrnet_backbone import HighResolutionModule
+    from contrastiveseg_amd.lib.models.tools.module_helper import mark_conv_bn_pairs
+    K.CONV3X3_SB_MIN_TILES = 1
+    torch.manual_seed(0)
+    chans = [48, 96, 192, 384]
+    mod = mark_conv_bn_pairs(HighResolutionModule(chans, 4, "torchbn", 0.1).train())
+    xs0 = [torch.zeros(2, c, 64 >> i, 128 >> i) for i, c in enumerate(chans)]
+    dys = [torch.zeros_like(t) for t in xs0]
+    calls = []
+    orig = _hip.call
+    _hip.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+
+    def run(n):
+        t_f = t_b = 0.0
+        for _ in range(n):
+            xs = [t.clone().requires_grad_(True) for t in xs0]
+            t0 = time.perf_counter()
+            ys = mod([t * 1.0 for t in xs])
+            t1 = time.perf_counter()
+            torch.autograd.backward(ys, dys)
+            t2 = time.perf_counter()
+            t_f += t1 - t0
+            t_b += t2 - t1
+        return t_f / n * 1e3, t_b / n * 1e3
+    run(2)
+    calls.clear()
+    run(1)
+    n_calls = len(calls)
+    _hip.call = orig
+    f, b = run(10)
+    print("stage-4 exchange unit: forward %.2f ms, backward %.2f ms of host time (%d library calls per forward + backward%s)"
+          % (f, b, n_calls, ", native blocks" if K.NATIVE_BLOCK else ""))
+    if profile:
+        pr = cProfile.Profile()
+        pr.enable()
+        run(5)
+        pr.disable()
+        s = io.StringIO()
+        pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40)
+        print(s.getvalue())
+
+
 if __name__ == "__main__":
     install_null()
     if "--native" in sys.argv:
         K.NATIVE_BLOCK = True
-    bench_block("--profile" in sys.argv)
+    (bench_module if "module" in sys.argv else bench_block)("--profile" in sys.argv)
