@@ -386,6 +386,62 @@ def fuse_sum_relu(same, low):
 
 
 # ----------------------------------------------------------------------------------------------------------
+# One gradient sum per branch of an exchange unit (round 4, opt-in: CSEG_FANOUT_SUM=1; not yet timed on the hardware).
+# Every branch output of a HighResolutionModule feeds all of its (up to four) output resolutions (reference hrnet_backbone.py:271-286),
+# so autograd accumulates up to four gradients per branch with `add` kernels: 72 launches and ~1.7 ms per step at batch 8
+# (profiles/r04_step_steady_kernel_stats_epilogue_stats.csv), three read-read-write passes where one pass over the terms does.
+# fan_out() hands every consumer its own alias of the tensor through ONE autograd node whose backward sums what arrives with the
+# n-ary sum kernel of the exchange unit (cseg_fuse_sum_fwd without coarse terms and without the ReLU).
+# ----------------------------------------------------------------------------------------------------------
+FANOUT_SUM = os.environ.get("CSEG_FANOUT_SUM", "0") == "1"
+
+
+def sum_same(terms):
+    """terms: 2..4 tensors [B,C,h,w] of one shape -> their sum, one kernel (no autograd)."""
+    terms = [t.contiguous() for t in terms]
+    B, C, h, w = terms[0].shape
+    out = torch.empty(B, C, h, w, dtype=F32, device=terms[0].device)
+    sp = (ctypes.c_void_p * len(terms))(*[_p(t, F32, "term").value for t in terms])
+    lp = (ctypes.c_void_p * 1)(None)
+    _hip.call("cseg_fuse_sum_fwd", sp, len(terms), lp, _int_arr([1]), _int_arr([1]), 0, B, C, h, w, 0, _p(out, F32, "out"),
+              _hip.stream_ptr())
+    return out
+
+
+class FanOutSum(Function):
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        if len(gs) > 4 or gs[0].dim() != 4 or gs[0].dtype != F32 or not _on_device(gs[0]) or any(g.shape != gs[0].shape for g in gs):
+            total = gs[0]
+            for g in gs[1:]:
+                total = total + g
+            return total, None
+        return sum_same(gs), None
+
+
+def fan_out(x, n):
+    """-> n aliases of x for n consumers, behind one autograd node that sums their gradients in one kernel. The max|.| record of x
+    travels with every alias."""
+    if n <= 1 or not x.requires_grad:
+        return [x] * n
+    outs = FanOutSum.apply(x, n)
+    a = getattr(x, "_cseg_amax", None)
+    if a is not None and a[1] == x._version:
+        for o in outs:
+            o._cseg_amax = (a[0], o._version) + tuple(a[2:])
+    return list(outs)
+
+
+# ----------------------------------------------------------------------------------------------------------
 # segmentation term: upsample + weighted CE
 # ----------------------------------------------------------------------------------------------------------
 class UpsampleCE(Function):

@@ -207,7 +207,8 @@ class HighResolutionModule(nn.Module):
                 if j == i:
                     continue
                 chains[(i, j)] = [row[j]] if j > i else list(row[j])
-        cur = {key: x[key[1]] for key in chains}
+        take = self._fan(x)
+        cur = {key: take(key[1], key[0]) for key in chains}
         for depth in range(max(len(c) for c in chains.values())):
             keys = [key for key, c in chains.items() if len(c) > depth]
             convs = [chains[key][depth][0](cur[key]) for key in keys]
@@ -216,10 +217,19 @@ class HighResolutionModule(nn.Module):
                 cur[key] = o
         outs = []
         for i in range(len(self.fuse_layers)):
-            same = [x[j] if j == i else cur[(i, j)] for j in range(i + 1)]
+            same = [take(j, i) if j == i else cur[(i, j)] for j in range(i + 1)]
             low = [cur[(i, j)] for j in range(i + 1, self.num_branches)]
             outs.append(K.fuse_sum_relu(same, low))
         return outs
+
+    def _fan(self, x):
+        """-> take(j, i): branch j as output i reads it. With K.FANOUT_SUM every output gets its own alias behind one autograd node
+        per branch (one gradient sum instead of up to three `add` launches, kernels.fan_out); otherwise the tensor itself."""
+        n_out = len(self.fuse_layers)
+        if K.FANOUT_SUM and n_out > 1:
+            xf = [K.fan_out(xj, n_out) for xj in x]
+            return lambda j, i: xf[j][i]
+        return lambda j, i: x[j]
 
     def _branches_forked(self, x):
         """Inside a hipGraph capture (segmentor/tools/step_graph.py): every branch after the first on a side stream of its own, forked
@@ -249,11 +259,12 @@ class HighResolutionModule(nn.Module):
         import torch
         cur = torch.cuda.current_stream(x[0].device)
         streams = _fork_streams(x[0].device, len(self.fuse_layers) - 1)
+        take = self._fan(x)
 
         def row_out(i):
             row = self.fuse_layers[i]
-            same = [x[j] if j == i else row[j](x[j]) for j in range(i + 1)]
-            low = [row[j](x[j]) for j in range(i + 1, self.num_branches)]
+            same = [take(j, i) if j == i else row[j](take(j, i)) for j in range(i + 1)]
+            low = [row[j](take(j, i)) for j in range(i + 1, self.num_branches)]
             return K.fuse_sum_relu(same, low)
 
         outs = [None] * len(self.fuse_layers)
@@ -287,10 +298,11 @@ class HighResolutionModule(nn.Module):
             # r04j12 -- while the branch forks alone capture fine; the replay keeps the exchange unit on the capturing stream)
             return self._exchange_forked(x)
         outs = []
+        take = self._fan(x)
         for i, row in enumerate(self.fuse_layers):
-            same = [x[j] if j == i else row[j](x[j]) for j in range(i + 1)]     # finer branches arrive strided
-            low = [row[j](x[j]) for j in range(i + 1, self.num_branches)]       # coarser ones: 1x1 conv + BN
-            outs.append(K.fuse_sum_relu(same, low))                              # summed in branch order, then ReLU
+            same = [take(j, i) if j == i else row[j](take(j, i)) for j in range(i + 1)]     # finer branches arrive strided
+            low = [row[j](take(j, i)) for j in range(i + 1, self.num_branches)]             # coarser ones: 1x1 conv + BN
+            outs.append(K.fuse_sum_relu(same, low))                                          # summed in branch order, then ReLU
         return outs
 
 

@@ -157,6 +157,14 @@ def fuse_sum_relu(same, low):
     return F.relu(y)
 
 
+FANOUT_SUM = False          # kernels.FANOUT_SUM: the gradient sums of the exchange unit are autograd's own here
+
+
+def fan_out(x, n):
+    """kernels.fan_out: n consumers of one tensor (autograd accumulates their gradients)."""
+    return [x] * n
+
+
 def upsample_ce(seg, target, weight=None, ignore_index=-1, status=None):
     pred = F.interpolate(seg, size=target.shape[-2:], mode="bilinear", align_corners=True)   # loss_contrast.py:180
     return F.cross_entropy(pred, target, weight=weight, ignore_index=ignore_index)            # loss_helper.py:186

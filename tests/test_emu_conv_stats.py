@@ -211,3 +211,45 @@ def test_native_block_executor_equals_the_python_node(channels, hw, monkeypatch)
     assert len(res[True]) == len(res[False])
     for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("channels", [[48, 96], [48, 96, 192]])
+def test_fan_out_node_sums_the_branch_gradients_in_one_kernel(channels, monkeypatch):
+    """kernels.fan_out (opt-in, CSEG_FANOUT_SUM=1): an exchange unit of HRNet with every branch output handed to its consumers through
+    ONE autograd node whose backward sums the arriving gradients with the n-ary sum kernel -- same outputs bit for bit, input and
+    parameter gradients equal to autograd's own accumulation up to the order of the additions, and the max|.| record of a branch
+    output still reaches its consumers (no extra pass over the tensor)."""
+    from contrastiveseg_amd import kernels as K
+    from contrastiveseg_amd.lib.models.backbones.hrnet_backbone import HighResolutionModule
+    from contrastiveseg_amd.lib.models.tools.module_helper import mark_conv_bn_pairs
+    inject.install(monkeypatch)
+    monkeypatch.setattr(K, "SPLIT_ARITH", "f16x3")
+    monkeypatch.setattr(K, "SPLIT_WEIGHTS", K.SplitWeights())
+    monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
+    torch.manual_seed(len(channels))
+    mod = mark_conv_bn_pairs(HighResolutionModule(channels, 1, "torchbn", 0.1).train())
+    state0 = {k: v.clone() for k, v in mod.state_dict().items()}
+    xs0 = [torch.randn(2, c, 8 >> i, 64 >> i) * 0.5 for i, c in enumerate(channels)]
+    gys = [torch.randn(2, c, 8 >> i, 64 >> i) for i, c in enumerate(channels)]
+    res = {}
+    for fan in (False, True):
+        monkeypatch.setattr(K, "FANOUT_SUM", fan)
+        mod.load_state_dict(state0)
+        K.SPLIT_WEIGHTS.invalidate()
+        mod.zero_grad()
+        calls = []
+        orig = K._hip.call
+        monkeypatch.setattr(K._hip, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+        xs = [t.clone().requires_grad_(True) for t in xs0]
+        ys = mod([t * 1.0 for t in xs])
+        torch.autograd.backward(ys, gys)
+        monkeypatch.setattr(K._hip, "call", orig)
+        res[fan] = ([y.detach().clone() for y in ys], [x.grad.clone() for x in xs] + [p.grad.clone() for p in mod.parameters()], calls)
+    for a, b in zip(res[False][0], res[True][0]):
+        assert torch.equal(a, b), "the forward must not change"
+    for a, b in zip(res[False][1], res[True][1]):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1e-3, float(a.abs().max()))
+    n = len(channels)
+    # one n-ary sum per branch (forward fuse sums: n launches either way); no additional max|.| passes
+    assert res[True][2].count("cseg_fuse_sum_fwd") == res[False][2].count("cseg_fuse_sum_fwd") + n
+    assert res[True][2].count("cseg_amax_f32") == res[False][2].count("cseg_amax_f32")
