@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_kernel(const float* __restr
                                                             const float* __restrict__ bias, int Cin, int Cout, int plane_i,
                                                             int tiles_p, const unsigned* __restrict__ amax_x,
                                                             const unsigned* __restrict__ amax_w, float* __restrict__ y,
-                                                            float4* __restrict__ stats, int n_seg) {
+                                                            float4* __restrict__ stats, int n_seg, int xmap) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_o[];
     constexpr int NP = AR::NP;
     constexpr int A1_CELLS = NP * 4 * MT_PX;       // one A buffer: [piece][octet][pixel]
@@ -103,10 +103,15 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_kernel(const float* __restr
     const int g = lane >> 4, n = lane & 15;
     const int n_cot = Cout / (NT * 16);
     const size_t plane = (size_t)plane_i;
-    int t = blockIdx.x;
+    // (orders as in conv3x3_sb.hip: plain = pixel tile fastest; XCD-aware, opt-in = contiguous runs per XCD, channel tile group fastest:
+    // a 1x1 convolution has no halo, what its blocks share is the input tile of the n_cot groups)
+    int t = cseg_xcd_block(blockIdx.x, gridDim.x, xmap);
+    const bool cot_first = xmap && (gridDim.x & 7) == 0;
+    int cot = 0;
+    if (cot_first) { cot = t % n_cot; t /= n_cot; }
     const int tp = t % tiles_p; t /= tiles_p;
-    const int cot = t % n_cot;
-    const int b = t / n_cot;
+    if (!cot_first) { cot = t % n_cot; t /= n_cot; }
+    const int b = t;
     const int px0 = tp * MT_PX;
     const int n_steps = steps1(Cin);
     const uint4* wbase = wp + (size_t)cot * n_steps * BSTEP;
@@ -221,7 +226,7 @@ int launch_1x1(const float* x, const uint4* wp, const float* bias, int B, int Ci
     const long n_tiles = (long)B * (Cout / (NT * 16)) * tiles_p;
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv1x1_sb: grid too large");
     hipLaunchKernelGGL((conv1x1_sb_kernel<AR, NT>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, Cin, Cout, plane,
-                       tiles_p, amax_x, amax_w, y, stats, B * ((plane + 63) / 64));
+                       tiles_p, amax_x, amax_w, y, stats, B * ((plane + 63) / 64), cseg_xcd_remap());
     CSEG_CHECK_LAUNCH("conv1x1_sb_kernel");
     return 1;
 }

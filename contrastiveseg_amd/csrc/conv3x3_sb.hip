@@ -194,11 +194,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
     const int g = lane >> 4, n = lane & 15;
     const int n_cot = Cout / (NT * 16);
     const size_t plane = (size_t)H * W;
+    // plain order: column tile fastest, then row tile, channel tile group, image. XCD-aware order (opt-in): every XCD gets a
+    // contiguous run of logical blocks with the CHANNEL TILE GROUP fastest -- the n_cot blocks that read one patch run side by side
+    // on one XCD, followed by the neighbouring tiles that share its halo
     int t = cseg_xcd_block(blockIdx.x, gridDim.x, xmap);
+    const bool cot_first = xmap && (gridDim.x & 7) == 0;
+    int cot = 0;
+    if (cot_first) { cot = t % n_cot; t /= n_cot; }
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y; t /= tiles_y;
-    const int cot = t % n_cot;
-    const int b = t / n_cot;
+    if (!cot_first) { cot = t % n_cot; t /= n_cot; }
+    const int b = t;
     const int x0 = tx * TC, y0 = ty * TR;
 
     const int n_full = Cin / 32;

@@ -44,7 +44,8 @@ void cseg_set_error(const char* fmt, ...);
 // XCD-aware block order for grids of independent tiles (round 4, opt-in: CSEG_XCD_REMAP=1). Workgroup b of a grid runs on XCD b % 8
 // (observed on gfx950; only speed depends on it), so consecutive tiles -- neighbours that share halo rows, the channel tile groups
 // that read one patch -- land in 8 different L2 caches. The remap gives every XCD a contiguous run of n / 8 logical blocks, walked
-// in order; it needs n % 8 == 0 and is the identity otherwise. (The persistent kernels of conv3x3_sb16.hip have their own form of
+// in order (the kernels then decode the logical index with the channel tile group fastest); it needs n % 8 == 0 and is the identity
+// otherwise. (The persistent kernels of conv3x3_sb16.hip have their own form of
 // it, on by default: -7 % at 48 channels)
 __device__ __forceinline__ int cseg_xcd_block(int b, int n, int on) { return (on && (n & 7) == 0) ? (b & 7) * (n >> 3) + (b >> 3) : b; }
 static inline int cseg_xcd_remap() {

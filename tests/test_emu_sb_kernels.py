@@ -468,3 +468,18 @@ def test_xcd_block_order_is_a_permutation(case, nt, kernel, what, monkeypatch, t
     launched = trace.read_text()
     assert kernel + "<" in launched, "expected %s, got %s" % (kernel, launched)
     assert np.array_equal(y0, y1), what
+
+
+@pytest.mark.parametrize("case", [(2, 64, 288, 8, 64), (1, 48, 96, 5, 20)])
+def test_xcd_block_order_of_the_pointwise_kernel(case, monkeypatch, tmp_path):
+    """1x1 convolution under CSEG_XCD_REMAP=1 (channel tile group fastest inside contiguous per-XCD runs): a permutation of the grid --
+    2 images x 2 pixel tiles x 2 channel tile groups = 8 blocks in the first case, the identity in the second (one block)."""
+    B, ci, co, H, W = case
+    x, w, b = _rand((B, ci, H, W), 111, 2.0), _rand((co, ci, 1, 1), 112, 1.0 / ci ** 0.5), _rand((co,), 113)
+    y0 = E.conv1x1_sb(x, w, b, arith=E.F16X3)
+    monkeypatch.setenv("CSEG_XCD_REMAP", "1")
+    trace = tmp_path / "launches.txt"
+    monkeypatch.setenv("CSEG_EMU_TRACE", str(trace))
+    y1 = E.conv1x1_sb(x, w, b, arith=E.F16X3)
+    assert "conv1x1_sb_kernel<" in trace.read_text()
+    assert np.array_equal(y0, y1)

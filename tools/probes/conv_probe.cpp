@@ -2,7 +2,7 @@
 // instead of the minutes a Python process needs to import torch, so that kernel variants can be compared within a small budget.
 //   g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tools/probes/conv_probe.cpp -o tools/probes/conv_probe \
 //       -L/opt/rocm/lib -lamdhip64 -ldl
-//   tools/probes/conv_probe [--shape B,C,H,W]... [--variant 'name:KEY=VAL;KEY=VAL']... [--wrw] [--iters N] [--nt N]
+//   tools/probes/conv_probe [--shape B,C,H,W]... [--variant 'name:KEY=VAL;KEY=VAL']... [--wrw] [--c1] [--pair] [--iters N] [--nt N]
 // For every shape: x (non-negative, like an activation) and w are generated on the host, max|.| records and packed weights are
 // made by the library, then every variant (a set of environment switches the library reads per call) is timed with HIP events:
 // forward with the BatchNorm statistics epilogue (`fwd_st`), plain forward (`fwd`), optionally the weight gradient. The output of
@@ -69,7 +69,7 @@ static double time_us(Fn&& fn, int iters, hipStream_t st) {
 int main(int argc, char** argv) {
     std::vector<Shape> shapes;
     std::vector<Variant> variants;
-    bool wrw = false, pair = false;
+    bool wrw = false, pair = false, c1 = false;
     int iters = 20, nt = 0;
     std::vector<std::string> keys;
     for (int i = 1; i < argc; ++i) {
@@ -96,6 +96,7 @@ int main(int argc, char** argv) {
             variants.push_back(var);
         } else if (a == "--wrw") wrw = true;
         else if (a == "--iters" && i + 1 < argc) iters = atoi(argv[++i]);
+        else if (a == "--c1") c1 = true;              // also: the 1x1 convolution C -> C on the same tensor (`c1_us`)
         else if (a == "--pair") pair = true;          // also: two launches side by side on two streams (own outputs), wall clock per pair
         else if (a == "--nt" && i + 1 < argc) nt = atoi(argv[++i]);          // channel tiling of pack + forward (265 = CSEG_NT_SB8: the head kernel)
     }
@@ -114,6 +115,9 @@ int main(int argc, char** argv) {
     auto p_wrw_ws = sym<decltype(&cseg_conv3x3_sb_wrw_ws_floats)>("cseg_conv3x3_sb_wrw_ws_floats");
     auto p_wrw = sym<decltype(&cseg_conv3x3_split_wrw)>("cseg_conv3x3_split_wrw");
     auto p_err = sym<decltype(&cseg_last_error)>("cseg_last_error");
+    auto p_c1_bytes = sym<decltype(&cseg_conv1x1_split_packed_bytes)>("cseg_conv1x1_split_packed_bytes");
+    auto p_c1_pack = sym<decltype(&cseg_conv1x1_split_pack)>("cseg_conv1x1_split_pack");
+    auto p_c1_fwd = sym<decltype(&cseg_conv1x1_split_fwd)>("cseg_conv1x1_split_fwd");
 
     HIPCHECK(hipSetDevice(0));
     hipStream_t st;
@@ -214,6 +218,21 @@ int main(int argc, char** argv) {
                 }
                 if (!ok) { fprintf(stderr, "pair (%s): %s\n", v.name.c_str(), p_err()); return 2; }
             }
+            double us_c1 = -1.0, c1diff = 0.0;
+            if (c1) {                      // the first C x C weights of `w` as a 1x1 operator
+                static std::vector<float> hc1, hc10;
+                void* wp1;
+                HIPCHECK(hipMalloc(&wp1, p_c1_bytes(CSEG_ARITH_F16X3, s.C, s.C)));
+                if (!p_c1_pack(w, s.C, s.C, 0, CSEG_ARITH_F16X3, aw, wp1, st)) { fprintf(stderr, "c1 pack: %s\n", p_err()); return 2; }
+                auto f1 = [&]() { ok = ok && p_c1_fwd(x, wp1, nullptr, s.B, s.C, s.C, s.H * s.W, CSEG_ARITH_F16X3, ax, aw, y, st); };
+                us_c1 = time_us(f1, iters, st);
+                if (!ok) { fprintf(stderr, "c1 (%s): %s\n", v.name.c_str(), p_err()); return 2; }
+                hc1.resize(n);
+                HIPCHECK(hipMemcpy(hc1.data(), y, n * 4, hipMemcpyDeviceToHost));
+                if (first) hc10 = hc1;
+                for (size_t i = 0; i < n; ++i) c1diff = std::max(c1diff, (double)std::fabs(hc1[i] - hc10[i]));
+                HIPCHECK(hipFree(wp1));
+            }
             double us_wrw = -1.0, wdiff = 0.0;
             if (wrw) {
                 auto f_w = [&]() { ok = ok && p_wrw(x, dy, s.B, s.C, s.C, s.H, s.W, CSEG_ARITH_F16X3, ax, ady, wsb, dw, st); };
@@ -229,6 +248,7 @@ int main(int argc, char** argv) {
                    s.B, s.C, s.H, s.W, v.name.c_str(), us_st, us_pl, gf / us_st * 1e-3, maxdiff, maxabs);
             if (wrw) printf(", \"wrw_us\": %.1f, \"wrw_max_abs_diff_vs_first\": %.3g", us_wrw, wdiff);
             if (pair) printf(", \"pair_us\": %.1f", us_pair);
+            if (c1) printf(", \"c1_us\": %.1f, \"c1_max_abs_diff_vs_first\": %.3g", us_c1, c1diff);
             printf("}\n");
             fflush(stdout);
             first = false;
