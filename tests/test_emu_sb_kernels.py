@@ -483,3 +483,20 @@ def test_xcd_block_order_of_the_pointwise_kernel(case, monkeypatch, tmp_path):
     y1 = E.conv1x1_sb(x, w, b, arith=E.F16X3)
     assert "conv1x1_sb_kernel<" in trace.read_text()
     assert np.array_equal(y0, y1)
+
+
+@pytest.mark.parametrize("case", [(1, 16, 48, 128, 256), (1, 16, 48, 72, 256), (1, 32, 192, 32, 64), (2, 32, 192, 32, 64), (3, 16, 384, 16, 32),
+                                  (1, 16, 96, 64, 128)])
+def test_xcd_tile_order_of_the_persistent_kernels_is_a_permutation(case, monkeypatch):
+    """CSEG_SB16_XCD (default 1) against the plain tile order at the tile counts of small per-GPU batches: 128 and 72 tiles on as many
+    blocks (one channel tile group), 8 / 16 / 12 tiles x 4 / 8 channel tile groups (the n_cot blocks of a tile on one XCD), 2 groups."""
+    monkeypatch.setenv("CSEG_CONV3X3_SB16_CH", "48,96,192,384")
+    B, ci, co, H, W = case
+    x, w = _rand((B, ci, H, W), 121, 2.0), _rand((co, ci, 3, 3), 122, 1.0 / (3 * ci ** 0.5))
+    monkeypatch.setenv("CSEG_SB16_XCD", "0")
+    y0 = E.conv3x3_sb(x, w, None, arith=E.F16X3)
+    monkeypatch.setenv("CSEG_SB16_XCD", "1")
+    y1 = E.conv3x3_sb(x, w, None, arith=E.F16X3)
+    ref = E.ref_conv3x3(x, w, None)
+    assert np.abs(y1 - ref).max() <= _bound(ref, 9 * ci)
+    assert np.array_equal(y0, y1)
