@@ -553,13 +553,16 @@ def _bn_dims(x):
 
 
 _BN_WS = {}      # (device index, stream) -> scratch, grown on demand
+_BN_WS_NEED = {}  # (B, C, HW) -> floats of scratch the library wants
 
 
 def _bn_ws(B, C, HW, device):
     """Reduction scratch of the BN kernels. Every kernel that writes it is followed on the SAME stream by the kernel that
     reads it, so one buffer per (device, stream) serves all layers (saves two allocator round trips per BN call: the
     step issues ~600 of them and is host-bound at small per-GPU batches)."""
-    need = max(1, _hip.lib().cseg_bn_ws_floats(B, C, HW))
+    need = _BN_WS_NEED.get((B, C, HW))
+    if need is None:                          # (a pure function of the three sizes: asked once per shape, not once per BN call)
+        need = _BN_WS_NEED[(B, C, HW)] = max(1, _hip.lib().cseg_bn_ws_floats(B, C, HW))
     key = (device.index, _hip.raw_stream()) if device.type == "cuda" else (-1, 0)     # callers run on the current device (_hip.dev)
     buf = _BN_WS.get(key)
     if buf is None or buf.numel() < need:
@@ -834,10 +837,16 @@ def amax_of(t):
 CONV_EPILOGUE_STATS = os.environ.get("CSEG_CONV_STATS", "1") == "1"
 
 
+_STAT_SEGMENTS = {}
+
+
 def tile_stats_buffer(kind, c_out, B, H, W, device):
     """[Cout, T, 4] f32 for the statistics epilogue of a forward convolution whose OUTPUT is [B, Cout, H, W] (kind 0: 3x3 kernels,
     1: 1x1 kernels)."""
-    T = _hip.lib().cseg_conv_stat_segments(int(kind), int(B), int(H), int(W))
+    key = (kind, B, H, W)
+    T = _STAT_SEGMENTS.get(key)
+    if T is None:                             # (a pure function of the output's shape)
+        T = _STAT_SEGMENTS[key] = _hip.lib().cseg_conv_stat_segments(int(kind), int(B), int(H), int(W))
     return torch.empty(c_out, T, 4, dtype=F32, device=device)
 
 
