@@ -253,3 +253,35 @@ def test_fan_out_node_sums_the_branch_gradients_in_one_kernel(channels, monkeypa
     # one n-ary sum per branch (forward fuse sums: n launches either way); no additional max|.| passes
     assert res[True][2].count("cseg_fuse_sum_fwd") == res[False][2].count("cseg_fuse_sum_fwd") + n
     assert res[True][2].count("cseg_amax_f32") == res[False][2].count("cseg_amax_f32")
+
+
+def test_fan_out_node_in_the_lockstep_exchange(monkeypatch):
+    """The SyncBN form of the exchange unit (HighResolutionModule._exchange_lockstep: all conv+BN paths advanced side by side) with
+    kernels.fan_out: same outputs and gradients as without it (single process: the grouped BN call degenerates to per-site calls)."""
+    from contrastiveseg_amd import kernels as K
+    from contrastiveseg_amd.lib.models.backbones.hrnet_backbone import HighResolutionModule
+    from contrastiveseg_amd.lib.models.tools.module_helper import mark_conv_bn_pairs
+    inject.install(monkeypatch)
+    monkeypatch.setattr(K, "SPLIT_ARITH", "f16x3")
+    monkeypatch.setattr(K, "SPLIT_WEIGHTS", K.SplitWeights())
+    monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
+    torch.manual_seed(5)
+    channels = [48, 96, 192]
+    mod = mark_conv_bn_pairs(HighResolutionModule(channels, 1, "torchbn", 0.1).train())
+    state0 = {k: v.clone() for k, v in mod.state_dict().items()}
+    xs0 = [torch.randn(2, c, 8 >> i, 64 >> i) * 0.5 for i, c in enumerate(channels)]
+    gys = [torch.randn(2, c, 8 >> i, 64 >> i) for i, c in enumerate(channels)]
+    res = {}
+    for fan in (False, True):
+        monkeypatch.setattr(K, "FANOUT_SUM", fan)
+        mod.load_state_dict(state0)
+        K.SPLIT_WEIGHTS.invalidate()
+        mod.zero_grad()
+        xs = [t.clone().requires_grad_(True) for t in xs0]
+        ys = mod._exchange_lockstep([t * 1.0 for t in xs])
+        torch.autograd.backward(ys, gys)
+        res[fan] = ([y.detach().clone() for y in ys], [x.grad.clone() for x in xs] + [p.grad.clone() for p in mod.fuse_layers.parameters()])
+    for a, b in zip(res[False][0], res[True][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[False][1], res[True][1]):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1e-3, float(a.abs().max()))
