@@ -390,17 +390,52 @@ def split_kernel_rooflines(counts, device, Kn):
     return rows, split_flops
 
 
+FAMILIES = {"conv3x3_sb_wrw": "3x3 weight gradients (conv3x3_sb_wrw2_kernel + sb_wrw_reduce_kernel)",
+            "conv3x3_sb_run": "3x3 stride-1 forward / backward-data (conv3x3_sb16r/sb16p/sb/sb16/sb8 kernels)",
+            "conv1x1_sb_run": "1x1 forward / backward-data (conv1x1_sb_kernel)", "conv1x1_sb_wrw": "1x1 weight gradients (conv1x1_sb_wrw_kernel)",
+            "conv3x3_s2_run": "3x3 stride-2 forward", "conv3x3_s2_bwd_run": "3x3 stride-2 backward-data", "conv3x3_s2_wrw": "3x3 stride-2 weight gradients"}
+
+
+def kernel_families(split_rows):
+    """The per-(op, shape) rows summed per kernel FAMILY -- one entry point of contrastiveseg_amd.kernels = the device kernels
+    rocprofv3 lists under one name pattern: flops and time over ALL launches of a step, so that `frac` is what the step pays for the
+    family, not what its best launch reaches (the line used to show the 720-channel head launch alone, 0.46,
+    while the 184 small launches of the same kernel ran at 0.27)."""
+    fam = {}
+    for r in split_rows or []:
+        f = fam.setdefault(r["entry"], {"entry": r["entry"], "name": FAMILIES.get(r["entry"], r["entry"]), "calls_per_step": 0,
+                                        "ms_per_step": 0.0, "flops_per_step": 0.0, "peak_TFLOPs": r["peak_TFLOPs"], "members": []})
+        f["calls_per_step"] += r["calls_per_step"]
+        f["ms_per_step"] += r["ms_per_step"]
+        f["flops_per_step"] += r["calls_per_step"] * r["algorithmic_flops_per_launch"]
+        f["members"].append({"kernel": r["kernel"], "calls_per_step": r["calls_per_step"], "us_per_launch": r["us_per_launch"],
+                             "frac": r["frac"]})
+    out = []
+    for f in fam.values():
+        f["achieved_TFLOPs"] = round(f["flops_per_step"] / max(f["ms_per_step"], 1e-9) * 1e-9, 1)
+        f["frac"] = round(f["achieved_TFLOPs"] / f["peak_TFLOPs"], 4)
+        f["ms_per_step"] = round(f["ms_per_step"], 3)
+        out.append(f)
+    out.sort(key=lambda f: -f["ms_per_step"])
+    return out
+
+
 def dominant_kernel(split_rows, arith):
-    """roofline.dominant_kernel: the split-operand kernel with the largest calls x time product of THIS run."""
-    if not split_rows:
+    """roofline.dominant_kernel: the split-operand kernel FAMILY with the largest time per step of THIS run (isolated HIP-event
+    timings of every (op, shape) the step launches x its calls per step), flops and time summed over the family's launches."""
+    fams = kernel_families(split_rows)
+    if not fams:
         return None
-    d = split_rows[0]
-    return {"name": d["kernel"], "entry": d["entry"], "bound": "mfma", "achieved": d["achieved_TFLOPs"], "peak": d["peak_TFLOPs"],
+    d = fams[0]
+    worst = min(d["members"], key=lambda m: m["frac"])
+    return {"name": d["name"], "entry": d["entry"], "bound": "mfma", "achieved": d["achieved_TFLOPs"], "peak": d["peak_TFLOPs"],
             "unit": "TFLOP/s fp32-equivalent (%s: %d MFMAs per product, peak = 2500 / %d)"
                     % (arith, MFMAS_PER_PRODUCT[arith], MFMAS_PER_PRODUCT[arith]),
-            "frac": d["frac"], "us_per_launch": d["us_per_launch"], "calls_per_step": d["calls_per_step"],
-            "ms_per_step": d["ms_per_step"], "algorithmic_flops_per_launch": d["algorithmic_flops_per_launch"],
-            "picked_from": "live tally of one train step x live HIP-event timings (bench.py:split_kernel_rooflines)"}
+            "frac": d["frac"], "us_per_launch": round(d["ms_per_step"] * 1e3 / max(d["calls_per_step"], 1), 1),
+            "calls_per_step": d["calls_per_step"], "ms_per_step": d["ms_per_step"],
+            "algorithmic_flops_per_step": int(d["flops_per_step"]), "worst_member": worst, "members": d["members"],
+            "picked_from": "live tally of one train step x live HIP-event timings in isolation (bench.py:split_kernel_rooflines), summed "
+                           "per entry point; in-step durations under the forked streams: profiles/r05_step_steady_kernel_stats.csv"}
 
 
 LINE_LIMIT = 2048          # bytes of the contract line: the driver keeps a bounded tail of stdout (BENCH_r03: parsed null at ~12 KB)
@@ -445,8 +480,11 @@ def assemble_line(args, wl, cfg, world, global_batch, dt, ev_ms, final_loss, spl
                 "vs_fp32_mfma_peak": round(achieved / (PEAK_FP32_MFMA_TFLOPS * world), 4)}
     dom = dominant_kernel(split_rows, arith) if (split_on and split_rows) else None
     if dom is not None:
-        roofline["dominant_kernel"] = {"name": dom["name"], "frac": dom["frac"], "us": dom["us_per_launch"],
-                                       "achieved": dom["achieved"], "peak": dom["peak"], "calls_per_step": dom["calls_per_step"]}
+        roofline["dominant_kernel"] = {"name": dom["name"][:90], "frac": dom["frac"], "us": dom["us_per_launch"],
+                                       "achieved": dom["achieved"], "peak": dom["peak"], "calls_per_step": dom["calls_per_step"],
+                                       "ms_per_step": dom["ms_per_step"]}
+    if traffic is not None:
+        roofline["traffic_source"] = "committed PMC passes of an earlier tree, not this run: " + (traffic_src or "")[:60]
     cpu_short = None
     if cpu is not None:
         cpu_short = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "error") if k in cpu}
@@ -486,6 +524,7 @@ def assemble_line(args, wl, cfg, world, global_batch, dt, ev_ms, final_loss, spl
                              "at 2500 / %d TFLOP/s + remaining flops at 157.3 TFLOP/s (dense peaks, MI355X_MICROARCH.md)"
                              % (wl["tflop"], MFMAS_PER_PRODUCT[arith])},
         "fp32_conv_path": fp32_pass, "weak": weak, "cpu_baseline": cpu, "kernels": kernels, "split_kernels": split_rows,
+        "split_kernel_families": kernel_families(split_rows),
     }
     # the contract line must fit whatever a configuration puts into it: shed the optional fields before a parser loses the head
     for victim in ("weak", "fp32_conv_path_ms_per_step", "detail"):
@@ -670,7 +709,7 @@ def self_launch(args):
 def step_traffic():
     """HBM bytes per step of the default workload at N=1, from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs; gfx950 FETCH_SIZE x2 for wide coalesced reads per MI355X_MICROARCH.md)."""
-    for name in ("r04_step_pmc.json", "r03_step_pmc.json", "r02_step_pmc.json"):
+    for name in ("r05_step_pmc.json", "r04_step_pmc.json", "r03_step_pmc.json", "r02_step_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break

@@ -606,21 +606,6 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, const flo
         case 6: return launch_sb<AR, 6, G, V>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);             \
         default: return launch_sb<AR, 3, G, V>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);            \
     }
-    if (arith == CSEG_ARITH_F16X3 && NT == 9 && var >= 1) {
-        const char* abl_env = getenv("CSEG_ABLATE");                // timing experiments only (wrong results)
-        switch (abl_env ? atoi(abl_env) : 0) {
-            case 0: break;
-            case 1: return launch_sb<SplitF16x3, 9, true, 1, 1>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
-            case 2: return launch_sb<SplitF16x3, 9, true, 1, 2>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
-            case 4: return launch_sb<SplitF16x3, 9, true, 1, 4>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
-            case 6: return launch_sb<SplitF16x3, 9, true, 1, 6>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
-            case 8: return launch_sb<SplitF16x3, 9, true, 1, 8>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
-            case 14: return launch_sb<SplitF16x3, 9, true, 1, 14>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
-            case 7: return launch_sb<SplitF16x3, 9, true, 1, 7>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
-            case 9: return launch_sb<SplitF16x3, 9, true, 1, 9>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
-            default: return launch_sb<SplitF16x3, 9, true, 1, 15>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
-        }
-    }
     if (arith == CSEG_ARITH_F16X3) {
         // LDS-DMA for the weights, buffer-load addressing of the patch when the offsets fit 32 bits; weights staged a filter row
         // (3 K-steps) at a time unless CSEG_CONV3X3_SB_SPS=1

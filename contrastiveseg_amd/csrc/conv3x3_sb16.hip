@@ -434,13 +434,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16p_kernel(const float* __re
     }
 }
 
-// CUs a persistent launch spreads its blocks over (one block per CU). CSEG_PERSIST_CUS < 256 leaves the rest of the chip to a
-// kernel of another stream (experiments with side-by-side branch kernels, tools/probes/conv_probe --pair).
-long persist_cus() {
-    const char* e = getenv("CSEG_PERSIST_CUS");
-    const long c = e ? atol(e) : 256;
-    return c < 8 ? 8 : (c > 256 ? 256 : c);
-}
+// CUs a persistent launch spreads its blocks over (one block per CU). (Round 4 tried two branch kernels side by side on half the chip
+// each: not faster than two full-chip launches back to back, DESIGN.md section 11.8 -- the switch is gone.)
+constexpr long persist_cus() { return 256; }
 
 // XCD-aware tile order of the persistent kernels: CSEG_SB16_XCD (default 1), possible when the tile groups divide over the 8 XCDs
 int xcd_order(long groups) {
@@ -487,257 +483,6 @@ bool sb16p_plan(int arith, int Cin, int NT, size_t& lds, bool& res) {
     // 4 (64 ch: 83.2 vs 72.9 us for the one-tile kernel, which keeps two blocks per CU) -- tools/branch_conv_probe.py
     if (NT == 3 && a + 2 * chunk <= cap) { lds = a + 2 * chunk; res = false; return true; }
     return false;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Round 4, opt-in (CSEG_SB16_PF = 1 or 2, three channel tiles per block only): the persistent kernel above with a DEEPER patch
-// prefetch. Why: the branch convolutions move 127 MB per launch for 10.9 GFLOP -- 13 us of MFMA issue against 16-21 us of HBM time
-// -- and run in 48-57 us. A block of the kernel above has the fp32 loads of ONE (tile, chunk) item in flight, 25 KB per CU and
-// only while the MFMAs of the item before run (~1 us); sustaining 8 TB/s over 256 CUs at 1-2 us of loaded latency needs ~60 KB in
-// flight per CU. Here the loads of item it + PF are issued while item it is computed; the fetched values wait in a ring of PF
-// register sets (16 registers each), everything else -- LDS images, K-steps, epilogue, order of the accumulation -- is the code
-// above, so the results are bit-identical to it. PF = 1 is the schedule of the kernel above.
-// `ablate` (CSEG_ABLATE, timing experiments only, wrong results; tools/probes/conv_probe.cpp): 1 patch loads without traffic, 2 no split /
-// LDS store, 4 no K-steps, 8 no statistics, 16 no output store, 32 no weight stores inside the loop,
-// 64 statistics computed but not stored.
-// ---------------------------------------------------------------------------------------------------------
-// (The 16-instruction split and the unmasked statistics pass were first switched on in this copy -- CSEG_SB16_FEAT of GPU calls
-// r04j26 / r04j27 -- and are the library's defaults since.)
-template <class AR, int NT, bool RES, int PF>
-__global__ __launch_bounds__(512, 1) void conv3x3_sb16q_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
-                                                               const float* __restrict__ bias, const float* __restrict__ addend, int Cin, int Cout, int H, int W,
-                                                               int tiles_x, int tiles_y, int n_spatial, int groups,
-                                                               const unsigned* __restrict__ amax_x,
-                                                               const unsigned* __restrict__ amax_w, float* __restrict__ y,
-                                                               float4* __restrict__ stats, int n_seg, int ablate) {
-    extern __shared__ __attribute__((aligned(16))) uint4 smem_s16q[];
-    constexpr int NP = AR::NP;
-    constexpr int A_CELLS = NP * NOCT * PLANE;
-    constexpr int BSTEP = NT * NP * 64;
-    constexpr int BCHUNK = STEPS * BSTEP;
-    constexpr int NT0 = (NT + 1) / 2, NT1 = NT - NT0;
-    uint4* As = smem_s16q;                         // [2][piece NP][octet 2][CELLS]
-    uint4* Bs = smem_s16q + 2 * A_CELLS;           // RES: [n_chunks][BCHUNK]; else [2][BCHUNK]
-    const unsigned ex = AR::SCALED ? split_amax_exp(amax_x) : 141u, ew = AR::SCALED ? split_amax_exp(amax_w) : 141u;
-    const float xscale = split_scale_of(ex);
-    const float unscale = split_unscale_of(ex) * split_unscale_of(ew);
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int row = wave & 3, half = wave >> 2;
-    const int g = lane >> 4, n = lane & 15;
-    const int n_cot = Cout / (NT * 16);
-    const size_t plane = (size_t)H * W;
-    const int cot = blockIdx.x % n_cot, grp = blockIdx.x / n_cot;
-    const int n_chunks = Cin / 16;
-    const uint4* wbase = wp + (size_t)cot * n_chunks * BCHUNK;
-    const int my_tiles = grp < n_spatial ? (n_spatial - grp + groups - 1) / groups : 0;
-    const int n_items = my_tiles * n_chunks;
-    if (n_items == 0) return;
-
-    auto b_dma = [&](int chunk, uint4* dst) {
-        constexpr int ROWS = STEPS * NT * NP;
-#pragma unroll
-        for (int i = 0; i < (ROWS + 7) / 8; ++i) {
-            const int r = wave + 8 * i;
-            if (r < ROWS)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(wbase + (size_t)chunk * BCHUNK + r * 64 + lane),
-                    (__attribute__((address_space(3))) void*)(dst + r * 64), 16, 0, 0);
-        }
-    };
-    auto tile_of = [&](int tile, int& b, int& y0, int& x0) {
-        int t = grp + tile * groups;
-        const int tx = t % tiles_x; t /= tiles_x;
-        const int ty = t % tiles_y;
-        b = t / tiles_y;
-        x0 = tx * TC; y0 = ty * TR;
-    };
-    int it_r[AU], it_col[AU], it_cell[AU], it_plane[AU];
-    bool it_in[AU];
-#pragma unroll
-    for (int u = 0; u < AU; ++u) {
-        const int item = tid + 512 * u;
-        const int oct = item / CELLS, rc = item - oct * CELLS;
-        it_r[u] = rc / XCOLS;
-        it_col[u] = rc - it_r[u] * XCOLS;
-        it_in[u] = oct < NOCT;
-        it_cell[u] = oct * PLANE + rc;
-        it_plane[u] = min(oct, NOCT - 1) * 8 * (int)plane;
-    }
-    // Streamed weights travel through REGISTERS here, not by LDS-DMA: the compiler waits for vmcnt(0) wherever an LDS-DMA may be
-    // pending (every barrier and every LDS store of the loop), which would drain the deeper patch prefetch at each item. As plain
-    // loads, issued BEFORE the patch loads of the pass, the wait for them leaves those younger loads in flight.
-    constexpr int WU = (BCHUNK + 511) / 512;       // 16-byte cells per thread and chunk: 4 at three channel tiles
-    uint4 breg[WU];
-#pragma unroll
-    for (int u = 0; u < WU; ++u) breg[u] = make_uint4(0u, 0u, 0u, 0u);
-    auto b_issue = [&](int chunk) {
-#pragma unroll
-        for (int u = 0; u < WU; ++u) breg[u] = wbase[(size_t)chunk * BCHUNK + min(tid + 512 * u, BCHUNK - 1)];
-    };
-    auto b_store = [&](uint4* dst) {
-#pragma unroll
-        for (int u = 0; u < WU; ++u)
-            if (tid + 512 * u < BCHUNK) dst[tid + 512 * u] = breg[u];
-    };
-    // ring of PF fetched items; `slot` is a constant after unrolling wherever these are called
-    float apre[PF][AU][8];
-    int sl_b[PF], sl_y0[PF], sl_x0[PF];
-#pragma unroll
-    for (int k = 0; k < PF; ++k) {
-        sl_b[k] = sl_y0[k] = sl_x0[k] = 0;
-#pragma unroll
-        for (int u = 0; u < AU; ++u)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) apre[k][u][j] = 0.f;
-    }
-    int is_tile = 0, is_chunk = 0, ib = 0, iy0 = 0, ix0 = 0;          // the item the next a_issue() fetches (items are issued in order)
-    // Always called once per computed item, also past the block's last item (it then fetches the last tile again, values never
-    // used): the compiler's s_waitcnt placement takes the MINIMUM of the outstanding-load counts over all paths, and a conditional
-    // issue made it wait for vmcnt(15) where 31 are in flight -- the deeper prefetch was waited away.
-    auto a_issue = [&](int slot) {
-        if (is_chunk == 0) tile_of(min(is_tile, my_tiles - 1), ib, iy0, ix0);
-        sl_b[slot] = ib; sl_y0[slot] = iy0; sl_x0[slot] = ix0;
-        const float* xc = x + ((size_t)ib * Cin + (size_t)is_chunk * 16) * plane;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xc, 0, (int)(16 * plane * sizeof(float)),
-                                                                            0x00020000);
-#pragma unroll
-        for (int u = 0; u < AU; ++u) {
-            const int yc = min(max(iy0 + it_r[u] - 1, 0), H - 1), xcl = min(max(ix0 + it_col[u] - 1, 0), W - 1);
-            // (ablation 1 keeps the load INSTRUCTIONS -- a path without them would change the compiler's s_waitcnt placement --
-            // and points every lane at the first pixel of the chunk: no traffic to speak of)
-            const int off = (ablate & 1) ? 0 : (it_plane[u] + yc * W + xcl) * (int)sizeof(float);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                apre[slot][u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                                 rs, off, j * (int)plane * (int)sizeof(float), 0));
-        }
-        if (++is_chunk == n_chunks) { is_chunk = 0; ++is_tile; }
-    };
-    int nb = 0, ny0 = 0, nx0 = 0;                  // tile of the item whose LDS image was written last = the next one computed
-    auto a_store = [&](int slot, uint4* dst) {
-        nb = sl_b[slot]; ny0 = sl_y0[slot]; nx0 = sl_x0[slot];
-        if (ablate & 2) return;
-#pragma unroll
-        for (int u = 0; u < AU; ++u) {
-            if (it_in[u]) {
-                const int yy = ny0 + it_r[u] - 1, xx = nx0 + it_col[u] - 1;
-                const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-                uint4 cells[NP];
-                split_cells8_masked<AR>(apre[slot][u], ok, xscale, cells);
-#pragma unroll
-                for (int p = 0; p < NP; ++p) dst[p * NOCT * PLANE + it_cell[u]] = cells[p];
-            }
-        }
-    };
-
-    f32x4 acc[4][NT0];
-#pragma unroll
-    for (int k = 0; k < PF; ++k) a_issue(k);
-    if (RES) {
-        for (int c = 0; c < n_chunks; ++c) b_dma(c, Bs + (size_t)c * BCHUNK);
-    } else {
-        b_dma(0, Bs);
-    }
-    a_store(0, As);
-    __syncthreads();
-    int cb = 0, cy0 = 0, cx0 = 0, chunk = 0;
-
-    const int a_lane_off = row * XCOLS + n;
-    const int b_lane_off = (half ? NT0 * NP * 64 : 0) + lane;
-#pragma unroll 1
-    for (int it0 = 0; it0 < n_items; it0 += PF) {
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int it = it0 + k;                // it % PF == k (PF = 2: it & 1 == k)
-            if (it < n_items) {
-                if (chunk == 0) {
-                    cb = nb; cy0 = ny0; cx0 = nx0;
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT0; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-                const int next_chunk = chunk + 1 == n_chunks ? 0 : chunk + 1;
-                if (!RES) b_issue(next_chunk);                     // weights of item it + 1 (always issued: see a_issue), before the patch loads
-                a_issue(k);                                        // item it + PF; slot k held item `it`: in LDS since the end of the previous pass
-                const uint4* a_lane = As + (size_t)(it & 1) * A_CELLS + a_lane_off;
-                const uint4* b_base = (RES ? Bs + (size_t)chunk * BCHUNK : Bs + (size_t)(it & 1) * BCHUNK) + b_lane_off;
-                if (!(ablate & 4)) {
-#pragma unroll
-                    for (int s = 0; s < STEPS; ++s) {
-                        const int tap = min(2 * s + (g >> 1), 8);
-                        const int ky = tap / 3, kx = tap - 3 * ky;
-                        const int a_off = (g & 1) * PLANE + ky * XCOLS + kx;
-                        if (half == 0) sb16_kstep<AR, NT0, NT0>(a_lane + a_off, b_base + s * BSTEP, acc);
-                        else if (NT1 > 0) sb16_kstep<AR, NT1, NT0>(a_lane + a_off, b_base + s * BSTEP, acc);
-                    }
-                }
-                if (chunk == n_chunks - 1) {
-                    const int yy = cy0 + row;
-                    if (yy < H) {
-                        float* ybc = y + (size_t)cb * Cout * plane;
-                        const float* abc = addend ? addend + (size_t)cb * Cout * plane : nullptr;
-                        const int co0 = cot * NT * 16;
-                        if (!(ablate & 16)) {
-                            if (half == 0) sb16_store<NT0, NT0>(acc, ybc, bias, abc, co0, plane, yy, cx0, W, g, n, unscale);
-                            else if (NT1 > 0) sb16_store<NT1, NT0>(acc, ybc, bias, abc, co0 + NT0 * 16, plane, yy, cx0, W, g, n, unscale);
-                        }
-                        if (stats && !(ablate & 8)) {
-                            const size_t seg = ((size_t)cb * H + yy) * tiles_x + cx0 / TC;
-                            const bool st_store = !(ablate & 64);
-                            if (half == 0)
-                                cseg_stats_emit<NT0, NT0>(acc, bias, co0, unscale, cx0, W, g, n, stats + (size_t)co0 * n_seg + seg, n_seg,
-                                                          st_store);
-                            else if (NT1 > 0)
-                                cseg_stats_emit<NT1, NT0>(acc, bias, co0 + NT0 * 16, unscale, cx0, W, g, n,
-                                                          stats + (size_t)(co0 + NT0 * 16) * n_seg + seg, n_seg, st_store);
-                        }
-                    }
-                }
-                if (it + 1 < n_items) {
-                    a_store((k + 1) % PF, As + (size_t)((it + 1) & 1) * A_CELLS);
-                    if (!RES && !(ablate & 32)) b_store(Bs + (size_t)((it + 1) & 1) * BCHUNK);      // that buffer was last read in item it - 1
-                }
-                __syncthreads();
-                chunk = next_chunk;
-            }
-        }
-    }
-}
-
-template <class AR, int NT, bool RES, int PF>
-int launch_sb16q(const float* x, const uint4* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W,
-                 const unsigned* amax_x, const unsigned* amax_w, float* y, float4* stats, size_t lds, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)(conv3x3_sb16q_kernel<AR, NT, RES, PF>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
-            cseg_set_error("conv3x3_sb16q: cannot raise dynamic LDS to %zu bytes", lds);
-            return 0;
-        }
-        attr_set = true;
-    }
-    const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
-    const int n_cot = Cout / (NT * 16);
-    const long n_spatial = (long)B * tiles_y * tiles_x;
-    CSEG_REQUIRE(n_spatial < 2147483647L, "conv3x3_sb16q: too many tiles");
-    long groups = persist_cus() / n_cot;
-    if (groups < 1) groups = 1;
-    if (groups > n_spatial) groups = n_spatial;
-    const char* abl = getenv("CSEG_ABLATE");
-    hipLaunchKernelGGL((conv3x3_sb16q_kernel<AR, NT, RES, PF>), dim3((unsigned)(groups * n_cot)), dim3(512), lds, stream, x, wp, bias,
-                       addend, Cin, Cout, H, W, tiles_x, tiles_y, (int)n_spatial, (int)groups, amax_x, amax_w, y, stats, B * H * tiles_x,
-                       abl ? atoi(abl) : 0);
-    CSEG_CHECK_LAUNCH("conv3x3_sb16q_kernel");
-    return 1;
-}
-
-// prefetch distance of the opt-in kernel: 0 = the kernel above
-int sb16q_distance() {
-    const char* e = getenv("CSEG_SB16_PF");
-    const int pf = e ? atoi(e) : 0;
-    return pf < 0 ? 0 : (pf > 2 ? 2 : pf);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1282,17 +1027,10 @@ int fwd(const float* x, const void* wp, const float* bias, const float* addend, 
     const uint4* wq = (const uint4*)wp;
     size_t lds = 0;
     bool res = false;
-    if (sb16q_distance() == 0 && sb16r_plan(arith, B, Cin, Cout, H, W, NT, lds, res))      // (the experimental kernel, when asked for, goes first)
+    if (sb16r_plan(arith, B, Cin, Cout, H, W, NT, lds, res))
         return res ? launch_sb16r<SplitF16x3, true>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream)
                    : launch_sb16r<SplitF16x3, false>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream);
     if (sb16p_plan(arith, Cin, NT, lds, res)) {
-        const int pf = NT == 3 ? sb16q_distance() : 0;
-#define SB16Q(P)                                                                                                                  \
-    if (pf == P)                                                                                                                  \
-        return res ? launch_sb16q<SplitF16x3, 3, true, P>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream) \
-                   : launch_sb16q<SplitF16x3, 3, false, P>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream);
-        SB16Q(1) SB16Q(2)
-#undef SB16Q
 #define SB16P(N)                                                                                                              \
     return res ? launch_sb16p<SplitF16x3, N, true>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream)          \
                : launch_sb16p<SplitF16x3, N, false>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, lds, stream);

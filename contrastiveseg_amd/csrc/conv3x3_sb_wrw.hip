@@ -274,7 +274,7 @@ __device__ __forceinline__ int d2_idx(int buf, int p, int co, int i) { return ((
 // ABL != 0: ABLATION builds for timing experiments only (results are wrong): bit 0 = the consumers skip their MFMAs, bit 1 = the
 // loaders store truncated bits instead of splitting (no conversion arithmetic), bit 2 = the loaders skip the global loads, bit 3 =
 // the loaders do not stage anything after a unit's prologue (consumer-only time).
-// Reached with CSEG_ABLATE=<bits> (tools/ablate_probe.py); never set in the product.
+// (The ablation switches are a template parameter that the library no longer instantiates: timing experiments only, round 4.)
 template <class AR, int SEGW, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                  int B, int Cin, int Cout, int H, int W, int n_split, int rpu,
@@ -729,26 +729,6 @@ int wrw_impl(const float* x, const float* dy, int B, int Cin, int Cout, int H, i
         CSEG_REQUIRE((long)Cin * H * W * 4 < 2147483647L && (long)Cout * H * W * 4 < 2147483647L,
                      "conv3x3_sb_wrw: one image of x / dy must stay below 2 GiB (32-bit offsets)");
         const bool wide = wrw2_seg(W) == 64;
-        const char* abl_env = getenv("CSEG_ABLATE");
-        const int abl = abl_env ? atoi(abl_env) : 0;
-        if (abl && arith == CSEG_ARITH_F16X3 && wide) {                 // timing experiments only (wrong results)
-            int ok2 = 0;
-            switch (abl) {
-                case 1: ok2 = launch_wrw2<SplitF16x3, 64, 1>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
-                case 2: ok2 = launch_wrw2<SplitF16x3, 64, 2>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
-                case 4: ok2 = launch_wrw2<SplitF16x3, 64, 4>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
-                case 6: ok2 = launch_wrw2<SplitF16x3, 64, 6>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
-                case 3: ok2 = launch_wrw2<SplitF16x3, 64, 3>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
-                case 5: ok2 = launch_wrw2<SplitF16x3, 64, 5>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
-                case 14: ok2 = launch_wrw2<SplitF16x3, 64, 14>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
-                default: ok2 = launch_wrw2<SplitF16x3, 64, 7>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream); break;
-            }
-            if (!ok2) return 0;
-            const int total_a = 9 * Cin * Cout;
-            hipLaunchKernelGGL(sb_wrw_reduce_kernel, dim3((total_a + 63) / 64), dim3(256), 0, stream, ws, n_split, Cout, Cin, dw);
-            CSEG_CHECK_LAUNCH("sb_wrw_reduce_kernel");
-            return 1;
-        }
         const int ok = arith == CSEG_ARITH_F16X3
                            ? (wide ? launch_wrw2<SplitF16x3, 64>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream)
                                    : launch_wrw2<SplitF16x3, 32>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream))

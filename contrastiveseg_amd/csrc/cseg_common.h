@@ -41,16 +41,18 @@ __device__ __forceinline__ float4 cseg_load_f4(const void* uniform_base, unsigne
 void cseg_set_error(const char* fmt, ...);
 
 // reference convention: 1 = ok, 0 = error (lib/extensions/cc_attention/src/ca.cu:199-204)
-// XCD-aware block order for grids of independent tiles (round 4, opt-in: CSEG_XCD_REMAP=1). Workgroup b of a grid runs on XCD b % 8
-// (observed on gfx950; only speed depends on it), so consecutive tiles -- neighbours that share halo rows, the channel tile groups
-// that read one patch -- land in 8 different L2 caches. The remap gives every XCD a contiguous run of n / 8 logical blocks, walked
-// in order (the kernels then decode the logical index with the channel tile group fastest); it needs n % 8 == 0 and is the identity
-// otherwise. (The persistent kernels of conv3x3_sb16.hip have their own form of
-// it, on by default: -7 % at 48 channels)
+// XCD-aware block order for grids of independent tiles (round 4; default since round 5, CSEG_XCD_REMAP=0 switches it off). Workgroup b
+// of a grid runs on XCD b % 8 (observed on gfx950; only speed depends on it), so consecutive tiles -- neighbours that share halo rows,
+// the channel tile groups that read one patch -- land in 8 different L2 caches. The remap gives every XCD a contiguous run of n / 8
+// logical blocks, walked in order (the kernels then decode the logical index with the channel tile group fastest); it needs
+// n % 8 == 0 and is the identity otherwise. Measured on the MI355X, A/B/A/B on one box, outputs bit-identical
+// (profiles/r05_xcd_remap_one_tile.txt): 96 channels at 8 x 64 x 128 42.5 / 42.0 -> 40.1 / 39.9 us with statistics, 64 channels at
+// 8 x 128 x 256 76.5 / 77.7 -> 73.6 / 74.7, 192 channels 1-2 %, the 720-channel head 5.46 / 5.48 -> 5.36 / 5.38 ms. (The persistent
+// kernels of conv3x3_sb16.hip have their own form of it: -7 % at 48 channels)
 __device__ __forceinline__ int cseg_xcd_block(int b, int n, int on) { return (on && (n & 7) == 0) ? (b & 7) * (n >> 3) + (b >> 3) : b; }
 static inline int cseg_xcd_remap() {
     const char* e = getenv("CSEG_XCD_REMAP");
-    return e && atoi(e) != 0 ? 1 : 0;
+    return e && atoi(e) == 0 ? 0 : 1;
 }
 
 #define CSEG_CHECK_LAUNCH(name)                                                     \

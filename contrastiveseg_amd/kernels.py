@@ -963,6 +963,8 @@ class SplitWeights(object):
         self.arenas = {}                                 # device -> [arena [n, AMAX_WORDS] int32 (one record per weight), next free row]
         self.table_cache = {}                            # (device, kind of table) -> (identity tuple, device tensor, n_jobs, total_blocks)
         self.epoch = 0
+        self.generation = 0                              # bumped when record ADDRESSES change (_grow): captured hipGraphs hold them
+        self.retired = []                                # outgrown arenas stay allocated: a graph captured earlier may still read them
 
     def invalidate(self):
         """Marks every packed weight (and its max|w| record) stale: call after any change of weight VALUES that does not go through
@@ -988,9 +990,15 @@ class SplitWeights(object):
         key = self._dkey(device)
         old = self.arenas.get(key)
         n = 0 if old is None else old[0].shape[0]
-        new = torch.zeros(max(512, 2 * n), AMAX_WORDS, dtype=I32, device=device)
+        # 2 048 records (8 MB) to start with: HRNet-W48-contrast registers ~330 weights, a second model in the same process still fits
+        new = torch.zeros(max(2048, 2 * n), AMAX_WORDS, dtype=I32, device=device)
         if n:
             new[:n].copy_(old[0])
+            # a hipGraph captured before this point has the OLD record addresses baked in. The old arena is kept alive (no
+            # read of freed memory) and `generation` tells segmentor/tools/step_graph.py to capture again (its records are refreshed
+            # in the new arena only).
+            self.retired.append(old[0])
+            self.generation += 1
         self.arenas[key] = [new, 0 if old is None else old[1]]
         for st in self.weights.values():
             if st["dev"] == key:

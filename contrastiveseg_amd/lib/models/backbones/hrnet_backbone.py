@@ -53,12 +53,17 @@ class BasicBlock(nn.Module):
         fn = getattr(K, "basic_block_split_ok", None)
         if fn is None or self.downsample is not None or not self.training:
             return False
+        # everything the decision reads is in the key: a BatchNorm frozen on its own (`bn.eval()` inside a training block),
+        # a process group / CSEG_DIST_SINGLE_RANK that appears after the first forward, a stride -- each changes the route at once
+        bn1, bn2 = self.bn1, self.bn2
+        g1, g2 = getattr(bn1, "_sync_group", None), getattr(bn2, "_sync_group", None)
+        g1, g2 = (g1() if g1 is not None else None), (g2() if g2 is not None else None)
         key = (x.shape, x.requires_grad, x.is_contiguous(), K.BLOCK_FUSED, K.CONV3X3_SPLIT_BF16, K.CONV3X3_SB_WRW, K.CONV3X3_FORK, K.SPLIT_ARITH,
-               K.CONV3X3_SB_MIN_TILES)
+               K.CONV3X3_SB_MIN_TILES, bn1.training, bn2.training, id(g1), id(g2), self.stride)
         hit = self.__dict__.get("_route")
         if hit is None or hit[0] != key:
-            bn_ok = all(b.track_running_stats and b.momentum is not None and getattr(b, "_sync_group", lambda: None)() is None
-                        and b.weight is not None for b in (self.bn1, self.bn2))
+            bn_ok = all(b.training and b.track_running_stats and b.momentum is not None and g is None and b.weight is not None
+                        for b, g in ((bn1, g1), (bn2, g2))) and self.stride == 1
             hit = (key, bool(bn_ok and fn(x, self.conv1.weight, self.conv2.weight)))
             self.__dict__["_route"] = hit
         return hit[1]

@@ -59,7 +59,35 @@ class ModuleRunner(object):
                       broadcast_buffers=False)
         if next(net.parameters()).is_cuda:
             kwargs.update(device_ids=[device_index()], output_device=device_index())
-        return torch.nn.parallel.DistributedDataParallel(net, **kwargs)
+        ddp = torch.nn.parallel.DistributedDataParallel(net, **kwargs)
+        # that argument only holds while every norm layer IS a SyncBN. With bn_type torchbn / FusedBatchNorm2d under DDP
+        # each rank would drift to its own running statistics (and the rank-0 checkpoint would carry rank 0's only, unannounced).
+        # The reference's behaviour for those layers -- rank 0's buffers win before every forward (DDP's default
+        # broadcast_buffers=True, reference module_runner.py:62-71) -- is kept for exactly those buffers, a few hundred KB, without
+        # bringing the 2 x 97 MB queue broadcast back.
+        unsynced = self.unsynced_norm_buffers(net)
+        if unsynced:
+            Log.info('DDP: {} running-statistics buffers of non-synchronised norm layers follow rank 0 before every forward.'
+                     .format(len(unsynced)))
+            ddp.register_forward_pre_hook(lambda _mod, _args: self.broadcast_from_rank0(unsynced))
+        return ddp
+
+    @staticmethod
+    def unsynced_norm_buffers(net):
+        """Buffers of norm layers that keep running statistics but do not synchronise them across ranks."""
+        norm = torch.nn.modules.batchnorm._NormBase
+        out = []
+        for m in net.modules():
+            if isinstance(m, norm) and m.track_running_stats and not isinstance(m, torch.nn.SyncBatchNorm):
+                out += [b for b in m.buffers(recurse=False)]
+        return out
+
+    @staticmethod
+    def broadcast_from_rank0(tensors, bucket_bytes=32 << 20):
+        """What DDP's own buffer synchronisation does (torch/nn/parallel/distributed.py: _sync_buffers), for the given tensors."""
+        if tensors and is_distributed():
+            with torch.no_grad():
+                torch.distributed._broadcast_coalesced(torch.distributed.group.WORLD, tensors, bucket_bytes, 0)
 
     def _has_unused_parameters(self):
         """True when the model has a head whose output the configured criterion never reads (its parameters would get

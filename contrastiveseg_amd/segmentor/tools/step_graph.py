@@ -21,7 +21,8 @@ torch.randperm draws, the contrast kernels), the memory-bank update and the opti
 The reference semantics are unchanged (segmentor/trainer_contrastive.py:193-267): the same kernels run in the same order on the
 same values; `Trainer.train_step` still does forward -> loss -> zero_grad -> backward -> step. Validation, eval mode,
 no_grad calls, other input shapes than the captured ones and multi-rank runs (SyncBN / DDP collectives between the kernels)
-take the eager path.
+take the eager path: REPLAY IS SINGLE-RANK ONLY (install() returns None under a process group), so the default "auto" mode speeds up
+one-image-per-GPU runs of ONE process, not the ranks of a DDP job.
 
 Findings of the capture probe on the MI355X (tools/graph_probe.py, profiles/r04_graph_probe.txt): capture + replay of forward
 and backward are bit-identical to eager; an autograd graph of an EARLIER eager iteration that is still alive during the capture
@@ -63,7 +64,7 @@ def _set_state(text):
 
 class _Captured(object):
     """One input shape: static input, outputs, gradient buffers and the two graphs."""
-    __slots__ = ("x", "out", "keys", "grad_keys", "g_out", "rows", "sel", "g_fwd", "g_bwd", "grads", "reach", "cap")
+    __slots__ = ("x", "out", "keys", "grad_keys", "g_out", "rows", "sel", "g_fwd", "g_bwd", "grads", "reach", "cap", "gen")
 
 
 class _Replay(torch.autograd.Function):
@@ -144,17 +145,23 @@ class GraphedEncoder(object):
             return self.eager_forward(x_, with_embed=with_embed, is_eval=is_eval, **kw)
         key = (tuple(x_.shape), x_.device.index)
         cap = self.captured.get(key)
+        if cap is not None and cap.gen != K.SPLIT_WEIGHTS.generation:
+            # the max|w| records moved (another model registered its weights and the arena grew): the graphs hold the old addresses
+            del self.captured[key]
+            cap = None
         if cap is None:
             if len(self.captured) >= MAX_SHAPES:
                 return self.eager_forward(x_, with_embed=with_embed, is_eval=is_eval)
             try:
                 cap = self._capture(x_)
             except Exception as e:               # a failed capture must not cost the run: eager from here on
+                # (_capture has already put the BatchNorm buffers / the RNG back and dropped the capture's max|.| arenas)
                 self.failed = repr(e)
                 _CAPTURING[0] = False
                 _set_state("eager (capture failed: %s)" % self.failed[:120])
                 Log.warn("step graph: capture failed, continuing eagerly: %s" % self.failed)
-                torch.cuda.synchronize()
+                if not torch.cuda.is_current_stream_capturing():      # a synchronize inside a live capture raises by itself
+                    torch.cuda.synchronize()
                 return self.eager_forward(x_, with_embed=with_embed, is_eval=is_eval)
             self.captured[key] = cap
         slot = K.SparseGradSlot() if cap.rows is not None else None
@@ -182,6 +189,7 @@ class GraphedEncoder(object):
         cap.cap = self.max_rows
         main = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
+        done = False
         torch.cuda.synchronize(dev)
         gc.collect()                       # no autograd graph of an earlier iteration may survive into the capture (module docstring)
         side.wait_stream(main)
@@ -233,17 +241,35 @@ class GraphedEncoder(object):
                         gout.append(cap.g_out[k])
                 with torch.cuda.graph(cap.g_bwd, pool=pool, stream=side):
                     cap.grads = torch.autograd.grad([out[k] for k in cap.grad_keys], self.params, gout, allow_unused=True)
-                K._AMAX_ARENAS.clear()     # eager code gets arenas of its own again (the captured ones are re-zeroed by every replay)
+            done = True
         finally:
             _CAPTURING[0] = False
+            K._AMAX_ARENAS.clear()         # eager code gets arenas of its own again (the captured ones are re-zeroed by every replay)
+            if not done:
+                # the warm-up iterations (and a capture that broke half-way) have advanced the running statistics,
+                # num_batches_tracked and the RNG -- the eager fallback must start from the state the caller handed in
+                self._restore_after_failure(restore, main, side, dev)
         main.wait_stream(side)
         torch.cuda.synchronize(dev)
         restore()
+        cap.gen = K.SPLIT_WEIGHTS.generation
         n_p = sum(1 for g in cap.grads if g is not None)
         _set_state("replay (forward + backward hipGraphs, %d parameter gradients, %s)"
                    % (n_p, "row-sparse embedding gradient, capacity %d" % cap.cap if cap.rows is not None else "dense gradients"))
         Log.info("step graph: captured forward + backward for input %s" % (tuple(x.shape),))
         return cap
+
+    @staticmethod
+    def _restore_after_failure(restore, main, side, dev):
+        """Best effort, never raises (the original exception is the one the caller reports)."""
+        try:
+            if torch.cuda.is_current_stream_capturing():
+                return                     # still inside a capture that could not be ended: nothing can be copied here
+            main.wait_stream(side)
+            torch.cuda.synchronize(dev)
+            restore()
+        except Exception as e:             # pragma: no cover  (a device that is gone)
+            Log.warn("step graph: could not restore the BatchNorm buffers / RNG after a failed capture: %r" % (e,))
 
     def _standin_grad(self, out, k):
         """Gradient fed to output `k` during warm-up: zeros -- through the sparse slot for the embedding, so that the warm-up runs the

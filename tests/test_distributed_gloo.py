@@ -597,6 +597,12 @@ def test_ddp_wrap_does_not_broadcast_buffers():
     from contrastiveseg_amd.segmentor.tools import module_runner
     src = inspect.getsource(module_runner.ModuleRunner._make_parallel)
     assert "broadcast_buffers=False" in src and "has_queues" not in src
+    # ... except for the running statistics of norm layers that do not synchronise themselves (rank 0's win, as in the reference)
+    import torch
+    from contrastiveseg_amd.lib.models.tools.fused_bn import FusedBatchNorm2d, FusedSyncBatchNorm
+    net = torch.nn.Sequential(FusedSyncBatchNorm(4), FusedBatchNorm2d(4), torch.nn.BatchNorm2d(4), torch.nn.SyncBatchNorm(4))
+    bufs = module_runner.ModuleRunner.unsynced_norm_buffers(net)
+    assert len(bufs) == 6 and all(any(b is x for x in list(net[1].buffers()) + list(net[2].buffers())) for b in bufs)
 
 
 def _ddp_mem_worker(rank, world, port, q):
@@ -630,12 +636,19 @@ def _ddp_mem_worker(rank, world, port, q):
     torch.manual_seed(1000 + rank)                          # the ranks' CPU generators differ from here on (anchor / enqueue draws)
     loader = SyntheticLoader(cfg, torch.device("cpu"), length=3, mode="blocky")
     tr.seg_net.train()
+    # running statistics of a NON-synchronised norm layer that drifted on rank 1: rank 0's win before the next forward (the reference's
+    # DDP default for every buffer, kept for these few -- ADVICE r4)
+    bn = next(m for m in ddp.module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm))
+    assert not isinstance(bn, torch.nn.SyncBatchNorm)
+    if rank == 1:
+        with torch.no_grad():
+            bn.running_mean.fill_(7.0)
     for b in loader:
         loss = tr.train_step(b)
     net = ddp.module
     q.put((rank, float(loss), net.segment_queue.numpy().copy(), net.pixel_queue.numpy().copy(),
            net.segment_queue_ptr.numpy().copy(), net.pixel_queue_ptr.numpy().copy(),
-           next(net.parameters()).detach().reshape(-1)[:8].numpy().copy()))
+           next(net.parameters()).detach().reshape(-1)[:8].numpy().copy(), bn.running_mean.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -656,6 +669,9 @@ def test_trainer_ddp_memory_bank_stays_identical_without_buffer_broadcast():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert np.isfinite(res[0][1]) and np.isfinite(res[1][1])
-    for a, b in zip(res[0][2:], res[1][2:]):
+    for a, b in zip(res[0][2:7], res[1][2:7]):
         assert np.array_equal(a, b), "the ranks diverged"
     assert int(res[0][4].sum()) > 0 and int(res[0][5].sum()) > 0, "nothing was enqueued"
+    # plain BatchNorm under DDP: the 7.0 planted on rank 1 was replaced by rank 0's statistics before the first forward; what is left
+    # after the last step is 0.1 x the difference of the two ranks' batch means (without the hook: 0.9^3 x 7 = 5.1)
+    assert np.abs(res[0][7] - res[1][7]).max() < 0.5, np.abs(res[0][7] - res[1][7]).max()

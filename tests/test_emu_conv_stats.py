@@ -22,9 +22,8 @@ CASES = [
 ]
 
 
-# opt-in variants of the persistent small-channel kernel (conv3x3_sb16q_kernel: CSEG_SB16_PF, round 4) on the cases it takes
-OPT_IN = [({}, c) for c in CASES] + [({"CSEG_SB16_PF": "1"}, CASES[0]), ({"CSEG_SB16_PF": "2"}, CASES[3]),
-                                     ({"CSEG_SB16_ROWS8": "2"}, CASES[0]), ({"CSEG_SB16_ROWS8": "2"}, CASES[3])]    # the 8-row tiles
+# the default route of every case + the 8-row tiles forced on the two cases the persistent small-channel kernels take
+OPT_IN = [({}, c) for c in CASES] + [({"CSEG_SB16_ROWS8": "2"}, CASES[0]), ({"CSEG_SB16_ROWS8": "2"}, CASES[3])]
 
 
 @pytest.mark.parametrize("env,case", OPT_IN)

@@ -391,31 +391,6 @@ def test_epilogue_addend(case, arith, wave_order):
     assert np.abs(y - ref).max() <= _bound(ref, 9 * ci)
 
 
-# ---- round 4 (opt-in, CSEG_SB16_PF): the persistent kernel with the patch prefetch 1 - 3 items deep (conv3x3_sb16q_kernel) --------
-@pytest.mark.parametrize("pf", ["1", "2"])
-@pytest.mark.parametrize("case,what", [
-    ((1, 48, 48, 6, 68), "weights resident, ragged tiles, one tile per block"),
-    ((1, 16, 48, 5, 68), "ONE chunk per tile: fewer items than ring slots at pf 2 / 3"),
-    ((1, 32, 48, 104, 640), "260 tiles on 256 blocks: some blocks walk two tiles with the weights resident"),
-    ((1, 96, 48, 5, 68), "weights streamed through registers (6 chunks do not fit), ragged tiles"),
-    ((2, 96, 48, 52, 640), "260 tiles, streamed weights across the tile boundary"),
-])
-def test_deeper_prefetch_is_bit_identical_to_the_persistent_kernel(case, what, pf, monkeypatch, tmp_path):
-    monkeypatch.setenv("CSEG_EMU_WAVE_ORDER", "shuffle:%s" % pf)
-    B, ci, co, H, W = case
-    x, w, b = _rand((B, ci, H, W), 81, 2.0), _rand((co, ci, 3, 3), 82, 1.0 / (3 * ci ** 0.5)), _rand((co,), 83)
-    y0 = E.conv3x3_sb(x, w, b, arith=E.F16X3)
-    ref = E.ref_conv3x3(x, w, b)
-    assert np.abs(y0 - ref).max() <= _bound(ref, 9 * ci), what
-    monkeypatch.setenv("CSEG_SB16_PF", pf)
-    trace = tmp_path / "launches.txt"
-    monkeypatch.setenv("CSEG_EMU_TRACE", str(trace))
-    y1 = E.conv3x3_sb(x, w, b, arith=E.F16X3)
-    assert "conv3x3_sb16q_kernel" in trace.read_text(), "the switch did not route to the opt-in kernel"
-    assert not np.isnan(y1).any()
-    assert np.array_equal(y0, y1), "same LDS images, same K-steps, same accumulation order: bit-identical (%s)" % what
-
-
 # ---- round 4 (CSEG_SB16_ROWS8; default where the tiles fill 256 blocks): 8 x 64-pixel tiles, one wave per output row x three channel tiles (conv3x3_sb16r_kernel) ----
 @pytest.mark.parametrize("case,what", [
     ((1, 48, 48, 11, 68), "weights resident + ONE patch buffer (two barriers per chunk), ragged tiles both ways (11 rows, 68 columns)"),

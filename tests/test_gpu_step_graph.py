@@ -146,3 +146,58 @@ def test_graph_falls_back_for_what_it_does_not_cover(monkeypatch):
         out = net(torch.randn(2, 3, 128, w, device=x.device), with_embed=True)
         assert torch.isfinite(out["seg"]).all()
     assert len(g.captured) == step_graph.MAX_SHAPES
+
+
+@pytest.mark.parametrize("where", ["warmup", "capture"])
+def test_failed_capture_leaves_the_training_state_untouched(where, monkeypatch):
+    """a capture that breaks -- in the warm-up iterations or inside the stream capture -- falls back to the eager step
+    FROM THE STATE THE CALLER HAD: BatchNorm running statistics, num_batches_tracked and the CUDA RNG are what they were before the
+    attempt, so the first eager step after the failure equals the first step of a run that never tried to capture."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from contrastiveseg_amd.segmentor.tools import step_graph
+    monkeypatch.setattr(step_graph, "MODE", "1")
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
+    states = {}
+    for name, on in (("eager", False), ("broken", True)):
+        monkeypatch.setattr(step_graph, "ENABLED", on)
+        tr, data = _trainer(*CASES[0])
+        if on:
+            g = tr.step_graph
+            assert g is not None
+            if where == "warmup":
+                calls = [0]
+                real = g.eager_forward
+
+                def flaky(*a, **k):
+                    calls[0] += 1
+                    if calls[0] == 2:                        # the second warm-up iteration: buffers and RNG have moved by then
+                        raise RuntimeError("planted warm-up failure")
+                    return real(*a, **k)
+                g.eager_forward = flaky
+            else:
+                class Broken(object):
+                    def __init__(self, *a, **k):
+                        raise RuntimeError("planted capture failure")
+                monkeypatch.setattr(torch.cuda, "CUDAGraph", Broken)
+        before = {k: v.detach().clone() for k, v in tr.seg_net.state_dict().items() if "running_" in k or "num_batches" in k}
+        torch.manual_seed(17)
+        torch.cuda.manual_seed(5)
+        loss = float(tr.train_step(data))
+        torch.cuda.synchronize()
+        if on:
+            assert g.failed is not None and "planted" in g.failed and not g.captured
+            assert os.environ.get("CSEG_STEP_GRAPH_STATE", "").startswith("eager (capture failed")
+        states[name] = (loss, before, {k: v.detach().clone() for k, v in tr.seg_net.state_dict().items() if k in before},
+                        torch.cuda.get_rng_state())
+        del tr, data
+        torch.cuda.empty_cache()
+    (le, be, ae, re_), (lb, bb, ab, rb) = states["eager"], states["broken"]
+    assert abs(le - lb) <= 2e-6 * abs(le), (le, lb)
+    for k in ae:
+        assert torch.equal(be[k], bb[k])
+        if k.endswith("num_batches_tracked"):
+            assert int(ab[k]) == int(ae[k]) == int(be[k]) + 1, (k, int(be[k]), int(ae[k]), int(ab[k]))     # ONE step, not 1 + warm-ups
+        else:
+            assert torch.allclose(ae[k], ab[k], rtol=1e-5, atol=1e-6), k
+    assert torch.equal(re_, rb)

@@ -170,9 +170,12 @@ def test_bench_line_is_assembled_from_measurements(monkeypatch, tmp_path):
             args = types.SimpleNamespace(steps=10, warmup=3, scaling="strong", workload=workload, labels=None, miopen_find=0,
                                          channels_last=0)
             kernels = {"upcat_fwd": {"us": 190.0, "note": "n" * 3000}} if extras else {"error": "boom"}
-            rows = [{"kernel": "conv3x3 720->720 forward @8x128x256 " + "k" * (40 * i), "entry": "conv3x3_sb_run", "calls_per_step": 1,
-                     "us_per_launch": 6500.0 - i, "ms_per_step": 6.5, "algorithmic_flops_per_launch": 2446118092800,
-                     "achieved_TFLOPs": 376.3, "peak_TFLOPs": 833.3, "frac": 0.4516} for i in range(60)] if extras else None
+            # two kernel families: 30 rows of one entry point at 6.5 ms each, 30 of another at 3 ms -- the line names the FAMILY with
+            # the larger time per step, flops and time summed over its launches
+            rows = [{"kernel": "conv3x3 720->720 forward @8x128x256 " + "k" * (40 * i), "entry": "conv3x3_sb_run" if i % 2 == 0 else "conv3x3_sb_wrw",
+                     "calls_per_step": 1, "us_per_launch": 6500.0 if i % 2 == 0 else 3000.0, "ms_per_step": 6.5 if i % 2 == 0 else 3.0,
+                     "algorithmic_flops_per_launch": 2446118092800, "achieved_TFLOPs": 376.3, "peak_TFLOPs": 833.3,
+                     "frac": 0.4516 if i else 0.2} for i in range(60)] if extras else None
             split_flops = 12.7e12 / world if split_on else 0.0
             line, detail = bench.assemble_line(
                 args, wl, cfg, world, wl["batch"], 1.766, 1765.0, 2.34567, split_on, Kn, "nccl" if world > 1 else None,
@@ -207,6 +210,12 @@ def test_bench_line_is_assembled_from_measurements(monkeypatch, tmp_path):
             assert ("dominant_kernel" in r) == (extras and split_on)
             if extras and split_on:
                 assert set(r["dominant_kernel"]) >= {"name", "frac", "us"} and r["dominant_kernel"]["us"] == 6500.0
+                assert r["dominant_kernel"]["calls_per_step"] == 30 and abs(r["dominant_kernel"]["ms_per_step"] - 195.0) < 1e-6
+                assert abs(r["dominant_kernel"]["frac"] - 2446118092800 / 6.5e-3 * 1e-12 / 833.3) < 2e-3
+                fam = detail["split_kernel_families"]
+                assert [f["entry"] for f in fam] == ["conv3x3_sb_run", "conv3x3_sb_wrw"] and len(fam[0]["members"]) == 30
+                assert detail["roofline"]["dominant_kernel"]["worst_member"]["frac"] == 0.2
+                assert "traffic_source" in r or r["traffic"] is None
                 assert back["cpu_baseline"]["kind"] == "port" and len(back["cpu_baseline"]["sample"]) <= 160
             # nothing is lost: the tables are in the detail object, which is what bench.py writes next to itself
             assert detail["kernels"] == kernels and detail["split_kernels"] == rows

@@ -253,7 +253,7 @@ def test_whole_step_timings_for_the_next_round():
 
 
 _FAMILIES = [("conv3x3_sb_wrw_s2", "s2"), ("conv3x3_s2_", "s2"),                                   # stride-2 kernels (round 3), before "conv3x3_sb_wrw"
-             ("conv3x3_sb_kernel", "c3"), ("conv3x3_sb16_kernel", "c3"), ("conv3x3_sb16p_kernel", "c3"), ("conv3x3_sb16r_kernel", "c3"), ("conv3x3_sb16q_kernel", "c3"),
+             ("conv3x3_sb_kernel", "c3"), ("conv3x3_sb16_kernel", "c3"), ("conv3x3_sb16p_kernel", "c3"), ("conv3x3_sb16r_kernel", "c3"),
              ("conv3x3_sb8_kernel", "c3"), ("conv3x3_sb_wrw", "c3wrw"),
              ("sb_wrw_reduce", "c3wrw"), ("pack_batch", "pack"), ("amax_batch", "amax"),
              ("pack_weights", "pack"), ("conv1x1_sb", "c1"), ("sb_wrw1_reduce", "c1"), ("amax_kernel", "amax"),

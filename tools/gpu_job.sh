@@ -1,0 +1,73 @@
+#!/bin/bash
+# ONE parametrised script for everything this repo puts on an MI355X box through `gpurun` (replaces the 79 one-shot
+# tools/gpu_jobs/r0N_job*.sh lab-notebook scripts of rounds 2-4; the numbers they produced are under profiles/ and in DESIGN.md).
+#   gpurun --timeout 900 -- 'bash tools/gpu_job.sh <tag> <step> [<step> ...]'
+# writes to gpurun_out/<tag>/ . Steps (run in the order given; each bounded by its own `timeout`):
+#   smoke            __graft_entry__.smoke()
+#   suite[:<expr>]   pytest -m gpu (optionally -k <expr>)
+#   bench[:<args>]   bench.py with extra args (comma-separated, e.g. bench:--steps,20,--warmup,5); default = the short form
+#   ab:<ENV=VAL>     short bench without / with / without / with the environment setting (A/B/A/B on one box)
+#   stats            rocprofv3 --kernel-trace of 6 steady steps -> step_steady_kernel_stats.csv + idle gaps
+#   pmc              rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) -> step_pmc.json
+#   longrun[:<n>]    tools/long_run_arith.py (default 200 steps): default arithmetic vs strict fp32 vs a one-ulp perturbation
+#   probe:<args>     tools/probes/conv_probe with the given arguments (';' separates arguments)
+#   host             tools/host_profile.py 8
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:?tag}; shift
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+SHORT="--no-kernels --no-cpu-baseline --no-fp32-pass --steps 12 --warmup 4"
+for step in "$@"; do
+  name=${step%%:*}; arg=""; [ "$step" != "$name" ] && arg=${step#*:}
+  case $name in
+    smoke) timeout 150 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
+    suite)
+      if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -k "$arg" > $O/tests.log 2>&1
+      else timeout 1500 python -m pytest tests -m gpu -q --timeout 600 > $O/tests.log 2>&1; fi
+      grep -E "passed|failed|Error|Fatal|CSEG_ZZ|^FAILED" $O/tests.log | cut -c1-1500 | tail -12 ;;
+    bench)
+      a=${arg//,/ }; [ -z "$a" ] && a=$SHORT
+      CSEG_BENCH_GUARD=0 timeout 900 python bench.py $a > $O/bench.log 2> $O/bench.err; tail -1 $O/bench.log | cut -c1-1800
+      cp bench_detail.json $O/bench_detail.json 2>/dev/null ;;
+    ab)
+      for r in 1 2; do for on in 0 1; do
+        if [ $on = 1 ]; then env "$arg" CSEG_BENCH_GUARD=0 timeout 200 python bench.py $SHORT > $O/ab_${on}_$r.log 2> $O/ab_${on}_$r.err
+        else CSEG_BENCH_GUARD=0 timeout 200 python bench.py $SHORT > $O/ab_${on}_$r.log 2> $O/ab_${on}_$r.err; fi
+        echo "$arg on=$on run $r: $(tail -1 $O/ab_${on}_$r.log | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], "ms/step", d["value"], "img/s")' 2>&1 | tail -1)"
+      done; done | tee $O/ab.txt ;;
+    stats)
+      cd /tmp
+      CSEG_BENCH_GUARD=0 timeout 400 rocprofv3 --kernel-trace -d $O/trace -o t --output-format csv -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernels --no-fp32-pass > $O/bench_under_rocprof.json 2> $O/trace.err
+      cd $R
+      T=$(find $O/trace -name "*kernel_trace.csv" | head -1)
+      MS=$(tail -1 $O/bench_under_rocprof.json | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"])')
+      echo "under rocprof: $MS ms/step"
+      python tools/trace_window_stats.py $T $(python -c "print(5*$MS/1000.0)") > $O/step_steady_kernel_stats.csv 2> $O/window.txt; cat $O/window.txt
+      python tools/trace_gaps.py $T $(python -c "print(3*$MS/1000.0)") 30 > $O/step_trace_gaps.txt; head -12 $O/step_trace_gaps.txt | cut -c1-200
+      rm -rf $O/trace ;;
+    pmc)
+      cd /tmp
+      for ctr in FETCH_SIZE WRITE_SIZE; do
+        CSEG_BENCH_GUARD=0 timeout 400 rocprofv3 --pmc $ctr --kernel-trace -d $O/pmc_$ctr -o p --output-format csv -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-kernels --no-fp32-pass > $O/pmc_$ctr.out 2> $O/pmc_$ctr.err
+        c=$(find $O/pmc_$ctr -name '*counter_collection.csv' | head -1)
+        [ -n "$c" ] && python $R/tools/step_pmc_summary.py $c $ctr 2 > $O/step_pmc_$ctr.json 2> $O/step_pmc_$ctr.err
+        rm -rf $O/pmc_$ctr
+      done
+      cd $R
+      python tools/merge_step_pmc.py $O/step_pmc_FETCH_SIZE.json $O/step_pmc_WRITE_SIZE.json "tree of $TAG" > $O/step_pmc.json 2> $O/step_pmc.err
+      head -5 $O/step_pmc.json | cut -c1-200 ;;
+    longrun)
+      timeout 600 python tools/long_run_arith.py --steps ${arg:-200} > $O/long_run_arith.json 2> $O/long_run_arith.err
+      tail -3 $O/long_run_arith.err; python -c "import json; d=json.load(open('$O/long_run_arith.json')); print(d['finite']); print(d['window_mean_rel_dev'])" ;;
+    probe)
+      export LD_LIBRARY_PATH=/opt/rocm/lib:$LD_LIBRARY_PATH
+      P=tools/probes/conv_probe
+      [ -x $P ] || g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tools/probes/conv_probe.cpp -o $P -L/opt/rocm/lib -lamdhip64 -ldl
+      IFS=';' read -ra PA <<< "$arg"
+      timeout 120 $P "${PA[@]}" > $O/probe_$(date +%s%N).jsonl 2>> $O/probe.err; cat $O/probe_*.jsonl | tail -40 | cut -c1-400 ;;
+    host) timeout 200 python tools/host_profile.py 8 > $O/host_profile.txt 2>&1; head -3 $O/host_profile.txt ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
