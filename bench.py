@@ -87,6 +87,12 @@ def parse():
     p.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; gloo lets several "
                                                    "ranks share one GPU for a dry run)")
     p.add_argument("--no-weak", action="store_true", help="skip the extra weak-scaling measurement at N > 1")
+    p.add_argument("--dist-single-rank", action="store_true",
+                   help="N = 1 only: run inside a process group of ONE rank with CSEG_DIST_SINGLE_RANK=1, so that every multi-rank code "
+                        "path (DDP wrapper and its bucketed all-reduce, the batched SyncBN exchange with the branches in lockstep, the "
+                        "counts / anchor all-gathers) runs -- through RCCL on the default backend. What one rank of an N-GPU job pays per "
+                        "step at the given --global-batch (= its per-GPU batch), minus the wire time: the measurable part of the "
+                        "multi-GPU design on a 1-GPU box. NOT the BASELINE metric: reported as workload '<wl>+dist1'.")
     p.add_argument("--miopen-find", type=int, default=0,
                    help="cudnn.benchmark = MIOpen exhaustive find (a 20+ min warm-up on a fresh box); default off: "
                         "immediate mode + the tuned records shipped in contrastiveseg_amd/miopen_db")
@@ -491,8 +497,8 @@ def assemble_line(args, wl, cfg, world, global_batch, dt, ev_ms, final_loss, spl
         if "sample" in cpu:
             cpu_short["sample"] = cpu["sample"][:160]
     line = {
-        "metric": "images/sec contrastive train step, HRNet-W48 1024x512 bs8" if args.workload == "cfg2" else
-                  "images/sec contrastive train step, " + args.workload,
+        "metric": "images/sec contrastive train step, HRNet-W48 1024x512 bs8" if (args.workload == "cfg2" and not getattr(args, "dist_single_rank", False)) else
+                  "images/sec contrastive train step, " + args.workload + ("+dist1" if getattr(args, "dist_single_rank", False) else ""),
         "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": arithmetic_name(Kn, split_on), "data": "synthetic",
@@ -500,7 +506,9 @@ def assemble_line(args, wl, cfg, world, global_batch, dt, ev_ms, final_loss, spl
                    "loss": cfg.get("loss", "loss_type"), "global_batch": global_batch,
                    "per_gpu_batch": global_batch // world, "input": [3, H, W],
                    "arithmetic": ("%s on the matrix cores for the 3x3 / 1x1 convolutions, rest fp32" % arith) if split_on else "fp32",
-                   "parallelism": "dp%d" % world, "backend": backend,
+                   "parallelism": "dp%d" % world if not getattr(args, "dist_single_rank", False) else
+                                  "dp1 inside a one-rank process group: multi-rank code paths on (DDP, SyncBN exchange, all-gathers)",
+                   "backend": backend,
                    "step_graph": os.environ.get("CSEG_STEP_GRAPH_STATE"),
                    "final_loss": round(final_loss, 5)},
         "roofline": roofline, "cpu_baseline": cpu_short, "detail": DETAIL_NAME,
@@ -738,6 +746,13 @@ def main():
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     if args.backend:
         os.environ["CSEG_DIST_BACKEND"] = args.backend
+    if args.dist_single_rank:
+        assert world == 1, "--dist-single-rank is an N = 1 measurement"
+        os.environ.update(CSEG_DIST_SINGLE_RANK="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(D.free_port()))
+        torch.cuda.set_device(0)
+        torch.distributed.init_process_group(args.backend or "nccl", rank=0, world_size=1)
     D.setup_process_group()
     local = D.device_index()
     torch.cuda.set_device(local)
@@ -839,12 +854,12 @@ def main():
 
     if rank == 0:
         line, detail = assemble_line(args, wl, cfg, world, global_batch, dt, ev_ms, final_loss, split_on, Kn,
-                                     torch.distributed.get_backend() if world > 1 else None, fp32_pass, weak, cpu, kernels,
+                                     torch.distributed.get_backend() if (world > 1 or args.dist_single_rank) else None, fp32_pass, weak, cpu, kernels,
                                      split_rows if (split_rows and "error" not in split_rows[0]) else None, split_flops)
         write_detail(detail)
         sys.stderr.flush()
         print(json.dumps(line), flush=True)           # the LAST line of stdout, <= LINE_LIMIT bytes
-    if world > 1:
+    if world > 1 or args.dist_single_rank:
         torch.distributed.destroy_process_group()
 
 

@@ -65,12 +65,33 @@ class ModuleRunner(object):
         # The reference's behaviour for those layers -- rank 0's buffers win before every forward (DDP's default
         # broadcast_buffers=True, reference module_runner.py:62-71) -- is kept for exactly those buffers, a few hundred KB, without
         # bringing the 2 x 97 MB queue broadcast back.
+        if next(net.parameters()).is_cuda:
+            self._join_forks_before_collectives(ddp)
         unsynced = self.unsynced_norm_buffers(net)
         if unsynced:
             Log.info('DDP: {} running-statistics buffers of non-synchronised norm layers follow rank 0 before every forward.'
                      .format(len(unsynced)))
             ddp.register_forward_pre_hook(lambda _mod, _args: self.broadcast_from_rank0(unsynced))
         return ddp
+
+    @staticmethod
+    def _join_forks_before_collectives(ddp):
+        """the forked HRNet branches / exchange paths (lib/models/backbones/hrnet_backbone.py) under DDP. The reducer
+        issues a bucket's all-reduce from the autograd hook of the LAST gradient that lands in the bucket, ordered after the stream that
+        hook runs on -- gradients of the same bucket written on the other fork streams were not waited for, which is why round 4 switched
+        the forks off under any process group. The comm hook below makes the hook's stream wait for every fork stream first (all
+        producers of the bucket have been ENQUEUED by then: a bucket completes only after each of its gradients was marked ready by its
+        own hook), then runs DDP's own all-reduce (mean over ranks). One wait per fork stream per bucket: ~5 buckets x 3 streams per
+        step. Reference: segmentor/tools/module_runner.py:62-76 (plain DDP on one stream)."""
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        from contrastiveseg_amd.lib.models.backbones import hrnet_backbone as HB
+
+        def hook(state, bucket):
+            HB.join_fork_streams(bucket.buffer().device)
+            return default_hooks.allreduce_hook(state, bucket)
+
+        ddp.register_comm_hook(None, hook)
+        HB.DDP_FORKS_OK = True
 
     @staticmethod
     def unsynced_norm_buffers(net):
