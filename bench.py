@@ -204,6 +204,20 @@ def kernel_rooflines(device, B, K=19, H=512, W=1024, stride=4, D=256):
     entry("contrast_bank_fwd 1024x4104", time_kernel(bank), flops=2.0 * 1024 * 4104 * D)
     entry("contrast_bank_fwd+bwd 1024x4104", time_kernel(lambda: torch.autograd.grad(bank(), A)),
           flops=2.0 * 1024 * 4104 * D * 2)
+    # the forward alone, both implementations: three launches with S through HBM vs the fused single launch.
+    # Host + device time of back-to-back calls as the step issues them; device-only durations: profiles/r05_contrast_fused_kernels.txt
+    anchors_self = Kn.gather_anchors(embed, cp["part_idx"], sel_pos)[0]
+    was = Kn.CONTRAST_FUSED
+    try:
+        for tag, flag in (("three launches, S via HBM", "0"), ("fused, one launch", "1")):
+            Kn.CONTRAST_FUSED = flag
+            d_self = Kn._desc(0, anchors_self, a_lab, 0.1, 0.07)
+            entry("contrast_self_fwd only [%s] N=%d" % (tag, N), time_kernel(lambda: Kn.contrast_forward(d_self, device)), flops=2.0 * N * N * D)
+            d_bank = Kn._desc(2, A.detach(), yl, 0.1, 0.07, None, None, sq, pq)
+            entry("contrast_bank_fwd only [%s] 1024x4104" % tag, time_kernel(lambda: Kn.contrast_forward(d_bank, device)),
+                  flops=2.0 * 1024 * 4104 * D)
+    finally:
+        Kn.CONTRAST_FUSED = was
     # HRNet head input
     chans = [48, 96, 192, 384]
     feats = [torch.randn(B, c, h >> i, w >> i, generator=g).to(device).requires_grad_(True)

@@ -33,6 +33,9 @@ SIGNATURES = {
     "cseg_scatter_anchor_grad": (_c_int, [_ptr, _c_int, _ptr, _c_int, _c_int, _c_int, _c_float, _ptr, _ptr]),
     "cseg_contrast_ws_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
     "cseg_contrast_fwd": (_c_int, [ctypes.POINTER(ContrastDesc), _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "cseg_contrast_fused_ws_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
+    "cseg_contrast_fused_counter_offset": (ctypes.c_size_t, [_c_int, _c_int]),
+    "cseg_contrast_fwd_fused": (_c_int, [ctypes.POINTER(ContrastDesc), _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_contrast_bwd_parts": (_c_int, [_c_int, _c_int, _c_int]),
     "cseg_contrast_bwd": (_c_int, [ctypes.POINTER(ContrastDesc), _ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_upcat_fwd": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr]),

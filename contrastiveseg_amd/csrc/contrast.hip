@@ -90,12 +90,11 @@ constexpr int SG_T = 64;      // tile edge (rows and columns)
 constexpr int SG_KC = 64;     // features per chunk
 constexpr int SG_LD = 68;     // LDS row stride in floats
 
-__global__ __launch_bounds__(256) void s_gemm_kernel(const float* __restrict__ A, int N, ColSrc col, float inv_tau,
-                                                     float* __restrict__ S, int ldS, int nJb) {
-    __shared__ __attribute__((aligned(16))) float As[SG_T * SG_LD];
-    __shared__ __attribute__((aligned(16))) float Cs[SG_T * SG_LD];
+// this wave's 32 x 32 part (wi = wave >> 1, wj = wave & 1) of the 64 x 64 tile (I0, J0) of A . C^T, unscaled; As / Cs: the block's
+// staging arrays. Starts with a block barrier (the previous tile's fragment reads), so calls can follow each other directly.
+__device__ __forceinline__ f32x16 s_tile_64(const float* __restrict__ A, int N, const ColSrc& col, int I0, int J0, float* __restrict__ As,
+                                            float* __restrict__ Cs) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int I0 = (blockIdx.x / nJb) * SG_T, J0 = (blockIdx.x % nJb) * SG_T;
     const int wi = wave >> 1, wj = wave & 1;
     const int h = lane >> 5, r32 = lane & 31;
     const int D = col.D;
@@ -151,6 +150,18 @@ __global__ __launch_bounds__(256) void s_gemm_kernel(const float* __restrict__ A
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
         }
     }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void s_gemm_kernel(const float* __restrict__ A, int N, ColSrc col, float inv_tau,
+                                                     float* __restrict__ S, int ldS, int nJb) {
+    __shared__ __attribute__((aligned(16))) float As[SG_T * SG_LD];
+    __shared__ __attribute__((aligned(16))) float Cs[SG_T * SG_LD];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int I0 = (blockIdx.x / nJb) * SG_T, J0 = (blockIdx.x % nJb) * SG_T;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int h = lane >> 5, r32 = lane & 31;
+    const f32x16 acc = s_tile_64(A, N, col, I0, J0, As, Cs);
     // C layout: this lane holds column j, rows (r&3) + 8*(r>>2) + 4*h of the wave's 32 x 32 tile
     const int j = J0 + wj * 32 + r32;
     if (j < ldS) {
@@ -227,6 +238,246 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ row
     for (int i = threadIdx.x; i < N; i += 256) v += row_loss[i];
     v = block_sum(v, red, threadIdx.x);
     if (threadIdx.x == 0) loss[0] = v / (float)N;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Round 5: the forward as ONE launch (north_star: "the contrastive loss as a fused CDNA4 kernel").
+// The three kernels above write S [N x M] to HBM, read it back three times in row_pass_kernel and once more in the backward. Here
+// a block owns a STRIP of 64 anchor rows and every nsplit-th 64-column tile of it:
+//   phase 1  S tiles on the fp32 MFMA (s_tile_64); every lane keeps an ONLINE (max, sum of negatives, positive count) for its
+//            16 rows over the columns it sees -- the rescaling form of the log-sum-exp, no second pass over a row; the first
+//            `t_cache` tiles of the block stay in LDS in the accumulator layout. Wavefront reductions (xor butterflies inside the
+//            32-lane halves) + one LDS step give the block's partial per row -> part1[split][row].
+//   hand-off per strip: release + counter; every block of the strip waits for the strip's nsplit partials (cseg_wait_counter: the
+//            grid is sized to be resident, MI355X_MICROARCH.md "Residency") and combines them in split order.
+//            Why a wait and not "the last block does the rest": log(exp(L_ij) + Neg_i) of every POSITIVE needs the complete
+//            negative sum of its row (loss_contrast.py:119-126), i.e. a second sweep over the positives of the whole strip --
+//            by one block that is 32 x fewer CUs than the problem has (110 us); with the wait every
+//            block sweeps its own tiles again, from LDS (or recomputed on the matrix cores beyond t_cache tiles).
+//   phase 2  sum over positives of L - log(e^L + Neg) and of 1 / (e^L + Neg) -> part2[split][row]; the LAST block of a strip to
+//            arrive combines them in split order and writes row_stats / row_loss; the last strip's finisher takes the mean in
+//            mean_kernel's order and resets the counters for the next launch.
+// Deterministic: every sum has a fixed order (tile order per lane, butterfly, wave pair, split index), whichever block arrives
+// last. Not bit-identical to the three-kernel path (online rescaling instead of max-then-sum): equal to ~1e-7 relative.
+// S_out (optional): the tiles are also stored once, for the backward that reads S (cseg_contrast_bwd); nullptr = no N x M array
+// exists at all (backward: cseg_contrast_bwd_recompute).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int FU_T = 64;                    // strip height and column tile width
+constexpr int FU_TILE_FLOATS = 4 * 16 * 64; // one tile in the accumulator layout: [wave][register][lane]
+
+__device__ __forceinline__ float max_nan(float a, float b) { return (b > a || b != b) ? b : a; }     // NaN wins, like torch.max
+// (m1, n1) + (m2, n2): sums of exponentials relative to their maxima -> relative to the common maximum
+__device__ __forceinline__ void lse_merge(float& m, float& n, float m2, float n2) {
+    const float mm = max_nan(m, m2);
+    const float e1 = (m == mm) ? 1.f : expf(m - mm), e2 = (m2 == mm) ? 1.f : expf(m2 - mm);      // (-inf, 0) merges as (x, 0 * 1)
+    n = n * e1 + n2 * e2;
+    m = mm;
+}
+
+__global__ __launch_bounds__(256) void contrast_fused_fwd_kernel(const float* __restrict__ A, int N, ColSrc col,
+                                                                 const int32_t* __restrict__ a_lab, float inv_tau, float coef,
+                                                                 int nsplit, int n_strips, int t_cache, float* __restrict__ part1,
+                                                                 float* __restrict__ part2, int* __restrict__ counters,
+                                                                 float* __restrict__ S_out, int ldS, float* __restrict__ row_stats,
+                                                                 float* __restrict__ row_loss, float* __restrict__ loss) {
+    __shared__ __attribute__((aligned(16))) float As[SG_T * SG_LD];
+    __shared__ __attribute__((aligned(16))) float Cs[SG_T * SG_LD];
+    __shared__ float p1[2][FU_T][4];        // per column half (wj): m, neg, cnt | slp, rs
+    __shared__ float fin[FU_T][4];          // per row of the strip: m, Neg, cnt
+    __shared__ float red[4];
+    __shared__ int flag;
+    extern __shared__ __attribute__((aligned(16))) float smem_fu[];          // [t_cache][FU_TILE_FLOATS]
+    float* stash = smem_fu;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wi = wave >> 1, wj = wave & 1, h = lane >> 5, r32 = lane & 31;
+    const int strip = blockIdx.x / nsplit, split = blockIdx.x - strip * nsplit;
+    const int I0 = strip * FU_T, M = col.M;
+    const int nJ = (M + FU_T - 1) / FU_T;
+    const int Npad = n_strips * FU_T;
+    int* cnt1 = counters;
+    int* cnt2 = counters + n_strips;
+    int* done = counters + 2 * n_strips;
+
+    float m[16], ng[16], ct[16];
+    int yi[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ii = I0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        yi[r] = ii < N ? a_lab[ii] : -0x7ffffffe;
+        m[r] = -INFINITY; ng[r] = 0.f; ct[r] = 0.f;
+    }
+    // ---- phase 1
+    int t = 0;
+    for (int jt = split; jt < nJ; jt += nsplit, ++t) {
+        const int J0 = jt * FU_T;
+        f32x16 acc = s_tile_64(A, N, col, I0, J0, As, Cs);
+        const int j = J0 + wj * 32 + r32;
+        const bool j_ok = j < M;
+        const int yj = col.label(j);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float sv = acc[r] * inv_tau;
+            acc[r] = sv;
+            if (j_ok) {
+                const int ii = I0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float mm = max_nan(m[r], sv);
+                const float e_old = (m[r] == mm) ? 1.f : expf(m[r] - mm);
+                const bool same = yj == yi[r];
+                ng[r] = ng[r] * e_old + (same ? 0.f : expf(sv - mm));
+                m[r] = mm;
+                ct[r] += (same && j != ii) ? 1.f : 0.f;
+            }
+        }
+        if (t < t_cache) {
+            float* st = stash + (size_t)t * FU_TILE_FLOATS + wave * (16 * 64) + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r * 64] = acc[r];
+        }
+        if (S_out != nullptr && j < ldS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ii = I0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (ii < N) S_out[(size_t)ii * ldS + j] = acc[r];
+            }
+        }
+    }
+    // the 32 lanes of a half hold different columns of the same 16 rows
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const float m2 = __shfl_xor(m[r], o, 64), n2 = __shfl_xor(ng[r], o, 64), c2 = __shfl_xor(ct[r], o, 64);
+            lse_merge(m[r], ng[r], m2, n2);
+            ct[r] += c2;
+        }
+    }
+    if (r32 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            p1[wj][row][0] = m[r]; p1[wj][row][1] = ng[r]; p1[wj][row][2] = ct[r];
+        }
+    }
+    __syncthreads();
+    if (tid < FU_T) {
+        float mm = p1[0][tid][0], nn = p1[0][tid][1];
+        lse_merge(mm, nn, p1[1][tid][0], p1[1][tid][1]);
+        float* o = part1 + ((size_t)split * Npad + I0 + tid) * 4;
+        o[0] = mm; o[1] = nn; o[2] = p1[0][tid][2] + p1[1][tid][2];
+    }
+    // ---- the strip's partials: publish, wait for all of them, combine in split order
+    __syncthreads();
+    if (tid == 0) {
+        cseg_release_agent();
+        cseg_counter_add(cnt1 + strip, 1);
+        cseg_wait_counter(cnt1 + strip, nsplit);
+        cseg_acquire_agent();
+    }
+    __syncthreads();
+    if (tid < FU_T) {
+        float mm = -INFINITY, nn = 0.f, cc = 0.f;
+        for (int s_ = 0; s_ < nsplit; ++s_) {
+            const float* o = part1 + ((size_t)s_ * Npad + I0 + tid) * 4;
+            lse_merge(mm, nn, o[0], o[1]);
+            cc += o[2];
+        }
+        fin[tid][0] = mm; fin[tid][1] = nn; fin[tid][2] = cc;
+    }
+    __syncthreads();
+    // ---- phase 2: the positives, with the complete row statistics
+    float slp[16], rs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        m[r] = fin[row][0]; ng[r] = fin[row][1];
+        slp[r] = 0.f; rs[r] = 0.f;
+    }
+    t = 0;
+    for (int jt = split; jt < nJ; jt += nsplit, ++t) {
+        const int J0 = jt * FU_T;
+        f32x16 acc;
+        if (t < t_cache) {
+            const float* st = stash + (size_t)t * FU_TILE_FLOATS + wave * (16 * 64) + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = st[r * 64];
+        } else {
+            acc = s_tile_64(A, N, col, I0, J0, As, Cs);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= inv_tau;
+        }
+        const int j = J0 + wj * 32 + r32;
+        const bool j_ok = j < M;
+        const int yj = col.label(j);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ii = I0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (j_ok && yj == yi[r] && j != ii) {
+                const float L = acc[r] - m[r];
+                const float den = expf(L) + ng[r];
+                slp[r] += L - logf(den);
+                rs[r] += 1.f / den;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            slp[r] += __shfl_xor(slp[r], o, 64);
+            rs[r] += __shfl_xor(rs[r], o, 64);
+        }
+    }
+    __syncthreads();                               // p1 is reused
+    if (r32 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            p1[wj][row][0] = slp[r]; p1[wj][row][1] = rs[r];
+        }
+    }
+    __syncthreads();
+    if (tid < FU_T) {
+        float* o = part2 + ((size_t)split * Npad + I0 + tid) * 2;
+        o[0] = p1[0][tid][0] + p1[1][tid][0];
+        o[1] = p1[0][tid][1] + p1[1][tid][1];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        cseg_release_agent();
+        const int old = cseg_counter_add(cnt2 + strip, 1);
+        flag = old == nsplit - 1;
+        if (flag) cseg_acquire_agent();
+    }
+    __syncthreads();
+    if (!flag) return;
+    // ---- the last block of the strip: row results
+    if (tid < FU_T && I0 + tid < N) {
+        float sl = 0.f, rr = 0.f;
+        for (int s_ = 0; s_ < nsplit; ++s_) {
+            const float* o = part2 + ((size_t)s_ * Npad + I0 + tid) * 2;
+            sl += o[0];
+            rr += o[1];
+        }
+        const int i = I0 + tid;
+        const float cnt = fin[tid][2];
+        row_loss[i] = -coef * (sl / cnt);                 // 0/0 -> NaN exactly like the reference (no positives)
+        *reinterpret_cast<float4*>(row_stats + 4 * (size_t)i) = make_float4(fin[tid][0], fin[tid][1], coef / ((float)N * cnt), rr);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        cseg_release_agent();
+        const int old = cseg_counter_add(done, 1);
+        flag = old == n_strips - 1;
+        if (flag) cseg_acquire_agent();
+    }
+    __syncthreads();
+    if (!flag) return;
+    // ---- the last strip: loss = mean_i row_loss[i] in mean_kernel's order; counters back to zero for the next launch
+    float v = 0.f;
+    for (int i = tid; i < N; i += 256) v += row_loss[i];
+    v = block_sum(v, red, tid);
+    if (tid == 0) loss[0] = v / (float)N;
+    for (int i = tid; i < 2 * n_strips + 1; i += 256) cseg_counter_store(counters + i, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -410,6 +661,72 @@ extern "C" int cseg_contrast_fwd(const cseg_contrast_desc* d, float* S_ws, float
     CSEG_CHECK_LAUNCH("row_pass_kernel");
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, stream, row_loss, d->N, loss);
     CSEG_CHECK_LAUNCH("mean_kernel");
+    return 1;
+}
+
+// Grid of the fused forward: n_strips x nsplit blocks, all of which must be resident at once (the blocks of a strip wait for each
+// other). At most FUSED_GRID_MAX blocks of <= 80 KB of LDS: two per CU fit, so even two processes that share a GPU (the 2-rank gloo
+// tests) cannot starve each other of the slots they wait for. CSEG_CONTRAST_FUSED_GRID overrides (tuning / tests).
+constexpr int FUSED_GRID_MAX = 248;
+constexpr size_t FUSED_LDS_CAP = 80 * 1024;
+constexpr size_t FUSED_LDS_STATIC = sizeof(float) * (2 * SG_T * SG_LD + 2 * FU_T * 4 + FU_T * 4 + 4) + 16;
+
+struct FusedPlan { int n_strips, nJ, nsplit, t_cache; size_t lds; };
+
+inline FusedPlan fused_plan(int N, int M) {
+    FusedPlan p;
+    p.n_strips = (N + FU_T - 1) / FU_T;
+    p.nJ = (M + FU_T - 1) / FU_T;
+    const char* e = getenv("CSEG_CONTRAST_FUSED_GRID");
+    int grid_max = e ? atoi(e) : FUSED_GRID_MAX;
+    if (grid_max < p.n_strips) grid_max = p.n_strips;
+    p.nsplit = grid_max / p.n_strips;
+    if (p.nsplit > p.nJ) p.nsplit = p.nJ;
+    if (p.nsplit < 1) p.nsplit = 1;
+    const int per_block = (p.nJ + p.nsplit - 1) / p.nsplit;
+    const int fit = (int)((FUSED_LDS_CAP - FUSED_LDS_STATIC) / (FU_TILE_FLOATS * sizeof(float)));
+    p.t_cache = per_block < fit ? per_block : fit;
+    p.lds = (size_t)p.t_cache * FU_TILE_FLOATS * sizeof(float);
+    return p;
+}
+
+// floats of scratch: part1 [nsplit][Npad][4], part2 [nsplit][Npad][2], then 2 * n_strips + 1 int counters (ZERO at the first launch
+// that uses the buffer; the kernel leaves them zero)
+extern "C" size_t cseg_contrast_fused_ws_bytes(int N, int M) {
+    const FusedPlan p = fused_plan(N, M);
+    return ((size_t)p.nsplit * p.n_strips * FU_T * 6 + 2 * p.n_strips + 1) * sizeof(float);
+}
+extern "C" size_t cseg_contrast_fused_counter_offset(int N, int M) {
+    const FusedPlan p = fused_plan(N, M);
+    return (size_t)p.nsplit * p.n_strips * FU_T * 6 * sizeof(float);
+}
+
+extern "C" int cseg_contrast_fwd_fused(const cseg_contrast_desc* d, float* fused_ws, float* S_out, float* row_stats, float* row_loss,
+                                       float* loss, cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ColSrc col;
+    if (!make_col(d, &col)) return 0;
+    CSEG_REQUIRE(fused_ws != nullptr, "contrast (fused forward): no scratch buffer");
+    const FusedPlan p = fused_plan(d->N, d->M);
+    const size_t npart = (size_t)p.nsplit * p.n_strips * FU_T;
+    float* part1 = fused_ws;
+    float* part2 = fused_ws + npart * 4;
+    int* counters = reinterpret_cast<int*>(fused_ws + npart * 6);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)contrast_fused_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(FUSED_LDS_CAP - FUSED_LDS_STATIC)) != hipSuccess) {
+            cseg_set_error("contrast (fused forward): cannot raise dynamic LDS");
+            return 0;
+        }
+        attr_set = true;
+    }
+    const float coef = d->temperature / d->base_temperature;
+    CSEG_GRID_RESIDENT_LAUNCH();
+    hipLaunchKernelGGL(contrast_fused_fwd_kernel, dim3(p.n_strips * p.nsplit), dim3(256), p.lds, stream, d->anchors, d->N, col, d->a_lab,
+                       1.0f / d->temperature, coef, p.nsplit, p.n_strips, p.t_cache, part1, part2, counters, S_out, round32(d->M),
+                       row_stats, row_loss, loss);
+    CSEG_CHECK_LAUNCH("contrast_fused_fwd_kernel");
     return 1;
 }
 

@@ -38,6 +38,68 @@ __device__ __forceinline__ float4 cseg_load_f4(const void* uniform_base, unsigne
     return *reinterpret_cast<const float4*>(static_cast<const char*>(uniform_base) + byte_offset);
 }
 
+// ---- hand-off between workgroups of ONE launch (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup
+// visibility"): producer = plain stores -> __syncthreads() -> ONE lane: cseg_release_agent() -> cseg_counter_add(); consumer = ONE lane
+// polls cseg_counter_load() (relaxed, with CSEG_SPIN_PAUSE between polls) -> cseg_acquire_agent() -> __syncthreads() -> plain loads.
+// (Per-XCD L2s are not coherent and a CU's L1 is never refreshed by another CU's stores; workgroup-scope fences are not enough. The
+// explicit vmcnt(0) after the release fence is the guide's fix for a compiler pass that may drop it.) The CPU emulation of the
+// execution model (tests/emu) compiles the #else branches; a launch whose blocks wait for each other announces itself with
+// CSEG_GRID_RESIDENT_LAUNCH() so that the emulator runs all its blocks at once.
+__device__ __forceinline__ void cseg_release_agent() {
+#if defined(__AMDGCN__)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+}
+__device__ __forceinline__ void cseg_acquire_agent() {
+#if defined(__AMDGCN__)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+}
+__device__ __forceinline__ int cseg_counter_add(int* p, int v) {       // -> the value before
+#if defined(__AMDGCN__)
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST);
+#endif
+}
+__device__ __forceinline__ int cseg_counter_load(const int* p) {
+#if defined(__AMDGCN__)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return __atomic_load_n(p, __ATOMIC_SEQ_CST);
+#endif
+}
+__device__ __forceinline__ void cseg_counter_store(int* p, int v) {
+#if defined(__AMDGCN__)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    __atomic_store_n(p, v, __ATOMIC_SEQ_CST);
+#endif
+}
+#ifndef CSEG_SPIN_PAUSE
+#if defined(__AMDGCN__)
+#define CSEG_SPIN_PAUSE() __builtin_amdgcn_s_sleep(16)
+#else
+#define CSEG_SPIN_PAUSE() ((void)0)
+#endif
+#endif
+#ifndef CSEG_GRID_RESIDENT_LAUNCH
+#define CSEG_GRID_RESIDENT_LAUNCH() ((void)0)
+#endif
+// one lane waits until *counter reaches `want`; a wait that cannot end (a block of the launch that never became resident: a grid larger
+// than the chip holds, which the launchers rule out) ends in a trap after ~10 s instead of hanging the device
+__device__ __forceinline__ void cseg_wait_counter(const int* counter, int want) {
+    for (long spins = 0; cseg_counter_load(counter) < want; ++spins) {
+        CSEG_SPIN_PAUSE();
+        if (spins > (1L << 25)) __builtin_trap();
+    }
+}
+
 void cseg_set_error(const char* fmt, ...);
 
 // reference convention: 1 = ok, 0 = error (lib/extensions/cc_attention/src/ca.cu:199-204)

@@ -128,14 +128,46 @@ def _desc(mode, anchors, a_lab, temperature, base_temperature, contrast=None, c_
     return d
 
 
+# Forward of the contrastive term (csrc/contrast.hip): "0" = three launches (S = A.C^T/tau to HBM, row pass over S, mean), "1" = ONE
+# launch (round 5: S tiles on the fp32 MFMA, online row statistics by wavefront reductions, the positives' sweep from LDS after an
+# in-launch hand-off between the blocks of a row strip) that also stores the S tiles once for the backward. Both are kept: the default
+# is whichever measured faster on the MI355X (bench_detail.json carries both timings).
+CONTRAST_FUSED = os.environ.get("CSEG_CONTRAST_FUSED", "1")
+_FUSED_WS = {}       # (device index, stream) -> scratch of the fused forward; its counters are zero between launches (the kernel resets them)
+
+
+def _fused_ws(N, M, device):
+    lib = _hip.lib()
+    need = lib.cseg_contrast_fused_ws_bytes(N, M) // 4
+    key = (device.index, _hip.raw_stream()) if device.type == "cuda" else (-1, 0)
+    buf = _FUSED_WS.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.zeros(max(need, 1 << 16), dtype=F32, device=device)         # zero ONCE: the counters live inside
+        _FUSED_WS[key] = buf
+    return buf
+
+
 def contrast_forward(desc, device):
-    """Runs cseg_contrast_fwd. Returns (loss [1], saved) where saved feeds contrast_backward."""
+    """Runs cseg_contrast_fwd / cseg_contrast_fwd_fused. Returns (loss [1], saved) where saved feeds contrast_backward."""
     lib = _hip.lib()
     ws = lib.cseg_contrast_ws_bytes(desc.N, desc.M)
     S = torch.empty(ws // 4, dtype=F32, device=device)
     row_stats = torch.empty(desc.N, 4, dtype=F32, device=device)
     row_loss = torch.empty(desc.N, dtype=F32, device=device)
     loss = torch.empty(1, dtype=F32, device=device)
+    if CONTRAST_FUSED != "0":
+        # (the scratch is laid out by the library for exactly this (N, M): counters behind the partials -- a buffer that served another
+        # shape still has its counters at zero, wherever they were)
+        scratch = _fused_ws(desc.N, desc.M, device)
+        off = lib.cseg_contrast_fused_counter_offset(desc.N, desc.M) // 4
+        n_ctr = lib.cseg_contrast_fused_ws_bytes(desc.N, desc.M) // 4 - off
+        key = (off, n_ctr)                                # where the counters of THIS launch plan sit
+        if getattr(scratch, "_cseg_shape", key) != key:
+            scratch[off:off + n_ctr].zero_()              # another (N, M) left ITS counters zero, but partials may sit where ours are
+        scratch._cseg_shape = key
+        _hip.call("cseg_contrast_fwd_fused", ctypes.byref(desc), _pf(scratch), _p(S, F32, "S_out"), _p(row_stats, F32, "row_stats"),
+                  _p(row_loss, F32, "row_loss"), _p(loss, F32, "loss"), _hip.stream_ptr())
+        return loss, (S, row_stats, row_loss)
     _hip.call("cseg_contrast_fwd", ctypes.byref(desc), _p(S, F32, "S_ws"), _p(row_stats, F32, "row_stats"),
               _p(row_loss, F32, "row_loss"), _p(loss, F32, "loss"), _hip.stream_ptr())
     return loss, (S, row_stats, row_loss)

@@ -91,6 +91,21 @@ typedef struct {
 size_t cseg_contrast_ws_bytes(int N, int M);
 int cseg_contrast_fwd(const cseg_contrast_desc* d, float* S_ws, float* row_stats, float* row_loss, float* loss,
                       cseg_stream_t stream);
+/* The same forward as ONE launch (round 5): S tiles on the fp32 MFMA, online (max, negative sum, positive count) per row by
+ * wavefront reductions, the positives' sweep from LDS after an in-launch hand-off between the blocks of a row strip. No S round
+ * trip through HBM inside the forward.
+ *   fused_ws  scratch of cseg_contrast_fused_ws_bytes(N, M) bytes whose LAST 2 * strips + 1 ints (at byte offset
+ *             cseg_contrast_fused_counter_offset(N, M)) are ZERO at the first launch that uses the buffer; the kernel leaves
+ *             them zero, so a buffer kept per (device, stream) needs no fill between launches. Not shared by concurrent launches.
+ *   S_out     [N, round32(M)] f32 or NULL: the similarity tiles stored once for cseg_contrast_bwd (which reads S); NULL = the
+ *             N x M array never exists.
+ * Same outputs as cseg_contrast_fwd (row_stats [N,4], row_loss [N], loss [1]), equal to ~1e-7 relative (online rescaling of the
+ * log-sum-exp instead of max-then-sum), run-to-run deterministic. Reference: lib/loss/loss_contrast.py:91-128,
+ * lib/loss/loss_contrast_mem.py:107-152. */
+size_t cseg_contrast_fused_ws_bytes(int N, int M);
+size_t cseg_contrast_fused_counter_offset(int N, int M);
+int cseg_contrast_fwd_fused(const cseg_contrast_desc* d, float* fused_ws, float* S_out, float* row_stats, float* row_loss,
+                            float* loss, cseg_stream_t stream);
 /* d_loss [1] f32 on the device (upstream gradient). Writes d_anchor_parts [n_parts, N, D] (sum over parts =
  * dLoss/dAnchors); in self mode this already contains both the row and the column role of every anchor. */
 int cseg_contrast_bwd_parts(int N, int M, int D);

@@ -8,6 +8,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -239,6 +240,10 @@ void wave_release() {
 
 hipError_t last_error() { return g_last_error.exchange(hipSuccess); }
 
+thread_local bool t_resident_next = false;
+void request_resident() { t_resident_next = true; }
+void spin_pause() { std::this_thread::sleep_for(std::chrono::microseconds(50)); }
+
 hipError_t launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body) {
     const int n_threads = (int)(block.x * block.y * block.z);
     const long n_blocks = (long)grid.x * grid.y * grid.z;
@@ -248,6 +253,15 @@ hipError_t launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<v
     }
     int n_os = (int)std::min<long>(n_blocks, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* e = getenv("CSEG_EMU_THREADS")) n_os = std::max(1, std::min(n_os, atoi(e)));
+    if (t_resident_next) {                      // blocks of this launch wait for each other: all of them must be running
+        t_resident_next = false;
+        if (n_blocks > 1024) {
+            fprintf(stderr, "emu: a grid-resident launch of %ld blocks (the hardware holds a few hundred)\n", n_blocks);
+            g_last_error = hipErrorLaunchFailure;
+            return hipErrorLaunchFailure;
+        }
+        n_os = (int)n_blocks;
+    }
     std::atomic<long> next{0};
     std::atomic<bool> failed{false};
     std::string first_error;

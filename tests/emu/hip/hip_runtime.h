@@ -31,6 +31,8 @@
 #include <functional>
 
 #define CSEG_WAVE_LOCKSTEP() emu::wave_sync()
+#define CSEG_GRID_RESIDENT_LAUNCH() emu::request_resident()
+#define CSEG_SPIN_PAUSE() emu::spin_pause()
 #define __global__
 #define __device__
 #define __host__
@@ -83,6 +85,11 @@ inline void wave_sync() { wave_exchange(nullptr, 0); }      // CSEG_WAVE_LOCKSTE
 template <class T>
 inline const T& slot(const unsigned char* area, int lane) { return *reinterpret_cast<const T*>(area + (size_t)lane * XSTRIDE); }
 hipError_t launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body);
+// Kernels whose blocks wait for each other (a counter another block of the SAME launch increments): the launch site announces it
+// (CSEG_GRID_RESIDENT_LAUNCH) and the next launch of this host thread gets one OS thread per block, so that every block is "resident";
+// a waiting lane calls spin_pause() between polls (CSEG_SPIN_PAUSE: s_sleep on the GPU).
+void request_resident();
+void spin_pause();
 hipError_t last_error();
 }  // namespace emu
 

@@ -100,6 +100,14 @@ def test_contrast_bank_matches_oracle(kw, monkeypatch):
     _replay(monkeypatch, "test_gpu_kernels", "test_contrast_bank_matches_oracle", kw)
 
 
+FUSED = _cases("test_gpu_kernels", "test_contrast_fused_forward_equals_the_three_launches")
+
+
+@pytest.mark.parametrize("kw", FUSED, ids=_ids(FUSED))
+def test_contrast_fused_forward_equals_the_three_launches(kw, monkeypatch):
+    _replay(monkeypatch, "test_gpu_kernels", "test_contrast_fused_forward_equals_the_three_launches", dict(kw, monkeypatch=monkeypatch))
+
+
 def test_upsample_concat_and_fuse_sum_match_torch(monkeypatch):
     _replay(monkeypatch, "test_gpu_kernels", "test_upsample_concat_matches_torch", {})
     _replay(monkeypatch, "test_gpu_kernels", "test_fuse_sum_relu_matches_torch", {})

@@ -188,6 +188,65 @@ def test_contrast_bank_matches_oracle(N, Kc, ms, D):
     assert np.allclose(A.grad.cpu().numpy(), dX.reshape(N, D), rtol=2e-3, atol=1e-7)
 
 
+@pytest.mark.parametrize("mode,N,M_or_ms,D,grid", [
+    ("self", 60, 0, 16, 0),                 # one strip, one tile, rows 60 .. 63 outside
+    ("self", 200, 0, 64, 0),                # 4 strips x 4 tiles, every block one cached tile
+    ("self", 200, 0, 64, 4),                # grid capped at 4 blocks: one block per strip walks 4 tiles, 2 from LDS + 2 recomputed
+    ("bank", 70, 20, 32, 0),                # M = 6 * 2 * 20 = 240: class-0 skip, zero tail, ragged last tile
+    ("bank", 152, 108, 256, 0),             # BASELINE "4096-entry bank": M = 4104, 65 column tiles
+    ("bank", 152, 108, 256, 6),             # ... with 3 strips x 2 splits: 33 tiles per block, almost all recomputed
+    ("plain", 90, 150, 32, 0),
+])
+def test_contrast_fused_forward_equals_the_three_launches(mode, N, M_or_ms, D, grid, monkeypatch):
+    """Round 5: cseg_contrast_fwd_fused (ONE launch: S tiles on the fp32 MFMA, online row statistics by wavefront reductions, in-launch
+    hand-off between the blocks of a row strip, positives from LDS or recomputed) against cseg_contrast_fwd (S to HBM, row pass, mean):
+    loss, row_stats, row_loss and the stored S equal to fp32 rounding (online rescaling of the log-sum-exp vs max-then-sum), a row
+    without positives is NaN in both, two runs on one scratch buffer are bit-identical (fixed summation orders whichever block arrives
+    last; the kernel leaves its counters at zero). Reference: lib/loss/loss_contrast.py:91-128, loss_contrast_mem.py:107-152."""
+    dev = _dev()
+    from contrastiveseg_amd import kernels as Kk
+    if grid:
+        monkeypatch.setenv("CSEG_CONTRAST_FUSED_GRID", str(grid))
+    rs = np.random.RandomState(N + D)
+    A = torch.from_numpy(_rand_unit(rs, N, D)).to(dev)
+    Kc = 6 if mode != "self" else 5
+    y = rs.randint(0, Kc, size=N).astype(np.int32)
+    if mode == "self":
+        y[7] = 97                               # a class of its own: no positives -> 0/0 = NaN in row 7, like the reference
+    lab = torch.from_numpy(y).to(dev)
+    kw = {}
+    if mode == "bank":
+        Kc, ms = (19, M_or_ms) if M_or_ms == 108 else (6, M_or_ms)
+        lab = torch.from_numpy(rs.randint(0, Kc, size=N).astype(np.int32)).to(dev)
+        kw = dict(segment_queue=torch.from_numpy(_rand_unit(rs, Kc * ms, D).reshape(Kc, ms, D)).to(dev),
+                  pixel_queue=torch.from_numpy(_rand_unit(rs, Kc * ms, D).reshape(Kc, ms, D)).to(dev))
+    elif mode == "plain":
+        kw = dict(contrast=torch.from_numpy(_rand_unit(rs, M_or_ms, D)).to(dev),
+                  c_lab=torch.from_numpy(rs.randint(0, Kc, size=M_or_ms).astype(np.int32)).to(dev))
+    desc = Kk._desc({"self": 0, "plain": 1, "bank": 2}[mode], A, lab, 0.1, 0.07, **kw)
+    out = {}
+    for name, fused in (("three", "0"), ("fused", "1"), ("fused_again", "1")):
+        monkeypatch.setattr(Kk, "CONTRAST_FUSED", fused)
+        loss, (S, row_stats, row_loss) = Kk.contrast_forward(desc, dev)
+        out[name] = [t.cpu().numpy().copy() for t in (loss, row_stats, row_loss, S)]
+    ld = (desc.M + 31) // 32 * 32
+    for a, b, what in zip(out["three"], out["fused"], ("loss", "row_stats", "row_loss", "S")):
+        if what == "S":
+            a, b = a.reshape(-1, ld)[:N, :desc.M], b.reshape(-1, ld)[:N, :desc.M]
+            assert np.array_equal(a, b), "the stored similarity tiles are the same MFMA products"
+            continue
+        assert np.array_equal(np.isnan(a), np.isnan(b)), what
+        ok = ~np.isnan(a)
+        if not ok.any():
+            continue
+        scale = np.abs(a[ok]).max()
+        assert np.abs(a[ok] - b[ok]).max() <= 2e-6 * max(scale, 1e-30) or np.allclose(a[ok], b[ok], rtol=5e-6, atol=0), (what, np.abs(a[ok] - b[ok]).max(), scale)
+    if mode == "self":
+        assert np.isnan(out["fused"][2][7]) and np.isnan(out["fused"][0][0])
+    for a, b in zip(out["fused"][:3], out["fused_again"][:3]):
+        assert np.array_equal(a, b, equal_nan=True), "two launches on one scratch buffer must be bit-identical"
+
+
 def test_contrast_headline_shape_properties():
     """BASELINE.json sizes: 1024 anchors x 4096-entry bank, D=256. Oracle parity on the scalar + properties:
     invariance to a permutation of bank slots inside a class, and plain mode == bank mode on the packed copy."""

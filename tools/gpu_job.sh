@@ -12,6 +12,7 @@
 #   longrun[:<n>]    tools/long_run_arith.py (default 200 steps): default arithmetic vs strict fp32 vs a one-ulp perturbation
 #   probe:<args>     tools/probes/conv_probe with the given arguments (';' separates arguments)
 #   host             tools/host_profile.py 8
+#   contrast         tools/contrast_probe.py under rocprofv3 --kernel-trace --stats: fused vs three-launch contrastive forward
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:?tag}; shift
@@ -67,6 +68,14 @@ for step in "$@"; do
       [ -x $P ] || g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tools/probes/conv_probe.cpp -o $P -L/opt/rocm/lib -lamdhip64 -ldl
       IFS=';' read -ra PA <<< "$arg"
       timeout 120 $P "${PA[@]}" > $O/probe_$(date +%s%N).jsonl 2>> $O/probe.err; cat $O/probe_*.jsonl | tail -40 | cut -c1-400 ;;
+    contrast)
+      cd /tmp
+      timeout 300 rocprofv3 --kernel-trace --stats -d $O/ctrace -o c --output-format csv -- python $R/tools/contrast_probe.py > $O/contrast_probe.json 2> $O/contrast_probe.err
+      cd $R
+      cat $O/contrast_probe.json | cut -c1-900
+      st=$(find $O/ctrace -name "*kernel_stats.csv" | head -1)
+      [ -n "$st" ] && grep -E "Name|s_gemm|row_pass|mean_kernel|contrast_fused" $st | cut -c1-220 > $O/contrast_fused_kernels.txt; cat $O/contrast_fused_kernels.txt
+      rm -rf $O/ctrace ;;
     host) timeout 200 python tools/host_profile.py 8 > $O/host_profile.txt 2>&1; head -3 $O/host_profile.txt ;;
     *) echo "unknown step $step" ;;
   esac
