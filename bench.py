@@ -866,15 +866,34 @@ def main():
     if world > 1:
         torch.distributed.barrier()
 
+    line = None
     if rank == 0:
         line, detail = assemble_line(args, wl, cfg, world, global_batch, dt, ev_ms, final_loss, split_on, Kn,
                                      torch.distributed.get_backend() if (world > 1 or args.dist_single_rank) else None, fp32_pass, weak, cpu, kernels,
                                      split_rows if (split_rows and "error" not in split_rows[0]) else None, split_flops)
         write_detail(detail)
-        sys.stderr.flush()
-        print(json.dumps(line), flush=True)           # the LAST line of stdout, <= LINE_LIMIT bytes
     if world > 1 or args.dist_single_rank:
+        try:                                          # every rank empties its C stdio buffers BEFORE rank 0 prints the line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if line is not None:
+        # The contract line must be the LAST line of stdout. RCCL writes its version banner through C stdio, which is block-buffered
+        # when stdout is a pipe or a file and would otherwise be flushed at exit -- AFTER a line printed from Python (seen on the MI355X
+        # in round 5: `tail -1` of a --dist-single-rank run was "Librccl path : ..."). So: tear the process group down first, flush
+        # the C buffers, then print.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stderr.flush()
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)           # the LAST line of stdout, <= LINE_LIMIT bytes
 
 
 if __name__ == "__main__":

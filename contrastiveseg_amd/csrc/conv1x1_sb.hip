@@ -67,17 +67,13 @@ __device__ __forceinline__ void o_store(const f32x4 (&acc)[4][NTMAX], float* __r
     for (int nt = 0; nt < NTW; ++nt) {
         float* orow = ybc + (size_t)(co0 + nt * 16 + n) * plane;
         const float bv = bias ? bias[co0 + nt * 16 + n] : 0.f;
+        const bool vec = (plane & 3) == 0;          // channel planes 16-byte aligned (else element by element: cseg_store_row4)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const size_t px = (size_t)px0 + 16 * mt + 4 * g;
+            const long px = (long)px0 + 16 * mt + 4 * g;
             f32x4 v = acc[mt][nt] * unscale;
             v += bv;
-            if (px + 3 < plane) *reinterpret_cast<float4*>(orow + px) = make_float4(v[0], v[1], v[2], v[3]);
-            else {
-                if (px < plane) orow[px] = v[0];
-                if (px + 1 < plane) orow[px + 1] = v[1];
-                if (px + 2 < plane) orow[px + 2] = v[2];
-            }
+            cseg_store_row4(orow, nullptr, px, (long)plane, vec, v);
         }
     }
 }
@@ -274,7 +270,7 @@ int run_1x1(const float* x, const void* wp, const float* bias, int B, int Cin, i
     const int NT = pick_nt1(Cout);
     CSEG_REQUIRE(B > 0 && HW > 0 && Cin > 0 && Cin % 16 == 0 && NT > 0, "conv1x1_sb: unsupported shape B=%d Cin=%d Cout=%d HW=%d",
                  B, Cin, Cout, HW);
-    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && HW % 4 == 0,
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
                  "conv1x1_sb: packed weights / output must be 16-byte aligned and H*W a multiple of 4");
     const uint4* wq = (const uint4*)wp;
     if (arith == CSEG_ARITH_F16X3) return fwd_1x1<SplitF16x3>(x, wq, bias, B, Cin, Cout, HW, NT, amax_x, amax_w, y, stats, stream);

@@ -29,7 +29,11 @@ constexpr int CH_ALL = CO_T + CI_T;                  // 272 channel rows per sta
 constexpr int LD_ITEMS = CH_ALL * 8;                 // float4 chunks per stage: 272 rows x 8 chunks of 4 pixels
 constexpr int LD_U = (LD_ITEMS + 255) / 256;         // per loader thread (9)
 
-template <class AR>
+// RAGGED (round 5): planes whose size is not a multiple of 32 pixels (DeepLab-R101-d8: 65 x 129 = 8 385; HRNet-OCR at 520 x 520:
+// 130 x 130 = 16 900). The last stage of an image is partly outside the plane, and channel rows are no longer 16-byte aligned: the
+// loaders fetch the four pixels of a chunk one by one from addresses clamped into the plane and zero what lies behind it; the
+// consumers see full zero-padded stages and do not change.
+template <class AR, bool RAGGED = false>
 __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                 int B, int Cin, int Cout, int plane_i, int n_split,
                                                                 const unsigned* __restrict__ amax_x,
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
     const int cib = blk % n_cib;
     const int cob = blk / n_cib;
     const size_t plane = (size_t)plane_i;
-    const int stages_per_img = plane_i / STG;
+    const int stages_per_img = RAGGED ? (plane_i + STG - 1) / STG : plane_i / STG;
     const long n_units = (long)B * stages_per_img;
     const long u_lo = n_units * split / n_split, u_hi = n_units * (split + 1) / n_split;     // this split's stages
 
@@ -67,6 +71,8 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
         // 64-bit address per item and stage, ~360 VALU instructions per stage against the consumers' 60 MFMAs.)
         unsigned off[LD_U];
         int lds_off[LD_U];
+        int nv[LD_U];                                  // RAGGED: pixels of the chunk fetched last that lie inside the plane (<= 0: none)
+        int pc[LD_U];                                  // first pixel of the item's chunk inside a stage
         bool ok[LD_U], is_dy[LD_U];
 #pragma unroll
         for (int u = 0; u < LD_U; ++u) {
@@ -77,20 +83,39 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
             off[u] = (unsigned)(ch * plane_i + 4 * c) * (unsigned)sizeof(float);
             ok[u] = item < LD_ITEMS && (is_dy[u] ? cob * CO_T + r < Cout : cib * CI_T + r - CO_T < Cin);
             lds_off[u] = is_dy[u] ? r * PITCH + 4 * c : (r - CO_T) * PITCH + 4 * c;
+            pc[u] = 4 * c;
         }
         int img = (int)(u_lo / stages_per_img), stage = (int)(u_lo % stages_per_img);       // of the next stage to LOAD
         auto load = [&](float4 (&v)[LD_U]) __attribute__((always_inline)) {
             const float* dyp = dy + ((size_t)img * Cout * plane + (size_t)stage * STG);     // uniform
             const float* xp = x + ((size_t)img * Cin * plane + (size_t)stage * STG);
 #pragma unroll
-            for (int u = 0; u < LD_U; ++u) v[u] = cseg_load_f4(is_dy[u] ? dyp : xp, off[u]);
+            for (int u = 0; u < LD_U; ++u) {
+                if (!RAGGED) {
+                    v[u] = cseg_load_f4(is_dy[u] ? dyp : xp, off[u]);
+                } else {
+                    // off[u] = (channel * plane + 4 * chunk) * 4 bytes from the start of the stage: element k sits `k` floats further,
+                    // unless that is behind the plane -- then the last pixel of the plane is read (finite) and zeroed in put()
+                    const int left = plane_i - stage * STG - pc[u];          // pixels from this chunk to the end of the plane
+                    nv[u] = left;
+                    const char* base = reinterpret_cast<const char*>(is_dy[u] ? dyp : xp) + off[u];
+                    float e[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) e[k] = *reinterpret_cast<const float*>(base + (long)min(k, left - 1) * 4);
+                    v[u] = make_float4(e[0], e[1], e[2], e[3]);
+                }
+            }
             if (++stage == stages_per_img) { stage = 0; ++img; }
         };
         auto put = [&](int buf, const float4 (&v)[LD_U]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < LD_U; ++u) {
                 if (ok[u] || lt + 256 * u < LD_ITEMS) {                          // rows beyond the channel count are zero-filled
-                    const float4 t = ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 t = ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (RAGGED) {
+                        t.x = nv[u] > 0 ? t.x : 0.f; t.y = nv[u] > 1 ? t.y : 0.f;
+                        t.z = nv[u] > 2 ? t.z : 0.f; t.w = nv[u] > 3 ? t.w : 0.f;
+                    }
                     uint2 cells[NP];
                     split_cells4<AR>(t, is_dy[u] ? dscale : xscale, cells);
                     unsigned short* base = is_dy[u] ? ds + buf * DY_ELEMS + lds_off[u] : xs + buf * X_ELEMS + lds_off[u];
@@ -199,7 +224,7 @@ __global__ __launch_bounds__(256) void sb_wrw1_reduce_kernel(const float* __rest
 // rounds x stages per block (+ the partials written and re-read per split) is taken. 720 x 720 at 8 x 128 x 256: 30 channel blocks;
 // the old rule (768 / 30 = 26 splits = 780 blocks) paid a fourth round for 12 blocks.
 int wrw1_splits(int B, int Cin, int Cout, int plane) {
-    const long units = (long)B * (plane / STG);
+    const long units = (long)B * ((plane + STG - 1) / STG);
     const int pairs = ((Cin + CI_T - 1) / CI_T) * ((Cout + CO_T - 1) / CO_T);
     const double stage_us = 0.75, split_us = 2.0 * Cin * Cout * sizeof(float) / 4.0e6;
     const long n_max = units < 64 ? units : 64;
@@ -217,25 +242,25 @@ int wrw1_splits(int B, int Cin, int Cout, int plane) {
 }  // namespace
 
 extern "C" size_t cseg_conv1x1_sb_wrw_ws_floats(int B, int Cin, int Cout, int HW) {
-    if (B <= 0 || Cin <= 0 || Cout <= 0 || HW <= 0 || Cin % 16 || Cout % 16 || HW % STG) return 0;
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || HW <= 0 || Cin % 16 || Cout % 16) return 0;
     return (size_t)wrw1_splits(B, Cin, Cout, HW) * Cin * Cout;
 }
 
 namespace {
-template <class AR>
+template <class AR, bool RAGGED>
 int launch_wrw1(const float* x, const float* dy, int B, int Cin, int Cout, int HW, int n_split, long blocks, const unsigned* amax_x,
                 const unsigned* amax_dy, float* ws, hipStream_t stream) {
     const size_t lds = sizeof(unsigned short) * 2 * (dy_elems(AR::NP) + x_elems(AR::NP));
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv1x1_sb_wrw_kernel<AR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        if (hipFuncSetAttribute((const void*)conv1x1_sb_wrw_kernel<AR, RAGGED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess) {
             cseg_set_error("conv1x1_sb_wrw: cannot raise dynamic LDS to %zu bytes", lds);
             return 0;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv1x1_sb_wrw_kernel<AR>, dim3((unsigned)blocks), dim3(512), lds, stream, x, dy, B, Cin, Cout, HW, n_split,
+    hipLaunchKernelGGL((conv1x1_sb_wrw_kernel<AR, RAGGED>), dim3((unsigned)blocks), dim3(512), lds, stream, x, dy, B, Cin, Cout, HW, n_split,
                        amax_x, amax_dy, ws);
     CSEG_CHECK_LAUNCH("conv1x1_sb_wrw_kernel");
     return 1;
@@ -244,9 +269,10 @@ int launch_wrw1(const float* x, const float* dy, int B, int Cin, int Cout, int H
 int wrw1_impl(const float* x, const float* dy, int B, int Cin, int Cout, int HW, int arith, const unsigned* amax_x,
               const unsigned* amax_dy, float* ws, float* dw, hipStream_t stream) {
     CSEG_REQUIRE(x && dy && ws && dw, "conv1x1_sb_wrw: null pointer");
-    CSEG_REQUIRE(B > 0 && HW > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0 && HW % STG == 0,
-                 "conv1x1_sb_wrw: unsupported shape B=%d Cin=%d Cout=%d HW=%d (needs channels %% 16, H*W %% 32)", B, Cin, Cout, HW);
-    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0,
+    CSEG_REQUIRE(B > 0 && HW > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0,
+                 "conv1x1_sb_wrw: unsupported shape B=%d Cin=%d Cout=%d HW=%d (needs channels %% 16)", B, Cin, Cout, HW);
+    const bool ragged = HW % STG != 0;                 // (the aligned form reads 16 bytes at a time from 16-byte aligned channel rows)
+    CSEG_REQUIRE(ragged || ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0),
                  "conv1x1_sb_wrw: tensors must be 16-byte aligned");
     CSEG_REQUIRE(arith == CSEG_ARITH_BF16X6 || (arith == CSEG_ARITH_F16X3 && amax_x && amax_dy),
                  "conv1x1 split wrw: arithmetic %d needs max|x| and max|dy|", arith);
@@ -255,9 +281,13 @@ int wrw1_impl(const float* x, const float* dy, int B, int Cin, int Cout, int HW,
     const int n_split = wrw1_splits(B, Cin, Cout, HW);
     const long blocks = (long)n_split * ((Cin + CI_T - 1) / CI_T) * ((Cout + CO_T - 1) / CO_T);
     CSEG_REQUIRE(blocks < 2147483647L && (long)Cin * Cout < 2147483647L, "conv1x1_sb_wrw: grid too large");
-    const int ok = arith == CSEG_ARITH_F16X3
-                       ? launch_wrw1<SplitF16x3>(x, dy, B, Cin, Cout, HW, n_split, blocks, amax_x, amax_dy, ws, stream)
-                       : launch_wrw1<SplitBF16x6>(x, dy, B, Cin, Cout, HW, n_split, blocks, amax_x, amax_dy, ws, stream);
+    int ok;
+    if (arith == CSEG_ARITH_F16X3)
+        ok = ragged ? launch_wrw1<SplitF16x3, true>(x, dy, B, Cin, Cout, HW, n_split, blocks, amax_x, amax_dy, ws, stream)
+                    : launch_wrw1<SplitF16x3, false>(x, dy, B, Cin, Cout, HW, n_split, blocks, amax_x, amax_dy, ws, stream);
+    else
+        ok = ragged ? launch_wrw1<SplitBF16x6, true>(x, dy, B, Cin, Cout, HW, n_split, blocks, amax_x, amax_dy, ws, stream)
+                    : launch_wrw1<SplitBF16x6, false>(x, dy, B, Cin, Cout, HW, n_split, blocks, amax_x, amax_dy, ws, stream);
     if (!ok) return 0;
     const int total = Cin * Cout;
     hipLaunchKernelGGL(sb_wrw1_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, ws, n_split, total, dw);

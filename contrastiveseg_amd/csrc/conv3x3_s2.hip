@@ -70,16 +70,12 @@ __device__ __forceinline__ void s2_store_fwd(const f32x4 (&acc)[4][NTMAX], float
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         float* orow = ybc + (size_t)(co0 + nt * 16 + n) * oplane + (size_t)yy * Wo;
+        const bool vec = (Wo & 3) == 0;             // output rows 16-byte aligned (else element by element: cseg_store_row4)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int xx = x0 + 16 * mt + 4 * g;
             const f32x4 v = acc[mt][nt] * unscale;
-            if (xx + 3 < Wo) *reinterpret_cast<float4*>(orow + xx) = make_float4(v[0], v[1], v[2], v[3]);
-            else {
-                if (xx < Wo) orow[xx] = v[0];
-                if (xx + 1 < Wo) orow[xx + 1] = v[1];
-                if (xx + 2 < Wo) orow[xx + 2] = v[2];
-            }
+            cseg_store_row4(orow, nullptr, xx, Wo, vec, v);
         }
     }
 }
@@ -459,7 +455,7 @@ static int s2_fwd_impl(const float* x, const void* wp, int B, int Cin, int Cout,
                        const unsigned* amax_w, float* y, float4* stats, cseg_stream_t stream_) {
     CSEG_REQUIRE(x && wp && y && amax_x && amax_w, "conv3x3_s2_fwd: null pointer");
     CSEG_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 15) == 0, "conv3x3_s2_fwd: the statistics buffer must be 16-byte aligned");
-    CSEG_REQUIRE(B > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cin % 16 == 0 && s2_nt_ok(nt, Cout) && Wo % 4 == 0 &&
+    CSEG_REQUIRE(B > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cin % 16 == 0 && s2_nt_ok(nt, Cout) &&
                      (long)Ho * Wo * 4 * 16 * 4 < 2147483647L,
                  "conv3x3_s2_fwd: unsupported shape Cin=%d Cout=%d out %dx%d with %d channel tiles per block", Cin, Cout, Ho, Wo, nt);
     CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,

@@ -150,22 +150,13 @@ __device__ __forceinline__ void sb_store(const f32x4 (&acc)[4][NTMAX], float* __
         const size_t roff = (size_t)(co0 + nt * 16 + n) * plane + (size_t)yy * W;
         float* orow = ybc + roff;
         const float bv = bias ? bias[co0 + nt * 16 + n] : 0.f;
+        const bool vec = (W & 3) == 0;              // rows 16-byte aligned (else element by element: cseg_store_row4)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int xx = x0 + 16 * mt + 4 * g;
             f32x4 v = acc[mt][nt] * unscale;
             v += bv;
-            if (xx + 3 < W) {
-                if (abc) {
-                    const float4 ad = *reinterpret_cast<const float4*>(abc + roff + xx);
-                    v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
-                }
-                *reinterpret_cast<float4*>(orow + xx) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                if (xx < W) orow[xx] = v[0] + (abc ? abc[roff + xx] : 0.f);
-                if (xx + 1 < W) orow[xx + 1] = v[1] + (abc ? abc[roff + xx + 1] : 0.f);
-                if (xx + 2 < W) orow[xx + 2] = v[2] + (abc ? abc[roff + xx + 2] : 0.f);
-            }
+            cseg_store_row4(orow, abc ? abc + roff : nullptr, xx, W, vec, v);
         }
     }
 }
@@ -577,20 +568,20 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, const flo
     CSEG_REQUIRE(arith_ok(arith) && (arith == CSEG_ARITH_BF16X6 || (amax_x && amax_w)),
                  "conv3x3 split: arithmetic %d needs max|x| and max|w|", arith);
     if (NT == CSEG_NT_SB8) {
-        CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && W % 4 == 0,
+        CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
                      "conv3x3_sb: packed weights / output must be 16-byte aligned and W a multiple of 4");
         CSEG_REQUIRE(!addend, "conv3x3_sb: the 8-row kernel takes no addend");
         return cseg_sb16::fwd8(x, wp, bias, B, Cin, Cout, H, W, arith, amax_x, amax_w, y, stats, stream);
     }
     if (use_sb16(Cout)) {
-        CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && W % 4 == 0,
+        CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
                      "conv3x3_sb: packed weights / output must be 16-byte aligned and W a multiple of 4");
         return cseg_sb16::fwd(x, wp, bias, addend, B, Cin, Cout, H, W, sb16_nt(Cout, NT), arith, amax_x, amax_w, y, stats, stream);
     }
     if (NT == 0) NT = pick_nt(Cout);
     CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && NT > 0 && nt_ok(NT, Cout),
                  "conv3x3_sb: unsupported shape B=%d Cin=%d Cout=%d %dx%d", B, Cin, Cout, H, W);
-    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && W % 4 == 0,
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
                  "conv3x3_sb: packed weights / output must be 16-byte aligned and W a multiple of 4");
     const uint4* wq = (const uint4*)wp;
     // CSEG_CONV3X3_SB_GLDS=0: stage B through registers instead of LDS-DMA

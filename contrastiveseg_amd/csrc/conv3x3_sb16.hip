@@ -75,22 +75,13 @@ __device__ __forceinline__ void sb16_store(const f32x4 (&acc)[4][NTMAX], float* 
         const size_t roff = (size_t)(co0 + nt * 16 + n) * plane + (size_t)yy * W;
         float* orow = ybc + roff;
         const float bv = bias ? bias[co0 + nt * 16 + n] : 0.f;
+        const bool vec = (W & 3) == 0;              // rows 16-byte aligned (else element by element: cseg_store_row4)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int xx = x0 + 16 * mt + 4 * g;
             f32x4 v = acc[mt][nt] * unscale;
             v += bv;
-            if (xx + 3 < W) {
-                if (abc) {                          // epilogue addend (see conv3x3_sb.hip:sb_store)
-                    const float4 ad = *reinterpret_cast<const float4*>(abc + roff + xx);
-                    v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
-                }
-                *reinterpret_cast<float4*>(orow + xx) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                if (xx < W) orow[xx] = v[0] + (abc ? abc[roff + xx] : 0.f);
-                if (xx + 1 < W) orow[xx + 1] = v[1] + (abc ? abc[roff + xx + 1] : 0.f);
-                if (xx + 2 < W) orow[xx + 2] = v[2] + (abc ? abc[roff + xx + 2] : 0.f);
-            }
+            cseg_store_row4(orow, abc ? abc + roff : nullptr, xx, W, vec, v);       // epilogue addend: see conv3x3_sb.hip:sb_store
         }
     }
 }
@@ -823,17 +814,13 @@ __device__ __forceinline__ void store8(const f32x4 (&acc)[4][NT], float* __restr
     for (int nt = 0; nt < NT; ++nt) {
         const float bv = bias ? bias[co0 + nt * 16 + n] : 0.f;
         float* orow = ybc + (size_t)(co0 + nt * 16 + n) * plane + (size_t)yy * W;
+        const bool vec = (W & 3) == 0;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int xx = x0 + 16 * mt + 4 * g;
             f32x4 v = acc[mt][nt] * unscale;
             v += bv;
-            if (xx + 3 < W) *reinterpret_cast<float4*>(orow + xx) = make_float4(v[0], v[1], v[2], v[3]);
-            else {
-                if (xx < W) orow[xx] = v[0];
-                if (xx + 1 < W) orow[xx + 1] = v[1];
-                if (xx + 2 < W) orow[xx + 2] = v[2];
-            }
+            cseg_store_row4(orow, nullptr, xx, W, vec, v);
         }
     }
 }
@@ -1053,8 +1040,8 @@ int fwd(const float* x, const void* wp, const float* bias, const float* addend, 
 int fwd8(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W, int arith, const unsigned* amax_x,
          const unsigned* amax_w, float* y, float4* stats, hipStream_t stream) {
     CSEG_REQUIRE(arith == CSEG_ARITH_F16X3 && amax_x && amax_w, "conv3x3_sb8: f16x3 only (needs max|x| and max|w|)");
-    CSEG_REQUIRE(Cout % 144 == 0 && Cin % 16 == 0 && W % 4 == 0 && (long)H * W * 16 * 4 < 2147483647L,
-                 "conv3x3_sb8: unsupported shape Cin=%d Cout=%d %dx%d (needs Cout %% 144, Cin %% 16, W %% 4)", Cin, Cout, H, W);
+    CSEG_REQUIRE(Cout % 144 == 0 && Cin % 16 == 0 && (long)H * W * 16 * 4 < 2147483647L,
+                 "conv3x3_sb8: unsupported shape Cin=%d Cout=%d %dx%d (needs Cout %% 144, Cin %% 16)", Cin, Cout, H, W);
     const size_t lds = sb8::lds_bytes();
     static bool attr_set = false;
     if (!attr_set) {

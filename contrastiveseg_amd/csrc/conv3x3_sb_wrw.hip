@@ -275,7 +275,11 @@ __device__ __forceinline__ int d2_idx(int buf, int p, int co, int i) { return ((
 // loaders store truncated bits instead of splitting (no conversion arithmetic), bit 2 = the loaders skip the global loads, bit 3 =
 // the loaders do not stage anything after a unit's prologue (consumer-only time).
 // (The ablation switches are a template parameter that the library no longer instantiates: timing experiments only, round 4.)
-template <class AR, int SEGW, int ABL = 0>
+// RAGGED (round 5): widths that are not multiples of the 32 / 64-pixel row segment (65 x 129 of DeepLab-R101-d8; 130 / 65 / 33 / 17
+// of HRNet at 520 x 520). The last segment of a row is partly outside the image and rows are not 16-byte aligned any more: the
+// loaders fetch the four pixels of a chunk one by one from columns clamped into the row and zero what lies outside (as they already
+// do for the halo columns); the consumers see full zero-padded segments and do not change.
+template <class AR, int SEGW, int ABL = 0, bool RAGGED = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                  int B, int Cin, int Cout, int H, int W, int n_split, int rpu,
                                                                  int SC, int SI, const unsigned* __restrict__ amax_x,
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
         cob = (st / n_si) * SC + j / SI;
     }
     const size_t plane = (size_t)H * W;
-    const int segs = W / SEGW;
+    const int segs = RAGGED ? (W + SEGW - 1) / SEGW : W / SEGW;
     const int runs = (H + rpu - 1) / rpu;
     const int n_units = B * segs * runs;
     const bool tile_ok = !loader && cib * CI_B + wave * 16 < Cin;
@@ -336,13 +340,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
         xi_ch[u] = min(cib * CI_B + ci, Cin - 1);
         xi_ok[u] = loader && item < CI_B * XCH && cib * CI_B + ci < Cin;
     }
-    int di_lds[DU], di_off[DU];                    // LDS offset (buffer 0, piece 0); element offset of (co, chunk) inside the image
+    int di_lds[DU], di_off[DU], di_c4[DU];         // LDS offset (buffer 0, piece 0); element offset of (co, chunk) inside the image; 4 * chunk
     bool di_ok[DU];
 #pragma unroll
     for (int u = 0; u < DU; ++u) {
         const int item = lt + 256 * u, itc = min(max(item, 0), CO_B * DCH - 1);
         const int co = itc / DCH, c = itc - co * DCH;
         di_lds[u] = d2_idx<NP, SEGW>(0, 0, co, 4 * c);
+        di_c4[u] = 4 * c;
         di_off[u] = (cob * CO_B + co) * (int)plane + 4 * c;
         di_ok[u] = loader && item < CO_B * DCH;
     }
@@ -351,24 +356,44 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
     const float* d_img = dy;
     unsigned xu_off[XU], du_off[DU];
     bool xu_ok[XU];
+    int xu_px[XU], du_px[DU];                      // RAGGED: column of element 0 of the item's chunk
     auto unit_setup = [&](int b, int x0) {
         x_img = x + (size_t)b * Cin * plane;
         d_img = dy + (size_t)b * Cout * plane;
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             const int px = x0 + xi_px[u];
-            xu_off[u] = (unsigned)(xi_ch[u] * (int)plane + min(max(px, 0), W - 4)) * (unsigned)sizeof(float);
-            xu_ok[u] = xi_ok[u] && px >= 0 && px < W;
+            if (RAGGED) {
+                xu_off[u] = (unsigned)(xi_ch[u] * (int)plane) * (unsigned)sizeof(float);      // the channel row; columns per element
+                xu_px[u] = px;
+                xu_ok[u] = xi_ok[u];
+            } else {
+                xu_off[u] = (unsigned)(xi_ch[u] * (int)plane + min(max(px, 0), W - 4)) * (unsigned)sizeof(float);
+                xu_ok[u] = xi_ok[u] && px >= 0 && px < W;
+            }
         }
 #pragma unroll
-        for (int u = 0; u < DU; ++u) du_off[u] = (unsigned)(di_off[u] + x0) * (unsigned)sizeof(float);
+        for (int u = 0; u < DU; ++u) {
+            if (RAGGED) {
+                du_off[u] = (unsigned)(di_off[u] - di_c4[u]) * (unsigned)sizeof(float);           // the channel row; columns per element
+                du_px[u] = x0 + di_c4[u];
+            } else {
+                du_off[u] = (unsigned)(di_off[u] + x0) * (unsigned)sizeof(float);
+            }
+        }
     };
     auto x_load = [&](int row, float4 (&v)[XU]) __attribute__((always_inline)) {
         const float* rowp = x_img + (size_t)min(max(row, 0), H - 1) * W;          // uniform
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             if (ABL & 4) v[u] = make_float4(1.f, 2.f, 3.f, 4.f);
-            else v[u] = cseg_load_f4(rowp, xu_off[u]);
+            else if (RAGGED) {
+                const char* chrow = reinterpret_cast<const char*>(rowp) + xu_off[u];
+                float e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = *reinterpret_cast<const float*>(chrow + (long)min(max(xu_px[u] + k, 0), W - 1) * 4);
+                v[u] = make_float4(e[0], e[1], e[2], e[3]);
+            } else v[u] = cseg_load_f4(rowp, xu_off[u]);
         }
     };
     auto x_put = [&](int row, int slot, const float4 (&v)[XU]) __attribute__((always_inline)) {
@@ -376,7 +401,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             if (xi_ok[u]) {
-                const float4 t = (xu_ok[u] && row_ok) ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 t = (xu_ok[u] && row_ok) ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (RAGGED) {                          // columns left of the image (halo) or right of it (halo / the ragged last segment)
+                    const int px = xu_px[u];
+                    t.x = (px >= 0 && px < W) ? t.x : 0.f;         t.y = (px + 1 >= 0 && px + 1 < W) ? t.y : 0.f;
+                    t.z = (px + 2 >= 0 && px + 2 < W) ? t.z : 0.f; t.w = (px + 3 >= 0 && px + 3 < W) ? t.w : 0.f;
+                }
                 uint2 cells[NP];
                 if (ABL & 2) {
 #pragma unroll
@@ -395,7 +425,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
 #pragma unroll
         for (int u = 0; u < DU; ++u) {
             if (ABL & 4) v[u] = make_float4(1.f, 2.f, 3.f, 4.f);
-            else v[u] = cseg_load_f4(rowp, du_off[u]);
+            else if (RAGGED) {
+                const char* chrow = reinterpret_cast<const char*>(rowp) + du_off[u];
+                float e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = *reinterpret_cast<const float*>(chrow + (long)min(du_px[u] + k, W - 1) * 4);
+                v[u] = make_float4(e[0], e[1], e[2], e[3]);
+            } else v[u] = cseg_load_f4(rowp, du_off[u]);
         }
     };
     auto d_put = [&](int buf, const float4 (&v)[DU]) __attribute__((always_inline)) {
@@ -403,12 +439,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
         for (int u = 0; u < DU; ++u) {
             if (di_ok[u]) {
                 uint2 cells[NP];
+                float4 t = v[u];
+                if (RAGGED) {                          // the ragged last segment: columns right of the image contribute nothing
+                    const int px = du_px[u];
+                    t.x = px < W ? t.x : 0.f;     t.y = px + 1 < W ? t.y : 0.f;
+                    t.z = px + 2 < W ? t.z : 0.f; t.w = px + 3 < W ? t.w : 0.f;
+                }
                 if (ABL & 2) {
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
                         cells[p] = make_uint2(__builtin_bit_cast(unsigned, v[u].x) >> 16 | (__builtin_bit_cast(unsigned, v[u].y) & 0xffff0000u),
                                               __builtin_bit_cast(unsigned, v[u].z) >> 16 | (__builtin_bit_cast(unsigned, v[u].w) & 0xffff0000u));
-                } else split_cells4<AR>(v[u], dscale, cells);
+                } else split_cells4<AR>(t, dscale, cells);
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
                     *reinterpret_cast<uint2*>(ds + di_lds[u] + (buf * NP + p) * CO_B * d2_pitch(NP, SEGW)) = cells[p];
@@ -617,7 +659,8 @@ int sb_wrw_version() {
 
 // version 2: 64-pixel row segments, or 32-pixel ones when the width is 32 mod 64 (the 384-channel maps of HRNet-W48: 16 x 32);
 // runs of 16 rows (8 on maps lower than 32 rows, so that the 16 x 32 maps still give every split a unit)
-int wrw2_seg(int W) { return W % 64 == 0 ? 64 : 32; }
+int wrw2_seg(int W) { return W % 64 == 0 ? 64 : (W % 32 == 0 ? 32 : (W > 48 ? 64 : 32)); }      // ragged widths: the segment that wastes less
+bool wrw2_ragged(int W) { return W % wrw2_seg(W) != 0; }
 int wrw2_rpu(int H) { return H >= 32 ? 16 : 8; }      // 8-row runs at 32 rows cost the 192-channel maps 52 -> 62 us (more splits, more partials)
 
 void sb_wrw_group(int n_cob, int n_cib, int& SC, int& SI);
@@ -630,7 +673,7 @@ int sb_wrw_splits(int B, int Cin, int Cout, int H, int W, int arith) {
     const bool v2 = arith == CSEG_ARITH_F16X3 || sb_wrw_version() == 2;
     const int rpu = v2 ? wrw2_rpu(H) : ROWS_PER_UNIT;
     const int seg = v2 ? wrw2_seg(W) : SEG;
-    const int units = B * (W / seg) * ((H + rpu - 1) / rpu);
+    const int units = B * ((W + seg - 1) / seg) * ((H + rpu - 1) / rpu);
     const int n_cib = (Cin + CI_B - 1) / CI_B, n_cob = Cout / CO_B;
     const int pairs = n_cib * n_cob;
     if (!v2) {
@@ -663,7 +706,9 @@ int sb_wrw_splits(int B, int Cin, int Cout, int H, int W, int arith) {
 
 // the larger of the two arithmetics' needs (they may split differently: version 1 has no 32-pixel segments)
 extern "C" size_t cseg_conv3x3_sb_wrw_ws_floats(int B, int Cin, int Cout, int H, int W) {
-    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || Cin % 16 || Cout % CO_B || W % 32) return 0;
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || Cin % 16 || Cout % CO_B) return 0;
+    if (W % 32 && sb_wrw_version() != 2) return 0;          // ragged widths: version 2 only
+    if (W % 32) return (size_t)sb_wrw_splits(B, Cin, Cout, H, W, CSEG_ARITH_F16X3) * 9 * Cin * Cout;       // (f16x3 only, below)
     if (W % SEG && sb_wrw_version() != 2) return (size_t)sb_wrw_splits(B, Cin, Cout, H, W, CSEG_ARITH_F16X3) * 9 * Cin * Cout;
     const int a = sb_wrw_splits(B, Cin, Cout, H, W, CSEG_ARITH_BF16X6), b = sb_wrw_splits(B, Cin, Cout, H, W, CSEG_ARITH_F16X3);
     return (size_t)(a > b ? a : b) * 9 * Cin * Cout;
@@ -686,13 +731,13 @@ void sb_wrw_group(int n_cob, int n_cib, int& SC, int& SI) {
     }
 }
 
-template <class AR, int SEGW, int ABL = 0>
+template <class AR, int SEGW, int ABL = 0, bool RAGGED = false>
 int launch_wrw2(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, int n_split, const unsigned* amax_x,
                 const unsigned* amax_dy, float* ws, hipStream_t stream) {
     const size_t lds2 = sizeof(unsigned short) * (x2_elems(AR::NP, SEGW) + d2_elems(AR::NP, SEGW));
     static bool attr2_set = false;
     if (!attr2_set) {
-        if (hipFuncSetAttribute((const void*)(conv3x3_sb_wrw2_kernel<AR, SEGW, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) !=
+        if (hipFuncSetAttribute((const void*)(conv3x3_sb_wrw2_kernel<AR, SEGW, ABL, RAGGED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) !=
             hipSuccess) {
             cseg_set_error("conv3x3_sb_wrw: cannot raise dynamic LDS to %zu bytes", lds2);
             return 0;
@@ -705,7 +750,7 @@ int launch_wrw2(const float* x, const float* dy, int B, int Cin, int Cout, int H
     const long n_groups = (long)n_split * (n_cob / SC) * (n_cib / SI);
     const long blocks = ((n_groups + 7) / 8) * 8 * SC * SI;
     CSEG_REQUIRE(blocks < 2147483647L, "conv3x3_sb_wrw: grid too large");
-    hipLaunchKernelGGL((conv3x3_sb_wrw2_kernel<AR, SEGW, ABL>), dim3((unsigned)blocks), dim3(512), lds2, stream, x, dy, B, Cin, Cout, H, W,
+    hipLaunchKernelGGL((conv3x3_sb_wrw2_kernel<AR, SEGW, ABL, RAGGED>), dim3((unsigned)blocks), dim3(512), lds2, stream, x, dy, B, Cin, Cout, H, W,
                        n_split, wrw2_rpu(H), SC, SI, amax_x, amax_dy, ws);
     CSEG_CHECK_LAUNCH("conv3x3_sb_wrw2_kernel");
     return 1;
@@ -715,8 +760,9 @@ int wrw_impl(const float* x, const float* dy, int B, int Cin, int Cout, int H, i
              const unsigned* amax_dy, float* ws, float* dw, hipStream_t stream) {
     CSEG_REQUIRE(x && dy && ws && dw, "conv3x3_sb_wrw: null pointer");
     const bool v2 = arith == CSEG_ARITH_F16X3 || sb_wrw_version() == 2;
-    CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % CO_B == 0 && W % (v2 ? 32 : SEG) == 0,
-                 "conv3x3_sb_wrw: unsupported shape B=%d Cin=%d Cout=%d %dx%d (needs Cin %% 16, Cout %% 48, W %% 32; version 1: W %% 64)",
+    const bool ragged = v2 && arith == CSEG_ARITH_F16X3 && wrw2_ragged(W);          // round 5: any width (f16x3, version 2)
+    CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % CO_B == 0 && (ragged || W % (v2 ? 32 : SEG) == 0),
+                 "conv3x3_sb_wrw: unsupported shape B=%d Cin=%d Cout=%d %dx%d (needs Cin %% 16, Cout %% 48; bf16x6: W %% 32; version 1: W %% 64)",
                  B, Cin, Cout, H, W);
     CSEG_REQUIRE(arith == CSEG_ARITH_BF16X6 || (arith == CSEG_ARITH_F16X3 && amax_x && amax_dy),
                  "conv3x3 split wrw: arithmetic %d needs max|x| and max|dy|", arith);
@@ -724,12 +770,15 @@ int wrw_impl(const float* x, const float* dy, int B, int Cin, int Cout, int H, i
     const long blocks = (long)n_split * ((Cin + CI_B - 1) / CI_B) * (Cout / CO_B);
     CSEG_REQUIRE(blocks < 2147483647L && (long)9 * Cin * Cout < 2147483647L, "conv3x3_sb_wrw: grid too large");
     if (v2) {
-        CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0,
+        CSEG_REQUIRE(ragged || ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0),
                      "conv3x3_sb_wrw: tensors must be 16-byte aligned");
         CSEG_REQUIRE((long)Cin * H * W * 4 < 2147483647L && (long)Cout * H * W * 4 < 2147483647L,
                      "conv3x3_sb_wrw: one image of x / dy must stay below 2 GiB (32-bit offsets)");
         const bool wide = wrw2_seg(W) == 64;
-        const int ok = arith == CSEG_ARITH_F16X3
+        const int ok = ragged
+                           ? (wide ? launch_wrw2<SplitF16x3, 64, 0, true>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream)
+                                   : launch_wrw2<SplitF16x3, 32, 0, true>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream))
+                       : arith == CSEG_ARITH_F16X3
                            ? (wide ? launch_wrw2<SplitF16x3, 64>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream)
                                    : launch_wrw2<SplitF16x3, 32>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream))
                            : (wide ? launch_wrw2<SplitBF16x6, 64>(x, dy, B, Cin, Cout, H, W, n_split, amax_x, amax_dy, ws, stream)

@@ -100,6 +100,26 @@ __device__ __forceinline__ void cseg_wait_counter(const int* counter, int want) 
     }
 }
 
+// Four consecutive outputs v[0..3] of one NCHW row at columns xx .. xx + 3 (xx % 4 == 0), optional epilogue addend of the same layout.
+// Rows of a tensor whose width (or, for the flat-plane kernels, H*W) is a multiple of 4 floats start 16-byte aligned: one dwordx4 store
+// (and load). Round 5: other widths (the 65 x 129 maps of DeepLab-R101-d8, the 130 / 65 / 33 / 17-wide maps of HRNet at 520 x 520) go
+// element by element -- a uniform branch, so the aligned shapes pay nothing.
+typedef float cseg_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void cseg_store_row4(float* __restrict__ orow, const float* __restrict__ arow, long xx, long W, bool vec,
+                                                cseg_f32x4 v) {
+    if (vec && xx + 3 < W) {
+        if (arow) {
+            const float4 ad = *reinterpret_cast<const float4*>(arow + xx);
+            v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
+        }
+        *reinterpret_cast<float4*>(orow + xx) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (xx + k < W) orow[xx + k] = v[k] + (arow ? arow[xx + k] : 0.f);
+    }
+}
+
 void cseg_set_error(const char* fmt, ...);
 
 // reference convention: 1 = ok, 0 = error (lib/extensions/cc_attention/src/ca.cu:199-204)

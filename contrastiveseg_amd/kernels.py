@@ -132,7 +132,12 @@ def _desc(mode, anchors, a_lab, temperature, base_temperature, contrast=None, c_
 # launch (round 5: S tiles on the fp32 MFMA, online row statistics by wavefront reductions, the positives' sweep from LDS after an
 # in-launch hand-off between the blocks of a row strip) that also stores the S tiles once for the backward. Both are kept: the default
 # is whichever measured faster on the MI355X (bench_detail.json carries both timings).
-CONTRAST_FUSED = os.environ.get("CSEG_CONTRAST_FUSED", "1")
+# Measured on the MI355X (profiles/r05_contrast_fused_probe.json, host + device time of back-to-back calls): self N = 912 37.0 us (three)
+# vs 52.4 (fused); bank 1024 x 4104 56.7 vs 105.9; bank 152 x 190 000 (the reference's memory_size 5000) 936 vs 670. The single launch
+# pays two in-launch hand-offs and a serial finish (last block of a strip -> last strip -> mean) that three back-to-back launches do not,
+# and wins once S is large enough for its HBM round trips to matter. "auto" (default): fused from N * M >= 2^24 on.
+CONTRAST_FUSED = os.environ.get("CSEG_CONTRAST_FUSED", "auto")
+CONTRAST_FUSED_MIN_NM = 1 << 24
 _FUSED_WS = {}       # (device index, stream) -> scratch of the fused forward; its counters are zero between launches (the kernel resets them)
 
 
@@ -155,7 +160,7 @@ def contrast_forward(desc, device):
     row_stats = torch.empty(desc.N, 4, dtype=F32, device=device)
     row_loss = torch.empty(desc.N, dtype=F32, device=device)
     loss = torch.empty(1, dtype=F32, device=device)
-    if CONTRAST_FUSED != "0":
+    if CONTRAST_FUSED == "1" or (CONTRAST_FUSED == "auto" and desc.N * desc.M >= CONTRAST_FUSED_MIN_NM):
         # (the scratch is laid out by the library for exactly this (N, M): counters behind the partials -- a buffer that served another
         # shape still has its counters at zero, wherever they were)
         scratch = _fused_ws(desc.N, desc.M, device)
@@ -1188,12 +1193,13 @@ CONV3X3_SB_PICK_NT_CHANNELS = (192, 384)
 
 def conv3x3_sb_eligible(x, weight):
     """NCHW fp32 on the GPU, 3x3, channels % 48 (or exactly 64: the layer-1 bottlenecks) both ways (forward needs Cin % 16 and
-    a tiling Cout, backward-data the mirror image), width % 4."""
+    a tiling Cout, backward-data the mirror image)."""
     if not (_on_device(x) and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4 and x.is_contiguous()):
         return False
     co, ci, kh, kw = weight.shape
     ok = lambda c: c % 48 == 0 or c % 64 == 0
-    return (kh, kw) == (3, 3) and ok(ci) and ok(co) and x.shape[1] == ci and x.shape[3] % 4 == 0
+    # (any width since round 5: rows that are not 16-byte aligned are stored element by element, cseg_store_row4)
+    return (kh, kw) == (3, 3) and ok(ci) and ok(co) and x.shape[1] == ci
 
 
 # nt value that selects the 8 x 64-pixel kernel (include/cseg_hip.h: CSEG_NT_SB8) for wide layers: f16x3, output channels % 144
@@ -1293,10 +1299,10 @@ CONV3X3_SB_WRW_PAIRS = ((256, 48),)
 
 
 def conv3x3_sb_wrw_eligible(x, dy):
-    """Shapes the kernel covers (NCHW fp32, Cin % 16, Cout % 48, width % 32: 64-pixel row segments, 32-pixel ones for the
-    16 x 32 maps of the 384-channel branch)."""
+    """Shapes the kernel covers (NCHW fp32, Cin % 16, Cout % 48; 64-pixel row segments, 32-pixel ones for the 16 x 32 maps of the
+    384-channel branch; since round 5 any width in the f16x3 arithmetic -- the last segment of a row may be ragged)."""
     return (_on_device(x) and x.dtype == F32 and dy.dtype == F32 and x.is_contiguous() and dy.is_contiguous()
-            and x.shape[1] % 16 == 0 and dy.shape[1] % 48 == 0 and x.shape[3] % 32 == 0)
+            and x.shape[1] % 16 == 0 and dy.shape[1] % 48 == 0 and (x.shape[3] % 32 == 0 or SPLIT_ARITH == "f16x3"))
 
 
 def conv3x3_sb_wrw_wanted(x, dy):
@@ -1358,7 +1364,7 @@ class Conv3x3SplitBF16(Function):
                 dw = _on_wgrad_stream(lambda: conv3x3_sb_wrw(x, dy, ax=ctx.ax, ady=ady), x, dy, ctx.ax, ady) \
                     if ctx.needs_input_grad[1] else None
                 db = dy.sum((0, 2, 3)) if want_db else None
-            elif not ctx.has_bias and co == ci and co in CONV3X3_WRW_CHANNELS:
+            elif not ctx.has_bias and co == ci and co in CONV3X3_WRW_CHANNELS and x.shape[3] % 4 == 0:
                 dw = _conv3x3_wrw(x, dy, co, ci)
             else:
                 _, dw, db = torch.ops.aten.convolution_backward(
@@ -1401,7 +1407,7 @@ class Conv3x3SplitFork(Function):
             co, ci = weight.shape[:2]
             if conv3x3_sb_wrw_wanted(x, dy):
                 dw = _on_wgrad_stream(lambda: conv3x3_sb_wrw(x, dy, ax=ctx.ax, ady=ady), x, dy, ctx.ax, ady)
-            elif co == ci and co in CONV3X3_WRW_CHANNELS:
+            elif co == ci and co in CONV3X3_WRW_CHANNELS and x.shape[3] % 4 == 0:
                 dw = _conv3x3_wrw(x, dy, co, ci)
             else:
                 dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
@@ -1605,7 +1611,7 @@ def _s2_base_ok(x, weight):
 
 def conv3x3_s2_fwd_eligible(x, weight):
     co, ci = weight.shape[:2]
-    return _s2_base_ok(x, weight) and x.shape[1] == ci and ci % 16 == 0 and co % 48 == 0 and x.shape[3] % 8 == 0
+    return _s2_base_ok(x, weight) and x.shape[1] == ci and ci % 16 == 0 and co % 48 == 0          # (even input; any output width since round 5)
 
 
 def conv3x3_s2_bwd_eligible(x, weight):
@@ -1720,12 +1726,12 @@ CONV1X1_SB_MIN_TILES = int(os.environ.get("CSEG_SB_MIN_TILES", "256"))
 
 
 def conv1x1_sb_eligible(x, weight):
-    """NCHW fp32 on the GPU, 1x1, Cin % 16 and Cout % 48|64 in both directions (backward-data swaps them), H*W % 4."""
+    """NCHW fp32 on the GPU, 1x1, Cin % 16 and Cout % 48|64 in both directions (backward-data swaps them)."""
     if not (_on_device(x) and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4 and x.is_contiguous()):
         return False
     co, ci, kh, kw = weight.shape
     ok = lambda c: c % 48 == 0 or c % 64 == 0
-    return (kh, kw) == (1, 1) and ok(ci) and ok(co) and x.shape[1] == ci and (x.shape[2] * x.shape[3]) % 4 == 0
+    return (kh, kw) == (1, 1) and ok(ci) and ok(co) and x.shape[1] == ci          # (any H*W since round 5, see conv3x3_sb_eligible)
 
 
 def conv1x1_sb_tiles(x, c_out):
@@ -1765,7 +1771,7 @@ CONV1X1_SB_WRW_MIN_CH = int(os.environ.get("CSEG_CONV1X1_SB_WRW_MIN_CH", "16")) 
 
 def conv1x1_sb_wrw_eligible(x, dy):
     return (_on_device(x) and x.dtype == F32 and dy.dtype == F32 and x.is_contiguous() and dy.is_contiguous()
-            and x.shape[1] % 16 == 0 and dy.shape[1] % 16 == 0 and (x.shape[2] * x.shape[3]) % 32 == 0)
+            and x.shape[1] % 16 == 0 and dy.shape[1] % 16 == 0)          # (any H*W since round 5: ragged loader variant)
 
 
 def conv1x1_sb_wrw_wanted(x, dy):

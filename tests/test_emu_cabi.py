@@ -313,7 +313,7 @@ def test_train_steps_on_the_emulated_device_equal_the_torch_restatement(case, mo
 def test_conv3x3_module_routes_to_the_split_kernels(channels, hw, monkeypatch):
     """nn.Conv2d semantics of the module whatever the route: forward / backward-data on the split-bf16 kernel (192 channels
     through the explicit-tiling entry points, exactly as _hip.SIGNATURES declares them), weight gradient on the split-bf16
-    kernel (48 / 96 at widths % 64), the fp32-MFMA kernel or aten."""
+    kernel (48 / 96 / 192 at any width), the fp32-MFMA kernel or aten."""
     import torch.nn.functional as F
     from contrastiveseg_amd import kernels as K
     from contrastiveseg_amd.lib.models.tools.module_helper import Conv3x3
@@ -339,8 +339,8 @@ def test_conv3x3_module_routes_to_the_split_kernels(channels, hw, monkeypatch):
     if channels in K.CONV3X3_SB_PICK_NT_CHANNELS:
         assert calls[0][1] == calls[1][1] == K.conv3x3_sb_pick_nt(x, channels) and calls[0][1] in (3, 6)
     wrw_route = [c[0] for c in calls[2:]]
-    if channels in K.CONV3X3_SB_WRW_CHANNELS and hw[1] % 64 == 0:
-        assert wrw_route == ["conv3x3_sb_wrw"]
+    if channels in K.CONV3X3_SB_WRW_CHANNELS:              # (any width since round 5: ragged row segments, f16x3)
+        assert K.SPLIT_ARITH == "f16x3" and wrw_route == ["conv3x3_sb_wrw"]
     elif channels in K.CONV3X3_WRW_CHANNELS:
         assert wrw_route == ["_conv3x3_wrw"]
     else:

@@ -284,3 +284,143 @@ def test_fan_out_node_in_the_lockstep_exchange(monkeypatch):
         assert torch.equal(a, b)
     for a, b in zip(res[False][1], res[True][1]):
         assert float((a - b).abs().max()) <= 2e-6 * max(1e-3, float(a.abs().max()))
+
+
+# ---- round 5: widths / planes that are NOT multiples of 4 floats (DeepLab-R101-d8: 65 x 129; HRNet at 520 x 520: 130, 65, 33, 17) ----
+RAGGED = [
+    # kind, B, Cin, Cout, H, W, nt, bias, env
+    ("c3", 1, 48, 48, 9, 65, 0, False, {}),                          # 8-row / 4-row persistent kernels, odd width, two column tiles
+    ("c3", 1, 48, 48, 9, 65, 0, False, {"CSEG_SB16_ROWS8": "2"}),
+    ("c3", 2, 96, 96, 5, 33, 0, True, {}),                           # conv3x3_sb_kernel<6>, with bias
+    ("c3", 1, 64, 64, 6, 130, 0, False, {}),                         # W % 4 == 2: one-tile 16-channel-chunk kernel
+    ("c3", 1, 192, 192, 3, 17, 3, False, {}),                        # streamed weights
+    ("c3", 1, 144, 144, 9, 129, 0x109, True, {}),                    # the 8-row head kernel
+    ("c1", 2, 64, 256, 5, 13, 0, True, {}),                          # plane 65
+    ("c1", 1, 48, 144, 13, 43, 0, False, {}),                        # plane 559 = 2 x 256 + 47
+]
+
+
+@pytest.mark.parametrize("case", RAGGED, ids=lambda c: "%s-%d-%dx%d" % (c[0], c[2], c[4], c[5]))
+def test_widths_that_are_not_multiples_of_four(case, monkeypatch):
+    """The split-operand forward / backward-data kernels at odd widths: output, epilogue addend (3x3) and the statistics epilogue
+    against torch in float64 -- the stores (and the addend loads) go element by element when a row is not 16-byte aligned
+    (cseg_store_row4); the loaders never needed alignment."""
+    kind, B, Cin, Cout, H, W, nt, bias, env = case
+    from contrastiveseg_amd import kernels as K
+    inject.install(monkeypatch)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setattr(K, "SPLIT_ARITH", "f16x3")
+    monkeypatch.setattr(K, "SPLIT_WEIGHTS", K.SplitWeights())
+    monkeypatch.setattr(K, "CONV_EPILOGUE_STATS", True)
+    g = torch.Generator().manual_seed(3 + Cin + W)
+    k = 1 if kind == "c1" else 3
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (k * k * Cin) ** 0.5
+    bvec = (torch.randn(Cout, generator=g) * 0.5) if bias else None
+    x = torch.randn(B, Cin, H, W, generator=g) + 0.3
+    assert (H * W) % 4 != 0 if kind == "c1" else W % 4 != 0
+    if kind == "c1":
+        assert K.conv1x1_sb_eligible(x, w)
+        y = K.conv1x1_sb_run(x, w, False, bvec, want_stats=True)
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), None if bvec is None else bvec.double())
+        gy = torch.randn(B, Cout, H, W, generator=g)
+        dx = K.conv1x1_sb_run(gy, w, True)
+        dref = torch.nn.functional.conv_transpose2d(gy.double(), w.double())
+    else:
+        assert K.conv3x3_sb_eligible(x, w)
+        y = K.conv3x3_sb_run(x, w, False, bvec, nt, want_stats=True)
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), None if bvec is None else bvec.double(), 1, 1)
+        gy = torch.randn(B, Cout, H, W, generator=g)
+        if nt == 0x109:
+            dx = K.conv3x3_sb_run(gy, w, True, None, nt)
+            dref = torch.nn.functional.conv_transpose2d(gy.double(), w.double(), None, 1, 1)
+        else:
+            ad = torch.randn(B, Cin, H, W, generator=g)
+            dx = K.conv3x3_sb_run(gy, w, True, None, nt, addend=ad)
+            dref = torch.nn.functional.conv_transpose2d(gy.double(), w.double(), None, 1, 1) + ad.double()
+    assert not torch.isnan(y).any() and not torch.isnan(dx).any()
+    assert float((y.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+    assert float((dx.double() - dref).abs().max()) <= 3e-5 * float(dref.abs().max())
+    st = K.known_tile_stats(y)
+    n = y.numel() // Cout
+    assert abs(float(st[:, :, 0].sum()) - Cout * n) < 0.5
+    mi = K.bn_tiles_finalize(st, 1e-5, 0.1, None, None, None)
+    yd = y.double().transpose(0, 1).reshape(Cout, -1)
+    assert float((mi[:, 0].double() - yd.mean(1)).abs().max()) <= 2e-6 * max(1.0, float(yd.mean(1).abs().max()))
+    assert float((mi[:, 1].double() * torch.sqrt(yd.var(1, unbiased=False) + 1e-5) - 1).abs().max()) <= 2e-6
+
+
+def test_residual_block_at_an_odd_width_takes_the_split_kernels_for_forward_and_backward_data(monkeypatch):
+    """A BasicBlock on 6 x 65 maps (the 1/8-resolution maps of HRNet at 520 x 520): forward, backward-data (incl. the identity gradient
+    in its epilogue) and weight gradients of both convolutions on the split kernels -- as ONE autograd node, like at the aligned widths --
+    against the same block on torch's own convolutions."""
+    from contrastiveseg_amd import kernels as K
+    from contrastiveseg_amd.lib.models.backbones.hrnet_backbone import BasicBlock
+    from contrastiveseg_amd.lib.models.tools.module_helper import mark_conv_bn_pairs
+    inject.install(monkeypatch)
+    monkeypatch.setattr(K, "SPLIT_ARITH", "f16x3")
+    monkeypatch.setattr(K, "SPLIT_WEIGHTS", K.SplitWeights())
+    monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
+    torch.manual_seed(5)
+    blk = mark_conv_bn_pairs(BasicBlock(48, 48, bn_type="torchbn").train())
+    x0 = torch.randn(2, 48, 6, 65) + 0.2
+    gy = torch.randn(2, 48, 6, 65)
+    res = {}
+    for split in (True, False):
+        monkeypatch.setattr(K, "CONV3X3_SPLIT_BF16", split)
+        for bn in (blk.bn1, blk.bn2):
+            bn.reset_running_stats()
+        calls = []
+        orig = K._hip.call
+        monkeypatch.setattr(K._hip, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+        x = x0.clone().requires_grad_(True)
+        y = blk(x)
+        y.backward(gy)
+        monkeypatch.setattr(K._hip, "call", orig)
+        res[split] = (y.detach(), x.grad.clone(), blk.conv1.weight.grad.clone(), blk.conv2.weight.grad.clone(), calls)
+        blk.zero_grad()
+    assert res[True][4].count("cseg_conv3x3_split_fwd_st") == 2 and "cseg_conv3x3_split_fwd_add" in res[True][4]
+    assert res[True][4].count("cseg_conv3x3_split_wrw") == 2
+    assert not any(n.startswith("cseg_conv3x3_split") for n in res[False][4])
+    for a, b, what in zip(res[True][:4], res[False][:4], ("out", "dx", "dw1", "dw2")):
+        assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max())), what
+
+
+@pytest.mark.parametrize("case", [(2, 48, 64, 5, 13), (1, 144, 160, 13, 43), (2, 64, 256, 9, 17), (1, 272, 144, 1, 33)])
+def test_pointwise_weight_gradient_on_ragged_planes(case, monkeypatch):
+    """cseg_conv1x1_split_wrw on planes that are not multiples of 32 pixels (round 5, the RAGGED loader: element loads clamped into the
+    plane, zeros behind it): 65, 559, 153 and 33 pixels per plane, two channel blocks in both directions in the last case --
+    against float64, twice (deterministic)."""
+    from contrastiveseg_amd import kernels as K
+    inject.install(monkeypatch)
+    monkeypatch.setattr(K, "SPLIT_ARITH", "f16x3")
+    B, ci, co, H, W = case
+    assert (H * W) % 32 != 0
+    g = torch.Generator().manual_seed(8 + W)
+    x = torch.randn(B, ci, H, W, generator=g)
+    dy = torch.randn(B, co, H, W, generator=g)
+    ref = torch.einsum("bohw,bchw->oc", dy.double(), x.double()).reshape(co, ci, 1, 1)
+    assert K.conv1x1_sb_wrw_eligible(x, dy)
+    got = K.conv1x1_sb_wrw(x, dy)
+    assert not torch.isnan(got).any()
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert torch.equal(got, K.conv1x1_sb_wrw(x, dy))
+
+
+@pytest.mark.parametrize("case", [(2, 48, 48, 5, 65), (1, 64, 96, 9, 33), (1, 16, 48, 18, 130), (2, 96, 48, 3, 17)])
+def test_weight_gradient_on_ragged_widths(case, monkeypatch):
+    """cseg_conv3x3_split_wrw at widths that are not multiples of the row segment (round 5, RAGGED loaders): 65 = 64 + 1, 33 = 32 + 1,
+    130 = 2 x 64 + 2 (with a run boundary: 18 rows), 17 < 32 -- against float64, twice (deterministic)."""
+    from contrastiveseg_amd import kernels as K
+    inject.install(monkeypatch)
+    monkeypatch.setattr(K, "SPLIT_ARITH", "f16x3")
+    B, ci, co, H, W = case
+    g = torch.Generator().manual_seed(18 + W)
+    x = torch.randn(B, ci, H, W, generator=g)
+    dy = torch.randn(B, co, H, W, generator=g)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (co, ci, 3, 3), dy.double(), padding=1)
+    assert K.conv3x3_sb_wrw_eligible(x, dy)
+    got = K.conv3x3_sb_wrw(x, dy)
+    assert not torch.isnan(got).any()
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), float((got.double() - ref).abs().max()) / float(ref.abs().max())
+    assert torch.equal(got, K.conv3x3_sb_wrw(x, dy))

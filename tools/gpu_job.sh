@@ -3,6 +3,7 @@
 # tools/gpu_jobs/r0N_job*.sh lab-notebook scripts of rounds 2-4; the numbers they produced are under profiles/ and in DESIGN.md).
 #   gpurun --timeout 900 -- 'bash tools/gpu_job.sh <tag> <step> [<step> ...]'
 # writes to gpurun_out/<tag>/ . Steps (run in the order given; each bounded by its own `timeout`):
+#   env:<VAR=VAL> / unenv:<VAR>   environment for the steps that follow
 #   smoke            __graft_entry__.smoke()
 #   suite[:<expr>]   pytest -m gpu (optionally -k <expr>)
 #   bench[:<args>]   bench.py with extra args (comma-separated, e.g. bench:--steps,20,--warmup,5); default = the short form
@@ -23,6 +24,8 @@ SHORT="--no-kernels --no-cpu-baseline --no-fp32-pass --steps 12 --warmup 4"
 for step in "$@"; do
   name=${step%%:*}; arg=""; [ "$step" != "$name" ] && arg=${step#*:}
   case $name in
+    env) export "$arg"; echo "export $arg" ;;
+    unenv) unset "$arg"; echo "unset $arg" ;;
     smoke) timeout 150 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
     suite)
       if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -k "$arg" > $O/tests.log 2>&1
@@ -30,7 +33,7 @@ for step in "$@"; do
       grep -E "passed|failed|Error|Fatal|CSEG_ZZ|^FAILED" $O/tests.log | cut -c1-1500 | tail -12 ;;
     bench)
       a=${arg//,/ }; [ -z "$a" ] && a=$SHORT
-      CSEG_BENCH_GUARD=0 timeout 900 python bench.py $a > $O/bench.log 2> $O/bench.err; tail -1 $O/bench.log | cut -c1-1800
+      CSEG_BENCH_GUARD=0 timeout 900 python bench.py $a > $O/bench.log 2> $O/bench.err; grep '^{"metric"' $O/bench.log | tail -1 | cut -c1-1800 | tee -a $O/bench_lines.txt
       cp bench_detail.json $O/bench_detail.json 2>/dev/null ;;
     ab)
       for r in 1 2; do for on in 0 1; do
