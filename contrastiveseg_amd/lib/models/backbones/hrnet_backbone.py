@@ -163,6 +163,7 @@ def _capture_forks(x=None):
     return DDP_FORKS_OK or not is_distributed()
 
 
+LOCKSTEP_FORKS = _os.environ.get("CSEG_LOCKSTEP_FORKS", "0") == "1"
 DDP_FORKS_OK = False        # set by ModuleRunner._make_parallel once the DDP wrapper joins the fork streams before its collectives
 
 
@@ -241,11 +242,13 @@ class HighResolutionModule(nn.Module):
         """The branches are independent residual chains of equal length: run them block by block side by side, so that
         the BN sites of one depth share ONE statistics all-reduce per direction (fused_bn.bn_act_group)."""
         x = list(x)
-        # Round 5: the convolutions of one depth are independent -- with forks allowed (per-GPU batch large enough for one host thread
-        # to feed four queues, _capture_forks) branch i > 0 runs its convolution on side stream i and the streams join before the
-        # batched statistics exchange, which stays on the calling stream with its ONE collective per direction. Same kernels, same
-        # values; autograd replays the forks in backward (a node's backward runs on its forward stream).
-        par = _ParallelConvs(x[0], len(self.branches)) if (_capture_forks(x[0]) and not _capturing()) else None
+        # Round 5, OPT-IN (CSEG_LOCKSTEP_FORKS=1): the convolutions of one depth are independent -- branch i > 0 runs its convolution
+        # on side stream i and the streams join before the batched statistics exchange, which stays on the calling stream with its ONE
+        # collective per direction. Same kernels, same values (tests/test_gpu_multirank.py); autograd replays the forks in backward.
+        # MEASURED on the MI355X inside a one-rank RCCL process group (bench.py --dist-single-rank, profiles/r05_dist_single_rank.txt):
+        # batch 8 118.3 ms/step with the forks vs 111.9 without, batch 4 98.7 vs 98.0 -- two fork / join pairs per block depth cost
+        # the host more than four short side-by-side convolutions give back, and this path is host-bound. Hence off by default.
+        par = _ParallelConvs(x[0], len(self.branches)) if (LOCKSTEP_FORKS and _capture_forks(x[0]) and not _capturing()) else None
         for k in range(len(self.branches[0])):
             blocks = [branch[k] for branch in self.branches]
             if par is None:

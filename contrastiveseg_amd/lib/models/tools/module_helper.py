@@ -96,6 +96,34 @@ class Conv1x1(nn.Conv2d):
         return super(Conv1x1, self).forward(x)
 
 
+class SplitConv2d(nn.Conv2d):
+    """nn.Conv2d (same constructor, parameters, initialisation and state_dict) for the 1x1 and plain 3x3 convolutions OUTSIDE the HRNet
+    branches (round 5): the bottleneck 1x1 layers and the deep stem of the ResNet encoders, ASPP's 1x1 branch and 3x3 projection,
+    the DSN / refine convolutions of the DeepLab head, the 3x3 + 1x1 layers of the OCR head (reference
+    lib/models/backbones/resnet/resnet_models.py:60-105, lib/models/modules/decoder_block.py:39-85, 151-179,
+    lib/models/modules/spatial_ocr_block.py:116-217, lib/models/nets/hrnet.py:113-131). Stride 1, no dilation, groups 1, `same`
+    padding and channel counts the split-operand kernels tile (multiples of 48 or 64 both ways), launches that fill the chip: forward
+    and backward-data on cseg_conv1x1_split_* / cseg_conv3x3_split_* at ANY width (the 65 x 129 and 130 x 130 maps of these models are
+    why the kernels lost their width % 4 requirement), weight gradients there too where kernels.conv*_wrw_wanted says so. Everything
+    else (dilated, strided, 7x7, class-count outputs) is the reference's convolution on MIOpen."""
+
+    bn_follows = False        # see Conv3x3
+
+    def forward(self, x):
+        from contrastiveseg_amd import kernels as K
+        k = self.kernel_size[0]
+        if (K._on_device(x) and self.kernel_size in ((1, 1), (3, 3)) and self.stride == (1, 1) and self.dilation == (1, 1)
+                and self.groups == 1 and self.padding == (k // 2, k // 2) and self.padding_mode == 'zeros' and x.dim() == 4):
+            if k == 1:
+                if (K.CONV1X1_SPLIT_BF16 and K.conv1x1_sb_eligible(x, self.weight)
+                        and K.conv1x1_sb_tiles(x, self.out_channels) >= K.CONV1X1_SB_MIN_TILES):
+                    return K.conv1x1_split_bf16(x, self.weight, self.bias, self.bn_follows)
+            elif (K.CONV3X3_SPLIT_BF16 and K.conv3x3_sb_eligible(x, self.weight)
+                    and K.conv3x3_sb_tiles(x, self.out_channels) >= K.CONV3X3_SB_MIN_TILES):
+                return K.conv3x3_split_bf16(x, self.weight, self.bias, self.bn_follows)
+        return super(SplitConv2d, self).forward(x)
+
+
 def mark_conv_bn_pairs(module):
     """Sets `bn_follows` on every split-kernel convolution of `module` whose output goes straight into a BatchNorm: the (conv, norm)
     neighbours of every nn.Sequential (the `_conv_bn` chains, classifier / projection heads, `BNReLU` wrappers included) and the
@@ -108,7 +136,7 @@ def mark_conv_bn_pairs(module):
             return True
         return isinstance(m, nn.Sequential) and len(m) > 0 and first_norm(m[0])
 
-    kinds = (Conv3x3, HeadConv3x3, Conv1x1)
+    kinds = (Conv3x3, HeadConv3x3, Conv1x1, SplitConv2d)
     for m in module.modules():
         if isinstance(m, nn.Sequential):
             kids = list(m)

@@ -245,6 +245,17 @@ def test_contrast_fused_forward_equals_the_three_launches(mode, N, M_or_ms, D, g
         assert np.isnan(out["fused"][2][7]) and np.isnan(out["fused"][0][0])
     for a, b in zip(out["fused"][:3], out["fused_again"][:3]):
         assert np.array_equal(a, b, equal_nan=True), "two launches on one scratch buffer must be bit-identical"
+    # S_out = NULL: the N x M array never exists (forward-only uses: validation of the contrastive term, memory-bound bank sizes)
+    import ctypes
+    from contrastiveseg_amd import _hip
+    rs2 = torch.empty(N, 4, dtype=torch.float32, device=dev)
+    rl2 = torch.empty(N, dtype=torch.float32, device=dev)
+    l2 = torch.empty(1, dtype=torch.float32, device=dev)
+    scratch = Kk._fused_ws(desc.N, desc.M, dev)
+    _hip.call("cseg_contrast_fwd_fused", ctypes.byref(desc), ctypes.c_void_p(scratch.data_ptr()), ctypes.c_void_p(None),
+              ctypes.c_void_p(rs2.data_ptr()), ctypes.c_void_p(rl2.data_ptr()), ctypes.c_void_p(l2.data_ptr()), _hip.stream_ptr())
+    for a, b in zip(out["fused"][:3], (l2, rs2, rl2)):
+        assert np.array_equal(a, b.cpu().numpy(), equal_nan=True), "without the S store the results are the same bits"
 
 
 def test_contrast_headline_shape_properties():

@@ -243,6 +243,7 @@ def _lockstep_worker(rank, world, port, q, backend, forks):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                       CSEG_DIST_BACKEND=backend, CSEG_DIST_SINGLE_RANK="1", CSEG_BRANCH_STREAMS="1" if forks else "0",
+                      CSEG_LOCKSTEP_FORKS="1" if forks else "0",
                       CSEG_BRANCH_STREAMS_MIN_PIXELS="1", CSEG_SB_MIN_TILES="1")
     import torch.distributed as dist
     torch.cuda.set_device(0)
