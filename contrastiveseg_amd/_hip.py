@@ -73,6 +73,7 @@ SIGNATURES = {
     "cseg_conv3x3_split_fwd": (_c_int, [_ptr, _ptr, _ptr] + [_c_int] * 7 + [_ptr, _ptr, _ptr, _ptr]),
     "cseg_conv3x3_split_wrw": (_c_int, [_ptr, _ptr] + [_c_int] * 6 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_conv3x3_split_fwd_add": (_c_int, [_ptr, _ptr, _ptr, _ptr] + [_c_int] * 7 + [_ptr, _ptr, _ptr, _ptr]),
+    "cseg_conv3x3_split_dil_fwd": (_c_int, [_ptr, _ptr, _ptr, _ptr] + [_c_int] * 7 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_conv3x3_s2_split_packed_bytes": (ctypes.c_size_t, [_c_int] * 2),
     "cseg_conv3x3_s2_split_plan": (_c_int, [_c_int] * 4 + [_ptr, _ptr]),
     "cseg_conv3x3_s2_split_pack": (_c_int, [_ptr] + [_c_int] * 4 + [_ptr, _ptr, _ptr]),

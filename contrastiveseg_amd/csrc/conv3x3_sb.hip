@@ -46,6 +46,8 @@ int fwd8(const float* x, const void* wp, const float* bias, int B, int Cin, int 
          const unsigned* amax_w, float* y, float4* stats, hipStream_t stream);
 int fwd(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W, int NT, int arith,
         const unsigned* amax_x, const unsigned* amax_w, float* y, float4* stats, hipStream_t stream);
+int fwd_dil(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W, int NT, int dil,
+            int arith, const unsigned* amax_x, const unsigned* amax_w, float* y, float4* stats, hipStream_t stream);
 }  // namespace cseg_sb16
 
 namespace {
@@ -645,6 +647,24 @@ extern "C" int cseg_conv3x3_split_fwd_st(const float* x, const void* wp, const f
     CSEG_REQUIRE(stats, "conv3x3_split_fwd_st: null statistics buffer");
     return fwd_impl(x, wp, bias, nullptr, B, Cin, Cout, H, W, nt, arith, amax_x, amax_w, y, (hipStream_t)stream_,
                     reinterpret_cast<float4*>(stats));
+}
+
+// Round 5: y = conv2d(x, w, bias, stride 1, padding = dilation, dilation) (+ addend, + statistics epilogue), dilation 2 or 4 -- the
+// 3x3 convolutions of the dilated ResNet stages of DeepLab-V3 (reference lib/models/backbones/resnet/resnet_backbone.py:88-101). f16x3;
+// output channel counts whose packed form is the 16-channel-chunk one (cseg_conv3x3_split_plan -> kind CSEG_PACK_C3_16): multiples of
+// 64 that are not multiples of 48 (256, 512, ...), or 48 / 192. The SAME packed weights as the undilated operator (pack the
+// transposed operator for backward-data). addend / stats nullable (not both).
+extern "C" int cseg_conv3x3_split_dil_fwd(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin, int Cout,
+                                          int H, int W, int dil, int arith, const unsigned* amax_x, const unsigned* amax_w, float* y,
+                                          float* stats, cseg_stream_t stream_) {
+    CSEG_REQUIRE(x && wp && y, "conv3x3 dilated: null pointer");
+    CSEG_REQUIRE(!stats || (!addend && (reinterpret_cast<uintptr_t>(stats) & 15) == 0),
+                 "conv3x3 dilated: the statistics epilogue takes no addend and needs a 16-byte aligned buffer");
+    CSEG_REQUIRE(use_sb16(Cout), "conv3x3 dilated: %d output channels are not packed in the 16-channel-chunk form", Cout);
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
+                 "conv3x3 dilated: packed weights / output must be 16-byte aligned");
+    return cseg_sb16::fwd_dil(x, wp, bias, addend, B, Cin, Cout, H, W, sb16_nt(Cout, 0), dil, arith, amax_x, amax_w, y,
+                              reinterpret_cast<float4*>(stats), (hipStream_t)stream_);
 }
 
 // segments per channel of a statistics buffer: kind 0 = 3x3 kernels (stride 1: H, W of the tensor; stride 2: of the OUTPUT),

@@ -237,6 +237,182 @@ __global__ __launch_bounds__(512, NT == 3 ? 4 : 2) void conv3x3_sb16_kernel(cons
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Round 5: the one-tile kernel above with a DILATION (2 or 4, padding = dilation): the 3x3 convolutions of the dilated ResNet stages
+// of DeepLab-V3 (reference lib/models/backbones/resnet/resnet_backbone.py:88-101 `_nostride_dilate`: layer3 at rate 2, layer4 at
+// rate 4; 23 + 1 of the 3x3 layers of R-101-d8, 256 -> 256 and 512 -> 512 on 65 x 129 maps). Everything is the kernel above --
+// same packed weights (CSEG_PACK_C3_16), K-steps, fragment layout, epilogue -- except the patch: (TR + 2 d) x (TC + 2 d) pixels
+// around the 4 x 64 tile, tap (ky, kx) at cell offset (ky d, kx d). Backward-data = the same kernel on the transposed packing.
+// ASPP's rates (12 / 24 / 36) would need patches of 28 .. 76 rows for 4 output rows and stay on MIOpen.
+// ---------------------------------------------------------------------------------------------------------
+template <int DIL>
+struct DilGeom {
+    static constexpr int XROWS_D = TR + 2 * DIL, XCOLS_D = TC + 2 * DIL;
+    static constexpr int CELLS_D = XROWS_D * XCOLS_D;
+    static constexpr int PLANE_D = (CELLS_D + 15) / 16 * 16;
+    static constexpr int A_ITEMS_D = NOCT * CELLS_D;
+    static constexpr int AU_D = (A_ITEMS_D + 511) / 512;
+};
+
+template <class AR, int NT, int DIL>
+__global__ __launch_bounds__(512, 2) void conv3x3_sb16d_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
+                                                               const float* __restrict__ bias, const float* __restrict__ addend, int Cin, int Cout, int H,
+                                                               int W, int tiles_x, int tiles_y, const unsigned* __restrict__ amax_x,
+                                                               const unsigned* __restrict__ amax_w, float* __restrict__ y,
+                                                               float4* __restrict__ stats, int n_seg, int xmap) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_s16d[];
+    typedef DilGeom<DIL> G;
+    constexpr int NP = AR::NP;
+    constexpr int A_CELLS = NP * NOCT * G::PLANE_D;
+    uint4* As = smem_s16d;                         // [piece NP][octet 2][PLANE_D]
+    uint4* Bs = smem_s16d + A_CELLS;               // [2][NT*NP*64]
+    constexpr int BSTEP = NT * NP * 64;
+    const unsigned ex = AR::SCALED ? split_amax_exp(amax_x) : 141u, ew = AR::SCALED ? split_amax_exp(amax_w) : 141u;
+    const float xscale = split_scale_of(ex);
+    constexpr int NT0 = (NT + 1) / 2, NT1 = NT - NT0;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row = wave & 3, half = wave >> 2;
+    const int g = lane >> 4, n = lane & 15;
+    const int n_cot = Cout / (NT * 16);
+    const size_t plane = (size_t)H * W;
+    int t = cseg_xcd_block(blockIdx.x, gridDim.x, xmap);
+    const bool cot_first = xmap && (gridDim.x & 7) == 0;
+    int cot = 0;
+    if (cot_first) { cot = t % n_cot; t /= n_cot; }
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    if (!cot_first) { cot = t % n_cot; t /= n_cot; }
+    const int b = t;
+    const int x0 = tx * TC, y0 = ty * TR;
+    const int n_chunks = Cin / 16;
+    const int n_steps = n_chunks * STEPS;
+    const uint4* wbase = wp + (size_t)cot * n_steps * BSTEP;
+
+    auto b_glds = [&](int ks, int buf) {
+#pragma unroll
+        for (int i = 0; i < (NT * NP + 7) / 8; ++i) {
+            const int r = wave + 8 * i;
+            if (r < NT * NP)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(wbase + (size_t)ks * BSTEP + r * 64 + lane),
+                    (__attribute__((address_space(3))) void*)(Bs + buf * BSTEP + r * 64), 16, 0, 0);
+        }
+    };
+    float apre[G::AU_D][8];
+    auto a_item = [&](int u, int& oct, int& rc, bool& ok) {
+        const int item = tid + 512 * u;
+        oct = item / G::CELLS_D; rc = item - oct * G::CELLS_D;
+        const int r = rc / G::XCOLS_D, col = rc - r * G::XCOLS_D;
+        const int yy = y0 + r - DIL, xx = x0 + col - DIL;
+        ok = oct < NOCT && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    };
+    auto a_issue = [&](int chunk) {
+        const float* xc = x + ((size_t)b * Cin + (size_t)chunk * 16) * plane;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xc, 0, (int)(16 * plane * sizeof(float)),
+                                                                            0x00020000);
+#pragma unroll
+        for (int u = 0; u < G::AU_D; ++u) {
+            int oct, rc;
+            bool ok;
+            a_item(u, oct, rc, ok);
+            const int r = rc / G::XCOLS_D, col = rc - r * G::XCOLS_D;
+            const int octc = min(oct, NOCT - 1), yc = min(max(y0 + r - DIL, 0), H - 1), xcl = min(max(x0 + col - DIL, 0), W - 1);
+            const int off = (octc * 8 * (int)plane + yc * W + xcl) * (int)sizeof(float);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                apre[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                           rs, off, j * (int)plane * (int)sizeof(float), 0));
+        }
+    };
+    auto a_store = [&]() {
+#pragma unroll
+        for (int u = 0; u < G::AU_D; ++u) {
+            int oct, rc;
+            bool ok;
+            a_item(u, oct, rc, ok);
+            if (oct < NOCT) {
+                uint4 cells[NP];
+                split_cells8_masked<AR>(apre[u], ok, xscale, cells);            // zero padding / outside the tensor
+                const int item = oct * G::PLANE_D + rc;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) As[p * NOCT * G::PLANE_D + item] = cells[p];
+            }
+        }
+    };
+    // one K-step of a wave on the dilated image (sb16_kstep with this geometry's plane pitch)
+    auto kstep = [&](const uint4* ap, const uint4* bp, f32x4 (&acc)[4][NT0], int ntw) {
+        typedef typename AR::frag_t frag_t;
+        frag_t a[4][NP];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) a[mt][p] = __builtin_bit_cast(frag_t, ap[p * NOCT * G::PLANE_D + 16 * mt]);
+#pragma unroll
+        for (int nt = 0; nt < NT0; ++nt) {
+            if (nt < ntw) {
+                frag_t bfr[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) bfr[p] = __builtin_bit_cast(frag_t, bp[(nt * NP + p) * 64]);
+#pragma unroll
+                for (int tt = 0; tt < AR::NTERMS; ++tt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = AR::mfma(a[mt][AR::ta(tt)], bfr[AR::tb(tt)], acc[mt][nt]);
+            }
+        }
+    };
+
+    f32x4 acc[4][NT0];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT0; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    a_issue(0);
+    b_glds(0, 0);
+    a_store();
+    __syncthreads();
+
+    const uint4* a_lane = As + row * G::XCOLS_D + n;
+    const uint4* b_lane = Bs + (half ? NT0 * NP * 64 : 0) + lane;
+    int ks = 0, buf = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+#pragma unroll 1
+        for (int s_ = 0; s_ < STEPS; ++s_) {
+            const bool more = ks + 1 < n_steps;
+            if (more) b_glds(ks + 1, buf ^ 1);
+            if (s_ == STEPS - 3 && c + 1 < n_chunks) a_issue(c + 1);
+            const int tap = min(2 * s_ + (g >> 1), 8);                 // the tenth tap slot multiplies zero weights
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int a_off = (g & 1) * G::PLANE_D + ky * DIL * G::XCOLS_D + kx * DIL;
+            kstep(a_lane + a_off, b_lane + buf * BSTEP, acc, half == 0 ? NT0 : NT1);
+            if (s_ == STEPS - 1 && c + 1 < n_chunks) {
+                __syncthreads();                    // every wave is done with this chunk's patch
+                a_store();
+            }
+            __syncthreads();
+            buf ^= 1;
+            ++ks;
+        }
+    }
+
+    const int yy = y0 + row;
+    if (yy < H) {
+        float* ybc = y + (size_t)b * Cout * plane;
+        const int co0 = cot * NT * 16;
+        const float unscale = split_unscale_of(ex) * split_unscale_of(ew);
+        const float* abc = addend ? addend + (size_t)b * Cout * plane : nullptr;
+        if (half == 0) sb16_store<NT0, NT0>(acc, ybc, bias, abc, co0, plane, yy, x0, W, g, n, unscale);
+        else if (NT1 > 0) sb16_store<NT1, NT0>(acc, ybc, bias, abc, co0 + NT0 * 16, plane, yy, x0, W, g, n, unscale);
+        if (stats) {
+            const size_t seg = ((size_t)b * H + yy) * tiles_x + tx;
+            if (half == 0) cseg_stats_emit<NT0, NT0>(acc, bias, co0, unscale, x0, W, g, n, stats + (size_t)co0 * n_seg + seg, n_seg);
+            else if (NT1 > 0)
+                cseg_stats_emit<NT1, NT0>(acc, bias, co0 + NT0 * 16, unscale, x0, W, g, n, stats + (size_t)(co0 + NT0 * 16) * n_seg + seg, n_seg);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Round 3: persistent form for the small-channel convolutions. The kernel above is LATENCY-bound on the branches (48 channels at
 // 8x128x256: 52 us against 9 us of MFMA time and 20 us of HBM time): every one of its 15 K-steps ends in a barrier that waits for
 // the LDS-DMA of the next step's weights, issued only one short step (~0.25 us of MFMAs) earlier, and a block lives for one
@@ -1034,6 +1210,46 @@ int fwd(const float* x, const void* wp, const float* bias, const float* addend, 
     if (NT == 6) return launch_sb16<SplitBF16x6, 6>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
     if (NT == 4) return launch_sb16<SplitBF16x6, 4>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
     return launch_sb16<SplitBF16x6, 3>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
+}
+
+// dilated form (conv3x3_sb16d_kernel): f16x3, dilation 2 or 4
+template <int NT, int DIL>
+int launch_sb16d(const float* x, const uint4* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W,
+                 const unsigned* amax_x, const unsigned* amax_w, float* y, float4* stats, hipStream_t stream) {
+    typedef DilGeom<DIL> G;
+    const size_t lds = sizeof(uint4) * (2 * NOCT * G::PLANE_D + 2 * NT * 2 * 64);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv3x3_sb16d_kernel<SplitF16x3, NT, DIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            cseg_set_error("conv3x3_sb16d: cannot raise dynamic LDS to %zu bytes", lds);
+            return 0;
+        }
+        attr_set = true;
+    }
+    const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
+    const long n_tiles = (long)B * (Cout / (NT * 16)) * tiles_y * tiles_x;
+    CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb16d: grid too large");
+    hipLaunchKernelGGL((conv3x3_sb16d_kernel<SplitF16x3, NT, DIL>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, addend, Cin,
+                       Cout, H, W, tiles_x, tiles_y, amax_x, amax_w, y, stats, B * H * tiles_x, cseg_xcd_remap());
+    CSEG_CHECK_LAUNCH("conv3x3_sb16d_kernel");
+    return 1;
+}
+
+int fwd_dil(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W, int NT, int dil,
+            int arith, const unsigned* amax_x, const unsigned* amax_w, float* y, float4* stats, hipStream_t stream) {
+    CSEG_REQUIRE(arith == CSEG_ARITH_F16X3 && amax_x && amax_w, "conv3x3 dilated: f16x3 only (needs max|x| and max|w|)");
+    CSEG_REQUIRE((dil == 2 || dil == 4) && (NT == 3 || NT == 4 || NT == 6) && Cout % (NT * 16) == 0 && Cin % 16 == 0 &&
+                     (long)H * W * 16 * 4 < 2147483647L,
+                 "conv3x3 dilated: unsupported dilation %d / shape Cin=%d Cout=%d %dx%d with %d channel tiles per block", dil, Cin, Cout, H, W, NT);
+    const uint4* wq = (const uint4*)wp;
+#define SB16D(N)                                                                                                                     \
+    return dil == 2 ? launch_sb16d<N, 2>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream)                  \
+                    : launch_sb16d<N, 4>(x, wq, bias, addend, B, Cin, Cout, H, W, amax_x, amax_w, y, stats, stream);
+    if (NT == 6) { SB16D(6) }
+    if (NT == 4) { SB16D(4) }
+    SB16D(3)
+#undef SB16D
 }
 
 // the 8-row head kernel (namespace sb8 above): f16x3, 9 channel tiles per block, weights packed by pack(..., NT = 9, ...)

@@ -1590,6 +1590,70 @@ def basic_block_split(x, blk):
                                  blk.bn1, blk.bn2, blk.conv1.bn_follows, blk.conv2.bn_follows)
 
 
+# ----------------------------------------------------------------------------------------------------------
+# Dilated 3x3 convolutions (round 5, csrc/conv3x3_sb16.hip: conv3x3_sb16d_kernel): rate 2 / 4, padding = rate, stride 1 -- layer3 / layer4
+# of the dilated ResNet encoders of DeepLab-V3 (reference lib/models/backbones/resnet/resnet_backbone.py:88-101). Forward and
+# backward-data on the split kernel (f16x3), weight / bias gradients on MIOpen.
+# ----------------------------------------------------------------------------------------------------------
+CONV3X3_DIL_SPLIT = os.environ.get("CSEG_CONV3X3_DIL_SPLIT", "1") == "1"
+
+
+def conv3x3_dil_eligible(x, weight, dilation):
+    """NCHW fp32 on the GPU, 3x3, rate 2 or 4, channel counts that are packed in the 16-channel-chunk form both ways (multiples of 64
+    that are not multiples of 48: 64, 128, 256, 512, 1024, ...), f16x3 arithmetic."""
+    if not (CONV3X3_DIL_SPLIT and CONV3X3_SPLIT_BF16 and SPLIT_ARITH == "f16x3" and _on_device(x) and x.dtype == F32 and weight.dtype == F32
+            and x.dim() == 4 and x.is_contiguous()):
+        return False
+    co, ci, kh, kw = weight.shape
+    ok = lambda c: c % 64 == 0 and c % 48 != 0
+    return (kh, kw) == (3, 3) and tuple(dilation) in ((2, 2), (4, 4)) and ok(ci) and ok(co) and x.shape[1] == ci
+
+
+def conv3x3_dil_run(x, weight, dil, transpose_flip=False, bias=None, ax=None, addend=None, want_stats=False):
+    """y = conv2d(x, weight, bias, stride 1, padding dil, dilation dil) (transpose_flip: the backward-data operator applied to x)."""
+    co, ci = weight.shape[:2]
+    conv_in, conv_out = (co, ci) if transpose_flip else (ci, co)
+    B, _, H, W = x.shape
+    wp, aw = SPLIT_WEIGHTS.get(weight, "c3", transpose_flip, 0)
+    if ax is None:
+        ax = tensor_amax(x)
+    y = torch.empty(B, conv_out, H, W, dtype=F32, device=x.device)
+    st = tile_stats_buffer(0, conv_out, B, H, W, x.device) if (want_stats and CONV_EPILOGUE_STATS and addend is None) else None
+    _hip.call("cseg_conv3x3_split_dil_fwd", _pq(x, "x"), wp.data_ptr(), _opt(bias, F32, "bias"),
+              _p(addend, F32, "addend") if addend is not None else _null(), B, conv_in, conv_out, H, W, int(dil), split_arith_id(),
+              _pf(ax), _pf(aw), _pf(y), _pf(st) if st is not None else _null(), _hip.stream_ptr())
+    return tile_stats_attach(y, st) if st is not None else y
+
+
+class Conv3x3DilSplit(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, dil, want_stats=False):
+        weight = weight.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias, ctx.dil = bias is not None, int(dil)
+        ctx.ax = amax_of(x)
+        return conv3x3_dil_run(x, weight, dil, False, bias, ax=ctx.ax, want_stats=want_stats)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        d = ctx.dil
+        ady = amax_of(dy)
+        dy = dy.contiguous()
+        dx = conv3x3_dil_run(dy, weight, d, True, None, ax=ady) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_db:
+            _, dw, db = torch.ops.aten.convolution_backward(
+                dy, x, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [d, d], [d, d], False, [0, 0], 1,
+                [False, bool(ctx.needs_input_grad[1]), bool(want_db)])
+        return dx, dw, db, None, None
+
+
+def conv3x3_dil_split(x, weight, bias, dil, want_stats=False):
+    return Conv3x3DilSplit.apply(x, weight, bias, dil, want_stats)
+
+
 def conv3x3_split_fork(x, weight, want_stats=False):
     return Conv3x3SplitFork.apply(x, weight, want_stats)
 

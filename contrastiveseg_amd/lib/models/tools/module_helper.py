@@ -121,6 +121,12 @@ class SplitConv2d(nn.Conv2d):
             elif (K.CONV3X3_SPLIT_BF16 and K.conv3x3_sb_eligible(x, self.weight)
                     and K.conv3x3_sb_tiles(x, self.out_channels) >= K.CONV3X3_SB_MIN_TILES):
                 return K.conv3x3_split_bf16(x, self.weight, self.bias, self.bn_follows)
+        elif (K._on_device(x) and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.dilation in ((2, 2), (4, 4))
+                and self.padding == self.dilation and self.groups == 1 and self.padding_mode == 'zeros' and x.dim() == 4
+                and K.conv3x3_dil_eligible(x, self.weight, self.dilation)
+                and K.conv3x3_sb_tiles(x, self.out_channels) >= K.CONV3X3_SB_MIN_TILES):
+            # layer3 / layer4 of the dilated ResNets (rate 2 / 4): conv3x3_sb16d_kernel
+            return K.conv3x3_dil_split(x, self.weight, self.bias, self.dilation[0], self.bn_follows)
         return super(SplitConv2d, self).forward(x)
 
 

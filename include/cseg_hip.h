@@ -376,6 +376,14 @@ int cseg_conv3x3_split_fwd(const float* x, const void* wp, const float* bias, in
 int cseg_conv3x3_split_fwd_add(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin, int Cout,
                                int H, int W, int nt, int arith, const unsigned* amax_x, const unsigned* amax_w, float* y,
                                cseg_stream_t stream);
+/* Round 5 (ABI 5): the same operator with a dilation of 2 or 4 (padding = dilation): the 3x3 convolutions of the dilated ResNet
+ * stages of DeepLab-V3-R101-d8 (reference lib/models/backbones/resnet/resnet_backbone.py:88-101; layer3 rate 2, layer4 rate 4).
+ * f16x3 only; Cout must be packed in the 16-channel-chunk form (multiples of 64 that are not multiples of 48, or 48 / 192: what
+ * cseg_conv3x3_split_plan reports as kind 1); wp = the packed weights of cseg_conv3x3_split_pack (nt 0) for the same (Cout, Cin) --
+ * transposed packing for backward-data. addend / stats nullable, not both. Any width. */
+int cseg_conv3x3_split_dil_fwd(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H,
+                               int W, int dil, int arith, const unsigned* amax_x, const unsigned* amax_w, float* y, float* stats,
+                               cseg_stream_t stream);
 /* ws: cseg_conv3x3_sb_wrw_ws_floats(...) */
 int cseg_conv3x3_split_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, int arith,
                            const unsigned* amax_x, const unsigned* amax_dy, float* ws, float* dw, cseg_stream_t stream);

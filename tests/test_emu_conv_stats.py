@@ -424,3 +424,44 @@ def test_weight_gradient_on_ragged_widths(case, monkeypatch):
     assert not torch.isnan(got).any()
     assert float((got.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), float((got.double() - ref).abs().max()) / float(ref.abs().max())
     assert torch.equal(got, K.conv3x3_sb_wrw(x, dy))
+
+
+@pytest.mark.parametrize("case", [(1, 64, 64, 7, 65, 2, False), (2, 128, 64, 9, 33, 4, True), (1, 64, 128, 5, 130, 2, True), (1, 256, 256, 6, 20, 4, False)])
+def test_dilated_convolution_matches_fp64(case, monkeypatch):
+    """cseg_conv3x3_split_dil_fwd (round 5): rate 2 / 4, padding = rate, at ragged widths -- forward (with bias and the statistics
+    epilogue), backward-data with an epilogue addend, and the autograd wrapper against torch in float64."""
+    from contrastiveseg_amd import kernels as K
+    inject.install(monkeypatch)
+    monkeypatch.setattr(K, "SPLIT_ARITH", "f16x3")
+    monkeypatch.setattr(K, "SPLIT_WEIGHTS", K.SplitWeights())
+    monkeypatch.setattr(K, "CONV_EPILOGUE_STATS", True)
+    B, ci, co, H, W, d, bias = case
+    g = torch.Generator().manual_seed(31 + W + d)
+    x = torch.randn(B, ci, H, W, generator=g) + 0.2
+    w = torch.randn(co, ci, 3, 3, generator=g) / (9 * ci) ** 0.5
+    b = torch.randn(co, generator=g) * 0.5 if bias else None
+    assert K.conv3x3_dil_eligible(x, w, (d, d))
+    y = K.conv3x3_dil_run(x, w, d, False, b, want_stats=True)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None if b is None else b.double(), 1, d, d)
+    assert not torch.isnan(y).any()
+    assert float((y.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+    st = K.known_tile_stats(y)
+    mi = K.bn_tiles_finalize(st, 1e-5, 0.1, None, None, None)
+    yd = y.double().transpose(0, 1).reshape(co, -1)
+    assert float((mi[:, 0].double() - yd.mean(1)).abs().max()) <= 2e-6 * max(1.0, float(yd.mean(1).abs().max()))
+    gy = torch.randn(B, co, H, W, generator=g)
+    ad = torch.randn(B, ci, H, W, generator=g)
+    dx = K.conv3x3_dil_run(gy, w, d, True, None, addend=ad)
+    dref = torch.nn.functional.conv_transpose2d(gy.double(), w.double(), None, 1, d, 0, 1, d) + ad.double()
+    assert float((dx.double() - dref).abs().max()) <= 3e-5 * float(dref.abs().max())
+    # autograd wrapper: dx on the split kernel, dw / db on the library convolution
+    xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    bg = b.clone().requires_grad_(True) if bias else None
+    K.conv3x3_dil_split(xg, wg, bg, d).backward(gy)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True) if bias else None
+    torch.nn.functional.conv2d(x64, w64, b64, 1, d, d).backward(gy.double())
+    assert float((xg.grad.double() - x64.grad).abs().max()) <= 3e-5 * float(x64.grad.abs().max())
+    assert float((wg.grad.double() - w64.grad).abs().max()) <= 1e-4 * float(w64.grad.abs().max())
+    if bias:
+        assert float((bg.grad.double() - b64.grad).abs().max()) <= 1e-4 * float(b64.grad.abs().max())

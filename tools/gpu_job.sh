@@ -8,7 +8,7 @@
 #   suite[:<expr>]   pytest -m gpu (optionally -k <expr>)
 #   bench[:<args>]   bench.py with extra args (comma-separated, e.g. bench:--steps,20,--warmup,5); default = the short form
 #   ab:<ENV=VAL>     short bench without / with / without / with the environment setting (A/B/A/B on one box)
-#   stats            rocprofv3 --kernel-trace of 6 steady steps -> step_steady_kernel_stats.csv + idle gaps
+#   stats[:<args>]   rocprofv3 --kernel-trace of 6 steady steps (extra bench.py args, comma-separated) -> step_steady_kernel_stats.csv + idle gaps
 #   pmc              rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) -> step_pmc.json
 #   longrun[:<n>]    tools/long_run_arith.py (default 200 steps): default arithmetic vs strict fp32 vs a one-ulp perturbation
 #   probe:<args>     tools/probes/conv_probe with the given arguments (';' separates arguments)
@@ -43,10 +43,10 @@ for step in "$@"; do
       done; done | tee $O/ab.txt ;;
     stats)
       cd /tmp
-      CSEG_BENCH_GUARD=0 timeout 400 rocprofv3 --kernel-trace -d $O/trace -o t --output-format csv -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernels --no-fp32-pass > $O/bench_under_rocprof.json 2> $O/trace.err
+      CSEG_BENCH_GUARD=0 timeout 500 rocprofv3 --kernel-trace -d $O/trace -o t --output-format csv -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernels --no-fp32-pass ${arg//,/ } > $O/bench_under_rocprof.json 2> $O/trace.err
       cd $R
       T=$(find $O/trace -name "*kernel_trace.csv" | head -1)
-      MS=$(tail -1 $O/bench_under_rocprof.json | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"])')
+      MS=$(grep '^{"metric"' $O/bench_under_rocprof.json | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"])')
       echo "under rocprof: $MS ms/step"
       python tools/trace_window_stats.py $T $(python -c "print(5*$MS/1000.0)") > $O/step_steady_kernel_stats.csv 2> $O/window.txt; cat $O/window.txt
       python tools/trace_gaps.py $T $(python -c "print(3*$MS/1000.0)") 30 > $O/step_trace_gaps.txt; head -12 $O/step_trace_gaps.txt | cut -c1-200
@@ -79,7 +79,8 @@ for step in "$@"; do
       st=$(find $O/ctrace -name "*kernel_stats.csv" | head -1)
       [ -n "$st" ] && grep -E "Name|s_gemm|row_pass|mean_kernel|contrast_fused" $st | cut -c1-220 > $O/contrast_fused_kernels.txt; cat $O/contrast_fused_kernels.txt
       rm -rf $O/ctrace ;;
-    host) timeout 200 python tools/host_profile.py 8 > $O/host_profile.txt 2>&1; head -3 $O/host_profile.txt ;;
+    host) a=${arg//,/ }; [ -z "$a" ] && a=8
+      timeout 200 python tools/host_profile.py $a > $O/host_profile_${a// /_}.txt 2>&1; grep "host enqueue" $O/host_profile_${a// /_}.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done

@@ -1,6 +1,7 @@
 """Host-side cost of one train step of the benched configuration: cProfile over 3 steady steps (the GPU runs asynchronously; what
 is measured is Python + launch time on the enqueueing threads), top functions by own time and by cumulative time. Optional arg:
-global batch (default 8; 1 = the per-GPU batch of the 8-GPU strong-scaling point)."""
+global batch (default 8; 1 = the per-GPU batch of the 8-GPU strong-scaling point); second arg `dist1` = inside a one-rank RCCL process group
+with the multi-rank code paths on (what a rank of an N-GPU job pays on the host)."""
 import cProfile
 import io
 import os
@@ -15,9 +16,16 @@ import torch
 import bench
 
 gb = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+dist1 = len(sys.argv) > 2 and sys.argv[2] == "dist1"       # the multi-rank code paths inside a one-rank RCCL process group
 sys.argv = [sys.argv[0]]
 args = bench.parse()
 dev = torch.device("cuda:0")
+if dist1:
+    from contrastiveseg_amd.lib.utils import distributed as D
+    os.environ.update(CSEG_DIST_SINGLE_RANK="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(D.free_port()))
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1)
 tr, cfg, batch = bench.build_trainer(args, 1, dev, gb)
 for _ in range(4):
     tr.train_step(batch)
