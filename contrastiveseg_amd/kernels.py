@@ -1270,7 +1270,14 @@ def conv3x3_sb_run(x, weight, transpose_flip=False, bias=None, nt=0, ax=None, ad
 
 # Forward / backward-data go to the split-bf16 kernel only when its grid fills the chip (4x64-pixel tiles x channel tiles of
 # 144 / 96 / 48); smaller problems stay on MIOpen
-CONV3X3_SB_MIN_TILES = int(os.environ.get("CSEG_SB_MIN_TILES", "256"))     # 1 = route even tiny problems (parity runs)
+# Round 5: the threshold is 1 -- every shape the kernels cover takes them. The old rule (256 blocks, round 2: "one image: 35 vs 25 us on
+# MIOpen") priced GPU time only; below ~4 images per GPU the step is HOST-bound, and a torch.conv2d costs the host ~29 us (forward) and
+# an aten::convolution_backward ~50 us against ~6 us per call into this library, and MIOpen's output carries no BatchNorm statistics
+# (one more pass + launch per site). Measured on the MI355X, ms/step old -> new (profiles/r05_min_tiles.txt): batch 4 62.9 -> 48.9,
+# batch 2 57.1 -> 50.5, batch 1 eager 62.0 -> 45.3 (replayed 47.6 -> 42.9), batch 8 85.5 / 87.5 -> 85.6 / 85.8 (unchanged: its layers
+# were above the threshold anyway); inside a process group (bench.py --dist-single-rank) batch 4 98.7 -> 83.9, batch 2 79.4 -> 71.8,
+# batch 1 79.7 -> 70.2. CSEG_SB_MIN_TILES=256 restores the old routing.
+CONV3X3_SB_MIN_TILES = int(os.environ.get("CSEG_SB_MIN_TILES", "1"))
 
 
 def conv3x3_sb_tiles(x, c_out):
@@ -1786,7 +1793,7 @@ def conv3x3_s2_split(x, weight, want_stats=False):
 # 1x1 convolution on the BF16 matrix cores with split operands (csrc/conv1x1_sb.hip): first hardware run pending -> opt-in
 # ----------------------------------------------------------------------------------------------------------
 CONV1X1_SPLIT_BF16 = os.environ.get("CSEG_CONV1X1_SPLIT_BF16", "1") == "1"
-CONV1X1_SB_MIN_TILES = int(os.environ.get("CSEG_SB_MIN_TILES", "256"))
+CONV1X1_SB_MIN_TILES = int(os.environ.get("CSEG_SB_MIN_TILES", "1"))       # (see CONV3X3_SB_MIN_TILES)
 
 
 def conv1x1_sb_eligible(x, weight):

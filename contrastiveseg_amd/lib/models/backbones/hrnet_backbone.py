@@ -11,7 +11,7 @@ to torch SyncBN with momentum 0.1 exactly as the reference factory does (:773)."
 import torch.nn as nn
 
 from contrastiveseg_amd import kernels as K
-from contrastiveseg_amd.lib.models.tools.fused_bn import bn_act_group
+from contrastiveseg_amd.lib.models.tools.fused_bn import basic_block_group, bn_act_group
 from contrastiveseg_amd.lib.models.tools.module_helper import Conv1x1, Conv3x3, ModuleHelper
 
 # width -> per-stage (modules, blocks per branch); channel list is width * (1, 2, 4, 8)[:branches]
@@ -164,6 +164,7 @@ def _capture_forks(x=None):
 
 
 LOCKSTEP_FORKS = _os.environ.get("CSEG_LOCKSTEP_FORKS", "0") == "1"
+LOCKSTEP_GROUP_NODE = _os.environ.get("CSEG_LOCKSTEP_GROUP_NODE", "1") == "1"      # fused_bn.BasicBlockGroupSync (round 5)
 DDP_FORKS_OK = False        # set by ModuleRunner._make_parallel once the DDP wrapper joins the fork streams before its collectives
 
 
@@ -251,6 +252,11 @@ class HighResolutionModule(nn.Module):
         par = _ParallelConvs(x[0], len(self.branches)) if (LOCKSTEP_FORKS and _capture_forks(x[0]) and not _capturing()) else None
         for k in range(len(self.branches[0])):
             blocks = [branch[k] for branch in self.branches]
+            if par is None and LOCKSTEP_GROUP_NODE:
+                grouped = basic_block_group(blocks, x)        # the whole depth as ONE autograd node where every block qualifies
+                if grouped is not None:
+                    x = grouped
+                    continue
             if par is None:
                 c1 = [blk.conv1(xi) for blk, xi in zip(blocks, x)]
             else:

@@ -28,7 +28,14 @@ class ASPPModule(nn.Module):
 
     def forward(self, x):
         h, w = x.shape[2:]
-        pooled = F.interpolate(self.b4(x), size=(h, w), mode='bilinear', align_corners=True)
+        pooled = self.b4(x)
+        if pooled.shape[2:] == (1, 1):
+            # bilinear upsampling (align_corners=True) of a 1 x 1 map is the constant map, bit for bit; as a broadcast its backward is
+            # a sum over the plane instead of upsample_bilinear2d_backward's scatter (12.4 ms per step at 8 x 512 x 65 x 129,
+            # profiles/r05_cfg4_step_steady_kernel_stats.csv). Reference: lib/models/modules/decoder_block.py:74-77.
+            pooled = pooled.expand(-1, -1, h, w)
+        else:
+            pooled = F.interpolate(pooled, size=(h, w), mode='bilinear', align_corners=True)
         return self.project(torch.cat((self.b0(x), self.b1(x), self.b2(x), self.b3(x), pooled), dim=1))
 
 

@@ -181,6 +181,132 @@ class _BNActGroup(torch.autograd.Function):
         return tuple(grads)
 
 
+# ----------------------------------------------------------------------------------------------------------
+# Round 5: the residual blocks of ONE depth of HRNet's parallel branches under SyncBN as ONE autograd node.
+# Reference shape of the work: BasicBlock.forward (lib/models/backbones/hrnet/hrnet_backbone.py:49-65) of n = 2..4 branches that have
+# no data dependence on each other; nn.SyncBatchNorm would issue 2 n collectives per direction here, _BNActGroup issues 2, and the
+# lockstep form of HighResolutionModule used to build them from 2 n convolution nodes + 2 grouped-BN nodes. The multi-rank path is
+# HOST-bound below ~4 images per GPU (profiles/r05_dist_single_rank.txt), so the nodes are what costs: this Function issues exactly the
+# same library calls and collectives in the same order (bit-identical results, tests/test_distributed_gloo.py) behind one apply().
+# ----------------------------------------------------------------------------------------------------------
+def _group_exchange_forward(xs, bns, residuals, relu, sync_group):
+    """Grouped SyncBN(+residual)+ReLU over independent sites (the body of _BNActGroup.forward) -> (outs, mean_invstd per site, max|y|
+    records). ONE all-reduce of the concatenated [C_i + 1, 2] fp64 moments."""
+    moments = []
+    for x in xs:
+        tiles = K.known_tile_stats(x)
+        moments.append(K.bn_tiles_moments(tiles) if tiles is not None else K.bn_stats(x))
+    packed = _all_reduce(torch.cat(moments, dim=0), sync_group)
+    outs, mis, ams = [], [], []
+    off = 0
+    for x, bn, r in zip(xs, bns, residuals):
+        C = x.shape[1]
+        mi = K.bn_finalize(packed[off:off + C + 1], SYNC_COUNT, float(bn.eps), float(bn.momentum), bn.running_mean, bn.running_var,
+                           bn.num_batches_tracked)
+        off += C + 1
+        amax = K.amax_request(x)
+        outs.append(K.bn_apply(x, mi, bn.weight, bn.bias, r, relu, amax=amax))
+        mis.append(mi)
+        ams.append(amax)
+    return outs, mis, ams
+
+
+def _group_exchange_backward(dys, xs, outs, mis, bns, mode, sync_group):
+    """Adjoint of _group_exchange_forward -> per site (dx, d_weight, d_bias, masked gradient or None, max|dx| record). ONE all-reduce of
+    the concatenated gradient sums. mode: 1 = ReLU mask from x, 2 = from `out` (residual sites; the masked gradient is also the
+    residual's)."""
+    red = []
+    for dy, x, out, mi, bn in zip(dys, xs, outs, mis, bns):
+        red.append(K.bn_bwd_reduce(dy, x, out if mode == 2 else None, mi, bn.weight, bn.bias, mode))
+    packed = _all_reduce(torch.cat([r[0] for r in red], dim=0), sync_group)
+    res = []
+    off = 0
+    for dy, x, mi, bn, (_, d_w, d_b, g) in zip(dys, xs, mis, bns, red):
+        C = x.shape[1]
+        amax = K.amax_request(x)
+        dx = K.bn_bwd_apply(g if mode == 2 else dy, x, mi, bn.weight, bn.bias, packed[off:off + C + 1], SYNC_COUNT, mode == 1, amax=amax)
+        off += C + 1
+        res.append((dx, d_w, d_b, g, amax))
+    return res
+
+
+class BasicBlockGroupSync(torch.autograd.Function):
+    """n residual blocks (conv3x3 -> SyncBN -> ReLU -> conv3x3 -> SyncBN -> + x -> ReLU) of one depth, statistics exchanged together.
+    tensors: per block x, w1, g1, b1, w2, g2, b2."""
+
+    @staticmethod
+    def forward(ctx, blocks, sync_group, *tensors):
+        n = len(blocks)
+        xs = [tensors[7 * i].contiguous() for i in range(n)]
+        nts, axs, c1s = [], [], []
+        for blk, x in zip(blocks, xs):
+            c = blk.conv1.weight.shape[0]
+            nt = K.conv3x3_sb_pick_nt(x, c) if c in K.CONV3X3_SB_PICK_NT_CHANNELS else 0
+            ax = K.amax_of(x)
+            nts.append(nt)
+            axs.append(ax)
+            c1s.append(K.conv3x3_sb_run(x, blk.conv1.weight, False, None, nt, ax=ax, want_stats=True))
+        a1s, mi1, am1 = _group_exchange_forward(c1s, [b.bn1 for b in blocks], [None] * n, True, sync_group)
+        c2s = [K.conv3x3_sb_run(a1, blk.conv2.weight, False, None, nt, ax=am, want_stats=True)
+               for a1, blk, nt, am in zip(a1s, blocks, nts, am1)]
+        outs, mi2, am2 = _group_exchange_forward(c2s, [b.bn2 for b in blocks], xs, True, sync_group)
+        for o, am in zip(outs, am2):
+            K.amax_attach(o, am)
+        ctx.blocks, ctx.sync_group, ctx.nts, ctx.axs, ctx.am1 = blocks, sync_group, nts, axs, am1
+        ctx.save_for_backward(*(xs + c1s + a1s + c2s + outs + mi1 + mi2))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        blocks, sync_group, nts, axs, am1 = ctx.blocks, ctx.sync_group, ctx.nts, ctx.axs, ctx.am1
+        n = len(blocks)
+        sv = ctx.saved_tensors
+        xs, c1s, a1s, c2s, outs, mi1, mi2 = (list(sv[k * n:(k + 1) * n]) for k in range(7))
+        dys = [d.contiguous() for d in dys]
+        r2 = _group_exchange_backward(dys, c2s, outs, mi2, [b.bn2 for b in blocks], 2, sync_group)
+        da1s, dw2s = [], []
+        for i, blk in enumerate(blocks):
+            dc2, _, _, _, am = r2[i]
+            da1s.append(K.conv3x3_sb_run(dc2, blk.conv2.weight, True, None, nts[i], ax=am))
+            dw2s.append(K.conv3x3_sb_wrw(a1s[i], dc2, ax=am1[i], ady=am) if ctx.needs_input_grad[2 + 7 * i + 4] else None)
+        r1 = _group_exchange_backward(da1s, c1s, [None] * n, mi1, [b.bn1 for b in blocks], 1, sync_group)
+        grads = [None, None]
+        for i, blk in enumerate(blocks):
+            dc1, dg1, db1, _, amb = r1[i]
+            _, dg2, db2, g, _ = r2[i]
+            dx = K.conv3x3_sb_run(dc1, blk.conv1.weight, True, None, nts[i], ax=amb, addend=g) if ctx.needs_input_grad[2 + 7 * i] else None
+            dw1 = K.conv3x3_sb_wrw(xs[i], dc1, ax=axs[i], ady=amb) if ctx.needs_input_grad[2 + 7 * i + 1] else None
+            grads += [dx, dw1, dg1 if blk.bn1.weight is not None else None, db1 if blk.bn1.bias is not None else None, dw2s[i],
+                      dg2 if blk.bn2.weight is not None else None, db2 if blk.bn2.bias is not None else None]
+        return tuple(grads)
+
+
+def basic_block_group(blocks, xs):
+    """The blocks of one depth of parallel branches on inputs xs -> outputs, as ONE node where every block qualifies (split kernels in
+    all three directions, SyncBN in training mode with one shared group, no downsample), else None (the caller takes the per-op path)."""
+    if len(blocks) < 2 or not getattr(K, "BLOCK_FUSED", False) or not hasattr(K, "basic_block_split_ok"):
+        return None
+    group = None
+    for blk, x in zip(blocks, xs):
+        if blk.downsample is not None or blk.stride != 1 or not blk.training:
+            return None
+        for bn in (blk.bn1, blk.bn2):
+            if not (isinstance(bn, FusedSyncBatchNorm) and bn.training and bn.track_running_stats and bn.momentum is not None
+                    and bn.weight is not None):
+                return None
+            g = bn._sync_group()
+            if g is None or (group is not None and g is not group):
+                return None
+            group = g
+        if not (blk.conv1.bn_follows and blk.conv2.bn_follows and K.CONV_EPILOGUE_STATS and K.split_arith_id()
+                and K.basic_block_split_ok(x, blk.conv1.weight, blk.conv2.weight)):
+            return None
+    tensors = []
+    for blk, x in zip(blocks, xs):
+        tensors += [x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias]
+    return list(BasicBlockGroupSync.apply(tuple(blocks), group, *tensors))
+
+
 def bn_act_group(sites):
     """sites: list of (bn module, x, residual or None, relu or None). Returns the list of outputs. Sites whose module is
     not in synchronised training mode (single rank, eval) are evaluated one by one through the module itself."""

@@ -675,3 +675,80 @@ def test_trainer_ddp_memory_bank_stays_identical_without_buffer_broadcast():
     # plain BatchNorm under DDP: the 7.0 planted on rank 1 was replaced by rank 0's statistics before the first forward; what is left
     # after the last step is 0.1 x the difference of the two ranks' batch means (without the hook: 0.9^3 x 7 = 5.1)
     assert np.abs(res[0][7] - res[1][7]).max() < 0.5, np.abs(res[0][7] - res[1][7]).max()
+
+
+# ---- round 5: the residual blocks of one depth of parallel branches as ONE autograd node under SyncBN (fused_bn.BasicBlockGroupSync) ----
+def _group_node_worker(rank, world, port, q, group_node):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      CSEG_LOCKSTEP_GROUP_NODE="1" if group_node else "0", CSEG_TEST_DEVICE_HALF="emu")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_device_half()
+    from contrastiveseg_amd import kernels as K
+    from contrastiveseg_amd.lib.models.backbones import hrnet_backbone as HB
+    from contrastiveseg_amd.lib.models.tools import fused_bn
+    from contrastiveseg_amd.lib.models.tools.module_helper import mark_conv_bn_pairs
+    assert HB.LOCKSTEP_GROUP_NODE == group_node and K.CONV3X3_SB_MIN_TILES == 1
+    calls = {"reduce": 0, "group": 0}
+    real = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **k: (calls.__setitem__("reduce", calls["reduce"] + 1), real(t, *a, **k))[1]
+    real_group = HB.basic_block_group
+
+    def counted(blocks, xs):
+        out = real_group(blocks, xs)
+        calls["group"] += out is not None
+        return out
+    HB.basic_block_group = counted
+    torch.manual_seed(304)
+    mod = mark_conv_bn_pairs(HB.HighResolutionModule([48, 96], 2, "torchsyncbn", 0.1).train())
+    g = torch.Generator().manual_seed(5)
+    x0 = (torch.randn(4, 48, 8, 16, generator=g) + 0.1)[rank * 2:rank * 2 + 2].clone().requires_grad_(True)
+    x1 = (torch.randn(4, 96, 4, 8, generator=g) + 0.1)[rank * 2:rank * 2 + 2].clone().requires_grad_(True)
+    outs = mod([x0, x1])
+    n_fwd = calls["reduce"]
+    sum(o.square().mean() for o in outs).backward()
+    grads = {k: p.grad.numpy().copy() for k, p in mod.named_parameters() if k in (
+        "branches.0.0.conv1.weight", "branches.1.1.conv2.weight", "branches.0.1.bn2.weight", "branches.1.0.bn1.bias")}
+    q.put((rank, [o.detach().numpy() for o in outs], x0.grad.numpy(), x1.grad.numpy(), grads, n_fwd, calls["reduce"] - n_fwd,
+           mod.branches[1][1].bn2.running_var.numpy().copy(), calls["group"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_lockstep_depth_as_one_autograd_node_is_bit_identical_to_the_per_op_form():
+    """Two ranks x two images, HighResolutionModule([48, 96]) with FusedSyncBatchNorm on the HIP sources (emulator): the residual
+    blocks of a depth as ONE node (fused_bn.BasicBlockGroupSync: the same library calls and collectives in the same order) against the
+    per-op lockstep form -- outputs, input gradients, parameter gradients and running statistics IDENTICAL, the same number of
+    all-reduces (2 per depth and direction for the branches + the exchange unit's), and both ranks' replicas consistent."""
+    from tests.emu import build_emu
+    if not os.path.exists(build_emu.CLANG):
+        pytest.skip("host clang++ of the ROCm toolchain not found")
+    try:
+        build_emu.build()
+    except build_emu.EmuBuildError as e:
+        pytest.skip(str(e))
+    res = {}
+    for group_node in (False, True):
+        world = 2
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_group_node_worker, args=(r, world, port, q, group_node)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        res[group_node] = out
+    for rank in (0, 1):
+        a, b = res[False][rank], res[True][rank]
+        for u, v in zip(a[1], b[1]):
+            assert np.array_equal(u, v), "outputs differ between the per-op form and the group node"
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]), "input gradients differ"
+        for k in a[4]:
+            assert np.array_equal(a[4][k], b[4][k]), "parameter gradient differs: " + k
+        assert a[5] == b[5] and a[6] == b[6], ("collective counts", a[5:7], b[5:7])
+        assert np.array_equal(a[7], b[7])
+    assert np.array_equal(res[True][0][7], res[True][1][7]), "running statistics differ between the ranks"
+    assert res[False][0][8] == 0 and res[True][0][8] == 2, ("depths taken by the group node", res[False][0][8], res[True][0][8])

@@ -296,3 +296,31 @@ def test_eight_row_tiles_on_hardware(monkeypatch):
     fp32_dx = (F.conv_transpose2d(xd, wd, None, 1, 1) + ad).cpu()
     err, tol = _bound(ref_dx, dx8.cpu(), fp32_dx)
     assert err <= tol, ("backward-data", err, tol)
+
+
+@pytest.mark.parametrize("case", [(1, 64, 64, 7, 65, 2), (2, 256, 256, 9, 129, 2), (1, 512, 512, 6, 129, 4), (2, 128, 64, 5, 36, 4)])
+def test_dilated_convolution_matches_fp64(case):
+    """Round 5: cseg_conv3x3_split_dil_fwd (rate 2 / 4, padding = rate; layer3 / layer4 of DeepLab-V3's dilated ResNet, reference
+    lib/models/backbones/resnet/resnet_backbone.py:88-101) -- forward with bias, backward-data and the autograd wrapper (weight / bias
+    gradient on MIOpen) against float64, MIOpen's fp32 dilated convolution as the yardstick for "fp32 rounding class"."""
+    from contrastiveseg_amd import kernels as K
+    B, ci, co, H, W, d = case
+    g = torch.Generator().manual_seed(41 + W)
+    x = torch.randn(B, ci, H, W, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (3.0 * ci ** 0.5)
+    b = torch.randn(co, generator=g)
+    dy = torch.randn(B, co, H, W, generator=g)
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+    y64 = F.conv2d(x64, w64, b64, 1, d, d)
+    y64.backward(dy.double())
+    xd, wd, bd = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    assert K.conv3x3_dil_eligible(xd, wd, (d, d))
+    y = K.conv3x3_dil_split(xd, wd, bd, d)
+    y.backward(dy.cuda())
+    xr, wr, br = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, 1, d, d)
+    yr.backward(dy.cuda())
+    for name, t64, got, fp32 in (("y", y64.detach(), y.detach(), yr.detach()), ("dx", x64.grad, xd.grad, xr.grad),
+                                 ("dw", w64.grad, wd.grad, wr.grad), ("db", b64.grad, bd.grad, br.grad)):
+        err, tol = _bound(t64, got.cpu(), fp32.cpu())
+        assert err <= tol, (case, name, err, tol)
