@@ -305,7 +305,9 @@ def test_train_steps_on_the_emulated_device_equal_the_torch_restatement(case, mo
     assert abs(losses[1] - ref_losses[1]) <= 5e-2 * max(1.0, abs(ref_losses[1])), (losses, ref_losses)
     # (gradients of these freshly initialised networks differ by ~1e-2 between two fp32 evaluation orders -- the reference
     # against its own fp64 evaluation included; a wrong adjoint moves this by O(1))
-    assert float((w - ref_w).norm() / ref_w.norm()) <= 5e-3
+    # (round 5: every covered convolution of these small encoders runs on the split kernels now -- CSEG_SB_MIN_TILES = 1 -- instead of
+    # torch's fp32 convolution on both sides, so more of the step differs in evaluation order: 6.0e-3 for deeplab_v3_mem, was < 5e-3)
+    assert float((w - ref_w).norm() / ref_w.norm()) <= 1e-2
 
 
 # ---- module-level dispatch of the residual-branch convolutions (module_helper.Conv3x3 / HeadConv3x3) -----------------------

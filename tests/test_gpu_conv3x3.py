@@ -54,7 +54,7 @@ def test_conv3x3_module_dispatch_and_state_dict():
     assert list(m.state_dict()) == ["weight"] and torch.equal(m.weight, ref.weight)
     x = torch.randn(2, 48, 16, 32, device=dev)
     assert float((m(x) - ref(x)).abs().max()) <= 1e-4             # MFMA kernel vs MIOpen
-    x_odd = torch.randn(2, 48, 16, 30, device=dev)                 # W % 4 != 0: MIOpen path, identical module
-    assert torch.equal(m(x_odd), ref(x_odd))
+    x_odd = torch.randn(2, 48, 16, 30, device=dev)                 # W % 4 != 0: since round 5 the split kernel too (element stores)
+    assert float((m(x_odd) - ref(x_odd)).abs().max()) <= 1e-4
     m2 = Conv3x3(48, 48, stride=2).to(dev)                         # strided: MIOpen path
     assert m2(x).shape == (2, 48, 8, 16)
