@@ -860,6 +860,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb16r_kernel(const float* __re
     }
 }
 
+// (Round 5 tried a two-team form of this kernel -- four waves run the K-steps of their tile while the other four store outputs, split
+// the next patch and issue loads, one barrier per phase, weights shared -- bit-identical output, NOT faster: 41.7 / 48.0 us against
+// 40.9 / 44.6 at 8 x 48 x 128 x 256 (profiles/r05_two_team_probe.jsonl). The launch is the memory side's 29-32 us at ~4 TB/s plus
+// ~10 us of launch / prologue / tail; the MFMAs were already hidden. The kernel left the library again: git history)
 template <class AR, bool RES>
 int launch_sb16r(const float* x, const uint4* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int H, int W,
                  const unsigned* amax_x, const unsigned* amax_w, float* y, float4* stats, size_t lds, hipStream_t stream) {
