@@ -420,7 +420,8 @@ def test_host_tiling_heuristics():
     assert K.conv3x3_sb_pick_nt(meta(1, 384, 16, 32), 384) == 3          # never fills the chip: smallest tiling
     # grid sizes used for the "does it fill the chip" gate
     assert K.conv3x3_sb_tiles(meta(8, 720, 128, 256), 720) == 8 * 5 * 32 * 4
-    assert K.conv3x3_sb_tiles(meta(2, 48, 16, 32), 48) == 2 * 1 * 4 * 1 < K.CONV3X3_SB_MIN_TILES
+    assert K.conv3x3_sb_tiles(meta(2, 48, 16, 32), 48) == 2 * 1 * 4 * 1
+    assert K.CONV3X3_SB_MIN_TILES == K.CONV1X1_SB_MIN_TILES == 1          # round 5: every covered shape takes the split kernels (host-bound below ~4 images)
     assert K.conv1x1_sb_tiles(meta(8, 720, 128, 256), 256) == 8 * 2 * 128
     assert K.conv1x1_sb_tiles(meta(8, 720, 128, 256), 720) == 8 * 5 * 128
     # defaults (round 3): every split kernel that won its hardware timing in the round-2 driver pass is on
