@@ -296,18 +296,26 @@ def test_train_steps_on_the_emulated_device_equal_the_torch_restatement(case, mo
     same first loss and same weights after the first update (a slice of every 8th tensor); the second loss within the
     sensitivity of the freshly initialised network."""
     from oracle import cpu_port
+    from contrastiveseg_amd import kernels as K
+
+    def emulated():
+        inject.install(monkeypatch)
+        # the launch-size threshold of rounds 2-4: the small convolutions of these toy encoders stay on torch on BOTH sides, as they did
+        # when the bound below was set (with the round-5 default of 1 every covered layer runs through the emulator: 12 minutes instead
+        # of 40 s for the two families, and 6.0e-3 instead of < 5e-3 for deeplab_v3_mem -- the split kernels have their own emulator
+        # tests at every route, tests/test_emu_sb_kernels.py / test_emu_conv_stats.py, and the default routing runs in the GPU suite)
+        monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 256)
+        monkeypatch.setattr(K, "CONV1X1_SB_MIN_TILES", 256)
     ref_losses, ref_w = _trainer_losses(case, lambda: cpu_port.install(monkeypatch))
     monkeypatch.undo()
-    losses, w = _trainer_losses(case, lambda: inject.install(monkeypatch))
+    losses, w = _trainer_losses(case, emulated)
     # step 1: the same arithmetic up to summation order. Step 2 sees that difference through a freshly initialised network
     # whose backward amplifies perturbations (DESIGN.md section 2; the step goldens bound it at 5 % too)
     assert abs(losses[0] - ref_losses[0]) <= 1e-5 * max(1.0, abs(ref_losses[0])), (losses, ref_losses)
     assert abs(losses[1] - ref_losses[1]) <= 5e-2 * max(1.0, abs(ref_losses[1])), (losses, ref_losses)
     # (gradients of these freshly initialised networks differ by ~1e-2 between two fp32 evaluation orders -- the reference
     # against its own fp64 evaluation included; a wrong adjoint moves this by O(1))
-    # (round 5: every covered convolution of these small encoders runs on the split kernels now -- CSEG_SB_MIN_TILES = 1 -- instead of
-    # torch's fp32 convolution on both sides, so more of the step differs in evaluation order: 6.0e-3 for deeplab_v3_mem, was < 5e-3)
-    assert float((w - ref_w).norm() / ref_w.norm()) <= 1e-2
+    assert float((w - ref_w).norm() / ref_w.norm()) <= 5e-3
 
 
 # ---- module-level dispatch of the residual-branch convolutions (module_helper.Conv3x3 / HeadConv3x3) -----------------------
