@@ -406,9 +406,9 @@ extern "C" int cseg_conv3x3_fwd(const float* x, const float* wp, int B, int Cin,
     const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
     const long n_tiles = (long)B * (Cout / CO_T) * tiles_y * tiles_x;
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3: grid too large");
-    // persistent blocks: at most `tpb` tiles each (CSEG_CONV3X3_TPB, default 2), never fewer than 512 blocks
-    static const int tpb = getenv("CSEG_CONV3X3_TPB") ? atoi(getenv("CSEG_CONV3X3_TPB")) : 2;
-    long blocks = (n_tiles + (tpb > 0 ? tpb : 1) - 1) / (tpb > 0 ? tpb : 1);
+    // persistent blocks: at most two tiles each, never fewer than 512 blocks
+    constexpr int tpb = 2;
+    long blocks = (n_tiles + tpb - 1) / tpb;
     if (blocks < 512) blocks = n_tiles < 512 ? n_tiles : 512;
     hipLaunchKernelGGL(conv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, wp, Cin, Cout, H, W, tiles_x,
                        tiles_y, (int)n_tiles, y);

@@ -435,11 +435,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_kernel(const float* __restr
 
 // channel tiles per block: the largest of {9, 6, 3} x 16 that divides Cout
 int pick_nt(int Cout) {
-    const char* e = getenv("CSEG_CONV3X3_SB_NT");          // tuning override (must divide Cout / 16)
-    if (e) {
-        const int nt = atoi(e);
-        if ((nt == 3 || nt == 6 || nt == 9) && Cout % (nt * 16) == 0) return nt;
-    }
     if (Cout % 144 == 0) return 9;
     if (Cout % 96 == 0) return 6;
     if (Cout % 48 == 0) return 3;
