@@ -87,6 +87,7 @@ SIGNATURES = {
     "cseg_conv1x1_split_wrw": (_c_int, [_ptr, _ptr] + [_c_int] * 5 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_conv3x3_split_plan": (_c_int, [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "cseg_conv1x1_split_plan": (_c_int, [_c_int, _c_int, _ptr, _ptr]),
+    "cseg_conv1x1_split_plan_arith": (_c_int, [_c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_long)]),
     "cseg_amax_batch": (_c_int, [_ptr, _c_int, _c_int, _ptr]),
     "cseg_split_pack_batch": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr]),
     "cseg_augment_batch": (_c_int, [_ptr, _ptr, _ptr, _ptr] + [_c_int] * 5 + [_c_float, _ptr, _ptr, _ptr, _ptr, _ptr]),

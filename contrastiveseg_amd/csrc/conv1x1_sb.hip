@@ -197,8 +197,20 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_kernel(const float* __restr
     }
 }
 
-// channel tiles per block: the largest of {9, 8, 6, 4, 3} x 16 that divides Cout
-int pick_nt1(int Cout) {
+// channel tiles per block: the largest of {9, 8, 6, 4, 3} x 16 that divides Cout. Round 5, f16x3 only (two pieces: the LDS holds
+// 2 x 32 KB of patch + 2 x 32 KB of weights): 16 tiles for multiples of 256 from 512 on, 15 for multiples of 240 (the 720-channel
+// projection head) -- a block of 144 / 128 output channels re-reads every 32-channel slab of the input for 64 flop per byte, below
+// what a CU can stream (the kernel ran at 0.19-0.29 of its roof, load-bound); 240 / 256 channels per block nearly double that.
+// Not for exactly 256 output channels: one channel tile group leaves grids of ~264 blocks (DeepLab's 65 x 129 maps at batch 8)
+// with a nearly empty second round. Measured (profiles/r05_conv1x1_wide_tiling.txt): 720 -> 720 at 8 x 128 x 256 1014 -> 869 us,
+// 512 -> 512 at 8 x 65 x 129 228 -> 216 us. CSEG_CONV1X1_WIDE=0 restores the narrow tiling; read ONCE per process, because the
+// packed weights carry the tiling and a pack made under one setting must never meet a forward made under the other.
+int pick_nt1(int Cout, int arith) {
+    static const bool wide = [] { const char* e = getenv("CSEG_CONV1X1_WIDE"); return !(e && atoi(e) == 0); }();
+    if (arith == CSEG_ARITH_F16X3 && wide) {
+        if (Cout % 256 == 0 && Cout >= 512) return 16;
+        if (Cout % 240 == 0) return 15;
+    }
     const int opts[] = {9, 8, 6, 4, 3};
     for (int nt : opts)
         if (Cout % (nt * 16) == 0) return nt;
@@ -231,6 +243,8 @@ template <class AR>
 int fwd_1x1(const float* x, const uint4* wq, const float* bias, int B, int Cin, int Cout, int HW, int NT, const unsigned* amax_x,
             const unsigned* amax_w, float* y, float4* stats, hipStream_t stream) {
     switch (NT) {
+        case 16: if constexpr (AR::NP == 2) return launch_1x1<AR, 16>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
+        case 15: if constexpr (AR::NP == 2) return launch_1x1<AR, 15>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
         case 9: return launch_1x1<AR, 9>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
         case 8: return launch_1x1<AR, 8>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
         case 6: return launch_1x1<AR, 6>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
@@ -244,7 +258,7 @@ int pack_1x1(const float* w, int Cout, int Cin, int transpose, int arith, const 
     CSEG_REQUIRE(w && wp, "conv1x1_sb_pack_weights: null pointer");
     CSEG_REQUIRE(arith == CSEG_ARITH_BF16X6 || (arith == CSEG_ARITH_F16X3 && amax_w), "conv1x1 split pack: arithmetic %d needs max|w|",
                  arith);
-    const int NT = pick_nt1(conv_out);
+    const int NT = pick_nt1(conv_out, arith);
     CSEG_REQUIRE(conv_in % 16 == 0 && NT > 0,
                  "conv1x1_sb: needs input channels %% 16 == 0 and output channels %% 48 == 0 or %% 64 == 0 (got %d -> %d)", conv_in,
                  conv_out);
@@ -267,7 +281,7 @@ int run_1x1(const float* x, const void* wp, const float* bias, int B, int Cin, i
     CSEG_REQUIRE(x && wp && y, "conv1x1_sb: null pointer");
     CSEG_REQUIRE(arith == CSEG_ARITH_BF16X6 || (arith == CSEG_ARITH_F16X3 && amax_x && amax_w),
                  "conv1x1 split: arithmetic %d needs max|x| and max|w|", arith);
-    const int NT = pick_nt1(Cout);
+    const int NT = pick_nt1(Cout, arith);
     CSEG_REQUIRE(B > 0 && HW > 0 && Cin > 0 && Cin % 16 == 0 && NT > 0, "conv1x1_sb: unsupported shape B=%d Cin=%d Cout=%d HW=%d",
                  B, Cin, Cout, HW);
     CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
@@ -279,15 +293,20 @@ int run_1x1(const float* x, const void* wp, const float* bias, int B, int Cin, i
 
 }  // namespace
 
-extern "C" int cseg_conv1x1_split_plan(int conv_in, int conv_out, int* nt, long* threads) {
-    if (!nt || !threads || conv_in <= 0 || conv_out <= 0 || conv_in % 16 || pick_nt1(conv_out) == 0) return 0;
-    *nt = pick_nt1(conv_out);
+// channel tiles per block and packing threads of a (conv_in -> conv_out) operator in the given arithmetic (the tiling depends on it
+// since round 5: pick_nt1). cseg_conv1x1_split_plan = the bf16x6 answer (round-3 signature, kept).
+extern "C" int cseg_conv1x1_split_plan_arith(int arith, int conv_in, int conv_out, int* nt, long* threads) {
+    if (!nt || !threads || conv_in <= 0 || conv_out <= 0 || conv_in % 16 || pick_nt1(conv_out, arith) == 0) return 0;
+    *nt = pick_nt1(conv_out, arith);
     *threads = (long)(conv_out / 16) * steps1(conv_in) * 64;
     return 1;
 }
+extern "C" int cseg_conv1x1_split_plan(int conv_in, int conv_out, int* nt, long* threads) {
+    return cseg_conv1x1_split_plan_arith(CSEG_ARITH_BF16X6, conv_in, conv_out, nt, threads);
+}
 
 extern "C" size_t cseg_conv1x1_split_packed_bytes(int arith, int Cin, int Cout) {
-    if ((arith != CSEG_ARITH_BF16X6 && arith != CSEG_ARITH_F16X3) || Cin <= 0 || Cout <= 0 || Cin % 16 || pick_nt1(Cout) == 0) return 0;
+    if ((arith != CSEG_ARITH_BF16X6 && arith != CSEG_ARITH_F16X3) || Cin <= 0 || Cout <= 0 || Cin % 16 || pick_nt1(Cout, arith) == 0) return 0;
     return (size_t)(Cout / 16) * steps1(Cin) * (arith == CSEG_ARITH_F16X3 ? 2 : 3) * 64 * sizeof(uint4);
 }
 

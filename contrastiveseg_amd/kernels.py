@@ -1086,7 +1086,7 @@ class SplitWeights(object):
             nt = ctypes.c_int(int(nt_req))
             n_bytes = lib.cseg_conv3x3_s2_split_packed_bytes(conv_in, conv_out)
         else:
-            ok = lib.cseg_conv1x1_split_plan(conv_in, conv_out, ctypes.byref(nt), ctypes.byref(threads))
+            ok = lib.cseg_conv1x1_split_plan_arith(arith, conv_in, conv_out, ctypes.byref(nt), ctypes.byref(threads))
             kind = ctypes.c_int(2)
             n_bytes = lib.cseg_conv1x1_split_packed_bytes(arith, conv_in, conv_out)
         if not ok or n_bytes == 0:

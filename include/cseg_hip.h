@@ -416,6 +416,9 @@ int cseg_conv3x3_s2_split_wrw(const float* x, const float* dy, int B, int Cin, i
 #define CSEG_PACK_C3_S2T 3   /* backward-data operator of the stride-2 convolution, see cseg_pack.h */
 int cseg_conv3x3_split_plan(int conv_in, int conv_out, int nt_request, int* kind, int* nt, long* threads);
 int cseg_conv1x1_split_plan(int conv_in, int conv_out, int* nt, long* threads);
+/* Round 5: the tiling depends on the arithmetic (f16x3: 15 / 16 channel tiles per block for multiples of 240 / 256 from 512 on); the
+ * call above answers for bf16x6. Pack with the nt this reports (cseg_split_pack_batch) or let cseg_conv1x1_split_pack pick it. */
+int cseg_conv1x1_split_plan_arith(int arith, int conv_in, int conv_out, int* nt, long* threads);
 /* Batched form: jobs_dev = DEVICE array of n_jobs records sorted by block0 (block0 of job 0 = 0; job i owns blocks
  * [block0_i, block0_{i+1}) of a grid of total_blocks 256-thread blocks).
  *   cseg_amax_batch:       src = float tensor, total = its element count, amax = its (zeroed) max|.| record; any block count >= 1

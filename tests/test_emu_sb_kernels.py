@@ -101,6 +101,9 @@ ONE_CASES = [  # B, Cin, Cout, H, W
     (2, 144, 48, 16, 16),      # NT = 3, five K-steps with a tail
     (1, 64, 256, 4, 20),       # NT = 8 (the projection head's second layer), 80 pixels
     (1, 32, 144, 6, 44),       # NT = 9
+    (1, 48, 512, 3, 44),       # f16x3: NT = 16 (round 5, wide tiling), ragged pixel tile; bf16x6: NT = 8, two channel groups
+    (1, 32, 240, 4, 20),       # f16x3: NT = 15 (the 720-channel head's tiling); bf16x6: NT = 3, five channel groups
+    (1, 512, 48, 2, 36),       # the backward-data operator of a 48 -> 512 layer: 16 tiles on the transposed weights
 ]
 
 

@@ -142,6 +142,8 @@ ONE_CASES = [  # B, Cin, Cout, H, W
     (2, 64, 256, 5, 13),        # round 5: planes that are not multiples of 4 / 32 pixels (65, 559, 8385 = 65 x 129)
     (1, 48, 144, 13, 43),
     (1, 256, 64, 65, 129),
+    (1, 64, 512, 8, 24),        # round 5: 16 channel tiles per block in f16x3 (ASPP / OCR widths)
+    (1, 48, 240, 5, 13),        # ... and 15 (the 720-channel head's tiling) on a ragged plane
 ]
 
 
