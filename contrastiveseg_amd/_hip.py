@@ -24,6 +24,18 @@ class ContrastDesc(ctypes.Structure):
                 ("temperature", _c_float), ("base_temperature", _c_float)]
 
 
+class ConvGroupMember(ctypes.Structure):
+    """cseg_conv_group_member of include/cseg_hip.h: one convolution of a grouped launch."""
+    _fields_ = [("x", _ptr), ("wp", _ptr), ("bias", _ptr), ("addend", _ptr), ("y", _ptr), ("stats", _ptr), ("amax_x", _ptr),
+                ("amax_w", _ptr), ("B", _c_int), ("Cin", _c_int), ("Cout", _c_int), ("H", _c_int), ("W", _c_int),
+                ("reserved", _c_int * 3)]
+
+
+GROUP_MAX = 8              # CSEG_GROUP_MAX
+GROUP_SCHED_INTS = 320     # CSEG_GROUP_SCHED_INTS
+NT_GROUP = 0x203           # CSEG_NT_GROUP
+
+
 # name -> (restype, argtypes); must list every symbol of include/cseg_hip.h (tests/test_cabi.py checks it)
 SIGNATURES = {
     "cseg_abi_version": (_c_int, []),
@@ -73,6 +85,7 @@ SIGNATURES = {
     "cseg_conv3x3_split_fwd": (_c_int, [_ptr, _ptr, _ptr] + [_c_int] * 7 + [_ptr, _ptr, _ptr, _ptr]),
     "cseg_conv3x3_split_wrw": (_c_int, [_ptr, _ptr] + [_c_int] * 6 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_conv3x3_split_fwd_add": (_c_int, [_ptr, _ptr, _ptr, _ptr] + [_c_int] * 7 + [_ptr, _ptr, _ptr, _ptr]),
+    "cseg_conv3x3_split_group_fwd": (_c_int, [_ptr, _c_int, _c_int, _ptr, _ptr]),
     "cseg_conv3x3_split_dil_fwd": (_c_int, [_ptr, _ptr, _ptr, _ptr] + [_c_int] * 7 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_conv3x3_s2_split_packed_bytes": (ctypes.c_size_t, [_c_int] * 2),
     "cseg_conv3x3_s2_split_plan": (_c_int, [_c_int] * 4 + [_ptr, _ptr]),

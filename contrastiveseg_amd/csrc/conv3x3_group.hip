@@ -1,0 +1,350 @@
+// Grouped launch: several independent 3x3 / stride 1 / pad 1 split-operand convolutions (f16x3) as ONE kernel.
+// Reference shape of the work: HighResolutionModule runs its parallel branches one after the other in a Python loop
+// (lib/models/backbones/hrnet/hrnet_backbone.py:262-288: `for i in range(self.num_branches): x[i] = self.branches[i](x[i])`), i.e.
+// at every depth of the residual chains 2-4 convolutions of equal flops and very different shape (HRNet-W48 at batch 8: 48 ch on
+// 128 x 256, 96 on 64 x 128, 192 on 32 x 64, 384 on 16 x 32) that do not depend on each other. One launch per branch gives the
+// coarse branches too few tiles for 256 CUs (384 ch: 0.17 of the split roof, 192 ch: 0.29) and the step ~2 800 dispatches.
+// Here the members of a group share one persistent launch:
+//   * work unit = (member, 4 x 64-pixel tile, group of 48 output channels); a unit costs Cin / 16 chunk iterations (16 input
+//     channels x 9 taps = 5 K-steps), so units of the wide members are 8x heavier than those of the narrow ones;
+//   * every XCD owns a contiguous range of each member's tiles (halos and the channel groups that read one patch meet in that
+//     XCD's L2) and a queue over its units ordered HEAVY FIRST; the 32 blocks of an XCD pull units with one atomic each (longest
+//     processing time first: the heavy units start together, the light ones fill the tail), so MFMA-bound and HBM-bound members
+//     share the chip and nobody waits for a launch boundary;
+//   * a block runs the tile body of conv3x3_sb16p_kernel (conv3x3_sb16.hip): patch of the NEXT chunk iteration fetched under the
+//     MFMAs of the current one -- across unit and member boundaries --, weights by LDS-DMA: streamed one chunk ahead, or resident
+//     for members whose whole operator fits (Cin <= 48) for as long as the block stays on that member;
+//   * per output element the K order is that of the one-launch kernels (chunk by chunk, five K-steps, term-major): results are
+//     BIT-IDENTICAL to cseg_conv3x3_split_fwd[_st|_add] with nt = CSEG_NT_GROUP, whichever block computes a tile.
+// Epilogue per member: bias, addend (the residual gradient of a BasicBlock's first convolution), BatchNorm statistics records.
+// The queue counters live in `sched` (CSEG_GROUP_SCHED_INTS ints, zero before the first launch); the last block to finish puts
+// them back to zero, so the same buffer serves every launch on a stream.
+#include "cseg_sb16_tile.h"
+
+namespace {
+
+using namespace cseg_sb16t;
+
+constexpr int GNT = 3;                  // 16-channel tiles per unit (48 output channels)
+constexpr int WSLOTS = 3;               // weight chunk slots in LDS: a resident operator of <= 3 chunks, or slots 1 / 2 as the stream's double buffer
+constexpr int SCHED_STRIDE = 32;        // ints between two counters (128 bytes: one cache line each)
+
+struct GMember {
+    const float* x;
+    const uint4* wp;
+    const float* bias;
+    const float* addend;
+    float* y;
+    float4* stats;
+    const unsigned* amax_x;
+    const unsigned* amax_w;
+    int Cin, Cout, H, W;
+    int tiles_x, tiles_y, n_spatial, n_seg;
+    int n_cot, n_chunks, per_xcd, unit0;          // per_xcd: tiles per XCD range; unit0: first unit of this member in an XCD's queue
+};
+
+struct GArgs {
+    GMember m[CSEG_GROUP_MAX];
+    int n_members, units_per_xcd;
+    int* sched;
+};
+
+template <class AR>
+__global__ __launch_bounds__(512, 1) void conv3x3_group_kernel(const GArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_grp[];
+    __shared__ int next_unit;
+    __shared__ float scales[CSEG_GROUP_MAX][2];
+    constexpr int NP = AR::NP;
+    constexpr int A_CELLS = NP * NOCT * PLANE;
+    constexpr int BSTEP = GNT * NP * 64;            // uint4 per K-step
+    constexpr int BCHUNK = STEPS * BSTEP;           // uint4 per 16-channel chunk
+    constexpr int NT0 = (GNT + 1) / 2, NT1 = GNT - NT0;
+    uint4* As = smem_grp;                           // [2][piece NP][octet 2][PLANE]
+    uint4* Bs = smem_grp + 2 * A_CELLS;             // [WSLOTS][BCHUNK]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row = wave & 3, half = wave >> 2;
+    const int g = lane >> 4, n = lane & 15;
+    const int q = blockIdx.x & 7;                   // block b runs on XCD b % 8 (observed on gfx950; only speed depends on it)
+    int* head = a.sched + q * SCHED_STRIDE;
+
+    // per-member scales of the f16x3 split (max|x|, max|w| records -> powers of two), once per block
+    for (int i = 0; i < a.n_members; ++i) {
+        const unsigned ex = split_amax_exp(a.m[i].amax_x), ew = split_amax_exp(a.m[i].amax_w);      // every thread (shuffles inside)
+        if (tid == 0) {
+            scales[i][0] = split_scale_of(ex);
+            scales[i][1] = split_unscale_of(ex) * split_unscale_of(ew);
+        }
+    }
+
+    // thread 0: the next unit of this XCD's queue that names a tile inside the image batch, or -1
+    auto grab = [&]() -> int {
+        for (;;) {
+            const int u = cseg_counter_add(head, 1);
+            if (u >= a.units_per_xcd) return -1;
+            int mi = 0;
+            for (int i = 1; i < a.n_members; ++i) mi = u >= a.m[i].unit0 ? i : mi;
+            const int tl = (u - a.m[mi].unit0) / a.m[mi].n_cot;
+            if (q * a.m[mi].per_xcd + tl < a.m[mi].n_spatial) return u;
+        }
+    };
+
+    struct Unit {                                   // everything a unit needs; uniform over the block
+        const float* x;
+        const uint4* wbase;
+        float* y;
+        const float* bias;
+        const float* addend;
+        float4* stats;
+        int Cin, Cout, H, W, tiles_x, n_seg, n_chunks, key, cot, b, y0, x0;
+        float xscale, unscale;
+    };
+    auto decode = [&](int u, Unit& U) {
+        int mi = 0;
+        for (int i = 1; i < a.n_members; ++i) mi = u >= a.m[i].unit0 ? i : mi;
+        const GMember& M = a.m[mi];
+        const int local = u - M.unit0;
+        U.cot = local % M.n_cot;
+        int t = q * M.per_xcd + local / M.n_cot;
+        const int tx = t % M.tiles_x; t /= M.tiles_x;
+        const int ty = t % M.tiles_y;
+        U.b = t / M.tiles_y;
+        U.x0 = tx * TC; U.y0 = ty * TR;
+        U.x = M.x; U.y = M.y; U.bias = M.bias; U.addend = M.addend; U.stats = M.stats;
+        U.Cin = M.Cin; U.Cout = M.Cout; U.H = M.H; U.W = M.W; U.tiles_x = M.tiles_x; U.n_seg = M.n_seg; U.n_chunks = M.n_chunks;
+        U.wbase = M.wp + (size_t)U.cot * M.n_chunks * BCHUNK;
+        U.key = mi * 4096 + U.cot;
+        U.xscale = scales[mi][0]; U.unscale = scales[mi][1];
+    };
+
+    if (tid == 0) next_unit = grab();
+    __syncthreads();                                // (also publishes `scales`)
+    int u_first = __builtin_amdgcn_readfirstlane(next_unit);
+
+    Unit su;                                        // unit being staged (patch loads, weight DMA)
+    // staging items of a thread: (octet, patch row, patch column) do not depend on the unit
+    float apre[AU][8];
+    int it_r[AU], it_col[AU], it_cell[AU], it_oct8[AU];
+    bool it_in[AU];
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+        const int item = tid + 512 * u;
+        const int oct = item / CELLS, rc = item - oct * CELLS;
+        it_r[u] = rc / XCOLS;
+        it_col[u] = rc - it_r[u] * XCOLS;
+        it_in[u] = oct < NOCT;
+        it_cell[u] = oct * PLANE + rc;
+        it_oct8[u] = min(oct, NOCT - 1) * 8;
+    }
+    auto a_issue = [&](int chunk) {                 // fp32 patch of (su, chunk) into registers
+        const int plane = su.H * su.W;
+        const float* xc = su.x + ((size_t)su.b * su.Cin + (size_t)chunk * 16) * plane;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xc, 0, (int)(16 * plane * sizeof(float)), 0x00020000);
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            const int yc = min(max(su.y0 + it_r[u] - 1, 0), su.H - 1), xcl = min(max(su.x0 + it_col[u] - 1, 0), su.W - 1);
+            const int off = (it_oct8[u] * plane + yc * su.W + xcl) * (int)sizeof(float);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                apre[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, j * plane * (int)sizeof(float), 0));
+        }
+    };
+    auto a_store = [&](uint4* dst) {                // ... split and stored (same unit as the a_issue before it)
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            if (it_in[u]) {
+                const int yy = su.y0 + it_r[u] - 1, xx = su.x0 + it_col[u] - 1;
+                const bool ok = yy >= 0 && yy < su.H && xx >= 0 && xx < su.W;
+                uint4 cells[NP];
+                split_cells8_masked<AR>(apre[u], ok, su.xscale, cells);         // zero padding / outside the tensor
+#pragma unroll
+                for (int p = 0; p < NP; ++p) dst[p * NOCT * PLANE + it_cell[u]] = cells[p];
+            }
+        }
+    };
+    auto b_dma = [&](const uint4* wbase, int chunk, int slot) {   // one 16-channel chunk of packed weights: STEPS * GNT * NP rows of 1 KB
+        constexpr int ROWS = STEPS * GNT * NP;
+        uint4* dst = Bs + (size_t)slot * BCHUNK;
+#pragma unroll
+        for (int i = 0; i < (ROWS + 7) / 8; ++i) {
+            const int r = wave + 8 * i;
+            if (r < ROWS)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + (size_t)chunk * BCHUNK + r * 64 + lane),
+                                                 (__attribute__((address_space(3))) void*)(dst + r * 64), 16, 0, 0);
+        }
+    };
+
+    if (u_first >= 0) {
+        decode(u_first, su);
+        int w_key = -1;                             // (member, channel group) whose whole operator sits in slots 0 .. n_chunks - 1
+        int ws_cur;                                 // weight slot the current item reads
+        int late = -1;                              // chunk of a resident operator that could not be loaded while its slot was being read
+        // ---- prologue: patch of the first item, its weights
+        a_issue(0);
+        if (su.n_chunks <= WSLOTS) {
+            for (int c = 0; c < su.n_chunks; ++c) b_dma(su.wbase, c, c);
+            w_key = su.key;
+            ws_cur = 0;
+        } else {
+            b_dma(su.wbase, 0, 1);
+            ws_cur = 1;
+        }
+        a_store(As);
+        __syncthreads();
+
+        Unit cu = su;                               // unit being computed
+        f32x4 acc[4][NT0];
+        const int a_lane_off = row * XCOLS + n;
+        const int b_lane_off = (half ? NT0 * NP * 64 : 0) + lane;
+        int chunk = 0, buf = 0;
+#pragma unroll 1
+        for (;;) {
+            if (chunk == 0) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT0; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (tid == 0) next_unit = grab();                    // read at this unit's last chunk: at least one barrier later (n_chunks >= 2)
+            }
+            if (late >= 0) {                        // the slot the previous unit's last item was reading: free since the barrier
+                b_dma(cu.wbase, late, late);
+                late = -1;
+            }
+            const bool last = chunk == cu.n_chunks - 1;
+            bool more = true;
+            int nchunk = chunk + 1;
+            if (last) {
+                const int nu = __builtin_amdgcn_readfirstlane(next_unit);
+                more = nu >= 0;
+                nchunk = 0;
+                if (more) decode(nu, su);
+            }
+            int ws_next = ws_cur;
+            if (more) {
+                a_issue(nchunk);                                     // fp32 loads of the next item fly under the MFMAs below
+                if (su.n_chunks <= WSLOTS) {                         // resident operator
+                    if (nchunk == 0 && su.key != w_key) {
+                        for (int c = 0; c < su.n_chunks; ++c) {
+                            if (c != ws_cur) b_dma(su.wbase, c, c);
+                            else late = c;                           // (never chunk 0: a streamed item reads slot 1 or 2, a resident one its last chunk)
+                        }
+                        w_key = su.key;
+                    }
+                    ws_next = nchunk;
+                } else {                                             // streamed: slots 1 and 2 alternate
+                    w_key = -1;
+                    ws_next = ws_cur == 1 ? 2 : 1;
+                    b_dma(su.wbase, nchunk, ws_next);
+                }
+            }
+            const uint4* a_lane = As + (size_t)buf * A_CELLS + a_lane_off;
+            const uint4* b_base = Bs + (size_t)ws_cur * BCHUNK + b_lane_off;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                // the ninth tap is paired with a tenth that does not exist: its packed weights are zero
+                const int tap = min(2 * s + (g >> 1), 8);
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const int a_off = (g & 1) * PLANE + ky * XCOLS + kx;
+                if (half == 0) sb16_kstep<AR, NT0, NT0>(a_lane + a_off, b_base + s * BSTEP, acc);
+                else if (NT1 > 0) sb16_kstep<AR, NT1, NT0>(a_lane + a_off, b_base + s * BSTEP, acc);
+            }
+            if (last) {
+                const int yy = cu.y0 + row;
+                if (yy < cu.H) {
+                    const size_t plane = (size_t)cu.H * cu.W;
+                    float* ybc = cu.y + (size_t)cu.b * cu.Cout * plane;
+                    const float* abc = cu.addend ? cu.addend + (size_t)cu.b * cu.Cout * plane : nullptr;
+                    const int co0 = cu.cot * GNT * 16;
+                    if (half == 0) sb16_store<NT0, NT0>(acc, ybc, cu.bias, abc, co0, plane, yy, cu.x0, cu.W, g, n, cu.unscale);
+                    else if (NT1 > 0) sb16_store<NT1, NT0>(acc, ybc, cu.bias, abc, co0 + NT0 * 16, plane, yy, cu.x0, cu.W, g, n, cu.unscale);
+                    if (cu.stats) {
+                        const size_t seg = ((size_t)cu.b * cu.H + yy) * cu.tiles_x + cu.x0 / TC;
+                        if (half == 0)
+                            cseg_stats_emit<NT0, NT0>(acc, cu.bias, co0, cu.unscale, cu.x0, cu.W, g, n, cu.stats + (size_t)co0 * cu.n_seg + seg, cu.n_seg);
+                        else if (NT1 > 0)
+                            cseg_stats_emit<NT1, NT0>(acc, cu.bias, co0 + NT0 * 16, cu.unscale, cu.x0, cu.W, g, n,
+                                                      cu.stats + (size_t)(co0 + NT0 * 16) * cu.n_seg + seg, cu.n_seg);
+                    }
+                }
+            }
+            if (more) a_store(As + (size_t)(buf ^ 1) * A_CELLS);       // the other patch buffer: last read in the previous item
+            __syncthreads();
+            if (!more) break;
+            if (last) { cu = su; chunk = 0; } else ++chunk;
+            buf ^= 1;
+            ws_cur = ws_next;
+        }
+    }
+    // ---- the last block to get here puts the counters back to zero (every block has made its last, failing, grab by then)
+    if (tid == 0) {
+        int* done = a.sched + 8 * SCHED_STRIDE;
+        if (cseg_counter_add(done, 1) == (int)gridDim.x - 1) {
+            for (int i = 0; i < 8; ++i) cseg_counter_store(a.sched + i * SCHED_STRIDE, 0);
+            cseg_counter_store(done, 0);
+        }
+    }
+}
+
+constexpr size_t group_lds_bytes() { return sizeof(uint4) * (2 * 2 * NOCT * PLANE + WSLOTS * STEPS * GNT * 2 * 64); }
+
+}  // namespace
+
+// One launch for n <= CSEG_GROUP_MAX independent convolutions y_i = conv2d(x_i, w_i, bias_i, stride 1, padding 1) [+ addend_i]
+// [+ statistics records of y_i] -- see include/cseg_hip.h. f16x3 only.
+extern "C" int cseg_conv3x3_split_group_fwd(const cseg_conv_group_member* mem, int n, int arith, int* sched, cseg_stream_t stream_) {
+    CSEG_REQUIRE(mem && sched && n >= 1 && n <= CSEG_GROUP_MAX, "conv3x3 group: needs 1 .. %d members and a scheduling record", CSEG_GROUP_MAX);
+    CSEG_REQUIRE(arith == CSEG_ARITH_F16X3, "conv3x3 group: f16x3 arithmetic only (got %d)", arith);
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(sched) & 127) == 0, "conv3x3 group: the scheduling record must be 128-byte aligned");
+    // heavy first: members in descending order of the chunk iterations per unit (stable: equal members keep the caller's order)
+    int order[CSEG_GROUP_MAX];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0 && mem[order[j]].Cin > mem[order[j - 1]].Cin; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    GArgs a;
+    int unit0 = 0;
+    for (int k = 0; k < n; ++k) {
+        const cseg_conv_group_member& s = mem[order[k]];
+        CSEG_REQUIRE(s.x && s.wp && s.y && s.amax_x && s.amax_w, "conv3x3 group: member %d has a null pointer", order[k]);
+        CSEG_REQUIRE(s.B > 0 && s.H > 0 && s.W > 0 && s.Cin >= 32 && s.Cin % 16 == 0 && s.Cout > 0 && s.Cout % 48 == 0 &&
+                         (long)s.H * s.W * 16 * 4 < 2147483647L,
+                     "conv3x3 group: member %d: unsupported shape B=%d Cin=%d Cout=%d %dx%d (needs Cin %% 16, Cin >= 32, Cout %% 48)", order[k],
+                     s.B, s.Cin, s.Cout, s.H, s.W);
+        CSEG_REQUIRE((reinterpret_cast<uintptr_t>(s.wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(s.y) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(s.addend) & 15) == 0 && (reinterpret_cast<uintptr_t>(s.stats) & 15) == 0,
+                     "conv3x3 group: member %d: packed weights / output / addend / statistics must be 16-byte aligned", order[k]);
+        CSEG_REQUIRE(!(s.stats && s.addend), "conv3x3 group: member %d: the statistics epilogue takes no addend", order[k]);
+        GMember& m = a.m[k];
+        m.x = s.x; m.wp = (const uint4*)s.wp; m.bias = s.bias; m.addend = s.addend; m.y = s.y; m.stats = (float4*)s.stats;
+        m.amax_x = s.amax_x; m.amax_w = s.amax_w;
+        m.Cin = s.Cin; m.Cout = s.Cout; m.H = s.H; m.W = s.W;
+        m.tiles_x = (s.W + TC - 1) / TC; m.tiles_y = (s.H + TR - 1) / TR;
+        const long n_spatial = (long)s.B * m.tiles_y * m.tiles_x;
+        CSEG_REQUIRE(n_spatial < (1L << 28) && s.Cout / 48 < 4096, "conv3x3 group: member %d: too many tiles", order[k]);
+        m.n_spatial = (int)n_spatial;
+        m.n_seg = s.B * s.H * m.tiles_x;
+        m.n_cot = s.Cout / (GNT * 16);
+        m.n_chunks = s.Cin / 16;
+        m.per_xcd = (m.n_spatial + 7) / 8;
+        m.unit0 = unit0;
+        const long units = (long)m.per_xcd * m.n_cot;
+        CSEG_REQUIRE(unit0 + units < 2147483647L, "conv3x3 group: too many units");
+        unit0 += (int)units;
+    }
+    for (int k = n; k < CSEG_GROUP_MAX; ++k) a.m[k] = a.m[0];
+    a.n_members = n;
+    a.units_per_xcd = unit0;
+    a.sched = sched;
+    const size_t lds = group_lds_bytes();
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv3x3_group_kernel<SplitF16x3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            cseg_set_error("conv3x3 group: cannot raise dynamic LDS to %zu bytes", lds);
+            return 0;
+        }
+        attr_set = true;
+    }
+    const int per_xcd_blocks = unit0 < 32 ? unit0 : 32;       // one block per CU: 32 CUs per XCD
+    hipLaunchKernelGGL(conv3x3_group_kernel<SplitF16x3>, dim3((unsigned)(8 * per_xcd_blocks)), dim3(512), lds, (hipStream_t)stream_, a);
+    CSEG_CHECK_LAUNCH("conv3x3_group_kernel");
+    return 1;
+}

@@ -476,7 +476,7 @@ extern "C" size_t cseg_conv3x3_split_packed_bytes(int arith, int Cin, int Cout) 
     if (!arith_ok(arith) || Cin <= 0 || Cout <= 0 || Cin % 16 || pick_nt(Cout) == 0) return 0;
     if (use_sb16(Cout)) return cseg_sb16::packed_bytes(arith, Cin, Cout);
     const size_t own = (size_t)(Cout / 16) * steps_of(Cin) * np_of(arith) * 64 * sizeof(uint4);
-    if (arith == CSEG_ARITH_F16X3 && Cout % 144 == 0) {          // nt = CSEG_NT_SB8 packs the 16-channel-chunk format: room for either
+    if (arith == CSEG_ARITH_F16X3 && Cout % 48 == 0) {           // nt = CSEG_NT_SB8 / CSEG_NT_GROUP pack the 16-channel-chunk format: room for either
         const size_t alt = cseg_sb16::packed_bytes(arith, Cin, Cout);
         return alt > own ? alt : own;
     }
@@ -489,6 +489,13 @@ extern "C" int cseg_conv3x3_split_plan(int conv_in, int conv_out, int nt_request
         if (conv_out % 144) return 0;
         *kind = CSEG_PACK_C3_16;
         *nt = 9;
+        *threads = (long)(conv_out / 16) * pack_steps_c3_16(conv_in) * 64;
+        return 1;
+    }
+    if (nt_request == CSEG_NT_GROUP) {                           // member of a grouped launch: 16-channel-chunk format, three tiles
+        if (conv_out % 48) return 0;
+        *kind = CSEG_PACK_C3_16;
+        *nt = 3;
         *threads = (long)(conv_out / 16) * pack_steps_c3_16(conv_in) * 64;
         return 1;
     }
@@ -519,6 +526,10 @@ static int pack_impl(const float* w, int Cout, int Cin, int transpose_flip, int 
     if (NT == CSEG_NT_SB8) {
         CSEG_REQUIRE(arith == CSEG_ARITH_F16X3 && conv_out % 144 == 0, "conv3x3 split pack: nt = CSEG_NT_SB8 needs f16x3 and output channels %% 144");
         return cseg_sb16::pack(w, Cout, Cin, transpose_flip, 9, arith, amax_w, wp, stream);
+    }
+    if (NT == CSEG_NT_GROUP) {
+        CSEG_REQUIRE(conv_out % 48 == 0, "conv3x3 split pack: nt = CSEG_NT_GROUP needs output channels %% 48");
+        return cseg_sb16::pack(w, Cout, Cin, transpose_flip, 3, arith, amax_w, wp, stream);
     }
     if (use_sb16(conv_out)) return cseg_sb16::pack(w, Cout, Cin, transpose_flip, sb16_nt(conv_out, NT), arith, amax_w, wp, stream);
     if (NT == 0) NT = pick_nt(conv_out);
@@ -553,7 +564,7 @@ extern "C" int cseg_conv3x3_sb_pack_weights_nt(const float* w, int Cout, int Cin
 // nt = 0: the library's channel tiling. arith: CSEG_ARITH_BF16X6 (amax_w may be null) | CSEG_ARITH_F16X3 (amax_w = max|w| bits)
 extern "C" int cseg_conv3x3_split_pack(const float* w, int Cout, int Cin, int transpose_flip, int nt, int arith,
                                        const unsigned* amax_w, void* wp, cseg_stream_t stream_) {
-    CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9 || nt == CSEG_NT_SB8, "conv3x3_split_pack: nt must be 0, 3, 6, 9 or CSEG_NT_SB8 (got %d)", nt);
+    CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9 || nt == CSEG_NT_SB8 || nt == CSEG_NT_GROUP, "conv3x3_split_pack: nt must be 0, 3, 6, 9, CSEG_NT_SB8 or CSEG_NT_GROUP (got %d)", nt);
     return pack_impl(w, Cout, Cin, transpose_flip, nt, arith, amax_w, wp, (hipStream_t)stream_);
 }
 
@@ -570,10 +581,12 @@ static int fwd_impl(const float* x, const void* wp, const float* bias, const flo
         CSEG_REQUIRE(!addend, "conv3x3_sb: the 8-row kernel takes no addend");
         return cseg_sb16::fwd8(x, wp, bias, B, Cin, Cout, H, W, arith, amax_x, amax_w, y, stats, stream);
     }
-    if (use_sb16(Cout)) {
+    if (NT == CSEG_NT_GROUP || use_sb16(Cout)) {
         CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
                      "conv3x3_sb: packed weights / output must be 16-byte aligned and W a multiple of 4");
-        return cseg_sb16::fwd(x, wp, bias, addend, B, Cin, Cout, H, W, sb16_nt(Cout, NT), arith, amax_x, amax_w, y, stats, stream);
+        CSEG_REQUIRE(NT != CSEG_NT_GROUP || Cout % 48 == 0, "conv3x3_sb: nt = CSEG_NT_GROUP needs output channels %% 48");
+        return cseg_sb16::fwd(x, wp, bias, addend, B, Cin, Cout, H, W, NT == CSEG_NT_GROUP ? 3 : sb16_nt(Cout, NT), arith, amax_x, amax_w, y,
+                              stats, stream);
     }
     if (NT == 0) NT = pick_nt(Cout);
     CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && NT > 0 && nt_ok(NT, Cout),
@@ -628,7 +641,7 @@ extern "C" int cseg_conv3x3_sb_fwd_nt(const float* x, const void* wp, const floa
 extern "C" int cseg_conv3x3_split_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
                                       int nt, int arith, const unsigned* amax_x, const unsigned* amax_w, float* y,
                                       cseg_stream_t stream_) {
-    CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9 || nt == CSEG_NT_SB8, "conv3x3_split_fwd: nt must be 0, 3, 6, 9 or CSEG_NT_SB8 (got %d)", nt);
+    CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9 || nt == CSEG_NT_SB8 || nt == CSEG_NT_GROUP, "conv3x3_split_fwd: nt must be 0, 3, 6, 9, CSEG_NT_SB8 or CSEG_NT_GROUP (got %d)", nt);
     return fwd_impl(x, wp, bias, nullptr, B, Cin, Cout, H, W, nt, arith, amax_x, amax_w, y, (hipStream_t)stream_);
 }
 
@@ -638,7 +651,7 @@ extern "C" int cseg_conv3x3_split_fwd(const float* x, const void* wp, const floa
 extern "C" int cseg_conv3x3_split_fwd_st(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int H, int W,
                                          int nt, int arith, const unsigned* amax_x, const unsigned* amax_w, float* y, float* stats,
                                          cseg_stream_t stream_) {
-    CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9 || nt == CSEG_NT_SB8, "conv3x3_split_fwd_st: nt must be 0, 3, 6, 9 or CSEG_NT_SB8 (got %d)", nt);
+    CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9 || nt == CSEG_NT_SB8 || nt == CSEG_NT_GROUP, "conv3x3_split_fwd_st: nt must be 0, 3, 6, 9, CSEG_NT_SB8 or CSEG_NT_GROUP (got %d)", nt);
     CSEG_REQUIRE(stats, "conv3x3_split_fwd_st: null statistics buffer");
     return fwd_impl(x, wp, bias, nullptr, B, Cin, Cout, H, W, nt, arith, amax_x, amax_w, y, (hipStream_t)stream_,
                     reinterpret_cast<float4*>(stats));
@@ -706,7 +719,7 @@ extern "C" int cseg_amax_f32(const float* x, long n, unsigned* amax_bits, cseg_s
 extern "C" int cseg_conv3x3_split_fwd_add(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin,
                                           int Cout, int H, int W, int nt, int arith, const unsigned* amax_x, const unsigned* amax_w,
                                           float* y, cseg_stream_t stream_) {
-    CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9, "conv3x3_split_fwd_add: nt must be 0, 3, 6 or 9 (got %d)", nt);
+    CSEG_REQUIRE(nt == 0 || nt == 3 || nt == 6 || nt == 9 || nt == CSEG_NT_GROUP, "conv3x3_split_fwd_add: nt must be 0, 3, 6, 9 or CSEG_NT_GROUP (got %d)", nt);
     CSEG_REQUIRE((reinterpret_cast<uintptr_t>(addend) & 15) == 0, "conv3x3_split_fwd_add: addend must be 16-byte aligned");
     return fwd_impl(x, wp, bias, addend, B, Cin, Cout, H, W, nt, arith, amax_x, amax_w, y, (hipStream_t)stream_);
 }

@@ -12,24 +12,12 @@
 // Entry points: the cseg_conv3x3_sb_* family dispatches here when CSEG_CONV3X3_SB_VAR=2 (packing and forward must run under
 // the same setting; kernels.conv3x3_sb_run does both back to back).
 // Round 3: default for 48 / 192 output channels; written against the arithmetic traits of cseg_split.h (bf16x6 and f16x3).
-#include "cseg_pack.h"
-#include "cseg_stats.h"
+#include "cseg_sb16_tile.h"
 #include <stdlib.h>
 
 namespace {
 
-constexpr int TR = 4;                 // output rows per block (one per wave)
-constexpr int TC = 64;                // output columns per block
-constexpr int XROWS = TR + 2;
-constexpr int XCOLS = TC + 2;         // cell 0 = column x0 - 1
-constexpr int CELLS = XROWS * XCOLS;  // 396 pixels per (piece, octet)
-constexpr int PLANE = (CELLS + 15) / 16 * 16;     // LDS stride of a (piece, octet) plane: 0 mod 256 bytes, see conv3x3_sb.hip
-constexpr int NOCT = 2;               // channel octets per chunk
-constexpr int A_ITEMS = NOCT * CELLS; // (octet, pixel) staging items of a 16-channel chunk
-constexpr int AU = (A_ITEMS + 511) / 512;     // staging items per thread (512 threads): 2
-constexpr int STEPS = 5;              // K-steps per chunk: taps (0,1) (2,3) (4,5) (6,7) (8,-)
-
-__host__ __device__ constexpr int steps16(int Cin) { return pack_steps_c3_16(Cin); }
+using namespace cseg_sb16t;
 
 // Packed weights: Wp[co_tile][kstep][nt][piece][lane] of uint4 (8 bf16, element j), lane = 16*g + n; K-step ks = 5*chunk + q:
 //   value(co = (co_tile*NT + nt)*16 + n, ci = 16*chunk + 8*(g&1) + j, tap = 2q + (g>>1))   (zero when tap > 8)
@@ -41,49 +29,6 @@ __global__ __launch_bounds__(256) void pack_weights_sb16_kernel(const float* __r
     const int e = blockIdx.x * 256 + threadIdx.x;          // one thread per (co_tile, kstep, nt, lane)
     if (e >= total) return;
     pack_elem_c3_16<AR>(w, Cout, Cin, transpose_flip, NT, wscale, wp, e);
-}
-
-// One K-step of a wave: 4 pixel tiles x NTW channel tiles x 6 piece products (see conv3x3_sb.hip:sb_kstep)
-template <class AR, int NTW, int NTMAX>
-__device__ __forceinline__ void sb16_kstep(const uint4* __restrict__ ap, const uint4* __restrict__ bp,
-                                           f32x4 (&acc)[4][NTMAX]) {
-    typedef typename AR::frag_t frag_t;
-    frag_t a[4][AR::NP];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int p = 0; p < AR::NP; ++p) a[mt][p] = __builtin_bit_cast(frag_t, ap[p * NOCT * PLANE + 16 * mt]);
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        frag_t b[AR::NP];
-#pragma unroll
-        for (int p = 0; p < AR::NP; ++p) b[p] = __builtin_bit_cast(frag_t, bp[(nt * AR::NP + p) * 64]);
-#pragma unroll
-        for (int t = 0; t < AR::NTERMS; ++t)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = AR::mfma(a[mt][AR::ta(t)], b[AR::tb(t)], acc[mt][nt]);
-    }
-}
-
-// accumulator layout: D[m = 4*g + r][n]: pixel column x0 + 16*mt + 4*g + r, channel co0 + 16*nt + n
-template <int NTW, int NTMAX>
-__device__ __forceinline__ void sb16_store(const f32x4 (&acc)[4][NTMAX], float* __restrict__ ybc,
-                                           const float* __restrict__ bias, const float* __restrict__ abc, int co0, size_t plane, int yy,
-                                           int x0, int W, int g, int n, float unscale) {
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        const size_t roff = (size_t)(co0 + nt * 16 + n) * plane + (size_t)yy * W;
-        float* orow = ybc + roff;
-        const float bv = bias ? bias[co0 + nt * 16 + n] : 0.f;
-        const bool vec = (W & 3) == 0;              // rows 16-byte aligned (else element by element: cseg_store_row4)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int xx = x0 + 16 * mt + 4 * g;
-            f32x4 v = acc[mt][nt] * unscale;
-            v += bv;
-            cseg_store_row4(orow, abc ? abc + roff : nullptr, xx, W, vec, v);       // epilogue addend: see conv3x3_sb.hip:sb_store
-        }
-    }
 }
 
 // 8 waves: wave = (row = wave & 3, half = wave >> 2); the halves split the NT channel tiles. Two blocks per CU = 4 waves per

@@ -387,6 +387,39 @@ int cseg_conv3x3_split_dil_fwd(const float* x, const void* wp, const float* bias
 /* ws: cseg_conv3x3_sb_wrw_ws_floats(...) */
 int cseg_conv3x3_split_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int H, int W, int arith,
                            const unsigned* amax_x, const unsigned* amax_dy, float* ws, float* dw, cseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Round 6 (ABI 6): GROUPED launches -- the work of several independent layers in ONE kernel launch each.  Replaces the Python loop
+ * over the parallel branches of an HRNet exchange unit (reference lib/models/backbones/hrnet/hrnet_backbone.py:262-288,
+ * `for i in range(self.num_branches): x[i] = self.branches[i](x[i])`): at every depth of the residual chains (BasicBlock.forward,
+ * :49-65) the 2-4 branches run convolutions / BatchNorms of equal flops and very different shapes that do not depend on each other.
+ * A group = n <= CSEG_GROUP_MAX members described by HOST arrays of the structs below (read during the call; device pointers inside).
+ * Results are bit-identical to the one-layer entry points named with each call, member by member.
+ *
+ * cseg_conv3x3_split_group_fwd: y_i = conv2d(x_i, w_i, bias_i, stride 1, padding 1) [+ addend_i] [+ BatchNorm statistics records of
+ *   y_i as cseg_conv3x3_split_fwd_st writes them]; f16x3 only; Cin % 16 == 0, Cin >= 32, Cout % 48 == 0, any width. wp_i = weights
+ *   packed with nt = CSEG_NT_GROUP (16-channel-chunk format, three 16-channel tiles per unit; transpose_flip for backward-data).
+ *   One persistent launch: every XCD pulls (member, 4 x 64-pixel tile, 48-channel group) units from its own queue, heaviest members
+ *   first. == cseg_conv3x3_split_fwd / _fwd_st / _fwd_add with nt = CSEG_NT_GROUP per member.
+ *   sched: CSEG_GROUP_SCHED_INTS int32 on the device, 128-byte aligned, ZERO before the first launch that uses it; every launch
+ *   leaves it zero again, so one record serves all launches of a stream (not two launches that may run concurrently).
+ * ------------------------------------------------------------------------------------------------ */
+#define CSEG_GROUP_MAX 8
+#define CSEG_GROUP_SCHED_INTS 320
+#define CSEG_NT_GROUP 0x203
+typedef struct cseg_conv_group_member {
+    const float* x;           /* [B, Cin, H, W] */
+    const void* wp;           /* packed weights (cseg_conv3x3_split_pack / cseg_split_pack_batch, nt = CSEG_NT_GROUP) */
+    const float* bias;        /* [Cout] or NULL */
+    const float* addend;      /* [B, Cout, H, W] or NULL */
+    float* y;                 /* [B, Cout, H, W] */
+    float* stats;             /* [Cout][cseg_conv_stat_segments(0, B, H, W)][4] or NULL (not together with addend) */
+    const unsigned* amax_x;   /* max|x| record */
+    const unsigned* amax_w;   /* max|w| record */
+    int B, Cin, Cout, H, W;
+    int reserved[3];
+} cseg_conv_group_member;
+int cseg_conv3x3_split_group_fwd(const cseg_conv_group_member* members, int n, int arith, int* sched, cseg_stream_t stream);
 /* ---- stride 2 (round 3): the 3x3 / stride 2 / pad 1 convolutions of HRNet's fuse and transition layers (reference:
  * lib/models/backbones/hrnet/hrnet_backbone.py:230-250 fuse layers, :652-660 transition layers -- nn.Conv2d(.., 3, 2, 1, bias=False)),
  * f16x3 arithmetic only. x is [B, Cin, 2 Ho, 2 Wo], y / dy are [B, Cout, Ho, Wo].

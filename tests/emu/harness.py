@@ -21,7 +21,7 @@ def lib():
         _LIB = ctypes.CDLL(path)
         for name in ("cseg_conv3x3_sb_packed_bytes", "cseg_conv1x1_sb_packed_bytes", "cseg_conv3x3_sb_wrw_ws_floats",
                      "cseg_conv1x1_sb_wrw_ws_floats", "cseg_conv3x3_split_packed_bytes", "cseg_conv1x1_split_packed_bytes",
-                     "cseg_conv3x3_s2_split_packed_bytes", "cseg_conv3x3_s2_wrw_ws_floats"):
+                     "cseg_conv3x3_s2_split_packed_bytes", "cseg_conv3x3_s2_wrw_ws_floats", "cseg_conv_stat_segments"):
             getattr(_LIB, name).restype = ctypes.c_size_t
         _LIB.cseg_last_error.restype = ctypes.c_char_p
     return _LIB
@@ -123,6 +123,74 @@ def conv3x3_sb(x, w, bias=None, transpose_flip=False, nt=0, arith=None, addend=N
         call("cseg_conv3x3_sb_pack_weights", ptr(wd), co, ci, int(transpose_flip), ptr(wp), None)
         call("cseg_conv3x3_sb_fwd", ptr(xd), ptr(wp), ptr(bd), B, conv_in, conv_out, H, W, ptr(y), None)
     return y
+
+
+NT_GROUP = 0x203
+
+
+def conv3x3_group(members, sched=None, order=None):
+    """members: list of dict(x, w, bias=None, addend=None, stats=False, transpose_flip=False) -> list of (y, stats or None): ONE
+    cseg_conv3x3_split_group_fwd launch (f16x3). `sched`: the scheduling record to use (zeroed int32[320]); checked to be zero after."""
+    from contrastiveseg_amd._hip import ConvGroupMember, GROUP_SCHED_INTS
+    arr = (ConvGroupMember * len(members))()
+    keep, outs = [], []
+    for i, m in enumerate(members):
+        x, w = m["x"], m["w"]
+        co, ci = w.shape[:2]
+        flip = bool(m.get("transpose_flip"))
+        conv_in, conv_out = (co, ci) if flip else (ci, co)
+        B, _, H, W = x.shape
+        n = lib().cseg_conv3x3_split_packed_bytes(F16X3, conv_in, conv_out)
+        assert n > 0
+        wp = aligned((n,), np.uint8, 0xFF)
+        ax, aw = amax(x), amax(w)
+        call("cseg_conv3x3_split_pack", ptr(dev(w)), co, ci, int(flip), NT_GROUP, F16X3, ptr(aw), ptr(wp), None)
+        y = aligned((B, conv_out, H, W))
+        st = None
+        if m.get("stats"):
+            T = lib().cseg_conv_stat_segments(0, B, H, W)
+            st = aligned((conv_out, T, 4))
+        xd = dev(x)
+        bd = None if m.get("bias") is None else dev(m["bias"])
+        ad = None if m.get("addend") is None else dev(m["addend"])
+        keep += [xd, wp, ax, aw, bd, ad]
+        e = arr[i]
+        e.x, e.wp, e.y, e.amax_x, e.amax_w = ptr(xd), ptr(wp), ptr(y), ptr(ax), ptr(aw)
+        e.bias, e.addend, e.stats = ptr(bd), ptr(ad), ptr(st)
+        e.B, e.Cin, e.Cout, e.H, e.W = B, conv_in, conv_out, H, W
+        outs.append((y, st))
+    if sched is None:
+        sched = aligned_to((GROUP_SCHED_INTS,), np.int32, 128)
+    call("cseg_conv3x3_split_group_fwd", ctypes.byref(arr), len(members), F16X3, ptr(sched), None)
+    assert not sched.any(), "the launch must leave its scheduling record zeroed"
+    return outs
+
+
+def aligned_to(shape, dtype, align):
+    """zero-filled array whose first byte is `align`-byte aligned"""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    raw = np.zeros(n + align, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align
+    _KEEP.append(raw)
+    return raw[off:off + n].view(dtype).reshape(shape)
+
+
+def conv3x3_sb_st(x, w, bias=None, nt=0, transpose_flip=False):
+    """cseg_conv3x3_split_fwd_st (f16x3) -> (y, stats)"""
+    co, ci = w.shape[:2]
+    conv_in, conv_out = (co, ci) if transpose_flip else (ci, co)
+    B, _, H, W = x.shape
+    n = lib().cseg_conv3x3_split_packed_bytes(F16X3, conv_in, conv_out)
+    wp = aligned((n,), np.uint8, 0xFF)
+    ax, aw = amax(x), amax(w)
+    call("cseg_conv3x3_split_pack", ptr(dev(w)), co, ci, int(transpose_flip), nt, F16X3, ptr(aw), ptr(wp), None)
+    y = aligned((B, conv_out, H, W))
+    T = lib().cseg_conv_stat_segments(0, B, H, W)
+    st = aligned((conv_out, T, 4))
+    bd = None if bias is None else dev(bias)
+    call("cseg_conv3x3_split_fwd_st", ptr(dev(x)), ptr(wp), ptr(bd), B, conv_in, conv_out, H, W, nt, F16X3, ptr(ax), ptr(aw), ptr(y),
+         ptr(st), None)
+    return y, st
 
 
 def conv3x3_sb_wrw(x, dy, arith=None):
