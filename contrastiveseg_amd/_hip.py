@@ -31,6 +31,20 @@ class ConvGroupMember(ctypes.Structure):
                 ("reserved", _c_int * 3)]
 
 
+class BnGroupMember(ctypes.Structure):
+    """cseg_bn_group_member of include/cseg_hip.h: one BatchNorm site of a grouped launch."""
+    _fields_ = [("x", _ptr), ("residual", _ptr), ("y", _ptr), ("stats", _ptr), ("mean_invstd", _ptr), ("weight", _ptr), ("bias", _ptr),
+                ("running_mean", _ptr), ("running_var", _ptr), ("num_batches_tracked", _ptr), ("amax_out", _ptr), ("dy", _ptr),
+                ("out", _ptr), ("g_masked", _ptr), ("d_weight", _ptr), ("d_bias", _ptr), ("dx", _ptr), ("ws", _ptr),
+                ("B", _c_int), ("C", _c_int), ("HW", _c_int), ("T", ctypes.c_long), ("eps", _c_float), ("momentum", _c_float)]
+
+
+class WrwGroupMember(ctypes.Structure):
+    """cseg_wrw_group_member of include/cseg_hip.h: one weight gradient of a grouped launch."""
+    _fields_ = [("x", _ptr), ("dy", _ptr), ("amax_x", _ptr), ("amax_dy", _ptr), ("ws", _ptr), ("dw", _ptr), ("B", _c_int), ("Cin", _c_int),
+                ("Cout", _c_int), ("H", _c_int), ("W", _c_int), ("reserved", _c_int * 3)]
+
+
 GROUP_MAX = 8              # CSEG_GROUP_MAX
 GROUP_SCHED_INTS = 320     # CSEG_GROUP_SCHED_INTS
 NT_GROUP = 0x203           # CSEG_NT_GROUP
@@ -86,6 +100,10 @@ SIGNATURES = {
     "cseg_conv3x3_split_wrw": (_c_int, [_ptr, _ptr] + [_c_int] * 6 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_conv3x3_split_fwd_add": (_c_int, [_ptr, _ptr, _ptr, _ptr] + [_c_int] * 7 + [_ptr, _ptr, _ptr, _ptr]),
     "cseg_conv3x3_split_group_fwd": (_c_int, [_ptr, _c_int, _c_int, _ptr, _ptr]),
+    "cseg_conv3x3_split_group_wrw": (_c_int, [_ptr, _c_int, _c_int, _ptr]),
+    "cseg_bn_group_tiles_finalize": (_c_int, [_ptr, _c_int, _ptr]),
+    "cseg_bn_group_apply": (_c_int, [_ptr, _c_int, _c_int, _ptr]),
+    "cseg_bn_group_bwd": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr]),
     "cseg_conv3x3_split_dil_fwd": (_c_int, [_ptr, _ptr, _ptr, _ptr] + [_c_int] * 7 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_conv3x3_s2_split_packed_bytes": (ctypes.c_size_t, [_c_int] * 2),
     "cseg_conv3x3_s2_split_plan": (_c_int, [_c_int] * 4 + [_ptr, _ptr]),

@@ -195,12 +195,14 @@ __device__ __forceinline__ void publish_amax(unsigned m, unsigned* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------
 // forward apply: y = act((x - mean) * (gamma * invstd) + beta [+ residual])
 // ---------------------------------------------------------------------------------------------------------
+// (`bid`: the block's index inside THIS layer's grid -- blockIdx.x for the one-layer launch, blockIdx.x minus the member's first block
+// in a grouped launch, bn_group_* below)
 template <bool VEC, bool RES>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                       const float* __restrict__ mean_invstd,
-                                                       const float* __restrict__ weight, const float* __restrict__ bias,
-                                                       BnDims d, int relu, float* __restrict__ y, unsigned* __restrict__ amax_out) {
-    const int plane = blockIdx.x / d.n_ck, ck = blockIdx.x - plane * d.n_ck;
+__device__ __forceinline__ void bn_apply_body(const float* __restrict__ x, const float* __restrict__ res,
+                                              const float* __restrict__ mean_invstd,
+                                              const float* __restrict__ weight, const float* __restrict__ bias,
+                                              const BnDims& d, int relu, float* __restrict__ y, unsigned* __restrict__ amax_out, int bid) {
+    const int plane = bid / d.n_ck, ck = bid - plane * d.n_ck;
     const int c = plane % d.C;
     const float mean = mean_invstd[2 * c];
     const float a = (weight ? weight[c] : 1.f) * mean_invstd[2 * c + 1];
@@ -239,6 +241,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
     if (amax_out) publish_amax(am, amax_out);
 }
+template <bool VEC, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                       const float* __restrict__ mean_invstd,
+                                                       const float* __restrict__ weight, const float* __restrict__ bias,
+                                                       BnDims d, int relu, float* __restrict__ y, unsigned* __restrict__ amax_out) {
+    bn_apply_body<VEC, RES>(x, res, mean_invstd, weight, bias, d, relu, y, amax_out, (int)blockIdx.x);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // backward reduction: sums of dy' and dy' * (x - mean); dy' = dy masked by the ReLU
@@ -246,14 +255,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 //   MODE 2: mask from `out` (residual case); dy' is written to g_out (it is also the gradient of the residual)
 // ---------------------------------------------------------------------------------------------------------
 template <bool VEC, int MODE>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                            const float* __restrict__ out,
-                                                            const float* __restrict__ mean_invstd,
-                                                            const float* __restrict__ weight,
-                                                            const float* __restrict__ bias, BnDims d,
-                                                            float* __restrict__ g_out, float* __restrict__ partial) {
+__device__ __forceinline__ void bn_bwd_reduce_body(const float* __restrict__ dy, const float* __restrict__ x,
+                                                   const float* __restrict__ out,
+                                                   const float* __restrict__ mean_invstd,
+                                                   const float* __restrict__ weight,
+                                                   const float* __restrict__ bias, const BnDims& d,
+                                                   float* __restrict__ g_out, float* __restrict__ partial, int bid) {
     __shared__ float red[2][4];
-    const int c = blockIdx.x % d.C, s = blockIdx.x / d.C;
+    const int c = bid % d.C, s = bid / d.C;
     const float mean = mean_invstd[2 * c];
     const float a = (weight ? weight[c] : 1.f) * mean_invstd[2 * c + 1];
     const float beta = bias ? bias[c] : 0.f;
@@ -300,6 +309,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         partial[((size_t)s * d.C + c) * 2 + 0] = s0;
         partial[((size_t)s * d.C + c) * 2 + 1] = s1;
     }
+}
+template <bool VEC, int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ out,
+                                                            const float* __restrict__ mean_invstd,
+                                                            const float* __restrict__ weight,
+                                                            const float* __restrict__ bias, BnDims d,
+                                                            float* __restrict__ g_out, float* __restrict__ partial) {
+    bn_bwd_reduce_body<VEC, MODE>(dy, x, out, mean_invstd, weight, bias, d, g_out, partial, (int)blockIdx.x);
 }
 
 // one wave per channel: partials -> fp64 sums [C,2]; d_gamma = s1 * invstd, d_beta = s0 (rank-local, like torch's SyncBN)
@@ -470,15 +488,15 @@ __global__ __launch_bounds__(256) void bn_apply_fused_kernel(const float* __rest
 // backward twin: every bwd-apply block reduces the channel's partial sums itself; the publisher block writes
 // d_weight / d_bias (and the fp64 sums, kept for inspection)
 template <bool VEC, bool MASK>
-__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                 const float* __restrict__ mean_invstd,
-                                                                 const float* __restrict__ weight,
-                                                                 const float* __restrict__ bias,
-                                                                 const float* __restrict__ partial, int training,
-                                                                 BnDims d, float* __restrict__ d_weight,
-                                                                 float* __restrict__ d_bias, float* __restrict__ dx, unsigned* __restrict__ amax_out) {
+__device__ __forceinline__ void bn_bwd_apply_fused_body(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ mean_invstd,
+                                                        const float* __restrict__ weight,
+                                                        const float* __restrict__ bias,
+                                                        const float* __restrict__ partial, int training,
+                                                        const BnDims& d, float* __restrict__ d_weight,
+                                                        float* __restrict__ d_bias, float* __restrict__ dx, unsigned* __restrict__ amax_out, int bid) {
     __shared__ float kk[3];            // k0 (hi), k1, k0 (lo): see bn_bwd_apply_kernel
-    const int plane = blockIdx.x / d.n_ck, ck = blockIdx.x - plane * d.n_ck;
+    const int plane = bid / d.n_ck, ck = bid - plane * d.n_ck;
     const int c = plane % d.C;
     const float mean = mean_invstd[2 * c], invstd = mean_invstd[2 * c + 1];
     if (threadIdx.x < 64) {
@@ -539,6 +557,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const float* __
     }
     if (amax_out) publish_amax(am, amax_out);
 }
+template <bool VEC, bool MASK>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ mean_invstd,
+                                                                 const float* __restrict__ weight,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ partial, int training,
+                                                                 BnDims d, float* __restrict__ d_weight,
+                                                                 float* __restrict__ d_bias, float* __restrict__ dx, unsigned* __restrict__ amax_out) {
+    bn_bwd_apply_fused_body<VEC, MASK>(dy, x, mean_invstd, weight, bias, partial, training, d, d_weight, d_bias, dx, amax_out, (int)blockIdx.x);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Statistics that came out of the producing convolution's epilogue (cseg_stats.h): per channel T float4 = (count, mean, M2) of
@@ -579,14 +607,18 @@ __device__ __forceinline__ void tiles_combine(const float4* __restrict__ st, lon
     m1 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
 }
 
-__global__ __launch_bounds__(256) void bn_tiles_finalize_kernel(const float4* __restrict__ st, long T, int C, float eps, float momentum,
-                                                                float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                                                                float* __restrict__ mean_invstd) {
-    const int c = blockIdx.x;
+__device__ __forceinline__ void bn_tiles_finalize_body(const float4* __restrict__ st, long T, float eps, float momentum,
+                                                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                                       float* __restrict__ mean_invstd, int c) {
     if (c == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
     double count, m0, m1;
     tiles_combine(st, T, c, count, m0, m1);
     if (threadIdx.x == 0) finalize_channel(m0, m1, count > 0.0 ? count : 1.0, eps, momentum, running_mean, running_var, c, mean_invstd);
+}
+__global__ __launch_bounds__(256) void bn_tiles_finalize_kernel(const float4* __restrict__ st, long T, int C, float eps, float momentum,
+                                                                float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                                                float* __restrict__ mean_invstd) {
+    bn_tiles_finalize_body(st, T, eps, momentum, running_mean, running_var, num_batches_tracked, mean_invstd, (int)blockIdx.x);
 }
 
 // SyncBN form: the raw fp64 moments [C+1, 2] the exchange all-reduces (row C = this rank's element count)
@@ -849,4 +881,151 @@ extern "C" int cseg_bn_bwd_amax(const float* dy, const float* x, const float* ou
                                 cseg_stream_t stream_) {
     return bn_bwd_impl(dy, x, out, mean_invstd, weight, bias, mode, training, B, C, HW, ws, g_masked, d_weight, d_bias, dx,
                        amax_out, stream_);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Round 6: GROUPED launches -- the BatchNorm passes of several independent layers (the sites of one depth of HRNet's parallel
+// branches: reference lib/models/backbones/hrnet/hrnet_backbone.py:262-288 loops over the branches, :49-65 is the block) in ONE
+// launch per pass. The grid is the concatenation of the members' one-layer grids (member i owns blocks [block0_i, block0_{i+1})),
+// every block runs the one-layer kernel's body on its member with its local block index: bit-identical results, a quarter of the
+// launches, and the 5-us kernels of the coarse branches ride along with the fine branch's instead of paying a launch each.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct BnGM {
+    const float* x; const float* res; float* y; const float4* st; float* mi; const float* w; const float* b;
+    float* rm; float* rv; int64_t* nbt; unsigned* amax;
+    const float* dy; const float* out; float* g; float* dw; float* db; float* dx; float* ws;
+    BnDims d;
+    long T;
+    float eps, momentum;
+    int block0;
+};
+struct BnGArgs { BnGM m[CSEG_GROUP_MAX]; int n; };
+
+__device__ __forceinline__ int bn_group_member(const BnGArgs& a, int bid) {
+    int mi = 0;
+    for (int i = 1; i < a.n; ++i) mi = bid >= a.m[i].block0 ? i : mi;
+    return mi;
+}
+
+__global__ __launch_bounds__(256) void bn_group_tiles_finalize_kernel(const BnGArgs a) {
+    const BnGM& M = a.m[bn_group_member(a, (int)blockIdx.x)];
+    bn_tiles_finalize_body(M.st, M.T, M.eps, M.momentum, M.rm, M.rv, M.nbt, M.mi, (int)blockIdx.x - M.block0);
+}
+template <bool RES>
+__global__ __launch_bounds__(256) void bn_group_apply_kernel(const BnGArgs a, int relu) {
+    const BnGM& M = a.m[bn_group_member(a, (int)blockIdx.x)];
+    bn_apply_body<true, RES>(M.x, M.res, M.mi, M.w, M.b, M.d, relu, M.y, M.amax, (int)blockIdx.x - M.block0);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_group_bwd_reduce_kernel(const BnGArgs a) {
+    const BnGM& M = a.m[bn_group_member(a, (int)blockIdx.x)];
+    bn_bwd_reduce_body<true, MODE>(M.dy, M.x, M.out, M.mi, M.w, M.b, M.d, M.g, M.ws, (int)blockIdx.x - M.block0);
+}
+template <bool MASK, bool FROM_G>
+__global__ __launch_bounds__(256) void bn_group_bwd_apply_kernel(const BnGArgs a, int training) {
+    const BnGM& M = a.m[bn_group_member(a, (int)blockIdx.x)];
+    bn_bwd_apply_fused_body<true, MASK>(FROM_G ? M.g : M.dy, M.x, M.mi, M.w, M.b, M.ws, training, M.d, M.dw, M.db, M.dx, M.amax,
+                                        (int)blockIdx.x - M.block0);
+}
+
+int bn_group_fill(const char* who, const cseg_bn_group_member* mem, int n, int grid_kind, BnGArgs& a, long& total, bool& all_vec) {
+    CSEG_REQUIRE(mem && n >= 1 && n <= CSEG_GROUP_MAX, "%s: needs 1 .. %d members", who, CSEG_GROUP_MAX);
+    total = 0;
+    all_vec = true;
+    for (int i = 0; i < n; ++i) {
+        const cseg_bn_group_member& s = mem[i];
+        BnGM& m = a.m[i];
+        if (grid_kind != 0 && !check_dims(who, s.B, s.C, s.HW)) return 0;
+        CSEG_REQUIRE(s.C > 0, "%s: member %d has no channels", who, i);
+        m.x = s.x; m.res = s.residual; m.y = s.y; m.st = reinterpret_cast<const float4*>(s.stats); m.mi = s.mean_invstd; m.w = s.weight; m.b = s.bias;
+        m.rm = s.running_mean; m.rv = s.running_var; m.nbt = s.num_batches_tracked; m.amax = s.amax_out;
+        m.dy = s.dy; m.out = s.out; m.g = s.g_masked; m.dw = s.d_weight; m.db = s.d_bias; m.dx = s.dx; m.ws = s.ws;
+        m.d = grid_kind != 0 ? bn_dims(s.B, s.C, s.HW) : BnDims{s.B, s.C, s.HW, 0, 0};
+        m.T = s.T; m.eps = s.eps; m.momentum = s.momentum;
+        m.block0 = (int)total;
+        // 0: one block per channel; 1: one per (image, channel, chunk); 2: splits x channels (the reduction kernels)
+        total += grid_kind == 0 ? s.C : grid_kind == 1 ? (long)s.B * s.C * m.d.n_ck : (long)m.d.S * s.C;
+        CSEG_REQUIRE(total < 2147483647L, "%s: grid too large", who);
+    }
+    for (int i = n; i < CSEG_GROUP_MAX; ++i) a.m[i] = a.m[0];
+    a.n = n;
+    return 1;
+}
+
+}  // namespace
+
+// == cseg_bn_tiles_finalize per member (stats, T, eps, momentum, running statistics, num_batches_tracked -> mean_invstd)
+extern "C" int cseg_bn_group_tiles_finalize(const cseg_bn_group_member* mem, int n, cseg_stream_t stream_) {
+    BnGArgs a;
+    long total;
+    bool vec;
+    if (!bn_group_fill("bn_group_tiles_finalize", mem, n, 0, a, total, vec)) return 0;
+    for (int i = 0; i < n; ++i) {
+        CSEG_REQUIRE(mem[i].stats && mem[i].mean_invstd && mem[i].T > 0, "bn_group_tiles_finalize: member %d: bad arguments", i);
+        CSEG_REQUIRE((reinterpret_cast<uintptr_t>(mem[i].stats) & 15) == 0, "bn_group_tiles_finalize: member %d: the statistics buffer must be 16-byte aligned", i);
+        CSEG_REQUIRE((mem[i].running_mean == nullptr) == (mem[i].running_var == nullptr), "bn_group_tiles_finalize: running_mean/var must come together");
+    }
+    hipLaunchKernelGGL(bn_group_tiles_finalize_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream_, a);
+    CSEG_CHECK_LAUNCH("bn_group_tiles_finalize");
+    return 1;
+}
+
+// == cseg_bn_apply_amax per member (x, residual, mean_invstd, weight, bias -> y, amax_out). Members that cannot take the 16-byte path
+// (H*W not a multiple of 4, unaligned pointers), or a group that mixes members with and without a residual, run one launch per member.
+extern "C" int cseg_bn_group_apply(const cseg_bn_group_member* mem, int n, int relu, cseg_stream_t stream_) {
+    BnGArgs a;
+    long total;
+    bool vec;
+    if (!bn_group_fill("bn_group_apply", mem, n, 1, a, total, vec)) return 0;
+    bool grouped = true;
+    for (int i = 0; i < n; ++i) {
+        CSEG_REQUIRE(mem[i].x && mem[i].mean_invstd && mem[i].y, "bn_group_apply: member %d: null pointer", i);
+        grouped = grouped && vec_ok(mem[i].HW, mem[i].x, mem[i].residual, mem[i].y) && ((mem[i].residual != nullptr) == (mem[0].residual != nullptr));
+    }
+    if (!grouped) {
+        for (int i = 0; i < n; ++i)
+            if (!bn_apply_impl(mem[i].x, mem[i].residual, mem[i].mean_invstd, mem[i].weight, mem[i].bias, relu, mem[i].B, mem[i].C, mem[i].HW,
+                               mem[i].y, mem[i].amax_out, stream_))
+                return 0;
+        return 1;
+    }
+    if (mem[0].residual) hipLaunchKernelGGL(bn_group_apply_kernel<true>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream_, a, relu);
+    else hipLaunchKernelGGL(bn_group_apply_kernel<false>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream_, a, relu);
+    CSEG_CHECK_LAUNCH("bn_group_apply");
+    return 1;
+}
+
+// == cseg_bn_bwd_amax per member (dy, x, out, mean_invstd, weight, bias, ws -> g_masked, d_weight, d_bias, dx, amax_out), dx wanted
+// for every member: two launches for the whole group (reduction, apply).
+extern "C" int cseg_bn_group_bwd(const cseg_bn_group_member* mem, int n, int mode, int training, cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CSEG_REQUIRE(mode >= 0 && mode <= 2, "bn_group_bwd: mode %d", mode);
+    BnGArgs a;
+    long total;
+    bool vec;
+    if (!bn_group_fill("bn_group_bwd", mem, n, 2, a, total, vec)) return 0;
+    bool grouped = true;
+    for (int i = 0; i < n; ++i) {
+        CSEG_REQUIRE(mem[i].dy && mem[i].x && mem[i].mean_invstd && mem[i].ws, "bn_group_bwd: member %d: null pointer", i);
+        CSEG_REQUIRE(mode != 2 || (mem[i].out && mem[i].g_masked), "bn_group_bwd: mode 2 needs `out` and `g_masked`");
+        grouped = grouped && mem[i].dx && vec_ok(mem[i].HW, mem[i].dy, mem[i].x, mem[i].out, mem[i].g_masked) && vec_ok(mem[i].HW, mem[i].dx);
+    }
+    if (!grouped) {
+        for (int i = 0; i < n; ++i)
+            if (!bn_bwd_impl(mem[i].dy, mem[i].x, mem[i].out, mem[i].mean_invstd, mem[i].weight, mem[i].bias, mode, training, mem[i].B, mem[i].C,
+                             mem[i].HW, mem[i].ws, mem[i].g_masked, mem[i].d_weight, mem[i].d_bias, mem[i].dx, mem[i].amax_out, stream_))
+                return 0;
+        return 1;
+    }
+    if (mode == 0) hipLaunchKernelGGL(bn_group_bwd_reduce_kernel<0>, dim3((unsigned)total), dim3(256), 0, stream, a);
+    else if (mode == 1) hipLaunchKernelGGL(bn_group_bwd_reduce_kernel<1>, dim3((unsigned)total), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(bn_group_bwd_reduce_kernel<2>, dim3((unsigned)total), dim3(256), 0, stream, a);
+    if (!bn_group_fill("bn_group_bwd", mem, n, 1, a, total, vec)) return 0;
+    if (mode == 1) hipLaunchKernelGGL((bn_group_bwd_apply_kernel<true, false>), dim3((unsigned)total), dim3(256), 0, stream, a, training);
+    else if (mode == 2) hipLaunchKernelGGL((bn_group_bwd_apply_kernel<false, true>), dim3((unsigned)total), dim3(256), 0, stream, a, training);
+    else hipLaunchKernelGGL((bn_group_bwd_apply_kernel<false, false>), dim3((unsigned)total), dim3(256), 0, stream, a, training);
+    CSEG_CHECK_LAUNCH("bn_group_bwd");
+    return 1;
 }

@@ -14,4 +14,4 @@ void cseg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* cseg_last_error(void) { return g_err; }
-extern "C" int cseg_abi_version(void) { return 5; }   // 2: bn_* entry points, lse buffer of upsample_ce; 3: cseg_*_split_* (selectable arithmetic), cseg_amax_f32; 4: count row of the BN moments / sums; 5: cseg_contrast_fwd_fused, cseg_conv3x3_split_dil_fwd, any width in the split kernels
+extern "C" int cseg_abi_version(void) { return 6; }   // 6: grouped launches (cseg_*_group_*), CSEG_NT_GROUP; 2: bn_* entry points, lse buffer of upsample_ce; 3: cseg_*_split_* (selectable arithmetic), cseg_amax_f32; 4: count row of the BN moments / sums; 5: cseg_contrast_fwd_fused, cseg_conv3x3_split_dil_fwd, any width in the split kernels

@@ -279,13 +279,14 @@ __device__ __forceinline__ int d2_idx(int buf, int p, int co, int i) { return ((
 // of HRNet at 520 x 520). The last segment of a row is partly outside the image and rows are not 16-byte aligned any more: the
 // loaders fetch the four pixels of a chunk one by one from columns clamped into the row and zero what lies outside (as they already
 // do for the halo columns); the consumers see full zero-padded segments and do not change.
+// (`bid`: the block's index inside THIS layer's grid -- blockIdx.x for the one-layer launch, blockIdx.x minus the member's first block,
+// a multiple of 8, in the grouped launch conv3x3_wrw2_group_kernel below; `smem_w`: the block's dynamic LDS)
 template <class AR, int SEGW, int ABL = 0, bool RAGGED = false>
-__global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                 int B, int Cin, int Cout, int H, int W, int n_split, int rpu,
-                                                                 int SC, int SI, const unsigned* __restrict__ amax_x,
-                                                                 const unsigned* __restrict__ amax_dy,
-                                                                 float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem_w[];
+__device__ __forceinline__ void conv3x3_sb_wrw2_body(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     int B, int Cin, int Cout, int H, int W, int n_split, int rpu,
+                                                     int SC, int SI, const unsigned* __restrict__ amax_x,
+                                                     const unsigned* __restrict__ amax_dy,
+                                                     float* __restrict__ partial, int bid, unsigned short* smem_w) {
     constexpr int NP = AR::NP;
     typedef typename AR::frag_t frag_t;
     unsigned short* xs = smem_w;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
     {
         const int n_cob = Cout / CO_B;
         const int n_si = n_cib / SI, gsz = SC * SI, n_groups = n_split * (n_cob / SC) * n_si;
-        const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+        const int xcd = bid & 7, l = bid >> 3;
         const int grp = (l / gsz) * 8 + xcd, j = l % gsz;
         if (grp >= n_groups) return;                   // the grid is rounded up to 8 x groups-per-XCD x group size
         split = grp % n_split;
@@ -624,12 +625,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __
     }
 }
 
+template <class AR, int SEGW, int ABL = 0, bool RAGGED = false>
+__global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 int B, int Cin, int Cout, int H, int W, int n_split, int rpu,
+                                                                 int SC, int SI, const unsigned* __restrict__ amax_x,
+                                                                 const unsigned* __restrict__ amax_dy,
+                                                                 float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_w2[];
+    conv3x3_sb_wrw2_body<AR, SEGW, ABL, RAGGED>(x, dy, B, Cin, Cout, H, W, n_split, rpu, SC, SI, amax_x, amax_dy, partial, (int)blockIdx.x, smem_w2);
+}
+
 // dW[co][ci][tap] = sum over splits of partial[split][tap][co][ci], fixed order (same scheme as conv3x3.hip)
-__global__ __launch_bounds__(256) void sb_wrw_reduce_kernel(const float* __restrict__ partial, int n_split, int Cout, int Cin,
-                                                            float* __restrict__ dw) {
+__device__ __forceinline__ void sb_wrw_reduce_body(const float* __restrict__ partial, int n_split, int Cout, int Cin,
+                                                   float* __restrict__ dw, int bid) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + lane;                  // e = (tap * Cout + co) * Cin + ci
+    const int e = bid * 64 + lane;                         // e = (tap * Cout + co) * Cin + ci
     const int total = 9 * Cout * Cin;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (e < total) {
@@ -650,6 +661,10 @@ __global__ __launch_bounds__(256) void sb_wrw_reduce_kernel(const float* __restr
         const int co = rest % Cout, tap = rest / Cout;
         dw[((size_t)co * Cin + ci) * 9 + tap] = v;
     }
+}
+__global__ __launch_bounds__(256) void sb_wrw_reduce_kernel(const float* __restrict__ partial, int n_split, int Cout, int Cin,
+                                                            float* __restrict__ dw) {
+    sb_wrw_reduce_body(partial, n_split, Cout, Cin, dw, (int)blockIdx.x);
 }
 
 int sb_wrw_version() {
@@ -805,7 +820,122 @@ int wrw_impl(const float* x, const float* dy, int B, int Cin, int Cout, int H, i
     return 1;
 }
 
+
+// ---- Round 6: the weight gradients of several independent convolutions in ONE launch (+ one for the fixed-order reductions):
+// the layers of one depth of HRNet's parallel branches (reference lib/models/backbones/hrnet/hrnet_backbone.py:262-288). The grid is
+// the concatenation of the members' one-layer grids (each a multiple of 8 blocks, so the XCD-aware order of a member is kept), every
+// block runs conv3x3_sb_wrw2_body on its member with the split count the one-layer launch would use: bit-identical gradients.
+struct WrwGM {
+    const float* x; const float* dy; const unsigned* amax_x; const unsigned* amax_dy; float* ws; float* dw;
+    int B, Cin, Cout, H, W, n_split, rpu, SC, SI, kind, block0, rblock0;      // kind: bit 0 = 32-pixel segments, bit 1 = ragged width
+};
+struct WrwGArgs { WrwGM m[CSEG_GROUP_MAX]; int n; };
+
+template <int SEGW>
+__global__ __launch_bounds__(512, 1) void conv3x3_wrw2_group_kernel(const WrwGArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_wg[];
+    int mi = 0;
+    for (int i = 1; i < a.n; ++i) mi = (int)blockIdx.x >= a.m[i].block0 ? i : mi;
+    const WrwGM& M = a.m[mi];
+    conv3x3_sb_wrw2_body<SplitF16x3, SEGW, 0, false>(M.x, M.dy, M.B, M.Cin, M.Cout, M.H, M.W, M.n_split, M.rpu, M.SC, M.SI, M.amax_x, M.amax_dy, M.ws,
+                                                     (int)blockIdx.x - M.block0, smem_wg);
+}
+__global__ __launch_bounds__(256) void sb_wrw_reduce_group_kernel(const WrwGArgs a) {
+    int mi = 0;
+    for (int i = 1; i < a.n; ++i) mi = (int)blockIdx.x >= a.m[i].rblock0 ? i : mi;
+    const WrwGM& M = a.m[mi];
+    sb_wrw_reduce_body(M.ws, M.n_split, M.Cout, M.Cin, M.dw, (int)blockIdx.x - M.rblock0);
+}
+
+template <int SEGW>
+int launch_wrw2_group(const WrwGArgs& a, long blocks, hipStream_t stream) {
+    const size_t lds = sizeof(unsigned short) * (x2_elems(2, SEGW) + d2_elems(2, SEGW));
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv3x3_wrw2_group_kernel<SEGW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            cseg_set_error("conv3x3 group wrw: cannot raise dynamic LDS to %zu bytes", lds);
+            return 0;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_wrw2_group_kernel<SEGW>, dim3((unsigned)blocks), dim3(512), lds, stream, a);
+    CSEG_CHECK_LAUNCH("conv3x3_wrw2_group_kernel");
+    return 1;
+}
+
+int wrw_group_impl(const cseg_wrw_group_member* mem, int n, hipStream_t stream) {
+    bool any_ragged = false;
+    for (int i = 0; i < n; ++i) {
+        const cseg_wrw_group_member& s = mem[i];
+        CSEG_REQUIRE(s.x && s.dy && s.ws && s.dw && s.amax_x && s.amax_dy, "conv3x3 group wrw: member %d has a null pointer", i);
+        CSEG_REQUIRE(s.B > 0 && s.H > 0 && s.W > 0 && s.Cin > 0 && s.Cout > 0 && s.Cin % 16 == 0 && s.Cout % CO_B == 0,
+                     "conv3x3 group wrw: member %d: unsupported shape B=%d Cin=%d Cout=%d %dx%d (needs Cin %% 16, Cout %% 48)", i, s.B, s.Cin, s.Cout,
+                     s.H, s.W);
+        any_ragged = any_ragged || wrw2_ragged(s.W);
+    }
+    if (any_ragged) {                               // widths that are not multiples of the row segment: one launch per member (same results)
+        for (int i = 0; i < n; ++i)
+            if (!wrw_impl(mem[i].x, mem[i].dy, mem[i].B, mem[i].Cin, mem[i].Cout, mem[i].H, mem[i].W, CSEG_ARITH_F16X3, mem[i].amax_x, mem[i].amax_dy,
+                          mem[i].ws, mem[i].dw, stream))
+                return 0;
+        return 1;
+    }
+    WrwGArgs all;                                   // every member (the reduction launch), and the members of one segment width each
+    long rblocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const cseg_wrw_group_member& s = mem[i];
+        CSEG_REQUIRE((reinterpret_cast<uintptr_t>(s.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(s.dy) & 15) == 0,
+                     "conv3x3 group wrw: member %d: tensors must be 16-byte aligned", i);
+        CSEG_REQUIRE((long)s.Cin * s.H * s.W * 4 < 2147483647L && (long)s.Cout * s.H * s.W * 4 < 2147483647L && (long)9 * s.Cin * s.Cout < 2147483647L,
+                     "conv3x3 group wrw: member %d: one image of x / dy must stay below 2 GiB (32-bit offsets)", i);
+        WrwGM& m = all.m[i];
+        m.x = s.x; m.dy = s.dy; m.amax_x = s.amax_x; m.amax_dy = s.amax_dy; m.ws = s.ws; m.dw = s.dw;
+        m.B = s.B; m.Cin = s.Cin; m.Cout = s.Cout; m.H = s.H; m.W = s.W;
+        m.n_split = sb_wrw_splits(s.B, s.Cin, s.Cout, s.H, s.W, CSEG_ARITH_F16X3);
+        m.rpu = wrw2_rpu(s.H);
+        const int n_cob = s.Cout / CO_B, n_cib = (s.Cin + CI_B - 1) / CI_B;
+        sb_wrw_group(n_cob, n_cib, m.SC, m.SI);
+        m.kind = wrw2_seg(s.W) == 64 ? 0 : 1;
+        m.block0 = 0;
+        m.rblock0 = (int)rblocks;
+        rblocks += (9L * s.Cin * s.Cout + 63) / 64;
+        CSEG_REQUIRE(rblocks < 2147483647L, "conv3x3 group wrw: grid too large");
+    }
+    for (int i = n; i < CSEG_GROUP_MAX; ++i) all.m[i] = all.m[0];
+    all.n = n;
+    for (int kind = 0; kind < 2; ++kind) {
+        WrwGArgs a;
+        long blocks = 0;
+        int k = 0;
+        for (int i = 0; i < n; ++i) {
+            if (all.m[i].kind != kind) continue;
+            a.m[k] = all.m[i];
+            const WrwGM& m = a.m[k];
+            const long n_groups = (long)m.n_split * ((m.Cout / CO_B) / m.SC) * (((m.Cin + CI_B - 1) / CI_B) / m.SI);
+            a.m[k].block0 = (int)blocks;
+            blocks += ((n_groups + 7) / 8) * 8 * m.SC * m.SI;
+            CSEG_REQUIRE(blocks < 2147483647L, "conv3x3 group wrw: grid too large");
+            ++k;
+        }
+        if (k == 0) continue;
+        for (int i = k; i < CSEG_GROUP_MAX; ++i) a.m[i] = a.m[0];
+        a.n = k;
+        if (!(kind == 0 ? launch_wrw2_group<64>(a, blocks, stream) : launch_wrw2_group<32>(a, blocks, stream))) return 0;
+    }
+    hipLaunchKernelGGL(sb_wrw_reduce_group_kernel, dim3((unsigned)rblocks), dim3(256), 0, stream, all);
+    CSEG_CHECK_LAUNCH("sb_wrw_reduce_group_kernel");
+    return 1;
+}
+
 }  // namespace
+
+// == cseg_conv3x3_split_wrw (f16x3) per member: dw_i [Cout, Cin, 3, 3] of conv2d(x_i, w_i, stride 1, padding 1) for the output gradient
+// dy_i; ws_i = cseg_conv3x3_sb_wrw_ws_floats(B, Cin, Cout, H, W) floats. Two launches for the whole group.
+extern "C" int cseg_conv3x3_split_group_wrw(const cseg_wrw_group_member* mem, int n, int arith, cseg_stream_t stream_) {
+    CSEG_REQUIRE(mem && n >= 1 && n <= CSEG_GROUP_MAX, "conv3x3 group wrw: needs 1 .. %d members", CSEG_GROUP_MAX);
+    CSEG_REQUIRE(arith == CSEG_ARITH_F16X3, "conv3x3 group wrw: f16x3 arithmetic only (got %d)", arith);
+    return wrw_group_impl(mem, n, (hipStream_t)stream_);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Stride 2 (round 3): dW[co][ci][ky][kx] = sum_{b,oy,ox} dy[b][co][oy][ox] * x[b][ci][2 oy + ky - 1][2 ox + kx - 1]   (pad 1, x is

@@ -1598,6 +1598,243 @@ def basic_block_split(x, blk):
 
 
 # ----------------------------------------------------------------------------------------------------------
+# Round 6: GROUPED launches over the parallel branches of an HRNet exchange unit. Reference shape of the work:
+# lib/models/backbones/hrnet/hrnet_backbone.py:262-288 loops over the branches in Python; at every depth of the residual chains the
+# n = 2..4 BasicBlocks (:49-65) are independent, of equal flops and of very different shape. Through round 5 every (branch, conv / BN
+# pass) was its own launch -- 2 780 dispatches per batch-8 step, 1 664 of them inside these blocks, the coarse branches' launches too
+# small for 256 CUs -- with the branches forked onto four HIP streams to get some overlap back. Here ONE autograd node runs a whole
+# depth: 6 launches forward (conv group, statistics finalisation, apply; twice), 10 backward, whatever n is; the library's grouped
+# entry points (include/cseg_hip.h, ABI 6) schedule the members' tiles inside one kernel. Results per member are those of the one-layer
+# calls with the group's tile body (nt = CSEG_NT_GROUP): bit-identical (tests/test_emu_group.py, tools/probes/group_probe.cpp).
+# CSEG_BLOCK_GROUP=0 restores the per-branch nodes (and with them the forked streams).
+# ----------------------------------------------------------------------------------------------------------
+BLOCK_GROUP = os.environ.get("CSEG_BLOCK_GROUP", "1") == "1"
+NT_GROUP = _hip.NT_GROUP
+_GROUP_SCHED = {}        # (device index, stream) -> scheduling record of the grouped convolution launches (zero between launches)
+
+
+def _group_sched(device):
+    key = (device.index, _hip.raw_stream()) if device.type == "cuda" else (-1, 0)
+    buf = _GROUP_SCHED.get(key)
+    if buf is None:
+        buf = _GROUP_SCHED[key] = torch.zeros(_hip.GROUP_SCHED_INTS, dtype=I32, device=device)       # zero ONCE: every launch leaves it zero
+    return buf
+
+
+def conv3x3_group_run(items, want_stats=False):
+    """items: [(x, weight, transpose_flip, ax, addend or None)] -> ([y], [stats or None]): one cseg_conv3x3_split_group_fwd launch.
+    y_i = conv2d(x_i, w_i, None, 1, 1) (transpose_flip: the backward-data operator) [+ addend_i]; want_stats: with the BatchNorm
+    statistics epilogue (not together with an addend)."""
+    n = len(items)
+    arr = (_hip.ConvGroupMember * n)()
+    ys, sts = [], []
+    stats_on = want_stats and CONV_EPILOGUE_STATS
+    for e, (x, weight, flip, ax, addend) in zip(arr, items):
+        co, ci = weight.shape[:2]
+        conv_in, conv_out = (co, ci) if flip else (ci, co)
+        B, _, H, W = x.shape
+        wp, aw = SPLIT_WEIGHTS.get(weight, "c3", flip, NT_GROUP)
+        y = torch.empty(B, conv_out, H, W, dtype=F32, device=x.device)
+        e.x, e.wp, e.y, e.amax_x, e.amax_w = _pq(x, "x").value, wp.data_ptr(), y.data_ptr(), ax.data_ptr(), aw.data_ptr()
+        if addend is not None:
+            e.addend = _pq(addend, "addend").value
+        st = None
+        if stats_on and addend is None:
+            st = tile_stats_buffer(0, conv_out, B, H, W, x.device)
+            e.stats = st.data_ptr()
+            tile_stats_attach(y, st)
+        e.B, e.Cin, e.Cout, e.H, e.W = B, conv_in, conv_out, H, W
+        ys.append(y)
+        sts.append(st)
+    _hip.call("cseg_conv3x3_split_group_fwd", ctypes.byref(arr), n, split_arith_id(), _pf(_group_sched(ys[0].device)), _hip.stream_ptr())
+    return ys, sts
+
+
+def conv3x3_group_wrw(items):
+    """items: [(x, dy, ax, ady)] -> [dw]: the weight gradients of the members' convolutions, two launches (cseg_conv3x3_split_group_wrw)."""
+    n = len(items)
+    arr = (_hip.WrwGroupMember * n)()
+    lib = _hip.lib()
+    dws, keep = [], []
+    for e, (x, dy, ax, ady) in zip(arr, items):
+        B, ci, H, W = x.shape
+        co = dy.shape[1]
+        nf = lib.cseg_conv3x3_sb_wrw_ws_floats(B, ci, co, H, W)
+        if nf == 0:
+            raise RuntimeError("conv3x3_group_wrw: unsupported shape %s x %s" % (tuple(x.shape), tuple(dy.shape)))
+        ws = torch.empty(nf, dtype=F32, device=x.device)
+        dw = torch.empty(co, ci, 3, 3, dtype=F32, device=x.device)
+        e.x, e.dy, e.amax_x, e.amax_dy, e.ws, e.dw = _pq(x, "x").value, _pq(dy, "dy").value, ax.data_ptr(), ady.data_ptr(), ws.data_ptr(), dw.data_ptr()
+        e.B, e.Cin, e.Cout, e.H, e.W = B, ci, co, H, W
+        dws.append(dw)
+        keep.append(ws)
+    _hip.call("cseg_conv3x3_split_group_wrw", ctypes.byref(arr), n, split_arith_id(), _hip.stream_ptr())
+    return dws
+
+
+def bn_group_fwd(xs, bns, residuals, relu):
+    """Single-rank training-mode BN(+residual)(+ReLU) of n independent sites whose inputs carry the producing convolution's epilogue
+    statistics -> ([y], [mean_invstd], [max|y| record]): cseg_bn_group_tiles_finalize + cseg_bn_group_apply, two launches."""
+    n = len(xs)
+    arr = (_hip.BnGroupMember * n)()
+    ys, mis, ams = [], [], []
+    for e, x, bn, r in zip(arr, xs, bns, residuals):
+        B, C, HW = _bn_dims(x)
+        st = known_tile_stats(x)
+        if st is None:
+            raise RuntimeError("bn_group_fwd: an input without epilogue statistics")
+        mi = torch.empty(C, 2, dtype=F32, device=x.device)
+        y = torch.empty_like(x)
+        am = amax_request(x)
+        p, b = bn._parameters, bn._buffers
+        e.x, e.y, e.stats, e.mean_invstd = x.data_ptr(), y.data_ptr(), st.data_ptr(), mi.data_ptr()
+        if r is not None:
+            e.residual = _pq(r, "residual").value
+        w_, b_ = p.get("weight"), p.get("bias")
+        if w_ is not None:
+            e.weight = w_.data_ptr()
+        if b_ is not None:
+            e.bias = b_.data_ptr()
+        rm, rv, nbt = b.get("running_mean"), b.get("running_var"), b.get("num_batches_tracked")
+        if rm is not None:
+            e.running_mean, e.running_var = rm.data_ptr(), rv.data_ptr()
+        if nbt is not None:
+            e.num_batches_tracked = nbt.data_ptr()
+        if am is not None:
+            e.amax_out = am.data_ptr()
+        e.B, e.C, e.HW, e.T, e.eps, e.momentum = B, C, HW, st.shape[1], float(bn.eps), float(bn.momentum)
+        ys.append(y)
+        mis.append(mi)
+        ams.append(am)
+    sp = _hip.stream_ptr()
+    _hip.call("cseg_bn_group_tiles_finalize", ctypes.byref(arr), n, sp)
+    _hip.call("cseg_bn_group_apply", ctypes.byref(arr), n, int(bool(relu)), sp)
+    return ys, mis, ams
+
+
+_BN_GROUP_WS = {}        # (device index, stream) -> reduction scratch of the grouped BN backward, grown on demand
+
+
+def bn_group_bwd(dys, xs, outs, mis, bns, mode):
+    """Adjoint of bn_group_fwd (training statistics, single rank) -> per site (dx, d_weight, d_bias, masked gradient or None, max|dx|
+    record): cseg_bn_group_bwd, two launches. mode: 1 = ReLU mask from x, 2 = from `out` (residual sites)."""
+    n = len(xs)
+    arr = (_hip.BnGroupMember * n)()
+    lib = _hip.lib()
+    needs, total = [], 0
+    for x in xs:
+        B, C, HW = _bn_dims(x)
+        nf = _BN_WS_NEED.get((B, C, HW))
+        if nf is None:
+            nf = _BN_WS_NEED[(B, C, HW)] = max(1, lib.cseg_bn_ws_floats(B, C, HW))
+        needs.append(total)
+        total += (nf + 63) // 64 * 64
+    dev = xs[0].device
+    key = (dev.index, _hip.raw_stream()) if dev.type == "cuda" else (-1, 0)
+    ws = _BN_GROUP_WS.get(key)
+    if ws is None or ws.numel() < total:
+        ws = _BN_GROUP_WS[key] = torch.empty(max(total, 1 << 17), dtype=F32, device=dev)
+    base = ws.data_ptr()
+    res = []
+    for e, dy, x, out, mi, bn, off in zip(arr, dys, xs, outs, mis, bns, needs):
+        B, C, HW = _bn_dims(x)
+        d_wb = torch.empty(2, C, dtype=F32, device=dev)
+        g = torch.empty_like(x) if mode == 2 else None
+        dx = torch.empty_like(x)
+        am = amax_request(x)
+        p = bn._parameters
+        e.dy, e.x, e.mean_invstd, e.dx, e.ws = _pq(dy, "dy").value, x.data_ptr(), mi.data_ptr(), dx.data_ptr(), base + 4 * off
+        e.d_weight, e.d_bias = d_wb.data_ptr(), d_wb.data_ptr() + 4 * C
+        if mode == 2:
+            e.out, e.g_masked = out.data_ptr(), g.data_ptr()
+        w_, b_ = p.get("weight"), p.get("bias")
+        if w_ is not None:
+            e.weight = w_.data_ptr()
+        if b_ is not None:
+            e.bias = b_.data_ptr()
+        if am is not None:
+            e.amax_out = am.data_ptr()
+        e.B, e.C, e.HW = B, C, HW
+        res.append((dx, d_wb[0], d_wb[1], g, am))
+    _hip.call("cseg_bn_group_bwd", ctypes.byref(arr), n, int(mode), 1, _hip.stream_ptr())
+    return res
+
+
+def basic_block_group_ok(blocks, xs):
+    """Every block of the depth qualifies for the grouped node: what BasicBlockSplit needs (split kernels in all three directions,
+    plain single-rank batch statistics from the convolution epilogues), f16x3, at least two members."""
+    if not (BLOCK_GROUP and 2 <= len(blocks) <= _hip.GROUP_MAX and split_arith_id() == ARITH_IDS["f16x3"] and CONV_EPILOGUE_STATS
+            and not _WGRAD["on"]):
+        return False
+    for blk, x in zip(blocks, xs):
+        c = blk.conv1.weight.shape[0]
+        if not (c >= 32 and blk.conv1.bn_follows and blk.conv2.bn_follows and blk.bn1.momentum is not None and blk.bn2.momentum is not None
+                and basic_block_split_ok(x, blk.conv1.weight, blk.conv2.weight)):
+            return False
+    return True
+
+
+class BasicBlockGroup(Function):
+    """n residual blocks (conv3x3 -> BN -> ReLU -> conv3x3 -> BN -> + x -> ReLU) of one depth of parallel branches as ONE node on
+    the grouped launches. tensors: per block x, w1, g1, b1, w2, g2, b2. Same arithmetic per block as BasicBlockSplit."""
+
+    @staticmethod
+    def forward(ctx, blocks, *tensors):
+        n = len(blocks)
+        xs = [tensors[7 * i].contiguous() for i in range(n)]
+        w1s = [tensors[7 * i + 1] for i in range(n)]
+        w2s = [tensors[7 * i + 4] for i in range(n)]
+        axs = [amax_of(x) for x in xs]
+        c1s, _ = conv3x3_group_run([(x, w, False, ax, None) for x, w, ax in zip(xs, w1s, axs)], want_stats=True)
+        a1s, mi1, am1 = bn_group_fwd(c1s, [b.bn1 for b in blocks], [None] * n, True)
+        c2s, _ = conv3x3_group_run([(a, w, False, am, None) for a, w, am in zip(a1s, w2s, am1)], want_stats=True)
+        outs, mi2, am2 = bn_group_fwd(c2s, [b.bn2 for b in blocks], xs, True)
+        for o, am in zip(outs, am2):
+            amax_attach(o, am)
+        ctx.blocks, ctx.axs, ctx.am1 = blocks, axs, am1
+        ctx.save_for_backward(*(xs + c1s + a1s + c2s + outs + mi1 + mi2))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        blocks, axs, am1 = ctx.blocks, ctx.axs, ctx.am1
+        n = len(blocks)
+        sv = ctx.saved_tensors
+        xs, c1s, a1s, c2s, outs, mi1, mi2 = (list(sv[k * n:(k + 1) * n]) for k in range(7))
+        need = ctx.needs_input_grad
+        dys = [d.contiguous() for d in dys]
+        # bn2 + add + ReLU (mask from `out`; the masked gradient g is also the identity path's gradient)
+        r2 = bn_group_bwd(dys, c2s, outs, mi2, [b.bn2 for b in blocks], 2)
+        da1s, _ = conv3x3_group_run([(r2[i][0], blocks[i].conv2.weight, True, r2[i][4], None) for i in range(n)])
+        dw2s = conv3x3_group_wrw([(a1s[i], r2[i][0], am1[i], r2[i][4]) for i in range(n)])
+        # bn1 + ReLU (mask recomputed from c1)
+        r1 = bn_group_bwd(da1s, c1s, [None] * n, mi1, [b.bn1 for b in blocks], 1)
+        # conv1: backward-data with the identity path's gradient added in the epilogue
+        dxs, _ = conv3x3_group_run([(r1[i][0], blocks[i].conv1.weight, True, r1[i][4], r2[i][3]) for i in range(n)])
+        dw1s = conv3x3_group_wrw([(xs[i], r1[i][0], axs[i], r1[i][4]) for i in range(n)])
+        grads = [None]
+        for i, blk in enumerate(blocks):
+            _, dg1, db1, _, _ = r1[i]
+            _, dg2, db2, _, _ = r2[i]
+            grads += [dxs[i] if need[1 + 7 * i] else None, dw1s[i] if need[2 + 7 * i] else None,
+                      dg1 if blk.bn1.weight is not None else None, db1 if blk.bn1.bias is not None else None,
+                      dw2s[i] if need[5 + 7 * i] else None,
+                      dg2 if blk.bn2.weight is not None else None, db2 if blk.bn2.bias is not None else None]
+        return tuple(grads)
+
+
+def basic_block_group(blocks, xs):
+    """The residual blocks of one depth of parallel branches on inputs xs -> outputs, as ONE node on the grouped launches, or None
+    when a block does not qualify (the caller then runs the branches one by one)."""
+    if not basic_block_group_ok(blocks, xs):
+        return None
+    tensors = []
+    for blk, x in zip(blocks, xs):
+        tensors += [x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias]
+    return list(BasicBlockGroup.apply(tuple(blocks), *tensors))
+
+
+# ----------------------------------------------------------------------------------------------------------
 # Dilated 3x3 convolutions (round 5, csrc/conv3x3_sb16.hip: conv3x3_sb16d_kernel): rate 2 / 4, padding = rate, stride 1 -- layer3 / layer4
 # of the dilated ResNet encoders of DeepLab-V3 (reference lib/models/backbones/resnet/resnet_backbone.py:88-101). Forward and
 # backward-data on the split kernel (f16x3), weight / bias gradients on MIOpen.

@@ -352,9 +352,34 @@ class HighResolutionModule(nn.Module):
             outs[i + 1].record_stream(cur)
         return outs
 
+    def _branches_grouped(self, x):
+        """Round 6, single rank: the branches advance depth by depth, every depth ONE autograd node on the grouped launches
+        (kernels.BasicBlockGroup: the convolutions / BatchNorm passes / weight gradients of all n branches in one kernel each) -- the
+        reference's loop over the branches (hrnet_backbone.py:262-288) turned inside out. Returns None when a block of the first depth
+        does not qualify (eval mode, frozen statistics, strict-fp32 arithmetic, CSEG_BLOCK_GROUP=0 ...): the caller then takes the
+        per-branch path."""
+        group = getattr(K, "basic_block_group", None)
+        if group is None or not getattr(K, "BLOCK_GROUP", False):
+            return None
+        x = list(x)
+        for k in range(len(self.branches[0])):
+            blocks = [branch[k] for branch in self.branches]
+            out = group(blocks, x) if all(blk._fused_route(xi) for blk, xi in zip(blocks, x)) else None
+            if out is None:
+                if k == 0:
+                    return None
+                out = [blk(xi) for blk, xi in zip(blocks, x)]
+            x = out
+        return x
+
     def forward(self, x):
         sync = self._sync_active()
-        if sync and self.num_branches > 1:
+        grouped = None
+        if not sync and self.num_branches > 1 and self.training:
+            grouped = self._branches_grouped(x)
+        if grouped is not None:
+            x = grouped
+        elif sync and self.num_branches > 1:
             x = self._branches_lockstep(x)
         elif self.num_branches > 1 and _capture_forks(x[0]):
             x = self._branches_forked(x)

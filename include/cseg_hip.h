@@ -401,7 +401,7 @@ int cseg_conv3x3_split_wrw(const float* x, const float* dy, int B, int Cin, int 
  *   packed with nt = CSEG_NT_GROUP (16-channel-chunk format, three 16-channel tiles per unit; transpose_flip for backward-data).
  *   One persistent launch: every XCD pulls (member, 4 x 64-pixel tile, 48-channel group) units from its own queue, heaviest members
  *   first. == cseg_conv3x3_split_fwd / _fwd_st / _fwd_add with nt = CSEG_NT_GROUP per member.
- *   sched: CSEG_GROUP_SCHED_INTS int32 on the device, 128-byte aligned, ZERO before the first launch that uses it; every launch
+ *   sched: CSEG_GROUP_SCHED_INTS int32 on the device (best 128-byte aligned: one counter per cache line), ZERO before the first launch that uses it; every launch
  *   leaves it zero again, so one record serves all launches of a stream (not two launches that may run concurrently).
  * ------------------------------------------------------------------------------------------------ */
 #define CSEG_GROUP_MAX 8
@@ -420,6 +420,54 @@ typedef struct cseg_conv_group_member {
     int reserved[3];
 } cseg_conv_group_member;
 int cseg_conv3x3_split_group_fwd(const cseg_conv_group_member* members, int n, int arith, int* sched, cseg_stream_t stream);
+/* The BatchNorm passes of the members in one launch per pass (grid = the members' one-layer grids back to back). Fields a call does
+ * not use may be NULL / 0. Members whose plane size is not a multiple of 4 floats (or unaligned) make the call fall back to one launch
+ * per member -- same results.
+ *   cseg_bn_group_tiles_finalize  == cseg_bn_tiles_finalize per member: stats [C][T][4] -> mean_invstd [C,2], running statistics,
+ *                                    num_batches_tracked.
+ *   cseg_bn_group_apply           == cseg_bn_apply_amax per member: y = act(bn(x) [+ residual]), max|y| into amax_out.
+ *   cseg_bn_group_bwd             == cseg_bn_bwd_amax per member (mode / training as there; ws = cseg_bn_ws_floats(B, C, HW) floats
+ *                                    per member): g_masked (mode 2), d_weight, d_bias, dx, max|dx| into amax_out. Two launches. */
+typedef struct cseg_bn_group_member {
+    const float* x;            /* [B, C, HW] the BatchNorm's input (the convolution's output) */
+    const float* residual;     /* apply: [B, C, HW] or NULL */
+    float* y;                  /* apply: output */
+    const float* stats;        /* tiles_finalize: the convolution epilogue's records */
+    float* mean_invstd;        /* [C, 2]: written by tiles_finalize, read by apply / bwd */
+    const float* weight;       /* [C] or NULL */
+    const float* bias;         /* [C] or NULL */
+    float* running_mean;       /* [C] or NULL (with running_var) */
+    float* running_var;
+    int64_t* num_batches_tracked;
+    unsigned* amax_out;        /* max|.| record of what apply / bwd write (y / dx), or NULL */
+    const float* dy;           /* bwd: gradient of the output */
+    const float* out;          /* bwd mode 2: the forward's output (ReLU mask) */
+    float* g_masked;           /* bwd mode 2: masked gradient (= the residual's gradient) */
+    float* d_weight;           /* bwd: [C] */
+    float* d_bias;             /* bwd: [C] */
+    float* dx;                 /* bwd: [B, C, HW] */
+    float* ws;                 /* bwd: scratch */
+    int B, C, HW;
+    long T;                    /* tiles_finalize: records per channel */
+    float eps, momentum;
+} cseg_bn_group_member;
+int cseg_bn_group_tiles_finalize(const cseg_bn_group_member* members, int n, cseg_stream_t stream);
+int cseg_bn_group_apply(const cseg_bn_group_member* members, int n, int relu, cseg_stream_t stream);
+int cseg_bn_group_bwd(const cseg_bn_group_member* members, int n, int mode, int training, cseg_stream_t stream);
+/* The weight gradients of the members' convolutions (3x3 / stride 1 / pad 1, f16x3): == cseg_conv3x3_split_wrw per member (same split
+ * counts, same fixed-order reductions: bit-identical), two launches for the group. ws = cseg_conv3x3_sb_wrw_ws_floats(B, Cin, Cout, H, W)
+ * floats per member. */
+typedef struct cseg_wrw_group_member {
+    const float* x;            /* [B, Cin, H, W] the convolution's input */
+    const float* dy;           /* [B, Cout, H, W] gradient of its output */
+    const unsigned* amax_x;    /* max|x| record */
+    const unsigned* amax_dy;   /* max|dy| record */
+    float* ws;                 /* scratch */
+    float* dw;                 /* [Cout, Cin, 3, 3] */
+    int B, Cin, Cout, H, W;
+    int reserved[3];
+} cseg_wrw_group_member;
+int cseg_conv3x3_split_group_wrw(const cseg_wrw_group_member* members, int n, int arith, cseg_stream_t stream);
 /* ---- stride 2 (round 3): the 3x3 / stride 2 / pad 1 convolutions of HRNet's fuse and transition layers (reference:
  * lib/models/backbones/hrnet/hrnet_backbone.py:230-250 fuse layers, :652-660 transition layers -- nn.Conv2d(.., 3, 2, 1, bias=False)),
  * f16x3 arithmetic only. x is [B, Cin, 2 Ho, 2 Wo], y / dy are [B, Cout, Ho, Wo].

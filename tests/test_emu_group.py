@@ -47,7 +47,10 @@ def test_group_forward_equals_the_one_layer_launches_bit_for_bit(shapes, wave_or
         y1, st1 = E.conv3x3_sb_st(m["x"], m["w"], m["bias"], nt=E.NT_GROUP)
         assert not np.isnan(y).any() and not np.isnan(st[..., :3]).any()
         assert np.array_equal(y, y1)
-        assert np.array_equal(st[..., :3], st1[..., :3])
+        # (count, mean, M2) per row segment: this kernel's own fixed summation order -- equal to the one-layer kernel's to rounding
+        assert np.array_equal(st[..., 0], st1[..., 0])
+        assert np.abs(st[..., 1] - st1[..., 1]).max() <= 2e-6 * max(1.0, np.abs(st1[..., 1]).max())
+        assert np.abs(st[..., 2] - st1[..., 2]).max() <= 1e-5 * max(1.0, np.abs(st1[..., 2]).max())
         ref = E.ref_conv3x3(m["x"], m["w"], m["bias"])
         assert np.abs(y - ref).max() <= _bound(ref, 9 * m["x"].shape[1])
 
@@ -74,3 +77,65 @@ def test_group_rejects_what_it_does_not_cover():
     x, w = _rand((1, 16, 4, 8), 1), _rand((48, 16, 3, 3), 2)
     with pytest.raises(RuntimeError, match="Cin >= 32"):
         E.conv3x3_group([dict(x=x, w=w)])
+
+
+# ---- the autograd node on top of the grouped launches -------------------------------------------------------------------------
+import torch
+
+from tests.emu import inject
+
+
+@pytest.mark.parametrize("channels,shapes", [((48, 96), ((6, 40), (3, 20))), ((48, 96, 192), ((8, 64), (4, 32), (2, 16)))])
+def test_grouped_depth_node_equals_the_per_branch_nodes_bit_for_bit(channels, shapes, monkeypatch):
+    """kernels.BasicBlockGroup (ONE autograd node for the residual blocks of a depth of HRNet's parallel branches, on the grouped
+    conv / BatchNorm / weight-gradient launches) against one kernels.BasicBlockSplit per branch with the group's tile body
+    (nt = CSEG_NT_GROUP): outputs, every gradient, running statistics, num_batches_tracked and the max|.| records are bit-identical
+    over two consecutive steps; the grouped node issues 12 library calls (16 launches) per depth whatever the number of branches."""
+    from contrastiveseg_amd import kernels as K
+    from contrastiveseg_amd.lib.models.backbones.hrnet_backbone import BasicBlock
+    from contrastiveseg_amd.lib.models.tools.module_helper import mark_conv_bn_pairs
+    inject.install(monkeypatch)
+    monkeypatch.setattr(K, "SPLIT_ARITH", "f16x3")
+    monkeypatch.setattr(K, "SPLIT_WEIGHTS", K.SplitWeights())
+    monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
+    monkeypatch.setattr(K, "CONV_EPILOGUE_STATS", True)
+    monkeypatch.setattr(K, "_GROUP_SCHED", {})
+    # the per-branch nodes on the group's tile body: every channel count asks for nt = CSEG_NT_GROUP
+    monkeypatch.setattr(K, "CONV3X3_SB_PICK_NT_CHANNELS", tuple(channels))
+    monkeypatch.setattr(K, "conv3x3_sb_pick_nt", lambda x, c: K.NT_GROUP)
+    monkeypatch.setattr(K, "conv3x3_sb_tiles", lambda x, c: 1 << 20)          # (the routing threshold counts blocks of the default tiling)
+    torch.manual_seed(sum(channels))
+    blocks = [mark_conv_bn_pairs(BasicBlock(c, c, bn_type="torchbn").train()) for c in channels]
+    x0 = [torch.randn(2, c, *hw) * 0.7 + 0.1 for c, hw in zip(channels, shapes)]
+    gy = [torch.randn(2, c, *hw) for c, hw in zip(channels, shapes)]
+    res = {}
+    for grouped in (False, True):
+        for blk in blocks:
+            blk.zero_grad()
+            for bn in (blk.bn1, blk.bn2):
+                bn.reset_running_stats()
+        calls = []
+        orig = K._hip.call
+        monkeypatch.setattr(K._hip, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+        out = []
+        for step in range(2):
+            xs = [(x.clone() * 1.0).requires_grad_(True) for x in x0]
+            ins = [x * 1.0 for x in xs]                  # non-leaf inputs, as inside the network
+            if grouped:
+                ys = K.basic_block_group(blocks, ins)
+                assert ys is not None
+            else:
+                ys = [K.basic_block_split(xi, blk) for xi, blk in zip(ins, blocks)]
+            assert all(K.known_amax(y) is not None for y in ys)
+            torch.autograd.backward(ys, gy)
+            for y, x, blk in zip(ys, xs, blocks):
+                out += [y.detach().clone(), x.grad.clone(), blk.conv1.weight.grad.clone(), blk.conv2.weight.grad.clone(),
+                        blk.bn1.weight.grad.clone(), blk.bn1.bias.grad.clone(), blk.bn2.weight.grad.clone(), blk.bn2.bias.grad.clone(),
+                        blk.bn1.running_mean.clone(), blk.bn1.running_var.clone(), blk.bn2.running_mean.clone(), blk.bn2.running_var.clone(),
+                        blk.bn1.num_batches_tracked.clone(), blk.bn2.num_batches_tracked.clone(), K.known_amax(y).clone()]
+        monkeypatch.setattr(K._hip, "call", orig)
+        res[grouped] = (out, [c for c in calls if c not in ("cseg_amax_batch", "cseg_split_pack_batch", "cseg_amax_f32")])
+    assert len(res[True][1]) == 2 * 12, res[True][1]                  # 12 library calls (16 launches) per depth and step
+    assert len(res[False][1]) == 2 * 12 * len(channels), len(res[False][1])
+    for i, (a, b) in enumerate(zip(res[False][0], res[True][0])):
+        assert torch.equal(a, b), (i % 15, i // 15)

@@ -12,6 +12,7 @@
 #   pmc              rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) -> step_pmc.json
 #   longrun[:<n>]    tools/long_run_arith.py (default 200 steps): default arithmetic vs strict fp32 vs a one-ulp perturbation
 #   probe:<args>     tools/probes/conv_probe with the given arguments (';' separates arguments)
+#   gprobe:<args>    tools/probes/group_probe (grouped launches vs the one-layer launches they replace; ';' separates arguments)
 #   host             tools/host_profile.py 8
 #   contrast         tools/contrast_probe.py under rocprofv3 --kernel-trace --stats: fused vs three-launch contrastive forward
 export TMPDIR=/tmp
@@ -71,6 +72,12 @@ for step in "$@"; do
       [ -x $P ] || g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tools/probes/conv_probe.cpp -o $P -L/opt/rocm/lib -lamdhip64 -ldl
       IFS=';' read -ra PA <<< "$arg"
       timeout 120 $P "${PA[@]}" > $O/probe_$(date +%s%N).jsonl 2>> $O/probe.err; cat $O/probe_*.jsonl | tail -40 | cut -c1-400 ;;
+    gprobe)
+      export LD_LIBRARY_PATH=/opt/rocm/lib:$LD_LIBRARY_PATH
+      P=tools/probes/group_probe
+      [ -x $P ] || g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tools/probes/group_probe.cpp -o $P -L/opt/rocm/lib -lamdhip64 -ldl
+      IFS=';' read -ra PA <<< "$arg"
+      timeout 120 $P "${PA[@]}" >> $O/group_probe.jsonl 2>> $O/group_probe.err; tail -3 $O/group_probe.jsonl | cut -c1-600; tail -2 $O/group_probe.err ;;
     contrast)
       cd /tmp
       timeout 300 rocprofv3 --kernel-trace --stats -d $O/ctrace -o c --output-format csv -- python $R/tools/contrast_probe.py > $O/contrast_probe.json 2> $O/contrast_probe.err
