@@ -27,6 +27,7 @@
 // The queue counters live in `sched` (CSEG_GROUP_SCHED_INTS ints, zero before the first launch); the last block to finish puts
 // them back to zero, so the same buffer serves every launch on a stream.
 #include "cseg_sb16_tile.h"
+#include <type_traits>
 
 namespace {
 
@@ -361,6 +362,327 @@ __global__ __launch_bounds__(512, 1) void conv3x3_group_kernel(const GArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The 512-pixel form with PRODUCER / CONSUMER waves (CSEG_GROUP_PC, see the launcher). In the kernel above all eight waves walk the
+// same phases -- issue the next patch's loads, K-steps, wait for the loads, split + store them, barrier -- and the phases ADD UP
+// (measured: ~6.1 us per chunk iteration against 2.4 us of MFMA issue; DESIGN.md section 11.8 found the same sum for the one-layer
+// kernels). Here waves 0-3 only compute: one per SIMD, two 64-pixel row segments x three channel tiles each (24 accumulators, per
+// K-step 22 ds_read_b128 for 72 MFMAs), and waves 4-7 only stage: the fp32 patch of the NEXT chunk iteration (loads, f16x3 split,
+// LDS image) and its weight chunk (LDS-DMA), on the same SIMDs underneath the consumers' MFMAs (separate pipes: a matrix-only and a
+// VALU / memory-only wave of one SIMD run concurrently, MI355X_MICROARCH.md "Wave scheduling"). One barrier per chunk iteration,
+// the same unit queue, the same arithmetic per output element (bit-identical results).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PAU = 6;                  // staging items per PRODUCER thread: 2 octets x <= 660 cells over 256 threads
+
+template <class AR>
+__global__ __launch_bounds__(512, 1) void conv3x3_group_pc_kernel(const GArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_gpc[];
+    __shared__ int next_unit;
+    __shared__ float scales[CSEG_GROUP_MAX][2];
+    constexpr int NP = AR::NP;
+    constexpr int A_CELLS = NP * NOCT * GPLANE;
+    constexpr int BSTEP = GNT * NP * 64;            // uint4 per K-step
+    constexpr int BCHUNK = STEPS * BSTEP;           // uint4 per 16-channel chunk
+    uint4* As = smem_gpc;                           // [2][piece NP][octet 2][GPLANE]
+    uint4* Bs = smem_gpc + 2 * A_CELLS;             // [2][BCHUNK]
+
+    // readfirstlane: the role split below must be a SCALAR branch (the wave index is uniform, which the compiler cannot see)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool producer = wave >= 4;
+    const int pt = tid - 256;                       // producer thread index
+    const int g = lane >> 4, n = lane & 15;
+    const int q = blockIdx.x & 7;
+    int* head = a.sched + q * SCHED_STRIDE;
+
+    for (int i = 0; i < a.n_members; ++i) {
+        const unsigned ex = split_amax_exp(a.m[i].amax_x), ew = split_amax_exp(a.m[i].amax_w);      // every thread (shuffles inside)
+        if (tid == 0) {
+            scales[i][0] = split_scale_of(ex);
+            scales[i][1] = split_unscale_of(ex) * split_unscale_of(ew);
+        }
+    }
+    auto grab = [&]() -> int {
+        for (;;) {
+            const int u = cseg_counter_add(head, 1);
+            if (u >= a.units_per_xcd) return -1;
+            int mi = 0;
+            for (int i = 1; i < a.n_members; ++i) mi = u >= a.m[i].unit0 ? i : mi;
+            const int tl = (u - a.m[mi].unit0) / a.m[mi].n_cot;
+            if (q * a.m[mi].per_xcd + tl < a.m[mi].n_spatial) return u;
+        }
+    };
+    struct Unit {
+        const float* x;
+        const uint4* wbase;
+        float* y;
+        const float* bias;
+        const float* addend;
+        float4* stats;
+        int Cin, Cout, H, W, n_seg, n_chunks, geo, cot, b, y0, x0;
+        float xscale, unscale;
+    };
+    auto decode = [&](int u, Unit& U) {
+        int mi = 0;
+        for (int i = 1; i < a.n_members; ++i) mi = u >= a.m[i].unit0 ? i : mi;
+        const GMember& M = a.m[mi];
+        const int local = u - M.unit0;
+        U.cot = local % M.n_cot;
+        int t = q * M.per_xcd + local / M.n_cot;
+        const int tx = t % M.tiles_x; t /= M.tiles_x;
+        const int ty = t % M.tiles_y;
+        U.b = t / M.tiles_y;
+        U.geo = M.geo;
+        U.x0 = tx * (64 >> M.geo); U.y0 = ty * (8 << M.geo);
+        U.x = M.x; U.y = M.y; U.bias = M.bias; U.addend = M.addend; U.stats = M.stats;
+        U.Cin = M.Cin; U.Cout = M.Cout; U.H = M.H; U.W = M.W; U.n_seg = M.n_seg; U.n_chunks = M.n_chunks;
+        U.wbase = M.wp + (size_t)U.cot * M.n_chunks * BCHUNK;
+        U.xscale = scales[mi][0]; U.unscale = scales[mi][1];
+    };
+
+    if (tid == 0) next_unit = grab();
+    __syncthreads();
+    const int u_first = __builtin_amdgcn_readfirstlane(next_unit);
+    if (u_first >= 0) {
+        Unit su;                                    // unit of the item being staged (producers) / the next one (consumers track it for `cu`)
+        decode(u_first, su);
+        if (producer) {
+            // ---------------- producers: the patches of items k + 1 and k + 2 are in flight while the consumers compute item k.
+            // The loads of an item are issued TWO chunk iterations before the consumers need it: a fetch sees the L2 (61 % hits in
+            // the first version, rocprofv3 counters in profiles/r06_group_pmc.csv), the fabric and HBM under the load of 256 CUs,
+            // and with one iteration of lead every chunk iteration exposed a round trip (MFMA pipe busy 40 % of the kernel).
+            // Two register sets (A: items of even distance, B: odd) hold the raw fp32 values; the loop body is written twice so that
+            // the sets are compile-time. Loads are issued UNCONDITIONALLY (past the end of the queue: the last item's addresses
+            // again), so that the compiler counts outstanding loads exactly and the wait for one set leaves the other in flight
+            // (a conditional issue makes s_waitcnt drain both: DESIGN.md section 11.8). Producers issue no LDS-DMA for the same
+            // reason (the consumers bring the weights in).
+            float apre[2][PAU][8];
+            int set_cell[2][PAU];                   // LDS cell of every staged item (piece 0), -1 = no such item
+            unsigned set_ok[2];                     // bit u: item u lies inside the image (else zero padding)
+            float set_scale[2];
+            bool set_valid[2] = {false, false};
+            int it_r[PAU], it_col[PAU], it_cell[PAU], it_oct8[PAU];
+            bool it_in[PAU];
+            int s_geo = -1;
+            auto stage_geometry = [&](int geo) {
+                const int xcols = (64 >> geo) + 2, cells = ((8 << geo) + 2) * xcols;
+#pragma unroll
+                for (int u = 0; u < PAU; ++u) {
+                    const int item = pt + 256 * u;
+                    const int oct = item >= cells ? 1 : 0, rc = min(item - oct * cells, cells - 1);
+                    it_r[u] = rc / xcols;
+                    it_col[u] = rc - it_r[u] * xcols;
+                    it_in[u] = item < 2 * cells;
+                    it_cell[u] = oct * GPLANE + rc;
+                    it_oct8[u] = oct * 8;
+                }
+                s_geo = geo;
+            };
+            // issue cursor: the next item to fetch = (su, i_chunk); i_chunk == su.n_chunks: the first chunk of the unit after su
+            int i_chunk = 0;
+            bool i_valid = true;
+            auto issue = [&](auto SET) {
+                constexpr int S = decltype(SET)::value;
+                if (i_valid && i_chunk == su.n_chunks) {             // (the consumers are at least one barrier past the grab of that unit)
+                    const int nu = __builtin_amdgcn_readfirstlane(next_unit);
+                    i_valid = nu >= 0;
+                    if (i_valid) {
+                        decode(nu, su);
+                        if (su.geo != s_geo) stage_geometry(su.geo);
+                        i_chunk = 0;
+                    }
+                }
+                const int chunk = i_valid ? i_chunk : su.n_chunks - 1;
+                const int plane = su.H * su.W;
+                const float* xc = su.x + ((size_t)su.b * su.Cin + (size_t)chunk * 16) * plane;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xc, 0, (int)(16 * plane * sizeof(float)), 0x00020000);
+                unsigned okm = 0;
+#pragma unroll
+                for (int u = 0; u < PAU; ++u) {
+                    const int yy = su.y0 + it_r[u] - 1, xx = su.x0 + it_col[u] - 1;
+                    okm |= (yy >= 0 && yy < su.H && xx >= 0 && xx < su.W) ? 1u << u : 0u;
+                    const int yc = min(max(yy, 0), su.H - 1), xcl = min(max(xx, 0), su.W - 1);
+                    const int off = (it_oct8[u] * plane + yc * su.W + xcl) * (int)sizeof(float);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        apre[S][u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, j * plane * (int)sizeof(float), 0));
+                    set_cell[S][u] = it_in[u] ? it_cell[u] : -1;
+                }
+                set_ok[S] = okm;
+                set_scale[S] = su.xscale;
+                set_valid[S] = i_valid;
+                if (i_valid) ++i_chunk;
+            };
+            auto store = [&](auto SET, uint4* dst) {
+                constexpr int S = decltype(SET)::value;
+#pragma unroll
+                for (int u = 0; u < PAU; ++u) {
+                    if (set_cell[S][u] >= 0) {
+                        uint4 cells[NP];
+                        split_cells8_masked<AR>(apre[S][u], (set_ok[S] >> u & 1u) != 0, set_scale[S], cells);
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) dst[p * NOCT * GPLANE + set_cell[S][u]] = cells[p];
+                    }
+                }
+            };
+            typedef std::integral_constant<int, 0> SetA;
+            typedef std::integral_constant<int, 1> SetB;
+            stage_geometry(su.geo);
+            issue(SetA());                          // item 0
+            store(SetA(), As);
+            issue(SetB());                          // item 1
+            __syncthreads();                        // (P) item 0 is staged
+            // iteration k (the consumers compute item k from buffer k & 1): fetch item k + 2 into the set that held item k, then
+            // split + store item k + 1 (fetched an iteration ago) into the other buffer
+#pragma unroll 1
+            for (;;) {
+                {   // even k: item k + 1 is in set B
+                    const bool have_next = set_valid[1];
+                    issue(SetA());
+                    if (have_next) store(SetB(), As + A_CELLS);
+                    __syncthreads();                // (I)
+                    if (!have_next) break;
+                }
+                {   // odd k: item k + 1 is in set A
+                    const bool have_next = set_valid[0];
+                    issue(SetB());
+                    if (have_next) store(SetA(), As);
+                    __syncthreads();                // (I)
+                    if (!have_next) break;
+                }
+            }
+        } else {
+            // ---------------- consumers: wave w computes the pixels of the 8-wave form's waves 2 w and 2 w + 1
+            Unit cu = su;
+            f32x4 acc[8][GNT];
+            int c_row[8], c_col[8], c_off[8], c_xcols = 0;
+            auto compute_geometry = [&](int geo) {
+                c_xcols = (64 >> geo) + 2;
+                const int per = 4 >> geo;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        c_row[4 * h + mt] = ((2 * wave + h) << geo) + mt / per;
+                        c_col[4 * h + mt] = 16 * (mt % per);
+                        c_off[4 * h + mt] = c_row[4 * h + mt] * c_xcols + c_col[4 * h + mt] + n;
+                    }
+            };
+            compute_geometry(cu.geo);
+            auto b_dma = [&](const uint4* wbase, int chunk, int slot) {      // STEPS * GNT * NP = 30 rows of 1 KB over the four consumer waves
+                constexpr int ROWS = STEPS * GNT * NP;
+                uint4* dst = Bs + (size_t)slot * BCHUNK;
+#pragma unroll
+                for (int i = 0; i < (ROWS + 3) / 4; ++i) {
+                    const int r = wave + 4 * i;
+                    if (r < ROWS)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + (size_t)chunk * BCHUNK + r * 64 + lane),
+                                                         (__attribute__((address_space(3))) void*)(dst + r * 64), 16, 0, 0);
+                }
+            };
+            b_dma(cu.wbase, 0, 0);                  // weights of item 0
+            __syncthreads();                        // (P)
+            int chunk = 0, buf = 0;
+#pragma unroll 1
+            for (;;) {
+                if (chunk == 0) {
+#pragma unroll
+                    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < GNT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (tid == 0) next_unit = grab();                // read by everybody at this unit's last chunk (n_chunks >= 2)
+                }
+                const bool last = chunk == cu.n_chunks - 1;
+                bool more = true;
+                if (last) {
+                    const int nu = __builtin_amdgcn_readfirstlane(next_unit);
+                    more = nu >= 0;
+                    if (more) decode(nu, su);
+                }
+                if (more) b_dma(last ? su.wbase : cu.wbase, last ? 0 : chunk + 1, buf ^ 1);      // weights of item k + 1: that slot was last read in item k - 1
+                const uint4* a_base = As + (size_t)buf * A_CELLS;
+                const uint4* b_base = Bs + (size_t)buf * BCHUNK + lane;
+                typedef typename AR::frag_t frag_t;
+#pragma unroll
+                for (int s = 0; s < STEPS; ++s) {
+                    const int tap = min(2 * s + (g >> 1), 8);        // the tenth tap slot multiplies zero weights
+                    const int ky = tap / 3, kx = tap - 3 * ky;
+                    const uint4* ap = a_base + (g & 1) * GPLANE + ky * c_xcols + kx;
+                    frag_t bf[GNT][NP];
+#pragma unroll
+                    for (int nt = 0; nt < GNT; ++nt)
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) bf[nt][p] = __builtin_bit_cast(frag_t, b_base[s * BSTEP + (nt * NP + p) * 64]);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        frag_t af[4][NP];
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) af[mt][p] = __builtin_bit_cast(frag_t, ap[p * NOCT * GPLANE + c_off[4 * h + mt]]);
+#pragma unroll
+                        for (int nt = 0; nt < GNT; ++nt)
+#pragma unroll
+                            for (int t = 0; t < AR::NTERMS; ++t)
+#pragma unroll
+                                for (int mt = 0; mt < 4; ++mt)
+                                    acc[4 * h + mt][nt] = AR::mfma(af[mt][AR::ta(t)], bf[nt][AR::tb(t)], acc[4 * h + mt][nt]);
+                    }
+                }
+                if (last) {
+                    const size_t plane = (size_t)cu.H * cu.W;
+                    float* ybc = cu.y + (size_t)cu.b * cu.Cout * plane;
+                    const float* abc = cu.addend ? cu.addend + (size_t)cu.b * cu.Cout * plane : nullptr;
+                    const int co0 = cu.cot * GNT * 16;
+                    const bool vec = (cu.W & 3) == 0;
+#pragma unroll
+                    for (int nt = 0; nt < GNT; ++nt) {
+                        const float bv = cu.bias ? cu.bias[co0 + nt * 16 + n] : 0.f;
+#pragma unroll
+                        for (int mt = 0; mt < 8; ++mt) {
+                            const int yy = cu.y0 + c_row[mt];
+                            if (yy < cu.H) {
+                                const size_t roff = (size_t)(co0 + nt * 16 + n) * plane + (size_t)yy * cu.W;
+                                f32x4 v = acc[mt][nt] * cu.unscale;
+                                v += bv;
+                                cseg_store_row4(ybc + roff, abc ? abc + roff : nullptr, cu.x0 + c_col[mt] + 4 * g, cu.W, vec, v);
+                            }
+                        }
+                    }
+                    if (cu.stats) {
+                        float4* st = cu.stats + (size_t)co0 * cu.n_seg;
+                        const int tx64 = (cu.W + 63) / 64;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const f32x4(&ah)[4][GNT] = reinterpret_cast<const f32x4(&)[4][GNT]>(acc[4 * h]);
+                            const int y0w = cu.y0 + ((2 * wave + h) << cu.geo);
+                            if (cu.geo == 0) group_stats_emit<0>(ah, cu.bias, co0, cu.unscale, cu.b, y0w, cu.x0, cu.H, cu.W, tx64, g, n, st, cu.n_seg);
+                            else if (cu.geo == 1) group_stats_emit<1>(ah, cu.bias, co0, cu.unscale, cu.b, y0w, cu.x0, cu.H, cu.W, tx64, g, n, st, cu.n_seg);
+                            else group_stats_emit<2>(ah, cu.bias, co0, cu.unscale, cu.b, y0w, cu.x0, cu.H, cu.W, tx64, g, n, st, cu.n_seg);
+                        }
+                    }
+                }
+                __syncthreads();                    // (I)
+                if (!more) break;
+                if (last) {
+                    if (su.geo != cu.geo) compute_geometry(su.geo);
+                    cu = su;
+                    chunk = 0;
+                } else {
+                    ++chunk;
+                }
+                buf ^= 1;
+            }
+        }
+    }
+    if (tid == 0) {
+        int* done = a.sched + 8 * SCHED_STRIDE;
+        if (cseg_counter_add(done, 1) == (int)gridDim.x - 1) {
+            for (int i = 0; i < 8; ++i) cseg_counter_store(a.sched + i * SCHED_STRIDE, 0);
+            cseg_counter_store(done, 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // The same launch on 4 x 64-pixel tiles (256 pixels per unit: two waves per image row split the three channel tiles, the tile body
 // of conv3x3_sb16p_kernel), for SMALL groups: when the heaviest unit of the 512-pixel form would be longer than a CU's share of the
 // whole group (per-GPU batches of 1 - 4 images: the 384-channel units are 24 chunk iterations, the group 12 per CU), units of half
@@ -683,6 +1005,7 @@ extern "C" int cseg_conv3x3_split_group_fwd(const cseg_conv_group_member* mem, i
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv3x3_group_kernel<SplitF16x3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)group_lds_bytes()) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_group_pc_kernel<SplitF16x3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)group_lds_bytes()) != hipSuccess ||
             hipFuncSetAttribute((const void*)g4::conv3x3_group4_kernel<SplitF16x3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g4::lds_bytes()) != hipSuccess) {
             cseg_set_error("conv3x3 group: cannot raise dynamic LDS to %zu bytes", lds);
             return 0;
@@ -690,7 +1013,12 @@ extern "C" int cseg_conv3x3_split_group_fwd(const cseg_conv_group_member* mem, i
         attr_set = true;
     }
     const int per_xcd_blocks = unit0 < 32 ? unit0 : 32;       // one block per CU: 32 CUs per XCD
-    if (big) hipLaunchKernelGGL(conv3x3_group_kernel<SplitF16x3>, dim3((unsigned)(8 * per_xcd_blocks)), dim3(512), lds, (hipStream_t)stream_, a);
+    // CSEG_GROUP_PC=0: the 512-pixel form with all eight waves in the same phases (first version of round 6) instead of producer / consumer waves
+    const char* pce = getenv("CSEG_GROUP_PC");
+    bool pc = !(pce && atoi(pce) == 0);
+    for (int i = 0; i < n; ++i) pc = pc && mem[i].Cin >= 48;      // (its producers run two chunk iterations ahead of the consumers: units of >= 3 chunks)
+    if (big && pc) hipLaunchKernelGGL(conv3x3_group_pc_kernel<SplitF16x3>, dim3((unsigned)(8 * per_xcd_blocks)), dim3(512), lds, (hipStream_t)stream_, a);
+    else if (big) hipLaunchKernelGGL(conv3x3_group_kernel<SplitF16x3>, dim3((unsigned)(8 * per_xcd_blocks)), dim3(512), lds, (hipStream_t)stream_, a);
     else hipLaunchKernelGGL(g4::conv3x3_group4_kernel<SplitF16x3>, dim3((unsigned)(8 * per_xcd_blocks)), dim3(512), lds, (hipStream_t)stream_, a);
     CSEG_CHECK_LAUNCH("conv3x3_group_kernel");
     return 1;

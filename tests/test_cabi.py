@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_binding_covers_every_symbol_and_loads(built):
     assert sorted(built.SIGNATURES) == _declared()
     lib = built.lib()
-    assert lib.cseg_abi_version() == 5
+    assert lib.cseg_abi_version() == 6
     assert lib.cseg_contrast_ws_bytes(1024, 4096) == 1024 * 4096 * 4
     assert lib.cseg_contrast_ws_bytes(33, 33) == 64 * 64 * 4
     assert lib.cseg_upsample_ce_blocks(8, 512, 1024) == 8 * 64 * 32

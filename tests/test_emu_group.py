@@ -27,6 +27,15 @@ def wave_order(request, monkeypatch):
     return request.param
 
 
+@pytest.fixture(params=["tile4", "tile8", "tile8pc"])
+def form(request, monkeypatch):
+    """The three tile forms of the grouped convolution kernel (the library picks by the size of the group; forced here): 256-pixel
+    tiles, 512-pixel tiles with all waves in the same phases, 512-pixel tiles with producer / consumer waves."""
+    monkeypatch.setenv("CSEG_GROUP_TILE", "4" if request.param == "tile4" else "8")
+    monkeypatch.setenv("CSEG_GROUP_PC", "1" if request.param == "tile8pc" else "0")
+    return request.param
+
+
 # (B, Cin, Cout, H, W) per member: the channel ladder of HRNet's branches on small maps -- resident (48) and streamed (>= 64) operators,
 # several channel groups per tile, ragged tiles, a width that is not a multiple of 4, fewer tiles than XCDs
 GROUPS = [
@@ -37,7 +46,7 @@ GROUPS = [
 
 
 @pytest.mark.parametrize("shapes", GROUPS)
-def test_group_forward_equals_the_one_layer_launches_bit_for_bit(shapes, wave_order):
+def test_group_forward_equals_the_one_layer_launches_bit_for_bit(shapes, wave_order, form):
     members = []
     for i, (B, ci, co, H, W) in enumerate(shapes):
         members.append(dict(x=_rand((B, ci, H, W), 10 + i, 1.0 + i), w=_rand((co, ci, 3, 3), 20 + i, 1.0 / (3 * ci ** 0.5)),
@@ -55,7 +64,7 @@ def test_group_forward_equals_the_one_layer_launches_bit_for_bit(shapes, wave_or
         assert np.abs(y - ref).max() <= _bound(ref, 9 * m["x"].shape[1])
 
 
-def test_group_backward_data_with_addend_and_a_reused_scheduling_record(wave_order):
+def test_group_backward_data_with_addend_and_a_reused_scheduling_record(wave_order, form):
     """The backward-data operators of a depth (transposed packing), one of them with the residual gradient added in the epilogue; the
     same scheduling record serves two launches (each leaves it zero)."""
     shapes = [(1, 48, 48, 6, 40), (1, 96, 96, 3, 24)]
@@ -86,7 +95,7 @@ from tests.emu import inject
 
 
 @pytest.mark.parametrize("channels,shapes", [((48, 96), ((6, 40), (3, 20))), ((48, 96, 192), ((8, 64), (4, 32), (2, 16)))])
-def test_grouped_depth_node_equals_the_per_branch_nodes_bit_for_bit(channels, shapes, monkeypatch):
+def test_grouped_depth_node_equals_the_per_branch_nodes_bit_for_bit(channels, shapes, form, monkeypatch):
     """kernels.BasicBlockGroup (ONE autograd node for the residual blocks of a depth of HRNet's parallel branches, on the grouped
     conv / BatchNorm / weight-gradient launches) against one kernels.BasicBlockSplit per branch with the group's tile body
     (nt = CSEG_NT_GROUP): outputs, every gradient, running statistics, num_batches_tracked and the max|.| records are bit-identical

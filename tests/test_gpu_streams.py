@@ -68,14 +68,16 @@ def test_forked_streams_and_wgrad_stream_give_the_single_stream_gradients(monkey
     for name, forks, wgrad in (("forks", True, False), ("wgrad", False, True), ("forks+wgrad", True, True)):
         got, g = _run(forks, wgrad, monkeypatch)
         assert abs(got[0] - base[0]) <= 2e-6 * abs(base[0]), (name, got, base)
-        assert abs(got[1] - base[1]) <= max(2e-5 * abs(base[1]), 4 * abs(again[1] - base[1])), (name, got, base)
         assert set(g) == set(g0)
         gnorm = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in g0.values()))
-        worst = 0.0
+        worst, bad = 0.0, []
         for k, a in g0.items():
             den = max(float(np.linalg.norm(a)), 1e-6 * gnorm)
             dev, own = float(np.linalg.norm(a - g[k])) / den, float(np.linalg.norm(a - g0b[k])) / den
             worst = max(worst, dev)
-            assert dev <= max(4.0 * own, 2e-4), (name, k, dev, own)
+            if dev > max(4.0 * own, 2e-4):
+                bad.append((k, "%.2e" % dev, "%.2e" % own))
+        assert not bad, (name, len(bad), bad[:12], got, base, again)
+        assert abs(got[1] - base[1]) <= max(2e-5 * abs(base[1]), 4 * abs(again[1] - base[1])), (name, got, base, again, worst)
         report.append("%s: losses %s, worst gradient deviation %.1e" % (name, [round(v, 6) for v in got], worst))
     print("single stream:", [round(v, 6) for v in base], "|", "; ".join(report))

@@ -191,12 +191,17 @@ def test_step_golden_with_the_split_kernels_engaged(name, min_runs, min_wrw, mon
     _dev()
     monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
     monkeypatch.setattr(K, "CONV1X1_SB_MIN_TILES", 1)
-    calls = _spy(monkeypatch, K, ["conv3x3_sb_run", "conv3x3_sb_wrw", "conv1x1_sb_run"])
+    calls = _spy(monkeypatch, K, ["conv3x3_sb_run", "conv3x3_sb_wrw", "conv1x1_sb_run", "conv3x3_group_run", "conv3x3_group_wrw"])
     torch.backends.cudnn.benchmark = False
     c = STEP_CASES[name]
     g = np.load(os.path.join(golden_dir, "%s.npz" % name))
     res = T._run(c, torch.device("cuda:0"))
+    # convolutions on the split kernels, one-layer launches + the members of the grouped launches (round 6: the residual blocks of
+    # HRNet's parallel branches run a depth at a time, kernels.BasicBlockGroup)
     n = [len([x for x in calls if x[0] == k]) for k in ("conv3x3_sb_run", "conv3x3_sb_wrw", "conv1x1_sb_run")]
+    n[0] += sum(len(x[1][0]) for x in calls if x[0] == "conv3x3_group_run")
+    n[1] += sum(len(x[1][0]) for x in calls if x[0] == "conv3x3_group_wrw")
+    REPORT.setdefault("step_group_launches", {})[name.replace("step_", "")] = len([x for x in calls if x[0].startswith("conv3x3_group")])
     REPORT.setdefault("step_split_launches", {})[name.replace("step_", "")] = n
     assert n[0] > min_runs and n[1] >= min_wrw and n[2] > 0, n
     worst = T._compare(res, g, c, 1e-3, 1e-3, 5e-2)
@@ -252,7 +257,8 @@ def test_whole_step_timings_for_the_next_round():
         pytest.xfail("; ".join(repr(e)[:200] for e in failed if e is not None))
 
 
-_FAMILIES = [("conv3x3_sb_wrw_s2", "s2"), ("conv3x3_s2_", "s2"),                                   # stride-2 kernels (round 3), before "conv3x3_sb_wrw"
+_FAMILIES = [("conv3x3_group", "c3g"), ("conv3x3_wrw2_group", "c3gwrw"), ("sb_wrw_reduce_group", "c3gwrw"), ("bn_group", "bng"),   # grouped launches (round 6)
+             ("conv3x3_sb_wrw_s2", "s2"), ("conv3x3_s2_", "s2"),                                   # stride-2 kernels (round 3), before "conv3x3_sb_wrw"
              ("conv3x3_sb_kernel", "c3"), ("conv3x3_sb16_kernel", "c3"), ("conv3x3_sb16p_kernel", "c3"), ("conv3x3_sb16r_kernel", "c3"),
              ("conv3x3_sb8_kernel", "c3"), ("conv3x3_sb_wrw", "c3wrw"),
              ("sb_wrw_reduce", "c3wrw"), ("pack_batch", "pack"), ("amax_batch", "amax"),

@@ -13,6 +13,7 @@
 #   longrun[:<n>]    tools/long_run_arith.py (default 200 steps): default arithmetic vs strict fp32 vs a one-ulp perturbation
 #   probe:<args>     tools/probes/conv_probe with the given arguments (';' separates arguments)
 #   gprobe:<args>    tools/probes/group_probe (grouped launches vs the one-layer launches they replace; ';' separates arguments)
+#   gpmc:<ctrs>|<args>  the same probe under rocprofv3 --pmc <ctrs> (comma separated) -> gpmc_summary.csv (per-kernel averages)
 #   host             tools/host_profile.py 8
 #   contrast         tools/contrast_probe.py under rocprofv3 --kernel-trace --stats: fused vs three-launch contrastive forward
 export TMPDIR=/tmp
@@ -78,6 +79,16 @@ for step in "$@"; do
       [ -x $P ] || g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tools/probes/group_probe.cpp -o $P -L/opt/rocm/lib -lamdhip64 -ldl
       IFS=';' read -ra PA <<< "$arg"
       timeout 120 $P "${PA[@]}" >> $O/group_probe.jsonl 2>> $O/group_probe.err; tail -3 $O/group_probe.jsonl | cut -c1-600; tail -2 $O/group_probe.err ;;
+    gpmc)          # gpmc:<counters, comma separated>|<probe args, ';' separated>: PMC counters of the grouped-launch probe's kernels
+      export LD_LIBRARY_PATH=/opt/rocm/lib:$LD_LIBRARY_PATH
+      ctrs=${arg%%|*}; pargs=${arg#*|}
+      IFS=';' read -ra PA <<< "$pargs"
+      cd /tmp
+      CSEG_LIB=$R/contrastiveseg_amd/libcseg_hip.so timeout 200 rocprofv3 --pmc ${ctrs//,/ } --kernel-trace -d $O/gpmc -o g --output-format csv -- $R/tools/probes/group_probe "${PA[@]}" > $O/gpmc_probe.out 2> $O/gpmc.err
+      cd $R
+      c=$(find $O/gpmc -name '*counter_collection.csv' | head -1)
+      [ -n "$c" ] && python tools/pmc_kernel_summary.py $c group >> $O/gpmc_summary.csv
+      rm -rf $O/gpmc; tail -4 $O/gpmc_summary.csv | cut -c1-700 ;;
     contrast)
       cd /tmp
       timeout 300 rocprofv3 --kernel-trace --stats -d $O/ctrace -o c --output-format csv -- python $R/tools/contrast_probe.py > $O/contrast_probe.json 2> $O/contrast_probe.err
