@@ -58,6 +58,8 @@ struct GArgs {
     GMember m[CSEG_GROUP_MAX];
     int n_members, units_per_xcd;
     int* sched;
+    int ablate, pad;                    // timing experiments only (CSEG_GROUP_ABLATE, producer / consumer kernel; results are wrong when set):
+                                        // 1 no MFMA K-steps, 2 no patch loads, 4 no split / LDS store, 8 no output stores, 16 no weight DMA
 };
 
 // BatchNorm statistics of a wave's 64 outputs per channel (cseg_stats.h): one record per (channel, image row, 64-column tile). With
@@ -393,21 +395,42 @@ __global__ __launch_bounds__(512, 1) void conv3x3_group_pc_kernel(const GArgs a)
     const int q = blockIdx.x & 7;
     int* head = a.sched + q * SCHED_STRIDE;
 
-    for (int i = 0; i < a.n_members; ++i) {
-        const unsigned ex = split_amax_exp(a.m[i].amax_x), ew = split_amax_exp(a.m[i].amax_w);      // every thread (shuffles inside)
-        if (tid == 0) {
-            scales[i][0] = split_scale_of(ex);
-            scales[i][1] = split_unscale_of(ex) * split_unscale_of(ew);
+    // the first unit's atomic and all 2 n max|.| records are requested before anything waits for one of them (one round trip, not 2 n + 1)
+    int pending = 0;
+    if (tid == 0) pending = cseg_counter_add(head, 1);
+    {
+        unsigned rec[2 * CSEG_GROUP_MAX];
+#pragma unroll
+        for (int i = 0; i < CSEG_GROUP_MAX; ++i) {          // (members beyond n_members are copies of member 0: valid pointers)
+            rec[2 * i] = a.m[i].amax_x[(tid & (CSEG_AMAX_SLOTS - 1)) * CSEG_AMAX_STRIDE];
+            rec[2 * i + 1] = a.m[i].amax_w[(tid & (CSEG_AMAX_SLOTS - 1)) * CSEG_AMAX_STRIDE];
+        }
+#pragma unroll
+        for (int i = 0; i < CSEG_GROUP_MAX; ++i) {
+            unsigned e[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {                   // split_amax_exp (cseg_split.h) on the value already loaded
+                unsigned v = rec[2 * i + k];
+#pragma unroll
+                for (int o = CSEG_AMAX_SLOTS / 2; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+                const unsigned ee = v >> 23 & 0xffu;
+                e[k] = ee < 15u ? 15u : (ee > 253u ? 253u : ee);
+            }
+            if (tid == 0) {
+                scales[i][0] = split_scale_of(e[0]);
+                scales[i][1] = split_unscale_of(e[0]) * split_unscale_of(e[1]);
+            }
         }
     }
-    auto grab = [&]() -> int {
+    // thread 0: `u` = a value taken from this XCD's queue -> the next unit that names a tile inside the image batch, or -1
+    auto settle = [&](int u) -> int {
         for (;;) {
-            const int u = cseg_counter_add(head, 1);
             if (u >= a.units_per_xcd) return -1;
             int mi = 0;
             for (int i = 1; i < a.n_members; ++i) mi = u >= a.m[i].unit0 ? i : mi;
             const int tl = (u - a.m[mi].unit0) / a.m[mi].n_cot;
             if (q * a.m[mi].per_xcd + tl < a.m[mi].n_spatial) return u;
+            u = cseg_counter_add(head, 1);
         }
     };
     struct Unit {
@@ -438,7 +461,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_group_pc_kernel(const GArgs a)
         U.xscale = scales[mi][0]; U.unscale = scales[mi][1];
     };
 
-    if (tid == 0) next_unit = grab();
+    if (tid == 0) next_unit = settle(pending);
     __syncthreads();
     const int u_first = __builtin_amdgcn_readfirstlane(next_unit);
     if (u_first >= 0) {
@@ -491,6 +514,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_group_pc_kernel(const GArgs a)
                     }
                 }
                 const int chunk = i_valid ? i_chunk : su.n_chunks - 1;
+                if (a.ablate & 64) {                         // (timing experiments: no address arithmetic either)
+                    set_valid[S] = i_valid;
+#pragma unroll
+                    for (int u = 0; u < PAU; ++u) set_cell[S][u] = -1;
+                    if (i_valid) ++i_chunk;
+                    return;
+                }
                 const int plane = su.H * su.W;
                 const float* xc = su.x + ((size_t)su.b * su.Cin + (size_t)chunk * 16) * plane;
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xc, 0, (int)(16 * plane * sizeof(float)), 0x00020000);
@@ -503,8 +533,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_group_pc_kernel(const GArgs a)
                     const int off = (it_oct8[u] * plane + yc * su.W + xcl) * (int)sizeof(float);
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        apre[S][u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, j * plane * (int)sizeof(float), 0));
-                    set_cell[S][u] = it_in[u] ? it_cell[u] : -1;
+                        apre[S][u][j] = (a.ablate & 2) ? 1.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, j * plane * (int)sizeof(float), 0));
+                    set_cell[S][u] = (it_in[u] && !(a.ablate & 4)) ? it_cell[u] : -1;
                 }
                 set_ok[S] = okm;
                 set_scale[S] = su.xscale;
@@ -538,14 +568,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_group_pc_kernel(const GArgs a)
                     const bool have_next = set_valid[1];
                     issue(SetA());
                     if (have_next) store(SetB(), As + A_CELLS);
-                    __syncthreads();                // (I)
+                    if (!(a.ablate & 32)) __syncthreads();                // (I)
                     if (!have_next) break;
                 }
                 {   // odd k: item k + 1 is in set A
                     const bool have_next = set_valid[0];
                     issue(SetB());
                     if (have_next) store(SetA(), As);
-                    __syncthreads();                // (I)
+                    if (!(a.ablate & 32)) __syncthreads();                // (I)
                     if (!have_next) break;
                 }
             }
@@ -588,7 +618,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_group_pc_kernel(const GArgs a)
                     for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < GNT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (tid == 0) next_unit = grab();                // read by everybody at this unit's last chunk (n_chunks >= 2)
+                    // the atomic that names the unit after this one is ISSUED here and its result looked at only after the K-steps
+                    // below: an L2 round trip (~2 us with 32 blocks on one counter) no wave waits for
+                    if (tid == 0) pending = cseg_counter_add(head, 1);
                 }
                 const bool last = chunk == cu.n_chunks - 1;
                 bool more = true;
@@ -597,10 +629,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_group_pc_kernel(const GArgs a)
                     more = nu >= 0;
                     if (more) decode(nu, su);
                 }
-                if (more) b_dma(last ? su.wbase : cu.wbase, last ? 0 : chunk + 1, buf ^ 1);      // weights of item k + 1: that slot was last read in item k - 1
+                if (more && !(a.ablate & 16)) b_dma(last ? su.wbase : cu.wbase, last ? 0 : chunk + 1, buf ^ 1);      // weights of item k + 1: that slot was last read in item k - 1
                 const uint4* a_base = As + (size_t)buf * A_CELLS;
                 const uint4* b_base = Bs + (size_t)buf * BCHUNK + lane;
                 typedef typename AR::frag_t frag_t;
+                if (!(a.ablate & 1))
 #pragma unroll
                 for (int s = 0; s < STEPS; ++s) {
                     const int tap = min(2 * s + (g >> 1), 8);        // the tenth tap slot multiplies zero weights
@@ -627,6 +660,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_group_pc_kernel(const GArgs a)
                                     acc[4 * h + mt][nt] = AR::mfma(af[mt][AR::ta(t)], bf[nt][AR::tb(t)], acc[4 * h + mt][nt]);
                     }
                 }
+                if (chunk == 0 && tid == 0) next_unit = settle(pending);           // read by everybody at this unit's last chunk (n_chunks >= 2)
                 if (last) {
                     const size_t plane = (size_t)cu.H * cu.W;
                     float* ybc = cu.y + (size_t)cu.b * cu.Cout * plane;
@@ -639,7 +673,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_group_pc_kernel(const GArgs a)
 #pragma unroll
                         for (int mt = 0; mt < 8; ++mt) {
                             const int yy = cu.y0 + c_row[mt];
-                            if (yy < cu.H) {
+                            if (yy < cu.H && !(a.ablate & 8)) {
                                 const size_t roff = (size_t)(co0 + nt * 16 + n) * plane + (size_t)yy * cu.W;
                                 f32x4 v = acc[mt][nt] * cu.unscale;
                                 v += bv;
@@ -658,6 +692,298 @@ __global__ __launch_bounds__(512, 1) void conv3x3_group_pc_kernel(const GArgs a)
                             else if (cu.geo == 1) group_stats_emit<1>(ah, cu.bias, co0, cu.unscale, cu.b, y0w, cu.x0, cu.H, cu.W, tx64, g, n, st, cu.n_seg);
                             else group_stats_emit<2>(ah, cu.bias, co0, cu.unscale, cu.b, y0w, cu.x0, cu.H, cu.W, tx64, g, n, st, cu.n_seg);
                         }
+                    }
+                }
+                if (!(a.ablate & 32)) __syncthreads();                    // (I)
+                if (!more) break;
+                if (last) {
+                    if (su.geo != cu.geo) compute_geometry(su.geo);
+                    cu = su;
+                    chunk = 0;
+                } else {
+                    ++chunk;
+                }
+                buf ^= 1;
+            }
+        }
+    }
+    if (tid == 0) {
+        int* done = a.sched + 8 * SCHED_STRIDE;
+        if (cseg_counter_add(done, 1) == (int)gridDim.x - 1) {
+            for (int i = 0; i < 8; ++i) cseg_counter_store(a.sched + i * SCHED_STRIDE, 0);
+            cseg_counter_store(done, 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// TWELVE waves: the eight computing waves of the first 512-pixel form (two per SIMD: one's LDS reads and waits hide under the
+// other's MFMAs -- measured: with ONE computing wave per SIMD the K-steps alone run at half the matrix rate, 120 us for the four
+// branches at batch 8 against 71 us at the sustained fp16 rate) PLUS four staging waves (one per SIMD) that fetch, split and store
+// the next chunk iteration's patch underneath them. Three waves per SIMD: 168 VGPRs each. Same queue, same arithmetic per output
+// element. CSEG_GROUP_PC selects: 2 (default) this kernel, 1 the 4 + 4 form above, 0 the form without staging waves.
+// ---------------------------------------------------------------------------------------------------------
+template <class AR>
+__global__ __launch_bounds__(768) void conv3x3_group_pc12_kernel(const GArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_g12[];
+    __shared__ int next_unit;
+    __shared__ float scales[CSEG_GROUP_MAX][2];
+    constexpr int NP = AR::NP;
+    constexpr int A_CELLS = NP * NOCT * GPLANE;
+    constexpr int BSTEP = GNT * NP * 64;
+    constexpr int BCHUNK = STEPS * BSTEP;
+    uint4* As = smem_g12;                           // [2][piece NP][octet 2][GPLANE]
+    uint4* Bs = smem_g12 + 2 * A_CELLS;             // [2][BCHUNK]
+
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool producer = wave >= 8;
+    const int pt = tid - 512;                       // producer thread index
+    const int g = lane >> 4, n = lane & 15;
+    const int q = blockIdx.x & 7;
+    int* head = a.sched + q * SCHED_STRIDE;
+
+    int pending = 0;
+    if (tid == 0) pending = cseg_counter_add(head, 1);
+    {
+        unsigned rec[2 * CSEG_GROUP_MAX];
+#pragma unroll
+        for (int i = 0; i < CSEG_GROUP_MAX; ++i) {          // (members beyond n_members are copies of member 0: valid pointers)
+            rec[2 * i] = a.m[i].amax_x[(tid & (CSEG_AMAX_SLOTS - 1)) * CSEG_AMAX_STRIDE];
+            rec[2 * i + 1] = a.m[i].amax_w[(tid & (CSEG_AMAX_SLOTS - 1)) * CSEG_AMAX_STRIDE];
+        }
+#pragma unroll
+        for (int i = 0; i < CSEG_GROUP_MAX; ++i) {
+            unsigned e[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                unsigned v = rec[2 * i + k];
+#pragma unroll
+                for (int o = CSEG_AMAX_SLOTS / 2; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+                const unsigned ee = v >> 23 & 0xffu;
+                e[k] = ee < 15u ? 15u : (ee > 253u ? 253u : ee);
+            }
+            if (tid == 0) {
+                scales[i][0] = split_scale_of(e[0]);
+                scales[i][1] = split_unscale_of(e[0]) * split_unscale_of(e[1]);
+            }
+        }
+    }
+    auto settle = [&](int u) -> int {
+        for (;;) {
+            if (u >= a.units_per_xcd) return -1;
+            int mi = 0;
+            for (int i = 1; i < a.n_members; ++i) mi = u >= a.m[i].unit0 ? i : mi;
+            const int tl = (u - a.m[mi].unit0) / a.m[mi].n_cot;
+            if (q * a.m[mi].per_xcd + tl < a.m[mi].n_spatial) return u;
+            u = cseg_counter_add(head, 1);
+        }
+    };
+    struct Unit {
+        const float* x;
+        const uint4* wbase;
+        float* y;
+        const float* bias;
+        const float* addend;
+        float4* stats;
+        int Cin, Cout, H, W, n_seg, n_chunks, geo, cot, b, y0, x0;
+        float xscale, unscale;
+    };
+    auto decode = [&](int u, Unit& U) {
+        int mi = 0;
+        for (int i = 1; i < a.n_members; ++i) mi = u >= a.m[i].unit0 ? i : mi;
+        const GMember& M = a.m[mi];
+        const int local = u - M.unit0;
+        U.cot = local % M.n_cot;
+        int t = q * M.per_xcd + local / M.n_cot;
+        const int tx = t % M.tiles_x; t /= M.tiles_x;
+        const int ty = t % M.tiles_y;
+        U.b = t / M.tiles_y;
+        U.geo = M.geo;
+        U.x0 = tx * (64 >> M.geo); U.y0 = ty * (8 << M.geo);
+        U.x = M.x; U.y = M.y; U.bias = M.bias; U.addend = M.addend; U.stats = M.stats;
+        U.Cin = M.Cin; U.Cout = M.Cout; U.H = M.H; U.W = M.W; U.n_seg = M.n_seg; U.n_chunks = M.n_chunks;
+        U.wbase = M.wp + (size_t)U.cot * M.n_chunks * BCHUNK;
+        U.xscale = scales[mi][0]; U.unscale = scales[mi][1];
+    };
+
+    if (tid == 0) next_unit = settle(pending);
+    __syncthreads();
+    const int u_first = __builtin_amdgcn_readfirstlane(next_unit);
+    if (u_first >= 0) {
+        Unit su;
+        decode(u_first, su);
+        if (producer) {
+            // ---------------- staging waves: the patch of item k + 1 while the computing waves are on item k
+            float apre[PAU][8];
+            int it_r[PAU], it_col[PAU], it_cell[PAU], it_oct8[PAU];
+            bool it_in[PAU];
+            int s_geo = -1;
+            auto stage_geometry = [&](int geo) {
+                const int xcols = (64 >> geo) + 2, cells = ((8 << geo) + 2) * xcols;
+#pragma unroll
+                for (int u = 0; u < PAU; ++u) {
+                    const int item = pt + 256 * u;
+                    const int oct = item >= cells ? 1 : 0, rc = min(item - oct * cells, cells - 1);
+                    it_r[u] = rc / xcols;
+                    it_col[u] = rc - it_r[u] * xcols;
+                    it_in[u] = item < 2 * cells;
+                    it_cell[u] = oct * GPLANE + rc;
+                    it_oct8[u] = oct * 8;
+                }
+                s_geo = geo;
+            };
+            auto a_issue = [&](int chunk) {
+                const int plane = su.H * su.W;
+                const float* xc = su.x + ((size_t)su.b * su.Cin + (size_t)chunk * 16) * plane;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xc, 0, (int)(16 * plane * sizeof(float)), 0x00020000);
+#pragma unroll
+                for (int u = 0; u < PAU; ++u) {
+                    const int yc = min(max(su.y0 + it_r[u] - 1, 0), su.H - 1), xcl = min(max(su.x0 + it_col[u] - 1, 0), su.W - 1);
+                    const int off = (it_oct8[u] * plane + yc * su.W + xcl) * (int)sizeof(float);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        apre[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, j * plane * (int)sizeof(float), 0));
+                }
+            };
+            auto a_store = [&](uint4* dst) {
+#pragma unroll
+                for (int u = 0; u < PAU; ++u) {
+                    if (it_in[u]) {
+                        const int yy = su.y0 + it_r[u] - 1, xx = su.x0 + it_col[u] - 1;
+                        const bool ok = yy >= 0 && yy < su.H && xx >= 0 && xx < su.W;
+                        uint4 cells[NP];
+                        split_cells8_masked<AR>(apre[u], ok, su.xscale, cells);
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) dst[p * NOCT * GPLANE + it_cell[u]] = cells[p];
+                    }
+                }
+            };
+            stage_geometry(su.geo);
+            a_issue(0);
+            a_store(As);
+            __syncthreads();                        // (P) item 0 is staged
+            int chunk = 0, buf = 0, n_chunks = su.n_chunks;      // the item the computing waves are on
+#pragma unroll 1
+            for (;;) {
+                const bool last = chunk == n_chunks - 1;
+                bool more = true;
+                int nchunk = chunk + 1;
+                if (last) {
+                    const int nu = __builtin_amdgcn_readfirstlane(next_unit);
+                    more = nu >= 0;
+                    nchunk = 0;
+                    if (more) {
+                        decode(nu, su);
+                        if (su.geo != s_geo) stage_geometry(su.geo);
+                    }
+                }
+                if (more) {
+                    a_issue(nchunk);
+                    a_store(As + (size_t)(buf ^ 1) * A_CELLS);
+                }
+                __syncthreads();                    // (I)
+                if (!more) break;
+                if (last) { chunk = 0; n_chunks = su.n_chunks; } else ++chunk;
+                buf ^= 1;
+            }
+        } else {
+            // ---------------- computing waves: wave w = 64 pixels x all three channel tiles
+            Unit cu = su;
+            f32x4 acc[4][GNT];
+            int c_row[4], c_col[4], c_off[4], c_xcols = 0;
+            auto compute_geometry = [&](int geo) {
+                c_xcols = (64 >> geo) + 2;
+                const int per = 4 >> geo;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    c_row[mt] = (wave << geo) + mt / per;
+                    c_col[mt] = 16 * (mt % per);
+                    c_off[mt] = c_row[mt] * c_xcols + c_col[mt] + n;
+                }
+            };
+            compute_geometry(cu.geo);
+            auto b_dma = [&](const uint4* wbase, int chunk, int slot) {      // 30 rows of 1 KB over the eight computing waves
+                constexpr int ROWS = STEPS * GNT * NP;
+                uint4* dst = Bs + (size_t)slot * BCHUNK;
+#pragma unroll
+                for (int i = 0; i < (ROWS + 7) / 8; ++i) {
+                    const int r = wave + 8 * i;
+                    if (r < ROWS)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + (size_t)chunk * BCHUNK + r * 64 + lane),
+                                                         (__attribute__((address_space(3))) void*)(dst + r * 64), 16, 0, 0);
+                }
+            };
+            b_dma(cu.wbase, 0, 0);
+            __syncthreads();                        // (P)
+            int chunk = 0, buf = 0;
+#pragma unroll 1
+            for (;;) {
+                if (chunk == 0) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < GNT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (tid == 0) pending = cseg_counter_add(head, 1);      // looked at after the K-steps: nobody waits for the round trip
+                }
+                const bool last = chunk == cu.n_chunks - 1;
+                bool more = true;
+                if (last) {
+                    const int nu = __builtin_amdgcn_readfirstlane(next_unit);
+                    more = nu >= 0;
+                    if (more) decode(nu, su);
+                }
+                if (more) b_dma(last ? su.wbase : cu.wbase, last ? 0 : chunk + 1, buf ^ 1);
+                const uint4* a_base = As + (size_t)buf * A_CELLS;
+                const uint4* b_base = Bs + (size_t)buf * BCHUNK + lane;
+                typedef typename AR::frag_t frag_t;
+#pragma unroll
+                for (int s = 0; s < STEPS; ++s) {
+                    const int tap = min(2 * s + (g >> 1), 8);        // the tenth tap slot multiplies zero weights
+                    const int ky = tap / 3, kx = tap - 3 * ky;
+                    const uint4* ap = a_base + (g & 1) * GPLANE + ky * c_xcols + kx;
+                    frag_t af[4][NP];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) af[mt][p] = __builtin_bit_cast(frag_t, ap[p * NOCT * GPLANE + c_off[mt]]);
+#pragma unroll
+                    for (int nt = 0; nt < GNT; ++nt) {
+                        frag_t bf[NP];
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) bf[p] = __builtin_bit_cast(frag_t, b_base[s * BSTEP + (nt * NP + p) * 64]);
+#pragma unroll
+                        for (int t = 0; t < AR::NTERMS; ++t)
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = AR::mfma(af[mt][AR::ta(t)], bf[AR::tb(t)], acc[mt][nt]);
+                    }
+                }
+                if (chunk == 0 && tid == 0) next_unit = settle(pending);           // read by everybody at this unit's last chunk (n_chunks >= 2)
+                if (last) {
+                    const size_t plane = (size_t)cu.H * cu.W;
+                    float* ybc = cu.y + (size_t)cu.b * cu.Cout * plane;
+                    const float* abc = cu.addend ? cu.addend + (size_t)cu.b * cu.Cout * plane : nullptr;
+                    const int co0 = cu.cot * GNT * 16;
+                    const bool vec = (cu.W & 3) == 0;
+#pragma unroll
+                    for (int nt = 0; nt < GNT; ++nt) {
+                        const float bv = cu.bias ? cu.bias[co0 + nt * 16 + n] : 0.f;
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) {
+                            const int yy = cu.y0 + c_row[mt];
+                            if (yy < cu.H) {
+                                const size_t roff = (size_t)(co0 + nt * 16 + n) * plane + (size_t)yy * cu.W;
+                                f32x4 v = acc[mt][nt] * cu.unscale;
+                                v += bv;
+                                cseg_store_row4(ybc + roff, abc ? abc + roff : nullptr, cu.x0 + c_col[mt] + 4 * g, cu.W, vec, v);
+                            }
+                        }
+                    }
+                    if (cu.stats) {
+                        float4* st = cu.stats + (size_t)co0 * cu.n_seg;
+                        const int tx64 = (cu.W + 63) / 64, y0w = cu.y0 + (wave << cu.geo);
+                        if (cu.geo == 0) group_stats_emit<0>(acc, cu.bias, co0, cu.unscale, cu.b, y0w, cu.x0, cu.H, cu.W, tx64, g, n, st, cu.n_seg);
+                        else if (cu.geo == 1) group_stats_emit<1>(acc, cu.bias, co0, cu.unscale, cu.b, y0w, cu.x0, cu.H, cu.W, tx64, g, n, st, cu.n_seg);
+                        else group_stats_emit<2>(acc, cu.bias, co0, cu.unscale, cu.b, y0w, cu.x0, cu.H, cu.W, tx64, g, n, st, cu.n_seg);
                     }
                 }
                 __syncthreads();                    // (I)
@@ -1001,11 +1327,15 @@ extern "C" int cseg_conv3x3_split_group_fwd(const cseg_conv_group_member* mem, i
     a.n_members = n;
     a.units_per_xcd = unit0;
     a.sched = sched;
+    const char* abl = getenv("CSEG_GROUP_ABLATE");
+    a.ablate = abl ? atoi(abl) : 0;
+    a.pad = 0;
     const size_t lds = big ? group_lds_bytes() : g4::lds_bytes();
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv3x3_group_kernel<SplitF16x3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)group_lds_bytes()) != hipSuccess ||
             hipFuncSetAttribute((const void*)conv3x3_group_pc_kernel<SplitF16x3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)group_lds_bytes()) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_group_pc12_kernel<SplitF16x3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)group_lds_bytes()) != hipSuccess ||
             hipFuncSetAttribute((const void*)g4::conv3x3_group4_kernel<SplitF16x3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g4::lds_bytes()) != hipSuccess) {
             cseg_set_error("conv3x3 group: cannot raise dynamic LDS to %zu bytes", lds);
             return 0;
@@ -1015,9 +1345,11 @@ extern "C" int cseg_conv3x3_split_group_fwd(const cseg_conv_group_member* mem, i
     const int per_xcd_blocks = unit0 < 32 ? unit0 : 32;       // one block per CU: 32 CUs per XCD
     // CSEG_GROUP_PC=0: the 512-pixel form with all eight waves in the same phases (first version of round 6) instead of producer / consumer waves
     const char* pce = getenv("CSEG_GROUP_PC");
-    bool pc = !(pce && atoi(pce) == 0);
-    for (int i = 0; i < n; ++i) pc = pc && mem[i].Cin >= 48;      // (its producers run two chunk iterations ahead of the consumers: units of >= 3 chunks)
-    if (big && pc) hipLaunchKernelGGL(conv3x3_group_pc_kernel<SplitF16x3>, dim3((unsigned)(8 * per_xcd_blocks)), dim3(512), lds, (hipStream_t)stream_, a);
+    int pc = pce ? atoi(pce) : 2;
+    if (pc == 1)
+        for (int i = 0; i < n; ++i) pc = mem[i].Cin >= 48 ? pc : 2;      // (the 4 + 4 form's producers run two chunk iterations ahead: units of >= 3 chunks)
+    if (big && pc == 2) hipLaunchKernelGGL(conv3x3_group_pc12_kernel<SplitF16x3>, dim3((unsigned)(8 * per_xcd_blocks)), dim3(768), lds, (hipStream_t)stream_, a);
+    else if (big && pc == 1) hipLaunchKernelGGL(conv3x3_group_pc_kernel<SplitF16x3>, dim3((unsigned)(8 * per_xcd_blocks)), dim3(512), lds, (hipStream_t)stream_, a);
     else if (big) hipLaunchKernelGGL(conv3x3_group_kernel<SplitF16x3>, dim3((unsigned)(8 * per_xcd_blocks)), dim3(512), lds, (hipStream_t)stream_, a);
     else hipLaunchKernelGGL(g4::conv3x3_group4_kernel<SplitF16x3>, dim3((unsigned)(8 * per_xcd_blocks)), dim3(512), lds, (hipStream_t)stream_, a);
     CSEG_CHECK_LAUNCH("conv3x3_group_kernel");

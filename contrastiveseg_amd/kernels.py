@@ -1039,6 +1039,7 @@ class SplitWeights(object):
         self.arenas[key] = [new, 0 if old is None else old[1]]
         for st in self.weights.values():
             if st["dev"] == key:
+                st["amax_of"] = None if n == 0 else st.get("amax_of")      # (the old records were copied into the new arena)
                 for e in st["entries"].values():
                     e["version"] = None                  # record addresses changed: every entry of this device is packed again
         for k in [k for k in self.table_cache if k[0] == key]:
@@ -1106,13 +1107,21 @@ class SplitWeights(object):
         """Host cost matters here: this runs at the top of every step, when the GPU has nothing queued behind the optimizer kernels
         (tools/host_profile.py: 2.7 ms per step for the first version, which rebuilt ~1 000 Python tuples and ~1 300 tensor views per
         step only to find the cached device tables unchanged). Now one pass over the entries collects what identifies the tables BY
-        VALUE (pointers, record rows, formats); the row tuples are only built on a cache miss."""
+        VALUE (pointers, record rows, formats); the row tuples are only built on a cache miss.
+        Round 6: a max|w| record is recomputed only when ITS weight changed (state "amax_of" = the (pointer, version, epoch) the
+        record was accumulated from). Before, ANY stale pack -- e.g. a packed form requested for the first time in the middle of the
+        first step: the transposed operators of the backward pass, a new tiling -- zero-filled the WHOLE arena and re-accumulated every
+        record on the requesting stream, while kernels of other streams (the forked exchange paths, autograd's concurrent replay of
+        them) were reading their layers' records: a scale taken from a half-accumulated record. Seen as a first-step gradient that
+        differed between the forked and the single-stream run (tests/test_gpu_streams.py) once the grouped launches moved the first
+        requests of a step onto the main stream. At the top of a step every weight is stale and nothing else runs: one fill + one
+        launch for all, as before."""
         arith = split_arith_id()
         dkey = self._dkey(device)
         arena = self.arenas[dkey][0]
         base = arena.data_ptr()
         epoch = self.epoch
-        stale, every = [], []
+        stale, every, need_amax = [], [], []
         for st in list(self.weights.values()):               # (a copy: weak-reference callbacks may drop entries meanwhile)
             w = st["ref"]()
             if w is None or st["dev"] != dkey or not _on_device(w):
@@ -1120,6 +1129,8 @@ class SplitWeights(object):
             ptr = w.data_ptr()
             now = (ptr, w._version, epoch)
             every.append((ptr, w.numel(), st["row"]))
+            if st.get("amax_of") != now:
+                need_amax.append((ptr, w.numel(), st["row"], st, now))
             for e in st["entries"].values():
                 if e["version"] != now and e["arith"] == arith:
                     stale.append((w, st, e, now))
@@ -1127,12 +1138,22 @@ class SplitWeights(object):
             return
         sp = _hip.stream_ptr()
         rec = lambda row: base + row * AMAX_WORDS * 4                    # device address of a max|w| record (int32 words)
-        if arith:
-            # all records are re-accumulated (140 MB of weights: ~30 us), so one fill serves them all
-            arena.zero_()
-            tab = self._table(dkey, "amax", tuple(every),
-                              lambda: [(ptr, 0, rec(row), 0, 0, 0, 0, 0, n, max(1, min(64, n // 16384))) for ptr, n, row in every])
+        if arith and need_amax:
+            if len(need_amax) == len(every):
+                # every record is re-accumulated (140 MB of weights: ~30 us), so one fill serves them all
+                arena.zero_()
+                tab = self._table(dkey, "amax", tuple(every),
+                                  lambda: [(ptr, 0, rec(row), 0, 0, 0, 0, 0, n, max(1, min(64, n // 16384))) for ptr, n, row in every])
+            else:
+                # some weights only (a layer used for the first time mid-step, an out-of-band write to a few tensors): their rows alone
+                rows = torch.tensor([r[2] for r in need_amax], dtype=torch.int64, device=arena.device)
+                arena.index_fill_(0, rows, 0)
+                ident = tuple((ptr, n, row) for ptr, n, row, _, _ in need_amax)
+                tab = self._table(dkey, "amax_some", ident,
+                                  lambda: [(ptr, 0, rec(row), 0, 0, 0, 0, 0, n, max(1, min(64, n // 16384))) for ptr, n, row in ident])
             _hip.call("cseg_amax_batch", tab[0].data_ptr(), tab[1], tab[2], sp)
+            for _, _, _, st, now in need_amax:
+                st["amax_of"] = now
         tab = self._table(dkey, "pack", tuple((now[0], e["wp_ptr"], st["row"], e["flag"], e["nt"], e["kind"], e["total"]) for _, st, e, now in stale),
                           lambda: [(now[0], e["wp_ptr"], rec(st["row"]) if arith else 0, w.shape[0], w.shape[1], e["flag"], e["nt"],
                                     e["kind"], e["total"], (e["total"] + 255) // 256) for w, st, e, now in stale])

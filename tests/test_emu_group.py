@@ -27,12 +27,12 @@ def wave_order(request, monkeypatch):
     return request.param
 
 
-@pytest.fixture(params=["tile4", "tile8", "tile8pc"])
+@pytest.fixture(params=["tile4", "tile8", "tile8pc", "tile8pc12"])
 def form(request, monkeypatch):
-    """The three tile forms of the grouped convolution kernel (the library picks by the size of the group; forced here): 256-pixel
-    tiles, 512-pixel tiles with all waves in the same phases, 512-pixel tiles with producer / consumer waves."""
+    """The tile forms of the grouped convolution kernel (the library picks by the size of the group; forced here): 256-pixel tiles,
+    512-pixel tiles with all waves in the same phases, with 4 producer + 4 consumer waves, with 8 computing + 4 staging waves."""
     monkeypatch.setenv("CSEG_GROUP_TILE", "4" if request.param == "tile4" else "8")
-    monkeypatch.setenv("CSEG_GROUP_PC", "1" if request.param == "tile8pc" else "0")
+    monkeypatch.setenv("CSEG_GROUP_PC", {"tile8pc": "1", "tile8pc12": "2"}.get(request.param, "0"))
     return request.param
 
 
