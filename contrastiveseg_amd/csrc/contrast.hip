@@ -671,14 +671,39 @@ constexpr int FUSED_GRID_MAX = 248;
 constexpr size_t FUSED_LDS_CAP = 80 * 1024;
 constexpr size_t FUSED_LDS_STATIC = sizeof(float) * (2 * SG_T * SG_LD + 2 * FU_T * 4 + FU_T * 4 + 4) + 16;
 
-struct FusedPlan { int n_strips, nJ, nsplit, t_cache; size_t lds; };
+struct FusedPlan { int n_strips, nJ, nsplit, t_cache; size_t lds; bool resident; };
+
+// Blocks of the fused forward that are resident at once ON THE CURRENT DEVICE (the grid was sized for a full MI355X; on a
+// partitioned one -- CPX mode, ~32 CUs -- or a part with less LDS the blocks of a strip would wait for blocks that are never
+// scheduled, until the 10 s trap). Asked once per device: CUs x what the occupancy calculator admits per CU at the kernel's LDS cap,
+// minus a margin (MI355X_MICROARCH.md: near a register-file edge the calculator can be one block per CU high), capped at
+// FUSED_GRID_MAX. 0 = the dynamic-LDS attribute cannot be raised here: no fused forward on this device.
+constexpr int FUSED_MAX_DEVICES = 64;
+int fused_resident_blocks() {
+    static int cap[FUSED_MAX_DEVICES];
+    static bool known[FUSED_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FUSED_MAX_DEVICES) return 0;
+    if (!known[dev]) {
+        int cus = 0, per_cu = 0, c = 0;
+        if (hipFuncSetAttribute((const void*)contrast_fused_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(FUSED_LDS_CAP - FUSED_LDS_STATIC)) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)contrast_fused_fwd_kernel, 256, FUSED_LDS_CAP - FUSED_LDS_STATIC) == hipSuccess)
+            c = cus * (per_cu > 2 ? 2 : per_cu) - cus / 32;      // at most two per CU counted; 8 of 512 slots kept free on a full MI355X
+        cap[dev] = c < 0 ? 0 : (c > FUSED_GRID_MAX ? FUSED_GRID_MAX : c);
+        known[dev] = true;
+    }
+    return cap[dev];
+}
 
 inline FusedPlan fused_plan(int N, int M) {
     FusedPlan p;
     p.n_strips = (N + FU_T - 1) / FU_T;
     p.nJ = (M + FU_T - 1) / FU_T;
     const char* e = getenv("CSEG_CONTRAST_FUSED_GRID");
-    int grid_max = e ? atoi(e) : FUSED_GRID_MAX;
+    int grid_max = e ? atoi(e) : fused_resident_blocks();
+    p.resident = grid_max >= p.n_strips;            // every strip needs at least one resident block
     if (grid_max < p.n_strips) grid_max = p.n_strips;
     p.nsplit = grid_max / p.n_strips;
     if (p.nsplit > p.nJ) p.nsplit = p.nJ;
@@ -708,19 +733,17 @@ extern "C" int cseg_contrast_fwd_fused(const cseg_contrast_desc* d, float* fused
     if (!make_col(d, &col)) return 0;
     CSEG_REQUIRE(fused_ws != nullptr, "contrast (fused forward): no scratch buffer");
     const FusedPlan p = fused_plan(d->N, d->M);
+    if (!p.resident) {
+        // this device cannot keep one block per strip resident (a partitioned GPU, a part with less LDS, an attribute call that
+        // failed): the same outputs from the three launches -- they need the similarity array, which S_out is when the caller keeps it
+        CSEG_REQUIRE(S_out != nullptr, "contrast (fused forward): %d strips do not fit this device's %d resident blocks and no S_out was given "
+                     "for the three-launch form", p.n_strips, fused_resident_blocks());
+        return cseg_contrast_fwd(d, S_out, row_stats, row_loss, loss, stream_);
+    }
     const size_t npart = (size_t)p.nsplit * p.n_strips * FU_T;
     float* part1 = fused_ws;
     float* part2 = fused_ws + npart * 4;
     int* counters = reinterpret_cast<int*>(fused_ws + npart * 6);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)contrast_fused_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(FUSED_LDS_CAP - FUSED_LDS_STATIC)) != hipSuccess) {
-            cseg_set_error("contrast (fused forward): cannot raise dynamic LDS");
-            return 0;
-        }
-        attr_set = true;
-    }
     const float coef = d->temperature / d->base_temperature;
     CSEG_GRID_RESIDENT_LAUNCH();
     hipLaunchKernelGGL(contrast_fused_fwd_kernel, dim3(p.n_strips * p.nsplit), dim3(256), p.lds, stream, d->anchors, d->N, col, d->a_lab,

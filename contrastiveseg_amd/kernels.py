@@ -430,7 +430,10 @@ def fuse_sum_relu(same, low):
 # fan_out() hands every consumer its own alias of the tensor through ONE autograd node whose backward sums what arrives with the
 # n-ary sum kernel of the exchange unit (cseg_fuse_sum_fwd without coarse terms and without the ReLU).
 # ----------------------------------------------------------------------------------------------------------
-FANOUT_SUM = os.environ.get("CSEG_FANOUT_SUM", "0") == "1"
+# Round 6: ON by default. With the residual blocks on the grouped launches the step is one long chain on the compute stream and every
+# launch in it is paid in wall time (before, the forked branches hid them): A/B/A/B on one MI355X 91.7 / 90.4 -> 86.3 / 85.4 ms per
+# step (profiles/r06_ab_fanout_wgrad.txt; round 5, forked branches: 87.6 vs 87.5).
+FANOUT_SUM = os.environ.get("CSEG_FANOUT_SUM", "1") == "1"
 
 
 def sum_same(terms):
@@ -928,7 +931,10 @@ def bn_tiles_moments(stats):
 # (91.1 / 89.6 ms with it, 88.7 / 86.6 without: the weight gradients then compete with the chain for the same CUs instead of
 # filling holes) -- so it is an opt-in experiment (CSEG_WGRAD_STREAM=1), gradients verified equal by tests/test_gpu_streams.py.
 # ----------------------------------------------------------------------------------------------------------
-WGRAD_STREAM = os.environ.get("CSEG_WGRAD_STREAM", "0") == "1"
+# Round 6: ON by default for the same reason as FANOUT_SUM above -- on the serial chain the weight gradients (matrix-bound) now run
+# beside the BatchNorm passes (HBM-bound) of the next block instead of between them: 89.0 / 92.0 -> 87.9 / 87.8 ms per step, A/B/A/B
+# on one MI355X (profiles/r06_ab_fanout_wgrad.txt).
+WGRAD_STREAM = os.environ.get("CSEG_WGRAD_STREAM", "1") == "1"
 _WGRAD = {"on": False, "stream": None, "main": None, "used": False}
 
 
@@ -1781,11 +1787,30 @@ def bn_group_bwd(dys, xs, outs, mis, bns, mode):
     return res
 
 
+def _group_wrw(items):
+    """conv3x3_group_wrw on the weight-gradient stream when wgrad_scope is open (Trainer.train_step, CSEG_WGRAD_STREAM=1): the two
+    launches of a depth's weight gradients then run beside the BatchNorm passes and the next backward-data launch of the chain instead
+    of between them (the gradients feed nothing until the optimizer runs)."""
+    if not _WGRAD["on"] or not items[0][0].is_cuda or torch.cuda.is_current_stream_capturing():
+        return conv3x3_group_wrw(items)
+    cur = torch.cuda.current_stream(items[0][0].device)
+    side = _WGRAD["stream"]
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        dws = conv3x3_group_wrw(items)
+    for it in items:
+        for t in it:
+            t.record_stream(side)
+    for dw in dws:
+        dw.record_stream(_WGRAD["main"])             # read by the optimizer on the trainer's stream, after wgrad_scope joined the side stream
+    _WGRAD["used"] = True
+    return dws
+
+
 def basic_block_group_ok(blocks, xs):
     """Every block of the depth qualifies for the grouped node: what BasicBlockSplit needs (split kernels in all three directions,
     plain single-rank batch statistics from the convolution epilogues), f16x3, at least two members."""
-    if not (BLOCK_GROUP and 2 <= len(blocks) <= _hip.GROUP_MAX and split_arith_id() == ARITH_IDS["f16x3"] and CONV_EPILOGUE_STATS
-            and not _WGRAD["on"]):
+    if not (BLOCK_GROUP and 2 <= len(blocks) <= _hip.GROUP_MAX and split_arith_id() == ARITH_IDS["f16x3"] and CONV_EPILOGUE_STATS):
         return False
     for blk, x in zip(blocks, xs):
         c = blk.conv1.weight.shape[0]
@@ -1827,12 +1852,12 @@ class BasicBlockGroup(Function):
         # bn2 + add + ReLU (mask from `out`; the masked gradient g is also the identity path's gradient)
         r2 = bn_group_bwd(dys, c2s, outs, mi2, [b.bn2 for b in blocks], 2)
         da1s, _ = conv3x3_group_run([(r2[i][0], blocks[i].conv2.weight, True, r2[i][4], None) for i in range(n)])
-        dw2s = conv3x3_group_wrw([(a1s[i], r2[i][0], am1[i], r2[i][4]) for i in range(n)])
+        dw2s = _group_wrw([(a1s[i], r2[i][0], am1[i], r2[i][4]) for i in range(n)])
         # bn1 + ReLU (mask recomputed from c1)
         r1 = bn_group_bwd(da1s, c1s, [None] * n, mi1, [b.bn1 for b in blocks], 1)
         # conv1: backward-data with the identity path's gradient added in the epilogue
         dxs, _ = conv3x3_group_run([(r1[i][0], blocks[i].conv1.weight, True, r1[i][4], r2[i][3]) for i in range(n)])
-        dw1s = conv3x3_group_wrw([(xs[i], r1[i][0], axs[i], r1[i][4]) for i in range(n)])
+        dw1s = _group_wrw([(xs[i], r1[i][0], axs[i], r1[i][4]) for i in range(n)])
         grads = [None]
         for i, blk in enumerate(blocks):
             _, dg1, db1, _, _ = r1[i]

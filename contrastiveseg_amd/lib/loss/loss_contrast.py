@@ -238,6 +238,10 @@ class ContrastCELoss(nn.Module, ABC):
         embedding = preds['embed']
         loss = self.seg_criterion(seg, target)                       # upsample fused into the CE kernel
         loss_contrast = self.contrast_criterion(embedding, target, seg=seg, seg_ready=preds.get('seg_ready'))
+        # the two terms of the last call, detached (no host sync): the segmentation term is a smooth function of the weights, the
+        # contrastive term is not (argmax decides hard / easy, rounding-level changes of the logits move anchors between the sets) --
+        # tests that compare two implementations after an SGD step bound the former tightly and the latter loosely
+        self.last_terms = (loss.detach(), loss_contrast.detach())
         if with_embed is True:
             return loss + self.loss_weight * loss_contrast
         return loss + 0 * loss_contrast  # same trick as the reference: keeps every parameter in the DDP graph
@@ -267,6 +271,10 @@ class ContrastAuxCELoss(nn.Module, ABC):
         embedding = preds['embed']
         loss = self.seg_criterion([seg_aux, seg], target)
         loss_contrast = self.contrast_criterion(embedding, target, seg=seg, seg_ready=preds.get('seg_ready'))
+        # the two terms of the last call, detached (no host sync): the segmentation term is a smooth function of the weights, the
+        # contrastive term is not (argmax decides hard / easy, rounding-level changes of the logits move anchors between the sets) --
+        # tests that compare two implementations after an SGD step bound the former tightly and the latter loosely
+        self.last_terms = (loss.detach(), loss_contrast.detach())
         if with_embed is True:
             return loss + self.loss_weight * loss_contrast
         return loss + 0 * loss_contrast

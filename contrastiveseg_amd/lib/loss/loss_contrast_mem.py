@@ -74,6 +74,10 @@ class ContrastCELoss(nn.Module, ABC):
                                                     pixel_queue=pixel_queue, seg_ready=preds.get('seg_ready'))
         else:
             loss_contrast = 0
+        # the two terms of the last call, detached (no host sync): the segmentation term is a smooth function of the weights, the
+        # contrastive term is not (argmax decides hard / easy, rounding-level changes of the logits move anchors between the sets) --
+        # tests that compare two implementations after an SGD step bound the former tightly and the latter loosely
+        self.last_terms = (loss.detach(), loss_contrast.detach())
         if with_embed is True:
             return loss + self.loss_weight * loss_contrast
         return loss + 0 * loss_contrast
@@ -103,6 +107,10 @@ class ContrastAuxCELoss(ContrastCELoss):
                                                     pixel_queue=pixel_queue, seg_ready=preds.get('seg_ready'))
         else:
             loss_contrast = 0
+        # the two terms of the last call, detached (no host sync): the segmentation term is a smooth function of the weights, the
+        # contrastive term is not (argmax decides hard / easy, rounding-level changes of the logits move anchors between the sets) --
+        # tests that compare two implementations after an SGD step bound the former tightly and the latter loosely
+        self.last_terms = (loss.detach(), loss_contrast.detach())
         if with_embed is True:
             return loss + self.loss_weight * loss_contrast
         return loss + 0 * loss_contrast

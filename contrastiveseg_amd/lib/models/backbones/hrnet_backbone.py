@@ -339,14 +339,21 @@ class HighResolutionModule(nn.Module):
             return K.fuse_sum_relu(same, low)
 
         outs = [None] * len(self.fuse_layers)
+        # Every side stream first waits for what is on the calling stream NOW (the branch outputs), then output 0 is enqueued on the
+        # calling stream and the others on their streams -- in the order 0, 1, 2, ... of the single-stream path, so that the autograd
+        # nodes are created in the same order and backward accumulates the (up to four) gradients that meet at a branch output in the
+        # same order: a forked step is then BIT-identical to the single-stream one. (Round 6: with outputs 1.. created before output 0 the
+        # fp32 sums differed in the last bit, and one SGD step of this network amplifies that to 1e-3 of the next loss -- the contrastive
+        # term's anchor mining is an argmax, tests/test_gpu_streams.py.)
         for i in range(1, len(self.fuse_layers)):
             s = streams[i - 1]
             s.wait_stream(cur)
             for xj in x:
                 xj.record_stream(s)                   # every output reads every branch
-            with torch.cuda.stream(s):
-                outs[i] = row_out(i)
         outs[0] = row_out(0)
+        for i in range(1, len(self.fuse_layers)):
+            with torch.cuda.stream(streams[i - 1]):
+                outs[i] = row_out(i)
         for i, s in enumerate(streams):
             cur.wait_stream(s)
             outs[i + 1].record_stream(cur)

@@ -103,6 +103,12 @@ static inline hipError_t hipGetLastError() { return emu::last_error(); }
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "emulated launch failure"; }
 template <class F>
 static inline hipError_t hipFuncSetAttribute(F, int, int bytes) { return bytes <= emu::LDS_BYTES ? hipSuccess : hipErrorLaunchFailure; }
+// the emulated device: a full MI355X (256 CUs; as many blocks per CU as 160 KB of LDS hold)
+enum { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 256; return hipSuccess; }
+template <class F>
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t lds) { *n = lds ? (int)(emu::LDS_BYTES / lds) : 8; return hipSuccess; }
 // CSEG_EMU_TRACE=<file>: one line per launch with the kernel expression as written at the launch site (which kernel a routing
 // switch really took -- tests assert on it)
 static inline void emu_trace_launch(const char* what) {

@@ -80,9 +80,14 @@ def test_graph_replay_equals_eager_steps(model, backbone, loss, cfg_file, contra
         # gradients of the first backward (same weights, same input in every run) and the state after the first update
         grads = {k: p.grad.detach().float().cpu().numpy().copy() for k, p in tr.seg_net.named_parameters() if p.grad is not None}
         sd = {k: v.detach().float().cpu().numpy().copy() for k, v in tr.seg_net.state_dict().items()}
-        losses = [l0] + [float(tr.train_step(data)) for _ in range(2)]
+        l1 = float(tr.train_step(data))
         torch.cuda.synchronize()
-        runs[name] = (losses, grads, sd)
+        crit = getattr(tr.pixel_loss, "module", tr.pixel_loss)
+        terms = tuple(float(t) for t in crit.last_terms)            # (segmentation term, contrastive term) of the second step
+        sel = set(crit.contrast_criterion.last_selection["sel_pix"].cpu().numpy().tolist())
+        losses = [l0, l1, float(tr.train_step(data))]
+        torch.cuda.synchronize()
+        runs[name] = (losses, grads, sd, terms, sel)
         if name == "graph":
             g = tr.step_graph
             assert g is not None and g.failed is None and len(g.captured) == 1, (g and g.failed)
@@ -108,9 +113,19 @@ def test_graph_replay_equals_eager_steps(model, backbone, loss, cfg_file, contra
     assert not bad, ("gradients of the replay differ from the eager ones", len(bad), bad[:8], le.tolist(), le2.tolist(), lg.tolist())
     # after ONE update from gradients that agree to <= 2e-4: a sanity bound only (at this initialisation a 1e-5 perturbation of the
     # forward moves the gradients by 3 % -- tools/stats_grad_probe.py on the MI355X -- and the second loss by up to 1e-3)
-    # (1e-2: the HRNet-OCR case came out at 3.4e-3 on one MI355X box of round 5 -- 3.4923 against 3.4806, identical with and without
-    # forked streams, every gradient inside its bound -- after passing at 3e-3 on every earlier box)
-    assert abs(le[1] - lg[1]) <= 1e-2 * abs(le[1]), (le.tolist(), le2.tolist(), lg.tolist())
+    # What the second loss can and cannot show (round 6, profiles/r06_stream_bisect.txt). The replay issues the eager step's kernels,
+    # but autograd.grad inside the capture visits the nodes in another order than backward(), so the fp32 sums of the gradients that
+    # meet at a fan-out (the branch outputs of an exchange unit, the head inputs) are taken in another order: last-bit differences in
+    # the first-step gradients, measured above. One SGD step later the SEGMENTATION term -- a smooth function of the weights -- has
+    # moved by <= 1e-3 relative (this network at its random initialisation amplifies a rounding-level change of the forward ~1000 x),
+    # while the CONTRASTIVE term is not continuous at all: which pixels are hard / easy anchors is decided by an argmax of the logits,
+    # a flipped pixel changes the counts and with them every later random draw. On the MI355X a pure summation-order change moved the
+    # second loss by 1e-3 with an unchanged anchor set; a changed set (HRNet-OCR in round 5: 3.4923 vs 3.4806) moves the contrastive
+    # term by percents. So: the smooth term is bounded tightly, the total loosely, and the message says how many anchors moved.
+    te, tg = runs["eager"][3], runs["graph"][3]
+    moved = len(runs["eager"][4] ^ runs["graph"][4])
+    assert abs(te[0] - tg[0]) <= 2e-3 * abs(te[0]), ("segmentation term of the second step", te, tg, moved)
+    assert abs(le[1] - lg[1]) <= 1e-2 * abs(le[1]), (le.tolist(), le2.tolist(), lg.tolist(), te, tg, "mined anchors that differ: %d" % moved)
     for k, a in runs["eager"][2].items():
         b = runs["graph"][2][k]
         scale = max(float(np.abs(a).max()), 1e-3)          # (a conv bias in front of a BN moves by lr x rounding noise only)
@@ -118,8 +133,8 @@ def test_graph_replay_equals_eager_steps(model, backbone, loss, cfg_file, contra
         # BN counters and queue pointers exactly; weights after one SGD step of lr 0.01, BN buffers and the bank to rounding
         assert dev <= (0.0 if k.endswith(("num_batches_tracked", "_ptr")) else 2e-5), ("state " + k, dev)
     print(model, loss, "streams" if streams else "one stream", "losses eager %s | graph %s (eager-vs-eager %.1e); worst gradient "
-          "deviation %s %.2e (eager-vs-eager %.2e)" % (le.round(6).tolist(), lg.round(6).tolist(), np.abs(le - le2).max(),
-                                                       worst[0], worst[1], worst[2]))
+          "deviation %s %.2e (eager-vs-eager %.2e); second step: segmentation term %.6f vs %.6f, contrastive %.6f vs %.6f, %d mined anchors differ"
+          % (le.round(6).tolist(), lg.round(6).tolist(), np.abs(le - le2).max(), worst[0], worst[1], worst[2], te[0], tg[0], te[1], tg[1], moved))
 
 
 def test_graph_falls_back_for_what_it_does_not_cover(monkeypatch):

@@ -1,4 +1,8 @@
-"""Concurrency inside the eager step (round 4): the HRNet branches / exchange paths on forked HIP streams
+"""Round 6: a forked step is BIT-identical to the single-stream step since HighResolutionModule._exchange_forked creates its autograd
+nodes in the single-stream order (before, outputs 1.. were built before output 0, backward summed the gradients that meet at a branch
+output in another order, and one SGD step amplified the last-bit difference to 1e-3 of the next loss: profiles/r06_stream_bisect.txt).
+
+Concurrency inside the eager step (round 4): the HRNet branches / exchange paths on forked HIP streams
 (lib/models/backbones/hrnet_backbone.py) and the weight gradients on their own stream (kernels.wgrad_scope, opened by
 Trainer.train_step). Both only re-order independent work, so one train step must give the gradients of the single-stream step:
 compared after the FIRST backward (same weights, same input; later steps of these freshly initialised networks amplify rounding
@@ -53,8 +57,12 @@ def _run(forks, wgrad, monkeypatch, model="hrnet_w48_contrast", backbone="hrnet4
     grads = {k: p.grad.detach().float().cpu().numpy().copy() for k, p in tr.seg_net.named_parameters() if p.grad is not None}
     l1 = float(tr.train_step(data))
     torch.cuda.synchronize()
+    crit = getattr(tr.pixel_loss, "module", tr.pixel_loss)
+    terms = tuple(float(t) for t in crit.last_terms)                      # (segmentation term, contrastive term) of the second step
+    sel = crit.contrast_criterion.last_selection["sel_pix"].cpu().numpy().copy()
     del tr, data
     torch.cuda.empty_cache()
+    _run.last_second_step = (terms, sel)
     return (l0, l1), grads
 
 

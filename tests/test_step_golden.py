@@ -143,6 +143,12 @@ def _compare(res, g, c, loss_rtol, grad_tol, loss1_rtol):
         assert np.abs(res["pixel_queue_after"] - g["pixel_queue_after"]).max() <= 1e-4
     # The second loss sees the gradient noise above multiplied by the step (lr 0.01 x gradients up to 84 at this
     # initialisation): a coarse sanity bound only -- the step went the same way by about the same amount.
+    # (Round 6, why it cannot be tight: profiles/r06_stream_bisect.txt. The contrastive term is not a continuous function of the
+    # weights -- an argmax of the logits decides which pixels are hard / easy anchors, and a changed count shifts every later random
+    # draw. On the MI355X two fp32 evaluations of THIS repository that differ only in the tiling of the 96-channel convolutions
+    # (first-step gradients equal to 1e-5) give second-step terms 1.84489 / 1.84545 (segmentation, smooth: 3e-4) and 6.570 / 6.791
+    # (contrastive: 3.4 %, every mined anchor different). The 5 -> 8 % of round 5 is that effect on the HRNet-OCR golden, whose
+    # auxiliary head doubles the logits an argmax flip can come from; the gradient and update checks above are the parity statement.)
     if not c.get("skip_loss1"):
         assert abs(res["loss1"] - float(g["loss1"])) <= loss1_rtol * abs(float(g["loss1"])), (res["loss1"], float(g["loss1"]))
     return worst
