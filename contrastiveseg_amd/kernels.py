@@ -931,10 +931,13 @@ def bn_tiles_moments(stats):
 # (91.1 / 89.6 ms with it, 88.7 / 86.6 without: the weight gradients then compete with the chain for the same CUs instead of
 # filling holes) -- so it is an opt-in experiment (CSEG_WGRAD_STREAM=1), gradients verified equal by tests/test_gpu_streams.py.
 # ----------------------------------------------------------------------------------------------------------
-# Round 6: ON by default for the same reason as FANOUT_SUM above -- on the serial chain the weight gradients (matrix-bound) now run
-# beside the BatchNorm passes (HBM-bound) of the next block instead of between them: 89.0 / 92.0 -> 87.9 / 87.8 ms per step, A/B/A/B
-# on one MI355X (profiles/r06_ab_fanout_wgrad.txt).
-WGRAD_STREAM = os.environ.get("CSEG_WGRAD_STREAM", "1") == "1"
+# Round 6: measured again on the serial chain of the grouped launches (the grouped weight gradients go through _group_wrw): the
+# weight gradients (matrix-bound) then run beside the BatchNorm passes (HBM-bound) of the next block -- 89.0 / 92.0 -> 87.9 / 87.8 ms per
+# step and, second box, 86.6 / 88.2 -> 85.5 / 86.4 (A/B/A/B, profiles/r06_ab_fanout_wgrad.txt): about -1.2 ms. STILL opt-in: a process
+# that ran eager steps with this stream and then captures a step graph (tests/test_gpu_step_graph.py runs both in one process) got
+# ZERO parameter gradients from the replay (71 and 920 of 920 tensors in two runs: a race, GPU calls r06_g16 / r06_g18; with the switch
+# off the same test passes) -- not understood, so not a default.
+WGRAD_STREAM = os.environ.get("CSEG_WGRAD_STREAM", "0") == "1"
 _WGRAD = {"on": False, "stream": None, "main": None, "used": False}
 
 

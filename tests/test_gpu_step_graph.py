@@ -110,7 +110,7 @@ def test_graph_replay_equals_eager_steps(model, backbone, loss, cfg_file, contra
     devs.sort(reverse=True)
     worst = (devs[0][2], devs[0][0], devs[0][1])
     bad = [(k, "%.2e" % d, "%.2e" % o) for d, o, k in devs if d > max(4.0 * o, 2e-4)]
-    assert not bad, ("gradients of the replay differ from the eager ones", len(bad), bad[:8], le.tolist(), le2.tolist(), lg.tolist())
+    assert not bad, ("gradients of the replay differ from the eager ones", len(bad), [b[0] for b in bad][:80], bad[:4], le.tolist(), le2.tolist(), lg.tolist())
     # after ONE update from gradients that agree to <= 2e-4: a sanity bound only (at this initialisation a 1e-5 perturbation of the
     # forward moves the gradients by 3 % -- tools/stats_grad_probe.py on the MI355X -- and the second loss by up to 1e-3)
     # What the second loss can and cannot show (round 6, profiles/r06_stream_bisect.txt). The replay issues the eager step's kernels,
