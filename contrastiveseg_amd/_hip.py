@@ -104,6 +104,10 @@ SIGNATURES = {
     "cseg_bn_group_tiles_finalize": (_c_int, [_ptr, _c_int, _ptr]),
     "cseg_bn_group_apply": (_c_int, [_ptr, _c_int, _c_int, _ptr]),
     "cseg_bn_group_bwd": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr]),
+    "cseg_bn_group_tiles_moments": (_c_int, [_ptr, _c_int, _ptr, _ptr]),
+    "cseg_bn_group_finalize": (_c_int, [_ptr, _c_int, _ptr, _ptr]),
+    "cseg_bn_group_bwd_reduce": (_c_int, [_ptr, _c_int, _c_int, _ptr, _ptr]),
+    "cseg_bn_group_bwd_apply": (_c_int, [_ptr, _c_int, _c_int, _ptr, _ptr]),
     "cseg_conv3x3_split_dil_fwd": (_c_int, [_ptr, _ptr, _ptr, _ptr] + [_c_int] * 7 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_conv3x3_s2_split_packed_bytes": (ctypes.c_size_t, [_c_int] * 2),
     "cseg_conv3x3_s2_split_plan": (_c_int, [_c_int] * 4 + [_ptr, _ptr]),

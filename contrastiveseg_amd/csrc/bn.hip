@@ -347,12 +347,12 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restric
 
 // dx = a * (dy' - sum(dy')/N - (x-mean) * invstd^2 * sum(dy'*(x-mean))/N);  with frozen statistics (eval) dx = a * dy'
 template <bool VEC, bool MASK>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                           const float* __restrict__ mean_invstd,
-                                                           const float* __restrict__ weight,
-                                                           const float* __restrict__ bias, const double* __restrict__ sums,
-                                                           double inv_count, BnDims d, float* __restrict__ dx, unsigned* __restrict__ amax_out) {
-    const int plane = blockIdx.x / d.n_ck, ck = blockIdx.x - plane * d.n_ck;
+__device__ __forceinline__ void bn_bwd_apply_body(const float* __restrict__ dy, const float* __restrict__ x,
+                                                  const float* __restrict__ mean_invstd,
+                                                  const float* __restrict__ weight,
+                                                  const float* __restrict__ bias, const double* __restrict__ sums,
+                                                  double inv_count, const BnDims& d, float* __restrict__ dx, unsigned* __restrict__ amax_out, int bid) {
+    const int plane = bid / d.n_ck, ck = bid - plane * d.n_ck;
     const int c = plane % d.C;
     const float mean = mean_invstd[2 * c], invstd = mean_invstd[2 * c + 1];
     const float a = (weight ? weight[c] : 1.f) * invstd;
@@ -397,6 +397,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         }
     }
     if (amax_out) publish_amax(am, amax_out);
+}
+template <bool VEC, bool MASK>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ mean_invstd,
+                                                           const float* __restrict__ weight,
+                                                           const float* __restrict__ bias, const double* __restrict__ sums,
+                                                           double inv_count, BnDims d, float* __restrict__ dx, unsigned* __restrict__ amax_out) {
+    bn_bwd_apply_body<VEC, MASK>(dy, x, mean_invstd, weight, bias, sums, inv_count, d, dx, amax_out, (int)blockIdx.x);
 }
 
 
@@ -930,6 +938,70 @@ __global__ __launch_bounds__(256) void bn_group_bwd_apply_kernel(const BnGArgs a
                                         (int)blockIdx.x - M.block0);
 }
 
+// SyncBN forms (the statistics cross the ranks between two launches): the members' [C_i + 1, 2] fp64 moments / gradient sums live
+// back to back in ONE buffer (member i at row `row0`), which is what the host all-reduces -- one collective per depth and direction,
+// no concatenation kernel.
+struct BnSyncRows { int row0[CSEG_GROUP_MAX]; };
+
+__global__ __launch_bounds__(256) void bn_group_tiles_moments_kernel(const BnGArgs a, const BnSyncRows r, double* __restrict__ packed) {
+    const int mi = bn_group_member(a, (int)blockIdx.x);
+    const BnGM& M = a.m[mi];
+    const int c = (int)blockIdx.x - M.block0;
+    double count, m0, m1;
+    tiles_combine(M.st, M.T, c, count, m0, m1);
+    if (threadIdx.x == 0) {
+        double* mom = packed + 2 * (size_t)r.row0[mi];
+        mom[2 * c] = m0;
+        mom[2 * c + 1] = m1;
+        if (c == 0) { mom[2 * M.d.C] = count; mom[2 * M.d.C + 1] = 0.0; }
+    }
+}
+// (globally summed moments -> mean / invstd / running statistics; the body of bn_finalize_kernel with the exchanged count of row C)
+__global__ __launch_bounds__(256) void bn_group_finalize_kernel(const BnGArgs a, const BnSyncRows r, const double* __restrict__ packed) {
+    const int mi = bn_group_member(a, (int)blockIdx.x);
+    const BnGM& M = a.m[mi];
+    const int c = ((int)blockIdx.x - M.block0) * 256 + (int)threadIdx.x;
+    if (c == 0 && M.nbt) *M.nbt += 1;
+    if (c >= M.d.C) return;
+    const double* mom = packed + 2 * (size_t)r.row0[mi];
+    finalize_channel(mom[2 * c], mom[2 * c + 1], mom[2 * M.d.C], M.eps, M.momentum, M.rm, M.rv, c, M.mi);
+}
+// (block partials of bn_group_bwd_reduce_kernel -> fp64 sums + this rank's element count, d_weight / d_bias: bn_bwd_sums_kernel)
+__global__ __launch_bounds__(256) void bn_group_bwd_sums_kernel(const BnGArgs a, const BnSyncRows r, double* __restrict__ packed) {
+    const int mi = bn_group_member(a, (int)blockIdx.x);
+    const BnGM& M = a.m[mi];
+    const int lb = (int)blockIdx.x - M.block0;
+    const int c = lb * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    double* sums = packed + 2 * (size_t)r.row0[mi];
+    if (lb == 0 && threadIdx.x == 0) {
+        sums[2 * M.d.C] = (double)M.d.B * (double)M.d.HW;
+        sums[2 * M.d.C + 1] = 0.0;
+    }
+    if (c >= M.d.C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int s = lane; s < M.d.S; s += 64) {
+        s0 += (double)M.ws[((size_t)s * M.d.C + c) * 2 + 0];
+        s1 += (double)M.ws[((size_t)s * M.d.C + c) * 2 + 1];
+    }
+    s0 = wave_sum_d(s0);
+    s1 = wave_sum_d(s1);
+    if (lane == 0) {
+        sums[2 * c] = s0;
+        sums[2 * c + 1] = s1;
+        if (M.dw) M.dw[c] = (float)(s1 * (double)M.mi[2 * c + 1]);
+        if (M.db) M.db[c] = (float)s0;
+    }
+}
+
+template <bool MASK, bool FROM_G>
+__global__ __launch_bounds__(256) void bn_group_bwd_apply_sync_kernel(const BnGArgs a, const BnSyncRows r, const double* __restrict__ packed) {
+    const int mi = bn_group_member(a, (int)blockIdx.x);
+    const BnGM& M = a.m[mi];
+    // inv_count 0: the exchanged element count of row C (bn_bwd_apply_body)
+    bn_bwd_apply_body<true, MASK>(FROM_G ? M.g : M.dy, M.x, M.mi, M.w, M.b, packed + 2 * (size_t)r.row0[mi], 0.0, M.d, M.dx, M.amax,
+                                  (int)blockIdx.x - M.block0);
+}
+
 int bn_group_fill(const char* who, const cseg_bn_group_member* mem, int n, int grid_kind, BnGArgs& a, long& total, bool& all_vec) {
     CSEG_REQUIRE(mem && n >= 1 && n <= CSEG_GROUP_MAX, "%s: needs 1 .. %d members", who, CSEG_GROUP_MAX);
     total = 0;
@@ -1027,5 +1099,122 @@ extern "C" int cseg_bn_group_bwd(const cseg_bn_group_member* mem, int n, int mod
     else if (mode == 2) hipLaunchKernelGGL((bn_group_bwd_apply_kernel<false, true>), dim3((unsigned)total), dim3(256), 0, stream, a, training);
     else hipLaunchKernelGGL((bn_group_bwd_apply_kernel<false, false>), dim3((unsigned)total), dim3(256), 0, stream, a, training);
     CSEG_CHECK_LAUNCH("bn_group_bwd");
+    return 1;
+}
+
+// ---- SyncBN forms of the grouped passes (cseg_hip.h): the members' fp64 [C_i + 1, 2] rows back to back in `packed`
+namespace {
+int bn_sync_rows(const cseg_bn_group_member* mem, int n, BnSyncRows& r) {
+    int row = 0;
+    for (int i = 0; i < CSEG_GROUP_MAX; ++i) {
+        r.row0[i] = row;
+        if (i < n) row += mem[i].C + 1;
+    }
+    return row;
+}
+}  // namespace
+
+// == cseg_bn_tiles_moments per member, written at row sum_{j<i} (C_j + 1) of packed [sum (C_i + 1), 2] f64
+extern "C" int cseg_bn_group_tiles_moments(const cseg_bn_group_member* mem, int n, double* packed, cseg_stream_t stream_) {
+    BnGArgs a;
+    long total;
+    bool vec;
+    if (!bn_group_fill("bn_group_tiles_moments", mem, n, 0, a, total, vec)) return 0;
+    CSEG_REQUIRE(packed, "bn_group_tiles_moments: null output");
+    for (int i = 0; i < n; ++i)
+        CSEG_REQUIRE(mem[i].stats && mem[i].T > 0 && (reinterpret_cast<uintptr_t>(mem[i].stats) & 15) == 0, "bn_group_tiles_moments: member %d: bad statistics buffer", i);
+    BnSyncRows r;
+    bn_sync_rows(mem, n, r);
+    hipLaunchKernelGGL(bn_group_tiles_moments_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream_, a, r, packed);
+    CSEG_CHECK_LAUNCH("bn_group_tiles_moments");
+    return 1;
+}
+
+// == cseg_bn_finalize(count 0) per member from its rows of the (all-reduced) packed moments
+extern "C" int cseg_bn_group_finalize(const cseg_bn_group_member* mem, int n, const double* packed, cseg_stream_t stream_) {
+    CSEG_REQUIRE(mem && packed && n >= 1 && n <= CSEG_GROUP_MAX, "bn_group_finalize: bad arguments");
+    BnGArgs a;
+    long total = 0;
+    for (int i = 0; i < n; ++i) {
+        const cseg_bn_group_member& s = mem[i];
+        CSEG_REQUIRE(s.C > 0 && s.mean_invstd, "bn_group_finalize: member %d: bad arguments", i);
+        CSEG_REQUIRE((s.running_mean == nullptr) == (s.running_var == nullptr), "bn_group_finalize: running_mean/var must come together");
+        BnGM& m = a.m[i];
+        m = BnGM();
+        m.mi = s.mean_invstd; m.rm = s.running_mean; m.rv = s.running_var; m.nbt = s.num_batches_tracked;
+        m.d = BnDims{s.B, s.C, s.HW, 0, 0};
+        m.eps = s.eps; m.momentum = s.momentum;
+        m.block0 = (int)total;
+        total += (s.C + 255) / 256;
+    }
+    for (int i = n; i < CSEG_GROUP_MAX; ++i) a.m[i] = a.m[0];
+    a.n = n;
+    BnSyncRows r;
+    bn_sync_rows(mem, n, r);
+    hipLaunchKernelGGL(bn_group_finalize_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream_, a, r, packed);
+    CSEG_CHECK_LAUNCH("bn_group_finalize");
+    return 1;
+}
+
+// == cseg_bn_bwd_reduce per member: g_masked (mode 2), d_weight, d_bias, and the fp64 sums [C_i + 1, 2] into the member's rows of packed
+extern "C" int cseg_bn_group_bwd_reduce(const cseg_bn_group_member* mem, int n, int mode, double* packed, cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CSEG_REQUIRE(mode >= 0 && mode <= 2 && packed, "bn_group_bwd_reduce: mode %d / null output", mode);
+    BnGArgs a;
+    long total;
+    bool vec;
+    if (!bn_group_fill("bn_group_bwd_reduce", mem, n, 2, a, total, vec)) return 0;
+    BnSyncRows r;
+    bn_sync_rows(mem, n, r);
+    bool grouped = true;
+    for (int i = 0; i < n; ++i) {
+        CSEG_REQUIRE(mem[i].dy && mem[i].x && mem[i].mean_invstd && mem[i].ws, "bn_group_bwd_reduce: member %d: null pointer", i);
+        CSEG_REQUIRE(mode != 2 || (mem[i].out && mem[i].g_masked), "bn_group_bwd_reduce: mode 2 needs `out` and `g_masked`");
+        grouped = grouped && vec_ok(mem[i].HW, mem[i].dy, mem[i].x, mem[i].out, mem[i].g_masked);
+    }
+    if (!grouped) {
+        for (int i = 0; i < n; ++i)
+            if (!cseg_bn_bwd_reduce(mem[i].dy, mem[i].x, mem[i].out, mem[i].mean_invstd, mem[i].weight, mem[i].bias, mode, mem[i].B, mem[i].C, mem[i].HW,
+                                    mem[i].ws, mem[i].g_masked, packed + 2 * (size_t)r.row0[i], mem[i].d_weight, mem[i].d_bias, stream_))
+                return 0;
+        return 1;
+    }
+    if (mode == 0) hipLaunchKernelGGL(bn_group_bwd_reduce_kernel<0>, dim3((unsigned)total), dim3(256), 0, stream, a);
+    else if (mode == 1) hipLaunchKernelGGL(bn_group_bwd_reduce_kernel<1>, dim3((unsigned)total), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(bn_group_bwd_reduce_kernel<2>, dim3((unsigned)total), dim3(256), 0, stream, a);
+    long blocks = 0;
+    for (int i = 0; i < n; ++i) { a.m[i].block0 = (int)blocks; blocks += (mem[i].C + 3) / 4; }
+    hipLaunchKernelGGL(bn_group_bwd_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, r, packed);
+    CSEG_CHECK_LAUNCH("bn_group_bwd_reduce");
+    return 1;
+}
+
+// == cseg_bn_bwd_apply_amax(count 0) per member from its rows of the (all-reduced) packed sums: dx, max|dx|
+extern "C" int cseg_bn_group_bwd_apply(const cseg_bn_group_member* mem, int n, int mode, const double* packed, cseg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CSEG_REQUIRE(mode >= 0 && mode <= 2 && packed, "bn_group_bwd_apply: mode %d / null sums", mode);
+    BnGArgs a;
+    long total;
+    bool vec;
+    if (!bn_group_fill("bn_group_bwd_apply", mem, n, 1, a, total, vec)) return 0;
+    BnSyncRows r;
+    bn_sync_rows(mem, n, r);
+    bool grouped = true;
+    for (int i = 0; i < n; ++i) {
+        CSEG_REQUIRE(mem[i].x && mem[i].mean_invstd && mem[i].dx && (mode == 2 ? mem[i].g_masked != nullptr : mem[i].dy != nullptr),
+                     "bn_group_bwd_apply: member %d: null pointer", i);
+        grouped = grouped && vec_ok(mem[i].HW, mode == 2 ? mem[i].g_masked : mem[i].dy, mem[i].x, mem[i].dx);
+    }
+    if (!grouped) {
+        for (int i = 0; i < n; ++i)
+            if (!bn_bwd_apply_impl(mode == 2 ? mem[i].g_masked : mem[i].dy, mem[i].x, mem[i].mean_invstd, mem[i].weight, mem[i].bias,
+                                   packed + 2 * (size_t)r.row0[i], 0.0, mode == 1, mem[i].B, mem[i].C, mem[i].HW, mem[i].dx, mem[i].amax_out, stream_))
+                return 0;
+        return 1;
+    }
+    if (mode == 1) hipLaunchKernelGGL((bn_group_bwd_apply_sync_kernel<true, false>), dim3((unsigned)total), dim3(256), 0, stream, a, r, packed);
+    else if (mode == 2) hipLaunchKernelGGL((bn_group_bwd_apply_sync_kernel<false, true>), dim3((unsigned)total), dim3(256), 0, stream, a, r, packed);
+    else hipLaunchKernelGGL((bn_group_bwd_apply_sync_kernel<false, false>), dim3((unsigned)total), dim3(256), 0, stream, a, r, packed);
+    CSEG_CHECK_LAUNCH("bn_group_bwd_apply");
     return 1;
 }

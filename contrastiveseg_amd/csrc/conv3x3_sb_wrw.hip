@@ -722,8 +722,9 @@ int sb_wrw_splits(int B, int Cin, int Cout, int H, int W, int arith) {
 // the larger of the two arithmetics' needs (they may split differently: version 1 has no 32-pixel segments)
 extern "C" size_t cseg_conv3x3_sb_wrw_ws_floats(int B, int Cin, int Cout, int H, int W) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || Cin % 16 || Cout % CO_B) return 0;
-    if (W % 32 && sb_wrw_version() != 2) return 0;          // ragged widths: version 2 only
-    if (W % 32) return (size_t)sb_wrw_splits(B, Cin, Cout, H, W, CSEG_ARITH_F16X3) * 9 * Cin * Cout;       // (f16x3 only, below)
+    // ragged widths: f16x3 only, and f16x3 always runs version 2 whatever CSEG_CONV3X3_SB_WRW_V says (wrw_impl) -- the size of that
+    // launch (with the version switch at 1 this returned 0 and the autograd path raised instead of running)
+    if (W % 32) return (size_t)sb_wrw_splits(B, Cin, Cout, H, W, CSEG_ARITH_F16X3) * 9 * Cin * Cout;
     if (W % SEG && sb_wrw_version() != 2) return (size_t)sb_wrw_splits(B, Cin, Cout, H, W, CSEG_ARITH_F16X3) * 9 * Cin * Cout;
     const int a = sb_wrw_splits(B, Cin, Cout, H, W, CSEG_ARITH_BF16X6), b = sb_wrw_splits(B, Cin, Cout, H, W, CSEG_ARITH_F16X3);
     return (size_t)(a > b ? a : b) * 9 * Cin * Cout;

@@ -1790,6 +1790,121 @@ def bn_group_bwd(dys, xs, outs, mis, bns, mode):
     return res
 
 
+# ---- SyncBN forms of the grouped BatchNorm passes: the statistics of a depth cross the ranks as ONE packed fp64 tensor between two
+# launches (lib/models/tools/fused_bn.BasicBlockGroupSync issues the all-reduce)
+def bn_group_sync_moments(xs):
+    """xs: convolution outputs that carry epilogue statistics -> packed moments [sum (C_i + 1), 2] f64 (row C_i of a member = this rank's
+    element count): cseg_bn_group_tiles_moments, one launch."""
+    n = len(xs)
+    arr = (_hip.BnGroupMember * n)()
+    rows = 0
+    for e, x in zip(arr, xs):
+        B, C, HW = _bn_dims(x)
+        st = known_tile_stats(x)
+        if st is None:
+            raise RuntimeError("bn_group_sync_moments: an input without epilogue statistics")
+        e.stats, e.B, e.C, e.HW, e.T = st.data_ptr(), B, C, HW, st.shape[1]
+        rows += C + 1
+    packed = torch.empty(rows, 2, dtype=F64, device=xs[0].device)
+    _hip.call("cseg_bn_group_tiles_moments", ctypes.byref(arr), n, _pf(packed), _hip.stream_ptr())
+    return packed
+
+
+def bn_group_sync_apply(xs, bns, residuals, relu, packed):
+    """The all-reduced packed moments -> mean / invstd / running statistics per site (cseg_bn_group_finalize), then
+    y = act(bn(x) [+ residual]) for all sites (cseg_bn_group_apply): two launches -> ([y], [mean_invstd], [max|y| record])."""
+    n = len(xs)
+    arr = (_hip.BnGroupMember * n)()
+    ys, mis, ams = [], [], []
+    for e, x, bn, r in zip(arr, xs, bns, residuals):
+        B, C, HW = _bn_dims(x)
+        mi = torch.empty(C, 2, dtype=F32, device=x.device)
+        y = torch.empty_like(x)
+        am = amax_request(x)
+        p, b = bn._parameters, bn._buffers
+        e.x, e.y, e.mean_invstd = x.data_ptr(), y.data_ptr(), mi.data_ptr()
+        if r is not None:
+            e.residual = _pq(r, "residual").value
+        w_, b_ = p.get("weight"), p.get("bias")
+        if w_ is not None:
+            e.weight = w_.data_ptr()
+        if b_ is not None:
+            e.bias = b_.data_ptr()
+        rm, rv, nbt = b.get("running_mean"), b.get("running_var"), b.get("num_batches_tracked")
+        if rm is not None:
+            e.running_mean, e.running_var = rm.data_ptr(), rv.data_ptr()
+        if nbt is not None:
+            e.num_batches_tracked = nbt.data_ptr()
+        if am is not None:
+            e.amax_out = am.data_ptr()
+        e.B, e.C, e.HW, e.eps, e.momentum = B, C, HW, float(bn.eps), float(bn.momentum)
+        ys.append(y)
+        mis.append(mi)
+        ams.append(am)
+    sp = _hip.stream_ptr()
+    _hip.call("cseg_bn_group_finalize", ctypes.byref(arr), n, _pf(packed), sp)
+    _hip.call("cseg_bn_group_apply", ctypes.byref(arr), n, int(bool(relu)), sp)
+    return ys, mis, ams
+
+
+def bn_group_sync_bwd_reduce(dys, xs, outs, mis, bns, mode):
+    """First half of the grouped SyncBN backward: masked gradients (mode 2), rank-local d_weight / d_bias and the packed fp64 gradient
+    sums [sum (C_i + 1), 2] the host all-reduces (cseg_bn_group_bwd_reduce, two launches) -> (packed, state for bn_group_sync_bwd_apply)."""
+    n = len(xs)
+    arr = (_hip.BnGroupMember * n)()
+    lib = _hip.lib()
+    needs, total, rows = [], 0, 0
+    for x in xs:
+        B, C, HW = _bn_dims(x)
+        nf = _BN_WS_NEED.get((B, C, HW))
+        if nf is None:
+            nf = _BN_WS_NEED[(B, C, HW)] = max(1, lib.cseg_bn_ws_floats(B, C, HW))
+        needs.append(total)
+        total += (nf + 63) // 64 * 64
+        rows += C + 1
+    dev = xs[0].device
+    key = (dev.index, _hip.raw_stream()) if dev.type == "cuda" else (-1, 0)
+    ws = _BN_GROUP_WS.get(key)
+    if ws is None or ws.numel() < total:
+        ws = _BN_GROUP_WS[key] = torch.empty(max(total, 1 << 17), dtype=F32, device=dev)
+    base = ws.data_ptr()
+    packed = torch.empty(rows, 2, dtype=F64, device=dev)
+    res = []
+    for e, dy, x, out, mi, bn, off in zip(arr, dys, xs, outs, mis, bns, needs):
+        B, C, HW = _bn_dims(x)
+        d_wb = torch.empty(2, C, dtype=F32, device=dev)
+        g = torch.empty_like(x) if mode == 2 else None
+        p = bn._parameters
+        e.dy, e.x, e.mean_invstd, e.ws = _pq(dy, "dy").value, x.data_ptr(), mi.data_ptr(), base + 4 * off
+        e.d_weight, e.d_bias = d_wb.data_ptr(), d_wb.data_ptr() + 4 * C
+        if mode == 2:
+            e.out, e.g_masked = out.data_ptr(), g.data_ptr()
+        w_, b_ = p.get("weight"), p.get("bias")
+        if w_ is not None:
+            e.weight = w_.data_ptr()
+        if b_ is not None:
+            e.bias = b_.data_ptr()
+        e.B, e.C, e.HW = B, C, HW
+        res.append([None, d_wb[0], d_wb[1], g, None])
+    _hip.call("cseg_bn_group_bwd_reduce", ctypes.byref(arr), n, int(mode), _pf(packed), _hip.stream_ptr())
+    return packed, (arr, res, mode, xs, dys)
+
+
+def bn_group_sync_bwd_apply(state, packed):
+    """Second half: dx of every site from the all-reduced packed sums (cseg_bn_group_bwd_apply, one launch) -> per site
+    (dx, d_weight, d_bias, masked gradient or None, max|dx| record)."""
+    arr, res, mode, xs, _dys = state
+    for e, x, r in zip(arr, xs, res):
+        dx = torch.empty_like(x)
+        am = amax_request(x)
+        e.dx = dx.data_ptr()
+        if am is not None:
+            e.amax_out = am.data_ptr()
+        r[0], r[4] = dx, am
+    _hip.call("cseg_bn_group_bwd_apply", ctypes.byref(arr), len(xs), int(mode), _pf(packed), _hip.stream_ptr())
+    return [tuple(r) for r in res]
+
+
 def _group_wrw(items):
     """conv3x3_group_wrw on the weight-gradient stream when wgrad_scope is open (Trainer.train_step, CSEG_WGRAD_STREAM=1): the two
     launches of a depth's weight gradients then run beside the BatchNorm passes and the next backward-data launch of the chain instead

@@ -230,6 +230,13 @@ def _group_exchange_backward(dys, xs, outs, mis, bns, mode, sync_group):
     return res
 
 
+def _grouped_sync_ok():
+    """The grouped launches of round 6 (kernels.conv3x3_group_run / bn_group_sync_* / conv3x3_group_wrw) serve the SyncBN node too:
+    per depth 8 launches + 2 collectives forward and 14 + 2 backward whatever the number of branches (before: 8 n and ~10 n launches).
+    CSEG_BLOCK_GROUP=0 restores the per-member calls."""
+    return getattr(K, "BLOCK_GROUP", False) and hasattr(K, "bn_group_sync_moments")
+
+
 class BasicBlockGroupSync(torch.autograd.Function):
     """n residual blocks (conv3x3 -> SyncBN -> ReLU -> conv3x3 -> SyncBN -> + x -> ReLU) of one depth, statistics exchanged together.
     tensors: per block x, w1, g1, b1, w2, g2, b2."""
@@ -238,6 +245,19 @@ class BasicBlockGroupSync(torch.autograd.Function):
     def forward(ctx, blocks, sync_group, *tensors):
         n = len(blocks)
         xs = [tensors[7 * i].contiguous() for i in range(n)]
+        if _grouped_sync_ok() and all(blk.conv1.weight.shape[0] >= 32 for blk in blocks):
+            axs = [K.amax_of(x) for x in xs]
+            c1s, _ = K.conv3x3_group_run([(x, blk.conv1.weight, False, ax, None) for x, blk, ax in zip(xs, blocks, axs)], want_stats=True)
+            a1s, mi1, am1 = K.bn_group_sync_apply(c1s, [b.bn1 for b in blocks], [None] * n, True,
+                                                  _all_reduce(K.bn_group_sync_moments(c1s), sync_group))
+            c2s, _ = K.conv3x3_group_run([(a1, blk.conv2.weight, False, am, None) for a1, blk, am in zip(a1s, blocks, am1)], want_stats=True)
+            outs, mi2, am2 = K.bn_group_sync_apply(c2s, [b.bn2 for b in blocks], xs, True,
+                                                   _all_reduce(K.bn_group_sync_moments(c2s), sync_group))
+            for o, am in zip(outs, am2):
+                K.amax_attach(o, am)
+            ctx.blocks, ctx.sync_group, ctx.nts, ctx.axs, ctx.am1 = blocks, sync_group, None, axs, am1
+            ctx.save_for_backward(*(xs + c1s + a1s + c2s + outs + mi1 + mi2))
+            return tuple(outs)
         nts, axs, c1s = [], [], []
         for blk, x in zip(blocks, xs):
             c = blk.conv1.weight.shape[0]
@@ -263,6 +283,23 @@ class BasicBlockGroupSync(torch.autograd.Function):
         sv = ctx.saved_tensors
         xs, c1s, a1s, c2s, outs, mi1, mi2 = (list(sv[k * n:(k + 1) * n]) for k in range(7))
         dys = [d.contiguous() for d in dys]
+        if nts is None:                             # the forward ran on the grouped launches
+            need = ctx.needs_input_grad
+            packed, st = K.bn_group_sync_bwd_reduce(dys, c2s, outs, mi2, [b.bn2 for b in blocks], 2)
+            r2 = K.bn_group_sync_bwd_apply(st, _all_reduce(packed, sync_group))
+            da1s, _ = K.conv3x3_group_run([(r2[i][0], blocks[i].conv2.weight, True, r2[i][4], None) for i in range(n)])
+            dw2s = K.conv3x3_group_wrw([(a1s[i], r2[i][0], am1[i], r2[i][4]) for i in range(n)])
+            packed, st = K.bn_group_sync_bwd_reduce(da1s, c1s, [None] * n, mi1, [b.bn1 for b in blocks], 1)
+            r1 = K.bn_group_sync_bwd_apply(st, _all_reduce(packed, sync_group))
+            dxs, _ = K.conv3x3_group_run([(r1[i][0], blocks[i].conv1.weight, True, r1[i][4], r2[i][3]) for i in range(n)])
+            dw1s = K.conv3x3_group_wrw([(xs[i], r1[i][0], axs[i], r1[i][4]) for i in range(n)])
+            grads = [None, None]
+            for i, blk in enumerate(blocks):
+                grads += [dxs[i] if need[2 + 7 * i] else None, dw1s[i] if need[2 + 7 * i + 1] else None,
+                          r1[i][1] if blk.bn1.weight is not None else None, r1[i][2] if blk.bn1.bias is not None else None,
+                          dw2s[i] if need[2 + 7 * i + 4] else None,
+                          r2[i][1] if blk.bn2.weight is not None else None, r2[i][2] if blk.bn2.bias is not None else None]
+            return tuple(grads)
         r2 = _group_exchange_backward(dys, c2s, outs, mi2, [b.bn2 for b in blocks], 2, sync_group)
         da1s, dw2s = [], []
         for i, blk in enumerate(blocks):

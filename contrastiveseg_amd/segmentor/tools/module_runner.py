@@ -71,7 +71,9 @@ class ModuleRunner(object):
         if unsynced:
             Log.info('DDP: {} running-statistics buffers of non-synchronised norm layers follow rank 0 before every forward.'
                      .format(len(unsynced)))
-            ddp.register_forward_pre_hook(lambda _mod, _args: self.broadcast_from_rank0(unsynced))
+            # only in training mode -- the buffers cannot change during evaluation, and a collective per eval forward would
+            # hang (or pair up with the metric's all-reduce) as soon as the ranks run different numbers of validation batches
+            ddp.register_forward_pre_hook(lambda mod, _args: self.broadcast_from_rank0(unsynced) if mod.training else None)
         return ddp
 
     @staticmethod

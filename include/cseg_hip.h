@@ -454,6 +454,18 @@ typedef struct cseg_bn_group_member {
 int cseg_bn_group_tiles_finalize(const cseg_bn_group_member* members, int n, cseg_stream_t stream);
 int cseg_bn_group_apply(const cseg_bn_group_member* members, int n, int relu, cseg_stream_t stream);
 int cseg_bn_group_bwd(const cseg_bn_group_member* members, int n, int mode, int training, cseg_stream_t stream);
+/* SyncBN forms (statistics summed over the ranks between two launches; reference nn.SyncBatchNorm behind
+ * lib/models/tools/module_helper.py:35-39). `packed` = fp64 [sum_i (C_i + 1), 2] on the device: member i's rows start at
+ * sum_{j<i} (C_j + 1), rows 0 .. C_i - 1 = per-channel pairs, row C_i = (this rank's element count, 0) -- the ONE tensor the host
+ * all-reduces per depth and direction.
+ *   cseg_bn_group_tiles_moments == cseg_bn_tiles_moments per member (epilogue records -> raw moments) into packed
+ *   cseg_bn_group_finalize      == cseg_bn_finalize(count 0) per member from the all-reduced packed moments
+ *   cseg_bn_group_bwd_reduce    == cseg_bn_bwd_reduce per member: g_masked (mode 2), d_weight, d_bias, sums into packed (two launches)
+ *   cseg_bn_group_bwd_apply     == cseg_bn_bwd_apply_amax(count 0) per member from the all-reduced packed sums: dx, max|dx| */
+int cseg_bn_group_tiles_moments(const cseg_bn_group_member* members, int n, double* packed, cseg_stream_t stream);
+int cseg_bn_group_finalize(const cseg_bn_group_member* members, int n, const double* packed, cseg_stream_t stream);
+int cseg_bn_group_bwd_reduce(const cseg_bn_group_member* members, int n, int mode, double* packed, cseg_stream_t stream);
+int cseg_bn_group_bwd_apply(const cseg_bn_group_member* members, int n, int mode, const double* packed, cseg_stream_t stream);
 /* The weight gradients of the members' convolutions (3x3 / stride 1 / pad 1, f16x3): == cseg_conv3x3_split_wrw per member (same split
  * counts, same fixed-order reductions: bit-identical), two launches for the group. ws = cseg_conv3x3_sb_wrw_ws_floats(B, Cin, Cout, H, W)
  * floats per member. */

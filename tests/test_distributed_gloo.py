@@ -681,7 +681,10 @@ def test_trainer_ddp_memory_bank_stays_identical_without_buffer_broadcast():
 def _group_node_worker(rank, world, port, q, group_node):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      CSEG_LOCKSTEP_GROUP_NODE="1" if group_node else "0", CSEG_TEST_DEVICE_HALF="emu")
+                      CSEG_LOCKSTEP_GROUP_NODE="1" if group_node else "0", CSEG_TEST_DEVICE_HALF="emu",
+                      # (round 6: the node runs on the GROUPED launches, whose tile body walks 16-channel chunks; the per-op form takes
+                      # the same body for both channel counts so that the comparison stays bit for bit)
+                      CSEG_CONV3X3_SB16_CH="48,96")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _install_device_half()
     from contrastiveseg_amd import kernels as K
@@ -717,8 +720,8 @@ def _group_node_worker(rank, world, port, q, group_node):
 
 def test_lockstep_depth_as_one_autograd_node_is_bit_identical_to_the_per_op_form():
     """Two ranks x two images, HighResolutionModule([48, 96]) with FusedSyncBatchNorm on the HIP sources (emulator): the residual
-    blocks of a depth as ONE node (fused_bn.BasicBlockGroupSync: the same library calls and collectives in the same order) against the
-    per-op lockstep form -- outputs, input gradients, parameter gradients and running statistics IDENTICAL, the same number of
+    blocks of a depth as ONE node (fused_bn.BasicBlockGroupSync, since round 6 on the grouped launches: one kernel per pass for all
+    branches, the statistics of a depth in one packed all-reduce) against the per-op lockstep form -- outputs, input gradients, parameter gradients and running statistics IDENTICAL, the same number of
     all-reduces (2 per depth and direction for the branches + the exchange unit's), and both ranks' replicas consistent."""
     from tests.emu import build_emu
     if not os.path.exists(build_emu.CLANG):
