@@ -312,27 +312,44 @@ SPLIT_OPS = ("conv3x3_sb_run", "conv1x1_sb_run", "conv3x3_sb_wrw", "conv1x1_sb_w
              "conv3x3_s2_run", "conv3x3_s2_bwd_run", "conv3x3_s2_wrw")     # the last three: stride 2 (round 3)
 
 
+GROUP_OPS = ("conv3x3_group_run", "conv3x3_group_wrw")     # round 6: one launch over the parallel branches of a depth (kernels.BasicBlockGroup)
+
+
+def _group_flops(name, members):
+    """fp32-equivalent flops of one grouped launch: the sum over its member convolutions (3x3, stride 1)."""
+    if name == "conv3x3_group_run":
+        return sum(2.0 * sx[0] * sx[2] * sx[3] * sw[0] * sw[1] * 9 for sx, sw, _flip, _add in members)
+    return sum(2.0 * sx[0] * sx[2] * sx[3] * sx[1] * sdy[1] * 9 for sx, sdy in members)
+
+
 def tally_split_calls(tr, batch, Kn):
     """One extra (untimed) train step with counting wrappers around the four split-operand entry points of
     contrastiveseg_amd.kernels: {(op, operand shapes, flag): calls per step}. What the step REALLY launches -- the dominant
     kernel is picked from this and from live timings, not from a table written by hand."""
     counts = {}
-    saved = {n: getattr(Kn, n) for n in SPLIT_OPS}
+    ops = SPLIT_OPS + tuple(n for n in GROUP_OPS if hasattr(Kn, n))
+    saved = {n: getattr(Kn, n) for n in ops}
 
     def wrap(name, fn):
         def inner(*a, **k):
-            flag = bool(a[2]) if (name.endswith("_run") and len(a) > 2) else False
-            key = (name, tuple(a[0].shape), tuple(a[1].shape), flag)
+            if name == "conv3x3_group_run":         # items: (x, weight, transpose_flip, max|x| record, addend)
+                members = tuple((tuple(x.shape), tuple(w.shape), bool(flip), add is not None) for x, w, flip, _ax, add in a[0])
+                key = (name, members, (), bool(k.get("want_stats", a[1] if len(a) > 1 else False)))
+            elif name == "conv3x3_group_wrw":       # items: (x, dy, max|x|, max|dy|)
+                key = (name, tuple((tuple(x.shape), tuple(dy.shape)) for x, dy, _ax, _ady in a[0]), (), False)
+            else:
+                flag = bool(a[2]) if (name.endswith("_run") and len(a) > 2) else False
+                key = (name, tuple(a[0].shape), tuple(a[1].shape), flag)
             counts[key] = counts.get(key, 0) + 1
             return fn(*a, **k)
         return inner
     try:
-        for n in SPLIT_OPS:
+        for n in ops:
             setattr(Kn, n, wrap(n, saved[n]))
         tr.train_step(batch)
         torch.cuda.synchronize()
     finally:
-        for n in SPLIT_OPS:
+        for n in ops:
             setattr(Kn, n, saved[n])
     return counts
 
@@ -341,7 +358,9 @@ def split_flops_of(counts):
     """fp32-equivalent flops per step on the split-operand kernels, from the tally alone (no timing)."""
     total = 0.0
     for (name, sa, sb, flag), n in counts.items():
-        if name.startswith("conv3x3_s2_"):
+        if name in GROUP_OPS:
+            flops = _group_flops(name, sa)
+        elif name.startswith("conv3x3_s2_"):
             if name == "conv3x3_s2_wrw":
                 ci, co, ho, wo = sa[1], sb[1], sb[2], sb[3]
             else:
@@ -364,6 +383,34 @@ def split_kernel_rooflines(counts, device, Kn):
     g = torch.Generator(device="cpu").manual_seed(7)
     rows, split_flops = [], 0.0
     for (name, sa, sb, flag), n in sorted(counts.items(), key=lambda kv: -kv[1]):
+        if name in GROUP_OPS:                       # a grouped launch: its members' operands, one call
+            flops = _group_flops(name, sa)
+            if name == "conv3x3_group_run":
+                items = []
+                for sx, sw, flip, add in sa:
+                    x = torch.randn(*sx, generator=g).to(device)
+                    w = (torch.randn(*sw, generator=g) / (9 * sw[1]) ** 0.5).to(device)
+                    y_shape = (sx[0], sw[1] if flip else sw[0], sx[2], sx[3])
+                    items.append((x, w, flip, Kn.tensor_amax(x), torch.randn(*y_shape, generator=g).to(device) if add else None))
+                fn = lambda: Kn.conv3x3_group_run(items, want_stats=flag)
+                kind = "backward-data" if sa[0][2] else ("forward + statistics" if flag else "forward")
+                what = "grouped conv3x3 %s: %s" % (kind, " + ".join("%d@%dx%dx%d" % (sx[1], sx[0], sx[2], sx[3]) for sx, _, _, _ in sa))
+            else:
+                items = []
+                for sx, sdy in sa:
+                    x = torch.randn(*sx, generator=g).to(device)
+                    dy = (torch.randn(*sdy, generator=g) * 1e-3).to(device)
+                    items.append((x, dy, Kn.tensor_amax(x), Kn.tensor_amax(dy)))
+                fn = lambda: Kn.conv3x3_group_wrw(items)
+                what = "grouped conv3x3 weight gradients: %s" % " + ".join("%d@%dx%dx%d" % (sx[1], sx[0], sx[2], sx[3]) for sx, _ in sa)
+            us = time_kernel(fn, iters=20, warm=2)
+            tf = flops / us * 1e-6
+            rows.append({"kernel": what, "entry": name, "calls_per_step": n, "us_per_launch": round(us, 1),
+                         "ms_per_step": round(n * us * 1e-3, 3), "algorithmic_flops_per_launch": int(flops),
+                         "achieved_TFLOPs": round(tf, 1), "peak_TFLOPs": round(peak, 1), "frac": round(tf / peak, 4)})
+            split_flops += n * flops
+            del items
+            continue
         a = torch.randn(*sa, generator=g).to(device)
         if name.startswith("conv3x3_s2_"):
             if name == "conv3x3_s2_wrw":
@@ -410,7 +457,9 @@ def split_kernel_rooflines(counts, device, Kn):
     return rows, split_flops
 
 
-FAMILIES = {"conv3x3_sb_wrw": "3x3 weight gradients (conv3x3_sb_wrw2_kernel + sb_wrw_reduce_kernel)",
+FAMILIES = {"conv3x3_group_run": "grouped 3x3 forward / backward-data over the parallel branches of a depth (conv3x3_group_pc12_kernel)",
+            "conv3x3_group_wrw": "grouped 3x3 weight gradients (conv3x3_wrw2_group_kernel + sb_wrw_reduce_group_kernel)",
+            "conv3x3_sb_wrw": "3x3 weight gradients (conv3x3_sb_wrw2_kernel + sb_wrw_reduce_kernel)",
             "conv3x3_sb_run": "3x3 stride-1 forward / backward-data (conv3x3_sb16r/sb16p/sb/sb16/sb8 kernels)",
             "conv1x1_sb_run": "1x1 forward / backward-data (conv1x1_sb_kernel)", "conv1x1_sb_wrw": "1x1 weight gradients (conv1x1_sb_wrw_kernel)",
             "conv3x3_s2_run": "3x3 stride-2 forward", "conv3x3_s2_bwd_run": "3x3 stride-2 backward-data", "conv3x3_s2_wrw": "3x3 stride-2 weight gradients"}
@@ -455,7 +504,7 @@ def dominant_kernel(split_rows, arith):
             "calls_per_step": d["calls_per_step"], "ms_per_step": d["ms_per_step"],
             "algorithmic_flops_per_step": int(d["flops_per_step"]), "worst_member": worst, "members": d["members"],
             "picked_from": "live tally of one train step x live HIP-event timings in isolation (bench.py:split_kernel_rooflines), summed "
-                           "per entry point; in-step durations under the forked streams: profiles/r05_step_steady_kernel_stats.csv"}
+                           "per entry point; in-step durations: profiles/r06_step_steady_kernel_stats.csv"}
 
 
 LINE_LIMIT = 2048          # bytes of the contract line: the driver keeps a bounded tail of stdout (BENCH_r03: parsed null at ~12 KB)
@@ -503,8 +552,8 @@ def assemble_line(args, wl, cfg, world, global_batch, dt, ev_ms, final_loss, spl
         roofline["dominant_kernel"] = {"name": dom["name"][:90], "frac": dom["frac"], "us": dom["us_per_launch"],
                                        "achieved": dom["achieved"], "peak": dom["peak"], "calls_per_step": dom["calls_per_step"],
                                        "ms_per_step": dom["ms_per_step"]}
-    if traffic is not None:
-        roofline["traffic_source"] = "committed PMC passes of an earlier tree, not this run: " + (traffic_src or "")[:60]
+    if traffic_src:
+        roofline["traffic_source"] = ("committed rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE runs): " if traffic is not None else "") + traffic_src[:110]
     cpu_short = None
     if cpu is not None:
         cpu_short = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "error") if k in cpu}
@@ -731,7 +780,7 @@ def self_launch(args):
 def step_traffic():
     """HBM bytes per step of the default workload at N=1, from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs; gfx950 FETCH_SIZE x2 for wide coalesced reads per MI355X_MICROARCH.md)."""
-    for name in ("r05_step_pmc.json", "r04_step_pmc.json", "r03_step_pmc.json", "r02_step_pmc.json"):
+    for name in ("r06_step_pmc.json", "r05_step_pmc.json", "r04_step_pmc.json", "r03_step_pmc.json", "r02_step_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
@@ -739,7 +788,14 @@ def step_traffic():
         return None, None
     try:
         d = json.load(open(path))
-        return d["hbm_bytes_per_step"], "profiles/%s (%s)" % (name, d.get("note", ""))
+        # (the counter passes carry a stamp of the kernel sources + kernels.py they were taken on, tools/merge_step_pmc.py;
+        # a file of another tree gives `traffic: null` and says so instead of passing for a measurement of this tree)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import importlib
+        stamp_now = importlib.import_module("merge_step_pmc_stamp").tree_stamp()
+        if d.get("tree_stamp") != stamp_now:
+            return None, "profiles/%s is stale (stamp %s, this tree %s): no traffic figure" % (name, d.get("tree_stamp"), stamp_now)
+        return d["hbm_bytes_per_step"], "profiles/%s, taken on this tree (stamp %s)" % (name, stamp_now)
     except Exception:
         return None, None
 

@@ -163,6 +163,7 @@ def _capture_forks(x=None):
     return DDP_FORKS_OK or not is_distributed()
 
 
+EXCHANGE_GROUPED = _os.environ.get("CSEG_EXCHANGE_GROUPED", "1") == "1"      # round 6: see HighResolutionModule.forward
 LOCKSTEP_FORKS = _os.environ.get("CSEG_LOCKSTEP_FORKS", "0") == "1"
 LOCKSTEP_GROUP_NODE = _os.environ.get("CSEG_LOCKSTEP_GROUP_NODE", "1") == "1"      # fused_bn.BasicBlockGroupSync (round 5)
 DDP_FORKS_OK = False        # set by ModuleRunner._make_parallel once the DDP wrapper joins the fork streams before its collectives
@@ -395,6 +396,12 @@ class HighResolutionModule(nn.Module):
         if self.num_branches == 1:
             return x
         if sync:
+            return self._exchange_lockstep(x)
+        if grouped is not None and EXCHANGE_GROUPED:
+            # Round 6: with the branches on the grouped launches the exchange unit advances depth by depth on the calling stream too,
+            # the BatchNorm sites of a depth on the grouped launches (fused_bn._BNActGroupLocal): two launches per depth and direction
+            # instead of two per site. Measured beside the forked form at batch 8: equal (profiles/r06_ab_fanout_wgrad.txt,
+            # CSEG_BRANCH_STREAMS=0), with 240 launches per step less.
             return self._exchange_lockstep(x)
         if _capture_forks(x[0]) and len(self.fuse_layers) > 1 and not _capturing():
             # (eager only: with these forks inside a hipGraph capture the END of the backward capture crashed on ROCm 7.2 -- GPU call

@@ -344,10 +344,73 @@ def basic_block_group(blocks, xs):
     return list(BasicBlockGroupSync.apply(tuple(blocks), group, *tensors))
 
 
+class _BNActGroupLocal(torch.autograd.Function):
+    """Round 6, single rank: independent BN(+ReLU) sites of one depth (the conv + BN paths of an HRNet exchange unit: reference
+    lib/models/backbones/hrnet/hrnet_backbone.py:230-250 builds them, :271-286 loops over them) on the grouped launches -- statistics
+    finalisation + apply forward, reduction + apply backward: two launches per direction for ALL sites instead of two per site
+    (16 sites in a four-branch unit). Same kernels' bodies per site as _BNAct: bit-identical. tensors: per site x, weight, bias."""
+
+    @staticmethod
+    def forward(ctx, bns, relu, *tensors):
+        n = len(bns)
+        xs = [tensors[3 * i].contiguous() for i in range(n)]
+        ys, mis, ams = K.bn_group_fwd(xs, bns, [None] * n, relu)
+        for y, am in zip(ys, ams):
+            K.amax_attach(y, am)
+        ctx.bns, ctx.relu = bns, relu
+        ctx.save_for_backward(*(xs + mis))
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        bns, n = ctx.bns, len(ctx.bns)
+        sv = ctx.saved_tensors
+        xs, mis = list(sv[:n]), list(sv[n:])
+        res = K.bn_group_bwd([d.contiguous() for d in dys], xs, [None] * n, mis, bns, 1 if ctx.relu else 0)
+        grads = [None, None]
+        for (dx, dw, db, _, am), bn in zip(res, bns):
+            K.amax_attach(dx, am)
+            grads += [dx, dw if bn.weight is not None else None, db if bn.bias is not None else None]
+        return tuple(grads)
+
+
+def _bn_act_group_local(sites):
+    """Single-rank training-mode sites whose inputs carry the producing convolution's epilogue statistics, grouped by their ReLU flag;
+    -> outputs in the order of `sites`, or None when the grouped launches do not apply (the caller evaluates the sites one by one)."""
+    if not (getattr(K, "BLOCK_GROUP", False) and hasattr(K, "bn_group_fwd") and hasattr(K, "known_tile_stats")):
+        return None
+    flags = []
+    for bn, x, r, relu in sites:
+        if not (isinstance(bn, _FusedMixin) and bn.training and bn.track_running_stats and bn.momentum is not None and r is None
+                and x.dim() == 4 and bn._sync_group() is None and K.known_tile_stats(x) is not None and x.requires_grad):
+            return None
+        flags.append((bn.act == 'relu') if relu is None else bool(relu))
+    outs = [None] * len(sites)
+    for flag in (True, False):
+        idx = [i for i, f in enumerate(flags) if f == flag]
+        for lo in range(0, len(idx), 8):                  # CSEG_GROUP_MAX members per launch
+            part = idx[lo:lo + 8]
+            if len(part) == 1:
+                bn, x, r, relu = sites[part[0]]
+                outs[part[0]] = bn(x, residual=r, relu=relu)
+            elif part:
+                tensors = []
+                for i in part:
+                    tensors += [sites[i][1], sites[i][0].weight, sites[i][0].bias]
+                for i, y in zip(part, _BNActGroupLocal.apply(tuple(sites[i][0] for i in part), flag, *tensors)):
+                    outs[i] = y
+    return outs
+
+
 def bn_act_group(sites):
     """sites: list of (bn module, x, residual or None, relu or None). Returns the list of outputs. Sites whose module is
-    not in synchronised training mode (single rank, eval) are evaluated one by one through the module itself."""
+    not in synchronised training mode (single rank, eval) are evaluated one by one through the module itself -- or, single rank in
+    training mode with epilogue statistics (round 6), together on the grouped launches."""
     groups = [bn._sync_group() if (bn.training and isinstance(bn, FusedSyncBatchNorm)) else None for bn, _, _, _ in sites]
+    if len(sites) >= 2 and all(g is None for g in groups):
+        local = _bn_act_group_local(sites)
+        if local is not None:
+            return local
     if len(sites) < 2 or any(g is None for g in groups) or any(g is not groups[0] for g in groups):
         return [bn(x, residual=r, relu=relu) for bn, x, r, relu in sites]
     meta, tensors = [], []

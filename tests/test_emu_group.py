@@ -148,3 +148,45 @@ def test_grouped_depth_node_equals_the_per_branch_nodes_bit_for_bit(channels, sh
     assert len(res[False][1]) == 2 * 12 * len(channels), len(res[False][1])
     for i, (a, b) in enumerate(zip(res[False][0], res[True][0])):
         assert torch.equal(a, b), (i % 15, i // 15)
+
+
+def test_exchange_unit_with_grouped_batchnorm_equals_the_per_site_form(monkeypatch):
+    """A three-branch HighResolutionModule in training mode, single rank, on the emulated device: branches on the grouped launches and
+    the exchange unit depth by depth with its BatchNorm sites on the grouped launches (fused_bn._BNActGroupLocal), against the same
+    module with the per-site BatchNorm calls (CSEG_EXCHANGE_GROUPED off): outputs, input and parameter gradients, running statistics
+    bit-identical; the grouped form issues fewer library calls."""
+    from contrastiveseg_amd import kernels as K
+    from contrastiveseg_amd.lib.models.backbones import hrnet_backbone as HB
+    from contrastiveseg_amd.lib.models.tools.module_helper import mark_conv_bn_pairs
+    inject.install(monkeypatch)
+    monkeypatch.setattr(K, "SPLIT_ARITH", "f16x3")
+    monkeypatch.setattr(K, "SPLIT_WEIGHTS", K.SplitWeights())
+    monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
+    monkeypatch.setattr(K, "CONV1X1_SB_MIN_TILES", 1)
+    monkeypatch.setattr(K, "CONV_EPILOGUE_STATS", True)
+    monkeypatch.setattr(K, "_GROUP_SCHED", {})
+    torch.manual_seed(7)
+    mod = mark_conv_bn_pairs(HB.HighResolutionModule([48, 96, 192], 1, "torchbn", 0.1).train())
+    g = torch.Generator().manual_seed(3)
+    x0 = [torch.randn(2, 48, 16, 64, generator=g) + 0.1, torch.randn(2, 96, 8, 32, generator=g) + 0.1, torch.randn(2, 192, 4, 16, generator=g) + 0.1]
+    res = {}
+    for grouped in (False, True):
+        monkeypatch.setattr(HB, "EXCHANGE_GROUPED", grouped)
+        mod.zero_grad()
+        for m in mod.modules():
+            if hasattr(m, "reset_running_stats"):
+                m.reset_running_stats()
+        calls = []
+        orig = K._hip.call
+        monkeypatch.setattr(K._hip, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+        xs = [x.clone().requires_grad_(True) for x in x0]
+        outs = mod([x * 1.0 for x in xs])
+        sum((o * o).mean() for o in outs).backward()
+        monkeypatch.setattr(K._hip, "call", orig)
+        res[grouped] = ([o.detach().clone() for o in outs] + [x.grad.clone() for x in xs]
+                        + [p.grad.clone() for p in mod.parameters()] + [b.clone() for b in mod.buffers()], calls)
+    assert any(c == "cseg_bn_group_apply" for c in res[True][1])
+    n_bn = lambda cs: sum(1 for c in cs if c.startswith("cseg_bn"))
+    assert n_bn(res[True][1]) < n_bn(res[False][1]), (n_bn(res[True][1]), n_bn(res[False][1]))
+    for a, b in zip(res[False][0], res[True][0]):
+        assert torch.equal(a, b)

@@ -1,11 +1,18 @@
 """profiles/r03_step_pmc.json from the two per-counter summaries of tools/step_pmc_summary.py (FETCH_SIZE and WRITE_SIZE are collected
 in separate rocprofv3 passes, MI355X_MICROARCH.md). Usage: merge_step_pmc.py FETCH.json WRITE.json "<what was measured>" > out.json"""
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+from merge_step_pmc_stamp import tree_stamp
 
 f, w = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
 fb, wb = f["per_step_KB"] * 1024, w["per_step_KB"] * 1024
 print(json.dumps({
+    "tree_stamp": tree_stamp(),
     "hbm_bytes_per_step": int(fb + wb), "fetch_bytes_per_step": int(fb), "write_bytes_per_step": int(wb),
     "fetch_bytes_per_step_x2": int(2 * fb), "by_family_fetch_KB": f["per_step_KB_by_family"],
     "by_family_write_KB": w["per_step_KB_by_family"], "dispatches_per_step": f["dispatches_per_step"],
