@@ -397,11 +397,12 @@ class HighResolutionModule(nn.Module):
             return x
         if sync:
             return self._exchange_lockstep(x)
-        if grouped is not None and EXCHANGE_GROUPED:
-            # Round 6: with the branches on the grouped launches the exchange unit advances depth by depth on the calling stream too,
-            # the BatchNorm sites of a depth on the grouped launches (fused_bn._BNActGroupLocal): two launches per depth and direction
-            # instead of two per site. Measured beside the forked form at batch 8: equal (profiles/r06_ab_fanout_wgrad.txt,
-            # CSEG_BRANCH_STREAMS=0), with 240 launches per step less.
+        if grouped is not None and EXCHANGE_GROUPED and not _capture_forks(x[0]):
+            # Round 6: where the exchange unit runs on ONE stream anyway (below four images per GPU the forks do not pay, under a
+            # hipGraph capture they crash), it advances depth by depth with the BatchNorm sites of a depth on the grouped launches
+            # (fused_bn._BNActGroupLocal): two launches per depth and direction instead of two per site -- 230 dispatches per step less.
+            # At batch 8 the forked form below stays: its four streams overlap the unit's small convolutions, which the depth-by-depth
+            # form serialises (A/B/A/B on one MI355X: 87.9 / 87.2 ms grouped against 84.7 / 85.7 forked, profiles/r06_ab_exchange.txt).
             return self._exchange_lockstep(x)
         if _capture_forks(x[0]) and len(self.fuse_layers) > 1 and not _capturing():
             # (eager only: with these forks inside a hipGraph capture the END of the backward capture crashed on ROCm 7.2 -- GPU call
