@@ -1526,103 +1526,8 @@ def _bn_train_fwd(x, weight, bias, residual, bn):
     return y, mi, amax
 
 
-# ----------------------------------------------------------------------------------------------------------
-# The same block through the native executor (csrc_host/block_exec.cpp -> _cseg_native.so; round 4, opt-in: CSEG_NATIVE_BLOCK=1).
-# One call from Python per direction runs the C-ABI entry points BasicBlockSplit calls, in the same order with the same arguments
-# (bit-identical results); what stays in Python is the autograd node, the max|.| records and the packed-weight lookups.
-# tools/host_null_bench.py (stub kernels, this container's CPU): 197 -> ~70 us of host time per block forward, 308 -> ~90 us per block
-# backward; 104 such blocks per step of HRNet-W48, on the one thread that feeds four HIP queues. Not yet timed on the MI355X: opt-in.
-# ----------------------------------------------------------------------------------------------------------
-NATIVE_BLOCK = os.environ.get("CSEG_NATIVE_BLOCK", "0") == "1"
-_NATIVE = {"mod": None, "tried": False, "bound": None}
-_NATIVE_NAMES = ("cseg_conv3x3_split_fwd_st", "cseg_conv3x3_split_fwd", "cseg_conv3x3_split_fwd_add", "cseg_conv3x3_split_wrw",
-                 "cseg_conv3x3_sb_wrw_ws_floats", "cseg_conv_stat_segments", "cseg_bn_tiles_finalize", "cseg_bn_apply_amax",
-                 "cseg_bn_bwd_amax", "cseg_last_error")
-
-
-def native_block_module():
-    """_cseg_native, bound to the entry points of the library this package currently calls (the ctypes handle of _hip.lib(): the
-    tests swap it for the emulated library, and the executor follows); None when the extension has not been built."""
-    if not _NATIVE["tried"]:
-        _NATIVE["tried"] = True
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_cseg_native.so")
-        if os.path.exists(path):
-            import importlib.util
-            spec = importlib.util.spec_from_file_location("_cseg_native", path)
-            mod = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(mod)
-            _NATIVE["mod"] = mod
-    mod = _NATIVE["mod"]
-    if mod is None:
-        return None
-    lib = _hip.lib()
-    if _NATIVE["bound"] is not lib:
-        mod.bind({n: ctypes.cast(getattr(lib, n), ctypes.c_void_p).value for n in _NATIVE_NAMES})
-        _NATIVE["bound"] = lib
-    return mod
-
-
-def _native_bn(bn):
-    # (the registries directly: seven nn.Module.__getattr__ fallbacks cost more than the native call that follows)
-    p, b = bn._parameters, bn._buffers
-    return _NATIVE["mod"].Bn(p.get("weight"), p.get("bias"), b.get("running_mean"), b.get("running_var"), b.get("num_batches_tracked"),
-                             float(bn.eps), float(bn.momentum))
-
-
-def basic_block_native_ok(blk):
-    """What the executor covers: f16x3 arithmetic, statistics from both convolution epilogues, BatchNorms with a momentum, weight
-    gradients on the backward stream."""
-    return (NATIVE_BLOCK and split_arith_id() == ARITH_IDS["f16x3"] and CONV_EPILOGUE_STATS and blk.conv1.bn_follows and blk.conv2.bn_follows
-            and blk.bn1.momentum is not None and blk.bn2.momentum is not None and blk.bn1.running_mean is not None
-            and blk.bn2.running_mean is not None and not _WGRAD["on"] and native_block_module() is not None)
-
-
-class BasicBlockNative(Function):
-    """BasicBlockSplit with the kernel calls of each direction issued by ONE native call."""
-
-    @staticmethod
-    def forward(ctx, x, w1, g1, b1, w2, g2, b2, bn1, bn2):
-        nat = native_block_module()
-        c = w1.shape[0]
-        nt = conv3x3_sb_pick_nt(x, c) if c in CONV3X3_SB_PICK_NT_CHANNELS else 0
-        ax = amax_of(x)
-        _pq(x, "x")                                               # (device, dtype, layout of the one user-facing operand)
-        wp1, aw1 = SPLIT_WEIGHTS.get(w1, "c3", False, nt)
-        wp2, aw2 = SPLIT_WEIGHTS.get(w2, "c3", False, nt)
-        am1, am2 = amax_slot(x.device), amax_slot(x.device)
-        out, c1, a1, c2, mi1, mi2 = nat.block_forward(x, wp1.data_ptr(), aw1.data_ptr(), wp2.data_ptr(), aw2.data_ptr(), ax.data_ptr(),
-                                                      _native_bn(bn1), _native_bn(bn2), am1.data_ptr(), am2.data_ptr(), int(nt),
-                                                      ARITH_IDS["f16x3"], _hip.stream_ptr().value or 0)
-        amax_attach(out, am2)
-        ctx.save_for_backward(x, w1, g1, b1, w2, g2, b2, c1, a1, c2, out, mi1, mi2)
-        ctx.misc = (nt, ax, am1, bn1, bn2)
-        return out
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w1, g1, b1, w2, g2, b2, c1, a1, c2, out, mi1, mi2 = ctx.saved_tensors
-        nt, ax, am1, bn1, bn2 = ctx.misc
-        nat = native_block_module()
-        dy = dy.contiguous()
-        _pq(dy, "dy")
-        wp1t, aw1 = SPLIT_WEIGHTS.get(w1, "c3", True, nt)
-        wp2t, aw2 = SPLIT_WEIGHTS.get(w2, "c3", True, nt)
-        am, amb = amax_slot(x.device), amax_slot(x.device)
-        B, C, HW = _bn_dims(x)
-        need = ctx.needs_input_grad
-        dx, dw1, dg1, db1, dw2, dg2, db2 = nat.block_backward(
-            dy, x, c1, a1, c2, out, mi1, mi2, wp1t.data_ptr(), aw1.data_ptr(), wp2t.data_ptr(), aw2.data_ptr(), ax.data_ptr(),
-            am1.data_ptr(), am.data_ptr(), amb.data_ptr(), _native_bn(bn1), _native_bn(bn2), _bn_ws(B, C, HW, x.device), int(nt),
-            ARITH_IDS["f16x3"], bool(need[0]), bool(need[1]), bool(need[4]), _hip.stream_ptr().value or 0)
-        return (dx, dw1, dg1 if g1 is not None else None, db1 if b1 is not None else None, dw2,
-                dg2 if g2 is not None else None, db2 if b2 is not None else None, None, None)
-
-
 def basic_block_split(x, blk):
     """blk: a residual block with conv1 / bn1 / conv2 / bn2 (no downsample, stride 1), BatchNorms in single-rank training mode."""
-    if NATIVE_BLOCK and basic_block_native_ok(blk):
-        return BasicBlockNative.apply(x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias,
-                                      blk.bn1, blk.bn2)
     return BasicBlockSplit.apply(x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias,
                                  blk.bn1, blk.bn2, blk.conv1.bn_follows, blk.conv2.bn_follows)
 

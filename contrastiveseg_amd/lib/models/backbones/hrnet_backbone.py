@@ -164,7 +164,6 @@ def _capture_forks(x=None):
 
 
 EXCHANGE_GROUPED = _os.environ.get("CSEG_EXCHANGE_GROUPED", "1") == "1"      # round 6: see HighResolutionModule.forward
-LOCKSTEP_FORKS = _os.environ.get("CSEG_LOCKSTEP_FORKS", "0") == "1"
 LOCKSTEP_GROUP_NODE = _os.environ.get("CSEG_LOCKSTEP_GROUP_NODE", "1") == "1"      # fused_bn.BasicBlockGroupSync (round 5)
 DDP_FORKS_OK = False        # set by ModuleRunner._make_parallel once the DDP wrapper joins the fork streams before its collectives
 
@@ -179,35 +178,6 @@ def join_fork_streams(device):
         cur = torch.cuda.current_stream(device)
         for s_ in have:
             cur.wait_stream(s_)
-
-
-class _ParallelConvs(object):
-    """fns[i](xs[i]) for i = 0 .. n-1 with i > 0 on side stream i - 1, joined to the calling stream before returning."""
-
-    def __init__(self, like, n):
-        import torch
-        self.torch = torch
-        self.dev = like.device
-        self.streams = _fork_streams(like.device, n - 1)
-
-    def run(self, fns, xs):
-        torch = self.torch
-        cur = torch.cuda.current_stream(self.dev)
-        outs = [None] * len(fns)
-        for i in range(1, len(fns)):
-            s = self.streams[i - 1]
-            s.wait_stream(cur)
-            xs[i].record_stream(s)                    # produced on `cur`, read here and (saved for backward) on the side stream
-            with torch.cuda.stream(s):
-                outs[i] = fns[i](xs[i])
-        outs[0] = fns[0](xs[0])
-        for i in range(1, len(fns)):
-            cur.wait_stream(self.streams[i - 1])
-            outs[i].record_stream(cur)                # allocated on the side stream, read by the grouped BatchNorm on `cur`
-            st = K.known_tile_stats(outs[i])          # ... and so is the statistics record buffer of the epilogue
-            if st is not None:
-                st.record_stream(cur)
-        return outs
 
 
 class HighResolutionModule(nn.Module):
@@ -244,29 +214,19 @@ class HighResolutionModule(nn.Module):
         """The branches are independent residual chains of equal length: run them block by block side by side, so that
         the BN sites of one depth share ONE statistics all-reduce per direction (fused_bn.bn_act_group)."""
         x = list(x)
-        # Round 5, OPT-IN (CSEG_LOCKSTEP_FORKS=1): the convolutions of one depth are independent -- branch i > 0 runs its convolution
-        # on side stream i and the streams join before the batched statistics exchange, which stays on the calling stream with its ONE
-        # collective per direction. Same kernels, same values (tests/test_gpu_multirank.py); autograd replays the forks in backward.
-        # MEASURED on the MI355X inside a one-rank RCCL process group (bench.py --dist-single-rank, profiles/r05_dist_single_rank.txt):
-        # batch 8 118.3 ms/step with the forks vs 111.9 without, batch 4 98.7 vs 98.0 -- two fork / join pairs per block depth cost
-        # the host more than four short side-by-side convolutions give back, and this path is host-bound. Hence off by default.
-        par = _ParallelConvs(x[0], len(self.branches)) if (LOCKSTEP_FORKS and _capture_forks(x[0]) and not _capturing()) else None
+        # (Round 5 also had an opt-in that forked the convolutions of a depth onto side streams, CSEG_LOCKSTEP_FORKS: measured slower inside
+        # a one-rank RCCL group -- 118.3 vs 111.9 ms at batch 8, profiles/r05_dist_single_rank.txt -- and superseded by the grouped launches
+        # of round 6, which run a depth's convolutions as ONE kernel; removed.)
         for k in range(len(self.branches[0])):
             blocks = [branch[k] for branch in self.branches]
-            if par is None and LOCKSTEP_GROUP_NODE:
+            if LOCKSTEP_GROUP_NODE:
                 grouped = basic_block_group(blocks, x)        # the whole depth as ONE autograd node where every block qualifies
                 if grouped is not None:
                     x = grouped
                     continue
-            if par is None:
-                c1 = [blk.conv1(xi) for blk, xi in zip(blocks, x)]
-            else:
-                c1 = par.run([blk.conv1 for blk in blocks], x)
+            c1 = [blk.conv1(xi) for blk, xi in zip(blocks, x)]
             y1 = bn_act_group([(blk.bn1, c, None, True) for blk, c in zip(blocks, c1)])
-            if par is None:
-                c2 = [blk.conv2(y) for blk, y in zip(blocks, y1)]
-            else:
-                c2 = par.run([blk.conv2 for blk in blocks], y1)
+            c2 = [blk.conv2(y) for blk, y in zip(blocks, y1)]
             res = [xi if blk.downsample is None else blk.downsample(xi) for blk, xi in zip(blocks, x)]
             x = bn_act_group([(blk.bn2, c, r, True) for blk, c, r in zip(blocks, c2, res)])
         return x

@@ -164,54 +164,6 @@ def test_fused_block_node_equals_the_four_nodes_it_replaces(channels, hw, monkey
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("channels,hw", [(48, (6, 64)), (96, (5, 128))])
-def test_native_block_executor_equals_the_python_node(channels, hw, monkeypatch):
-    """kernels.BasicBlockNative (csrc_host/block_exec.cpp: one native call per direction issues the block's kernels) against
-    kernels.BasicBlockSplit on the emulated device: the same entry points in the same order with the same arguments, so the output,
-    every gradient, the BN buffers (incl. num_batches_tracked) and the max|.| record of the output are bit-identical -- over two
-    consecutive steps (running statistics carried along) and with a second block consuming the first one's record."""
-    from contrastiveseg_amd import kernels as K
-    from contrastiveseg_amd.lib.models.backbones.hrnet_backbone import BasicBlock
-    from contrastiveseg_amd.lib.models.tools.module_helper import mark_conv_bn_pairs
-    inject.install(monkeypatch)
-    monkeypatch.setattr(K, "SPLIT_ARITH", "f16x3")
-    monkeypatch.setattr(K, "SPLIT_WEIGHTS", K.SplitWeights())
-    monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
-    monkeypatch.setattr(K, "CONV_EPILOGUE_STATS", True)
-    monkeypatch.setattr(K, "BLOCK_FUSED", True)
-    monkeypatch.setitem(K._NATIVE, "bound", None)                  # (bind again: this test's library is the emulated one)
-    if K.native_block_module() is None:
-        pytest.skip("contrastiveseg_amd/_cseg_native.so has not been built (python contrastiveseg_amd/csrc_host/build.py)")
-    torch.manual_seed(channels + 1)
-    net = mark_conv_bn_pairs(torch.nn.Sequential(BasicBlock(channels, channels, bn_type="torchbn"),
-                                                 BasicBlock(channels, channels, bn_type="torchbn")).train())
-    state0 = {k: v.clone() for k, v in net.state_dict().items()}
-    xs = [torch.randn(2, channels, *hw) * 0.7 + 0.1 for _ in range(2)]
-    gys = [torch.randn(2, channels, *hw) for _ in range(2)]
-    res = {}
-    for native in (False, True):
-        monkeypatch.setattr(K, "NATIVE_BLOCK", native)
-        net.load_state_dict(state0)
-        K.SPLIT_WEIGHTS.invalidate()
-        taken = []
-        for cls in (K.BasicBlockSplit, K.BasicBlockNative):
-            orig = cls.forward
-            monkeypatch.setattr(cls, "forward", staticmethod((lambda orig, name: lambda *a, **k: (taken.append(name), orig(*a, **k))[1])(orig, cls.__name__)))
-        got = []
-        for x0, gy in zip(xs, gys):
-            net.zero_grad()
-            x = x0.clone().requires_grad_(True)
-            y = net(x * 1.0)
-            y.backward(gy)
-            got += [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in net.parameters()] + [b.clone() for b in net.buffers()]
-            assert K.known_amax(y) is not None
-        res[native] = got
-        assert set(taken) == {"BasicBlockNative" if native else "BasicBlockSplit"}, taken
-    assert len(res[True]) == len(res[False])
-    for a, b in zip(res[False], res[True]):
-        assert torch.equal(a, b)
-
-
 @pytest.mark.parametrize("channels", [[48, 96], [48, 96, 192]])
 def test_fan_out_node_sums_the_branch_gradients_in_one_kernel(channels, monkeypatch):
     """kernels.fan_out (opt-in, CSEG_FANOUT_SUM=1): an exchange unit of HRNet with every branch output handed to its consumers through

@@ -237,20 +237,23 @@ def test_bench_launches_its_own_ranks():
     assert d["value"] > 0 and np.isfinite(d["config"]["final_loss"])
 
 
-def _lockstep_worker(rank, world, port, q, backend, forks):
+def _lockstep_worker(rank, world, port, q, backend, grouped):
     """One rank inside a process group with the multi-rank code paths forced on (CSEG_DIST_SINGLE_RANK=1): DDP wrapper, SyncBN with the
-    branches in lockstep around the batched exchange, counts / anchor all-gathers -- with or without the forked convolutions."""
+    branches in lockstep around the batched exchange, counts / anchor all-gathers -- the depth nodes on the grouped launches of round 6
+    or on the per-member calls."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-                      CSEG_DIST_BACKEND=backend, CSEG_DIST_SINGLE_RANK="1", CSEG_BRANCH_STREAMS="1" if forks else "0",
-                      CSEG_LOCKSTEP_FORKS="1" if forks else "0",
+                      CSEG_DIST_BACKEND=backend, CSEG_DIST_SINGLE_RANK="1", CSEG_BRANCH_STREAMS="0",
+                      CSEG_BLOCK_GROUP="1" if grouped else "0",
+                      # the per-member form on the grouped kernel's tile body (16-channel chunks) for every branch width
+                      CSEG_CONV3X3_SB16_CH="48,96,192,384",
                       CSEG_BRANCH_STREAMS_MIN_PIXELS="1", CSEG_SB_MIN_TILES="1")
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group(backend, rank=0, world_size=1)
     dev = torch.device("cuda", 0)
+    from contrastiveseg_amd import kernels as K
     from contrastiveseg_amd.lib.models.backbones import hrnet_backbone as HB
-    from contrastiveseg_amd.lib.models.tools import fused_bn
     from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
     torch.backends.cudnn.deterministic = True
     torch.manual_seed(304)
@@ -261,35 +264,37 @@ def _lockstep_worker(rank, world, port, q, backend, forks):
         if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
             m.p = 0.0
     tr.seg_net.train()
-    used = {"par": 0, "group": 0}
-    run0, apply0 = HB._ParallelConvs.run, fused_bn._BNActGroup.apply
+    used = {"group": 0}
+    run0 = K.conv3x3_group_run
 
-    def run(self, fns, xs):
-        used["par"] += 1
-        return run0(self, fns, xs)
-    HB._ParallelConvs.run = run
+    def run(items, want_stats=False):
+        used["group"] += 1
+        return run0(items, want_stats=want_stats)
+    K.conv3x3_group_run = run
     losses, picks = [], []
     for img, lab in _batches(4, 2):
         losses.append(float(tr.train_step({"img": img.to(dev), "labelmap": lab.to(dev)})))
         sd = tr.seg_net.module.state_dict()
         picks.append({k: sd[k].detach().cpu().numpy().copy() for k in PICK})
     torch.cuda.synchronize()
-    q.put((rank, losses, picks, used["par"]))
+    q.put((rank, losses, picks, used["group"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_lockstep_branches_with_forked_convolutions_equal_the_single_stream_form():
-    """VERDICT r4 next-3 (DDP inherits the forks). SyncBN models run their HRNet branches in lockstep around ONE batched statistics
-    exchange per depth; round 5 forks the independent convolutions of a depth onto side streams (hrnet_backbone._ParallelConvs) and
-    DDP joins the fork streams before every bucket's all-reduce (module_runner comm hook). Same kernels on the same values: losses and
-    the weights / BN buffers after two SGD steps must be IDENTICAL to the single-stream lockstep form."""
+def test_syncbn_depth_nodes_on_the_grouped_launches_equal_the_per_member_form():
+    """Round 6: under a process group the residual blocks of a depth run as ONE node (fused_bn.BasicBlockGroupSync) on the GROUPED
+    launches -- one kernel per pass for all branches, the statistics of a depth in one packed all-reduce. Against the same node on the
+    per-member calls (CSEG_BLOCK_GROUP=0; both on the 16-channel-chunk tile body): the same arithmetic per output element, so the first
+    loss agrees to rounding of the statistics records (each kernel sums a 64-pixel segment in its own fixed order) and the weights /
+    BN buffers after the first SGD step to 1e-5 of their scale. (Round 5's opt-in that forked the lockstep convolutions onto side
+    streams is gone: slower, and superseded by these launches.)"""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     a = _spawn(_lockstep_worker, 1, "gloo", False)[0]
     b = _spawn(_lockstep_worker, 1, "gloo", True)[0]
-    assert a[3] == 0 and b[3] > 0, ("forked convolutions taken", a[3], b[3])
-    assert a[1] == b[1], (a[1], b[1])
-    for step in (0, 1):
-        for k in PICK:
-            assert np.array_equal(a[2][step][k], b[2][step][k]), "forked lockstep differs from the single-stream form: " + k
+    assert a[3] == 0 and b[3] > 0, ("grouped launches taken", a[3], b[3])
+    assert abs(a[1][0] - b[1][0]) <= 2e-5 * abs(a[1][0]), (a[1], b[1])
+    for k in PICK:
+        u, v = a[2][0][k], b[2][0][k]
+        assert np.abs(u - v).max() <= 1e-5 * max(float(np.abs(u).max()), 1e-3), ("state after the first step differs: " + k, float(np.abs(u - v).max()))

@@ -311,21 +311,3 @@ def test_kernel_trace_of_the_default_step(tmp_path):
         pytest.xfail(repr(e)[:300])
 
 
-def test_native_block_executor_on_hardware():
-    """Non-gating (the executor is opt-in, CSEG_NATIVE_BLOCK=1, and has not run on an MI355X yet): tools/native_block_check.py in a
-    child process -- kernels.BasicBlockNative against kernels.BasicBlockSplit at a benched branch shape, bit-identical output /
-    gradients / BN buffers, host time per block of both. The result lands in the CSEG_ZZ line (`native_block`)."""
-    import json
-    import os
-    import subprocess
-    import sys
-    _dev()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    try:
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "native_block_check.py")], capture_output=True, text=True, timeout=150)
-        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        REPORT["native_block"] = json.loads(lines[-1]) if lines else {"rc": r.returncode, "stderr": r.stderr[-200:]}
-    except Exception as e:                        # noqa: BLE001
-        REPORT["native_block"] = {"error": repr(e)[:200]}
-    if REPORT["native_block"].get("bit_identical") is not True:
-        pytest.xfail(str(REPORT["native_block"])[:300])

@@ -2,7 +2,7 @@
 at once (size queries go to the real library), tensors live on the CPU and are never touched. What is timed is what the enqueueing
 thread pays per launch -- Python, autograd nodes, allocations, argument conversion -- i.e. the part of tools/host_profile.py's
 "host enqueue" that is not the HIP runtime. Absolute numbers are this container's CPU; the ratios guide the work.
-  python tools/host_null_bench.py [block|module] [--native] [--profile]"""
+  python tools/host_null_bench.py [block|module] [--profile]"""
 import cProfile
 import ctypes
 import io
@@ -122,7 +122,7 @@ def bench_module(profile):
     _hip.call = orig
     f, b = run(10)
     print("stage-4 exchange unit: forward %.2f ms, backward %.2f ms of host time (%d library calls per forward + backward%s)"
-          % (f, b, n_calls, ", native blocks" if K.NATIVE_BLOCK else ""))
+          % (f, b, n_calls, ""))
     if profile:
         pr = cProfile.Profile()
         pr.enable()
@@ -135,6 +135,4 @@ def bench_module(profile):
 
 if __name__ == "__main__":
     install_null()
-    if "--native" in sys.argv:
-        K.NATIVE_BLOCK = True
     (bench_module if "module" in sys.argv else bench_block)("--profile" in sys.argv)
