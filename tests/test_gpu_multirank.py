@@ -257,7 +257,9 @@ def _lockstep_worker(rank, world, port, q, backend, grouped):
     from contrastiveseg_amd.segmentor.trainer_contrastive import Trainer
     torch.backends.cudnn.deterministic = True
     torch.manual_seed(304)
-    tr = Trainer(_trainer_cfg(4), train_loader=[])
+    cfg = _trainer_cfg(4)
+    cfg.update(["network", "backbone"], "hrnet48")          # (HRNet-W18's 18 / 36 / 72 / 144 channels are outside the split kernels)
+    tr = Trainer(cfg, train_loader=[])
     assert isinstance(tr.seg_net, torch.nn.parallel.DistributedDataParallel)
     assert HB.DDP_FORKS_OK, "the DDP wrapper must join the fork streams before its collectives"
     for m in tr.seg_net.modules():
