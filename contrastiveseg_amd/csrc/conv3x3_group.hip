@@ -742,6 +742,24 @@ __global__ __launch_bounds__(768) void conv3x3_group_pc12_kernel(const GArgs a) 
     const int q = blockIdx.x & 7;
     int* head = a.sched + q * SCHED_STRIDE;
 
+    // CYCLE ACCOUNT (measurement only: built with -DCSEG_GROUP_TIMERS, switched on by CSEG_GROUP_ABLATE bit 128): where wave 0 and
+    // wave 4 (the two computing waves of one SIMD) and wave 8 (staging) of every block spend their shader cycles, summed over the blocks
+    // into the spare counter line of `sched` in units of 64 cycles (tools/probes/group_probe prints them, profiles/r06_group_cycles.txt):
+    // [0] blocks, wave 0: [1] until the first item is staged, [2] K-steps, [3] epilogue, [4] at the barrier, [7] draining loads / stores
+    // before it; wave 8: [5] loads issued -> split and stored, [6] at the barrier; wave 4: [8..12] as [1..4], [7]
+#ifdef CSEG_GROUP_TIMERS
+    const bool timed = (a.ablate & 128) != 0;
+#else
+    constexpr bool timed = false;
+#endif
+    long long tmr[5] = {0, 0, 0, 0, 0}, tlast = timed ? (long long)__builtin_readcyclecounter() : 0;
+    auto lap = [&](int k) {
+        if (timed) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            tmr[k] += now - tlast;
+            tlast = now;
+        }
+    };
     int pending = 0;
     if (tid == 0) pending = cseg_counter_add(head, 1);
     {
@@ -862,6 +880,7 @@ __global__ __launch_bounds__(768) void conv3x3_group_pc12_kernel(const GArgs a) 
             a_issue(0);
             a_store(As);
             __syncthreads();                        // (P) item 0 is staged
+            lap(0);
             int chunk = 0, buf = 0, n_chunks = su.n_chunks;      // the item the computing waves are on
 #pragma unroll 1
             for (;;) {
@@ -881,10 +900,16 @@ __global__ __launch_bounds__(768) void conv3x3_group_pc12_kernel(const GArgs a) 
                     a_issue(nchunk);
                     a_store(As + (size_t)(buf ^ 1) * A_CELLS);
                 }
+                lap(1);
                 __syncthreads();                    // (I)
+                lap(2);
                 if (!more) break;
                 if (last) { chunk = 0; n_chunks = su.n_chunks; } else ++chunk;
                 buf ^= 1;
+            }
+            if (timed && tid == 512) {
+                atomicAdd(a.sched + 9 * SCHED_STRIDE + 5, (int)(tmr[1] >> 6));
+                atomicAdd(a.sched + 9 * SCHED_STRIDE + 6, (int)(tmr[2] >> 6));
             }
         } else {
             // ---------------- computing waves: wave w = 64 pixels x all three channel tiles
@@ -915,6 +940,7 @@ __global__ __launch_bounds__(768) void conv3x3_group_pc12_kernel(const GArgs a) 
             };
             b_dma(cu.wbase, 0, 0);
             __syncthreads();                        // (P)
+            lap(0);
             int chunk = 0, buf = 0;
 #pragma unroll 1
             for (;;) {
@@ -936,6 +962,12 @@ __global__ __launch_bounds__(768) void conv3x3_group_pc12_kernel(const GArgs a) 
                 const uint4* a_base = As + (size_t)buf * A_CELLS;
                 const uint4* b_base = Bs + (size_t)buf * BCHUNK + lane;
                 typedef typename AR::frag_t frag_t;
+                // Tried on this loop and measured equal or worse (round 6, profiles/r06_group_cycles.txt; not
+                // kept): fragments of group i + 1 requested before group i multiplies (two register sets, reads
+                // pinned with sched_barrier: 132.8 / 135.6 us against 133.7 / 134.8); two items in flight in the staging waves (132.4);
+                // s_setprio 1 / 2 on the staging waves (144 / 145 us: their VALU work then displaces MFMAs one for one). The cycle
+                // account says why: wave 0 issues its 180 MFMAs per iteration in 5 740 cycles = the SIMD's matrix rate shared with wave
+                // 4, and every other instruction on the SIMD (staging ~260 VALU, epilogue, address arithmetic) ADDS to that.
 #pragma unroll
                 for (int s = 0; s < STEPS; ++s) {
                     const int tap = min(2 * s + (g >> 1), 8);        // the tenth tap slot multiplies zero weights
@@ -958,6 +990,7 @@ __global__ __launch_bounds__(768) void conv3x3_group_pc12_kernel(const GArgs a) 
                     }
                 }
                 if (chunk == 0 && tid == 0) next_unit = settle(pending);           // read by everybody at this unit's last chunk (n_chunks >= 2)
+                lap(1);
                 if (last) {
                     const size_t plane = (size_t)cu.H * cu.W;
                     float* ybc = cu.y + (size_t)cu.b * cu.Cout * plane;
@@ -986,7 +1019,10 @@ __global__ __launch_bounds__(768) void conv3x3_group_pc12_kernel(const GArgs a) 
                         else group_stats_emit<2>(acc, cu.bias, co0, cu.unscale, cu.b, y0w, cu.x0, cu.H, cu.W, tx64, g, n, st, cu.n_seg);
                     }
                 }
+                lap(2);
+                if (timed) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lap(4); }
                 __syncthreads();                    // (I)
+                lap(3);
                 if (!more) break;
                 if (last) {
                     if (su.geo != cu.geo) compute_geometry(su.geo);
@@ -997,6 +1033,13 @@ __global__ __launch_bounds__(768) void conv3x3_group_pc12_kernel(const GArgs a) 
                 }
                 buf ^= 1;
             }
+            if (timed && tid == 0) {
+                atomicAdd(a.sched + 9 * SCHED_STRIDE, 1);
+                for (int k = 0; k < 4; ++k) atomicAdd(a.sched + 9 * SCHED_STRIDE + 1 + k, (int)(tmr[k] >> 6));
+                atomicAdd(a.sched + 9 * SCHED_STRIDE + 7, (int)(tmr[4] >> 6));
+            }
+            if (timed && tid == 256)
+                for (int k = 0; k < 5; ++k) atomicAdd(a.sched + 9 * SCHED_STRIDE + 8 + k, (int)(tmr[k] >> 6));
         }
     }
     if (tid == 0) {

@@ -198,13 +198,16 @@ int main(int argc, char** argv) {
         std::vector<int> sc(CSEG_GROUP_SCHED_INTS);
         HIPCHECK(hipMemcpy(sc.data(), sched, sc.size() * 4, hipMemcpyDeviceToHost));
         int sched_dirty = 0;
-        for (int s : sc) sched_dirty += s != 0;
+        for (size_t i = 0; i < 9 * 32; ++i) sched_dirty += sc[i] != 0;
         double gf = 0.0;
         for (Member& m : ms) gf += 2.0 * m.B * m.H * m.W * (double)m.C * m.C * 9 * 1e-9;
         printf("{\"batch\": %d, \"branches\": %d, \"variant\": \"%s\", \"seq_default_us\": %.1f, \"seq_group_nt_us\": %.1f, \"group_us\": %.1f, "
                "\"group_tflops\": %.1f, \"mismatched_outputs\": %zu, \"mismatched_stats\": %zu, \"sched_dirty\": %d, \"per_member_default_us\": [",
                batch, branches, v.name.c_str(), us_seq_def, us_seq_grp, us_group, gf / us_group * 1e-3, bad_y, bad_st, sched_dirty);
         for (size_t i = 0; i < per_def.size(); ++i) printf("%s%.1f", i ? ", " : "", per_def[i]);
+        printf("], \"timers_x64cyc\": [");              // CSEG_GROUP_ABLATE bit 128: the kernel's cycle account (conv3x3_group.hip)
+        for (int i = 0; i < 13; ++i) printf("%s%d", i ? ", " : "", sc[9 * 32 + i]);
+        HIPCHECK(hipMemset(sched + 9 * 32, 0, 32 * 4));
         printf("], \"per_member_group_nt_us\": [");
         for (size_t i = 0; i < per_grp.size(); ++i) printf("%s%.1f", i ? ", " : "", per_grp[i]);
         printf("]}\n");
