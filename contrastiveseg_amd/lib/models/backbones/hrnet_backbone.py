@@ -357,7 +357,7 @@ class HighResolutionModule(nn.Module):
             return x
         if sync:
             return self._exchange_lockstep(x)
-        if grouped is not None and EXCHANGE_GROUPED and not _capture_forks(x[0]):
+        if grouped is not None and EXCHANGE_GROUPED and (_capturing() or not _capture_forks(x[0])):
             # Round 6: where the exchange unit runs on ONE stream anyway (below four images per GPU the forks do not pay, under a
             # hipGraph capture they crash), it advances depth by depth with the BatchNorm sites of a depth on the grouped launches
             # (fused_bn._BNActGroupLocal): two launches per depth and direction instead of two per site -- 230 dispatches per step less.
