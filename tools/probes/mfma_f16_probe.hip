@@ -27,6 +27,9 @@ __global__ __launch_bounds__(512) void rate_kernel(int iters, float* out) {
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc16[i][j] = 0.f;
     f16x8 ah, bh;
     bf16x8 ab, bb;
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    f16x4 a4, b4;
+    for (int j = 0; j < 4; ++j) { a4[j] = (_Float16)(0.001f * (threadIdx.x + j)); b4[j] = (_Float16)(0.002f * (threadIdx.x ^ j)); }
     for (int j = 0; j < 8; ++j) {
         ah[j] = (_Float16)(0.001f * (threadIdx.x + j)); bh[j] = (_Float16)(0.002f * (threadIdx.x ^ j));
         ab[j] = (__bf16)(0.001f * (threadIdx.x + j)); bb[j] = (__bf16)(0.002f * (threadIdx.x ^ j));
@@ -36,6 +39,7 @@ __global__ __launch_bounds__(512) void rate_kernel(int iters, float* out) {
         for (int i = 0; i < 8; ++i) {
             if (KIND == 0) acc4[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc4[i], 0, 0, 0);
             if (KIND == 1) acc4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, acc4[i], 0, 0, 0);
+            if (KIND == 4) acc4[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc4[i], 0, 0, 0);      // the K = 16 form (round 6: is it half the time?)
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -62,7 +66,7 @@ void rate(const char* name, int threads, float* d) {
     hipEventSynchronize(e1);
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
-    const double per = KIND < 2 ? 8.0 * 16 * 16 * 32 * 2 : 4.0 * 32 * 32 * 16 * 2;
+    const double per = KIND == 4 ? 8.0 * 16 * 16 * 16 * 2 : KIND < 2 ? 8.0 * 16 * 16 * 32 * 2 : 4.0 * 32 * 32 * 16 * 2;
     const double flop = per * iters * (threads / 64) * blocks;
     printf("{\"probe\": \"mfma_rate\", \"inst\": \"%s\", \"threads_per_block\": %d, \"ms\": %.3f, \"TFLOPs\": %.1f}\n", name, threads, ms,
            flop / ms * 1e-9);
@@ -86,6 +90,8 @@ int main() {
     rate<1>("v_mfma_f32_16x16x32_bf16", 256, d);
     rate<2>("v_mfma_f32_32x32x16_f16", 256, d);
     rate<3>("v_mfma_f32_32x32x16_bf16", 256, d);
+    rate<4>("v_mfma_f32_16x16x16_f16", 256, d);
+    rate<4>("v_mfma_f32_16x16x16_f16", 512, d);
     rate<0>("v_mfma_f32_16x16x32_f16", 512, d);
     rate<1>("v_mfma_f32_16x16x32_bf16", 512, d);
     return 0;
