@@ -71,7 +71,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
         // 64-bit address per item and stage, ~360 VALU instructions per stage against the consumers' 60 MFMAs.)
         unsigned off[LD_U];
         int lds_off[LD_U];
-        int nv[LD_U];                                  // RAGGED: pixels of the chunk fetched last that lie inside the plane (<= 0: none)
+        int room[4] = {0, 0, 0, 0};                    // RAGGED: pixels from the start of the stage held by register set s to the end of the plane
         int pc[LD_U];                                  // first pixel of the item's chunk inside a stage
         bool ok[LD_U], is_dy[LD_U];
 #pragma unroll
@@ -86,7 +86,8 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
             pc[u] = 4 * c;
         }
         int img = (int)(u_lo / stages_per_img), stage = (int)(u_lo % stages_per_img);       // of the next stage to LOAD
-        auto load = [&](float4 (&v)[LD_U]) __attribute__((always_inline)) {
+        long next_unit = u_lo;                                                                // its index; past u_hi - 1 the last stage is fetched again
+        auto load = [&](float4 (&v)[LD_U], int& room_of_set) __attribute__((always_inline)) {
             const float* dyp = dy + ((size_t)img * Cout * plane + (size_t)stage * STG);     // uniform
             const float* xp = x + ((size_t)img * Cin * plane + (size_t)stage * STG);
 #pragma unroll
@@ -97,7 +98,6 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
                     // off[u] = (channel * plane + 4 * chunk) * 4 bytes from the start of the stage: element k sits `k` floats further,
                     // unless that is behind the plane -- then the last pixel of the plane is read (finite) and zeroed in put()
                     const int left = plane_i - stage * STG - pc[u];          // pixels from this chunk to the end of the plane
-                    nv[u] = left;
                     const char* base = reinterpret_cast<const char*>(is_dy[u] ? dyp : xp) + off[u];
                     float e[4];
 #pragma unroll
@@ -105,16 +105,22 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
                     v[u] = make_float4(e[0], e[1], e[2], e[3]);
                 }
             }
-            if (++stage == stages_per_img) { stage = 0; ++img; }
+            room_of_set = plane_i - stage * STG;
+            // (issued UNCONDITIONALLY -- a stage behind this split's range re-reads the last one -- so that the compiler counts the
+            // outstanding loads exactly and the wait for one register set leaves the younger ones in flight)
+            if (++next_unit < u_hi) {
+                if (++stage == stages_per_img) { stage = 0; ++img; }
+            }
         };
-        auto put = [&](int buf, const float4 (&v)[LD_U]) __attribute__((always_inline)) {
+        auto put = [&](int buf, const float4 (&v)[LD_U], int room_of_set) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < LD_U; ++u) {
                 if (ok[u] || lt + 256 * u < LD_ITEMS) {                          // rows beyond the channel count are zero-filled
                     float4 t = ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
                     if (RAGGED) {
-                        t.x = nv[u] > 0 ? t.x : 0.f; t.y = nv[u] > 1 ? t.y : 0.f;
-                        t.z = nv[u] > 2 ? t.z : 0.f; t.w = nv[u] > 3 ? t.w : 0.f;
+                        const int nv = room_of_set - pc[u];              // pixels of this chunk inside the plane (<= 0: none)
+                        t.x = nv > 0 ? t.x : 0.f; t.y = nv > 1 ? t.y : 0.f;
+                        t.z = nv > 2 ? t.z : 0.f; t.w = nv > 3 ? t.w : 0.f;
                     }
                     uint2 cells[NP];
                     split_cells4<AR>(t, is_dy[u] ? dscale : xscale, cells);
@@ -125,24 +131,37 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
                 }
             }
         };
-        float4 v[LD_U];
+        // FOUR stages in flight (round 6). A stage is 32 pixels of 272 channel rows = 35 KB and 0.45 us of MFMAs; with ONE stage in
+        // flight (rounds 2-5) every stage waited out an HBM round trip of ~2 us -- the kernel ran at 0.23 of the split roof on the
+        // 720 x 720 head and at 1.7 TB/s on the 64 <-> 256 bottleneck layers, whose weight gradient is a stream of 335 MB
+        // (profiles/r06_bench_detail_default.json). Register set s & 3 holds stage s from its load until its put().
+        constexpr int PF = 4;
+        float4 v[PF][LD_U];
         if (u_lo < u_hi) {
-            load(v);
-            put(0, v);
-            if (u_lo + 1 < u_hi) load(v);
+            load(v[0], room[0]);
+            put(0, v[0], room[0]);
+#pragma unroll
+            for (int s = 1; s < PF; ++s) load(v[s], room[s]);           // stages 1 .. 3
+            load(v[0], room[0]);                                        // stage 4
         }
         __syncthreads();
+        long unit = u_lo;
+        // main part: four stages that all have a successor -- no branch between the loads, so s_waitcnt leaves three sets in flight
 #pragma unroll 1
-        for (long unit = u_lo; unit < u_hi; unit += 2) {
+        for (; unit + PF < u_hi; unit += PF) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {              // stage k = unit - u_lo + j: buffer k & 1 = j
-                if (unit + j < u_hi) {
-                    if (unit + j + 1 < u_hi) {
-                        put((j + 1) & 1, v);           // that buffer was last read in stage k - 1 (barrier since)
-                        if (unit + j + 2 < u_hi) load(v);
-                    }
-                    __syncthreads();
-                }
+            for (int j = 0; j < PF; ++j) {             // stage k = unit - u_lo + j: LDS buffer k & 1 = j & 1, register set k & 3 = j
+                put((j + 1) & 1, v[(j + 1) & 3], room[(j + 1) & 3]);       // that buffer was last read in stage k - 1 (barrier since)
+                load(v[(j + 1) & 3], room[(j + 1) & 3]);                   // stage k + 5
+                __syncthreads();
+            }
+        }
+        // the last one to four stages
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            if (unit + j < u_hi) {
+                if (unit + j + 1 < u_hi) put((j + 1) & 1, v[(j + 1) & 3], room[(j + 1) & 3]);
+                __syncthreads();
             }
         }
     } else {
@@ -227,7 +246,9 @@ int wrw1_splits(int B, int Cin, int Cout, int plane) {
     const long units = (long)B * ((plane + STG - 1) / STG);
     const int pairs = ((Cin + CI_T - 1) / CI_T) * ((Cout + CO_T - 1) / CO_T);
     const double stage_us = 0.75, split_us = 2.0 * Cin * Cout * sizeof(float) / 4.0e6;
-    const long n_max = units < 64 ? units : 64;
+    // up to 256 splits (round 6; 64 before): with ONE or two channel-block pairs -- the 64 <-> 256 bottleneck layers, the 1x1 convolutions of
+    // the exchange units -- 64 splits were 64 / 128 blocks on 256 CUs for a gradient that is a stream of up to 335 MB
+    const long n_max = units < 256 ? units : 256;
     auto cost_of = [&](long n) {
         const long rounds = (n * pairs + 255) / 256;
         return rounds * ((double)((units + n - 1) / n) * stage_us + 5.0) + n * split_us;

@@ -124,7 +124,10 @@ def test_conv1x1_forward_and_backward_data(case, wave_order):
     assert np.abs(dx - ref).max() <= _bound(ref, co)
 
 
-@pytest.mark.parametrize("case", [(2, 48, 64, 8, 8), (1, 144, 160, 8, 12), (2, 64, 256, 16, 16), (1, 16, 16, 4, 8)])
+# the last two: 1 280 / 1 315 stages = five and more per split at the 256 splits the library then takes, so that the loaders' four-deep register ring of round 6 goes round (aligned
+# planes; and a ragged one -- 65 x 129 -- whose last stage of an image is partly outside the plane while younger stages are in flight)
+@pytest.mark.parametrize("case", [(2, 48, 64, 8, 8), (1, 144, 160, 8, 12), (2, 64, 256, 16, 16), (1, 16, 16, 4, 8),
+                                  (1, 16, 16, 160, 256), (5, 16, 16, 65, 129)])
 def test_conv1x1_weight_gradient(case, wave_order):
     B, ci, co, H, W = case
     x, dy = _rand((B, ci, H, W), 13), _rand((B, co, H, W), 14)
