@@ -224,19 +224,29 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_wrw_kernel(const float* __r
     }
 }
 
-// dW[co][ci] = sum over splits of partial[split][co][ci], fixed order
+// dW[co][ci] = sum over splits of partial[split][co][ci], fixed order. A block = 64 elements x four waves: wave w adds the splits w, w + 4,
+// ... in four independent chains, the four waves' sums meet in LDS in a fixed order (the form of sb_wrw_reduce_body in conv3x3_sb_wrw.hip).
+// Round 6: with up to 256 splits the one-thread-per-element loop of rounds 2-5 (two chains of 128 dependent adds over loads 18 KB apart,
+// 18 blocks for a 96 x 48 gradient) took longer than the gradient kernel itself.
 __global__ __launch_bounds__(256) void sb_wrw1_reduce_kernel(const float* __restrict__ partial, int n_split, int total,
                                                              float* __restrict__ dw) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    float s0 = 0.f, s1 = 0.f;
-    int sp = 0;
-    for (; sp + 1 < n_split; sp += 2) {
-        s0 += partial[(size_t)sp * total + e];
-        s1 += partial[(size_t)(sp + 1) * total + e];
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < total) {
+        int sp = wave;
+        for (; sp + 12 < n_split; sp += 16) {
+            s0 += partial[(size_t)sp * total + e];
+            s1 += partial[(size_t)(sp + 4) * total + e];
+            s2 += partial[(size_t)(sp + 8) * total + e];
+            s3 += partial[(size_t)(sp + 12) * total + e];
+        }
+        for (; sp < n_split; sp += 4) s0 += partial[(size_t)sp * total + e];
     }
-    if (sp < n_split) s0 += partial[(size_t)sp * total + e];
-    dw[e] = s0 + s1;
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && e < total) dw[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // Pixel splits: one block per CU at a time (104 KB of LDS), so the launch runs in ROUNDS of 256 blocks; the count that minimises
@@ -311,7 +321,7 @@ int wrw1_impl(const float* x, const float* dy, int B, int Cin, int Cout, int HW,
                     : launch_wrw1<SplitBF16x6, false>(x, dy, B, Cin, Cout, HW, n_split, blocks, amax_x, amax_dy, ws, stream);
     if (!ok) return 0;
     const int total = Cin * Cout;
-    hipLaunchKernelGGL(sb_wrw1_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, ws, n_split, total, dw);
+    hipLaunchKernelGGL(sb_wrw1_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, ws, n_split, total, dw);
     CSEG_CHECK_LAUNCH("sb_wrw1_reduce_kernel");
     return 1;
 }
