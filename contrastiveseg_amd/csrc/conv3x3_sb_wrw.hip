@@ -307,7 +307,7 @@ __device__ __forceinline__ void conv3x3_sb_wrw2_body(const float* __restrict__ x
     const int n_cib = (Cin + CI_B - 1) / CI_B;
     int split, cib, cob;
     {
-        const int n_cob = Cout / CO_B;
+        const int n_cob = (Cout + CO_B - 1) / CO_B;    // round 6: the last block may hold 16 or 32 channels (Cout % 16 == 0: 64, 128, 256 ...)
         const int n_si = n_cib / SI, gsz = SC * SI, n_groups = n_split * (n_cob / SC) * n_si;
         const int xcd = bid & 7, l = bid >> 3;
         const int grp = (l / gsz) * 8 + xcd, j = l % gsz;
@@ -349,8 +349,10 @@ __device__ __forceinline__ void conv3x3_sb_wrw2_body(const float* __restrict__ x
         const int co = itc / DCH, c = itc - co * DCH;
         di_lds[u] = d2_idx<NP, SEGW>(0, 0, co, 4 * c);
         di_c4[u] = 4 * c;
-        di_off[u] = (cob * CO_B + co) * (int)plane + 4 * c;
-        di_ok[u] = loader && item < CO_B * DCH;
+        di_off[u] = min(cob * CO_B + co, Cout - 1) * (int)plane + 4 * c;
+        // (channel rows behind Cout in the last block are never staged: whatever their LDS rows hold reaches only accumulator rows
+        // that the epilogue does not store -- an output row depends on its own dy channel alone)
+        di_ok[u] = loader && item < CO_B * DCH && cob * CO_B + co < Cout;
     }
     // per unit (set by unit_setup): base pointers of the image, byte offsets of the items inside it, column validity
     const float* x_img = x;
@@ -617,6 +619,7 @@ __device__ __forceinline__ void conv3x3_sb_wrw2_body(const float* __restrict__ x
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     // D[m = 4g + r][n]: co = cob*48 + 16c + 4g + r, ci = this lane's column
+                    if (cob * CO_B + c * 16 >= Cout) continue;             // the last block of a channel count that is not a multiple of 48
                     float* dst = partial + (((size_t)split * 9 + t) * Cout + cob * CO_B + c * 16 + 4 * g) * Cin + ci;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dst[(size_t)r * Cin] = acc[t][c][r] * unscale;
@@ -689,7 +692,7 @@ int sb_wrw_splits(int B, int Cin, int Cout, int H, int W, int arith) {
     const int rpu = v2 ? wrw2_rpu(H) : ROWS_PER_UNIT;
     const int seg = v2 ? wrw2_seg(W) : SEG;
     const int units = B * ((W + seg - 1) / seg) * ((H + rpu - 1) / rpu);
-    const int n_cib = (Cin + CI_B - 1) / CI_B, n_cob = Cout / CO_B;
+    const int n_cib = (Cin + CI_B - 1) / CI_B, n_cob = (Cout + CO_B - 1) / CO_B;
     const int pairs = n_cib * n_cob;
     if (!v2) {
         int n = (768 + pairs - 1) / pairs;
@@ -721,7 +724,9 @@ int sb_wrw_splits(int B, int Cin, int Cout, int H, int W, int arith) {
 
 // the larger of the two arithmetics' needs (they may split differently: version 1 has no 32-pixel segments)
 extern "C" size_t cseg_conv3x3_sb_wrw_ws_floats(int B, int Cin, int Cout, int H, int W) {
-    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || Cin % 16 || Cout % CO_B) return 0;
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || Cin % 16 || Cout % 16) return 0;
+    // output channel counts that are not multiples of 48 (64, 128, 256 ...: a partly filled last channel block): f16x3, version 2 only
+    if (Cout % CO_B) return (size_t)sb_wrw_splits(B, Cin, Cout, H, W, CSEG_ARITH_F16X3) * 9 * Cin * Cout;
     // ragged widths: f16x3 only, and f16x3 always runs version 2 whatever CSEG_CONV3X3_SB_WRW_V says (wrw_impl) -- the size of that
     // launch (with the version switch at 1 this returned 0 and the autograd path raised instead of running)
     if (W % 32) return (size_t)sb_wrw_splits(B, Cin, Cout, H, W, CSEG_ARITH_F16X3) * 9 * Cin * Cout;
@@ -760,7 +765,7 @@ int launch_wrw2(const float* x, const float* dy, int B, int Cin, int Cout, int H
         }
         attr2_set = true;
     }
-    const int n_cob = Cout / CO_B, n_cib = (Cin + CI_B - 1) / CI_B;
+    const int n_cob = (Cout + CO_B - 1) / CO_B, n_cib = (Cin + CI_B - 1) / CI_B;
     int SC, SI;
     sb_wrw_group(n_cob, n_cib, SC, SI);
     const long n_groups = (long)n_split * (n_cob / SC) * (n_cib / SI);
@@ -777,13 +782,14 @@ int wrw_impl(const float* x, const float* dy, int B, int Cin, int Cout, int H, i
     CSEG_REQUIRE(x && dy && ws && dw, "conv3x3_sb_wrw: null pointer");
     const bool v2 = arith == CSEG_ARITH_F16X3 || sb_wrw_version() == 2;
     const bool ragged = v2 && arith == CSEG_ARITH_F16X3 && wrw2_ragged(W);          // round 5: any width (f16x3, version 2)
-    CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % CO_B == 0 && (ragged || W % (v2 ? 32 : SEG) == 0),
-                 "conv3x3_sb_wrw: unsupported shape B=%d Cin=%d Cout=%d %dx%d (needs Cin %% 16, Cout %% 48; bf16x6: W %% 32; version 1: W %% 64)",
+    CSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0 &&
+                     (Cout % CO_B == 0 || (v2 && arith == CSEG_ARITH_F16X3)) && (ragged || W % (v2 ? 32 : SEG) == 0),
+                 "conv3x3_sb_wrw: unsupported shape B=%d Cin=%d Cout=%d %dx%d (needs Cin %% 16, Cout %% 48 -- f16x3: Cout %% 16; bf16x6: W %% 32; version 1: W %% 64)",
                  B, Cin, Cout, H, W);
     CSEG_REQUIRE(arith == CSEG_ARITH_BF16X6 || (arith == CSEG_ARITH_F16X3 && amax_x && amax_dy),
                  "conv3x3 split wrw: arithmetic %d needs max|x| and max|dy|", arith);
     const int n_split = sb_wrw_splits(B, Cin, Cout, H, W, arith);
-    const long blocks = (long)n_split * ((Cin + CI_B - 1) / CI_B) * (Cout / CO_B);
+    const long blocks = (long)n_split * ((Cin + CI_B - 1) / CI_B) * ((Cout + CO_B - 1) / CO_B);
     CSEG_REQUIRE(blocks < 2147483647L && (long)9 * Cin * Cout < 2147483647L, "conv3x3_sb_wrw: grid too large");
     if (v2) {
         CSEG_REQUIRE(ragged || ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0),

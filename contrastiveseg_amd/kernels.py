@@ -1328,7 +1328,9 @@ def conv3x3_sb_tiles(x, c_out):
 # every eligible layer (tools/emu_step_golden.py, profiles/r02_emu_step_golden_*.json). CSEG_CONV3X3_SB_WRW=0 restores the
 # fp32-MFMA kernel / MIOpen; CSEG_CONV3X3_SB_WRW_V=2 selects the producer/consumer version (not yet run on hardware).
 CONV3X3_SB_WRW = os.environ.get("CSEG_CONV3X3_SB_WRW", "1") == "1"
-CONV3X3_SB_WRW_CHANNELS = tuple(int(c) for c in os.environ.get("CSEG_CONV3X3_SB_WRW_CHANNELS", "48,96,192,384,720").split(","))
+# 64 / 128 since round 6 (f16x3: output channels % 16, a partly filled last 48-channel block): the layer-1 bottlenecks of HRNet, ResNet's
+# layers 1 / 2 -- the last weight gradients of the HRNet step that went to MIOpen's NHWC implicit GEMM and its layout transposes
+CONV3X3_SB_WRW_CHANNELS = tuple(int(c) for c in os.environ.get("CSEG_CONV3X3_SB_WRW_CHANNELS", "48,64,96,128,192,384,720").split(","))
 
 
 # (Cin, Cout) pairs with different channel counts that take the split weight gradient too: transition 1 of HRNet (256 -> 48)
@@ -1339,7 +1341,8 @@ def conv3x3_sb_wrw_eligible(x, dy):
     """Shapes the kernel covers (NCHW fp32, Cin % 16, Cout % 48; 64-pixel row segments, 32-pixel ones for the 16 x 32 maps of the
     384-channel branch; since round 5 any width in the f16x3 arithmetic -- the last segment of a row may be ragged)."""
     return (_on_device(x) and x.dtype == F32 and dy.dtype == F32 and x.is_contiguous() and dy.is_contiguous()
-            and x.shape[1] % 16 == 0 and dy.shape[1] % 48 == 0 and (x.shape[3] % 32 == 0 or SPLIT_ARITH == "f16x3"))
+            and x.shape[1] % 16 == 0 and (dy.shape[1] % 48 == 0 or (dy.shape[1] % 16 == 0 and SPLIT_ARITH == "f16x3"))
+            and (x.shape[3] % 32 == 0 or SPLIT_ARITH == "f16x3"))
 
 
 def conv3x3_sb_wrw_wanted(x, dy):

@@ -223,6 +223,18 @@ def test_split_weight_gradient_32_pixel_segments(case, arith, wave_order):
     assert np.abs(dw - ref).max() <= 3e-6 * np.sqrt(B * H * W) * float(np.abs(ref).max())
 
 
+@pytest.mark.parametrize("case", [(1, 64, 64, 5, 64), (2, 32, 128, 3, 32), (1, 48, 16, 4, 65), (1, 16, 256, 2, 64)])
+def test_split_weight_gradient_partly_filled_channel_block(case, wave_order):
+    """Round 6, f16x3: output channel counts that are multiples of 16 but not of 48 (the 64-channel 3x3 convolutions of HRNet's layer 1,
+    ResNet's 64 / 128 / 256): the last 48-channel block holds 16 or 32 channels; its missing rows are neither staged nor stored."""
+    B, ci, co, H, W = case
+    x, dy = _rand((B, ci, H, W), 71, 3.0), _rand((B, co, H, W), 72, 1e-3)
+    dw = E.conv3x3_sb_wrw(x, dy, arith=E.F16X3)
+    ref = E.ref_conv3x3_wrw(x, dy)
+    assert not np.isnan(dw).any()
+    assert np.abs(dw - ref).max() <= 3e-6 * np.sqrt(B * H * W) * float(np.abs(ref).max())
+
+
 @pytest.mark.parametrize("case", [(1, 192, 192, 4, 64), (1, 96, 192, 4, 64)])
 def test_split_weight_gradient_group_order(case, wave_order):
     """several channel blocks each way: the XCD-aware block order (groups of SC x SI channel blocks) covers every block once."""

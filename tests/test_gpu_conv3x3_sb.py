@@ -93,6 +93,10 @@ WRW_CASES = [  # B, Cin, Cout, H, W
     (1, 64, 96, 9, 33),         # 32 + 1, two channel blocks on the output side
     (1, 16, 48, 18, 130),       # 2 x 64 + 2, two runs
     (2, 96, 48, 3, 17),         # narrower than a segment
+    # round 6 (version 2, f16x3 only): output channels % 16 but not % 48 -- a partly filled last channel block
+    (2, 64, 64, 16, 64),        # the 3x3 convolutions of HRNet's layer 1
+    (1, 32, 128, 9, 96),
+    (1, 64, 256, 5, 65),        # with a ragged width
 ]
 
 
@@ -102,8 +106,8 @@ def test_weight_gradient_matches_fp64(case, version, monkeypatch):
     from contrastiveseg_amd import kernels as K
     monkeypatch.setenv("CSEG_CONV3X3_SB_WRW_V", version)
     B, ci, co, H, W = case
-    if W % 32 and version == "1":
-        pytest.skip("version 1 has no ragged loaders")
+    if (W % 32 or co % 48) and version == "1":
+        pytest.skip("version 1 has no ragged loaders / no partly filled channel blocks")
     g = torch.Generator().manual_seed(3)
     x = torch.randn(B, ci, H, W, generator=g)
     dy = torch.randn(B, co, H, W, generator=g)
