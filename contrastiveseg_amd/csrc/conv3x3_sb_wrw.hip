@@ -995,7 +995,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw_s2_kernel(const float* 
     const int n_cib = (Cin + CI_B - 1) / CI_B;
     int split, cib, cob;
     {   // XCD-aware block order, see conv3x3_sb_wrw2_kernel
-        const int n_cob = Cout / CO_B;
+        const int n_cob = (Cout + CO_B - 1) / CO_B;    // (round 6: a partly filled last block, as in the stride-1 kernel)
         const int n_si = n_cib / SI, gsz = SC * SI, n_groups = n_split * (n_cob / SC) * n_si;
         const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
         const int grp = (l / gsz) * 8 + xcd, j = l % gsz;
@@ -1035,8 +1035,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw_s2_kernel(const float* 
         const int item = lt + 256 * u, itc = min(max(item, 0), CO_B * DCH - 1);
         const int co = itc / DCH, c = itc - co * DCH;
         di_lds[u] = (int)(d_at(0, 0, co, 4 * c) - ds);
-        di_off[u] = (cob * CO_B + co) * (int)oplane + 4 * c;
-        di_ok[u] = loader && item < CO_B * DCH;
+        di_off[u] = min(cob * CO_B + co, Cout - 1) * (int)oplane + 4 * c;
+        di_ok[u] = loader && item < CO_B * DCH && cob * CO_B + co < Cout;
     }
     const float* x_img = x;
     const float* d_img = dy;
@@ -1217,6 +1217,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw_s2_kernel(const float* 
             for (int t = 0; t < 9; ++t)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
+                    if (cob * CO_B + c * 16 >= Cout) continue;
                     float* dst = partial + (((size_t)split * 9 + t) * Cout + cob * CO_B + c * 16 + 4 * g) * Cin + ci;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dst[(size_t)r * Cin] = acc[t][c][r] * unscale;
@@ -1227,7 +1228,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb_wrw_s2_kernel(const float* 
 
 // rows per unit: the largest of 16 / 8 / 4 that still gives >= 256 blocks; number of pixel splits like sb_wrw_splits
 void s2_plan(int B, int Cin, int Cout, int Ho, int Wo, int& rpu, int& n_split) {
-    const int pairs = ((Cin + CI_B - 1) / CI_B) * (Cout / CO_B);
+    const int pairs = ((Cin + CI_B - 1) / CI_B) * ((Cout + CO_B - 1) / CO_B);
     int want = (768 + pairs - 1) / pairs;
     if (want > 256) want = 256;
     rpu = 4;
@@ -1244,7 +1245,7 @@ void s2_plan(int B, int Cin, int Cout, int Ho, int Wo, int& rpu, int& n_split) {
 }
 
 bool s2_shape_ok(int B, int Cin, int Cout, int Ho, int Wo) {
-    return B > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0 && Cin % 16 == 0 && Cout % CO_B == 0 && Wo % S2_SEG == 0;
+    return B > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0 && Cin % 16 == 0 && Cout % 16 == 0 && Wo % S2_SEG == 0;
 }
 
 }  // namespace
@@ -1264,7 +1265,7 @@ extern "C" int cseg_conv3x3_s2_split_wrw(const float* x, const float* dy, int B,
                                          cseg_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CSEG_REQUIRE(x && dy && ws && dw, "conv3x3_s2_wrw: null pointer");
-    CSEG_REQUIRE(s2_shape_ok(B, Cin, Cout, Ho, Wo), "conv3x3_s2_wrw: unsupported shape B=%d Cin=%d Cout=%d out %dx%d (needs Cin %% 16, Cout %% 48, Wo %% 32)",
+    CSEG_REQUIRE(s2_shape_ok(B, Cin, Cout, Ho, Wo), "conv3x3_s2_wrw: unsupported shape B=%d Cin=%d Cout=%d out %dx%d (needs Cin %% 16, Cout %% 16, Wo %% 32)",
                  B, Cin, Cout, Ho, Wo);
     CSEG_REQUIRE(arith == CSEG_ARITH_F16X3 && amax_x && amax_dy, "conv3x3_s2_wrw: f16x3 only (needs max|x| and max|dy|)");
     CSEG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0,
@@ -1284,7 +1285,7 @@ extern "C" int cseg_conv3x3_s2_split_wrw(const float* x, const float* dy, int B,
         }
         attr_set = true;
     }
-    const int n_cob = Cout / CO_B, n_cib = (Cin + CI_B - 1) / CI_B;
+    const int n_cob = (Cout + CO_B - 1) / CO_B, n_cib = (Cin + CI_B - 1) / CI_B;
     int SC, SI;
     sb_wrw_group(n_cob, n_cib, SC, SI);
     const long n_groups = (long)n_split * (n_cob / SC) * (n_cib / SI);

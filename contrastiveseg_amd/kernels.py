@@ -1991,7 +1991,7 @@ def _s2_base_ok(x, weight):
 
 def conv3x3_s2_fwd_eligible(x, weight):
     co, ci = weight.shape[:2]
-    return _s2_base_ok(x, weight) and x.shape[1] == ci and ci % 16 == 0 and co % 48 == 0          # (even input; any output width since round 5)
+    return _s2_base_ok(x, weight) and x.shape[1] == ci and ci % 16 == 0 and (co % 48 == 0 or co % 64 == 0)      # (even input; any output width since round 5; 64: the stem's second convolution, round 6)
 
 
 def conv3x3_s2_bwd_eligible(x, weight):
@@ -2001,7 +2001,7 @@ def conv3x3_s2_bwd_eligible(x, weight):
 
 def conv3x3_s2_wrw_eligible(x, weight):
     co, ci = weight.shape[:2]
-    return _s2_base_ok(x, weight) and ci % 16 == 0 and co % 48 == 0 and x.shape[3] % 64 == 0
+    return _s2_base_ok(x, weight) and ci % 16 == 0 and co % 16 == 0 and x.shape[3] % 64 == 0
 
 
 def conv3x3_s2_pick_nt(B, Ho, Wo, c_out):

@@ -382,7 +382,7 @@ class HighResolutionNet(nn.Module):
         super(HighResolutionNet, self).__init__()
         self.conv1 = nn.Conv2d(3, 64, 3, 2, 1, bias=False)
         self.bn1 = _norm(bn_type, 64, bn_momentum)
-        self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
+        self.conv2 = Conv3x3(64, 64, 2)                  # an nn.Conv2d(64, 64, 3, 2, 1, bias=False) (hrnet_backbone.py:519 of the reference); split stride-2 kernels since round 6
         self.bn2 = _norm(bn_type, 64, bn_momentum)
         self.layer1 = _block_chain(Bottleneck, 64, 64, 4, bn_type, bn_momentum)
         prev = [256]

@@ -305,6 +305,8 @@ S2_FWD_CASES = [  # B, Cin, Cout, Ho, Wo, nt
     (1, 48, 48, 5, 32, 3),       # ragged row tile, half a column tile
     (2, 32, 96, 3, 68, 6),       # two column tiles, the second ragged; six channel tiles per block
     (1, 16, 96, 9, 132, 3),      # one chunk, three row tiles, two channel tile groups
+    (1, 64, 64, 6, 64, 4),       # round 6: 64 output channels = four tiles per block (the second stem convolution of HRNet)
+    (2, 16, 128, 3, 36, 4),      # two 64-channel groups
 ]
 
 
@@ -329,7 +331,9 @@ def test_stride2_backward_data(case, wave_order):
     assert np.abs(dx - ref).max() <= 3e-6 * np.sqrt(4 * co) * float(np.abs(ref).max())
 
 
-@pytest.mark.parametrize("case", [(1, 48, 48, 5, 32), (2, 80, 96, 3, 64), (1, 16, 48, 18, 32), (1, 192, 96, 2, 32)])
+# the last two (round 6): output channels % 16, not % 48 -- a partly filled last 48-channel block (64 = 48 + 16, 128 = 2 x 48 + 32)
+@pytest.mark.parametrize("case", [(1, 48, 48, 5, 32), (2, 80, 96, 3, 64), (1, 16, 48, 18, 32), (1, 192, 96, 2, 32),
+                                  (1, 64, 64, 5, 32), (1, 16, 128, 3, 64)])
 @pytest.mark.parametrize("rpu", ["4", "16"])
 def test_stride2_weight_gradient(case, rpu, wave_order, monkeypatch):
     """runs of 4 / 16 rows (the benched shapes use 16 / 8), ragged channel block (80 = 64 + 16), several channel blocks each
