@@ -14,7 +14,7 @@ S2_CASES = [  # B, Cin, Cout, Ho, Wo
     (2, 192, 384, 4, 32),        # the widest pair of HRNet-W48
     (1, 256, 96, 8, 64),         # transition 1: 256 input channels = four channel tiles per block in the backward-data kernel
     (2, 64, 64, 8, 64),          # round 6: the second stem convolution (64 -> 64): four tiles per block forward and backward-data, a partly filled channel block in the weight gradient
-    (1, 32, 128, 6, 32),
+    (1, 64, 128, 6, 32),
 ]
 
 
