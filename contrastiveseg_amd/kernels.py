@@ -2099,6 +2099,53 @@ def conv3x3_s2_split(x, weight, want_stats=False):
 
 
 # ----------------------------------------------------------------------------------------------------------
+# The first convolution of the stem, nn.Conv2d(3, 64, 3, 2, 1, bias=False) on the image (csrc/conv3x3_stem.hip, round 6): fp32 FMA
+# kernels for the forward and the weight gradient -- the image needs no gradient, so there is no backward-data operator
+# ----------------------------------------------------------------------------------------------------------
+CONV3X3_RGB_STEM = os.environ.get("CSEG_CONV3X3_RGB_STEM", "1") == "1"
+
+
+def conv3x3_s2_rgb_eligible(x, weight):
+    return (CONV3X3_RGB_STEM and _on_device(x) and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4 and x.shape[1] == 3
+            and tuple(weight.shape) == (64, 3, 3, 3) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and not x.requires_grad)
+
+
+class Conv3x3S2Rgb(Function):
+    """y = conv2d(x, weight, None, stride 2, padding 1) for x [B, 3, H, W] that needs no gradient and weight [64, 3, 3, 3]."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x, weight = x.contiguous(), weight.contiguous()
+        ctx.save_for_backward(x, weight)
+        B, _, H, W = x.shape
+        y = torch.empty(B, 64, H // 2, W // 2, dtype=F32, device=x.device)
+        _hip.call("cseg_conv3x3_s2_rgb_fwd", _p(x, F32, "x"), _p(weight, F32, "weight"), B, 64, H, W, _pf(y), _hip.stream_ptr())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        if not ctx.needs_input_grad[1]:
+            return None, None
+        dy = dy.contiguous()
+        B, _, H, W = x.shape
+        n = _hip.lib().cseg_conv3x3_s2_rgb_wrw_ws_floats(B, 64, H, W)
+        if n == 0:
+            raise RuntimeError("conv3x3_s2_rgb_wrw: unsupported shape %s" % (tuple(x.shape),))
+
+        def wrw():
+            ws = torch.empty(n, dtype=F32, device=x.device)
+            dw = torch.empty(64, 3, 3, 3, dtype=F32, device=x.device)
+            _hip.call("cseg_conv3x3_s2_rgb_wrw", _p(x, F32, "x"), _p(dy, F32, "dy"), B, 64, H, W, _pf(ws), _pf(dw), _hip.stream_ptr())
+            return dw
+        return None, _on_wgrad_stream(wrw, x, dy)
+
+
+def conv3x3_s2_rgb(x, weight):
+    return Conv3x3S2Rgb.apply(x, weight)
+
+
+# ----------------------------------------------------------------------------------------------------------
 # 1x1 convolution on the BF16 matrix cores with split operands (csrc/conv1x1_sb.hip): first hardware run pending -> opt-in
 # ----------------------------------------------------------------------------------------------------------
 CONV1X1_SPLIT_BF16 = os.environ.get("CSEG_CONV1X1_SPLIT_BF16", "1") == "1"

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from contrastiveseg_amd import kernels as K
 from contrastiveseg_amd.lib.models.tools.fused_bn import basic_block_group, bn_act_group
-from contrastiveseg_amd.lib.models.tools.module_helper import Conv1x1, Conv3x3, ModuleHelper
+from contrastiveseg_amd.lib.models.tools.module_helper import Conv1x1, Conv3x3, ModuleHelper, StemConv3x3
 
 # width -> per-stage (modules, blocks per branch); channel list is width * (1, 2, 4, 8)[:branches]
 STAGES = {2: (1, 4), 3: (4, 4), 4: (3, 4)}
@@ -380,7 +380,7 @@ class HighResolutionModule(nn.Module):
 class HighResolutionNet(nn.Module):
     def __init__(self, width, bn_type='torchsyncbn', bn_momentum=0.1):
         super(HighResolutionNet, self).__init__()
-        self.conv1 = nn.Conv2d(3, 64, 3, 2, 1, bias=False)
+        self.conv1 = StemConv3x3(64)                      # an nn.Conv2d(3, 64, 3, 2, 1, bias=False); fp32 stem kernels since round 6
         self.bn1 = _norm(bn_type, 64, bn_momentum)
         self.conv2 = Conv3x3(64, 64, 2)                  # an nn.Conv2d(64, 64, 3, 2, 1, bias=False) (hrnet_backbone.py:519 of the reference); split stride-2 kernels since round 6
         self.bn2 = _norm(bn_type, 64, bn_momentum)

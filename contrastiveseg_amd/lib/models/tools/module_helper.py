@@ -59,6 +59,21 @@ class Conv3x3(nn.Conv2d):
         return self.forward(x), x
 
 
+class StemConv3x3(nn.Conv2d):
+    """nn.Conv2d(3, planes, 3, 2, 1, bias=False) -- the first convolution of the stem (reference hrnet_backbone.py:516): same parameters
+    and state_dict; on the GPU, for planes = 64 and an input that needs no gradient, the fp32 stem kernels of csrc/conv3x3_stem.hip
+    (forward and weight gradient), else the reference's convolution on MIOpen."""
+
+    def __init__(self, planes):
+        super(StemConv3x3, self).__init__(3, planes, kernel_size=3, stride=2, padding=1, bias=False)
+
+    def forward(self, x):
+        from contrastiveseg_amd import kernels as K
+        if K.conv3x3_s2_rgb_eligible(x, self.weight):
+            return K.conv3x3_s2_rgb(x, self.weight)
+        return super(StemConv3x3, self).forward(x)
+
+
 class HeadConv3x3(nn.Conv2d):
     """nn.Conv2d(C, C, 3, 1, 1) with bias (same parameters / state_dict) for the 720 -> 720 convolution in front of the
     classifier (44 % of the forward FLOPs of HRNet-W48-contrast). With kernels.CONV3X3_SPLIT_BF16 on, forward and

@@ -536,6 +536,17 @@ int cseg_conv1x1_split_wrw(const float* x, const float* dy, int B, int Cin, int 
                            const unsigned* amax_dy, float* ws, float* dw, cseg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Round 6: the FIRST convolution of the stem, nn.Conv2d(3, 64, 3, 2, 1, bias=False) on the image (reference
+ * lib/models/backbones/hrnet/hrnet_backbone.py:516-517, forward :664): three input channels, so both directions are streams with K = 27 --
+ * plain fp32 FMA kernels on NCHW tensors, no packed weights, no max|.| records, fixed summation order (csrc/conv3x3_stem.hip).
+ *   x [B,3,H,W] (H, W even), w [64,3,3,3], y / dy [B,64,H/2,W/2], dw [64,3,3,3]; Cout must be 64. No backward-data operator (the image
+ *   needs no gradient). ws: cseg_conv3x3_s2_rgb_wrw_ws_floats(B, Cout, H, W) floats (0 = unsupported shape).
+ * ------------------------------------------------------------------------------------------------ */
+int cseg_conv3x3_s2_rgb_fwd(const float* x, const float* w, int B, int Cout, int H, int W, float* y, cseg_stream_t stream);
+size_t cseg_conv3x3_s2_rgb_wrw_ws_floats(int B, int Cout, int H, int W);
+int cseg_conv3x3_s2_rgb_wrw(const float* x, const float* dy, int B, int Cout, int H, int W, float* ws, float* dw, cseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * GPU data pipeline: random resize (cv2 INTER_CUBIC image / INTER_NEAREST label) -> random
  * crop -> horizontal flip -> brightness shift -> ToTensor + Normalize(div, mean, std) + label look-up + ReLabel(255,-1)
  * -> collate padding to the fixed input size, as ONE kernel over the output batch.  Replaces the per-sample CPU chain

@@ -21,7 +21,8 @@ def lib():
         _LIB = ctypes.CDLL(path)
         for name in ("cseg_conv3x3_sb_packed_bytes", "cseg_conv1x1_sb_packed_bytes", "cseg_conv3x3_sb_wrw_ws_floats",
                      "cseg_conv1x1_sb_wrw_ws_floats", "cseg_conv3x3_split_packed_bytes", "cseg_conv1x1_split_packed_bytes",
-                     "cseg_conv3x3_s2_split_packed_bytes", "cseg_conv3x3_s2_wrw_ws_floats", "cseg_conv_stat_segments"):
+                     "cseg_conv3x3_s2_split_packed_bytes", "cseg_conv3x3_s2_wrw_ws_floats", "cseg_conv3x3_s2_rgb_wrw_ws_floats",
+                     "cseg_conv_stat_segments"):
             getattr(_LIB, name).restype = ctypes.c_size_t
         _LIB.cseg_last_error.restype = ctypes.c_char_p
     return _LIB
@@ -285,6 +286,23 @@ def conv3x3_s2_wrw(x, dy):
     ws, dw = aligned((n,)), aligned((co, ci, 3, 3))
     call("cseg_conv3x3_s2_split_wrw", ptr(dev(x)), ptr(dev(dy)), B, ci, co, Ho, Wo, F16X3, ptr(amax(x)), ptr(amax(dy)), ptr(ws), ptr(dw),
          None)
+    return dw
+
+
+def conv3x3_s2_rgb(x, w):
+    """the first stem convolution (csrc/conv3x3_stem.hip): x [B,3,H,W], w [64,3,3,3] -> y [B,64,H/2,W/2]"""
+    B, _, H, W = x.shape
+    y = aligned((B, 64, H // 2, W // 2), fill=np.nan)
+    call("cseg_conv3x3_s2_rgb_fwd", ptr(dev(x)), ptr(dev(w)), B, 64, H, W, ptr(y), None)
+    return y
+
+
+def conv3x3_s2_rgb_wrw(x, dy):
+    B, _, H, W = x.shape
+    n = lib().cseg_conv3x3_s2_rgb_wrw_ws_floats(B, 64, H, W)
+    assert n > 0
+    ws, dw = aligned((n,)), aligned((64, 3, 3, 3))
+    call("cseg_conv3x3_s2_rgb_wrw", ptr(dev(x)), ptr(dev(dy)), B, 64, H, W, ptr(ws), ptr(dw), None)
     return dw
 
 

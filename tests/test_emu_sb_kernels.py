@@ -348,6 +348,26 @@ def test_stride2_weight_gradient(case, rpu, wave_order, monkeypatch):
     assert np.array_equal(dw, E.conv3x3_s2_wrw(x, dy))          # fixed-order reduction: bit-identical on a second run
 
 
+# ---- the first stem convolution, nn.Conv2d(3, 64, 3, 2, 1) on the image (csrc/conv3x3_stem.hip, round 6): fp32 FMA kernels -------
+RGB_CASES = [(1, 8, 128), (2, 10, 132), (1, 2, 6), (3, 18, 260)]      # B, H, W of the image: one tile, ragged tiles both ways, smaller than a tile, several
+
+
+@pytest.mark.parametrize("case", RGB_CASES)
+def test_rgb_stem_forward_and_weight_gradient(case, wave_order):
+    B, H, W = case
+    x, w = _rand((B, 3, H, W), 91, 2.0), _rand((64, 3, 3, 3), 92, 0.2)
+    y = E.conv3x3_s2_rgb(x, w)
+    ref = E.ref_conv3x3_s2(x, w)
+    assert not np.isnan(y).any()                                       # every output element written (NaN-filled buffer)
+    assert np.abs(y - ref).max() <= 4e-6 * float(np.abs(ref).max())    # fp32 multiply-adds, K = 27
+    dy = _rand((B, 64, H // 2, W // 2), 93, 1e-3)
+    dw = E.conv3x3_s2_rgb_wrw(x, dy)
+    ref = E.ref_conv3x3_s2_wrw(x, dy)
+    assert not np.isnan(dw).any()
+    assert np.abs(dw - ref).max() <= 2e-6 * np.sqrt(B * H * W / 4) * float(np.abs(ref).max())
+    assert np.array_equal(dw, E.conv3x3_s2_rgb_wrw(x, dy))             # fixed-order sums: bit-identical on a second run
+
+
 # ---- transition 1 of HRNet (256 -> 48 at stride 1, 256 -> 96 at stride 2): channel counts that are multiples of 64, not of 48 ------
 def test_transition_layer_256_to_48(wave_order):
     """forward (conv_out 48, 16 chunks streamed), backward-data (conv_out 256: four channel tiles per block, 16-channel-chunk

@@ -121,3 +121,36 @@ def test_transition_256_to_48_module_matches_fp64(monkeypatch):
                                  ("dw", w64.grad, conv.weight.grad, wr.grad)):
         err, tol = _bound(ref, got.cpu(), fp32.cpu())
         assert err <= tol, (name, err, tol)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 128), (1, 18, 260), (8, 512, 1024)])
+def test_rgb_stem_module_matches_fp64(case):
+    """module_helper.StemConv3x3(64): the first stem convolution on the fp32 kernels of csrc/conv3x3_stem.hip (round 6) against an fp64
+    convolution, MIOpen's fp32 result as the yardstick; the weight gradient is bit-reproducible."""
+    from contrastiveseg_amd import kernels as K
+    from contrastiveseg_amd.lib.models.tools.module_helper import StemConv3x3
+    B, H, W = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) / 5.0
+    dy = torch.randn(B, 64, H // 2, W // 2, generator=g) * 1e-3
+    w64 = w.double().requires_grad_(True)
+    y64 = F.conv2d(x.double(), w64, None, 2, 1)
+    y64.backward(dy.double())
+    conv = StemConv3x3(64).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(w.cuda())
+    xd = x.cuda()
+    assert K.conv3x3_s2_rgb_eligible(xd, conv.weight)
+    y = conv(xd)
+    y.backward(dy.cuda())
+    wr = w.cuda().requires_grad_(True)
+    yr = F.conv2d(xd, wr, None, 2, 1)
+    yr.backward(dy.cuda())
+    for name, ref, got, fp32 in (("y", y64.detach(), y.detach(), yr.detach()), ("dw", w64.grad, conv.weight.grad, wr.grad)):
+        err, tol = _bound(ref, got.cpu(), fp32.cpu())
+        assert err <= tol, (case, name, err, tol)
+    g1 = conv.weight.grad.clone()
+    conv.weight.grad = None
+    conv(xd).backward(dy.cuda())
+    assert torch.equal(g1, conv.weight.grad), "weight gradient not deterministic"
