@@ -428,7 +428,7 @@ def test_host_tiling_heuristics():
     assert isinstance(K.CONV3X3_SPLIT_BF16, bool) and K.CONV3X3_SB_BRANCH_CHANNELS[:3] == (48, 64, 96)
     import os
     if not any(k.startswith("CSEG_CONV") for k in os.environ):
-        assert K.CONV3X3_SB_WRW and K.CONV3X3_SB_WRW_CHANNELS == (48, 96, 192, 384, 720)
+        assert K.CONV3X3_SB_WRW and K.CONV3X3_SB_WRW_CHANNELS == (48, 64, 96, 128, 192, 384, 720)      # 64 / 128: round 6 (partly filled channel block)
         assert K.CONV1X1_SPLIT_BF16 and K.CONV1X1_SB_WRW and K.CONV1X1_SB_WRW_MIN_CH == 16     # 256 until the lean loader (round 3)
         assert K.CONV3X3_S2_SPLIT and K.CONV3X3_SB8 and K.CONV3X3_SB_WRW_PAIRS == ((256, 48),)
         if "CSEG_SPARSE_EMBED_GRAD" not in os.environ:
