@@ -2259,54 +2259,6 @@ def conv1x1_split_bf16(x, weight, bias=None, want_stats=False):
     return Conv1x1SplitBF16.apply(x, weight, bias, want_stats)
 
 
-# ----------------------------------------------------------------------------------------------------------
-# The classifier, nn.Conv2d(C, num_classes, 1): 19 output channels tile nothing, so forward and backward-data stay rocBLAS GEMMs -- but its
-# WEIGHT GRADIENT went through MIOpen's NHWC implicit GEMM with two layout transposes of the 755 MB activation (0.5 ms per step of
-# kernels at 720 channels). Round 6: the output gradient is zero-padded to the next multiple of 16 channels (33 MB at 19 -> 32) and the
-# split 1x1 weight-gradient kernel streams the activation once; rows num_classes.. of its result are dropped.
-# ----------------------------------------------------------------------------------------------------------
-CLASSIFIER_SPLIT_WRW = os.environ.get("CSEG_CLASSIFIER_SPLIT_WRW", "1") == "1"
-
-
-def classifier_wrw_eligible(x, weight):
-    return (CLASSIFIER_SPLIT_WRW and CONV1X1_SPLIT_BF16 and CONV1X1_SB_WRW and SPLIT_ARITH == "f16x3" and _on_device(x) and x.dtype == F32
-            and weight.dtype == F32 and x.dim() == 4 and tuple(weight.shape[2:]) == (1, 1) and weight.shape[0] % 16 != 0
-            and weight.shape[0] <= 64 and x.shape[1] % 16 == 0 and x.shape[1] >= CONV1X1_SB_WRW_MIN_CH)
-
-
-class ClassifierConv1x1Fn(Function):
-    """y = conv2d(x, weight, bias) for a 1x1 kernel with few output channels: aten forward / backward-data, split weight gradient."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return torch.nn.functional.conv2d(x, weight, bias)
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
-        co = weight.shape[0]
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0]
-        if ctx.needs_input_grad[1]:
-            xc = x.contiguous()
-            cp = (co + 15) // 16 * 16
-            dyp = torch.zeros(dy.shape[0], cp, dy.shape[2], dy.shape[3], dtype=F32, device=dy.device)
-            dyp[:, :co].copy_(dy)
-            ax, ady = amax_of(xc), tensor_amax(dyp)
-            dw = _on_wgrad_stream(lambda: conv1x1_sb_wrw(xc, dyp, ax=ax, ady=ady), xc, dyp, ax, ady)[:co].contiguous()
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum((0, 2, 3))
-        return dx, dw, db
-
-
-def classifier_conv1x1(x, weight, bias=None):
-    return ClassifierConv1x1Fn.apply(x, weight, bias)
-
-
 def bn_fwd(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches_tracked, amax=None):
     """Single-rank training forward (2 launches): -> (y, mean_invstd [C,2]). amax: zeroed word that receives max|y|."""
     B, C, HW = _bn_dims(x)

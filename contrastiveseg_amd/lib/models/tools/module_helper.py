@@ -111,21 +111,6 @@ class Conv1x1(nn.Conv2d):
         return super(Conv1x1, self).forward(x)
 
 
-class ClassifierConv1x1(nn.Conv2d):
-    """nn.Conv2d(cin, num_classes, 1) -- the last layer of a segmentation head (reference lib/models/nets/hrnet.py:72-77): same parameters
-    and state_dict. On the GPU in training its weight gradient runs on the split 1x1 kernel over a zero-padded output gradient
-    (kernels.ClassifierConv1x1Fn); forward and backward-data are the reference's GEMMs."""
-
-    def __init__(self, cin, num_classes, bias=True):
-        super(ClassifierConv1x1, self).__init__(cin, num_classes, kernel_size=1, stride=1, padding=0, bias=bias)
-
-    def forward(self, x):
-        from contrastiveseg_amd import kernels as K
-        if self.training and torch.is_grad_enabled() and self.weight.requires_grad and K.classifier_wrw_eligible(x, self.weight):
-            return K.classifier_conv1x1(x, self.weight, self.bias)
-        return super(ClassifierConv1x1, self).forward(x)
-
-
 class SplitConv2d(nn.Conv2d):
     """nn.Conv2d (same constructor, parameters, initialisation and state_dict) for the 1x1 and plain 3x3 convolutions OUTSIDE the HRNet
     branches (round 5): the bottleneck 1x1 layers and the deep stem of the ResNet encoders, ASPP's 1x1 branch and 3x3 projection,
