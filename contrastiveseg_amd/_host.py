@@ -29,17 +29,21 @@ def lib():
     return _lib
 
 
-def randperm_prefixes(n_list, keep):
+def randperm_prefixes(n_list, keep, flat=False):
     """For every i: the first keep[i] entries of torch.randperm(n_list[i]), drawn in order from the default CPU
-    generator (n_list[i]-1 draws each, also when keep[i] == 0). Returns a list of int64 arrays."""
+    generator (n_list[i]-1 draws each, also when keep[i] == 0). Returns a list of int64 arrays (flat: ONE array, the prefixes
+    back to back)."""
     n_list = np.ascontiguousarray(n_list, dtype=np.int64)
     keep = np.ascontiguousarray(keep, dtype=np.int64)
     h = lib()
     if h is None:
-        return [torch.randperm(int(n)).numpy()[:int(k)] for n, k in zip(n_list, keep)]
+        parts = [torch.randperm(int(n)).numpy()[:int(k)] for n, k in zip(n_list, keep)]
+        return (np.concatenate(parts) if parts else np.empty(0, dtype=np.int64)) if flat else parts
     out = np.empty(int(keep.sum()), dtype=np.int64)
     ok = h.cseg_host_randperm_prefixes(n_list.ctypes.data_as(ctypes.c_void_p), keep.ctypes.data_as(ctypes.c_void_p),
                                        len(n_list), out.ctypes.data_as(ctypes.c_void_p))
     if ok != 1:
         raise RuntimeError("cseg_host_randperm_prefixes failed")
+    if flat:
+        return out
     return np.split(out, np.cumsum(keep)[:-1]) if len(keep) else []
