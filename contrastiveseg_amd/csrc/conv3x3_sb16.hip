@@ -1106,6 +1106,237 @@ __global__ __launch_bounds__(512, 1) void conv3x3_sb8_kernel(const float* __rest
 
 constexpr size_t lds_bytes() { return sizeof(uint4) * (2 * 2 * PLANE8 + 2 * NT * 2 * 64) + sizeof(float) * RAW_FLOATS; }      // 122 112
 
+// ---- round 6, version 2 of the head kernel: the same tile, packed weights, LDS images and arithmetic (bit-identical results), with
+// the three things taken out of the K-step that kept the matrix pipe idle at every one of its 225 barriers (both waves of a SIMD run
+// the same code in the same phase, so whatever one of them does between two MFMA groups the other does too):
+//   (1) the fragments of the NEXT K-step are in registers before the barrier: the weight stages form a ring of three (the stage of
+//       K-step ks + 1 landed one barrier earlier, so its first fragment pair may be read during K-step ks) and the patch image does not
+//       change inside a chunk -- one patch fragment of the next tap rides with each MFMA group, the next weight pair with the last.
+//       Before: ten ds_read_b128 per wave right after every barrier = 80 KB through the CU's LDS port with nothing to multiply;
+//   (2) inside a K-step the weight pair of group nt + 1 is requested before the MFMAs of group nt (two register pairs);
+//   (3) the raw-patch DMA addresses: the 20 (channel, row) line offsets of a wave are the same for every chunk -- computed once (SGPRs)
+//       instead of ~50 scalar instructions per line (64-bit divisions by 10) at the top of every K-step; the five K-steps of a chunk are
+//       unrolled so that line, tap and register-set indices are compile-time constants.
+// LDS: pieces 43 008 + 3 weight stages 55 296 + raw 42 240 + item geometry 6 144 = 146 688 bytes. CSEG_SB8_V=1 selects the version above.
+template <class AR>
+__global__ __launch_bounds__(512, 1) void conv3x3_sb8p_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
+                                                              const float* __restrict__ bias, int Cin, int Cout, int H, int W,
+                                                              int tiles_x, int tiles_y, const unsigned* __restrict__ amax_x,
+                                                              const unsigned* __restrict__ amax_w, float* __restrict__ y,
+                                                              float4* __restrict__ stats, int n_seg, int xmap) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_s8p[];
+    typedef typename AR::frag_t frag_t;
+    constexpr int NP = AR::NP;
+    constexpr int A_CELLS = NP * 2 * PLANE8;
+    constexpr int BSTEP = NT * NP * 64;
+    constexpr int LPW = RAW_LINES / 8;                         // raw lines per wave and chunk: 20
+    uint4* As = smem_s8p;                                      // [piece][octet 2][PLANE8]
+    uint4* Bs = smem_s8p + A_CELLS;                            // [3][BSTEP]
+    float* Raw = reinterpret_cast<float*>(Bs + 3 * BSTEP);     // [16 ch x 10 rows][64] + [16 ch x 10 rows][2]
+    const unsigned ex = split_amax_exp(amax_x), ew = split_amax_exp(amax_w);
+    const float xscale = split_scale_of(ex);
+
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int row = wave;
+    const int g = lane >> 4, n = lane & 15;
+    const int n_cot = Cout / (NT * 16);
+    const size_t plane = (size_t)H * W;
+    int t = cseg_xcd_block(blockIdx.x, gridDim.x, xmap);       // (block order: see conv3x3_sb8_kernel)
+    const bool cot_first = xmap && (gridDim.x & 7) == 0;
+    int cot = 0;
+    if (cot_first) { cot = t % n_cot; t /= n_cot; }
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    if (!cot_first) { cot = t % n_cot; t /= n_cot; }
+    const int b = t;
+    const int x0 = tx * C8, y0 = ty * R8;
+    const int n_chunks = Cin / 16;
+    const int n_steps = n_chunks * STEPS;
+    const uint4* wbase = wp + (size_t)cot * n_steps * BSTEP;
+
+    auto b_glds = [&](int ks, int stage) {
+#pragma unroll
+        for (int i = 0; i < (NT * NP + 7) / 8; ++i) {
+            const int r = wave + 8 * i;
+            if (r < NT * NP)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(wbase + (size_t)ks * BSTEP + r * 64 + lane),
+                    (__attribute__((address_space(3))) void*)(Bs + stage * BSTEP + r * 64), 16, 0, 0);
+        }
+    };
+
+    // raw patch by LDS-DMA, as in version 1; the element offset of this wave's line i inside a chunk is wave-uniform and constant
+    const int col_off = min(max(x0 - 1 + lane, 0), W - 1);
+    int raw_off[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        const int line = wave + 8 * i;
+        const int ch = line / XR, r = line - ch * XR;
+        raw_off[i] = __builtin_amdgcn_readfirstlane(ch * (int)plane + min(max(y0 - 1 + r, 0), H - 1) * W);
+    }
+    int extra_off;
+    {
+        const int line = min(32 * wave + (lane >> 1), RAW_LINES - 1), e = lane & 1;
+        const int ch = line / XR, r = line - ch * XR;
+        extra_off = ch * (int)plane + min(max(y0 - 1 + r, 0), H - 1) * W + min(max(x0 - 1 + 64 + e, 0), W - 1);
+    }
+    auto raw_line = [&](const float* xc, int i) {
+        const float* rp = xc + raw_off[i];         // wave-uniform; pinned to scalar registers so that the 20 per-lane sums raw_off[i] + col_off are
+#if defined(__AMDGCN__)                           // not hoisted out of the loop as 40 vector registers (they were, and spilled to scratch)
+        asm volatile("" : "+s"(rp));
+#endif
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rp + col_off),
+                                         (__attribute__((address_space(3))) void*)(Raw + 64 * (wave + 8 * i)), 4, 0, 0);
+    };
+    auto raw_extra = [&](const float* xc) {
+        if (wave < RAW_EXTRA / 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xc + extra_off),
+                                             (__attribute__((address_space(3))) void*)(Raw + RAW_MAIN + 64 * wave), 4, 0, 0);
+    };
+
+    // split phase: as in version 1, but an item's geometry (raw position, piece cell, flags) is a dword in LDS instead of five registers
+    // held across the MFMAs: bits 0..13 raw position of channel 0, 14..24 destination cell, 25 main part (channel stride 640, else 20),
+    // 26 the pixel lies inside the image. Items past S_ITEMS are not stored (the thread's third item may not exist).
+    unsigned* Geo = reinterpret_cast<unsigned*>(Raw + RAW_FLOATS);          // [S_U][512]
+#pragma unroll
+    for (int u = 0; u < S_U; ++u) {
+        const int item = tid + 512 * u, itc = min(item, S_ITEMS - 1);
+        const int oct = itc / CELLS8, cell = itc - oct * CELLS8;
+        const int r = cell / XC, c = cell - r * XC;
+        const int raw = c < 64 ? (oct * 8 * XR + r) * 64 + c : RAW_MAIN + (oct * 8 * XR + r) * 2 + (c - 64);
+        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        Geo[u * 512 + tid] = (unsigned)raw | ((unsigned)(oct * PLANE8 + cell) << 14) | (c < 64 ? 1u << 25 : 0u) | (in ? 1u << 26 : 0u);
+    }
+    auto split_phase = [&]() {
+#pragma unroll
+        for (int u = 0; u < S_U; ++u) {
+            if (tid + 512 * u < S_ITEMS) {
+                const unsigned geo = Geo[u * 512 + tid];
+                const int raw = geo & 0x3fff, dst = (geo >> 14) & 0x7ff, chs = (geo >> 25) & 1 ? XR * 64 : XR * 2;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = Raw[raw + j * chs];
+                uint4 cells[NP];
+                split_cells8_masked<AR>(v, (geo >> 26) & 1, xscale, cells);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) As[p * 2 * PLANE8 + dst] = cells[p];
+            }
+        }
+    };
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane cell offset of K-step s of a chunk: lanes g = 0, 1 read tap 2 s, lanes g = 2, 3 tap 2 s + 1 (the tenth slot: zero weights).
+    // Two compile-time constants per K-step and one select (not five registers held across the MFMAs).
+    const bool tap_hi = (g >> 1) != 0;
+    auto a_off = [&](int s) {
+        const int t0 = 2 * s, t1 = min(2 * s + 1, 8);
+        return tap_hi ? (t1 / 3) * XC + (t1 % 3) : (t0 / 3) * XC + (t0 % 3);
+    };
+    const uint4* a_lane = As + (g & 1) * PLANE8 + row * XC + n;
+    const uint4* b_lane = Bs + lane;
+
+    frag_t a[2][4][NP];            // patch fragments of this K-step (set s & 1) and of the next
+    frag_t bf[2][NP];              // weight fragments of this group and of the next
+    int st = 0;                    // ring stage of the K-step about to run
+
+    auto fresh = [&]() {           // first K-step of a chunk: nothing could be read ahead (the split phase has just rewritten the pieces)
+        const uint4* ap = a_lane + a_off(0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) a[0][mt][p] = __builtin_bit_cast(frag_t, ap[p * 2 * PLANE8 + 16 * mt]);
+        const uint4* bp = b_lane + st * BSTEP;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) bf[0][p] = __builtin_bit_cast(frag_t, bp[p * 64]);
+    };
+
+    const float* xc = x + (size_t)b * Cin * plane;             // chunk 0 of this image
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) raw_line(xc, i);
+    raw_extra(xc);
+    b_glds(0, 0);
+    b_glds(1, 1);                                              // (n_steps >= 5)
+    __syncthreads();                                           // (the fence of the barrier waits for this wave's DMA; the barrier for everyone's)
+    split_phase();
+    __syncthreads();
+    fresh();
+
+    int ks = 0;
+#pragma unroll 1
+    for (int c = 0; c < n_chunks; ++c) {
+        const bool more = c + 1 < n_chunks;
+        const float* xn = xc + 16 * plane;                     // next chunk's raw patch
+        auto kstep = [&](auto S_) {
+            constexpr int S = decltype(S_)::value;
+            constexpr int P0 = S & 1;
+            constexpr bool PF = S + 1 < STEPS;
+            const int st1 = st == 2 ? 0 : st + 1, st2 = st1 == 2 ? 0 : st1 + 1;
+            const uint4* bp = b_lane + st * BSTEP;
+            const uint4* bpn = b_lane + st1 * BSTEP;
+            const uint4* apn = a_lane + a_off(PF ? S + 1 : S);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int cur = (P0 + nt) & 1;
+                if (nt + 1 < NT) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) bf[cur ^ 1][p] = __builtin_bit_cast(frag_t, bp[((nt + 1) * NP + p) * 64]);
+                } else if (PF) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) bf[cur ^ 1][p] = __builtin_bit_cast(frag_t, bpn[p * 64]);
+                }
+                if (PF && nt < 4 * NP)
+                    a[P0 ^ 1][nt / NP][nt % NP] = __builtin_bit_cast(frag_t, apn[(nt % NP) * 2 * PLANE8 + 16 * (nt / NP)]);
+                if (nt == 1) {                                 // DMA issue under the first MFMA groups: stage ks + 2, a fifth of the next raw patch
+                    if (ks + 2 < n_steps) b_glds(ks + 2, st2);
+                    if (more) {
+#pragma unroll
+                        for (int j = 0; j < LPW / STEPS; ++j) raw_line(xn, S + STEPS * j);
+                        if (S == 0) raw_extra(xn);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tt = 0; tt < AR::NTERMS; ++tt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = AR::mfma(a[P0][mt][AR::ta(tt)], bf[cur][AR::tb(tt)], acc[mt][nt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            st = st1;
+            ++ks;
+        };
+        kstep(std::integral_constant<int, 0>());
+        kstep(std::integral_constant<int, 1>());
+        kstep(std::integral_constant<int, 2>());
+        kstep(std::integral_constant<int, 3>());
+        kstep(std::integral_constant<int, 4>());
+        if (more) {
+            split_phase();                         // raw chunk c + 1 landed before the last barrier (its fence waited for the DMA)
+            __syncthreads();
+            fresh();
+        }
+        xc = xn;
+    }
+
+    float* ybc = y + (size_t)b * Cout * plane;
+    const int co0 = cot * NT * 16;
+    const float unscale = split_unscale_of(ex) * split_unscale_of(ew);
+    if (y0 + row < H) {
+        store8(acc, ybc, bias, co0, plane, y0 + row, x0, W, g, n, unscale);
+        if (stats)
+            cseg_stats_emit<NT, NT>(acc, bias, co0, unscale, x0, W, g, n,
+                                    stats + (size_t)co0 * n_seg + ((size_t)b * H + y0 + row) * tiles_x + tx, n_seg);
+    }
+}
+
+constexpr size_t lds_bytes_p() { return sizeof(uint4) * (2 * 2 * PLANE8 + 3 * NT * 2 * 64) + sizeof(float) * RAW_FLOATS + sizeof(unsigned) * S_U * 512; }    // 146 688
+
 }  // namespace sb8
 
 // Reached from the cseg_conv3x3_sb_* / cseg_conv3x3_split_* entry points of conv3x3_sb.hip (NT = 3, 4, 6; 9 = the 8-row head kernel).
@@ -1207,6 +1438,27 @@ int fwd8(const float* x, const void* wp, const float* bias, int B, int Cin, int 
     CSEG_REQUIRE(arith == CSEG_ARITH_F16X3 && amax_x && amax_w, "conv3x3_sb8: f16x3 only (needs max|x| and max|w|)");
     CSEG_REQUIRE(Cout % 144 == 0 && Cin % 16 == 0 && (long)H * W * 16 * 4 < 2147483647L,
                  "conv3x3_sb8: unsupported shape Cin=%d Cout=%d %dx%d (needs Cout %% 144, Cin %% 16)", Cin, Cout, H, W);
+    const char* ver = getenv("CSEG_SB8_V");          // (read per call: tests switch it inside one process)
+    const int version = ver ? atoi(ver) : 2;
+    const int tiles_x = (W + sb8::C8 - 1) / sb8::C8, tiles_y = (H + sb8::R8 - 1) / sb8::R8;
+    const long n_tiles = (long)B * (Cout / 144) * tiles_y * tiles_x;
+    CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb8: grid too large");
+    if (version != 1) {
+        const size_t lds = sb8::lds_bytes_p();
+        static bool attr_set_p = false;
+        if (!attr_set_p) {
+            if (hipFuncSetAttribute((const void*)sb8::conv3x3_sb8p_kernel<SplitF16x3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+                hipSuccess) {
+                cseg_set_error("conv3x3_sb8p: cannot raise dynamic LDS to %zu bytes", lds);
+                return 0;
+            }
+            attr_set_p = true;
+        }
+        hipLaunchKernelGGL(sb8::conv3x3_sb8p_kernel<SplitF16x3>, dim3((unsigned)n_tiles), dim3(512), lds, stream, x, (const uint4*)wp, bias, Cin,
+                           Cout, H, W, tiles_x, tiles_y, amax_x, amax_w, y, stats, B * H * tiles_x, cseg_xcd_remap());
+        CSEG_CHECK_LAUNCH("conv3x3_sb8p_kernel");
+        return 1;
+    }
     const size_t lds = sb8::lds_bytes();
     static bool attr_set = false;
     if (!attr_set) {
@@ -1217,9 +1469,6 @@ int fwd8(const float* x, const void* wp, const float* bias, int B, int Cin, int 
         }
         attr_set = true;
     }
-    const int tiles_x = (W + sb8::C8 - 1) / sb8::C8, tiles_y = (H + sb8::R8 - 1) / sb8::R8;
-    const long n_tiles = (long)B * (Cout / 144) * tiles_y * tiles_x;
-    CSEG_REQUIRE(n_tiles < 2147483647L, "conv3x3_sb8: grid too large");
     hipLaunchKernelGGL(sb8::conv3x3_sb8_kernel<SplitF16x3>, dim3((unsigned)n_tiles), dim3(512), lds, stream, x, (const uint4*)wp, bias, Cin,
                        Cout, H, W, tiles_x, tiles_y, amax_x, amax_w, y, stats, B * H * tiles_x, cseg_xcd_remap());
     CSEG_CHECK_LAUNCH("conv3x3_sb8_kernel");

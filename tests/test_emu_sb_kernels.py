@@ -420,6 +420,24 @@ def test_head_kernel_8_rows(case, wave_order):
     assert np.abs(dx - ref).max() <= 3e-6 * np.sqrt(9 * 144) * float(np.abs(ref).max())
 
 
+@pytest.mark.parametrize("case", [(1, 48, 144, 9, 68), (2, 32, 288, 8, 64)])
+def test_head_kernel_version_2_is_bit_identical_to_version_1(case, wave_order, monkeypatch, tmp_path):
+    """conv3x3_sb8p_kernel (round 6: weight stages as a ring of three, the next K-step's fragments read before the barrier, raw-patch
+    line offsets computed once) against conv3x3_sb8_kernel (CSEG_SB8_V=1): same packed weights, K-steps and accumulation order, so
+    the outputs must agree to the last bit -- three / two chunks (the read-ahead crosses K-steps but never a chunk boundary)."""
+    B, ci, co, H, W = case
+    x, w, b = _rand((B, ci, H, W), 191, 3.0), _rand((co, ci, 3, 3), 192, 0.1), _rand((co,), 193)
+    trace = tmp_path / "launches.txt"
+    monkeypatch.setenv("CSEG_EMU_TRACE", str(trace))
+    y2 = E.conv3x3_sb(x, w, bias=b, nt=NT_SB8, arith=E.F16X3)
+    assert "conv3x3_sb8p_kernel<" in trace.read_text()
+    monkeypatch.setenv("CSEG_SB8_V", "1")
+    y1 = E.conv3x3_sb(x, w, bias=b, nt=NT_SB8, arith=E.F16X3)
+    assert "conv3x3_sb8_kernel<" in trace.read_text()
+    assert not np.isnan(y2).any()
+    assert np.array_equal(y1, y2)
+
+
 @pytest.mark.parametrize("arith", ARITHS)
 @pytest.mark.parametrize("case", [(1, 48, 48, 6, 68), (2, 16, 96, 4, 64), (1, 64, 64, 5, 20), (1, 32, 192, 3, 36)])
 def test_epilogue_addend(case, arith, wave_order):
@@ -467,7 +485,7 @@ def test_eight_row_tiles_are_bit_identical_to_the_four_row_kernels(case, what, m
 @pytest.mark.parametrize("case,nt,kernel,what", [
     ((2, 32, 96, 8, 128), 0, "conv3x3_sb_kernel", "6 channel tiles: 2 images x 2 row tiles x 2 column tiles = 8 blocks"),
     ((1, 32, 64, 30, 72), 0, "conv3x3_sb16_kernel", "4 channel tiles: 8 row tiles x 2 column tiles = 16 blocks, ragged"),
-    ((2, 16, 288, 9, 68), NT_SB8, "conv3x3_sb8_kernel", "head kernel: 2 images x 2 channel tile groups x 2 x 2 tiles = 16 blocks, ragged"),
+    ((2, 16, 288, 9, 68), NT_SB8, "conv3x3_sb8p_kernel", "head kernel: 2 images x 2 channel tile groups x 2 x 2 tiles = 16 blocks, ragged"),
     ((1, 32, 96, 12, 64), 0, "conv3x3_sb_kernel", "3 blocks: not a multiple of 8, the remap must be the identity"),
 ])
 def test_xcd_block_order_is_a_permutation(case, nt, kernel, what, monkeypatch, tmp_path):

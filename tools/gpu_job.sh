@@ -14,6 +14,7 @@
 #   probe:<args>     tools/probes/conv_probe with the given arguments (';' separates arguments)
 #   gprobe:<args>    tools/probes/group_probe (grouped launches vs the one-layer launches they replace; ';' separates arguments)
 #   gpmc:<ctrs>|<args>  the same probe under rocprofv3 --pmc <ctrs> (comma separated) -> gpmc_summary.csv (per-kernel averages)
+#   py:<script,args> any python script of tools/ (comma-separated arguments), output kept as py_<script>.txt
 #   host             tools/host_profile.py 8
 #   contrast         tools/contrast_probe.py under rocprofv3 --kernel-trace --stats: fused vs three-launch contrastive forward
 export TMPDIR=/tmp
@@ -52,6 +53,7 @@ for step in "$@"; do
       echo "under rocprof: $MS ms/step"
       python tools/trace_window_stats.py $T $(python -c "print(5*$MS/1000.0)") > $O/step_steady_kernel_stats.csv 2> $O/window.txt; cat $O/window.txt
       python tools/trace_gaps.py $T $(python -c "print(3*$MS/1000.0)") 30 > $O/step_trace_gaps.txt; head -12 $O/step_trace_gaps.txt | cut -c1-200
+      [ -n "$CSEG_KEEP_TRACE" ] && gzip -c $T > $O/kernel_trace.csv.gz          # (env:CSEG_KEEP_TRACE=1: the raw dispatch list, ~1 MB, for timeline questions)
       rm -rf $O/trace ;;
     pmc)
       cd /tmp
@@ -97,6 +99,7 @@ for step in "$@"; do
       st=$(find $O/ctrace -name "*kernel_stats.csv" | head -1)
       [ -n "$st" ] && grep -E "Name|s_gemm|row_pass|mean_kernel|contrast_fused" $st | cut -c1-220 > $O/contrast_fused_kernels.txt; cat $O/contrast_fused_kernels.txt
       rm -rf $O/ctrace ;;
+    py) a=${arg//,/ }; timeout 600 python $a 2>&1 | tee $O/py_$(basename ${a%% *} .py).txt | cut -c1-1500 | tail -20 ;;
     host) a=${arg//,/ }; [ -z "$a" ] && a=8
       timeout 200 python tools/host_profile.py $a > $O/host_profile_${a// /_}.txt 2>&1; grep "host enqueue" $O/host_profile_${a// /_}.txt ;;
     *) echo "unknown step $step" ;;
