@@ -267,6 +267,23 @@ def kernel_rooflines(device, B, K=19, H=512, W=1024, stride=4, D=256):
                   time_kernel(lambda: torch.autograd.grad(y2, (x, r), gy, retain_graph=True)), bytes_=7 * nb)
             del y2
         del bn, x, r, y, gy
+    # the classifier (720 -> K, csrc/cls1x1.hip): three streams over the 720-channel activation; algorithmic bytes = the wide tensor once
+    # (+ the K-channel tensor), DESIGN.md section 13.13
+    xc = torch.randn(B, 720, h, w, generator=g).relu_().to(device).requires_grad_(True)
+    wc = (torch.randn(K, 720, 1, 1, generator=g) / 720 ** 0.5).to(device).requires_grad_(True)
+    mk = (torch.rand(B, 720, 1, 1, generator=g) > 0.1).float().div_(0.9).to(device)
+    wide, narrow = xc.numel() * 4, B * K * P * 4
+    if Kn.cls1x1_eligible(xc, wc):
+        wtc = Kn.cls1x1_weights(wc, B, mk).detach().requires_grad_(True)
+        entry("cls1x1_fwd 720->%d" % K, time_kernel(lambda: Kn.Cls1x1.apply(xc, wtc, None, K)), bytes_=wide + narrow)
+        yc = Kn.Cls1x1.apply(xc, wtc, None, K)
+        gc = torch.randn_like(yc)
+        entry("cls1x1_bwd 720->%d (backward-data)" % K, time_kernel(lambda: torch.autograd.grad(yc, xc, gc, retain_graph=True)),
+              bytes_=wide + narrow)
+        entry("cls1x1_wrw 720->%d (weight gradient)" % K, time_kernel(lambda: torch.autograd.grad(yc, wtc, gc, retain_graph=True)),
+              bytes_=wide + narrow)
+        del wtc, yc, gc
+    del xc, wc, mk
     # the head's 3x3 convolution in the current split arithmetic (forward = backward-data): fp32-equivalent flops vs 2500 / k TF/s
     C = 720
     xh = torch.randn(B, C, h, w, device=device)

@@ -117,6 +117,10 @@ SIGNATURES = {
     "cseg_conv3x3_s2_rgb_fwd": (_c_int, [_ptr, _ptr] + [_c_int] * 4 + [_ptr, _ptr]),
     "cseg_conv3x3_s2_rgb_wrw_ws_floats": (ctypes.c_size_t, [_c_int] * 4),
     "cseg_conv3x3_s2_rgb_wrw": (_c_int, [_ptr, _ptr] + [_c_int] * 4 + [_ptr, _ptr, _ptr]),
+    "cseg_cls1x1_fwd": (_c_int, [_ptr, _ptr, _ptr] + [_c_int] * 4 + [ctypes.c_long, _ptr, _ptr]),
+    "cseg_cls1x1_bwd": (_c_int, [_ptr, _ptr] + [_c_int] * 4 + [ctypes.c_long, _ptr, _ptr]),
+    "cseg_cls1x1_wrw_ws_floats": (ctypes.c_size_t, [_c_int, _c_int, _c_int, ctypes.c_long]),
+    "cseg_cls1x1_wrw": (_c_int, [_ptr, _ptr] + [_c_int] * 4 + [ctypes.c_long, _ptr, _ptr, _ptr]),
     "cseg_conv3x3_s2_wrw_ws_floats": (ctypes.c_size_t, [_c_int] * 5),
     "cseg_conv3x3_s2_split_wrw": (_c_int, [_ptr, _ptr] + [_c_int] * 6 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_conv1x1_split_packed_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int]),

@@ -2146,6 +2146,83 @@ def conv3x3_s2_rgb(x, weight):
 
 
 # ----------------------------------------------------------------------------------------------------------
+# The classifier convolution (csrc/cls1x1.hip, round 6): 1x1 onto K <= 32 output channels from a wide activation, with the channel
+# dropout in front of it folded into per-image weights. Reference: the tail of `cls_head`, lib/models/nets/hrnet.py:73-80
+# (BNReLU -> nn.Dropout2d(0.10) -> nn.Conv2d(720, num_classes, 1)); there a dropout pass over the 755 MB activation forward and
+# backward, and a library GEMM with 19 columns each way (rocBLAS 0.40 + 0.26 ms, MIOpen's NHWC weight gradient + two transposes 0.54 ms).
+# ----------------------------------------------------------------------------------------------------------
+CLS1X1 = os.environ.get("CSEG_CLS1X1", "1") == "1"
+CLS1X1_MAX_K = 32
+
+
+def cls1x1_eligible(x, weight):
+    """NCHW fp32 on the GPU, a 1x1 kernel with at most 32 output channels."""
+    return (CLS1X1 and _on_device(x) and x.dtype == F32 and weight.dtype == F32 and x.dim() == 4 and weight.dim() == 4
+            and tuple(weight.shape[2:]) == (1, 1) and weight.shape[0] <= CLS1X1_MAX_K and weight.shape[1] == x.shape[1])
+
+
+def cls1x1_kp(k):
+    return 20 if k <= 20 else 32
+
+
+class Cls1x1(Function):
+    """y [B,K,H,W] = bias + sum_c wt[b][c][k] x[b][c]; wt [B, C, KP] (kernels.cls1x1_weights) carries the transposed, padded and
+    channel-masked weights, and receives its gradient in the same layout (autograd takes it back to the [K, C, 1, 1] parameter)."""
+
+    @staticmethod
+    def forward(ctx, x, wt, bias, K_):
+        x, wt = x.contiguous(), wt.contiguous()
+        B, C, H, W = x.shape
+        KP = wt.shape[2]
+        y = torch.empty(B, K_, H, W, dtype=F32, device=x.device)
+        _hip.call("cseg_cls1x1_fwd", _p(x, F32, "x"), _p(wt, F32, "wt"), _opt(bias, F32, "bias"), B, C, K_, KP, ctypes.c_long(H * W),
+                  _pf(y), _hip.stream_ptr())
+        ctx.save_for_backward(x, wt)
+        ctx.K = K_
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wt = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, C, H, W = x.shape
+        K_, KP, P = ctx.K, wt.shape[2], H * W
+        dx = dwt = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _hip.call("cseg_cls1x1_bwd", _p(dy, F32, "dy"), _p(wt, F32, "wt"), B, C, K_, KP, ctypes.c_long(P), _pf(dx), _hip.stream_ptr())
+        if ctx.needs_input_grad[1]:
+            n = _hip.lib().cseg_cls1x1_wrw_ws_floats(B, C, KP, ctypes.c_long(P))
+            if n == 0:
+                raise RuntimeError("cls1x1_wrw: unsupported shape %s x %s" % (tuple(x.shape), tuple(dy.shape)))
+            ws = torch.empty(n, dtype=F32, device=x.device)
+            dwt = torch.empty(B, C, KP, dtype=F32, device=x.device)
+            _hip.call("cseg_cls1x1_wrw", _p(x, F32, "x"), _p(dy, F32, "dy"), B, C, K_, KP, ctypes.c_long(P), _pf(ws), _pf(dwt),
+                      _hip.stream_ptr())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 2, 3))
+        return dx, dwt, db, None
+
+
+def cls1x1_weights(weight, B, mask=None):
+    """[K, C, 1, 1] parameter -> wt [B, C, KP]: transposed, zero-padded to KP columns, times the channel mask [B, C] of a folded
+    Dropout2d (entries 0 or 1 / (1 - p)) when there is one. A few small tensor operations on 19 x 720 numbers, differentiable."""
+    K_, C = weight.shape[:2]
+    KP = cls1x1_kp(K_)
+    w2 = weight.reshape(K_, C).t()
+    if KP > K_:
+        w2 = torch.nn.functional.pad(w2, (0, KP - K_))
+    if mask is None:
+        return w2.unsqueeze(0).expand(B, C, KP).contiguous()
+    return w2.unsqueeze(0) * mask.reshape(B, C, 1)
+
+
+def cls1x1(x, weight, bias=None, mask=None):
+    return Cls1x1.apply(x, cls1x1_weights(weight, x.shape[0], mask), bias, weight.shape[0])
+
+
+# ----------------------------------------------------------------------------------------------------------
 # 1x1 convolution on the BF16 matrix cores with split operands (csrc/conv1x1_sb.hip): first hardware run pending -> opt-in
 # ----------------------------------------------------------------------------------------------------------
 CONV1X1_SPLIT_BF16 = os.environ.get("CSEG_CONV1X1_SPLIT_BF16", "1") == "1"

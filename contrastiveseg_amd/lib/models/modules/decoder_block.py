@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from contrastiveseg_amd.lib.models.tools.module_helper import ModuleHelper, SplitConv2d
+from contrastiveseg_amd.lib.models.tools.module_helper import ClassifierConv1x1, ModuleHelper, SplitConv2d
 
 
 def _branch(cin, cout, k, rate, bn_type):
@@ -44,11 +44,11 @@ class DeepLabHead(nn.Module):
         super(DeepLabHead, self).__init__()
         self.layer_dsn = nn.Sequential(SplitConv2d(in_channels[0], 256, kernel_size=3, stride=1, padding=1),
                                        ModuleHelper.BNReLU(256, bn_type=bn_type),
-                                       nn.Conv2d(256, num_classes, kernel_size=1, stride=1, padding=0, bias=True))
+                                       ClassifierConv1x1(256, num_classes, kernel_size=1, stride=1, padding=0, bias=True))
         self.layer_aspp = ASPPModule(in_channels[1], 512, bn_type=bn_type)
         self.refine = nn.Sequential(SplitConv2d(512, 512, kernel_size=3, padding=1, stride=1, bias=False),
                                     ModuleHelper.BatchNorm2d(bn_type=bn_type)(512),
-                                    nn.Conv2d(512, num_classes, kernel_size=1, stride=1, bias=True))
+                                    ClassifierConv1x1(512, num_classes, kernel_size=1, stride=1, bias=True))
 
     def forward(self, x):
         x_dsn = self.layer_dsn(x[2])

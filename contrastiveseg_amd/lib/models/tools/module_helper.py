@@ -93,6 +93,47 @@ class HeadConv3x3(nn.Conv2d):
         return super(HeadConv3x3, self).forward(x)
 
 
+class ClassifierConv1x1(nn.Conv2d):
+    """nn.Conv2d(cin, num_classes, 1) (same parameters / state_dict): the classifier at the end of `cls_head` / the auxiliary head
+    (reference lib/models/nets/hrnet.py:73-80, :113-131). Up to 32 classes on the GPU: the three fp32 streaming kernels of
+    csrc/cls1x1.hip (kernels.cls1x1) instead of library GEMMs with 19 columns; a channel mask left on the input by FoldedDropout2d is
+    folded into the weights. Anything else (more classes, CPU) is the reference's convolution -- with the mask applied first."""
+
+    def forward(self, x):
+        from contrastiveseg_amd import kernels as K
+        fold = getattr(x, '_cseg_drop_mask', None)
+        mask = fold[0] if fold is not None and fold[1] == x._version else None
+        if (K.cls1x1_eligible(x, self.weight) and self.stride == (1, 1) and self.padding == (0, 0) and self.dilation == (1, 1)
+                and self.groups == 1):
+            return K.cls1x1(x, self.weight, self.bias, mask)
+        if mask is not None:
+            x = x * mask
+        return super(ClassifierConv1x1, self).forward(x)
+
+
+class FoldedDropout2d(nn.Dropout2d):
+    """nn.Dropout2d in front of a ClassifierConv1x1 (`consumer`): in training it draws the channel mask exactly as F.dropout2d does
+    (aten/src/ATen/native/Dropout.cpp, feature noise: `input.new_empty([B, C, 1, 1]).bernoulli_(1 - p).div_(1 - p)` -- the same
+    generator draws, so a run stays comparable with the reference's) but does NOT multiply the activation: the mask travels with the
+    tensor and the classifier multiplies its 19 x 720 weights instead (one read + one write of the 755 MB activation less, forward
+    and backward). Where the classifier's fast path does not apply this is nn.Dropout2d."""
+
+    def __init__(self, p, consumer):
+        super(FoldedDropout2d, self).__init__(p)
+        self._consumer = (consumer,)               # (a tuple: not registered as a sub-module -- the Sequential already owns it)
+
+    def forward(self, x):
+        from contrastiveseg_amd import kernels as K
+        conv = self._consumer[0]
+        if (not self.training or self.inplace or not 0.0 < self.p < 1.0 or x.dim() != 4 or not isinstance(conv, ClassifierConv1x1)
+                or not K.cls1x1_eligible(x, conv.weight)):
+            return super(FoldedDropout2d, self).forward(x)
+        mask = x.new_empty((x.shape[0], x.shape[1], 1, 1)).bernoulli_(1 - self.p).div_(1 - self.p)
+        out = x.view_as(x)                         # a new tensor object for the attribute; the values are untouched
+        out._cseg_drop_mask = (mask, out._version)
+        return out
+
+
 class Conv1x1(nn.Conv2d):
     """nn.Conv2d(cin, cout, 1) (same parameters / state_dict). With kernels.CONV1X1_SPLIT_BF16 on, forward and
     backward-data of the shapes the split-bf16 kernel covers (csrc/conv1x1_sb.hip) run there -- and the weight gradient

@@ -547,6 +547,24 @@ size_t cseg_conv3x3_s2_rgb_wrw_ws_floats(int B, int Cout, int H, int W);
 int cseg_conv3x3_s2_rgb_wrw(const float* x, const float* dy, int B, int Cout, int H, int W, float* ws, float* dw, cseg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Round 6 (ABI 6): the CLASSIFIER convolution -- a 1x1 convolution onto K <= 32 output channels (num_classes) from a wide activation:
+ * the last layer of `cls_head`, reference lib/models/nets/hrnet.py:73-80 (nn.Conv2d(720, num_classes, 1) behind BNReLU +
+ * nn.Dropout2d(0.10)) and :113-131 (the OCR classifier), which the reference runs as a library GEMM. Three fp32 streams over the wide
+ * tensor (csrc/cls1x1.hip), fixed summation order. The weights are PER IMAGE, transposed and padded:
+ *   wt [B][C][KP], KP = 20 or 32 >= K, wt[b][c][k] = w[k][c] * m[b][c] for k < K and 0 for k >= K,
+ * m = the channel mask of the Dropout2d in front of the classifier (1 without dropout): the mask is folded into 19 x 720 numbers per
+ * image instead of a pass over the 755 MB activation. P = H * W; x / dx [B,C,P], y / dy [B,K,P] (NCHW, contiguous), bias [K] or NULL.
+ *   fwd  y[b][k][p]   = bias[k] + sum_c wt[b][c][k] x[b][c][p]
+ *   bwd  dx[b][c][p]  = sum_k wt[b][c][k] dy[b][k][p]
+ *   wrw  dwt[b][c][k] = sum_p x[b][c][p] dy[b][k][p]       (dwt [B][C][KP]; ws: cseg_cls1x1_wrw_ws_floats(B, C, KP, P) floats, 0 = unsupported)
+ * ------------------------------------------------------------------------------------------------ */
+int cseg_cls1x1_fwd(const float* x, const float* wt, const float* bias, int B, int C, int K, int KP, long P, float* y,
+                    cseg_stream_t stream);
+int cseg_cls1x1_bwd(const float* dy, const float* wt, int B, int C, int K, int KP, long P, float* dx, cseg_stream_t stream);
+size_t cseg_cls1x1_wrw_ws_floats(int B, int C, int KP, long P);
+int cseg_cls1x1_wrw(const float* x, const float* dy, int B, int C, int K, int KP, long P, float* ws, float* dwt, cseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * GPU data pipeline: random resize (cv2 INTER_CUBIC image / INTER_NEAREST label) -> random
  * crop -> horizontal flip -> brightness shift -> ToTensor + Normalize(div, mean, std) + label look-up + ReLabel(255,-1)
  * -> collate padding to the fixed input size, as ONE kernel over the output batch.  Replaces the per-sample CPU chain

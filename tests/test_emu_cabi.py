@@ -113,6 +113,19 @@ def test_upsample_concat_and_fuse_sum_match_torch(monkeypatch):
     _replay(monkeypatch, "test_gpu_kernels", "test_fuse_sum_relu_matches_torch", {})
 
 
+CLS = _cases("test_gpu_cls1x1", "test_classifier_with_folded_dropout_matches_the_reference_modules")
+
+
+@pytest.mark.parametrize("kw", CLS, ids=_ids(CLS))
+def test_classifier_with_folded_dropout_matches_the_reference_modules(kw, monkeypatch):
+    """csrc/cls1x1.hip (forward, backward-data, weight gradient) under module_helper.FoldedDropout2d + ClassifierConv1x1"""
+    _replay(monkeypatch, "test_gpu_cls1x1", "test_classifier_with_folded_dropout_matches_the_reference_modules", dict(kw, monkeypatch=monkeypatch))
+
+
+def test_classifier_eval_mode_and_fallbacks(monkeypatch):
+    _replay(monkeypatch, "test_gpu_cls1x1", "test_classifier_eval_mode_and_fallbacks", {"monkeypatch": monkeypatch})
+
+
 CE = _cases("test_gpu_kernels", "test_upsample_ce_matches_torch_and_oracle", lambda kw: kw["B"] * kw["H"] * kw["W"] <= 2 * 256 * 512)
 
 

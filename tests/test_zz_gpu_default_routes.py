@@ -260,7 +260,7 @@ def test_whole_step_timings_for_the_next_round():
 _FAMILIES = [("conv3x3_group", "c3g"), ("conv3x3_wrw2_group", "c3gwrw"), ("sb_wrw_reduce_group", "c3gwrw"), ("bn_group", "bng"),   # grouped launches (round 6)
              ("conv3x3_sb_wrw_s2", "s2"), ("conv3x3_s2_", "s2"),                                   # stride-2 kernels (round 3), before "conv3x3_sb_wrw"
              ("conv3x3_sb_kernel", "c3"), ("conv3x3_sb16_kernel", "c3"), ("conv3x3_sb16p_kernel", "c3"), ("conv3x3_sb16r_kernel", "c3"),
-             ("conv3x3_sb8_kernel", "c3"), ("conv3x3_sb_wrw", "c3wrw"),
+             ("conv3x3_sb8_kernel", "c3"), ("conv3x3_sb8p_kernel", "c3"), ("conv3x3_sb_wrw", "c3wrw"), ("cls1x1_", "cls"),
              ("sb_wrw_reduce", "c3wrw"), ("pack_batch", "pack"), ("amax_batch", "amax"),
              ("pack_weights", "pack"), ("conv1x1_sb", "c1"), ("sb_wrw1_reduce", "c1"), ("amax_kernel", "amax"),
              ("conv3x3_wrw_kernel", "f32wrw"), ("wrw_reduce_kernel", "f32wrw"), ("conv3x3_kernel", "f32conv"),
