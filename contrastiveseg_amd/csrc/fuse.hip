@@ -6,6 +6,7 @@
 // same-resolution term; coarse terms get the exact adjoint gather (cseg_bilinear.h) with the mask fused in.
 #include "cseg_common.h"
 #include "cseg_bilinear.h"
+#include "cseg_split.h"
 
 namespace {
 
@@ -17,50 +18,63 @@ struct FuseArgs {
     int C, h, w;
 };
 
+// `amax` (may be null): max|out| record for the split-operand convolutions of the next unit (cseg_amax_f32's format), accumulated while
+// the values are stored.
 template <bool VEC>
-__global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a, int relu, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a, int relu, float* __restrict__ out, unsigned* __restrict__ amax) {
     constexpr int V = VEC ? 4 : 1;
     const int c = blockIdx.y, b = blockIdx.z;
     const int wv = a.w / V;
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= a.h * wv) return;
-    const int y = e / wv, x = (e - y * wv) * V;
-    const size_t off = (((size_t)b * a.C + c) * a.h + y) * a.w + x;
-    float acc[V];
+    const bool live = e < a.h * wv;
+    float vmax = 0.f;
+    if (live) {
+        const int y = e / wv, x = (e - y * wv) * V;
+        const size_t off = (((size_t)b * a.C + c) * a.h + y) * a.w + x;
+        float acc[V];
 #pragma unroll
-    for (int t = 0; t < V; ++t) acc[t] = 0.f;
-    for (int s = 0; s < a.n_same; ++s) {
-        if (VEC) {
-            const float4 v = *reinterpret_cast<const float4*>(a.same[s] + off);
-            acc[0] += v.x; acc[1 % V] += v.y; acc[2 % V] += v.z; acc[3 % V] += v.w;
-        } else {
-            acc[0] += a.same[s][off];
+        for (int t = 0; t < V; ++t) acc[t] = 0.f;
+        for (int s = 0; s < a.n_same; ++s) {
+            if (VEC) {
+                const float4 v = *reinterpret_cast<const float4*>(a.same[s] + off);
+                acc[0] += v.x; acc[1 % V] += v.y; acc[2 % V] += v.z; acc[3 % V] += v.w;
+            } else {
+                acc[0] += a.same[s][off];
+            }
         }
-    }
-    for (int l = 0; l < a.n_low; ++l) {
-        const int hs = a.lh[l], ws = a.lw[l];
-        const float sy = ac_scale(hs, a.h), sx = ac_scale(ws, a.w);
-        const float fy = sy * (float)y;
-        const int y0 = (int)fy;
-        const int y1 = y0 + (y0 < hs - 1 ? 1 : 0);
-        const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
-        const float* r0 = a.low[l] + (((size_t)b * a.C + c) * hs + y0) * ws;
-        const float* r1 = a.low[l] + (((size_t)b * a.C + c) * hs + y1) * ws;
+        for (int l = 0; l < a.n_low; ++l) {
+            const int hs = a.lh[l], ws = a.lw[l];
+            const float sy = ac_scale(hs, a.h), sx = ac_scale(ws, a.w);
+            const float fy = sy * (float)y;
+            const int y0 = (int)fy;
+            const int y1 = y0 + (y0 < hs - 1 ? 1 : 0);
+            const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+            const float* r0 = a.low[l] + (((size_t)b * a.C + c) * hs + y0) * ws;
+            const float* r1 = a.low[l] + (((size_t)b * a.C + c) * hs + y1) * ws;
 #pragma unroll
-        for (int t = 0; t < V; ++t) {
-            const float fx = sx * (float)(x + t);
-            const int x0 = (int)fx;
-            const int x1 = x0 + (x0 < ws - 1 ? 1 : 0);
-            const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
-            acc[t] += ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+            for (int t = 0; t < V; ++t) {
+                const float fx = sx * (float)(x + t);
+                const int x0 = (int)fx;
+                const int x1 = x0 + (x0 < ws - 1 ? 1 : 0);
+                const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+                acc[t] += ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+            }
         }
-    }
-    if (relu) {
+        if (relu) {
 #pragma unroll
-        for (int t = 0; t < V; ++t) acc[t] = fmaxf(acc[t], 0.f);
+            for (int t = 0; t < V; ++t) acc[t] = fmaxf(acc[t], 0.f);
+        }
+        if (VEC) *reinterpret_cast<float4*>(out + off) = make_float4(acc[0], acc[1 % V], acc[2 % V], acc[3 % V]);
+        else out[off] = acc[0];
+#pragma unroll
+        for (int t = 0; t < V; ++t) vmax = fmaxf(vmax, fabsf(acc[t]));
     }
-    if (VEC) *reinterpret_cast<float4*>(out + off) = make_float4(acc[0], acc[1 % V], acc[2 % V], acc[3 % V]);
-    else out[off] = acc[0];
+    if (amax) {                                    // (block-uniform) one candidate per wave
+        unsigned bits = __builtin_bit_cast(unsigned, vmax);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o, 64));
+        if ((threadIdx.x & 63) == 0) amax_publish_block(bits, amax);
+    }
 }
 
 __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ d_out, const float* __restrict__ act,
@@ -82,9 +96,8 @@ __global__ __launch_bounds__(256) void relu_mask_tail_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int cseg_fuse_sum_fwd(const float* const* same, int n_same, const float* const* low, const int* low_h,
-                                 const int* low_w, int n_low, int B, int C, int h, int w, int relu, float* out,
-                                 cseg_stream_t stream_) {
+static int fuse_sum_fwd_impl(const float* const* same, int n_same, const float* const* low, const int* low_h, const int* low_w, int n_low,
+                             int B, int C, int h, int w, int relu, float* out, unsigned* amax, cseg_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CSEG_REQUIRE(n_same >= 0 && n_same <= 4 && n_low >= 0 && n_low <= 3 && n_same + n_low >= 1,
                  "fuse_sum: n_same=%d n_low=%d out of range", n_same, n_low);
@@ -101,13 +114,27 @@ extern "C" int cseg_fuse_sum_fwd(const float* const* same, int n_same, const flo
     }
     if (w % 4 == 0) {
         dim3 grid((h * (w / 4) + 255) / 256, C, B);
-        hipLaunchKernelGGL(fuse_sum_kernel<true>, grid, dim3(256), 0, stream, a, relu, out);
+        hipLaunchKernelGGL(fuse_sum_kernel<true>, grid, dim3(256), 0, stream, a, relu, out, amax);
     } else {
         dim3 grid((h * w + 255) / 256, C, B);
-        hipLaunchKernelGGL(fuse_sum_kernel<false>, grid, dim3(256), 0, stream, a, relu, out);
+        hipLaunchKernelGGL(fuse_sum_kernel<false>, grid, dim3(256), 0, stream, a, relu, out, amax);
     }
     CSEG_CHECK_LAUNCH("fuse_sum_kernel");
     return 1;
+}
+
+extern "C" int cseg_fuse_sum_fwd(const float* const* same, int n_same, const float* const* low, const int* low_h,
+                                 const int* low_w, int n_low, int B, int C, int h, int w, int relu, float* out,
+                                 cseg_stream_t stream) {
+    return fuse_sum_fwd_impl(same, n_same, low, low_h, low_w, n_low, B, C, h, w, relu, out, nullptr, stream);
+}
+
+// the same with max|out| accumulated into `amax` (a zeroed record of CSEG_AMAX_WORDS words, as cseg_amax_f32 fills it)
+extern "C" int cseg_fuse_sum_fwd_amax(const float* const* same, int n_same, const float* const* low, const int* low_h,
+                                      const int* low_w, int n_low, int B, int C, int h, int w, int relu, float* out,
+                                      unsigned* amax, cseg_stream_t stream) {
+    CSEG_REQUIRE(amax, "fuse_sum_fwd_amax: null record");
+    return fuse_sum_fwd_impl(same, n_same, low, low_h, low_w, n_low, B, C, h, w, relu, out, amax, stream);
 }
 
 extern "C" int cseg_fuse_sum_bwd(const float* d_out, const float* out_act, const int* low_h, const int* low_w, int n_low,

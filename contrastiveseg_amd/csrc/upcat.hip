@@ -4,6 +4,7 @@
 // backward is the exact adjoint written as a gather (no atomics => deterministic).
 #include "cseg_common.h"
 #include "cseg_bilinear.h"
+#include "cseg_split.h"
 
 namespace {
 
@@ -24,59 +25,73 @@ __device__ __forceinline__ void store_nt4(float* p, float a, float b, float c, f
     __builtin_nontemporal_store((v4f){a, b, c, d}, reinterpret_cast<v4f*>(p));
 }
 
-__global__ __launch_bounds__(256) void upcat_fwd_kernel(UpcatMaps m, int Ctot, int tiles_x, float* __restrict__ out) {
+// `amax` (may be null): max|out| record for the split-operand convolutions that read the result (cseg_amax_f32's format) -- accumulated
+// while the values are in registers instead of a second pass over the 755 MB tensor.
+__global__ __launch_bounds__(256) void upcat_fwd_kernel(UpcatMaps m, int Ctot, int tiles_x, float* __restrict__ out,
+                                                        unsigned* __restrict__ amax) {
     const int c = blockIdx.y, b = blockIdx.z;
     const int h0 = m.h[0], w0 = m.w[0];
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int x = (tx * 64 + (threadIdx.x & 63)) * 4;
     const int yb = ty * (4 * UP_ROWS) + (threadIdx.x >> 6) * UP_ROWS;
-    if (x >= w0 || yb >= h0) return;
-    int mi = 0;
+    const bool live = x < w0 && yb < h0;
+    float vmax = 0.f;
+    if (live) {
+        int mi = 0;
 #pragma unroll
-    for (int k = 1; k < 4; ++k) if (k < m.n && c >= m.coff[k]) mi = k;
-    const int cm = c - m.coff[mi];
-    float* orow = out + (((size_t)b * Ctot + c) * h0 + yb) * w0 + x;
-    if (mi == 0) {
-        const float* irow = m.x[0] + (((size_t)b * m.C[0] + cm) * h0 + yb) * w0 + x;
+        for (int k = 1; k < 4; ++k) if (k < m.n && c >= m.coff[k]) mi = k;
+        const int cm = c - m.coff[mi];
+        float* orow = out + (((size_t)b * Ctot + c) * h0 + yb) * w0 + x;
+        if (mi == 0) {
+            const float* irow = m.x[0] + (((size_t)b * m.C[0] + cm) * h0 + yb) * w0 + x;
 #pragma unroll
-        for (int r = 0; r < UP_ROWS; ++r) {
-            if (yb + r < h0) {
-                const float4 v = *reinterpret_cast<const float4*>(irow + (size_t)r * w0);
-                store_nt4(orow + (size_t)r * w0, v.x, v.y, v.z, v.w);
+            for (int r = 0; r < UP_ROWS; ++r) {
+                if (yb + r < h0) {
+                    const float4 v = *reinterpret_cast<const float4*>(irow + (size_t)r * w0);
+                    store_nt4(orow + (size_t)r * w0, v.x, v.y, v.z, v.w);
+                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                }
             }
-        }
-        return;
-    }
-    const int hs = m.h[mi], ws = m.w[mi];
-    const float sy = ac_scale(hs, h0), sx = ac_scale(ws, w0);
-    int x0[4], x1[4];
-    float lx1[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float fx = sx * (float)(x + t);
-        x0[t] = (int)fx;
-        x1[t] = x0[t] + (x0[t] < ws - 1 ? 1 : 0);
-        lx1[t] = fx - (float)x0[t];
-    }
-    const float* plane = m.x[mi] + ((size_t)b * m.C[mi] + cm) * hs * ws;
-#pragma unroll
-    for (int r = 0; r < UP_ROWS; ++r) {
-        const int y = yb + r;
-        if (y < h0) {
-            const float fy = sy * (float)y;
-            const int y0 = (int)fy;
-            const int y1 = y0 + (y0 < hs - 1 ? 1 : 0);
-            const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
-            const float* r0 = plane + (size_t)y0 * ws;
-            const float* r1 = plane + (size_t)y1 * ws;
-            float o[4];
+        } else {
+            const int hs = m.h[mi], ws = m.w[mi];
+            const float sy = ac_scale(hs, h0), sx = ac_scale(ws, w0);
+            int x0[4], x1[4];
+            float lx1[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float lx0 = 1.f - lx1[t];
-                o[t] = ly0 * (lx0 * r0[x0[t]] + lx1[t] * r0[x1[t]]) + ly1 * (lx0 * r1[x0[t]] + lx1[t] * r1[x1[t]]);
+                const float fx = sx * (float)(x + t);
+                x0[t] = (int)fx;
+                x1[t] = x0[t] + (x0[t] < ws - 1 ? 1 : 0);
+                lx1[t] = fx - (float)x0[t];
             }
-            store_nt4(orow + (size_t)r * w0, o[0], o[1], o[2], o[3]);
+            const float* plane = m.x[mi] + ((size_t)b * m.C[mi] + cm) * hs * ws;
+#pragma unroll
+            for (int r = 0; r < UP_ROWS; ++r) {
+                const int y = yb + r;
+                if (y < h0) {
+                    const float fy = sy * (float)y;
+                    const int y0 = (int)fy;
+                    const int y1 = y0 + (y0 < hs - 1 ? 1 : 0);
+                    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+                    const float* r0 = plane + (size_t)y0 * ws;
+                    const float* r1 = plane + (size_t)y1 * ws;
+                    float o[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float lx0 = 1.f - lx1[t];
+                        o[t] = ly0 * (lx0 * r0[x0[t]] + lx1[t] * r0[x1[t]]) + ly1 * (lx0 * r1[x0[t]] + lx1[t] * r1[x1[t]]);
+                    }
+                    store_nt4(orow + (size_t)r * w0, o[0], o[1], o[2], o[3]);
+                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                }
+            }
         }
+    }
+    if (amax) {                                    // (block-uniform) one candidate per wave; |v| >= 0, so the bit patterns order like the values
+        unsigned bits = __builtin_bit_cast(unsigned, vmax);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o, 64));
+        if ((threadIdx.x & 63) == 0) amax_publish_block(bits, amax);
     }
 }
 
@@ -131,8 +146,8 @@ int fill_maps(UpcatMaps* m, const int* C, const int* hs, const int* ws, int n_ma
 
 }  // namespace
 
-extern "C" int cseg_upcat_fwd(const float* const* xs, const int* C, const int* hs, const int* ws, int n_maps, int B,
-                              float* out, cseg_stream_t stream_) {
+static int upcat_fwd_impl(const float* const* xs, const int* C, const int* hs, const int* ws, int n_maps, int B, float* out, unsigned* amax,
+                          cseg_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     UpcatMaps m;
     if (!fill_maps(&m, C, hs, ws, n_maps)) return 0;
@@ -142,13 +157,26 @@ extern "C" int cseg_upcat_fwd(const float* const* xs, const int* C, const int* h
     if (w0 % 4 == 0) {
         const int tiles_x = (w0 / 4 + 63) / 64, tiles_y = (h0 + 4 * UP_ROWS - 1) / (4 * UP_ROWS);
         dim3 grid(tiles_x * tiles_y, Ctot, B);
-        hipLaunchKernelGGL(upcat_fwd_kernel, grid, dim3(256), 0, stream, m, Ctot, tiles_x, out);
+        hipLaunchKernelGGL(upcat_fwd_kernel, grid, dim3(256), 0, stream, m, Ctot, tiles_x, out, amax);
     } else {
+        CSEG_REQUIRE(!amax, "upcat_fwd: the max|out| record needs a width that is a multiple of 4 (got %d)", w0);
         dim3 grid((h0 * w0 + 255) / 256, Ctot, B);
         hipLaunchKernelGGL(upcat_fwd_scalar_kernel, grid, dim3(256), 0, stream, m, Ctot, out);
     }
     CSEG_CHECK_LAUNCH("upcat_fwd_kernel");
     return 1;
+}
+
+extern "C" int cseg_upcat_fwd(const float* const* xs, const int* C, const int* hs, const int* ws, int n_maps, int B, float* out,
+                              cseg_stream_t stream) {
+    return upcat_fwd_impl(xs, C, hs, ws, n_maps, B, out, nullptr, stream);
+}
+
+// the same with max|out| accumulated into `amax` (a zeroed record of CSEG_AMAX_WORDS words, as cseg_amax_f32 fills it); width % 4 == 0
+extern "C" int cseg_upcat_fwd_amax(const float* const* xs, const int* C, const int* hs, const int* ws, int n_maps, int B, float* out,
+                                   unsigned* amax, cseg_stream_t stream) {
+    CSEG_REQUIRE(amax, "upcat_fwd_amax: null record");
+    return upcat_fwd_impl(xs, C, hs, ws, n_maps, B, out, amax, stream);
 }
 
 extern "C" int cseg_upcat_bwd(const float* d_out, const int* C, const int* hs, const int* ws, int n_maps, int B,

@@ -338,11 +338,16 @@ def _int_arr(vals):
     return (ctypes.c_int * len(vals))(*vals)
 
 
+# max|.| records from the kernels that WRITE a tensor read by split-operand convolutions (upsample + concat, the exchange unit's fused
+# sum) instead of a cseg_amax_f32 pass per tensor; CSEG_PRODUCER_AMAX=0 restores the passes (A/B: profiles/r06_ab_producer_amax.txt)
+PRODUCER_AMAX = os.environ.get("CSEG_PRODUCER_AMAX", "1") == "1"
+
+
 class UpsampleConcat(Function):
     """lib/models/nets/hrnet.py:86-91 as one kernel (forward) and its exact adjoint (backward)."""
 
     @staticmethod
-    def forward(ctx, *feats):
+    def forward(ctx, amax, *feats):
         feats = [f.contiguous() for f in feats]
         B = feats[0].shape[0]
         C = [f.shape[1] for f in feats]
@@ -350,8 +355,12 @@ class UpsampleConcat(Function):
         ws = [f.shape[3] for f in feats]
         out = torch.empty(B, sum(C), hs[0], ws[0], dtype=F32, device=feats[0].device)
         ptrs = (ctypes.c_void_p * len(feats))(*[_p(f, F32, "feat%d" % i).value for i, f in enumerate(feats)])
-        _hip.call("cseg_upcat_fwd", ptrs, _int_arr(C), _int_arr(hs), _int_arr(ws), len(feats), B,
-                  _p(out, F32, "out"), _hip.stream_ptr())
+        if amax is not None:
+            _hip.call("cseg_upcat_fwd_amax", ptrs, _int_arr(C), _int_arr(hs), _int_arr(ws), len(feats), B,
+                      _p(out, F32, "out"), _pf(amax), _hip.stream_ptr())
+        else:
+            _hip.call("cseg_upcat_fwd", ptrs, _int_arr(C), _int_arr(hs), _int_arr(ws), len(feats), B,
+                      _p(out, F32, "out"), _hip.stream_ptr())
         ctx.dims = (B, C, hs, ws)
         return out
 
@@ -362,7 +371,7 @@ class UpsampleConcat(Function):
         grads = []
         ptrs = []
         for i in range(len(C)):
-            if ctx.needs_input_grad[i]:
+            if ctx.needs_input_grad[i + 1]:
                 t = torch.empty(B, C[i], hs[i], ws[i], dtype=F32, device=g.device)
                 grads.append(t)
                 ptrs.append(t.data_ptr())
@@ -372,11 +381,15 @@ class UpsampleConcat(Function):
         arr = (ctypes.c_void_p * len(C))(*ptrs)
         _hip.call("cseg_upcat_bwd", _p(g, F32, "d_out"), _int_arr(C), _int_arr(hs), _int_arr(ws), len(C), B, arr,
                   _hip.stream_ptr())
-        return tuple(grads)
+        return (None,) + tuple(grads)
 
 
 def upsample_concat(feats):
-    return UpsampleConcat.apply(*feats)
+    # the result feeds two split-operand convolutions (the head's 3x3 and the projection head's 1x1): its max|.| record is accumulated
+    # by the kernel that writes it (a separate cseg_amax_f32 pass reads the 755 MB tensor once more: 0.15 ms)
+    f0 = feats[0]
+    amax = amax_request(f0) if (PRODUCER_AMAX and f0.shape[3] % 4 == 0 and f0.dtype == F32) else None
+    return amax_attach(UpsampleConcat.apply(amax, *feats), amax)
 
 
 class FuseSumReLU(Function):
@@ -384,7 +397,7 @@ class FuseSumReLU(Function):
     step of HighResolutionModule.forward (hrnet_backbone.py:271-286 of the reference)."""
 
     @staticmethod
-    def forward(ctx, n_same, *terms):
+    def forward(ctx, n_same, amax, *terms):
         if n_same < 1:
             raise RuntimeError("fuse_sum_relu needs at least one same-resolution term")
         terms = [t.contiguous() for t in terms]
@@ -395,8 +408,12 @@ class FuseSumReLU(Function):
         lp = (ctypes.c_void_p * max(1, len(low)))(*([_p(t, F32, "low").value for t in low] or [None]))
         lh = [t.shape[2] for t in low]
         lw = [t.shape[3] for t in low]
-        _hip.call("cseg_fuse_sum_fwd", sp, len(same), lp, _int_arr(lh or [1]), _int_arr(lw or [1]), len(low), B, C, h, w,
-                  1, _p(out, F32, "out"), _hip.stream_ptr())
+        if amax is not None:
+            _hip.call("cseg_fuse_sum_fwd_amax", sp, len(same), lp, _int_arr(lh or [1]), _int_arr(lw or [1]), len(low), B, C, h, w,
+                      1, _p(out, F32, "out"), _pf(amax), _hip.stream_ptr())
+        else:
+            _hip.call("cseg_fuse_sum_fwd", sp, len(same), lp, _int_arr(lh or [1]), _int_arr(lw or [1]), len(low), B, C, h, w,
+                      1, _p(out, F32, "out"), _hip.stream_ptr())
         ctx.save_for_backward(out)
         ctx.meta = (len(same), lh, lw, B, C, h, w)
         return out
@@ -406,20 +423,23 @@ class FuseSumReLU(Function):
         (out,) = ctx.saved_tensors
         n_same, lh, lw, B, C, h, w = ctx.meta
         g = g.contiguous()
-        need_same = any(ctx.needs_input_grad[1:1 + n_same])
+        need_same = any(ctx.needs_input_grad[2:2 + n_same])
         g_same = torch.empty_like(out) if need_same else None
         d_low = [torch.empty(B, C, lh[i], lw[i], dtype=F32, device=g.device)
-                 if ctx.needs_input_grad[1 + n_same + i] else None for i in range(len(lh))]
+                 if ctx.needs_input_grad[2 + n_same + i] else None for i in range(len(lh))]
         dl = (ctypes.c_void_p * max(1, len(d_low)))(*([t.data_ptr() if t is not None else None for t in d_low] or [None]))
         _hip.call("cseg_fuse_sum_bwd", _p(g, F32, "d_out"), _p(out, F32, "out"), _int_arr(lh or [1]), _int_arr(lw or [1]),
                   len(lh), B, C, h, w, _p(g_same, F32, "g_same") if need_same else _null(), dl, _hip.stream_ptr())
-        grads = [g_same if ctx.needs_input_grad[1 + i] else None for i in range(n_same)]
-        return (None,) + tuple(grads) + tuple(d_low)
+        grads = [g_same if ctx.needs_input_grad[2 + i] else None for i in range(n_same)]
+        return (None, None) + tuple(grads) + tuple(d_low)
 
 
 def fuse_sum_relu(same, low):
     """same: list of [B,C,h,w]; low: list of [B,C,hs,ws] coarser maps (upsampled with align_corners=True)."""
-    return FuseSumReLU.apply(len(same), *same, *low)
+    # the outputs of an exchange unit feed the split-operand convolutions of the next unit: the kernel that writes them leaves their
+    # max|.| record (otherwise kernels.amax_of spends a cseg_amax_f32 pass and a launch on each: ~20 per step)
+    amax = amax_request(same[0]) if PRODUCER_AMAX else None
+    return amax_attach(FuseSumReLU.apply(len(same), amax, *same, *low), amax)
 
 
 # ----------------------------------------------------------------------------------------------------------

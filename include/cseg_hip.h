@@ -119,6 +119,10 @@ int cseg_contrast_bwd(const cseg_contrast_desc* d, const float* S_ws, const floa
  * ------------------------------------------------------------------------------------------------ */
 int cseg_upcat_fwd(const float* const* xs, const int* C, const int* hs, const int* ws, int n_maps, int B,
                    float* out, cseg_stream_t stream);
+/* the same, with max|out| accumulated into `amax` while the values are stored (a zeroed CSEG_AMAX_WORDS record, the format of
+ * cseg_amax_f32): the 720-channel tensor is the input of two split-operand convolutions. Width of the finest map % 4 == 0. */
+int cseg_upcat_fwd_amax(const float* const* xs, const int* C, const int* hs, const int* ws, int n_maps, int B,
+                        float* out, unsigned* amax, cseg_stream_t stream);
 int cseg_upcat_bwd(const float* d_out, const int* C, const int* hs, const int* ws, int n_maps, int B,
                    float* const* d_xs, cseg_stream_t stream);
 
@@ -133,6 +137,11 @@ int cseg_upcat_bwd(const float* d_out, const int* C, const int* hs, const int* w
 int cseg_fuse_sum_fwd(const float* const* same, int n_same, const float* const* low, const int* low_h,
                       const int* low_w, int n_low, int B, int C, int h, int w, int relu, float* out,
                       cseg_stream_t stream);
+/* the same, with max|out| accumulated into `amax` while the values are stored (a zeroed CSEG_AMAX_WORDS record, the format of
+ * cseg_amax_f32): the outputs of an exchange unit are the inputs of the next unit's split-operand convolutions. */
+int cseg_fuse_sum_fwd_amax(const float* const* same, int n_same, const float* const* low, const int* low_h,
+                           const int* low_w, int n_low, int B, int C, int h, int w, int relu, float* out, unsigned* amax,
+                           cseg_stream_t stream);
 int cseg_fuse_sum_bwd(const float* d_out, const float* out_act, const int* low_h, const int* low_w, int n_low, int B,
                       int C, int h, int w, float* g_same, float* const* d_low, cseg_stream_t stream);
 

@@ -291,6 +291,12 @@ def test_upsample_concat_matches_torch():
         h, w = shp[0][2:]
         ref = torch.cat([xs[0]] + [F.interpolate(x, size=(h, w), mode="bilinear", align_corners=True) for x in xs[1:]], 1)
         assert torch.allclose(out, ref, rtol=1e-5, atol=5e-6), (out - ref).abs().max()   # fp32 rounding only
+        rec = Kk.known_amax(out)
+        if w % 4 == 0 and Kk.split_arith_id():
+            # the max|.| record the kernel leaves for the split-operand convolutions behind it: exactly max|out| (bit patterns of floats >= 0)
+            assert rec is not None and float(rec.view(torch.float32).max()) == float(out.detach().abs().max())
+        else:
+            assert rec is None
         g = torch.randn_like(out)
         got = torch.autograd.grad(out, xs, g)
         want = torch.autograd.grad(ref, xs, g)
@@ -313,6 +319,9 @@ def test_fuse_sum_relu_matches_torch():
         out = Kk.fuse_sum_relu(same, low)
         ref = cpu_port.fuse_sum_relu(same, low)
         assert torch.allclose(out, ref, rtol=1e-5, atol=5e-6), (out - ref).abs().max()
+        if Kk.split_arith_id():                       # the max|.| record left for the next unit's split-operand convolutions: exactly max|out|
+            rec = Kk.known_amax(out)
+            assert rec is not None and float(rec.view(torch.float32).max()) == float(out.detach().abs().max())
         g = torch.randn_like(out)
         got = torch.autograd.grad(out, same + low, g)
         want = torch.autograd.grad(ref, same + low, g)
