@@ -68,6 +68,7 @@ SIGNATURES = {
     "cseg_upcat_fwd_amax": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "cseg_upcat_bwd": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr]),
     "cseg_fuse_sum_fwd": (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _c_int] + [_c_int] * 5 + [_ptr, _ptr]),
+    "cseg_affine_channels": (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, ctypes.c_long, _ptr, _ptr, _ptr]),
     "cseg_fuse_sum_fwd_amax": (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _c_int] + [_c_int] * 5 + [_ptr, _ptr, _ptr]),
     "cseg_fuse_sum_bwd": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int] + [_c_int] * 4 + [_ptr, _ptr, _ptr]),
     "cseg_upsample_ce_blocks": (_c_int, [_c_int, _c_int, _c_int]),

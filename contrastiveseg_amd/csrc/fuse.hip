@@ -164,3 +164,56 @@ extern "C" int cseg_fuse_sum_bwd(const float* d_out, const float* out_act, const
     }
     return 1;
 }
+
+// ---- out[b][c][p] = a[c] + b[c] * u[b][c][p]: the dense part of the BatchNorm input gradient when the output gradient lives on N pixels
+// (lib/models/modules/projection.py, row-sparse tail of the projection head: du = A_c + B_c u everywhere, plus N corrected rows), with
+// max|out| accumulated for the split-operand convolution that reads it (torch.addcmul + a cseg_amax_f32 pass over 755 MB before).
+namespace {
+__global__ __launch_bounds__(256) void affine_channels_kernel(const float* __restrict__ u, const float* __restrict__ a,
+                                                              const float* __restrict__ bcoef, int C, long P, int chunks,
+                                                              float* __restrict__ out, unsigned* __restrict__ amax) {
+    const long row = blockIdx.x / chunks;                      // (image, channel)
+    const int chunk = blockIdx.x - (int)(row * chunks);
+    const int c = (int)(row % C);
+    const float av = a[c], bv = bcoef[c];
+    const float* up = u + (size_t)row * P;
+    float* op = out + (size_t)row * P;
+    float vmax = 0.f;
+    const long p4 = P / 4;
+    for (long i = (long)chunk * 256 + threadIdx.x; i < p4; i += (long)chunks * 256) {
+        const float4 v = reinterpret_cast<const float4*>(up)[i];
+        const float4 o = make_float4(__builtin_fmaf(bv, v.x, av), __builtin_fmaf(bv, v.y, av), __builtin_fmaf(bv, v.z, av),
+                                     __builtin_fmaf(bv, v.w, av));
+        reinterpret_cast<float4*>(op)[i] = o;
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    }
+    if (chunk == 0) {
+        for (long p = p4 * 4 + threadIdx.x; p < P; p += 256) {
+            const float o = __builtin_fmaf(bv, up[p], av);
+            op[p] = o;
+            vmax = fmaxf(vmax, fabsf(o));
+        }
+    }
+    if (amax) {
+        unsigned bits = __builtin_bit_cast(unsigned, vmax);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o, 64));
+        if ((threadIdx.x & 63) == 0) amax_publish_block(bits, amax);
+    }
+}
+}  // namespace
+
+extern "C" int cseg_affine_channels(const float* u, const float* a, const float* b, int B, int C, long P, float* out, unsigned* amax,
+                                    cseg_stream_t stream_) {
+    CSEG_REQUIRE(u && a && b && out && B > 0 && C > 0 && P > 0, "affine_channels: bad arguments");
+    CSEG_REQUIRE((P % 4 == 0 && ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(out)) & 15) == 0),
+                 "affine_channels: rows must be 16-byte aligned (P %% 4 == 0, aligned tensors); got P=%ld", P);
+    const long rows = (long)B * C;
+    int chunks = (int)((P / 4 + 2047) / 2048);                 // <= 8 float4 per thread
+    if (chunks < 1) chunks = 1;
+    CSEG_REQUIRE(rows * chunks < 2147483647L, "affine_channels: grid too large");
+    hipLaunchKernelGGL(affine_channels_kernel, dim3((unsigned)(rows * chunks)), dim3(256), 0, (hipStream_t)stream_, u, a, b, C, P, chunks, out,
+                       amax);
+    CSEG_CHECK_LAUNCH("affine_channels_kernel");
+    return 1;
+}

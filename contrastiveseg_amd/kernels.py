@@ -434,6 +434,18 @@ class FuseSumReLU(Function):
         return (None, None) + tuple(grads) + tuple(d_low)
 
 
+def affine_channels(u, a, b, want_amax=True):
+    """a[c] + b[c] * u[b, c] over an NCHW tensor (one read + one write), leaving the max|.| record of the result for the split-operand
+    convolution that reads it. -> (out, record or None)"""
+    B, C = u.shape[:2]
+    P = u[0, 0].numel()
+    out = torch.empty_like(u)
+    amax = amax_request(u) if want_amax else None
+    _hip.call("cseg_affine_channels", _p(u, F32, "u"), _p(a.contiguous(), F32, "a"), _p(b.contiguous(), F32, "b"), B, C, ctypes.c_long(P),
+              _pf(out), _pf(amax) if amax is not None else _null(), _hip.stream_ptr())
+    return out, amax
+
+
 def fuse_sum_relu(same, low):
     """same: list of [B,C,h,w]; low: list of [B,C,hs,ws] coarser maps (upsampled with align_corners=True)."""
     # the outputs of an exchange unit feed the split-operand convolutions of the next unit: the kernel that writes them leaves their

@@ -147,10 +147,21 @@ class _SparseTail(torch.autograd.Function):
                 s64, i64, mu64 = scale.double(), invstd.double(), mean.double()
                 b_c = -(s64 * i64 * m[:, 1])
                 a_c = -(s64 * m[:, 0]) - b_c * mu64
-                du = torch.addcmul(a_c.to(u.dtype).view(1, C, 1, 1), u, b_c.to(u.dtype).view(1, C, 1, 1))
+                am = None
+                if (_switches.PRODUCER_AMAX and _switches._on_device(u) and u.dtype == torch.float32 and P % 4 == 0
+                        and hasattr(K, 'affine_channels')):
+                    # one kernel: the affine map AND the max|du| record for proj.0's backward-data / weight-gradient kernels
+                    # (torch.addcmul + a max|.| pass over the 755 MB tensor before)
+                    du, am = K.affine_channels(u, a_c.to(u.dtype), b_c.to(u.dtype), _switches.split_arith_id() != 0)
+                else:
+                    du = torch.addcmul(a_c.to(u.dtype).view(1, C, 1, 1), u, b_c.to(u.dtype).view(1, C, 1, 1))
             else:
-                du = torch.zeros_like(u)                      # frozen statistics: only the N pixels carry gradient
+                du, am = torch.zeros_like(u), None            # frozen statistics: only the N pixels carry gradient
             _add_rows(du, b_idx, p_idx, vals)
+            if am is not None:
+                # the N corrected rows may exceed the affine part: their final values join the record (a [N, C] gather)
+                _switches.tensor_amax(du.view(B, C, P)[b_idx, :, p_idx].contiguous(), slot=am)
+                _switches.amax_attach(du, am)
         return du, d_gamma, d_beta, d_w2, d_b2, None, None
 
 

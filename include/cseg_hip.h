@@ -144,6 +144,11 @@ int cseg_fuse_sum_fwd_amax(const float* const* same, int n_same, const float* co
                            cseg_stream_t stream);
 int cseg_fuse_sum_bwd(const float* d_out, const float* out_act, const int* low_h, const int* low_w, int n_low, int B,
                       int C, int h, int w, float* g_same, float* const* d_low, cseg_stream_t stream);
+/* out[b][c][p] = a[c] + b[c] * u[b][c][p] over [B,C,P] (P % 4 == 0, 16-byte aligned), with max|out| accumulated into `amax` when it is not
+ * NULL (a zeroed CSEG_AMAX_WORDS record): the dense part of a BatchNorm input gradient whose output gradient lives on a few pixels --
+ * the row-sparse backward of the projection head (reference lib/models/modules/projection.py:8-24 runs the dense adjoint). */
+int cseg_affine_channels(const float* u, const float* a, const float* b, int B, int C, long P, float* out, unsigned* amax,
+                         cseg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Segmentation term: bilinear(align_corners=True) upsample of the logits to the label size fused with the
