@@ -72,26 +72,47 @@ __global__ __launch_bounds__(256) void cls1x1_fwd_kernel(const float* __restrict
     }
 }
 
-// ---- backward-data: thread = pixel, blockIdx.y = a quarter of the channels ---------------------------------------------------------------
-template <int KP>
+// ---- backward-data: thread = four consecutive pixels (16-byte loads of dy and stores of dx when P % 4 == 0), blockIdx.y = a part of the channels
+template <int KP, bool VEC>
 __global__ __launch_bounds__(256) void cls1x1_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ wt, int C, int K,
                                                          long P, int tiles, float* __restrict__ dx) {
+    constexpr int V = VEC ? 4 : 1;
     const int b = blockIdx.x / tiles, tile = blockIdx.x - b * tiles;
-    const long p = (long)tile * 256 + threadIdx.x;
+    const long p = ((long)tile * 256 + threadIdx.x) * V;
     const bool live = p < P;
-    const long pc = live ? p : P - 1;
-    float d[KP];
+    const long pc = live ? p : 0;
+    float d[KP][V];
 #pragma unroll
-    for (int k = 0; k < KP; ++k) d[k] = k < K ? dy[((size_t)b * K + k) * P + pc] : 0.f;
+    for (int k = 0; k < KP; ++k) {
+        if (k < K) {
+            const float* src = dy + ((size_t)b * K + k) * P + pc;
+            if (VEC) {
+                const float4 t4 = *reinterpret_cast<const float4*>(src);
+                d[k][0] = t4.x; d[k][1 % V] = t4.y; d[k][2 % V] = t4.z; d[k][3 % V] = t4.w;
+            } else {
+                d[k][0] = *src;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < V; ++t) d[k][t] = 0.f;
+        }
+    }
     const int per = (C + (int)gridDim.y - 1) / (int)gridDim.y;
     const int c0 = blockIdx.y * per, c1 = min(C, c0 + per);
     const float* wp = wt + ((size_t)b * C + c0) * KP;          // wave-uniform
     float* op = dx + ((size_t)b * C + c0) * P + pc;
     for (int c = c0; c < c1; ++c) {
-        float s = 0.f;
+        float s[V];
 #pragma unroll
-        for (int k = 0; k < KP; ++k) s = __builtin_fmaf(wp[k], d[k], s);
-        if (live) *op = s;
+        for (int t = 0; t < V; ++t) s[t] = 0.f;
+#pragma unroll
+        for (int k = 0; k < KP; ++k)
+#pragma unroll
+            for (int t = 0; t < V; ++t) s[t] = __builtin_fmaf(wp[k], d[k][t], s[t]);
+        if (live) {
+            if (VEC) *reinterpret_cast<float4*>(op) = make_float4(s[0], s[1 % V], s[2 % V], s[3 % V]);
+            else *op = s[0];
+        }
         wp += KP;
         op += P;
     }
@@ -201,7 +222,7 @@ int wrw_splits(int B, int C, long P) {
 
 bool shape_ok(int B, int C, int K, int KP, long P) {
     return B > 0 && C > 0 && K > 0 && K <= KP && (KP == 20 || KP == 32) && P > 0 && (long)B * C * P < (1L << 40) &&
-           (long)B * ((P + PX - 1) / PX) < 2147483647L;
+           (long)B * ((P + PX - 1) / PX) < 2147483647L / 16;
 }
 
 }  // namespace
@@ -224,12 +245,16 @@ extern "C" int cseg_cls1x1_bwd(const float* dy, const float* wt, int B, int C, i
     CSEG_REQUIRE(dy && wt && dx, "cls1x1_bwd: null pointer");
     CSEG_REQUIRE(shape_ok(B, C, K, KP, P), "cls1x1_bwd: unsupported shape B=%d C=%d K=%d KP=%d P=%ld (K <= KP, KP 20 or 32)", B, C, K, KP, P);
     hipStream_t stream = (hipStream_t)stream_;
-    const int tiles = (int)((P + 255) / 256);
-    const int parts = C >= 256 ? 4 : 1;
-    if (KP == 20)
-        hipLaunchKernelGGL(cls1x1_bwd_kernel<20>, dim3((unsigned)(B * tiles), parts), dim3(256), 0, stream, dy, wt, C, K, P, tiles, dx);
-    else
-        hipLaunchKernelGGL(cls1x1_bwd_kernel<32>, dim3((unsigned)(B * tiles), parts), dim3(256), 0, stream, dy, wt, C, K, P, tiles, dx);
+    const bool vec = P % 4 == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+    const long per_block = vec ? 1024 : 256;
+    const int tiles = (int)((P + per_block - 1) / per_block);
+    int parts = 1;                                             // channel parts: enough blocks for the chip (each re-reads the K-channel dy)
+    while (parts < 16 && (long)B * tiles * parts < 2048 && C / (parts * 2) >= 32) parts *= 2;
+#define CLS_BWD(KPV, V)                                                                                                                \
+    hipLaunchKernelGGL((cls1x1_bwd_kernel<KPV, V>), dim3((unsigned)(B * tiles), parts), dim3(256), 0, stream, dy, wt, C, K, P, tiles, dx)
+    if (KP == 20) { if (vec) CLS_BWD(20, true); else CLS_BWD(20, false); }
+    else          { if (vec) CLS_BWD(32, true); else CLS_BWD(32, false); }
+#undef CLS_BWD
     CSEG_CHECK_LAUNCH("cls1x1_bwd_kernel");
     return 1;
 }
