@@ -10,6 +10,7 @@
 #   ab:<ENV=VAL>     short bench without / with / without / with the environment setting (A/B/A/B on one box)
 #   stats[:<args>]   rocprofv3 --kernel-trace of 6 steady steps (extra bench.py args, comma-separated) -> step_steady_kernel_stats.csv + idle gaps
 #   pmc              rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) -> step_pmc.json
+#   usepmc           installs that step_pmc.json as profiles/r06_step_pmc.json on the box (for the bench steps of the same call)
 #   longrun[:<n>]    tools/long_run_arith.py (default 200 steps): default arithmetic vs strict fp32 vs a one-ulp perturbation
 #   probe:<args>     tools/probes/conv_probe with the given arguments (';' separates arguments)
 #   gprobe:<args>    tools/probes/group_probe (grouped launches vs the one-layer launches they replace; ';' separates arguments)
@@ -66,6 +67,7 @@ for step in "$@"; do
       cd $R
       python tools/merge_step_pmc.py $O/step_pmc_FETCH_SIZE.json $O/step_pmc_WRITE_SIZE.json "tree of $TAG" > $O/step_pmc.json 2> $O/step_pmc.err
       head -5 $O/step_pmc.json | cut -c1-200 ;;
+    usepmc) cp $O/step_pmc.json $R/profiles/r06_step_pmc.json && echo "profiles/r06_step_pmc.json <- $O/step_pmc.json" ;;      # (the bench steps that follow report it as roofline.traffic; copy the same file into profiles/ at home)
     longrun)
       timeout 600 python tools/long_run_arith.py --steps ${arg:-200} > $O/long_run_arith.json 2> $O/long_run_arith.err
       tail -3 $O/long_run_arith.err; python -c "import json; d=json.load(open('$O/long_run_arith.json')); print(d['finite']); print(d['window_mean_rel_dev'])" ;;
