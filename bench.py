@@ -274,15 +274,27 @@ def kernel_rooflines(device, B, K=19, H=512, W=1024, stride=4, D=256):
     mk = (torch.rand(B, 720, 1, 1, generator=g) > 0.1).float().div_(0.9).to(device)
     wide, narrow = xc.numel() * 4, B * K * P * 4
     if Kn.cls1x1_eligible(xc, wc):
-        wtc = Kn.cls1x1_weights(wc, B, mk).detach().requires_grad_(True)
-        entry("cls1x1_fwd 720->%d" % K, time_kernel(lambda: Kn.Cls1x1.apply(xc, wtc, None, K)), bytes_=wide + narrow)
-        yc = Kn.Cls1x1.apply(xc, wtc, None, K)
-        gc = torch.randn_like(yc)
-        entry("cls1x1_bwd 720->%d (backward-data)" % K, time_kernel(lambda: torch.autograd.grad(yc, xc, gc, retain_graph=True)),
-              bytes_=wide + narrow)
-        entry("cls1x1_wrw 720->%d (weight gradient)" % K, time_kernel(lambda: torch.autograd.grad(yc, wtc, gc, retain_graph=True)),
-              bytes_=wide + narrow)
-        del wtc, yc, gc
+        import ctypes
+        from contrastiveseg_amd import _hip
+        wtc = Kn.cls1x1_weights(wc, B, mk).detach().contiguous()
+        KPc = wtc.shape[2]
+        xd = xc.detach()
+        yc = torch.empty(B, K, h, w, device=device)
+        gc = torch.randn(B, K, h, w, generator=g).to(device)
+        dxc = torch.empty_like(xd)
+        wsn = _hip.lib().cseg_cls1x1_wrw_ws_floats(B, 720, KPc, ctypes.c_long(P))
+        wsc, dwc = torch.empty(wsn, device=device), torch.empty(B, 720, KPc, device=device)
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+        # (the C-ABI entry points with caller-owned buffers: through autograd.grad the host, not the kernel, sets the pace of a timing loop)
+        entry("cls1x1_fwd 720->%d" % K, time_kernel(lambda: _hip.call("cseg_cls1x1_fwd", ptr(xd), ptr(wtc), None, B, 720, K, KPc,
+                                                                    ctypes.c_long(P), ptr(yc), _hip.stream_ptr())), bytes_=wide + narrow)
+        entry("cls1x1_bwd 720->%d (backward-data)" % K,
+              time_kernel(lambda: _hip.call("cseg_cls1x1_bwd", ptr(gc), ptr(wtc), B, 720, K, KPc, ctypes.c_long(P), ptr(dxc),
+                                            _hip.stream_ptr())), bytes_=wide + narrow)
+        entry("cls1x1_wrw 720->%d (weight gradient)" % K,
+              time_kernel(lambda: _hip.call("cseg_cls1x1_wrw", ptr(xd), ptr(gc), B, 720, K, KPc, ctypes.c_long(P), ptr(wsc), ptr(dwc),
+                                            _hip.stream_ptr())), bytes_=wide + narrow)
+        del wtc, yc, gc, dxc, wsc, dwc, xd
     del xc, wc, mk
     # the head's 3x3 convolution in the current split arithmetic (forward = backward-data): fp32-equivalent flops vs 2500 / k TF/s
     C = 720
