@@ -42,6 +42,35 @@ def wrap(name):
 
 for n in ("_branches_grouped", "_exchange_forked", "_exchange_lockstep"):
     wrap(n)
+
+# step boundary: [end of the backward launches -> optimizer done] and [optimizer done -> first kernel of the next forward has run]
+bound = []            # (event after backward, event after optimizer.step, event after the stem of the next forward)
+_opt_step = tr.optimizer.step
+
+
+def opt_step(*a, **k):
+    if not on[0]:
+        return _opt_step(*a, **k)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = _opt_step(*a, **k)
+    e1.record()
+    bound.append([e0, e1, None])
+    return out
+
+
+tr.optimizer.step = opt_step
+net = tr.seg_net.module if hasattr(tr.seg_net, "module") else tr.seg_net
+backbone = getattr(net, "backbone", None)
+if backbone is not None:
+    def after_stem(mod, inp, out):
+        if on[0] and bound and bound[-1][2] is None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            bound[-1][2] = e
+    stem = getattr(backbone, "conv1", None)
+    if stem is not None:
+        stem.register_forward_hook(after_stem)
 for _ in range(4):
     tr.train_step(batch)
 torch.cuda.synchronize()
@@ -69,3 +98,9 @@ for (name, nb), (n, gpu, host) in sorted(agg.items()):
     t[1] += host / steps
 for name, (gpu, host) in tot.items():
     print("%-20s total: GPU span %.2f ms/step, host %.2f ms/step" % (name, gpu, host))
+
+done = [b for b in bound if b[2] is not None]
+if done:
+    print("step boundary, GPU time: end of backward -> optimizer done %.3f ms; optimizer done -> first stem convolution of the next step done %.3f ms "
+          "(the optimizer's kernels: ~0.7 ms, the stem convolution: ~0.12 ms; the rest is the GPU waiting for the host)"
+          % (sum(b[0].elapsed_time(b[1]) for b in done) / len(done), sum(b[1].elapsed_time(b[2]) for b in done) / len(done)))
