@@ -1,8 +1,9 @@
 """HRNet-W48 contrastive segmentors with the reference's registry classes, parameter names and output dicts
 (lib/models/nets/hrnet.py:59-95 HRNet_W48_CONTRAST, :98-150 HRNet_W48_OCR_CONTRAST, :153-188 HRNet_W48_MEM).
 
-The 3x F.interpolate + torch.cat that builds the 720-channel head input (:86-91) is one HIP kernel
-(cseg_upcat_fwd/bwd); encoder and head convolutions run on MIOpen."""
+The 3x F.interpolate + torch.cat that builds the 720-channel head input (:86-91) is one HIP kernel (cseg_upcat_fwd_amax / _bwd, which
+also leaves the max|.| record of its result); the head's 3x3 / 1x1 convolutions run on the split-operand kernels (module_helper), the
+classifier on csrc/cls1x1.hip with the Dropout2d in front of it folded into its weights (FoldedDropout2d + ClassifierConv1x1)."""
 import torch
 import torch.nn as nn
 
