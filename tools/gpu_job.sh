@@ -17,6 +17,7 @@
 #   gpmc:<ctrs>|<args>  the same probe under rocprofv3 --pmc <ctrs> (comma separated) -> gpmc_summary.csv (per-kernel averages)
 #   py:<script,args> any python script of tools/ (comma-separated arguments), output kept as py_<script>.txt
 #   host             tools/host_profile.py 8
+#   hpmc:<ctrs>|<args>  tools/probes/conv_probe under rocprofv3 --pmc <ctrs> -> hpmc_summary.csv (per-kernel averages; the head kernels: --nt 265 --wrw)
 #   contrast         tools/contrast_probe.py under rocprofv3 --kernel-trace --stats: fused vs three-launch contrastive forward
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -93,6 +94,18 @@ for step in "$@"; do
       c=$(find $O/gpmc -name '*counter_collection.csv' | head -1)
       [ -n "$c" ] && python tools/pmc_kernel_summary.py $c group >> $O/gpmc_summary.csv
       rm -rf $O/gpmc; tail -4 $O/gpmc_summary.csv | cut -c1-700 ;;
+    hpmc)          # hpmc:<counters, comma separated>|<conv_probe args, ';' separated>: PMC counters of the one-layer 3x3 kernels (the head: --nt 265)
+      export LD_LIBRARY_PATH=/opt/rocm/lib:$LD_LIBRARY_PATH
+      P=tools/probes/conv_probe
+      [ -x $P ] || g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tools/probes/conv_probe.cpp -o $P -L/opt/rocm/lib -lamdhip64 -ldl
+      ctrs=${arg%%|*}; pargs=${arg#*|}
+      IFS=';' read -ra PA <<< "$pargs"
+      cd /tmp
+      CSEG_LIB=$R/contrastiveseg_amd/libcseg_hip.so timeout 300 rocprofv3 --pmc ${ctrs//,/ } --kernel-trace -d $O/hpmc -o h --output-format csv -- $R/$P "${PA[@]}" > $O/hpmc_probe.out 2> $O/hpmc.err
+      cd $R
+      c=$(find $O/hpmc -name '*counter_collection.csv' | head -1)
+      [ -n "$c" ] && python tools/pmc_kernel_summary.py $c conv3x3 >> $O/hpmc_summary.csv
+      rm -rf $O/hpmc; tail -6 $O/hpmc_summary.csv | cut -c1-900 ;;
     contrast)
       cd /tmp
       timeout 300 rocprofv3 --kernel-trace --stats -d $O/ctrace -o c --output-format csv -- python $R/tools/contrast_probe.py > $O/contrast_probe.json 2> $O/contrast_probe.err
