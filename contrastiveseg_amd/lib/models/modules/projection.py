@@ -162,6 +162,8 @@ class _SparseTail(torch.autograd.Function):
                 # the N corrected rows may exceed the affine part: their final values join the record (a [N, C] gather)
                 _switches.tensor_amax(du.view(B, C, P)[b_idx, :, p_idx].contiguous(), slot=am)
                 _switches.amax_attach(du, am)
+            if training:
+                _switches.mark_zero_channel_sum(du)           # batch statistics: sum(du) = 0 per channel (kernels.bias_grad)
         return du, d_gamma, d_beta, d_w2, d_b2, None, None
 
 

@@ -85,6 +85,8 @@ def bn_backward(dy, x, out, mi, weight, bias, relu, has_res, training, count, sy
             dx = K.bn_bwd_apply(g if mode == 2 else dy, x, mi, weight, bias, sums, SYNC_COUNT, mode == 1, amax=amax)
     if dx is not None:
         K.amax_attach(dx, amax)
+        if training and hasattr(K, 'mark_zero_channel_sum'):
+            K.mark_zero_channel_sum(dx)          # batch statistics: sum(dx) = 0 per channel -> the bias gradient of the convolution in front
     d_res = None
     if has_res:
         d_res = g if mode == 2 else dy          # the add passes the (masked) gradient straight through

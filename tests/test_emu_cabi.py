@@ -122,6 +122,12 @@ def test_classifier_with_folded_dropout_matches_the_reference_modules(kw, monkey
     _replay(monkeypatch, "test_gpu_cls1x1", "test_classifier_with_folded_dropout_matches_the_reference_modules", dict(kw, monkeypatch=monkeypatch))
 
 
+@pytest.mark.parametrize("bn_training", [True, False])
+def test_bias_gradient_of_a_convolution_in_front_of_batchnorm(bn_training, monkeypatch):
+    _replay(monkeypatch, "test_gpu_cls1x1", "test_bias_gradient_of_a_convolution_in_front_of_batchnorm",
+            {"bn_training": bn_training, "monkeypatch": monkeypatch})
+
+
 def test_classifier_eval_mode_and_fallbacks(monkeypatch):
     _replay(monkeypatch, "test_gpu_cls1x1", "test_classifier_eval_mode_and_fallbacks", {"monkeypatch": monkeypatch})
 

@@ -98,3 +98,46 @@ def test_classifier_eval_mode_and_fallbacks(monkeypatch):
         b = ref(x)
         assert float((a - b).abs().max()) <= 1e-5, Kc
         assert K.cls1x1_eligible(x, conv.weight) == (Kc <= 32)
+
+
+@pytest.mark.parametrize("bn_training", [True, False])
+def test_bias_gradient_of_a_convolution_in_front_of_batchnorm(bn_training, monkeypatch):
+    """kernels.bias_grad: in front of a BatchNorm that uses the batch statistics the bias gradient is identically zero (the reference
+    sums rounding noise); the BatchNorm backward marks its dx and the convolution returns zeros without a pass over dy. With frozen
+    statistics (eval-mode BatchNorm) the sum is computed. Both against the reference's modules in fp64."""
+    from contrastiveseg_amd import kernels as K
+    from contrastiveseg_amd.lib.models.tools.module_helper import HeadConv3x3, ModuleHelper
+    dev = _dev()
+    C = 96                                      # (a channel count the split weight-gradient kernel takes: kernels.CONV3X3_SB_WRW_CHANNELS)
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(2, C, 8, 64, generator=g).relu_()
+    dy0 = torch.randn(2, C, 8, 64, generator=g)
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(HeadConv3x3(C), ModuleHelper.BNReLU(C, bn_type="torchsyncbn")).to(dev)
+    ref = torch.nn.Sequential(nn.Conv2d(C, C, 3, 1, 1), nn.BatchNorm2d(C), nn.ReLU()).double().to(dev)
+    ref[0].load_state_dict(net[0].state_dict())
+    with torch.no_grad():
+        rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+        for bn in [m for m in net.modules() if hasattr(m, "running_mean")] + [ref[1]]:
+            bn.running_mean.copy_(rm.to(bn.running_mean.dtype))
+            bn.running_var.copy_(rv.to(bn.running_var.dtype))
+    net.train(); ref.train()
+    if not bn_training:
+        for m in list(net.modules()) + [ref[1]]:
+            if hasattr(m, "running_mean"):
+                m.eval()
+    sums = []
+    monkeypatch.setattr(K, "bias_grad", lambda dy, f=K.bias_grad: (sums.append(getattr(dy, "_cseg_zero_chan_sum", None) == dy._version), f(dy))[1])
+    x = x0.to(dev).clone().requires_grad_(True)
+    net(x).backward(dy0.to(dev))
+    xr = x0.double().to(dev).clone().requires_grad_(True)
+    ref(xr).backward(dy0.double().to(dev))
+    got, want = net[0].bias.grad.double().cpu(), ref[0].bias.grad.cpu()
+    scale = float(ref[0].weight.grad.abs().max())
+    if K._on_device(x) and K.conv3x3_sb_eligible(x.detach(), net[0].weight) and K.conv3x3_sb_wrw_wanted(x.detach(), dy0.to(dev)):
+        assert sums == [bn_training], "the BatchNorm backward must mark dx exactly when it used the batch statistics"
+    if bn_training:
+        assert float(want.abs().max()) <= 1e-9 * max(scale, 1.0)              # the identity the shortcut rests on, in fp64
+        assert float(got.abs().max()) <= 1e-5 * scale
+    else:
+        assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
