@@ -129,6 +129,7 @@ SIGNATURES = {
     "cseg_conv1x1_split_packed_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int]),
     "cseg_conv1x1_split_pack": (_c_int, [_ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "cseg_conv1x1_split_fwd": (_c_int, [_ptr, _ptr, _ptr] + [_c_int] * 5 + [_ptr, _ptr, _ptr, _ptr]),
+    "cseg_conv1x1_split_fwd_add": (_c_int, [_ptr, _ptr, _ptr, _ptr] + [_c_int] * 5 + [_ptr, _ptr, _ptr, _ptr]),
     "cseg_conv1x1_split_wrw": (_c_int, [_ptr, _ptr] + [_c_int] * 5 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
     "cseg_conv3x3_split_plan": (_c_int, [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "cseg_conv1x1_split_plan": (_c_int, [_c_int, _c_int, _ptr, _ptr]),

@@ -62,10 +62,12 @@ __device__ __forceinline__ void o_kstep(const uint4* __restrict__ ap, const uint
 // accumulator layout: D[m = 4*g + r][n]: pixel px0 + 16*mt + 4*g + r, channel co0 + 16*nt + n
 template <int NTW, int NTMAX>
 __device__ __forceinline__ void o_store(const f32x4 (&acc)[4][NTMAX], float* __restrict__ ybc, const float* __restrict__ bias,
-                                        int co0, size_t plane, int px0, int g, int n, float unscale) {
+                                        int co0, size_t plane, int px0, int g, int n, float unscale,
+                                        const float* __restrict__ abc = nullptr) {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         float* orow = ybc + (size_t)(co0 + nt * 16 + n) * plane;
+        const float* arow = abc ? abc + (size_t)(co0 + nt * 16 + n) * plane : nullptr;      // y = conv + bias + addend (same layout as y)
         const float bv = bias ? bias[co0 + nt * 16 + n] : 0.f;
         const bool vec = (plane & 3) == 0;          // channel planes 16-byte aligned (else element by element: cseg_store_row4)
 #pragma unroll
@@ -73,7 +75,7 @@ __device__ __forceinline__ void o_store(const f32x4 (&acc)[4][NTMAX], float* __r
             const long px = (long)px0 + 16 * mt + 4 * g;
             f32x4 v = acc[mt][nt] * unscale;
             v += bv;
-            cseg_store_row4(orow, nullptr, px, (long)plane, vec, v);
+            cseg_store_row4(orow, arow, px, (long)plane, vec, v);
         }
     }
 }
@@ -83,7 +85,8 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_kernel(const float* __restr
                                                             const float* __restrict__ bias, int Cin, int Cout, int plane_i,
                                                             int tiles_p, const unsigned* __restrict__ amax_x,
                                                             const unsigned* __restrict__ amax_w, float* __restrict__ y,
-                                                            float4* __restrict__ stats, int n_seg, int xmap) {
+                                                            float4* __restrict__ stats, int n_seg, int xmap,
+                                                            const float* __restrict__ addend) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem_o[];
     constexpr int NP = AR::NP;
     constexpr int A1_CELLS = NP * 4 * MT_PX;       // one A buffer: [piece][octet][pixel]
@@ -185,8 +188,9 @@ __global__ __launch_bounds__(512, 1) void conv1x1_sb_kernel(const float* __restr
     float* ybc = y + (size_t)b * Cout * plane;
     const int co0 = cot * NT * 16;
     const float unscale = split_unscale_of(ex) * split_unscale_of(ew);
-    if (half == 0) o_store<NT0, NT0>(acc, ybc, bias, co0, plane, px0 + quarter * 64, g, n, unscale);
-    else if (NT1 > 0) o_store<NT1, NT0>(acc, ybc, bias, co0 + NT0 * 16, plane, px0 + quarter * 64, g, n, unscale);
+    const float* abc = addend ? addend + (size_t)b * Cout * plane : nullptr;
+    if (half == 0) o_store<NT0, NT0>(acc, ybc, bias, co0, plane, px0 + quarter * 64, g, n, unscale, abc);
+    else if (NT1 > 0) o_store<NT1, NT0>(acc, ybc, bias, co0 + NT0 * 16, plane, px0 + quarter * 64, g, n, unscale, abc);
     if (stats && (size_t)(px0 + quarter * 64) < plane) {      // BatchNorm statistics of what was just stored (cseg_stats.h)
         const size_t seg = (size_t)b * ((plane + 63) / 64) + (size_t)(px0 + quarter * 64) / 64;
         if (half == 0)
@@ -219,7 +223,7 @@ int pick_nt1(int Cout, int arith) {
 
 template <class AR, int NT>
 int launch_1x1(const float* x, const uint4* wp, const float* bias, int B, int Cin, int Cout, int plane, const unsigned* amax_x,
-               const unsigned* amax_w, float* y, float4* stats, hipStream_t stream) {
+               const unsigned* amax_w, float* y, float4* stats, hipStream_t stream, const float* addend) {
     const size_t lds = sizeof(uint4) * (2 * AR::NP * 4 * MT_PX + 2 * NT * AR::NP * 64);
     static bool attr_set = false;
     if (!attr_set) {
@@ -234,22 +238,22 @@ int launch_1x1(const float* x, const uint4* wp, const float* bias, int B, int Ci
     const long n_tiles = (long)B * (Cout / (NT * 16)) * tiles_p;
     CSEG_REQUIRE(n_tiles < 2147483647L, "conv1x1_sb: grid too large");
     hipLaunchKernelGGL((conv1x1_sb_kernel<AR, NT>), dim3((unsigned)n_tiles), dim3(512), lds, stream, x, wp, bias, Cin, Cout, plane,
-                       tiles_p, amax_x, amax_w, y, stats, B * ((plane + 63) / 64), cseg_xcd_remap());
+                       tiles_p, amax_x, amax_w, y, stats, B * ((plane + 63) / 64), cseg_xcd_remap(), addend);
     CSEG_CHECK_LAUNCH("conv1x1_sb_kernel");
     return 1;
 }
 
 template <class AR>
 int fwd_1x1(const float* x, const uint4* wq, const float* bias, int B, int Cin, int Cout, int HW, int NT, const unsigned* amax_x,
-            const unsigned* amax_w, float* y, float4* stats, hipStream_t stream) {
+            const unsigned* amax_w, float* y, float4* stats, hipStream_t stream, const float* addend) {
     switch (NT) {
-        case 16: if constexpr (AR::NP == 2) return launch_1x1<AR, 16>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
-        case 15: if constexpr (AR::NP == 2) return launch_1x1<AR, 15>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
-        case 9: return launch_1x1<AR, 9>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
-        case 8: return launch_1x1<AR, 8>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
-        case 6: return launch_1x1<AR, 6>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
-        case 4: return launch_1x1<AR, 4>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
-        default: return launch_1x1<AR, 3>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream);
+        case 16: if constexpr (AR::NP == 2) return launch_1x1<AR, 16>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream, addend);
+        case 15: if constexpr (AR::NP == 2) return launch_1x1<AR, 15>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream, addend);
+        case 9: return launch_1x1<AR, 9>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream, addend);
+        case 8: return launch_1x1<AR, 8>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream, addend);
+        case 6: return launch_1x1<AR, 6>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream, addend);
+        case 4: return launch_1x1<AR, 4>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream, addend);
+        default: return launch_1x1<AR, 3>(x, wq, bias, B, Cin, Cout, HW, amax_x, amax_w, y, stats, stream, addend);
     }
 }
 
@@ -276,7 +280,8 @@ int pack_1x1(const float* w, int Cout, int Cin, int transpose, int arith, const 
 }
 
 int run_1x1(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int HW, int arith, const unsigned* amax_x,
-            const unsigned* amax_w, float* y, hipStream_t stream, float4* stats = nullptr) {
+            const unsigned* amax_w, float* y, hipStream_t stream, float4* stats = nullptr, const float* addend = nullptr) {
+    CSEG_REQUIRE((reinterpret_cast<uintptr_t>(addend) & 15) == 0, "conv1x1 split: the addend must be 16-byte aligned like y");
     CSEG_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 15) == 0, "conv1x1 split: the statistics buffer must be 16-byte aligned");
     CSEG_REQUIRE(x && wp && y, "conv1x1_sb: null pointer");
     CSEG_REQUIRE(arith == CSEG_ARITH_BF16X6 || (arith == CSEG_ARITH_F16X3 && amax_x && amax_w),
@@ -287,8 +292,8 @@ int run_1x1(const float* x, const void* wp, const float* bias, int B, int Cin, i
     CSEG_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
                  "conv1x1_sb: packed weights / output must be 16-byte aligned and H*W a multiple of 4");
     const uint4* wq = (const uint4*)wp;
-    if (arith == CSEG_ARITH_F16X3) return fwd_1x1<SplitF16x3>(x, wq, bias, B, Cin, Cout, HW, NT, amax_x, amax_w, y, stats, stream);
-    return fwd_1x1<SplitBF16x6>(x, wq, bias, B, Cin, Cout, HW, NT, amax_x, amax_w, y, stats, stream);
+    if (arith == CSEG_ARITH_F16X3) return fwd_1x1<SplitF16x3>(x, wq, bias, B, Cin, Cout, HW, NT, amax_x, amax_w, y, stats, stream, addend);
+    return fwd_1x1<SplitBF16x6>(x, wq, bias, B, Cin, Cout, HW, NT, amax_x, amax_w, y, stats, stream, addend);
 }
 
 }  // namespace
@@ -337,4 +342,13 @@ extern "C" int cseg_conv1x1_split_fwd_st(const float* x, const void* wp, const f
                                          const unsigned* amax_x, const unsigned* amax_w, float* y, float* stats, cseg_stream_t stream_) {
     CSEG_REQUIRE(stats, "conv1x1_split_fwd_st: null statistics buffer");
     return run_1x1(x, wp, bias, B, Cin, Cout, HW, arith, amax_x, amax_w, y, (hipStream_t)stream_, reinterpret_cast<float4*>(stats));
+}
+
+// y = conv1x1(x) + bias + addend (addend [B, Cout, H*W] like y, 16-byte aligned): the input gradient of a residual block's first 1x1
+// convolution plus the gradient that arrives over the skip connection, in the epilogue instead of a separate add over both tensors.
+extern "C" int cseg_conv1x1_split_fwd_add(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin, int Cout,
+                                          int HW, int arith, const unsigned* amax_x, const unsigned* amax_w, float* y,
+                                          cseg_stream_t stream_) {
+    CSEG_REQUIRE(addend, "conv1x1_split_fwd_add: null addend");
+    return run_1x1(x, wp, bias, B, Cin, Cout, HW, arith, amax_x, amax_w, y, (hipStream_t)stream_, nullptr, addend);
 }

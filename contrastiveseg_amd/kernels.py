@@ -2300,8 +2300,9 @@ def conv1x1_sb_pack(weight, transpose=False):
     return SPLIT_WEIGHTS.get(weight, "c1", transpose, 0)
 
 
-def conv1x1_sb_run(x, weight, transpose=False, bias=None, ax=None, want_stats=False):
-    """y = conv2d(x, weight[Cout,Cin,1,1], bias) (transpose: the backward-data operator applied to x)."""
+def conv1x1_sb_run(x, weight, transpose=False, bias=None, ax=None, want_stats=False, addend=None):
+    """y = conv2d(x, weight[Cout,Cin,1,1], bias) (transpose: the backward-data operator applied to x); addend: a tensor of y's shape added
+    in the epilogue (not together with want_stats)."""
     co, ci = weight.shape[:2]
     conv_in, conv_out = (co, ci) if transpose else (ci, co)
     B, _, H, W = x.shape
@@ -2315,6 +2316,10 @@ def conv1x1_sb_run(x, weight, transpose=False, bias=None, ax=None, want_stats=Fa
         _hip.call("cseg_conv1x1_split_fwd_st", _pq(x, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H * W,
                   arith, _pf(ax) if arith else _null(), _pf(aw) if arith else _null(), _pf(y), _pf(st), _hip.stream_ptr())
         return tile_stats_attach(y, st)
+    if addend is not None:
+        _hip.call("cseg_conv1x1_split_fwd_add", _pq(x, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), _pq(addend, "addend"), B, conv_in,
+                  conv_out, H * W, arith, _pf(ax) if arith else _null(), _pf(aw) if arith else _null(), _pf(y), _hip.stream_ptr())
+        return y
     _hip.call("cseg_conv1x1_split_fwd", _pq(x, "x"), wp.data_ptr(), _opt(bias, F32, "bias"), B, conv_in, conv_out, H * W,
               arith, _pf(ax) if arith else _null(), _pf(aw) if arith else _null(), _pf(y), _hip.stream_ptr())
     return y
@@ -2387,6 +2392,59 @@ class Conv1x1SplitBF16(Function):
 
 def conv1x1_split_bf16(x, weight, bias=None, want_stats=False):
     return Conv1x1SplitBF16.apply(x, weight, bias, want_stats)
+
+
+class Conv1x1SplitSkip(Function):
+    """(conv2d(x, weight, bias), x) -- the first 1x1 convolution of a residual block together with the block's skip connection
+    (reference lib/models/backbones/hrnet/hrnet_backbone.py:68-105: `residual = x ... out += residual`). Forward: the convolution of
+    Conv1x1SplitBF16 and an alias of x for the skip path. Backward: the two gradients that meet at x -- W^T dy and what comes back over
+    the skip -- in ONE pass: the backward-data kernel adds the skip gradient in its epilogue (cseg_conv1x1_split_fwd_add) instead of
+    autograd's separate add over two 268 MB tensors per block of layer 1."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, want_stats=False):
+        weight = weight.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.ax = amax_of(x) if split_arith_id() else None
+        return conv1x1_sb_run(x, weight, False, bias, ax=ctx.ax, want_stats=want_stats), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, weight = ctx.saved_tensors
+        ady = amax_of(dy) if split_arith_id() else None
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            add = None
+            if dskip is not None and dskip.dtype == F32 and dskip.shape == x.shape and _on_device(dskip):
+                add = dskip.contiguous()
+            dx = conv1x1_sb_run(dy, weight, True, ax=ady, addend=add)
+            if dskip is not None and add is None:
+                dx = dx + dskip
+        dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if conv1x1_sb_wrw_wanted(x, dy):
+            dw = _on_wgrad_stream(lambda: conv1x1_sb_wrw(x, dy, ax=ctx.ax, ady=ady), x, dy, ctx.ax, ady) \
+                if ctx.needs_input_grad[1] else None
+            db = bias_grad(dy) if want_db else None
+        elif ctx.needs_input_grad[1] or want_db:
+            _, dw, db = torch.ops.aten.convolution_backward(
+                dy, x, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                [False, bool(ctx.needs_input_grad[1]), bool(want_db)])
+        return dx, dw, db, None
+
+
+SKIP_ADD_FUSED = os.environ.get("CSEG_SKIP_ADD_FUSED", "1") == "1"
+
+
+def conv1x1_split_skip(x, weight, bias=None, want_stats=False):
+    """-> (y, skip): see Conv1x1SplitSkip. The max|.| record of x travels with the alias."""
+    y, skip = Conv1x1SplitSkip.apply(x, weight, bias, want_stats)
+    a = getattr(x, "_cseg_amax", None)
+    if a is not None and a[1] == x._version:
+        skip._cseg_amax = (a[0], skip._version) + tuple(a[2:])
+    return y, skip
 
 
 def bn_fwd(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches_tracked, amax=None):

@@ -94,9 +94,14 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x), relu=True)
+        if self.downsample is None:
+            # conv1 and the skip connection as one autograd node: their two gradients meet in the epilogue of conv1's backward-data kernel
+            # (module_helper.Conv1x1.forward_skip) instead of autograd's add over two 268 MB tensors per block
+            c1, res = self.conv1.forward_skip(x)
+        else:
+            c1, res = self.conv1(x), self.downsample(x)
+        out = self.bn1(c1, relu=True)
         out = self.bn2(self.conv2(out), relu=True)
-        res = x if self.downsample is None else self.downsample(x)
         return self.bn3(self.conv3(out), residual=res, relu=True)
 
 

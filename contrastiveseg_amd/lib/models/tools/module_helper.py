@@ -151,6 +151,17 @@ class Conv1x1(nn.Conv2d):
             return K.conv1x1_split_bf16(x, self.weight, self.bias, self.bn_follows)
         return super(Conv1x1, self).forward(x)
 
+    def forward_skip(self, x):
+        """-> (self(x), x for the block's skip connection). On the split kernels in a differentiable pass the pair is ONE autograd node
+        whose backward adds the skip gradient in the epilogue of the backward-data kernel (kernels.Conv1x1SplitSkip); otherwise plainly
+        (self(x), x)."""
+        from contrastiveseg_amd import kernels as K
+        import torch
+        if (K.SKIP_ADD_FUSED and torch.is_grad_enabled() and x.requires_grad and K._on_device(x) and K.CONV1X1_SPLIT_BF16
+                and K.conv1x1_sb_eligible(x, self.weight) and K.conv1x1_sb_tiles(x, self.out_channels) >= K.CONV1X1_SB_MIN_TILES):
+            return K.conv1x1_split_skip(x, self.weight, self.bias, self.bn_follows)
+        return self(x), x
+
 
 class SplitConv2d(nn.Conv2d):
     """nn.Conv2d (same constructor, parameters, initialisation and state_dict) for the 1x1 and plain 3x3 convolutions OUTSIDE the HRNet

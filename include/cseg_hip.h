@@ -545,6 +545,11 @@ int cseg_conv1x1_split_pack(const float* w, int Cout, int Cin, int transpose, in
                             cseg_stream_t stream);
 int cseg_conv1x1_split_fwd(const float* x, const void* wp, const float* bias, int B, int Cin, int Cout, int HW, int arith,
                            const unsigned* amax_x, const unsigned* amax_w, float* y, cseg_stream_t stream);
+/* y = conv1x1(x) + bias + addend: addend [B,Cout,HW] in y's layout, 16-byte aligned (round 6: the input gradient of a residual block's
+ * first 1x1 convolution plus the gradient over the skip connection -- reference lib/models/backbones/hrnet/hrnet_backbone.py:68-105 sums
+ * them with a separate add). The same kernels as cseg_conv1x1_split_fwd. */
+int cseg_conv1x1_split_fwd_add(const float* x, const void* wp, const float* bias, const float* addend, int B, int Cin, int Cout, int HW,
+                               int arith, const unsigned* amax_x, const unsigned* amax_w, float* y, cseg_stream_t stream);
 /* ws: cseg_conv1x1_sb_wrw_ws_floats(...) */
 int cseg_conv1x1_split_wrw(const float* x, const float* dy, int B, int Cin, int Cout, int HW, int arith, const unsigned* amax_x,
                            const unsigned* amax_dy, float* ws, float* dw, cseg_stream_t stream);

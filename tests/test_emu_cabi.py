@@ -128,6 +128,10 @@ def test_bias_gradient_of_a_convolution_in_front_of_batchnorm(bn_training, monke
             {"bn_training": bn_training, "monkeypatch": monkeypatch})
 
 
+def test_bottleneck_skip_gradient_in_the_epilogue_is_bit_identical(monkeypatch):
+    _replay(monkeypatch, "test_gpu_cls1x1", "test_bottleneck_skip_gradient_in_the_epilogue_is_bit_identical", {"monkeypatch": monkeypatch})
+
+
 def test_classifier_eval_mode_and_fallbacks(monkeypatch):
     _replay(monkeypatch, "test_gpu_cls1x1", "test_classifier_eval_mode_and_fallbacks", {"monkeypatch": monkeypatch})
 

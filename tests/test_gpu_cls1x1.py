@@ -141,3 +141,53 @@ def test_bias_gradient_of_a_convolution_in_front_of_batchnorm(bn_training, monke
         assert float(got.abs().max()) <= 1e-5 * scale
     else:
         assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+def test_bottleneck_skip_gradient_in_the_epilogue_is_bit_identical(monkeypatch):
+    """hrnet_backbone.Bottleneck without a downsample path: conv1 + the skip connection as one autograd node whose backward adds the skip
+    gradient in the epilogue of the backward-data kernel (kernels.Conv1x1SplitSkip, cseg_conv1x1_split_fwd_add) against the two-node
+    form with autograd's add (CSEG_SKIP_ADD_FUSED=0): the same two fp32 operands are added either way -- every gradient bit for bit."""
+    from contrastiveseg_amd import kernels as K
+    from contrastiveseg_amd.lib.models.backbones.hrnet_backbone import Bottleneck
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    x0 = torch.randn(2, 256, 6, 40, generator=g).relu_()
+    dy0 = torch.randn(2, 256, 6, 40, generator=g)
+    torch.manual_seed(4)
+    blk = Bottleneck(256, 64, bn_type="torchsyncbn").to(dev).train()
+    monkeypatch.setattr(K, "CONV1X1_SB_MIN_TILES", 1)
+    monkeypatch.setattr(K, "CONV3X3_SB_MIN_TILES", 1)
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(K, "SKIP_ADD_FUSED", fused)
+        calls = []
+        orig = K.Conv1x1SplitSkip.apply
+        monkeypatch.setattr(K.Conv1x1SplitSkip, "apply", staticmethod(lambda *a, o=orig: (calls.append(1), o(*a))[1]))
+        state = {k: v.clone() for k, v in blk.state_dict().items()}
+        x = x0.to(dev).clone().requires_grad_(True)
+        blk.zero_grad()
+        y = blk(x)
+        y.backward(dy0.to(dev))
+        blk.load_state_dict(state)                   # (running statistics back: the second pass starts from the same buffers)
+        monkeypatch.setattr(K.Conv1x1SplitSkip, "apply", orig)
+        assert bool(calls) == fused
+        res.append([y.detach().cpu(), x.grad.cpu()] + [p.grad.cpu().clone() for p in blk.parameters()])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # and the block against the reference's arithmetic in fp64
+    ref = torch.nn.Sequential()
+    xr = x0.double().to(dev).clone().requires_grad_(True)
+    import torch.nn.functional as F
+    w = [p.detach().double() for p in (blk.conv1.weight, blk.conv2.weight, blk.conv3.weight)]
+    bns = [m for m in (blk.bn1, blk.bn2, blk.bn3)]
+
+    def bn(t, m):
+        mod = [q for q in m.modules() if hasattr(q, "running_mean")][0]
+        mu, var = t.mean((0, 2, 3), keepdim=True), t.var((0, 2, 3), unbiased=False, keepdim=True)
+        return (t - mu) / torch.sqrt(var + mod.eps) * mod.weight.detach().double().view(1, -1, 1, 1) + mod.bias.detach().double().view(1, -1, 1, 1)
+    o = bn(F.conv2d(xr, w[0]), bns[0]).relu()
+    o = bn(F.conv2d(o, w[1], padding=1), bns[1]).relu()
+    o = (bn(F.conv2d(o, w[2]), bns[2]) + xr).relu()
+    o.backward(dy0.double().to(dev))
+    err = float((res[0][1].double() - xr.grad.cpu()).abs().max())
+    assert err <= 2e-4 * float(xr.grad.abs().max()), err
