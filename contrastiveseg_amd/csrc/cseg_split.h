@@ -44,6 +44,13 @@ __device__ __forceinline__ void amax_publish_block(unsigned block_max, unsigned*
     unsigned* slot = amax_rec + (blockIdx.x & (CSEG_AMAX_SLOTS - 1)) * CSEG_AMAX_STRIDE;
     if (block_max > *reinterpret_cast<volatile unsigned*>(slot)) atomicMax(slot, block_max);
 }
+// a WAVE's maximum, from kernels whose blocks are too short to wait for the slot's current value (the producers of round 6: upsample +
+// concat, fused sum, per-channel affine map): one fire-and-forget atomic per wave (no return value: nothing waits for it), none for an
+// all-zero wave. `v`: bit pattern of a non-negative float, already reduced over the wave.
+__device__ __forceinline__ void amax_publish_wave(unsigned wave_max, unsigned* __restrict__ amax_rec) {
+    if ((threadIdx.x & 63) == 0 && wave_max != 0u)
+        atomicMax(amax_rec + ((blockIdx.x + (threadIdx.x >> 6)) & (CSEG_AMAX_SLOTS - 1)) * CSEG_AMAX_STRIDE, wave_max);
+}
 __device__ __forceinline__ float split_scale_of(unsigned e) { return __builtin_bit_cast(float, (268u - e) << 23); }     // 2^(141 - e)
 __device__ __forceinline__ float split_unscale_of(unsigned e) { return __builtin_bit_cast(float, (e - 14u) << 23); }    // 2^(e - 141)
 
