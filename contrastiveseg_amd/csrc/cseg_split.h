@@ -44,12 +44,17 @@ __device__ __forceinline__ void amax_publish_block(unsigned block_max, unsigned*
     unsigned* slot = amax_rec + (blockIdx.x & (CSEG_AMAX_SLOTS - 1)) * CSEG_AMAX_STRIDE;
     if (block_max > *reinterpret_cast<volatile unsigned*>(slot)) atomicMax(slot, block_max);
 }
-// a WAVE's maximum, from kernels whose blocks are too short to wait for the slot's current value (the producers of round 6: upsample +
-// concat, fused sum, per-channel affine map): one fire-and-forget atomic per wave (no return value: nothing waits for it), none for an
-// all-zero wave. `v`: bit pattern of a non-negative float, already reduced over the wave.
-__device__ __forceinline__ void amax_publish_wave(unsigned wave_max, unsigned* __restrict__ amax_rec) {
-    if ((threadIdx.x & 63) == 0 && wave_max != 0u)
-        atomicMax(amax_rec + ((blockIdx.x + (threadIdx.x >> 6)) & (CSEG_AMAX_SLOTS - 1)) * CSEG_AMAX_STRIDE, wave_max);
+// The maximum of a 256-thread block whose waves each hold a candidate (bit pattern of a non-negative float, already reduced over the wave):
+// combined through LDS, ONE look at the slot and at most one atomic per block. Measured on the producers of round 6 (MI355X, kernel
+// time inside the step): with one look + atomic per WAVE the 32 words of a record become a hot spot -- 184 000 requests to 32 cache lines in
+// the upsample + concat kernel, +24 us; the fused sum of the exchange units (12 000 blocks of 1 024 pixels) took 34.7 us per call instead of
+// 24.7, more than the separate cseg_amax_f32 pass it was meant to replace (8 us), whether the look came first, last or not at all.
+__device__ __forceinline__ void amax_publish_waves(unsigned wave_max, unsigned* __restrict__ amax_rec) {
+    __shared__ unsigned cseg_amax_red[4];
+    if ((threadIdx.x & 63) == 0) cseg_amax_red[(threadIdx.x >> 6) & 3] = wave_max;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        amax_publish_block(max(max(cseg_amax_red[0], cseg_amax_red[1]), max(cseg_amax_red[2], cseg_amax_red[3])), amax_rec);
 }
 __device__ __forceinline__ float split_scale_of(unsigned e) { return __builtin_bit_cast(float, (268u - e) << 23); }     // 2^(141 - e)
 __device__ __forceinline__ float split_unscale_of(unsigned e) { return __builtin_bit_cast(float, (e - 14u) << 23); }    // 2^(e - 141)

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a, int relu, flo
         unsigned bits = __builtin_bit_cast(unsigned, vmax);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o, 64));
-        amax_publish_wave(bits, amax);
+        amax_publish_waves(bits, amax);
     }
 }
 
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void affine_channels_kernel(const float* __res
         unsigned bits = __builtin_bit_cast(unsigned, vmax);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o, 64));
-        amax_publish_wave(bits, amax);
+        amax_publish_waves(bits, amax);
     }
 }
 }  // namespace

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(UpcatMaps m, int Ctot, i
         unsigned bits = __builtin_bit_cast(unsigned, vmax);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o, 64));
-        amax_publish_wave(bits, amax);
+        amax_publish_waves(bits, amax);
     }
 }
 

@@ -341,6 +341,10 @@ def _int_arr(vals):
 # max|.| records from the kernels that WRITE a tensor read by split-operand convolutions (upsample + concat, the exchange unit's fused
 # sum) instead of a cseg_amax_f32 pass per tensor; CSEG_PRODUCER_AMAX=0 restores the passes (A/B: profiles/r06_ab_producer_amax.txt)
 PRODUCER_AMAX = os.environ.get("CSEG_PRODUCER_AMAX", "1") == "1"
+# ... but NOT from the exchange unit's fused sum by default: its blocks are short (1 024 pixels) and there are 12 000 of them, and every
+# publish is a request to one of the record's 32 cache lines -- measured inside the step 34.7 us per call with the record against 24.7 without,
+# more than the 8 us pass it replaces. The entry point stays (cseg_fuse_sum_fwd_amax), tested, for callers with fat tiles.
+FUSE_SUM_AMAX = os.environ.get("CSEG_FUSE_SUM_AMAX", "0") == "1"
 
 
 class UpsampleConcat(Function):
@@ -448,9 +452,9 @@ def affine_channels(u, a, b, want_amax=True):
 
 def fuse_sum_relu(same, low):
     """same: list of [B,C,h,w]; low: list of [B,C,hs,ws] coarser maps (upsampled with align_corners=True)."""
-    # the outputs of an exchange unit feed the split-operand convolutions of the next unit: the kernel that writes them leaves their
-    # max|.| record (otherwise kernels.amax_of spends a cseg_amax_f32 pass and a launch on each: ~20 per step)
-    amax = amax_request(same[0]) if PRODUCER_AMAX else None
+    # the outputs of an exchange unit feed the split-operand convolutions of the next unit; the kernel CAN leave their max|.| record
+    # (FUSE_SUM_AMAX), but by default kernels.amax_of spends a cseg_amax_f32 pass on each (~20 per step, 8 us): cheaper, see above
+    amax = amax_request(same[0]) if FUSE_SUM_AMAX else None
     return amax_attach(FuseSumReLU.apply(len(same), amax, *same, *low), amax)
 
 

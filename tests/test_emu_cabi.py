@@ -110,7 +110,7 @@ def test_contrast_fused_forward_equals_the_three_launches(kw, monkeypatch):
 
 def test_upsample_concat_and_fuse_sum_match_torch(monkeypatch):
     _replay(monkeypatch, "test_gpu_kernels", "test_upsample_concat_matches_torch", {})
-    _replay(monkeypatch, "test_gpu_kernels", "test_fuse_sum_relu_matches_torch", {})
+    _replay(monkeypatch, "test_gpu_kernels", "test_fuse_sum_relu_matches_torch", {"monkeypatch": monkeypatch})
 
 
 CLS = _cases("test_gpu_cls1x1", "test_classifier_with_folded_dropout_matches_the_reference_modules")
